@@ -1,0 +1,166 @@
+/*
+ * mpe.h — C ABI of the MI355X (gfx950) compute back-end for the per-frame hot path of
+ * uzh-rpg/rpg_monocular_pose_estimator.
+ *
+ * The reference has no C ABI for this path; its seams are C++.  Every entry
+ * point below names the reference interface it replaces (paths relative to the reference root,
+ * lib = monocular_pose_estimator_lib).  The library is libmpe_hip.so, built by
+ * rpg_monocular_pose_estimator_amd/csrc/Makefile with hipcc --offload-arch=gfx950.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller owns every buffer; no exceptions cross the ABI.
+ *   - one mpe_handle = one GPU + one HIP stream; a handle is used by one thread at a time
+ *     (the reference's PoseEstimator is a single-threaded stateful object too, node.cpp:31).
+ *   - return value: 0 = call executed, <0 = usage / HIP error (see mpe_last_error()).
+ *     Per-frame outcome is in mpe_result.status: 0 = pose found (estimateBodyPose -> true),
+ *     1 = no pose (-> false), <0 = frame exceeded a documented device capacity (never silent).
+ *   - matrices are row-major doubles: K[9], T[16] (T_camera_object), cov[36] in twist order
+ *     (upsilon, omega) exactly as PoseEstimator::getPoseCovariance() / ROS.cpp:178-187.
+ *   - markers: n x 3 doubles (x,y,z) — List4DPoints without the homogeneous 1 (PE.h:351).
+ *   - detections: n x 2 doubles, undistorted pixels — List2DPoints (DT.h:50).
+ *   - correspondences: rows (marker, detection), 1-based, 0 = none — VectorXuPairs (DT.h:47).
+ *   - hist: n_det x n_markers uint32 row-major (row = detection) — hist_corr, PE.cpp:556.
+ */
+#ifndef MPE_H_
+#define MPE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPE_MAX_MARKERS 16    /* object_points_ capacity (reference: unbounded; 32-bit factorial
+                                 already overflows at 13, COMB.cpp:34-45 — replicated) */
+#define MPE_MAX_DETECTIONS 32 /* detections kept per frame; more -> status MPE_FRAME_TOO_MANY_DETECTIONS */
+#define MPE_MAX_RAW_BLOBS 256 /* external contours per frame before the shape filter */
+#define MPE_MAX_KSIZE 37      /* Gaussian kernel taps: sigma <= 6 (cfg:13) */
+
+/* per-frame status codes (mpe_result.status, mpe_detections.status) */
+#define MPE_FRAME_POSE 0
+#define MPE_FRAME_NO_POSE 1
+#define MPE_FRAME_TOO_MANY_DETECTIONS (-10) /* > MPE_MAX_DETECTIONS blobs passed the filter */
+#define MPE_FRAME_TOO_MANY_BLOBS (-11)      /* > MPE_MAX_RAW_BLOBS external contours */
+#define MPE_FRAME_TOO_MANY_ROWS (-12)       /* bright rows exceed the LDS band capacity */
+
+/* call-level error codes */
+#define MPE_OK 0
+#define MPE_ERR_ARG (-1)
+#define MPE_ERR_HIP (-2)
+#define MPE_ERR_UNSUPPORTED (-3)
+#define MPE_ERR_NO_DEVICE (-4)
+
+typedef struct mpe_handle mpe_handle;
+
+/* Mirrors the tuning members of PoseEstimator (PE.h:68-72, 85-91) and the dynamic-reconfigure
+ * contract (monocular_pose_estimator/cfg/MonocularPoseEstimator.cfg:12-22). */
+typedef struct mpe_params {
+  int threshold_value;                      /* detection_threshold_value_ */
+  double gaussian_sigma;                    /* gaussian_sigma_ */
+  double min_blob_area;                     /* min_blob_area_ */
+  double max_blob_area;                     /* max_blob_area_ */
+  double max_width_height_distortion;       /* max_width_height_distortion_ */
+  double max_circular_distortion;           /* max_circular_distortion_ */
+  double back_projection_pixel_tolerance;   /* setBackProjectionPixelTolerance, PE.h:483 */
+  double nearest_neighbour_pixel_tolerance; /* setNearestNeighbourPixelTolerance, PE.h:503 */
+  double certainty_threshold;               /* setCertaintyThreshold, PE.h:523 */
+  double valid_correspondence_threshold;    /* setValidCorrespondenceThreshold, PE.h:543 */
+  unsigned roi_border_thickness;            /* roi_border_thickness_ (tracking path only) */
+  unsigned histogram_threshold;             /* 0 -> numCombinations(n_markers,3) as PE.cpp:54 */
+} mpe_params;
+
+typedef struct mpe_result {
+  double T[16];      /* getPredictedPose(), PE.h:406 */
+  double cov[36];    /* getPoseCovariance(), PE.h:416 */
+  int status;        /* MPE_FRAME_* */
+  int n_det;         /* detections that passed the blob filter */
+  int n_corr;        /* rows of correspondences_ after correspondencesFromHistogram */
+  int gn_iterations; /* Gauss-Newton iterations used by optimisePose */
+} mpe_result;
+
+typedef struct mpe_detections {
+  int n;      /* min(number of detections, MPE_MAX_DETECTIONS) */
+  int status; /* 0 or MPE_FRAME_TOO_MANY_* */
+  double undist_xy[2 * MPE_MAX_DETECTIONS]; /* pixel_positions of findLeds (LED.h:84-88) */
+  float dist_xy[2 * MPE_MAX_DETECTIONS];    /* distorted_detection_centers */
+} mpe_detections;
+
+/* fills *p with the parameter set of launch/demo.launch:12-22 */
+void mpe_default_params(mpe_params* p);
+
+/* device < 0: use the current HIP device.  Fails (MPE_ERR_NO_DEVICE) when no gfx950 GPU is
+ * visible — there is no CPU fallback. */
+int mpe_create(mpe_handle** out, int device);
+void mpe_destroy(mpe_handle* h);
+const char* mpe_last_error(const mpe_handle* h);
+/* Use an existing hipStream_t (e.g. torch's current stream); NULL restores the handle's own. */
+int mpe_set_stream(mpe_handle* h, void* hip_stream);
+void* mpe_get_stream(mpe_handle* h);
+int mpe_synchronize(mpe_handle* h);
+
+/* ≙ LEDDetector::findLeds (lib/include/.../led_detector.h:84-88, lib/src/led_detector.cpp:35-112)
+ * on ONE host frame: threshold -> Gaussian blur -> external contours -> polygon area/moments ->
+ * shape filter -> undistortPoints.  undist_xy / dist_xy hold 2*cap values. */
+int mpe_find_leds(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t stride_bytes,
+                  int roi_x, int roi_y, int roi_w, int roi_h, const mpe_params* p,
+                  const double K[9], const double* D, int nD, double* undist_xy, float* dist_xy,
+                  int cap, int* n_out);
+
+/* ≙ PoseEstimator::setImagePoints + initialise + optimiseAndUpdatePose on a fresh estimator
+ * (lib/include/.../pose_estimator.h:425,749,773; lib/src/pose_estimator.cpp:80-91,544-721,
+ * 733-812).  hist (n_det*n_markers) and corr (2*n_markers) are optional outputs. */
+int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz,
+                         int n_markers, const double K[9], const mpe_params* p, mpe_result* out,
+                         uint32_t* hist, uint32_t* corr);
+
+/* ≙ PoseEstimator::estimateBodyPose (pose_estimator.h:366, pose_estimator.cpp:62-96) on a FRESH
+ * estimator per frame (it_since_initialized_ == 0: whole-image detection + brute-force
+ * initialisation) for a batch of independent frames — the measured entry point.
+ * frames: n_frames images, frame f at frames + f*frame_stride_bytes, rows of stride_bytes.
+ * frames_on_device != 0: `frames` is a device pointer (results is still a HOST pointer). */
+int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int rows, int cols,
+                       size_t stride_bytes, size_t frame_stride_bytes, int frames_on_device,
+                       const double* markers_xyz, int n_markers, const double K[9],
+                       const double* D, int nD, const mpe_params* p, mpe_result* results);
+
+/* Fully asynchronous variant for device-resident pipelines: frames AND results are device
+ * pointers, nothing is copied, the call only enqueues kernels on the handle's stream.
+ * frames must be 16-byte aligned with cols % 16 == 0, stride_bytes == cols and
+ * frame_stride_bytes == rows*cols (the packed layout). */
+int mpe_estimate_batch_device(mpe_handle* h, const uint8_t* d_frames, int n_frames, int rows,
+                              int cols, const double* markers_xyz, int n_markers,
+                              const double K[9], const double* D, int nD, const mpe_params* p,
+                              mpe_result* d_results);
+
+/* Stage-level batch entry points (used by the parity tests at every stage boundary). */
+/* detection only (a1): dets is a HOST array of n_frames records */
+int mpe_detect_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int rows, int cols,
+                     size_t stride_bytes, size_t frame_stride_bytes, int frames_on_device,
+                     const double K[9], const double* D, int nD, const mpe_params* p,
+                     mpe_detections* dets);
+/* voting only (a4, PE.cpp:544-702): det_xy is n_frames x MPE_MAX_DETECTIONS x 2 (host), n_det[f]
+ * valid rows each; hist is n_frames x MPE_MAX_DETECTIONS x MPE_MAX_MARKERS (host) */
+int mpe_vote_batch(mpe_handle* h, const double* det_xy, const int* n_det, int n_frames,
+                   const double* markers_xyz, int n_markers, const double K[9],
+                   double back_projection_pixel_tolerance, uint32_t* hist);
+
+/* Time (ms) of the kernels of the last mpe_estimate_batch* call, measured with HIP events on the
+ * handle's stream: [0] image scan, [1] blob extraction, [2] voting, [3] validate+refine, [4] total.
+ * Only valid after mpe_set_profiling(h, 1); profiling adds event records to the stream. */
+int mpe_set_profiling(mpe_handle* h, int enable);
+int mpe_last_kernel_ms(mpe_handle* h, float ms[5]);
+
+/* Tuning knobs that are not part of the reference surface: "lds_budget" (bytes of LDS per frame
+ * for the blob bitmaps, 8192..163840) and "vote_splits" (workgroups per frame in the voting
+ * kernel, 0 = auto). */
+int mpe_set_option(mpe_handle* h, const char* name, int value);
+
+/* library / device introspection */
+int mpe_device_count(void);
+const char* mpe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPE_H_ */

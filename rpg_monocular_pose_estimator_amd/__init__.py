@@ -1,0 +1,14 @@
+"""MI355X (gfx950) compute back-end for the per-frame hot path of rpg_monocular_pose_estimator.
+
+The product is the HIP library ``libmpe_hip.so`` (C ABI: ``include/mpe.h``).  This package is the
+thin host-side binding used by tests / bench: ctypes over the C ABI, numpy or torch buffers in, numpy
+out.  There is NO CPU fallback: if the library or a HIP device is missing every call raises.
+"""
+from .binding import (MpeError, MpeParams, MpeResult, MpeDetections, RESULT_DTYPE, DETECTIONS_DTYPE,  # noqa: F401
+                      MAX_DETECTIONS, MAX_MARKERS, Handle, build_library, library_path, load_library,
+                      demo_params, exported_symbols)
+from .pose_estimator import PoseEstimator  # noqa: F401
+
+__all__ = ["MpeError", "MpeParams", "MpeResult", "MpeDetections", "RESULT_DTYPE", "DETECTIONS_DTYPE",
+           "MAX_DETECTIONS", "MAX_MARKERS", "Handle", "build_library", "library_path", "load_library",
+           "demo_params", "exported_symbols", "PoseEstimator"]

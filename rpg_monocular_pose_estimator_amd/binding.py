@@ -1,0 +1,287 @@
+"""ctypes binding of libmpe_hip.so (include/mpe.h)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_LIB = os.path.join(_HERE, "libmpe_hip.so")
+_HEADER = os.path.join(os.path.dirname(_HERE), "include", "mpe.h")
+
+MAX_MARKERS = 16
+MAX_DETECTIONS = 32
+
+
+class MpeError(RuntimeError):
+    pass
+
+
+class MpeParams(C.Structure):
+    _fields_ = [
+        ("threshold_value", C.c_int),
+        ("gaussian_sigma", C.c_double),
+        ("min_blob_area", C.c_double),
+        ("max_blob_area", C.c_double),
+        ("max_width_height_distortion", C.c_double),
+        ("max_circular_distortion", C.c_double),
+        ("back_projection_pixel_tolerance", C.c_double),
+        ("nearest_neighbour_pixel_tolerance", C.c_double),
+        ("certainty_threshold", C.c_double),
+        ("valid_correspondence_threshold", C.c_double),
+        ("roi_border_thickness", C.c_uint),
+        ("histogram_threshold", C.c_uint),
+    ]
+
+
+class MpeResult(C.Structure):
+    _fields_ = [("T", C.c_double * 16), ("cov", C.c_double * 36), ("status", C.c_int), ("n_det", C.c_int),
+                ("n_corr", C.c_int), ("gn_iterations", C.c_int)]
+
+
+class MpeDetections(C.Structure):
+    _fields_ = [("n", C.c_int), ("status", C.c_int), ("undist_xy", C.c_double * (2 * MAX_DETECTIONS)),
+                ("dist_xy", C.c_float * (2 * MAX_DETECTIONS))]
+
+
+RESULT_DTYPE = np.dtype([("T", "f8", (16,)), ("cov", "f8", (36,)), ("status", "i4"), ("n_det", "i4"),
+                         ("n_corr", "i4"), ("gn_iterations", "i4")])
+DETECTIONS_DTYPE = np.dtype([("n", "i4"), ("status", "i4"), ("undist_xy", "f8", (2 * MAX_DETECTIONS,)),
+                             ("dist_xy", "f4", (2 * MAX_DETECTIONS,))])
+assert RESULT_DTYPE.itemsize == C.sizeof(MpeResult)
+assert DETECTIONS_DTYPE.itemsize == C.sizeof(MpeDetections)
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """Compile the HIP library for gfx950 with hipcc (csrc/Makefile).  Works without a GPU."""
+    cmd = ["make", "-s", "-C", _CSRC] + (["-B"] if force else [])
+    subprocess.check_call(cmd)
+    if not os.path.exists(_LIB):
+        raise MpeError("build did not produce %s" % _LIB)
+    return _LIB
+
+
+def exported_symbols():
+    """Function names declared in include/mpe.h (used by the symbol-export test)."""
+    txt = open(_HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpe_[a-z0-9_]+)\s*\(", txt)))
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmpe_hip.so.  Raises MpeError when it has not been built — no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise MpeError("%s is missing: run __graft_entry__.build() / make -C %s (there is no CPU fallback)"
+                       % (_LIB, _CSRC))
+    try:
+        import torch  # noqa: F401  (so that one HIP runtime — the one torch loaded — serves both)
+    except Exception:
+        pass
+    lib = C.CDLL(_LIB)
+    lib.mpe_version.restype = C.c_char_p
+    lib.mpe_last_error.restype = C.c_char_p
+    lib.mpe_last_error.argtypes = [C.c_void_p]
+    lib.mpe_get_stream.restype = C.c_void_p
+    lib.mpe_get_stream.argtypes = [C.c_void_p]
+    lib.mpe_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.mpe_destroy.argtypes = [C.c_void_p]
+    lib.mpe_destroy.restype = None
+    lib.mpe_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mpe_synchronize.argtypes = [C.c_void_p]
+    lib.mpe_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    lib.mpe_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.mpe_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.mpe_default_params.argtypes = [C.POINTER(MpeParams)]
+    lib.mpe_default_params.restype = None
+    dp = C.POINTER(C.c_double)
+    lib.mpe_find_leds.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.POINTER(MpeParams), dp, dp, C.c_int, dp, C.POINTER(C.c_float), C.c_int,
+                                  C.POINTER(C.c_int)]
+    lib.mpe_solve_bruteforce.argtypes = [C.c_void_p, dp, C.c_int, dp, C.c_int, dp, C.POINTER(MpeParams),
+                                         C.POINTER(MpeResult), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.mpe_estimate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                       C.c_int, dp, C.c_int, dp, dp, C.c_int, C.POINTER(MpeParams), C.c_void_p]
+    lib.mpe_estimate_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, dp,
+                                              C.c_int, C.POINTER(MpeParams), C.c_void_p]
+    lib.mpe_detect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int,
+                                     dp, dp, C.c_int, C.POINTER(MpeParams), C.c_void_p]
+    lib.mpe_vote_batch.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int), C.c_int, dp, C.c_int, dp, C.c_double,
+                                   C.POINTER(C.c_uint32)]
+    _lib = lib
+    return lib
+
+
+def demo_params(**kw):
+    """Parameter set of launch/demo.launch:12-22 (overridable by keyword)."""
+    p = MpeParams()
+    load_library().mpe_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Handle:
+    """One GPU + one HIP stream (mpe_handle)."""
+
+    def __init__(self, device=-1):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.mpe_create(C.byref(self._h), int(device))
+        if rc != 0:
+            self._h = None
+            raise MpeError("mpe_create failed (%d): no usable HIP device — there is no CPU fallback" % rc)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mpe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise MpeError("%s failed (%d): %s" % (what, rc, self._lib.mpe_last_error(self._h).decode()))
+
+    # ---- stream / options -------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.mpe_set_stream(self._h, C.c_void_p(stream_ptr or 0)), "mpe_set_stream")
+
+    def synchronize(self):
+        self._check(self._lib.mpe_synchronize(self._h), "mpe_synchronize")
+
+    def set_option(self, name, value):
+        self._check(self._lib.mpe_set_option(self._h, name.encode(), int(value)), "mpe_set_option")
+
+    def set_profiling(self, on):
+        self._check(self._lib.mpe_set_profiling(self._h, 1 if on else 0), "mpe_set_profiling")
+
+    def last_kernel_ms(self):
+        ms = (C.c_float * 5)()
+        self._check(self._lib.mpe_last_kernel_ms(self._h, ms), "mpe_last_kernel_ms")
+        return dict(scan=ms[0], blobs=ms[1], vote=ms[2], tail=ms[3], total=ms[4])
+
+    # ---- LEDDetector::findLeds ----------------------------------------------------------------
+    def find_leds(self, img, params, K, D, roi=None, cap=MAX_DETECTIONS):
+        img = np.ascontiguousarray(img, np.uint8)
+        rows, cols = img.shape
+        rx, ry, rw, rh = roi if roi is not None else (0, 0, cols, rows)
+        K = _f64(K).reshape(9)
+        D = _f64(D).reshape(-1)
+        und = np.zeros((cap, 2))
+        dst = np.zeros((cap, 2), np.float32)
+        n = C.c_int(0)
+        rc = self._lib.mpe_find_leds(self._h, img.ctypes.data, rows, cols, img.strides[0], rx, ry, rw, rh,
+                                     C.byref(params), _dp(K), _dp(D), len(D), _dp(und),
+                                     dst.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n))
+        self._check(rc, "mpe_find_leds")
+        return und[:n.value].copy(), dst[:n.value].copy()
+
+    # ---- setImagePoints + initialise + optimiseAndUpdatePose ---------------------------------
+    def solve_bruteforce(self, det, markers, K, params):
+        det = _f64(det).reshape(-1, 2)
+        markers = _f64(markers).reshape(-1, 3)
+        K = _f64(K).reshape(9)
+        res = MpeResult()
+        hist = np.zeros((max(len(det), 1), len(markers)), np.uint32)
+        corr = np.zeros((len(markers), 2), np.uint32)
+        rc = self._lib.mpe_solve_bruteforce(self._h, _dp(det), len(det), _dp(markers), len(markers), _dp(K),
+                                            C.byref(params), C.byref(res),
+                                            hist.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                            corr.ctypes.data_as(C.POINTER(C.c_uint32)))
+        self._check(rc, "mpe_solve_bruteforce")
+        return dict(status=res.status, T=np.array(res.T).reshape(4, 4), cov=np.array(res.cov).reshape(6, 6),
+                    n_det=res.n_det, n_corr=res.n_corr, gn_iterations=res.gn_iterations,
+                    hist=hist[:len(det)].copy(), corr=corr[:res.n_corr].copy())
+
+    # ---- estimateBodyPose on a fresh estimator per frame -------------------------------------
+    def estimate_batch(self, frames, markers, K, D, params):
+        """frames: numpy (n,rows,cols) uint8 on the host, or a torch uint8 CUDA tensor (n,rows,cols)."""
+        markers = _f64(markers).reshape(-1, 3)
+        K = _f64(K).reshape(9)
+        D = _f64(D).reshape(-1)
+        if _is_torch(frames):
+            assert frames.is_cuda and frames.is_contiguous() and frames.dtype.is_floating_point is False
+            n, rows, cols = frames.shape
+            ptr, on_dev, stride, fstride = frames.data_ptr(), 1, cols, rows * cols
+        else:
+            frames = np.ascontiguousarray(frames, np.uint8)
+            n, rows, cols = frames.shape
+            ptr, on_dev, stride, fstride = frames.ctypes.data, 0, frames.strides[1], frames.strides[0]
+        out = np.zeros(n, RESULT_DTYPE)
+        rc = self._lib.mpe_estimate_batch(self._h, C.c_void_p(ptr), n, rows, cols, stride, fstride, on_dev,
+                                          _dp(markers), len(markers), _dp(K), _dp(D), len(D), C.byref(params),
+                                          C.c_void_p(out.ctypes.data))
+        self._check(rc, "mpe_estimate_batch")
+        return out
+
+    def estimate_batch_device(self, d_frames_ptr, n, rows, cols, markers, K, D, params, d_results_ptr):
+        """Fully asynchronous: device frames in, device results out, kernels only."""
+        markers = _f64(markers).reshape(-1, 3)
+        K = _f64(K).reshape(9)
+        D = _f64(D).reshape(-1)
+        rc = self._lib.mpe_estimate_batch_device(self._h, C.c_void_p(d_frames_ptr), n, rows, cols, _dp(markers),
+                                                 len(markers), _dp(K), _dp(D), len(D), C.byref(params),
+                                                 C.c_void_p(d_results_ptr))
+        self._check(rc, "mpe_estimate_batch_device")
+
+    # ---- stage level ---------------------------------------------------------------------------
+    def detect_batch(self, frames, K, D, params):
+        K = _f64(K).reshape(9)
+        D = _f64(D).reshape(-1)
+        if _is_torch(frames):
+            n, rows, cols = frames.shape
+            ptr, on_dev, stride, fstride = frames.data_ptr(), 1, cols, rows * cols
+        else:
+            frames = np.ascontiguousarray(frames, np.uint8)
+            n, rows, cols = frames.shape
+            ptr, on_dev, stride, fstride = frames.ctypes.data, 0, frames.strides[1], frames.strides[0]
+        out = np.zeros(n, DETECTIONS_DTYPE)
+        rc = self._lib.mpe_detect_batch(self._h, C.c_void_p(ptr), n, rows, cols, stride, fstride, on_dev, _dp(K),
+                                        _dp(D), len(D), C.byref(params), C.c_void_p(out.ctypes.data))
+        self._check(rc, "mpe_detect_batch")
+        return out
+
+    def vote_batch(self, dets, markers, K, tol):
+        """dets: list of (n_i,2) arrays.  -> list of (n_i, n_markers) uint32 histograms."""
+        markers = _f64(markers).reshape(-1, 3)
+        K = _f64(K).reshape(9)
+        n = len(dets)
+        buf = np.zeros((n, MAX_DETECTIONS, 2))
+        nd = np.zeros(n, np.int32)
+        for i, d in enumerate(dets):
+            d = _f64(d).reshape(-1, 2)
+            nd[i] = len(d)
+            buf[i, :len(d)] = d
+        hist = np.zeros((n, MAX_DETECTIONS, MAX_MARKERS), np.uint32)
+        rc = self._lib.mpe_vote_batch(self._h, _dp(buf), nd.ctypes.data_as(C.POINTER(C.c_int)), n, _dp(markers),
+                                      len(markers), _dp(K), float(tol), hist.ctypes.data_as(C.POINTER(C.c_uint32)))
+        self._check(rc, "mpe_vote_batch")
+        return [hist[i, :nd[i], :len(markers)].copy() for i in range(n)]

@@ -1,0 +1,534 @@
+// mpe_abi.cpp — host side of libmpe_hip.so: the C ABI of include/mpe.h on top of the gfx950
+// kernels.  Owns device workspaces, the HIP stream, parameter marshalling; launches
+// K1a -> K1b -> K2 -> K3 per batch.  No torch, no CPU fallback: without a HIP device every entry
+// point fails with MPE_ERR_NO_DEVICE / MPE_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mpe_internal.h"
+
+using namespace mpe;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) return e;
+    cap = want;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct mpe_handle {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  DevBuf frames, flags, dets, hist, results, corr;
+  int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
+  int vote_splits = 0;         // 0 = auto
+  bool profiling = false;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float last_ms[5] = {0, 0, 0, 0, 0};
+  bool have_ms = false;
+};
+
+namespace {
+
+int fail(mpe_handle* h, int code, const char* what, hipError_t e = hipSuccess) {
+  if (h) {
+    h->err = what;
+    if (e != hipSuccess) {
+      h->err += ": ";
+      h->err += hipGetErrorString(e);
+    }
+  }
+  return code;
+}
+
+#define HIP_TRY(h, call)                                         \
+  do {                                                           \
+    hipError_t e__ = (call);                                     \
+    if (e__ != hipSuccess) return fail(h, MPE_ERR_HIP, #call, e__); \
+  } while (0)
+
+unsigned factorial_u32(int n) {  // combinations.cpp:34-40: 32-bit wrap-around kept on purpose
+  unsigned r = 1;
+  for (int i = 2; i <= n; ++i) r *= (unsigned)i;
+  return r;
+}
+unsigned num_combinations_u32(unsigned n, unsigned k) {  // combinations.cpp:42-45
+  const unsigned den = factorial_u32((int)k) * factorial_u32((int)(n - k));
+  return den ? factorial_u32((int)n) / den : 0u;
+}
+
+// cv::getGaussianKernel(n, sigma, CV_32F) quantised to 8 fractional bits, n = cvRound(6*sigma+1)|1
+// (what GaussianBlur(ksize = 0) uses for CV_8U, led_detector.cpp:48-51)
+int gaussian_taps(double sigma, int* taps) {
+  if (!(sigma > 0)) return -1;
+  const int n = (int)std::lrint(sigma * 3 * 2 + 1) | 1;
+  if (n > MPE_MAX_KSIZE) return -1;
+  float cf[MPE_MAX_KSIZE];
+  const double scale2x = -0.5 / (sigma * sigma);
+  double sum = 0;
+  for (int i = 0; i < n; ++i) {
+    const double x = i - (n - 1) * 0.5;
+    cf[i] = (float)std::exp(scale2x * x * x);
+    sum += cf[i];
+  }
+  sum = 1. / sum;
+  for (int i = 0; i < n; ++i) {
+    cf[i] = (float)(cf[i] * sum);
+    taps[i] = (int)std::lrint((double)cf[i] * 256.0);
+  }
+  return n;
+}
+
+int make_detect_params(const mpe_params* p, const double K[9], const double* D, int nD, int roi_x, int roi_y,
+                       DetectParams& dp) {
+  std::memset(&dp, 0, sizeof(dp));
+  dp.thr = p->threshold_value < -1 ? -1 : (p->threshold_value > 255 ? 255 : p->threshold_value);
+  dp.ksize = gaussian_taps(p->gaussian_sigma, dp.taps);
+  if (dp.ksize < 0) return -1;
+  dp.min_area = p->min_blob_area;
+  dp.max_area = p->max_blob_area;
+  dp.max_wh = p->max_width_height_distortion;
+  dp.max_circ = p->max_circular_distortion;
+  for (int i = 0; i < 9; ++i) dp.K[i] = K[i];
+  dp.ifx = 1. / K[0];
+  dp.ify = 1. / K[4];
+  for (int i = 0; i < 8; ++i) dp.k[i] = (D && i < nD) ? D[i] : 0.0;
+  dp.undist_iters = (D && nD > 0) ? 5 : 0;
+  dp.roi_x = roi_x;
+  dp.roi_y = roi_y;
+  return 0;
+}
+
+int make_solve_params(const mpe_params* p, const double* markers, int n_markers, const double K[9], SolveParams& sp) {
+  if (n_markers < 0 || n_markers > MPE_MAX_MARKERS) return -1;
+  std::memset(&sp, 0, sizeof(sp));
+  sp.n_markers = n_markers;
+  for (int i = 0; i < 3 * n_markers; ++i) sp.markers[i] = markers[i];
+  sp.fx = K[0];
+  sp.fy = K[4];
+  sp.cx = K[2];
+  sp.cy = K[5];
+  sp.back_tol = p->back_projection_pixel_tolerance;
+  sp.certainty_thr = p->certainty_threshold;
+  sp.valid_corr_thr = p->valid_correspondence_threshold;
+  sp.hist_thr = p->histogram_threshold ? p->histogram_threshold : num_combinations_u32((unsigned)n_markers, 3);
+  return 0;
+}
+
+int make_geom(const mpe_handle* h, int rows, int cols, FrameGeom& g) {
+  if (rows <= 0 || cols <= 0 || rows > 4096 || cols > 4000) return -1;
+  g.rows = rows;
+  g.cols = cols;
+  g.pitch = (cols + 15) & ~15;
+  g.segs_per_row = g.pitch / 16;
+  g.segs_per_frame = rows * g.segs_per_row;
+  g.wb = (cols + 2 + 63) / 64 + 1;
+  g.rw = (rows + 63) / 64;
+  g.tw = (g.segs_per_row + 63) / 64;
+  // bytes per bitmap row: 3 bitmaps + todo bits + its share of the word mask
+  const size_t per_slot = (size_t)(3 * g.wb + g.tw) * 8 + (size_t)g.wb / 8 + 1;
+  size_t fixed = 2 * (size_t)g.rw * 8 + 2 * (size_t)g.rw * 4 + 64;
+  long cap = ((long)h->lds_budget - (long)fixed) / (long)per_slot;
+  if (cap > rows + 2 + rows / 2) cap = rows + 2 + rows / 2;  // every row active, worst-case separators
+  if (cap < 8) return -1;
+  g.slot_cap = (int)cap;
+  return 0;
+}
+
+size_t flag_words(size_t n_bytes) {
+  const size_t n_seg = n_bytes / 16;
+  return ((n_seg + 255) / 256) * 4 + 4;
+}
+
+// Bring `n_frames` frames into the packed device layout.  Returns the device pointer to use.
+int stage_frames(mpe_handle* h, const uint8_t* frames, int n_frames, int rows, int cols, size_t stride,
+                 size_t frame_stride, int on_device, int roi_x, int roi_y, int roi_w, int roi_h, const FrameGeom& g,
+                 const uint8_t** d_out) {
+  const bool full = (roi_x == 0 && roi_y == 0 && roi_w == cols && roi_h == rows);
+  const bool packed = full && stride == (size_t)g.pitch && frame_stride == (size_t)rows * g.pitch &&
+                      (reinterpret_cast<uintptr_t>(frames) & 15) == 0 && g.pitch == cols;
+  if (on_device && packed) {
+    *d_out = frames;
+    return MPE_OK;
+  }
+  const size_t bytes = (size_t)n_frames * g.rows * g.pitch;
+  HIP_TRY(h, h->frames.reserve(bytes + 16));
+  uint8_t* dst = static_cast<uint8_t*>(h->frames.p);
+  if (on_device) {
+    HIP_TRY(h, launch_repack(frames, stride, frame_stride, n_frames, roi_x, roi_y, roi_w, roi_h, dst, g.pitch,
+                             h->stream));
+  } else {
+    if (g.pitch != roi_w) HIP_TRY(h, hipMemsetAsync(dst, 0, bytes, h->stream));
+    if (full && stride == (size_t)cols && frame_stride == (size_t)rows * cols && g.pitch == cols) {
+      HIP_TRY(h, hipMemcpyAsync(dst, frames, bytes, hipMemcpyHostToDevice, h->stream));
+    } else {
+      for (int f = 0; f < n_frames; ++f) {
+        const uint8_t* src = frames + (size_t)f * frame_stride + (size_t)roi_y * stride + roi_x;
+        HIP_TRY(h, hipMemcpy2DAsync(dst + (size_t)f * g.rows * g.pitch, g.pitch, src, stride, roi_w, roi_h,
+                                    hipMemcpyHostToDevice, h->stream));
+      }
+    }
+  }
+  *d_out = dst;
+  return MPE_OK;
+}
+
+int auto_splits(const mpe_handle* h, int n_frames, int n_markers) {
+  if (h->vote_splits > 0) return h->vote_splits;
+  // few frames with a large hypothesis space: spread one frame over several workgroups
+  if (n_frames >= 1024 || n_markers <= 5) return 1;
+  int s = 2048 / std::max(1, n_frames);
+  return std::max(1, std::min(s, 64));
+}
+
+void rec(mpe_handle* h, int i) {
+  if (h->profiling && h->ev[i]) (void)hipEventRecord(h->ev[i], h->stream);
+}
+
+// the full per-batch pipeline on device-resident, packed frames
+int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const FrameGeom& g, const DetectParams& dp,
+                 const SolveParams* sp, mpe_detections* d_dets, uint32_t* d_hist, mpe_result* d_results,
+                 uint32_t* d_corr) {
+  const size_t bytes = (size_t)n_frames * g.rows * g.pitch;
+  HIP_TRY(h, h->flags.reserve(flag_words(bytes) * 8));
+  unsigned long long* d_flags = static_cast<unsigned long long*>(h->flags.p);
+  rec(h, 0);
+  HIP_TRY(h, launch_k1a_scan(d_frames, bytes, d_flags, dp.thr, h->stream));
+  rec(h, 1);
+  HIP_TRY(h, launch_k1b_blobs(d_frames, d_flags, n_frames, g, dp, d_dets, h->stream));
+  rec(h, 2);
+  if (sp) {
+    HIP_TRY(h, hipMemsetAsync(d_hist, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
+    HIP_TRY(h, launch_k2_vote(d_dets, n_frames, *sp, d_hist, auto_splits(h, n_frames, sp->n_markers), h->stream));
+    rec(h, 3);
+    HIP_TRY(h, launch_k3_tail(d_dets, d_hist, n_frames, *sp, d_results, d_corr, h->stream));
+  } else {
+    rec(h, 3);
+  }
+  rec(h, 4);
+  h->have_ms = h->profiling;
+  return MPE_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* mpe_version(void) { return "mpe-hip 0.1 (gfx950)"; }
+
+int mpe_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void mpe_default_params(mpe_params* p) {  // monocular_pose_estimator/launch/demo.launch:12-22
+  p->threshold_value = 140;
+  p->gaussian_sigma = 0.6;
+  p->min_blob_area = 10;
+  p->max_blob_area = 200;
+  p->max_width_height_distortion = 0.5;
+  p->max_circular_distortion = 0.5;
+  p->back_projection_pixel_tolerance = 5;
+  p->nearest_neighbour_pixel_tolerance = 7;
+  p->certainty_threshold = 0.75;
+  p->valid_correspondence_threshold = 0.7;
+  p->roi_border_thickness = 20;
+  p->histogram_threshold = 0;
+}
+
+int mpe_create(mpe_handle** out, int device) {
+  if (!out) return MPE_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MPE_ERR_NO_DEVICE;
+  mpe_handle* h = new mpe_handle();
+  if (device < 0) {
+    if (hipGetDevice(&h->device) != hipSuccess) {
+      delete h;
+      return MPE_ERR_NO_DEVICE;
+    }
+  } else {
+    if (device >= n || hipSetDevice(device) != hipSuccess) {
+      delete h;
+      return MPE_ERR_NO_DEVICE;
+    }
+    h->device = device;
+  }
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return MPE_ERR_HIP;
+  }
+  h->stream = h->own_stream;
+  *out = h;
+  return MPE_OK;
+}
+
+void mpe_destroy(mpe_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  h->frames.release();
+  h->flags.release();
+  h->dets.release();
+  h->hist.release();
+  h->results.release();
+  h->corr.release();
+  for (auto& e : h->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+const char* mpe_last_error(const mpe_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int mpe_set_stream(mpe_handle* h, void* hip_stream) {
+  if (!h) return MPE_ERR_ARG;
+  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return MPE_OK;
+}
+void* mpe_get_stream(mpe_handle* h) { return h ? h->stream : nullptr; }
+
+int mpe_synchronize(mpe_handle* h) {
+  if (!h) return MPE_ERR_ARG;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPE_OK;
+}
+
+int mpe_set_profiling(mpe_handle* h, int enable) {
+  if (!h) return MPE_ERR_ARG;
+  h->profiling = enable != 0;
+  if (h->profiling)
+    for (auto& e : h->ev)
+      if (!e) HIP_TRY(h, hipEventCreate(&e));
+  return MPE_OK;
+}
+
+int mpe_last_kernel_ms(mpe_handle* h, float ms[5]) {
+  if (!h || !ms) return MPE_ERR_ARG;
+  if (!h->have_ms) return fail(h, MPE_ERR_ARG, "profiling not enabled for the last batch");
+  HIP_TRY(h, hipEventSynchronize(h->ev[4]));
+  for (int i = 0; i < 4; ++i) HIP_TRY(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+  HIP_TRY(h, hipEventElapsedTime(&ms[4], h->ev[0], h->ev[4]));
+  return MPE_OK;
+}
+
+// tuning knobs (not part of the reference surface; used by bench / tests)
+int mpe_set_option(mpe_handle* h, const char* name, int value) {
+  if (!h || !name) return MPE_ERR_ARG;
+  if (!std::strcmp(name, "lds_budget")) {
+    if (value < 8 * 1024 || value > 160 * 1024) return fail(h, MPE_ERR_ARG, "lds_budget out of range");
+    h->lds_budget = value;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "vote_splits")) {
+    h->vote_splits = value;
+    return MPE_OK;
+  }
+  return fail(h, MPE_ERR_ARG, "unknown option");
+}
+
+int mpe_detect_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int rows, int cols, size_t stride_bytes,
+                     size_t frame_stride_bytes, int frames_on_device, const double K[9], const double* D, int nD,
+                     const mpe_params* p, mpe_detections* dets) {
+  if (!h || !frames || !p || !K || !dets || n_frames < 0) return fail(h, MPE_ERR_ARG, "bad argument");
+  if (n_frames == 0) return MPE_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  FrameGeom g;
+  if (make_geom(h, rows, cols, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
+  DetectParams dp;
+  if (make_detect_params(p, K, D, nD, 0, 0, dp)) return fail(h, MPE_ERR_ARG, "gaussian_sigma must be in (0, 6]");
+  const uint8_t* d_frames = nullptr;
+  int rc = stage_frames(h, frames, n_frames, rows, cols, stride_bytes, frame_stride_bytes, frames_on_device, 0, 0, cols,
+                        rows, g, &d_frames);
+  if (rc) return rc;
+  HIP_TRY(h, h->dets.reserve((size_t)n_frames * sizeof(mpe_detections)));
+  rc = run_pipeline(h, d_frames, n_frames, g, dp, nullptr, static_cast<mpe_detections*>(h->dets.p), nullptr, nullptr,
+                    nullptr);
+  if (rc) return rc;
+  HIP_TRY(h, hipMemcpyAsync(dets, h->dets.p, (size_t)n_frames * sizeof(mpe_detections), hipMemcpyDeviceToHost,
+                            h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPE_OK;
+}
+
+int mpe_find_leds(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t stride_bytes, int roi_x, int roi_y,
+                  int roi_w, int roi_h, const mpe_params* p, const double K[9], const double* D, int nD,
+                  double* undist_xy, float* dist_xy, int cap, int* n_out) {
+  if (!h || !img || !p || !K) return fail(h, MPE_ERR_ARG, "bad argument");
+  if (roi_x < 0 || roi_y < 0 || roi_w <= 0 || roi_h <= 0 || roi_x + roi_w > cols || roi_y + roi_h > rows)
+    return fail(h, MPE_ERR_ARG, "ROI outside the image");  // cv::Mat::operator()(Rect) asserts the same
+  HIP_TRY(h, hipSetDevice(h->device));
+  FrameGeom g;
+  if (make_geom(h, roi_h, roi_w, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
+  DetectParams dp;
+  if (make_detect_params(p, K, D, nD, roi_x, roi_y, dp)) return fail(h, MPE_ERR_ARG, "gaussian_sigma must be in (0, 6]");
+  const uint8_t* d_frames = nullptr;
+  int rc = stage_frames(h, img, 1, rows, cols, stride_bytes, (size_t)rows * stride_bytes, 0, roi_x, roi_y, roi_w, roi_h,
+                        g, &d_frames);
+  if (rc) return rc;
+  HIP_TRY(h, h->dets.reserve(sizeof(mpe_detections)));
+  rc = run_pipeline(h, d_frames, 1, g, dp, nullptr, static_cast<mpe_detections*>(h->dets.p), nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  mpe_detections d;
+  HIP_TRY(h, hipMemcpyAsync(&d, h->dets.p, sizeof(d), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (n_out) *n_out = d.n;
+  if (d.status != 0) {
+    h->err = "frame exceeded a device capacity";
+    return d.status;
+  }
+  for (int i = 0; i < d.n && i < cap; ++i) {
+    if (undist_xy) {
+      undist_xy[2 * i] = d.undist_xy[2 * i];
+      undist_xy[2 * i + 1] = d.undist_xy[2 * i + 1];
+    }
+    if (dist_xy) {
+      dist_xy[2 * i] = d.dist_xy[2 * i];
+      dist_xy[2 * i + 1] = d.dist_xy[2 * i + 1];
+    }
+  }
+  return MPE_OK;
+}
+
+int mpe_vote_batch(mpe_handle* h, const double* det_xy, const int* n_det, int n_frames, const double* markers_xyz,
+                   int n_markers, const double K[9], double back_projection_pixel_tolerance, uint32_t* hist) {
+  if (!h || !det_xy || !n_det || !markers_xyz || !K || !hist || n_frames < 0) return fail(h, MPE_ERR_ARG, "bad argument");
+  if (n_frames == 0) return MPE_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  mpe_params p;
+  mpe_default_params(&p);
+  p.back_projection_pixel_tolerance = back_projection_pixel_tolerance;
+  SolveParams sp;
+  if (make_solve_params(&p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_ARG, "too many markers");
+  std::vector<mpe_detections> hd(n_frames);
+  for (int f = 0; f < n_frames; ++f) {
+    std::memset(&hd[f], 0, sizeof(mpe_detections));
+    if (n_det[f] < 0 || n_det[f] > MPE_MAX_DETECTIONS) return fail(h, MPE_ERR_ARG, "n_det out of range");
+    hd[f].n = n_det[f];
+    std::memcpy(hd[f].undist_xy, det_xy + (size_t)f * 2 * MPE_MAX_DETECTIONS, sizeof(double) * 2 * n_det[f]);
+  }
+  HIP_TRY(h, h->dets.reserve((size_t)n_frames * sizeof(mpe_detections)));
+  HIP_TRY(h, h->hist.reserve((size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t)));
+  HIP_TRY(h, hipMemcpyAsync(h->dets.p, hd.data(), (size_t)n_frames * sizeof(mpe_detections), hipMemcpyHostToDevice,
+                            h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
+  HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), n_frames, sp, static_cast<uint32_t*>(h->hist.p),
+                            auto_splits(h, n_frames, n_markers), h->stream));
+  HIP_TRY(h, hipMemcpyAsync(hist, h->hist.p, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPE_OK;
+}
+
+int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
+                         const double K[9], const mpe_params* p, mpe_result* out, uint32_t* hist, uint32_t* corr) {
+  if (!h || (!det_xy && n_det > 0) || !markers_xyz || !K || !p || !out || n_det < 0)
+    return fail(h, MPE_ERR_ARG, "bad argument");
+  if (n_det > MPE_MAX_DETECTIONS) return fail(h, MPE_ERR_UNSUPPORTED, "n_det > MPE_MAX_DETECTIONS");
+  HIP_TRY(h, hipSetDevice(h->device));
+  SolveParams sp;
+  if (make_solve_params(p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
+  mpe_detections hd;
+  std::memset(&hd, 0, sizeof(hd));
+  hd.n = n_det;
+  if (n_det) std::memcpy(hd.undist_xy, det_xy, sizeof(double) * 2 * n_det);
+  HIP_TRY(h, h->dets.reserve(sizeof(mpe_detections)));
+  HIP_TRY(h, h->hist.reserve(MPE_HIST_STRIDE * sizeof(uint32_t)));
+  HIP_TRY(h, h->results.reserve(sizeof(mpe_result)));
+  HIP_TRY(h, h->corr.reserve(2 * MPE_MAX_MARKERS * sizeof(uint32_t)));
+  HIP_TRY(h, hipMemcpyAsync(h->dets.p, &hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
+  HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), 1, sp, static_cast<uint32_t*>(h->hist.p),
+                            auto_splits(h, 1, n_markers), h->stream));
+  HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
+                            static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), h->stream));
+  uint32_t hh[MPE_HIST_STRIDE], hc[2 * MPE_MAX_MARKERS];
+  HIP_TRY(h, hipMemcpyAsync(out, h->results.p, sizeof(mpe_result), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(hh, h->hist.p, sizeof(hh), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(hc, h->corr.p, sizeof(hc), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (hist)
+    for (int r = 0; r < n_det; ++r)
+      for (int c = 0; c < n_markers; ++c) hist[r * n_markers + c] = hh[r * MPE_MAX_MARKERS + c];
+  if (corr) std::memcpy(corr, hc, sizeof(uint32_t) * 2 * n_markers);
+  return MPE_OK;
+}
+
+int mpe_estimate_batch_device(mpe_handle* h, const uint8_t* d_frames, int n_frames, int rows, int cols,
+                              const double* markers_xyz, int n_markers, const double K[9], const double* D, int nD,
+                              const mpe_params* p, mpe_result* d_results) {
+  if (!h || !d_frames || !markers_xyz || !K || !p || !d_results || n_frames < 0)
+    return fail(h, MPE_ERR_ARG, "bad argument");
+  if (n_frames == 0) return MPE_OK;
+  if ((cols & 15) || (reinterpret_cast<uintptr_t>(d_frames) & 15))
+    return fail(h, MPE_ERR_UNSUPPORTED, "device frames must be packed, 16-byte aligned, cols % 16 == 0");
+  HIP_TRY(h, hipSetDevice(h->device));
+  FrameGeom g;
+  if (make_geom(h, rows, cols, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
+  DetectParams dp;
+  if (make_detect_params(p, K, D, nD, 0, 0, dp)) return fail(h, MPE_ERR_ARG, "gaussian_sigma must be in (0, 6]");
+  SolveParams sp;
+  if (make_solve_params(p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
+  HIP_TRY(h, h->dets.reserve((size_t)n_frames * sizeof(mpe_detections)));
+  HIP_TRY(h, h->hist.reserve((size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t)));
+  return run_pipeline(h, d_frames, n_frames, g, dp, &sp, static_cast<mpe_detections*>(h->dets.p),
+                      static_cast<uint32_t*>(h->hist.p), d_results, nullptr);
+}
+
+int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int rows, int cols, size_t stride_bytes,
+                       size_t frame_stride_bytes, int frames_on_device, const double* markers_xyz, int n_markers,
+                       const double K[9], const double* D, int nD, const mpe_params* p, mpe_result* results) {
+  if (!h || !frames || !markers_xyz || !K || !p || !results || n_frames < 0) return fail(h, MPE_ERR_ARG, "bad argument");
+  if (n_frames == 0) return MPE_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  FrameGeom g;
+  if (make_geom(h, rows, cols, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
+  DetectParams dp;
+  if (make_detect_params(p, K, D, nD, 0, 0, dp)) return fail(h, MPE_ERR_ARG, "gaussian_sigma must be in (0, 6]");
+  SolveParams sp;
+  if (make_solve_params(p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
+  const uint8_t* d_frames = nullptr;
+  int rc = stage_frames(h, frames, n_frames, rows, cols, stride_bytes, frame_stride_bytes, frames_on_device, 0, 0, cols,
+                        rows, g, &d_frames);
+  if (rc) return rc;
+  HIP_TRY(h, h->dets.reserve((size_t)n_frames * sizeof(mpe_detections)));
+  HIP_TRY(h, h->hist.reserve((size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t)));
+  HIP_TRY(h, h->results.reserve((size_t)n_frames * sizeof(mpe_result)));
+  rc = run_pipeline(h, d_frames, n_frames, g, dp, &sp, static_cast<mpe_detections*>(h->dets.p),
+                    static_cast<uint32_t*>(h->hist.p), static_cast<mpe_result*>(h->results.p), nullptr);
+  if (rc) return rc;
+  HIP_TRY(h, hipMemcpyAsync(results, h->results.p, (size_t)n_frames * sizeof(mpe_result), hipMemcpyDeviceToHost,
+                            h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// mpe_internal.h — structures shared by the host side (mpe_abi.cpp) and the gfx950 kernels
+// (mpe_kernels.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mpe.h"
+
+namespace mpe {
+
+// ---- image geometry in HBM -------------------------------------------------------------------
+// A frame is rows x pitch bytes, pitch % 16 == 0, pixels at x >= cols are zero (never bright).
+// The image pass sees the whole batch as one flat array of 16-byte "segments"; flag bit G tells
+// whether segment G holds a pixel above the threshold.
+struct FrameGeom {
+  int rows, cols, pitch;
+  int segs_per_row;    // pitch / 16
+  int segs_per_frame;  // rows * segs_per_row
+  int wb;              // u64 words per bitmap row (bit index = x + 1, plus one pad word)
+  int rw;              // u64 words of the row-activity bitset
+  int tw;              // u64 words per row of the todo (segment) bitset
+  int slot_cap;        // bitmap rows that fit in LDS
+};
+
+struct DetectParams {
+  int thr;    // THRESH_TOZERO threshold (strict >), clamped to [-1, 255]
+  int ksize;  // Gaussian taps (odd, <= MPE_MAX_KSIZE); 1 = identity
+  int taps[MPE_MAX_KSIZE];
+  double min_area, max_area, max_wh, max_circ;
+  double K[9];
+  double ifx, ify;
+  double k[8];  // distortion coefficients k1 k2 p1 p2 k3 k4 k5 k6
+  int undist_iters;
+  int roi_x, roi_y;  // added to the centroid (float add), LED.cpp:74
+};
+
+struct SolveParams {
+  int n_markers;
+  double markers[MPE_MAX_MARKERS * 3];
+  double fx, fy, cx, cy;
+  double back_tol;        // back_projection_pixel_tolerance_
+  double certainty_thr;   // certainty_threshold_
+  double valid_corr_thr;  // valid_correspondence_threshold_
+  unsigned hist_thr;      // histogram_threshold_
+};
+
+#define MPE_HIST_STRIDE (MPE_MAX_DETECTIONS * MPE_MAX_MARKERS)
+
+// launchers (mpe_kernels.hip)
+size_t k1b_lds_bytes(const FrameGeom& g);
+hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long long* flags, int thr,
+                           hipStream_t s);
+hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
+                            const DetectParams& dp, mpe_detections* dets, hipStream_t s);
+hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist,
+                          int splits, hipStream_t s);
+hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
+                          mpe_result* results, uint32_t* corr_out, hipStream_t s);
+hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int n_frames, int roi_x,
+                         int roi_y, int roi_w, int roi_h, uint8_t* dst, int dst_pitch, hipStream_t s);
+
+}  // namespace mpe

@@ -1,0 +1,274 @@
+// mpe_p3p.h — FP64 device geometry for gfx950: small vectors, complex Ferrari quartic, Kneip P3P.
+//
+// Written for the CDNA4 VALU (wave64, FP64 FMA at 16 lanes/clk/SIMD); everything is inlined into
+// the calling kernel, state lives in VGPRs, no scratch arrays with dynamic indices.
+// Behaviour follows the reference P3P (monocular_pose_estimator_lib/src/p3p.cpp:65-286):
+// principal-branch complex sqrt / pow, REAL PARTS of the complex roots are consumed, NaNs flow
+// through and are filtered by the caller (pose_estimator.cpp:653).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mpe {
+
+struct V3 {
+  double x, y, z;
+};
+__device__ __forceinline__ V3 operator-(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator+(const V3& a, const V3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 vdiv(const V3& a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ V3 cross(const V3& a, const V3& b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double norm(const V3& a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+
+// 3x3 stored as three row vectors
+struct M3 {
+  V3 r0, r1, r2;
+};
+__device__ __forceinline__ V3 mul(const M3& A, const V3& v) { return {dot(A.r0, v), dot(A.r1, v), dot(A.r2, v)}; }
+// A^T * v
+__device__ __forceinline__ V3 mulT(const M3& A, const V3& v) {
+  return {A.r0.x * v.x + A.r1.x * v.y + A.r2.x * v.z, A.r0.y * v.x + A.r1.y * v.y + A.r2.y * v.z,
+          A.r0.z * v.x + A.r1.z * v.y + A.r2.z * v.z};
+}
+__device__ __forceinline__ M3 mul(const M3& A, const M3& B) {
+  M3 C;
+  C.r0 = {A.r0.x * B.r0.x + A.r0.y * B.r1.x + A.r0.z * B.r2.x, A.r0.x * B.r0.y + A.r0.y * B.r1.y + A.r0.z * B.r2.y,
+          A.r0.x * B.r0.z + A.r0.y * B.r1.z + A.r0.z * B.r2.z};
+  C.r1 = {A.r1.x * B.r0.x + A.r1.y * B.r1.x + A.r1.z * B.r2.x, A.r1.x * B.r0.y + A.r1.y * B.r1.y + A.r1.z * B.r2.y,
+          A.r1.x * B.r0.z + A.r1.y * B.r1.z + A.r1.z * B.r2.z};
+  C.r2 = {A.r2.x * B.r0.x + A.r2.y * B.r1.x + A.r2.z * B.r2.x, A.r2.x * B.r0.y + A.r2.y * B.r1.y + A.r2.z * B.r2.y,
+          A.r2.x * B.r0.z + A.r2.y * B.r1.z + A.r2.z * B.r2.z};
+  return C;
+}
+__device__ __forceinline__ M3 transpose(const M3& A) {
+  return {{A.r0.x, A.r1.x, A.r2.x}, {A.r0.y, A.r1.y, A.r2.y}, {A.r0.z, A.r1.z, A.r2.z}};
+}
+
+// ---- complex double (principal branches, as libstdc++ <complex> on top of C99 csqrt/clog) ----
+struct C2 {
+  double re, im;
+};
+__device__ __forceinline__ C2 cadd(C2 a, C2 b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ C2 csub(C2 a, C2 b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ C2 cscale(C2 a, double s) { return {a.re * s, a.im * s}; }
+// (a + ib) / (c + id), Smith's algorithm (what libgcc's __divdc3 evaluates for finite operands)
+__device__ __forceinline__ C2 cdiv(C2 n, C2 d) {
+  double a = n.re, b = n.im, c = d.re, e = d.im;
+  if (fabs(c) < fabs(e)) {
+    double ratio = c / e, denom = c * ratio + e;
+    return {(a * ratio + b) / denom, (b * ratio - a) / denom};
+  }
+  double ratio = e / c, denom = e * ratio + c;
+  return {(b * ratio + a) / denom, (b - a * ratio) / denom};
+}
+// principal square root
+__device__ __forceinline__ C2 csqrt_(C2 z) {
+  if (z.im == 0.0) {
+    if (z.re < 0.0) return {0.0, copysign(sqrt(-z.re), z.im)};
+    return {fabs(sqrt(z.re)), z.im};
+  }
+  double d = hypot(z.re, z.im);
+  double r, s;
+  if (z.re > 0.0) {
+    r = sqrt(0.5 * (d + z.re));
+    s = 0.5 * (z.im / r);
+  } else {
+    s = sqrt(0.5 * (d - z.re));
+    r = fabs(0.5 * (z.im / s));
+  }
+  return {r, copysign(s, z.im)};
+}
+// std::pow(complex z, double y) for y = 1/3: real pow when z is a positive real, else
+// polar(exp(y log|z|), y arg z).  |z|^(1/3) is evaluated with cbrt (same value to ~1 ulp).
+__device__ __forceinline__ C2 cpow_third(C2 z) {
+  const double third = 1.0 / 3.0;
+  if (z.im == 0.0 && z.re > 0.0) return {cbrt(z.re), 0.0};
+  double rho = cbrt(hypot(z.re, z.im));
+  double phi = third * atan2(z.im, z.re);
+  double s, c;
+  sincos(phi, &s, &c);
+  return {rho * c, rho * s};
+}
+// std::pow(complex(q,0), 2.0) and std::pow(complex(p,0), 3.0): for a negative real the library
+// goes through polar(|x|^y, y*pi); sin(2*pi_d) and sin(3*pi_d) are not zero in double, which gives
+// the discriminant its (branch-selecting) imaginary dust.  Replicated with the constants.
+__device__ __forceinline__ C2 cpow2_real(double q) {
+  double m = q * q;
+  if (q < 0.0) return {m, m * -2.4492935982947064e-16};
+  return {m, 0.0};
+}
+__device__ __forceinline__ C2 cpow3_real(double p) {
+  double m = p * p * p;
+  if (p < 0.0) return {m, -m * 3.6739403974420594e-16};
+  return {m, 0.0};
+}
+
+// Ferrari, real parts of the four (possibly complex) roots.  p3p.cpp:238-286
+__device__ __forceinline__ void solve_quartic(double A, double B, double C, double D, double E, double rr[4]) {
+  double A_pw2 = A * A, B_pw2 = B * B;
+  double A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B;
+  double A_pw4 = A_pw3 * A, B_pw4 = B_pw3 * B;
+  double alpha = -3 * B_pw2 / (8 * A_pw2) + C / A;
+  double beta = B_pw3 / (8 * A_pw3) - B * C / (2 * A_pw2) + D / A;
+  double gamma = -3 * B_pw4 / (256 * A_pw4) + B_pw2 * C / (16 * A_pw3) - B * D / (4 * A_pw2) + E / A;
+  double alpha_pw2 = alpha * alpha, alpha_pw3 = alpha_pw2 * alpha;
+
+  double Pr = -alpha_pw2 / 12 - gamma;
+  double Qr = -alpha_pw3 / 108 + alpha * gamma / 3 - (beta * beta) / 8;
+  C2 q2 = cpow2_real(Qr), p3 = cpow3_real(Pr);
+  C2 disc = {q2.re / 4.0 + p3.re / 27.0, q2.im / 4.0 + p3.im / 27.0};
+  C2 sq = csqrt_(disc);
+  C2 R = {-Qr / 2.0 + sq.re, sq.im};  // -Q/2 has imaginary part -0/2 = -0
+  C2 U = cpow_third(R);
+  C2 y;
+  if (U.re == 0.0) {
+    C2 qc = cpow_third(C2{Qr, 0.0});
+    y = {-5.0 * alpha / 6.0 - qc.re, -qc.im};
+  } else {
+    C2 t = cdiv(C2{Pr, 0.0}, cscale(U, 3.0));
+    y = {-5.0 * alpha / 6.0 - t.re + U.re, -t.im + U.im};
+  }
+  C2 w = csqrt_(C2{alpha + 2.0 * y.re, 2.0 * y.im});
+  C2 bw = cdiv(C2{2.0 * beta, 0.0}, w);
+  C2 base = {3.0 * alpha + 2.0 * y.re, 2.0 * y.im};
+  C2 s1 = csqrt_(C2{-(base.re + bw.re), -(base.im + bw.im)});
+  C2 s2 = csqrt_(C2{-(base.re - bw.re), -(base.im - bw.im)});
+  double off = -B / (4.0 * A);
+  rr[0] = off + 0.5 * (w.re + s1.re);
+  rr[1] = off + 0.5 * (w.re - s1.re);
+  rr[2] = off + 0.5 * (-w.re + s2.re);
+  rr[3] = off + 0.5 * (-w.re - s2.re);
+}
+
+// Everything of computePoses that does not depend on the root index.  p3p.cpp:65-190
+struct P3PCtx {
+  M3 T, N;
+  V3 P1;
+  double f_1, f_2, p_1, p_2, d_12, b;
+  double root[4];
+};
+
+// returns false iff the world points are exactly collinear (p3p.cpp:77-80)
+__device__ __forceinline__ bool p3p_prepare(const V3& fa, const V3& fb, const V3& fc, const V3& wa, const V3& wb,
+                                            const V3& wc, P3PCtx& c) {
+  V3 P1 = wa, P2 = wb, P3 = wc;
+  if (norm(cross(P2 - P1, P3 - P1)) == 0.0) return false;
+  V3 f1 = fa, f2 = fb;
+  V3 e1 = f1;
+  V3 e3 = cross(f1, f2);
+  e3 = vdiv(e3, norm(e3));
+  V3 e2 = cross(e3, e1);
+  M3 T = {e1, e2, e3};
+  V3 f3 = mul(T, fc);
+  if (f3.z > 0.0) {  // p3p.cpp:100-121: swap the first two correspondences
+    f1 = fb;
+    f2 = fa;
+    e1 = f1;
+    e3 = cross(f1, f2);
+    e3 = vdiv(e3, norm(e3));
+    e2 = cross(e3, e1);
+    T = {e1, e2, e3};
+    f3 = mul(T, fc);
+    P1 = wb;
+    P2 = wa;
+  }
+  V3 n1 = P2 - P1;
+  n1 = vdiv(n1, norm(n1));
+  V3 n3 = cross(n1, P3 - P1);
+  n3 = vdiv(n3, norm(n3));
+  V3 n2 = cross(n3, n1);
+  M3 N = {n1, n2, n3};
+  V3 P3n = mul(N, P3 - P1);
+  double d_12 = norm(P2 - P1);
+  double f_1 = f3.x / f3.z, f_2 = f3.y / f3.z;
+  double p_1 = P3n.x, p_2 = P3n.y;
+  double cos_beta = dot(f1, f2);
+  double b = 1 / (1 - cos_beta * cos_beta) - 1;
+  b = (cos_beta < 0) ? -sqrt(b) : sqrt(b);
+
+  double f_1_pw2 = f_1 * f_1, f_2_pw2 = f_2 * f_2;
+  double p_1_pw2 = p_1 * p_1, p_1_pw3 = p_1_pw2 * p_1, p_1_pw4 = p_1_pw3 * p_1;
+  double p_2_pw2 = p_2 * p_2, p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2;
+  double d_12_pw2 = d_12 * d_12, b_pw2 = b * b;
+
+  double F0 = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
+  double F1 = 2 * p_2_pw3 * d_12 * b + 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * f_2 * p_2_pw3 * f_1 * d_12;
+  double F2 = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 +
+              f_2_pw2 * p_2_pw4 + p_2_pw4 * f_1_pw2 + 2 * p_1 * p_2_pw2 * d_12 +
+              2 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b - p_2_pw2 * p_1_pw2 * f_1_pw2 +
+              2 * p_1 * p_2_pw2 * f_2_pw2 * d_12 - p_2_pw2 * d_12_pw2 * b_pw2 - 2 * p_1_pw2 * p_2_pw2;
+  double F3 = 2 * p_1_pw2 * p_2 * d_12 * b + 2 * f_2 * p_2_pw3 * f_1 * d_12 - 2 * f_2_pw2 * p_2_pw3 * d_12 * b -
+              2 * p_1 * p_2 * d_12_pw2 * b;
+  double F4 = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 + 2 * p_1_pw3 * d_12 -
+              p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 - 2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 +
+              p_2_pw2 * f_1_pw2 * p_1_pw2 + f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
+  solve_quartic(F0, F1, F2, F3, F4, c.root);
+  c.T = T;
+  c.N = N;
+  c.P1 = P1;
+  c.f_1 = f_1;
+  c.f_2 = f_2;
+  c.p_1 = p_1;
+  c.p_2 = p_2;
+  c.d_12 = d_12;
+  c.b = b;
+  return true;
+}
+
+// Back-substitution of one root: R (camera -> marker frame) and C (camera centre in the marker
+// frame).  p3p.cpp:193-233
+__device__ __forceinline__ void p3p_solution(const P3PCtx& c, double root, M3& R, V3& C) {
+  double cot_alpha = (-c.f_1 * c.p_1 / c.f_2 - root * c.p_2 + c.d_12 * c.b) /
+                     (-c.f_1 * root * c.p_2 / c.f_2 + c.p_1 - c.d_12);
+  double cos_theta = root;
+  double sin_theta = sqrt(1 - root * root);
+  double sin_alpha = sqrt(1 / (cot_alpha * cot_alpha + 1));
+  double cos_alpha = sqrt(1 - sin_alpha * sin_alpha);
+  if (cot_alpha < 0) cos_alpha = -cos_alpha;
+  double k = sin_alpha * c.b + cos_alpha;
+  V3 Cn = {c.d_12 * cos_alpha * k, cos_theta * c.d_12 * sin_alpha * k, sin_theta * c.d_12 * sin_alpha * k};
+  C = c.P1 + mulT(c.N, Cn);
+  // Rt = transpose of the matrix written at p3p.cpp:215-224
+  M3 Rt = {{-cos_alpha, sin_alpha, 0.0},
+           {-sin_alpha * cos_theta, -cos_alpha * cos_theta, -sin_theta},
+           {-sin_alpha * sin_theta, -cos_alpha * sin_theta, cos_theta}};
+  R = mul(mul(transpose(c.N), Rt), c.T);
+}
+
+// isFinite([R C; 0 0 0 1]) — pose_estimator.cpp:856-860
+__device__ __forceinline__ bool rc_finite(const M3& R, const V3& C) {
+  double z = (R.r0.x - R.r0.x) + (R.r0.y - R.r0.y) + (R.r0.z - R.r0.z) + (R.r1.x - R.r1.x) + (R.r1.y - R.r1.y) +
+             (R.r1.z - R.r1.z) + (R.r2.x - R.r2.x) + (R.r2.y - R.r2.y) + (R.r2.z - R.r2.z) + (C.x - C.x) +
+             (C.y - C.y) + (C.z - C.z);
+  return z == 0.0;
+}
+
+// Pinhole projection matrix of the INVERSE of H = [R C; 0 1]:  M = K [I|0] H^-1  (3x4).
+// The reference calls the general 4x4 inverse on this rigid transform (pose_estimator.cpp:660);
+// the rigid closed form [R^T | -R^T C] is the same matrix up to rounding of an orthonormal R.
+struct Proj {
+  V3 r0, r1, r2;    // rows of the 3x3 part
+  double t0, t1, t2;  // fourth column
+};
+__device__ __forceinline__ Proj make_projection(const M3& R, const V3& C, double fx, double fy, double cx, double cy) {
+  M3 Ri = transpose(R);
+  V3 ti = mul(Ri, C);
+  ti = {-ti.x, -ti.y, -ti.z};
+  Proj P;
+  P.r0 = {fx * Ri.r0.x + cx * Ri.r2.x, fx * Ri.r0.y + cx * Ri.r2.y, fx * Ri.r0.z + cx * Ri.r2.z};
+  P.r1 = {fy * Ri.r1.x + cy * Ri.r2.x, fy * Ri.r1.y + cy * Ri.r2.y, fy * Ri.r1.z + cy * Ri.r2.z};
+  P.r2 = Ri.r2;
+  P.t0 = fx * ti.x + cx * ti.z;
+  P.t1 = fy * ti.y + cy * ti.z;
+  P.t2 = ti.z;
+  return P;
+}
+__device__ __forceinline__ void project(const Proj& P, const V3& m, double& u, double& v) {
+  double x = dot(P.r0, m) + P.t0, y = dot(P.r1, m) + P.t1, z = dot(P.r2, m) + P.t2;
+  u = x / z;
+  v = y / z;
+}
+
+}  // namespace mpe

@@ -1,0 +1,134 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs, at every stage boundary.  Integer / index / float32-detection results must be bit-equal;
+poses within the north_star tolerance (<= 1e-4 m, <= 1e-3 rad)."""
+import numpy as np
+import pytest
+
+from rpg_monocular_pose_estimator_amd import synth
+import rpg_monocular_pose_estimator_amd as mpe
+from util import pose_diff, POS_TOL_M, ROT_TOL_RAD
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_dets(orc, d, P):
+    return [orc.find_leds(f, P, d["K"], d["D"]) for f in d["frames"]]
+
+
+@pytest.mark.parametrize("config,n", [("C2", 24), ("C3", 6), ("C1", 8), ("C4", 3)])
+def test_detection_bit_exact(hip, orc, config, n):
+    d = synth.make_frames(config, n, seed=101)
+    P = mpe.demo_params()
+    got = hip.detect_batch(d["frames"], d["K"], d["D"], P)
+    ref = _oracle_dets(orc, d, orc.make_params())
+    for i in range(n):
+        und, dist = ref[i]
+        assert got["status"][i] == 0
+        assert got["n"][i] == len(und), (i, got["n"][i], len(und))
+        k = len(und)
+        assert np.array_equal(got["dist_xy"][i][:2 * k].reshape(-1, 2), dist), i   # float32, bit-equal
+        assert np.array_equal(got["undist_xy"][i][:2 * k].reshape(-1, 2), und), i  # float32 widened
+
+
+@pytest.mark.parametrize("config,n", [("C2", 24), ("C3", 3), ("C1", 8)])
+def test_vote_histogram_integer_equal(hip, orc, config, n):
+    d = synth.make_frames(config, n, seed=202)
+    dets = [u for (u, _) in _oracle_dets(orc, d, orc.make_params())]
+    got = hip.vote_batch(dets, d["markers"], d["K"], 5.0)
+    for i in range(n):
+        ref = orc.vote_histogram(dets[i], d["markers"], d["K"], 5.0)
+        assert np.array_equal(got[i], ref), (i, got[i], ref)
+
+
+@pytest.mark.parametrize("config,n", [("C2", 24), ("C3", 3), ("C1", 8)])
+def test_solve_bruteforce_parity(hip, orc, config, n):
+    d = synth.make_frames(config, n, seed=303)
+    Po, Ph = orc.make_params(), mpe.demo_params()
+    n_pose = 0
+    for i in range(n):
+        und, _ = orc.find_leds(d["frames"][i], Po, d["K"], d["D"])
+        ro = orc.solve_bruteforce(und, d["markers"], d["K"], Po)
+        rh = hip.solve_bruteforce(und, d["markers"], d["K"], Ph)
+        assert np.array_equal(rh["hist"], ro["hist"]), i
+        assert rh["status"] == ro["status"], i
+        assert rh["n_corr"] == ro["n_corr"] and np.array_equal(rh["corr"], ro["corr"]), i
+        if ro["status"] == 0:
+            n_pose += 1
+            dp, dr = pose_diff(rh["T"], ro["T"])
+            assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (i, dp, dr)
+            assert np.allclose(rh["cov"], ro["cov"], rtol=1e-6, atol=1e-12), i
+    assert n_pose >= n // 2
+
+
+@pytest.mark.parametrize("config,n", [("C2", 48), ("C3", 4), ("C4", 3)])
+def test_estimate_batch_parity(hip, orc, config, n):
+    d = synth.make_frames(config, n, seed=404)
+    ro = orc.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], orc.make_params(), n_threads=4)
+    rh = hip.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], mpe.demo_params())
+    assert np.array_equal(rh["status"], ro["status"])
+    assert np.array_equal(rh["n_det"], ro["n_det"])
+    assert np.array_equal(rh["n_corr"], ro["n_corr"])
+    for i in range(n):
+        if ro["status"][i] == 0:
+            dp, dr = pose_diff(rh["T"][i], ro["T"][i])
+            assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (i, dp, dr)
+
+
+def test_edge_frames(hip, orc):
+    """Empty frame, frame with 3 LEDs only, blob touching the border, salt noise."""
+    K, D = synth.camera_for(480, 752)
+    Po, Ph = orc.make_params(), mpe.demo_params()
+    rng = np.random.default_rng(5)
+    frames = np.zeros((5, 480, 752), np.uint8)
+    frames[1] = synth.render_frame(rng, np.array([[100.5, 100.2], [300.1, 200.7], [500.9, 400.3]]), 480, 752)
+    frames[2] = synth.render_frame(rng, np.array([[1.0, 1.0], [750.5, 478.2], [0.3, 240.0], [400.0, 0.0], [375.5, 240.5]]), 480, 752)
+    frames[3] = (rng.random((480, 752)) > 0.9995).astype(np.uint8) * 255
+    frames[4] = synth.render_frame(rng, np.array([[200.0, 200.0], [207.0, 203.0], [400.0, 300.0], [404.0, 309.0], [600.0, 100.0]]), 480, 752)
+    got = hip.detect_batch(frames, K, D, Ph)
+    for i in range(len(frames)):
+        und, dist = orc.find_leds(frames[i], Po, K, D)
+        assert got["status"][i] == 0
+        assert got["n"][i] == len(und), (i, got["n"][i], len(und))
+        assert np.array_equal(got["dist_xy"][i][:2 * len(und)].reshape(-1, 2), dist), i
+    res = hip.estimate_batch(frames, synth.M5, K, D, Ph)
+    ro = orc.estimate_batch(frames, synth.M5, K, D, Po)
+    assert np.array_equal(res["status"], ro["status"])
+
+
+def test_find_leds_roi(hip, orc):
+    d = synth.make_frames("C2", 4, seed=9)
+    Po, Ph = orc.make_params(), mpe.demo_params()
+    for i in range(4):
+        s = d["spots"][i]
+        x0, y0 = int(max(0, s[:, 0].min() - 23)), int(max(0, s[:, 1].min() - 17))
+        x1, y1 = int(min(752, s[:, 0].max() + 31)), int(min(480, s[:, 1].max() + 29))
+        roi = (x0, y0, x1 - x0, y1 - y0)
+        uo, do = orc.find_leds(d["frames"][i], Po, d["K"], d["D"], roi=roi)
+        uh, dh = hip.find_leds(d["frames"][i], Ph, d["K"], d["D"], roi=roi)
+        assert np.array_equal(do, dh) and np.array_equal(uo, uh)
+
+
+def test_capacity_is_loud(hip):
+    """A fully bright frame exceeds the LDS row capacity: reported per frame, never silent."""
+    K, D = synth.camera_for(480, 752)
+    frames = np.full((1, 480, 752), 255, np.uint8)
+    got = hip.detect_batch(frames, K, D, mpe.demo_params())
+    assert got["status"][0] < 0
+
+
+def test_pose_estimator_facade(hip, orc):
+    d = synth.make_frames("C2", 6, seed=77)
+    for i in range(6):
+        pe = mpe.PoseEstimator(hip)
+        pe.setMarkerPositions(d["markers"])
+        pe.camera_matrix_K_ = d["K"]
+        pe.camera_distortion_coeffs_ = list(d["D"])
+        pe.detection_threshold_value_ = 140
+        pe.setBackProjectionPixelTolerance(5)
+        pe.setNearestNeighbourPixelTolerance(7)
+        ok = pe.estimateBodyPose(d["frames"][i], 0.1 * i)
+        ro = orc.estimate_batch(d["frames"][i:i + 1], d["markers"], d["K"], d["D"], orc.make_params())
+        assert ok == (ro["status"][0] == 0)
+        if ok:
+            dp, dr = pose_diff(pe.getPredictedPose(), ro["T"][0])
+            assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD
