@@ -40,10 +40,14 @@ def test_vote_histogram_integer_equal(hip, orc, config, n):
         assert np.array_equal(got[i], ref), (i, got[i], ref)
 
 
-@pytest.mark.parametrize("config,n", [("C2", 24), ("C3", 3), ("C1", 8)])
-def test_solve_bruteforce_parity(hip, orc, config, n):
+# C3 with the demo tolerance (5 px) mostly FAILS to initialise in the reference algorithm itself
+# (12 detections x 8 markers pollute the vote table) — parity of the failure is what is checked;
+# the 2 px variant exercises the 8-marker tail with poses found.
+@pytest.mark.parametrize("config,n,tol,min_pose", [("C2", 24, 5.0, 12), ("C3", 3, 5.0, 0), ("C3", 4, 2.0, 3),
+                                                   ("C1", 8, 5.0, 4)])
+def test_solve_bruteforce_parity(hip, orc, config, n, tol, min_pose):
     d = synth.make_frames(config, n, seed=303)
-    Po, Ph = orc.make_params(), mpe.demo_params()
+    Po, Ph = orc.make_params(back_projection_pixel_tolerance=tol), mpe.demo_params(back_projection_pixel_tolerance=tol)
     n_pose = 0
     for i in range(n):
         und, _ = orc.find_leds(d["frames"][i], Po, d["K"], d["D"])
@@ -57,7 +61,7 @@ def test_solve_bruteforce_parity(hip, orc, config, n):
             dp, dr = pose_diff(rh["T"], ro["T"])
             assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (i, dp, dr)
             assert np.allclose(rh["cov"], ro["cov"], rtol=1e-6, atol=1e-12), i
-    assert n_pose >= n // 2
+    assert n_pose >= min_pose
 
 
 @pytest.mark.parametrize("config,n", [("C2", 48), ("C3", 4), ("C4", 3)])
