@@ -225,7 +225,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   rec(h, 2);
   if (sp) {
     HIP_TRY(h, hipMemsetAsync(d_hist, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
-    HIP_TRY(h, launch_k2_vote(d_dets, n_frames, *sp, d_hist, auto_splits(h, n_frames, sp->n_markers), h->stream));
+    HIP_TRY(h, launch_k2_vote(d_dets, n_frames, *sp, d_hist, auto_splits(h, n_frames, sp->n_markers), sp->n_markers, h->stream));
     rec(h, 3);
     HIP_TRY(h, launch_k3_tail(d_dets, d_hist, n_frames, *sp, d_results, d_corr, h->stream));
   } else {
@@ -441,7 +441,7 @@ int mpe_vote_batch(mpe_handle* h, const double* det_xy, const int* n_det, int n_
                             h->stream));
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
   HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), n_frames, sp, static_cast<uint32_t*>(h->hist.p),
-                            auto_splits(h, n_frames, n_markers), h->stream));
+                            auto_splits(h, n_frames, n_markers), n_markers, h->stream));
   HIP_TRY(h, hipMemcpyAsync(hist, h->hist.p, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -467,7 +467,7 @@ int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const d
   HIP_TRY(h, hipMemcpyAsync(h->dets.p, &hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
   HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), 1, sp, static_cast<uint32_t*>(h->hist.p),
-                            auto_splits(h, 1, n_markers), h->stream));
+                            auto_splits(h, 1, n_markers), n_det, h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
                             static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), h->stream));
   uint32_t hh[MPE_HIST_STRIDE], hc[2 * MPE_MAX_MARKERS];

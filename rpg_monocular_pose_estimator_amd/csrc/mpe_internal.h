@@ -53,7 +53,7 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, hipStream_t s);
 hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist,
-                          int splits, hipStream_t s);
+                          int splits, int n_det_hint, hipStream_t s);
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
                           mpe_result* results, uint32_t* corr_out, hipStream_t s);
 hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int n_frames, int roi_x,

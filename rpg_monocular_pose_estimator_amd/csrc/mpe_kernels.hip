@@ -111,8 +111,21 @@ hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame
 }
 
 // =============================================================================================
-// K1b — blob extraction, one wave per frame
+// K1b — blob extraction, one wave per frame, small LDS footprint (high occupancy)
+//
+// The flag bits give the bright 16-byte segments of the frame.  Rows within +-r of a bright
+// segment form BANDS (maximal runs of such rows); inside a band the occupied segment columns
+// (dilated by the blur reach) split into ISLANDS.  Blurred-mask components can neither cross an
+// inactive row nor an empty column run, and an island cannot lie inside a hole of another island
+// (disjoint bounding boxes), so OpenCV's raster scan decomposes exactly: every island is scanned
+// on its own in a small LDS window (thresholded pixels + three bitmaps), and the blobs are put
+// back into raster order of their start pixels at the end.
 // =============================================================================================
+#define K1B_SEG_CAP 1024   // bright segments per frame kept in LDS
+#define K1B_PIX_CAP 8192   // bytes of thresholded pixels per island window
+#define K1B_BM_CAP 320     // u64 words per island bitmap
+#define K1B_KEPT_CAP 64    // blobs that pass the shape filter (> MPE_MAX_DETECTIONS -> status)
+
 struct BlobRec {
   long long a00, a10, a01;  // polygon sums: sum dxy, sum dxy*(x_{i-1}+x_i), sum dxy*(y_{i-1}+y_i)
   int xmin, xmax, ymin, ymax;
@@ -127,24 +140,6 @@ __device__ __forceinline__ int reflect101(int p, int len) {  // cv::borderInterp
   return p;
 }
 
-template <class F>
-__device__ __forceinline__ void for_each_bright_seg(const u64* __restrict__ flags, size_t G0, int spf, int lane, F f) {
-  const int nwin = (spf + 63) >> 6;
-  const size_t w0 = G0 >> 6;
-  const int sh = (int)(G0 & 63);
-  for (int i = lane; i < nwin; i += 64) {
-    u64 a = flags[w0 + i], b = flags[w0 + i + 1];
-    u64 v = sh ? ((a >> sh) | (b << (64 - sh))) : a;
-    const int rem = spf - i * 64;
-    if (rem < 64) v &= (1ull << rem) - 1;
-    while (v) {
-      const int bit = __builtin_ctzll(v);
-      v &= v - 1;
-      f(i * 64 + bit);
-    }
-  }
-}
-
 __device__ __forceinline__ void lds_set_range(u64* bits, int lo, int hi) {  // inclusive, hi - lo < 64
   const int wl = lo >> 6, wh = hi >> 6;
   if (wl == wh) {
@@ -156,48 +151,42 @@ __device__ __forceinline__ void lds_set_range(u64* bits, int lo, int hi) {  // i
   }
 }
 
-struct RowMap {
-  const u64* rowact;
-  const u64* rowstart;
-  const unsigned* rowpre;
-  const unsigned* bandpre;
-  __device__ __forceinline__ bool active(int y) const { return (rowact[y >> 6] >> (y & 63)) & 1; }
-  // slot = (#active rows < y) + (#band starts <= y); slot 0 and the slot after every band are
-  // all-zero separator rows, so border following can step +-1 slot without bounds checks.
-  __device__ __forceinline__ int slot(int y) const {
-    const int w = y >> 6, b = y & 63;
-    return (int)(rowpre[w] + __builtin_popcountll(rowact[w] & ((1ull << b) - 1)) + bandpre[w] +
-                 __builtin_popcountll(rowstart[w] & ((2ull << b) - 1)));
-  }
+// THRESH_TOZERO on four packed bytes: keep bytes > thr, zero the others (add = (255-thr)*0x10001)
+__device__ __forceinline__ unsigned tozero4(unsigned w, unsigned add) {
+  unsigned e = w & 0x00FF00FFu, o = (w >> 8) & 0x00FF00FFu;
+  const unsigned me = (((e + add) >> 8) & 0x00010001u) * 0xFFu;
+  const unsigned mo = (((o + add) >> 8) & 0x00010001u) * 0xFFu;
+  return (e & me) | ((o & mo) << 8);
+}
+
+// Window of thresholded pixels of one island in LDS: rows ylo..ylo+H-1, segment columns
+// pwc0..pwc0+nseg-1 (16 bytes each; columns outside the image hold zeros).
+struct PixWin {
+  const uint8_t* pix;
+  int ylo, H, pwc0, PW;  // PW = bytes per window row
 };
 
-// Fixed-point Gaussian of the thresholded image for 16 output pixels (x0..x0+15 of row y);
-// returns the 16-bit mask of non-zero results: (sum + 2^15) >> 16 != 0  <=>  sum >= 2^15.
+// fixed-point Gaussian for the 16 outputs x0..x0+15 of image row y, reading the LDS window.
+// Returns the bit mask of outputs whose blurred value is non-zero: (sum + 2^15) >> 16 != 0.
 template <int KS>
-__device__ __forceinline__ unsigned blur_item(const uint8_t* __restrict__ frame, int rows, int cols, int pitch, int y,
-                                              int x0, int thr, const int* __restrict__ taps) {
+__device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, int cols, int y, int c,
+                                                   const int* __restrict__ taps) {
   constexpr int R = KS / 2;
   int acc[16];
 #pragma unroll
   for (int x = 0; x < 16; ++x) acc[x] = 0;
-  const bool interior = (x0 - R >= 0) && (x0 + 15 + R < cols);
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
-    const int yy = reflect101(y + i - R, rows);
-    const uint8_t* rowp = frame + (size_t)yy * pitch;
+    const int yb = reflect101(y + i - R, rows) - w.ylo;
+    if ((unsigned)yb >= (unsigned)w.H) continue;  // rows outside the band hold no bright pixel
+    const uint4* p = reinterpret_cast<const uint4*>(w.pix + (size_t)yb * w.PW + 16 * (c - 1 - w.pwc0));
+    const uint4 q0 = p[0], q1 = p[1], q2 = p[2];
+    const unsigned q[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
     int t[16 + 2 * R];
-    if (interior) {
 #pragma unroll
-      for (int j = 0; j < 16 + 2 * R; ++j) {
-        const int v = rowp[x0 - R + j];
-        t[j] = v > thr ? v : 0;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16 + 2 * R; ++j) {
-        const int v = rowp[reflect101(x0 - R + j, cols)];
-        t[j] = v > thr ? v : 0;
-      }
+    for (int j = 0; j < 16 + 2 * R; ++j) {
+      const int k = 16 - R + j;
+      t[j] = (int)((q[k >> 2] >> (8 * (k & 3))) & 0xFFu);
     }
     const int ky = taps[i];
 #pragma unroll
@@ -211,25 +200,26 @@ __device__ __forceinline__ unsigned blur_item(const uint8_t* __restrict__ frame,
   unsigned m = 0;
 #pragma unroll
   for (int x = 0; x < 16; ++x)
-    if (acc[x] >= (1 << 15) && x0 + x < cols) m |= 1u << x;
+    if (acc[x] >= (1 << 15)) m |= 1u << x;
   return m;
 }
 
-// any kernel size (sigma up to 6): direct double loop per output pixel
-__device__ __noinline__ unsigned blur_item_generic(const uint8_t* __restrict__ frame, int rows, int cols, int pitch,
-                                                   int y, int x0, int thr, const int* __restrict__ taps, int ks) {
+// any kernel size / image border (BORDER_REFLECT_101 in x): byte-wise from the LDS window
+__device__ __noinline__ unsigned blur_item_generic(const PixWin& w, int rows, int cols, int y, int c,
+                                                   const int* __restrict__ taps, int ks) {
   const int r = ks / 2;
+  const int x0 = 16 * c;
   unsigned m = 0;
   for (int x = 0; x < 16; ++x) {
     if (x0 + x >= cols) break;
     int acc = 0;
     for (int i = 0; i < ks; ++i) {
-      const int yy = reflect101(y + i - r, rows);
-      const uint8_t* rowp = frame + (size_t)yy * pitch;
+      const int yb = reflect101(y + i - r, rows) - w.ylo;
+      if ((unsigned)yb >= (unsigned)w.H) continue;
       int h = 0;
       for (int j = 0; j < ks; ++j) {
-        const int v = rowp[reflect101(x0 + x + j - r, cols)];
-        h += taps[j] * (v > thr ? v : 0);
+        const int so = reflect101(x0 + x + j - r, cols) - 16 * w.pwc0;
+        if ((unsigned)so < (unsigned)w.PW) h += taps[j] * (int)w.pix[(size_t)yb * w.PW + so];
       }
       acc += taps[i] * h;
     }
@@ -238,7 +228,7 @@ __device__ __noinline__ unsigned blur_item_generic(const uint8_t* __restrict__ f
   return m;
 }
 
-// three bits (x-1, x, x+1) of a bitmap row at bit index xb (= x + 1 >= 1)
+// three bits (x-1, x, x+1) of a bitmap row at bit index xb (>= 1)
 __device__ __forceinline__ unsigned bits3(const u64* row, int xb) {
   const int lo = xb - 1, wi = lo >> 6, sh = lo & 63;
   const u64 a = row[wi], b = row[wi + 1];
@@ -299,8 +289,10 @@ __device__ __forceinline__ void set_bit(u64* bm, int wb, int slot, int xb) {
 
 // Suzuki-Abe outer-border following exactly as OpenCV's icvFetchContour (CHAIN_APPROX_NONE):
 // visited pixels are marked "positive" (pm) or, when the east neighbour was examined and is 0,
-// "negative" (ng, takes precedence).  Returns false if the step bound was hit.
-__device__ bool trace_outer_border(const u64* nz, u64* pm, u64* ng, int wb, int slot0, int xb0, int y0, PolyAcc& acc) {
+// "negative" (ng, takes precedence).  (xoff, yoff) turn window coordinates into image
+// coordinates.  Returns false if the step bound was hit.
+__device__ bool trace_outer_border(const u64* nz, u64* pm, u64* ng, int wb, int slot0, int xb0, int xoff, int yoff,
+                                   PolyAcc& acc) {
   acc.init();
   unsigned nb = neighbours(nz, wb, slot0, xb0);
   int s = 4;
@@ -312,13 +304,13 @@ __device__ bool trace_outer_border(const u64* nz, u64* pm, u64* ng, int wb, int 
   } while (!hit && s != s_end0);
   if (s == s_end0) {  // single-pixel component
     set_bit(ng, wb, slot0, xb0);
-    acc.emit(xb0 - 1, y0);
+    acc.emit(xb0 + xoff, slot0 + yoff);
     acc.close();
     return true;
   }
-  const int x1b = xb0 + dir_dx(s), y1 = y0 + dir_dy(s);
-  int xb = xb0, y = y0, slot = slot0;
-  for (int step = 0; step < (1 << 22); ++step) {
+  const int x1b = xb0 + dir_dx(s), s1 = slot0 + dir_dy(s);
+  int xb = xb0, slot = slot0;
+  for (int step = 0; step < (1 << 20); ++step) {
     const int s_end = s;
     const unsigned m16 = nb | (nb << 8);
     const int k = __builtin_ctz(m16 >> (s + 1));
@@ -327,15 +319,14 @@ __device__ bool trace_outer_border(const u64* nz, u64* pm, u64* ng, int wb, int 
       set_bit(ng, wb, slot, xb);
     else
       set_bit(pm, wb, slot, xb);
-    acc.emit(xb - 1, y);
-    const int nxb = xb + dir_dx(sn), ny = y + dir_dy(sn);
-    if (nxb == xb0 && ny == y0 && xb == x1b && y == y1) {
+    acc.emit(xb + xoff, slot + yoff);
+    const int nxb = xb + dir_dx(sn), nslot = slot + dir_dy(sn);
+    if (nxb == xb0 && nslot == slot0 && xb == x1b && slot == s1) {
       acc.close();
       return true;
     }
-    slot += dir_dy(sn);
+    slot = nslot;
     xb = nxb;
-    y = ny;
     s = (sn + 4) & 7;
     nb = neighbours(nz, wb, slot, xb);
   }
@@ -388,222 +379,287 @@ __device__ __forceinline__ bool blob_filter(const BlobRec& b, const DetectParams
 
 __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
                                                FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ BlobRec s_blobs[MPE_MAX_RAW_BLOBS];
-  __shared__ int s_nblobs, s_err;
+  __shared__ __attribute__((aligned(16))) uint8_t s_pix[K1B_PIX_CAP];
+  __shared__ u64 s_nz[K1B_BM_CAP], s_pm[K1B_BM_CAP], s_ng[K1B_BM_CAP];
+  __shared__ unsigned s_seg[K1B_SEG_CAP];  // y << 16 | segment column
+  __shared__ u64 s_rowact[64];
+  __shared__ u64 s_colocc[4];
+  __shared__ float s_kx[K1B_KEPT_CAP], s_ky[K1B_KEPT_CAP];
+  __shared__ unsigned s_kkey[K1B_KEPT_CAP];
+  __shared__ int s_nseg, s_nkept, s_over;
 
   const int lane = threadIdx.x;
   const int f = blockIdx.x;
   const uint8_t* frame = frames + (size_t)f * g.rows * g.pitch;
   mpe_detections* out = dets + f;
-
-  // LDS carve-up
-  const size_t bm_words = (size_t)g.slot_cap * g.wb;
-  u64* nz = reinterpret_cast<u64*>(smem);
-  u64* pm = nz + bm_words;
-  u64* ng = pm + bm_words;
-  u64* todo = ng + bm_words;
-  u64* rowact = todo + (size_t)g.slot_cap * g.tw;
-  u64* rowstart = rowact + g.rw;
-  u64* wordmask = rowstart + g.rw;
-  const int wm_words = (int)((bm_words + 63) / 64) + 1;
-  unsigned* rowpre = reinterpret_cast<unsigned*>(wordmask + wm_words);
-  unsigned* bandpre = rowpre + g.rw;
-
   const int r = dp.ksize / 2;
   const int dc = (r + 15) / 16;  // segment columns a bright segment can influence on each side
-  const size_t G0 = (size_t)f * g.segs_per_frame;
+  const int spr = g.segs_per_row;
+  const unsigned add = (unsigned)(255 - dp.thr) * 0x00010001u;
 
-  for (int i = lane; i < g.rw; i += 64) rowact[i] = 0;
+  s_rowact[lane] = 0;
   if (lane == 0) {
-    s_nblobs = 0;
-    s_err = 0;
+    s_nseg = 0;
+    s_nkept = 0;
+    s_over = 0;
   }
   __syncthreads();
 
-  // ---- A: rows within +-r of a bright segment become active
-  for_each_bright_seg(flags, G0, g.segs_per_frame, lane, [&](int s) {
-    const int y0 = s / g.segs_per_row;
-    lds_set_range(rowact, max(0, y0 - r), min(g.rows - 1, y0 + r));
-  });
-  __syncthreads();
-
-  // ---- B: rank / band prefix sums (rw <= 64 words: one per lane)
-  int n_active, n_bands;
+  // ---- A: bright segments of this frame -> LDS list; rows within +-r become active
   {
-    const u64 act = (lane < g.rw) ? rowact[lane] : 0;
-    const u64 prevw = (lane > 0 && lane < g.rw) ? rowact[lane - 1] : 0;
-    const u64 st = act & ~((act << 1) | (prevw >> 63));
-    const int ca = __builtin_popcountll(act), cs = __builtin_popcountll(st);
-    int pa = ca, ps = cs;
+    const size_t G0 = (size_t)f * g.segs_per_frame;
+    const int nwin = (g.segs_per_frame + 63) >> 6;
+    const size_t w0 = G0 >> 6;
+    const int sh = (int)(G0 & 63);
+    for (int i0 = 0; i0 < nwin; i0 += 256) {  // four independent flag loads per lane in flight
+      u64 v[4];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int ta = __shfl_up(pa, d), ts = __shfl_up(ps, d);
-      if (lane >= d) {
-        pa += ta;
-        ps += ts;
+      for (int k = 0; k < 4; ++k) {
+        const int i = i0 + 64 * k + lane;
+        v[k] = 0;
+        if (i < nwin) {
+          const u64 a = flags[w0 + i], b = flags[w0 + i + 1];
+          v[k] = sh ? ((a >> sh) | (b << (64 - sh))) : a;
+          const int rem = g.segs_per_frame - i * 64;
+          if (rem < 64) v[k] &= (1ull << rem) - 1;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        u64 vv = v[k];
+        const int i = i0 + 64 * k + lane;
+        while (vv) {
+          const int s = i * 64 + __builtin_ctzll(vv);
+          vv &= vv - 1;
+          const int y0 = s / spr, c0 = s - y0 * spr;
+          const int slot = atomicAdd(&s_nseg, 1);
+          if (slot < K1B_SEG_CAP) s_seg[slot] = ((unsigned)y0 << 16) | (unsigned)c0;
+          lds_set_range(s_rowact, max(0, y0 - r), min(g.rows - 1, y0 + r));
+        }
       }
     }
-    if (lane < g.rw) {
-      rowpre[lane] = (unsigned)(pa - ca);
-      bandpre[lane] = (unsigned)(ps - cs);
-      rowstart[lane] = st;
-    }
-    n_active = __shfl(pa, 63);
-    n_bands = __shfl(ps, 63);
   }
-  const int nslots = n_active + n_bands + 1;  // separator rows included
-  if (n_active == 0 || nslots > g.slot_cap) {
+  __syncthreads();
+  const int nseg_all = s_nseg;
+  if (nseg_all == 0 || nseg_all > K1B_SEG_CAP) {
     if (lane == 0) {
       out->n = 0;
-      out->status = (n_active == 0) ? 0 : MPE_FRAME_TOO_MANY_ROWS;
+      out->status = nseg_all == 0 ? 0 : MPE_FRAME_TOO_MANY_ROWS;
     }
     return;
   }
-  __syncthreads();
-  const RowMap rm = {rowact, rowstart, rowpre, bandpre};
+  const int nseg = nseg_all;
 
-  // ---- C: clear the bitmaps of the slots in use
-  for (int i = lane; i < nslots * g.wb; i += 64) {
-    nz[i] = 0;
-    pm[i] = 0;
-    ng[i] = 0;
-  }
-  for (int i = lane; i < nslots * g.tw; i += 64) todo[i] = 0;
-  __syncthreads();
-
-  // ---- D: output segments that can be non-zero after the blur
-  for_each_bright_seg(flags, G0, g.segs_per_frame, lane, [&](int s) {
-    const int y0 = s / g.segs_per_row, c0 = s - y0 * g.segs_per_row;
-    const int ylo = max(0, y0 - r), yhi = min(g.rows - 1, y0 + r);
-    const int clo = max(0, c0 - dc), chi = min(g.segs_per_row - 1, c0 + dc);
-    const int slo = rm.slot(ylo);  // rows ylo..yhi are all active and contiguous -> consecutive slots
-    for (int yy = ylo; yy <= yhi; ++yy)
-      for (int cc = clo; cc <= chi; ++cc) atomicOr(&todo[(size_t)(slo + yy - ylo) * g.tw + (cc >> 6)], 1ull << (cc & 63));
-  });
-  __syncthreads();
-
-  // ---- E/F: blur mask of the todo segments (lane owns rows y = lane mod 64)
-  for (int y = lane; y < g.rows; y += 64) {
-    if (!rm.active(y)) continue;
-    const int sl = rm.slot(y);
-    for (int tw = 0; tw < g.tw; ++tw) {
-      u64 tb = todo[(size_t)sl * g.tw + tw];
-      while (tb) {
-        const int c = tw * 64 + __builtin_ctzll(tb);
-        tb &= tb - 1;
-        const int x0 = c * 16;
-        if (x0 >= g.cols) continue;
-        unsigned m;
-        if (dp.ksize == 5)
-          m = blur_item<5>(frame, g.rows, g.cols, g.pitch, y, x0, dp.thr, dp.taps);
-        else if (dp.ksize == 3)
-          m = blur_item<3>(frame, g.rows, g.cols, g.pitch, y, x0, dp.thr, dp.taps);
-        else
-          m = blur_item_generic(frame, g.rows, g.cols, g.pitch, y, x0, dp.thr, dp.taps, dp.ksize);
-        if (m) {
-          const int xb0 = x0 + 1, wi = xb0 >> 6, sh = xb0 & 63;
-          atomicOr(&nz[(size_t)sl * g.wb + wi], (u64)m << sh);
-          if (sh > 48) atomicOr(&nz[(size_t)sl * g.wb + wi + 1], (u64)m >> (64 - sh));
+  // ---- B: bands (maximal runs of active rows), then islands (runs of occupied segment columns)
+  for (int rwi = 0; rwi < g.rw; ++rwi) {
+    u64 act = s_rowact[rwi];
+    while (act) {
+      // band start inside this word (or continuing from the previous one is handled below)
+      const int b0 = __builtin_ctzll(act);
+      int ylo = rwi * 64 + b0;
+      // extend downwards across words
+      int yhi = ylo;
+      {
+        int wi = rwi;
+        u64 run = act >> b0;  // bit 0 = row ylo
+        int base = ylo;
+        for (;;) {
+          const u64 inv = ~run;
+          const int len = inv ? __builtin_ctzll(inv) : 64;
+          const int avail = 64 - (base & 63);
+          if (len < avail) {
+            yhi = base + len - 1;
+            break;
+          }
+          // run reaches the end of this word: continue in the next one
+          yhi = base + avail - 1;
+          ++wi;
+          if (wi >= g.rw) break;
+          run = s_rowact[wi];
+          base = wi * 64;
+          if (!(run & 1)) break;
         }
+      }
+      // clear the band's bits in the loop state (only those inside word rwi matter for `act`)
+      {
+        const int end_in_word = min(yhi, rwi * 64 + 63) - rwi * 64;
+        const u64 m = (end_in_word == 63 ? ~0ull : ((2ull << end_in_word) - 1)) & (~0ull << b0);
+        act &= ~m;
+      }
+      const bool crosses = yhi > rwi * 64 + 63;
+
+      // segment-column occupancy of the band
+      if (lane < 4) s_colocc[lane] = 0;
+      __syncthreads();
+      for (int i = lane; i < nseg; i += 64) {
+        const unsigned sg = s_seg[i];
+        const int y = (int)(sg >> 16), c = (int)(sg & 0xFFFF);
+        if (y >= ylo && y <= yhi) atomicOr(&s_colocc[c >> 6], 1ull << (c & 63));
+      }
+      __syncthreads();
+
+      // islands: runs of set bits in the occupancy dilated by dc
+      for (int cstart = 0; cstart < spr;) {
+        // find next occupied column >= cstart
+        int cfirst = -1;
+        for (int wi = cstart >> 6; wi < 4 && wi * 64 < spr; ++wi) {
+          u64 w = s_colocc[wi];
+          if (wi == (cstart >> 6)) w &= ~0ull << (cstart & 63);
+          if (w) {
+            cfirst = wi * 64 + __builtin_ctzll(w);
+            break;
+          }
+        }
+        if (cfirst < 0) break;
+        // extend while the gap to the next occupied column is <= 2*dc (dilated runs touch)
+        int clast = cfirst;
+        for (;;) {
+          int nxt = -1;
+          for (int c = clast + 1; c <= min(spr - 1, clast + 2 * dc + 1); ++c)
+            if ((s_colocc[c >> 6] >> (c & 63)) & 1) {
+              nxt = c;
+              break;
+            }
+          if (nxt < 0) break;
+          clast = nxt;
+        }
+        cstart = clast + 2 * dc + 2;
+        const int clo = max(0, cfirst - dc), chi = min(spr - 1, clast + dc);  // output segment columns
+
+        // ---- island window
+        const int H = yhi - ylo + 1, S = H + 2;
+        const int xw0 = 16 * clo;
+        const int xhi = min(g.cols - 1, 16 * chi + 15);
+        const int W = ((xhi - xw0 + 1) + 2 + 63) / 64 + 1;
+        const int pwc0 = clo - 1, nps = chi - clo + 3, PW = 16 * nps;
+        if (S * W > K1B_BM_CAP || H * PW > K1B_PIX_CAP) {
+          if (lane == 0) s_over = 1;
+          continue;
+        }
+        for (int i = lane; i < S * W; i += 64) {
+          s_nz[i] = 0;
+          s_pm[i] = 0;
+          s_ng[i] = 0;
+        }
+        // stage the thresholded pixels (coalesced 16-byte loads)
+        for (int i = lane; i < H * nps; i += 64) {
+          const int yb = i / nps, sc = i - yb * nps;
+          const int cg = pwc0 + sc;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (cg >= 0 && cg < spr) {
+            v = *reinterpret_cast<const uint4*>(frame + (size_t)(ylo + yb) * g.pitch + 16 * cg);
+            v.x = tozero4(v.x, add);
+            v.y = tozero4(v.y, add);
+            v.z = tozero4(v.z, add);
+            v.w = tozero4(v.w, add);
+          }
+          *reinterpret_cast<uint4*>(s_pix + (size_t)yb * PW + 16 * sc) = v;
+        }
+        __syncthreads();
+        // blurred mask
+        const PixWin pw = {s_pix, ylo, H, pwc0, PW};
+        const int ncols = chi - clo + 1;
+        for (int i = lane; i < H * ncols; i += 64) {
+          const int yb = i / ncols, c = clo + (i - yb * ncols);
+          const int x0 = 16 * c;
+          if (x0 >= g.cols) continue;
+          unsigned m;
+          const bool interior = (x0 - r >= 0) && (x0 + 15 + r < g.cols);
+          if (interior && dp.ksize == 5)
+            m = blur_item_fast<5>(pw, g.rows, g.cols, ylo + yb, c, dp.taps);
+          else if (interior && dp.ksize == 3)
+            m = blur_item_fast<3>(pw, g.rows, g.cols, ylo + yb, c, dp.taps);
+          else
+            m = blur_item_generic(pw, g.rows, g.cols, ylo + yb, c, dp.taps, dp.ksize);
+          if (m) {
+            const int xb0 = x0 - xw0 + 1, wi = xb0 >> 6, shb = xb0 & 63;
+            atomicOr(&s_nz[(size_t)(yb + 1) * W + wi], (u64)m << shb);
+            if (shb > 48) atomicOr(&s_nz[(size_t)(yb + 1) * W + wi + 1], (u64)m >> (64 - shb));
+          }
+        }
+        __syncthreads();
+
+        // ---- OpenCV's raster scan for external contours (cvFindNextContour, RETR_EXTERNAL);
+        //      sequential by construction: lane 0 walks the island's bitmap rows in raster order
+        if (lane == 0) {
+          int nk = s_nkept;
+          for (int slot = 1; slot <= H; ++slot) {
+            u64* nzrow = s_nz + (size_t)slot * W;
+            u64* pmrow = s_pm + (size_t)slot * W;
+            u64* ngrow = s_ng + (size_t)slot * W;
+            int last_sign = 0;  // sign of the nearest marked pixel to the left (lnbd), 0 = none yet
+            for (int w = 0; w < W - 1; ++w) {
+              const u64 nzw = nzrow[w];
+              if (!nzw) continue;
+              const u64 leftnz = (nzw << 1) | (w ? (nzrow[w - 1] >> 63) : 0);
+              u64 done = 0;
+              for (;;) {
+                const u64 pw_ = pmrow[w], gw = ngrow[w];
+                const u64 cand = nzw & ~(pw_ | gw) & ~leftnz & ~done;  // unmarked 1 with a 0 on its left
+                if (!cand) break;
+                const int bb = __builtin_ctzll(cand);
+                done |= (bb == 63) ? ~0ull : ((2ull << bb) - 1);
+                const u64 below = (pw_ | gw) & ((1ull << bb) - 1);
+                int sign = last_sign;
+                if (below) {
+                  const int hb = 63 - __builtin_clzll(below);
+                  sign = ((gw >> hb) & 1) ? -1 : 1;
+                }
+                if (sign > 0) continue;  // inside an already traced outer border: not external
+                PolyAcc acc;
+                const int xb = w * 64 + bb;
+                if (!trace_outer_border(s_nz, s_pm, s_ng, W, slot, xb, xw0 - 1, ylo - 1, acc)) s_over = 1;
+                BlobRec br;
+                br.a00 = acc.a00;
+                br.a10 = acc.a10;
+                br.a01 = acc.a01;
+                br.xmin = acc.xmin;
+                br.xmax = acc.xmax;
+                br.ymin = acc.ymin;
+                br.ymax = acc.ymax;
+                float mcx, mcy;
+                if (blob_filter(br, dp, mcx, mcy)) {
+                  if (nk < K1B_KEPT_CAP) {
+                    s_kx[nk] = mcx;
+                    s_ky[nk] = mcy;
+                    s_kkey[nk] = ((unsigned)(ylo + slot - 1) << 12) | (unsigned)(xb + xw0 - 1);
+                  }
+                  ++nk;
+                }
+              }
+              const u64 mk = pmrow[w] | ngrow[w];
+              if (mk) {
+                const int hb = 63 - __builtin_clzll(mk);
+                last_sign = ((ngrow[w] >> hb) & 1) ? -1 : 1;
+              }
+            }
+          }
+          s_nkept = nk;
+        }
+        __syncthreads();
+      }  // islands
+      if (crosses) {
+        // the band continued into later words: drop its rows from them so they are not revisited
+        for (int wi = rwi + 1; wi <= (yhi >> 6) && wi < g.rw; ++wi) {
+          const int last = min(yhi, wi * 64 + 63) - wi * 64;
+          const u64 m = last == 63 ? ~0ull : ((2ull << last) - 1);
+          if (lane == 0) s_rowact[wi] &= ~m;
+        }
+        __syncthreads();
       }
     }
   }
-  __syncthreads();
 
-  // ---- G: which bitmap words are non-zero (raster order = index order)
-  {
-    const int total = nslots * g.wb;
-    for (int k = 0; k * 64 < total + 64; ++k) {
-      const int idx = k * 64 + lane;
-      const u64 b = __ballot(idx < total && nz[idx] != 0);
-      if (lane == 0) wordmask[k] = b;
-    }
-  }
-  __syncthreads();
-
-  // ---- H: OpenCV's raster scan for external contours (cvFindNextContour, mode RETR_EXTERNAL),
-  //         sequential by construction: lane 0 walks the non-zero words in raster order.
-  if (lane == 0) {
-    int nb = 0, err = 0;
-    int slot = -1;
-    for (int rwi = 0; rwi < g.rw; ++rwi) {
-      u64 act = rowact[rwi];
-      const u64 st = rowstart[rwi];
-      while (act) {
-        const int b = __builtin_ctzll(act);
-        act &= act - 1;
-        const int y = rwi * 64 + b;
-        slot += ((st >> b) & 1) ? 2 : 1;
-        // non-zero words of this bitmap row
-        const size_t bitpos = (size_t)slot * g.wb;
-        const int wi = (int)(bitpos >> 6), sh = (int)(bitpos & 63);
-        u64 wm = sh ? ((wordmask[wi] >> sh) | (wordmask[wi + 1] << (64 - sh))) : wordmask[wi];
-        if (g.wb < 64) wm &= (1ull << g.wb) - 1;
-        int last_sign = 0;  // sign of the nearest marked pixel to the left (lnbd), 0 = none yet
-        u64* nzrow = nz + (size_t)slot * g.wb;
-        u64* pmrow = pm + (size_t)slot * g.wb;
-        u64* ngrow = ng + (size_t)slot * g.wb;
-        while (wm) {
-          const int w = __builtin_ctzll(wm);
-          wm &= wm - 1;
-          const u64 nzw = nzrow[w];
-          const u64 leftnz = (nzw << 1) | (w ? (nzrow[w - 1] >> 63) : 0);
-          u64 done = 0;
-          for (;;) {
-            const u64 pw = pmrow[w], gw = ngrow[w];
-            const u64 cand = nzw & ~(pw | gw) & ~leftnz & ~done;  // unmarked 1 with a 0 to its left
-            if (!cand) break;
-            const int bb = __builtin_ctzll(cand);
-            done |= (bb == 63) ? ~0ull : ((2ull << bb) - 1);
-            const u64 below = (pw | gw) & ((1ull << bb) - 1);
-            int sign = last_sign;
-            if (below) {
-              const int hb = 63 - __builtin_clzll(below);
-              sign = ((gw >> hb) & 1) ? -1 : 1;
-            }
-            if (sign > 0) continue;  // inside an already traced outer border: not external
-            PolyAcc acc;
-            if (!trace_outer_border(nz, pm, ng, g.wb, slot, w * 64 + bb, y, acc)) err = 1;
-            if (nb < MPE_MAX_RAW_BLOBS) {
-              BlobRec br;
-              br.a00 = acc.a00;
-              br.a10 = acc.a10;
-              br.a01 = acc.a01;
-              br.xmin = acc.xmin;
-              br.xmax = acc.xmax;
-              br.ymin = acc.ymin;
-              br.ymax = acc.ymax;
-              s_blobs[nb] = br;
-            }
-            ++nb;
-          }
-          const u64 mk = pmrow[w] | ngrow[w];
-          if (mk) {
-            const int hb = 63 - __builtin_clzll(mk);
-            last_sign = ((ngrow[w] >> hb) & 1) ? -1 : 1;
-          }
-        }
-      }
-    }
-    s_nblobs = nb;
-    s_err = err;
-  }
-  __syncthreads();
-
-  // ---- I: shape filter, float32 centroid, undistort; output order = OpenCV's contour order
-  //         (newest contour first, i.e. reverse discovery order)
-  const int nb_all = s_nblobs;
-  const int nb = min(nb_all, MPE_MAX_RAW_BLOBS);
-  int kept = 0;
-  for (int base = ((nb - 1) / 64) * 64; base >= 0 && nb > 0; base -= 64) {
-    const int i = base + (63 - lane);
-    float mcx = 0.f, mcy = 0.f;
-    bool ok = false;
-    if (i < nb) ok = blob_filter(s_blobs[i], dp, mcx, mcy);
-    const u64 bal = __ballot(ok);
-    const int pos = kept + __builtin_popcountll(bal & ((1ull << lane) - 1));
-    if (ok && pos < MPE_MAX_DETECTIONS) {
+  // ---- C: output in OpenCV's contour order (newest first = descending raster order of the
+  //         start pixel), float32 centroid -> undistortPoints
+  const int nk_all = s_nkept;
+  const int nk = min(nk_all, K1B_KEPT_CAP);
+  if (lane < nk) {
+    const unsigned key = s_kkey[lane];
+    int pos = 0;
+    for (int j = 0; j < nk; ++j) pos += (s_kkey[j] > key) ? 1 : 0;
+    if (pos < MPE_MAX_DETECTIONS) {
+      const float mcx = s_kx[lane], mcy = s_ky[lane];
       float ux, uy;
       undistort_point(mcx, mcy, dp, ux, uy);
       out->dist_xy[2 * pos] = mcx;
@@ -611,36 +667,22 @@ __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ fram
       out->undist_xy[2 * pos] = (double)ux;
       out->undist_xy[2 * pos + 1] = (double)uy;
     }
-    kept += __builtin_popcountll(bal);
   }
   if (lane == 0) {
-    out->n = min(kept, MPE_MAX_DETECTIONS);
+    out->n = min(nk_all, MPE_MAX_DETECTIONS);
     int st = 0;
-    if (kept > MPE_MAX_DETECTIONS) st = MPE_FRAME_TOO_MANY_DETECTIONS;
-    if (nb_all > MPE_MAX_RAW_BLOBS || s_err) st = MPE_FRAME_TOO_MANY_BLOBS;
+    if (nk_all > MPE_MAX_DETECTIONS) st = MPE_FRAME_TOO_MANY_DETECTIONS;
+    if (s_over) st = MPE_FRAME_TOO_MANY_ROWS;
     out->status = st;
   }
 }
 
-size_t k1b_lds_bytes(const FrameGeom& g) {
-  const size_t bm_words = (size_t)g.slot_cap * g.wb;
-  const size_t wm_words = (bm_words + 63) / 64 + 1;
-  size_t words = 3 * bm_words + (size_t)g.slot_cap * g.tw + 2 * (size_t)g.rw + wm_words;
-  return words * 8 + 2 * (size_t)g.rw * 4 + 16;
-}
+size_t k1b_lds_bytes(const FrameGeom&) { return 0; }
 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, hipStream_t s) {
   if (n_frames <= 0) return hipSuccess;
-  const size_t lds = k1b_lds_bytes(g);
-  static size_t configured = 0;
-  if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1b_blobs),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = lds;
-  }
-  hipLaunchKernelGGL(k1b_blobs, dim3(n_frames), dim3(64), lds, s, frames, (const u64*)flags, g, dp, dets);
+  hipLaunchKernelGGL(k1b_blobs, dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets);
   return hipGetLastError();
 }
 
@@ -671,6 +713,9 @@ __device__ __forceinline__ V3 bearing(double u, double v, double fx, double fy, 
   return vdiv(s, norm(s));
 }
 
+__device__ __forceinline__ double pick_root(const P3PCtx& c, int k) {
+  return k == 0 ? c.root[0] : (k == 1 ? c.root[1] : (k == 2 ? c.root[2] : c.root[3]));
+}
 #define K2_THREADS 256
 __global__ __launch_bounds__(K2_THREADS) void k2_vote(const mpe_detections* __restrict__ dets, SolveParams sp,
                                                       uint32_t* __restrict__ hist, int splits) {
@@ -686,7 +731,8 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote(const mpe_detections* __re
   const int n_d = d->n, n_m = sp.n_markers;
   if (n_d < 4 || d->status != 0 || n_m < 4) return;  // min_num_leds_detected_ (pose_estimator.h:78)
 
-  for (int i = tid; i < MPE_HIST_STRIDE; i += K2_THREADS) s_hist[i] = 0;
+  const int nthr = blockDim.x;
+  for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) s_hist[i] = 0;
   if (tid < n_d) {
     const double u = d->undist_xy[2 * tid], v = d->undist_xy[2 * tid + 1];
     s_px[tid][0] = u;
@@ -710,7 +756,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote(const mpe_detections* __re
   const long long total = (long long)n_combos * n_perms;
   const int nuo = n_m - 3;
 
-  for (long long t = (long long)part * K2_THREADS + tid; t < total; t += (long long)splits * K2_THREADS) {
+  for (long long t = (long long)part * nthr + tid; t < total; t += (long long)splits * nthr) {
     const int ci = (int)(t / n_perms), pj = (int)(t - (long long)ci * n_perms);
     int c0, c1, c2;
     unrank_combo3(ci, n_d, c0, c1, c2);
@@ -736,7 +782,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote(const mpe_detections* __re
     for (int k = 0; k < 4; ++k) {
       M3 R;
       V3 C;
-      p3p_solution(ctx, ctx.root[k], R, C);
+      p3p_solution(ctx, pick_root(ctx, k), R, C);
       if (!rc_finite(R, C)) continue;
       const Proj P = make_projection(R, C, sp.fx, sp.fy, sp.cx, sp.cy);
       // back-project the unused markers (ascending marker index)
@@ -745,8 +791,8 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote(const mpe_detections* __re
         if (m == p0 || m == p1 || m == p2) continue;
         double u, v;
         project(P, V3{s_mk[m][0], s_mk[m][1], s_mk[m][2]}, u, v);
-        s_q[(2 * j) * K2_THREADS + tid] = u;
-        s_q[(2 * j + 1) * K2_THREADS + tid] = v;
+        s_q[(2 * j) * nthr + tid] = u;
+        s_q[(2 * j + 1) * nthr + tid] = v;
         ++j;
       }
       // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
@@ -757,7 +803,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote(const mpe_detections* __re
         double best = INFINITY;
         int bj = 0;
         for (int jj = 0; jj < nuo; ++jj) {
-          const double du = au - s_q[(2 * jj) * K2_THREADS + tid], dv = av - s_q[(2 * jj + 1) * K2_THREADS + tid];
+          const double du = au - s_q[(2 * jj) * nthr + tid], dv = av - s_q[(2 * jj + 1) * nthr + tid];
           const double d2 = du * du + dv * dv;
           if (d2 < best) {
             best = d2;
@@ -787,19 +833,34 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote(const mpe_detections* __re
   }
   __syncthreads();
   uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
-  for (int i = tid; i < MPE_HIST_STRIDE; i += K2_THREADS) {
+  for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) {
     const unsigned v = s_hist[i];
     if (v) atomicAdd(&gh[i], v);
   }
 }
 
 hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist, int splits,
-                          hipStream_t s) {
+                          int n_det_hint, hipStream_t s) {
   if (n_frames <= 0) return hipSuccess;
   if (splits < 1) splits = 1;
   const int nuo = sp.n_markers > 3 ? sp.n_markers - 3 : 1;
-  const size_t lds = (size_t)nuo * 2 * K2_THREADS * sizeof(double);
-  hipLaunchKernelGGL(k2_vote, dim3((unsigned)(n_frames * splits)), dim3(K2_THREADS), lds, s, dets, sp, hist, splits);
+  // block size: the multiple of 64 (<= 256) that wastes the fewest lanes on the expected item count
+  int threads = K2_THREADS;
+  if (n_det_hint >= 4) {
+    const long long nm = sp.n_markers;
+    const long long items = (long long)n_det_hint * (n_det_hint - 1) * (n_det_hint - 2) / 6 * nm * (nm - 1) * (nm - 2);
+    double best = 1e30;
+    for (int t = 64; t <= K2_THREADS; t += 64) {
+      const long long per = (items + (long long)splits * t - 1) / ((long long)splits * t);
+      const double waste = (double)(per * splits * t) / (double)items + 0.002 * (K2_THREADS / t);
+      if (waste < best - 1e-9) {
+        best = waste;
+        threads = t;
+      }
+    }
+  }
+  const size_t lds = (size_t)nuo * 2 * threads * sizeof(double);
+  hipLaunchKernelGGL(k2_vote, dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, hist, splits);
   return hipGetLastError();
 }
 
@@ -934,173 +995,238 @@ __device__ __forceinline__ void apply_exp(const double tw[6], T34& T) {
   T = N;
 }
 
-#define K3_THREADS 64
-__global__ __launch_bounds__(K3_THREADS) void k3_tail(const mpe_detections* __restrict__ dets,
-                                                      const uint32_t* __restrict__ hist, int n_frames,
-                                                      SolveParams sp, mpe_result* __restrict__ results,
-                                                      uint32_t* __restrict__ corr_out) {
-  const int f = blockIdx.x * K3_THREADS + threadIdx.x;
-  if (f >= n_frames) return;
-  const mpe_detections* d = dets + f;
-  mpe_result* res = results + f;
-  const int n_d = d->n, n_m = sp.n_markers;
-  const uint32_t* H = hist + (size_t)f * MPE_HIST_STRIDE;
+#define K3_GROUP 16                 // lanes cooperating on one frame
+#define K3_FRAMES_PER_BLOCK 4       // one wave = 4 frames
+#define K3_NU_MAX (MPE_MAX_MARKERS - 3)
+
+// butterfly sum over the 16 lanes of a group; every lane ends with the same total
+__device__ __forceinline__ double group_sum(double v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__ dets,
+                                              const uint32_t* __restrict__ hist, int n_frames, SolveParams sp,
+                                              mpe_result* __restrict__ results, uint32_t* __restrict__ corr_out) {
+  __shared__ double s_part[K3_FRAMES_PER_BLOCK][K3_GROUP][MPE_MAX_MARKERS * 3];
+  __shared__ double s_mean[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS * 3];
+  __shared__ double s_q[2 * K3_NU_MAX][64];  // back-projections, [2*j + {0,1}][lane]
+  __shared__ double s_det[K3_FRAMES_PER_BLOCK][MPE_MAX_DETECTIONS][2];
+  __shared__ double s_mk[MPE_MAX_MARKERS][3];
+  __shared__ unsigned s_valid[K3_FRAMES_PER_BLOCK][K3_GROUP];
+  __shared__ unsigned char s_cm[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS], s_cd[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS];
+  __shared__ int s_nc[K3_FRAMES_PER_BLOCK];
+
+  const int tid = threadIdx.x;
+  const int grp = tid >> 4, l = tid & 15;
+  const int f = blockIdx.x * K3_FRAMES_PER_BLOCK + grp;
+  const bool live = f < n_frames;
+  const mpe_detections* d = dets + (live ? f : 0);
+  mpe_result* res = results + (live ? f : 0);
+  const int n_d = live ? d->n : 0, n_m = sp.n_markers;
+  const int dstatus = live ? d->status : 0;
+  const uint32_t* H = hist + (size_t)(live ? f : 0) * MPE_HIST_STRIDE;
   const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
 
-  // default output: identity pose, zero covariance, no pose
-  for (int i = 0; i < 16; ++i) res->T[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  for (int i = 0; i < 36; ++i) res->cov[i] = 0.0;
-  res->n_det = n_d;
-  res->n_corr = 0;
-  res->gn_iterations = 0;
-  res->status = (d->status != 0) ? d->status : MPE_FRAME_NO_POSE;
-  if (corr_out)
-    for (int i = 0; i < 2 * MPE_MAX_MARKERS; ++i) corr_out[(size_t)f * 2 * MPE_MAX_MARKERS + i] = 0;
-  if (d->status != 0 || n_d < 4 || n_m < 4) return;
-
-  // ---- initialise(): all-zero histogram -> 0   (pose_estimator.cpp:704)
-  bool any = false;
-  for (int r = 0; r < n_d; ++r)
-    for (int c = 0; c < n_m; ++c) any |= (H[r * MPE_MAX_MARKERS + c] != 0);
-  if (!any) return;
-
-  // ---- correspondencesFromHistogram (pose_estimator.cpp:344-370)
-  unsigned char cm[MPE_MAX_MARKERS], cd[MPE_MAX_MARKERS];  // 1-based (marker, detection)
-  int n_c = 0;
-  unsigned removed = 0;  // zeroed columns
-  for (int j = 0; j < n_m; ++j) {
-    unsigned mv = 0;
-    int ri = 0, ci = 0;
-    bool first = true;
-    for (int c = 0; c < n_m; ++c)
-      for (int r = 0; r < n_d; ++r) {
-        const unsigned v = ((removed >> c) & 1) ? 0u : H[r * MPE_MAX_MARKERS + c];
-        if (first || v > mv) {
-          mv = v;
-          ri = r;
-          ci = c;
-          first = false;
-        }
-      }
-    if (mv < sp.hist_thr) break;
-    cm[n_c] = (unsigned char)(ci + 1);
-    cd[n_c] = (unsigned char)(ri + 1);
-    ++n_c;
-    removed |= 1u << ci;
+  // stage markers and detections in LDS; default output = identity pose, zero covariance
+  if (tid < n_m) {
+    s_mk[tid][0] = sp.markers[3 * tid];
+    s_mk[tid][1] = sp.markers[3 * tid + 1];
+    s_mk[tid][2] = sp.markers[3 * tid + 2];
   }
-  res->n_corr = n_c;
-  if (corr_out)
-    for (int i = 0; i < n_c; ++i) {
-      corr_out[(size_t)f * 2 * MPE_MAX_MARKERS + 2 * i] = cm[i];
-      corr_out[(size_t)f * 2 * MPE_MAX_MARKERS + 2 * i + 1] = cd[i];
-    }
+  for (int i = l; i < n_d; i += K3_GROUP) {
+    s_det[grp][i][0] = d->undist_xy[2 * i];
+    s_det[grp][i][1] = d->undist_xy[2 * i + 1];
+  }
+  if (live) {
+    for (int i = l; i < 16; i += K3_GROUP) res->T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int i = l; i < 36; i += K3_GROUP) res->cov[i] = 0.0;
+    if (corr_out)
+      for (int i = l; i < 2 * MPE_MAX_MARKERS; i += K3_GROUP) corr_out[(size_t)f * 2 * MPE_MAX_MARKERS + i] = 0;
+  }
+  for (int i = 0; i < 3 * MPE_MAX_MARKERS; ++i) s_part[grp][l][i] = 0.0;
 
-  // ---- checkCorrespondences (pose_estimator.cpp:394-542)
-  if (n_c < 4) return;
-  double mean[MPE_MAX_MARKERS][3];
-  for (int i = 0; i < n_m; ++i) mean[i][0] = mean[i][1] = mean[i][2] = 0.0;
-  const int nu = n_c - 3;
-  unsigned N = 0, num_valid = 0;
-  for (int a = 0; a < n_c; ++a)
-    for (int b = a + 1; b < n_c; ++b)
-      for (int c = b + 1; c < n_c; ++c) {
-        ++N;
-        const int rows3[3] = {a, b, c};
-        V3 fv[3], wp[3];
-        for (int k = 0; k < 3; ++k) {
-          const int mi = cm[rows3[k]] - 1, di = cd[rows3[k]] - 1;
-          wp[k] = {sp.markers[3 * mi], sp.markers[3 * mi + 1], sp.markers[3 * mi + 2]};
-          fv[k] = bearing(d->undist_xy[2 * di], d->undist_xy[2 * di + 1], fx, fy, cx, cy);
+  // ---- lane 0 of the group: initialise()'s all-zero test (pose_estimator.cpp:704) and
+  //      correspondencesFromHistogram (pose_estimator.cpp:344-370)
+  if (l == 0) {
+    int n_c = 0;
+    bool go0 = live && dstatus == 0 && n_d >= 4 && n_m >= 4;
+    if (go0) {
+      bool any = false;
+      for (int r = 0; r < n_d; ++r)
+        for (int c = 0; c < n_m; ++c) any |= (H[r * MPE_MAX_MARKERS + c] != 0);
+      go0 = any;
+    }
+    if (go0) {
+      unsigned removed = 0;  // zeroed columns
+      for (int j = 0; j < n_m; ++j) {
+        unsigned mv = 0;
+        int ri = 0, ci = 0;
+        bool first = true;
+        for (int c = 0; c < n_m; ++c)
+          for (int r = 0; r < n_d; ++r) {
+            const unsigned v = ((removed >> c) & 1) ? 0u : H[r * MPE_MAX_MARKERS + c];
+            if (first || v > mv) {
+              mv = v;
+              ri = r;
+              ci = c;
+              first = false;
+            }
+          }
+        if (mv < sp.hist_thr) break;
+        s_cm[grp][n_c] = (unsigned char)(ci + 1);
+        s_cd[grp][n_c] = (unsigned char)(ri + 1);
+        ++n_c;
+        removed |= 1u << ci;
+      }
+    }
+    s_nc[grp] = n_c;
+    if (live) {
+      res->n_det = n_d;
+      res->n_corr = n_c;
+      res->gn_iterations = 0;
+      res->status = (dstatus != 0) ? dstatus : MPE_FRAME_NO_POSE;
+      if (corr_out)
+        for (int i = 0; i < n_c; ++i) {
+          corr_out[(size_t)f * 2 * MPE_MAX_MARKERS + 2 * i] = s_cm[grp][i];
+          corr_out[(size_t)f * 2 * MPE_MAX_MARKERS + 2 * i + 1] = s_cd[grp][i];
         }
-        P3PCtx ctx;
-        if (!p3p_prepare(fv[0], fv[1], fv[2], wp[0], wp[1], wp[2], ctx)) continue;
-        double min_sq = INFINITY;
-        int best = -1;
-        for (int k = 0; k < 4; ++k) {
-          M3 R;
-          V3 C;
-          p3p_solution(ctx, ctx.root[k], R, C);
-          if (!rc_finite(R, C)) continue;
-          const Proj P = make_projection(R, C, fx, fy, cx, cy);
-          // unused correspondences, ascending row index
-          double bu[MPE_MAX_MARKERS], bv[MPE_MAX_MARKERS], iu[MPE_MAX_MARKERS], ivv[MPE_MAX_MARKERS];
-          int q = 0;
-          for (int l = 0; l < n_c; ++l) {
-            if (l == a || l == b || l == c) continue;
-            const int mi = cm[l] - 1, di = cd[l] - 1;
-            project(P, V3{sp.markers[3 * mi], sp.markers[3 * mi + 1], sp.markers[3 * mi + 2]}, bu[q], bv[q]);
-            iu[q] = d->undist_xy[2 * di];
-            ivv[q] = d->undist_xy[2 * di + 1];
-            ++q;
-          }
-          // calculateSquaredReprojectionErrorAndCertainty (pose_estimator.cpp:303-342): greedy
-          // global-minimum matching, column-major first minimum, rows = image points
-          unsigned rowdone = 0, coldone = 0;
-          double sq = 0;
-          unsigned ncorr = 0;
-          for (int it = 0; it < nu; ++it) {
-            double mv = 0;
-            int ri = 0, ci = 0;
-            bool first = true;
-            for (int cj = 0; cj < nu; ++cj)
-              for (int rr = 0; rr < nu; ++rr) {
-                double v;
-                if (((rowdone >> rr) & 1) || ((coldone >> cj) & 1))
-                  v = INFINITY;
-                else {
-                  const double du = iu[rr] - bu[cj], dv = ivv[rr] - bv[cj];
-                  v = sqrt(du * du + dv * dv);
-                }
-                if (first || v < mv) {
-                  mv = v;
-                  ri = rr;
-                  ci = cj;
-                  first = false;
-                }
-              }
-            if (mv <= sp.back_tol) {
-              sq += mv * mv;
-              ++ncorr;
-              rowdone |= 1u << ri;
-              coldone |= 1u << ci;
-            } else
-              break;
-          }
-          const double certainty = (double)ncorr / (double)nu;
-          if (certainty >= sp.certainty_thr) {  // pose_estimator.cpp:494-502
-            if (best < 0) best = -2;              // valid_correspondence_found
-            if (sq < min_sq) {
-              min_sq = sq;
-              best = k;
+    }
+  }
+  __syncthreads();
+  const int n_c = s_nc[grp];
+  const bool go = n_c >= 4;
+
+  // ---- checkCorrespondences (pose_estimator.cpp:394-542): the C(n_c,3) P3P validations are
+  //      spread over the 16 lanes; each lane sums inverse(H_best) * markers for its combinations
+  unsigned my_valid = 0;
+  const int nu = n_c - 3;
+  const int N = go ? n_c * (n_c - 1) * (n_c - 2) / 6 : 0;
+  for (int ci = l; ci < N; ci += K3_GROUP) {
+    int a, b, c;
+    unrank_combo3(ci, n_c, a, b, c);
+    V3 fv[3], wp[3];
+    {
+      const int rows3[3] = {a, b, c};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int mi = s_cm[grp][rows3[k]] - 1, di = s_cd[grp][rows3[k]] - 1;
+        wp[k] = {s_mk[mi][0], s_mk[mi][1], s_mk[mi][2]};
+        fv[k] = bearing(s_det[grp][di][0], s_det[grp][di][1], fx, fy, cx, cy);
+      }
+    }
+    P3PCtx ctx;
+    if (!p3p_prepare(fv[0], fv[1], fv[2], wp[0], wp[1], wp[2], ctx)) continue;
+    double min_sq = INFINITY;
+    int best = -1;
+    bool found = false;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      M3 R;
+      V3 C;
+      p3p_solution(ctx, pick_root(ctx, k), R, C);
+      if (!rc_finite(R, C)) continue;
+      const Proj P = make_projection(R, C, fx, fy, cx, cy);
+      // back-project the unused correspondences' markers, ascending row index
+      for (int q = 0; q < nu; ++q) {
+        int row = q;
+        row += (row >= a);
+        row += (row >= b);
+        row += (row >= c);
+        const int mi = s_cm[grp][row] - 1;
+        double u, v;
+        project(P, V3{s_mk[mi][0], s_mk[mi][1], s_mk[mi][2]}, u, v);
+        s_q[2 * q][tid] = u;
+        s_q[2 * q + 1][tid] = v;
+      }
+      // calculateSquaredReprojectionErrorAndCertainty (pose_estimator.cpp:303-342): greedy
+      // global-minimum matching, column-major first minimum, rows = image points
+      unsigned rowdone = 0, coldone = 0;
+      double sq = 0;
+      unsigned ncorr = 0;
+      for (int it = 0; it < nu; ++it) {
+        double mv = 0;
+        int ri = 0, cj0 = 0;
+        bool first = true;
+        for (int cj = 0; cj < nu; ++cj) {
+          const double bu = s_q[2 * cj][tid], bv = s_q[2 * cj + 1][tid];
+          for (int rr = 0; rr < nu; ++rr) {
+            double v;
+            if (((rowdone >> rr) & 1) || ((coldone >> cj) & 1))
+              v = INFINITY;
+            else {
+              int row = rr;
+              row += (row >= a);
+              row += (row >= b);
+              row += (row >= c);
+              const int di = s_cd[grp][row] - 1;
+              const double du = s_det[grp][di][0] - bu, dv = s_det[grp][di][1] - bv;
+              v = sqrt(du * du + dv * dv);
+            }
+            if (first || v < mv) {
+              mv = v;
+              ri = rr;
+              cj0 = cj;
+              first = false;
             }
           }
         }
-        if (best == -1) continue;
-        ++num_valid;
-        if (best < 0) best = 0;  // unreachable: sq is always finite, so a valid solution always sets the index
-        M3 R;
-        V3 C;
-        p3p_solution(ctx, ctx.root[best], R, C);
-        // inverse(H) * marker for ALL markers (pose_estimator.cpp:513-517)
-        for (int jj = 0; jj < n_m; ++jj) {
-          const V3 mk = {sp.markers[3 * jj] - C.x, sp.markers[3 * jj + 1] - C.y, sp.markers[3 * jj + 2] - C.z};
-          const V3 pc = mulT(R, mk);  // R^T (m - C)
-          mean[jj][0] += pc.x;
-          mean[jj][1] += pc.y;
-          mean[jj][2] += pc.z;
+        if (mv <= sp.back_tol) {
+          sq += mv * mv;
+          ++ncorr;
+          rowdone |= 1u << ri;
+          coldone |= 1u << cj0;
+        } else
+          break;
+      }
+      const double certainty = (double)ncorr / (double)nu;
+      if (certainty >= sp.certainty_thr) {  // pose_estimator.cpp:494-502
+        found = true;
+        if (sq < min_sq) {
+          min_sq = sq;
+          best = k;
         }
       }
-  if (!((double)num_valid / (double)N >= sp.valid_corr_thr)) return;
+    }
+    if (!found) continue;
+    ++my_valid;
+    if (best < 0) best = 0;  // unreachable: sq is always finite
+    M3 R;
+    V3 C;
+    p3p_solution(ctx, pick_root(ctx, best), R, C);
+    // inverse(H) * marker for ALL markers (pose_estimator.cpp:513-517)
+    for (int jj = 0; jj < n_m; ++jj) {
+      const V3 mk = {s_mk[jj][0] - C.x, s_mk[jj][1] - C.y, s_mk[jj][2] - C.z};
+      const V3 pc = mulT(R, mk);  // R^T (m - C)
+      s_part[grp][l][3 * jj] += pc.x;
+      s_part[grp][l][3 * jj + 1] += pc.y;
+      s_part[grp][l][3 * jj + 2] += pc.z;
+    }
+  }
+  s_valid[grp][l] = my_valid;
+  __syncthreads();
+  // ordered reduction over the lanes (= combination order while C(n_c,3) <= 16)
+  for (int v = l; v < 3 * MPE_MAX_MARKERS; v += K3_GROUP) {
+    double sacc = 0.0;
+    for (int q = 0; q < K3_GROUP; ++q) sacc += s_part[grp][q][v];
+    s_mean[grp][v] = sacc;
+  }
+  unsigned num_valid = 0;
+  for (int q = 0; q < K3_GROUP; ++q) num_valid += s_valid[grp][q];
+  __syncthreads();
+  bool active = go && ((double)num_valid / (double)N >= sp.valid_corr_thr);
 
-  // ---- computeTransformation (pose_estimator.cpp:908-930)
+  // ---- computeTransformation (pose_estimator.cpp:908-930); evaluated by every lane of the group
   T34 T;
-  {
+  if (active) {
     double mo[3] = {0, 0, 0}, mr[3] = {0, 0, 0};
     for (int i = 0; i < n_m; ++i)
       for (int k = 0; k < 3; ++k) {
-        mean[i][k] = mean[i][k] / (double)num_valid;
-        mo[k] += sp.markers[3 * i + k];
-        mr[k] += mean[i][k];
+        mo[k] += s_mk[i][k];
+        mr[k] += s_mean[grp][3 * i + k] / (double)num_valid;
       }
     for (int k = 0; k < 3; ++k) {
       mo[k] /= (double)n_m;
@@ -1109,7 +1235,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_tail(const mpe_detections* __re
     double Hm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int i = 0; i < n_m; ++i)
       for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) Hm[r][c] += (sp.markers[3 * i + r] - mo[r]) * (mean[i][c] - mr[c]);
+        for (int c = 0; c < 3; ++c)
+          Hm[r][c] += (s_mk[i][r] - mo[r]) * (s_mean[grp][3 * i + c] / (double)num_valid - mr[c]);
     double X[3][3];  // H^T
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) X[r][c] = Hm[c][r];
@@ -1120,71 +1247,107 @@ __global__ __launch_bounds__(K3_THREADS) void k3_tail(const mpe_detections* __re
     }
   }
 
-  // ---- optimisePose (pose_estimator.cpp:733-792): Gauss-Newton on SE(3)
+  // ---- optimisePose (pose_estimator.cpp:733-792): Gauss-Newton on SE(3).  Lane j of the group
+  //      evaluates correspondence j (J^T J and J^T e, upper triangle), a butterfly sum gives every
+  //      lane the normal equations, and all lanes take the same LDL^T / exp-map step.
+  double mkx = 0, mky = 0, mkz = 0, du_ = 0, dv_ = 0;
+  bool has = false;
+  if (active && l < n_c) {  // n_c <= MPE_MAX_MARKERS = K3_GROUP
+    const int mi = s_cm[grp][l] - 1, di = s_cd[grp][l] - 1;
+    mkx = s_mk[mi][0];
+    mky = s_mk[mi][1];
+    mkz = s_mk[mi][2];
+    du_ = s_det[grp][di][0];
+    dv_ = s_det[grp][di][1];
+    has = true;
+  }
   double A[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) A[r][c] = 0;
   int iters = 0;
+  bool running = active;
   for (int it = 0; it < 500; ++it) {
-    double b[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      b[r] = 0;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) A[r][c] = 0;
-    }
-    for (int j = 0; j < n_c; ++j) {
-      const int mi = cm[j] - 1, di = cd[j] - 1;
+    if (!__any(running)) break;
+    double J0[6] = {0, 0, 0, 0, 0, 0}, J1[6] = {0, 0, 0, 0, 0, 0}, e0 = 0, e1 = 0;
+    if (running && has) {
+      const double mk[3] = {mkx, mky, mkz};
       double u, v, x, y, z;
-      project_T(T, &sp.markers[3 * mi], fx, fy, cx, cy, u, v, x, y, z);
-      const double e0 = d->undist_xy[2 * di] - u, e1 = d->undist_xy[2 * di + 1] - v;
+      project_T(T, mk, fx, fy, cx, cy, u, v, x, y, z);
+      e0 = du_ - u;
+      e1 = dv_ - v;
       const double z_2 = z * z;
       // computeJacobian, pose_estimator.cpp:945-957
-      const double J0[6] = {1 / z * fx, 0, -x / z_2 * fx, -x * y / z_2 * fx, (1 + (x * x / z_2)) * fx, -y / z * fx};
-      const double J1[6] = {0, 1 / z * fy, -y / z_2 * fy, -(1 + y * y / z_2) * fy, x * y / z_2 * fy, x / z * fy};
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) A[r][c] += J0[r] * J0[c] + J1[r] * J1[c];
-        b[r] += J0[r] * e0 + J1[r] * e1;
-      }
+      J0[0] = 1 / z * fx;
+      J0[2] = -x / z_2 * fx;
+      J0[3] = -x * y / z_2 * fx;
+      J0[4] = (1 + (x * x / z_2)) * fx;
+      J0[5] = -y / z * fx;
+      J1[1] = 1 / z * fy;
+      J1[2] = -y / z_2 * fy;
+      J1[3] = -(1 + y * y / z_2) * fy;
+      J1[4] = x * y / z_2 * fy;
+      J1[5] = x / z * fy;
     }
-    LDL6 F;
-    ldl6_factor(A, F);
-    double dT[6];
-    ldl6_solve(F, b, dT);
-    apply_exp(dT, T);
-    iters = it + 1;
-    double mx = -1;  // norm_max, pose_estimator.cpp:1073-1085
+    double An[6][6], b[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      const double av = fabs(dT[r]);
-      if (av > mx) mx = av;
+#pragma unroll
+      for (int c = r; c < 6; ++c) {
+        An[r][c] = group_sum(J0[r] * J0[c] + J1[r] * J1[c]);
+        An[c][r] = An[r][c];
+      }
+      b[r] = group_sum(J0[r] * e0 + J1[r] * e1);
     }
-    if (mx <= 1e-13) break;
+    if (running) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) A[r][c] = An[r][c];
+      LDL6 F;
+      ldl6_factor(A, F);
+      double dT[6];
+      ldl6_solve(F, b, dT);
+      apply_exp(dT, T);
+      iters = it + 1;
+      double mx = -1;  // norm_max, pose_estimator.cpp:1073-1085
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double av = fabs(dT[r]);
+        if (av > mx) mx = av;
+      }
+      if (mx <= 1e-13) running = false;
+    }
   }
-  // pose_covariance_ = A.inverse() with the A of the last iteration (pose_estimator.cpp:790)
+  if (!active) return;
+  // pose_covariance_ = A.inverse() with the A of the last iteration (pose_estimator.cpp:790);
+  // lane c of the group solves for column c
   {
     LDL6 F;
     ldl6_factor(A, F);
+    if (l < 6) {
+      double e[6], x[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      double e[6] = {0, 0, 0, 0, 0, 0}, x[6];
-      e[c] = 1.0;
+      for (int r = 0; r < 6; ++r) e[r] = (r == l) ? 1.0 : 0.0;
       ldl6_solve(F, e, x);
 #pragma unroll
-      for (int r = 0; r < 6; ++r) res->cov[r * 6 + c] = x[r];
+      for (int r = 0; r < 6; ++r) res->cov[r * 6 + l] = x[r];
     }
   }
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 4; ++c) res->T[r * 4 + c] = T.m[r][c];
-  res->gn_iterations = iters;
-  res->status = MPE_FRAME_POSE;
+  if (l == 0) {
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) res->T[r * 4 + c] = T.m[r][c];
+    res->gn_iterations = iters;
+    res->status = MPE_FRAME_POSE;
+  }
 }
 
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
                           mpe_result* results, uint32_t* corr_out, hipStream_t s) {
   if (n_frames <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k3_tail, dim3((n_frames + K3_THREADS - 1) / K3_THREADS), dim3(K3_THREADS), 0, s, dets, hist,
-                     n_frames, sp, results, corr_out);
+  hipLaunchKernelGGL(k3_tail, dim3((n_frames + K3_FRAMES_PER_BLOCK - 1) / K3_FRAMES_PER_BLOCK), dim3(64), 0, s, dets,
+                     hist, n_frames, sp, results, corr_out);
   return hipGetLastError();
 }
 
