@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=4, help="sub-batches per step on separate HIP streams (1 = off)")
     args = ap.parse_args()
 
     import torch
@@ -66,6 +67,7 @@ def main():
     h = mpe.Handle(local_rank)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     P = mpe.demo_params()
+    h.set_option("pipeline", args.pipeline)
 
     def step():
         h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
@@ -119,6 +121,7 @@ def main():
                                    "frame, demo.launch parameters" % (args.config, cols, rows, len(markers),
                                                                       cfg["n_distractors"]),
                        "frames_per_gpu_per_step": B, "frames_resident_in_hbm": True,
+                       "streams_per_gpu": args.pipeline,
                        "parallelism": "frames sharded over %d GPU(s), all_gather of pose records" % world},
             "poses_found_frac": n_pose / B,
             "kernel_ms": kavg,

@@ -8,7 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_LIB = os.path.join(_HERE, "libmpe_hip.so")
+_LIB = os.environ.get("MPE_LIB") or os.path.join(_HERE, "libmpe_hip.so")  # MPE_LIB: kernel-variant experiments
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "mpe.h")
 
 MAX_MARKERS = 16

@@ -45,10 +45,16 @@ struct mpe_handle {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string err;
-  DevBuf frames, flags, dets, hist, results, corr;
+  DevBuf frames, flags, dets, hist, results, corr, mtab, work, scratch;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
   int vote_splits = 0;         // 0 = auto
   bool profiling = false;
+  int pipeline = 1;  // sub-batches run on separate streams so that the HBM-bound scan of one overlaps
+                     // the VALU/latency-bound blob, vote and tail kernels of another (1 = off)
+  static const int kMaxSub = 8;
+  hipStream_t sub_stream[kMaxSub] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t sub_done[kMaxSub] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float last_ms[5] = {0, 0, 0, 0, 0};
   bool have_ms = false;
@@ -211,28 +217,79 @@ void rec(mpe_handle* h, int i) {
   if (h->profiling && h->ev[i]) (void)hipEventRecord(h->ev[i], h->stream);
 }
 
-// the full per-batch pipeline on device-resident, packed frames
+// the per-batch pipeline on device-resident, packed frames, all kernels on stream `st`
+int run_chain(mpe_handle* h, hipStream_t st, bool prof, int chain, int chain_frames, const uint8_t* d_frames, int n_frames,
+              const FrameGeom& g, const DetectParams& dp, const SolveParams* sp, unsigned long long* d_flags,
+              mpe_detections* d_dets,
+              uint32_t* d_hist, mpe_result* d_results, uint32_t* d_corr) {
+  const size_t bytes = (size_t)n_frames * g.rows * g.pitch;
+  if (prof) rec(h, 0);
+  HIP_TRY(h, launch_k1a_scan(d_frames, bytes, d_flags, dp.thr, st));
+  if (prof) rec(h, 1);
+  HIP_TRY(h, launch_k1b_blobs(d_frames, d_flags, n_frames, g, dp, d_dets,
+                              static_cast<int*>(h->work.p) + (size_t)chain * (chain_frames + 1),
+                              static_cast<uint8_t*>(h->scratch.p) + (size_t)chain * k1b_scratch_bytes(g), st));
+  if (prof) rec(h, 2);
+  if (sp) {
+    HIP_TRY(h, hipMemsetAsync(d_hist, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), st));
+    HIP_TRY(h, launch_k2_vote(d_dets, n_frames, *sp, static_cast<const double*>(h->mtab.p), d_hist,
+                              auto_splits(h, n_frames, sp->n_markers), sp->n_markers, st));
+    if (prof) rec(h, 3);
+    HIP_TRY(h, launch_k3_tail(d_dets, d_hist, n_frames, *sp, d_results, d_corr, st));
+  } else if (prof) {
+    rec(h, 3);
+  }
+  if (prof) rec(h, 4);
+  return MPE_OK;
+}
+
 int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const FrameGeom& g, const DetectParams& dp,
                  const SolveParams* sp, mpe_detections* d_dets, uint32_t* d_hist, mpe_result* d_results,
                  uint32_t* d_corr) {
-  const size_t bytes = (size_t)n_frames * g.rows * g.pitch;
-  HIP_TRY(h, h->flags.reserve(flag_words(bytes) * 8));
-  unsigned long long* d_flags = static_cast<unsigned long long*>(h->flags.p);
-  rec(h, 0);
-  HIP_TRY(h, launch_k1a_scan(d_frames, bytes, d_flags, dp.thr, h->stream));
-  rec(h, 1);
-  HIP_TRY(h, launch_k1b_blobs(d_frames, d_flags, n_frames, g, dp, d_dets, h->stream));
-  rec(h, 2);
+  const size_t frame_bytes = (size_t)g.rows * g.pitch;
   if (sp) {
-    HIP_TRY(h, hipMemsetAsync(d_hist, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
-    HIP_TRY(h, launch_k2_vote(d_dets, n_frames, *sp, d_hist, auto_splits(h, n_frames, sp->n_markers), sp->n_markers, h->stream));
-    rec(h, 3);
-    HIP_TRY(h, launch_k3_tail(d_dets, d_hist, n_frames, *sp, d_results, d_corr, h->stream));
-  } else {
-    rec(h, 3);
+    HIP_TRY(h, h->mtab.reserve(k2_table_bytes(sp->n_markers)));
+    HIP_TRY(h, launch_k2_prep(*sp, static_cast<double*>(h->mtab.p), h->stream));
   }
-  rec(h, 4);
-  h->have_ms = h->profiling;
+  int nsub = h->profiling ? 1 : h->pipeline;
+  if (nsub > mpe_handle::kMaxSub) nsub = mpe_handle::kMaxSub;
+  if (n_frames < 512 * nsub) nsub = 1;  // small batches: one chain
+  h->have_ms = false;
+  if (nsub <= 1) {
+    HIP_TRY(h, h->flags.reserve(flag_words(frame_bytes * n_frames) * 8));
+    HIP_TRY(h, h->work.reserve((size_t)(n_frames + 1) * sizeof(int)));
+    HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
+    int rc = run_chain(h, h->stream, h->profiling, 0, n_frames, d_frames, n_frames, g, dp, sp,
+                       static_cast<unsigned long long*>(h->flags.p), d_dets, d_hist, d_results, d_corr);
+    h->have_ms = (rc == MPE_OK) && h->profiling;
+    return rc;
+  }
+  // frames per sub-batch: multiple of 64 so every sub-batch starts on a 16-byte / flag-word boundary
+  int per = ((n_frames + nsub - 1) / nsub + 63) & ~63;
+  const size_t fw_per = flag_words(frame_bytes * per);
+  HIP_TRY(h, h->flags.reserve(fw_per * nsub * 8));
+  HIP_TRY(h, h->work.reserve((size_t)(per + 1) * nsub * sizeof(int)));
+  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g) * nsub));
+  if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  HIP_TRY(h, hipEventRecord(h->fork_ev, h->stream));
+  int used = 0;
+  for (int s = 0; s < nsub; ++s) {
+    const int f0 = s * per;
+    if (f0 >= n_frames) break;
+    const int nf = std::min(per, n_frames - f0);
+    if (!h->sub_stream[s]) HIP_TRY(h, hipStreamCreateWithFlags(&h->sub_stream[s], hipStreamNonBlocking));
+    if (!h->sub_done[s]) HIP_TRY(h, hipEventCreateWithFlags(&h->sub_done[s], hipEventDisableTiming));
+    hipStream_t st = h->sub_stream[s];
+    HIP_TRY(h, hipStreamWaitEvent(st, h->fork_ev, 0));
+    int rc = run_chain(h, st, false, s, per, d_frames + (size_t)f0 * frame_bytes, nf, g, dp, sp,
+                       static_cast<unsigned long long*>(h->flags.p) + fw_per * s, d_dets + f0,
+                       d_hist ? d_hist + (size_t)f0 * MPE_HIST_STRIDE : nullptr, d_results ? d_results + f0 : nullptr,
+                       d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipEventRecord(h->sub_done[s], st));
+    used = s + 1;
+  }
+  for (int s = 0; s < used; ++s) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->sub_done[s], 0));
   return MPE_OK;
 }
 
@@ -301,8 +358,16 @@ void mpe_destroy(mpe_handle* h) {
   h->hist.release();
   h->results.release();
   h->corr.release();
+  h->mtab.release();
+  h->work.release();
+  h->scratch.release();
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->sub_done)
+    if (e) (void)hipEventDestroy(e);
+  if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+  for (auto& st : h->sub_stream)
+    if (st) (void)hipStreamDestroy(st);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -346,6 +411,11 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   if (!std::strcmp(name, "lds_budget")) {
     if (value < 8 * 1024 || value > 160 * 1024) return fail(h, MPE_ERR_ARG, "lds_budget out of range");
     h->lds_budget = value;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "pipeline")) {
+    if (value < 1 || value > mpe_handle::kMaxSub) return fail(h, MPE_ERR_ARG, "pipeline out of range");
+    h->pipeline = value;
     return MPE_OK;
   }
   if (!std::strcmp(name, "vote_splits")) {
@@ -440,8 +510,11 @@ int mpe_vote_batch(mpe_handle* h, const double* det_xy, const int* n_det, int n_
   HIP_TRY(h, hipMemcpyAsync(h->dets.p, hd.data(), (size_t)n_frames * sizeof(mpe_detections), hipMemcpyHostToDevice,
                             h->stream));
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
-  HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), n_frames, sp, static_cast<uint32_t*>(h->hist.p),
-                            auto_splits(h, n_frames, n_markers), n_markers, h->stream));
+  HIP_TRY(h, h->mtab.reserve(k2_table_bytes(n_markers)));
+  HIP_TRY(h, launch_k2_prep(sp, static_cast<double*>(h->mtab.p), h->stream));
+  HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), n_frames, sp, static_cast<const double*>(h->mtab.p),
+                            static_cast<uint32_t*>(h->hist.p), auto_splits(h, n_frames, n_markers), n_markers,
+                            h->stream));
   HIP_TRY(h, hipMemcpyAsync(hist, h->hist.p, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -466,8 +539,10 @@ int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const d
   HIP_TRY(h, h->corr.reserve(2 * MPE_MAX_MARKERS * sizeof(uint32_t)));
   HIP_TRY(h, hipMemcpyAsync(h->dets.p, &hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
-  HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), 1, sp, static_cast<uint32_t*>(h->hist.p),
-                            auto_splits(h, 1, n_markers), n_det, h->stream));
+  HIP_TRY(h, h->mtab.reserve(k2_table_bytes(n_markers)));
+  HIP_TRY(h, launch_k2_prep(sp, static_cast<double*>(h->mtab.p), h->stream));
+  HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), 1, sp, static_cast<const double*>(h->mtab.p),
+                            static_cast<uint32_t*>(h->hist.p), auto_splits(h, 1, n_markers), n_det, h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
                             static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), h->stream));
   uint32_t hh[MPE_HIST_STRIDE], hc[2 * MPE_MAX_MARKERS];

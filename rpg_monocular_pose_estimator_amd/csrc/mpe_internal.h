@@ -47,13 +47,16 @@ struct SolveParams {
 #define MPE_HIST_STRIDE (MPE_MAX_DETECTIONS * MPE_MAX_MARKERS)
 
 // launchers (mpe_kernels.hip)
-size_t k1b_lds_bytes(const FrameGeom& g);
+size_t k1b_scratch_bytes(const FrameGeom& g);
 hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long long* flags, int thr,
                            hipStream_t s);
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
-                            const DetectParams& dp, mpe_detections* dets, hipStream_t s);
-hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist,
-                          int splits, int n_det_hint, hipStream_t s);
+                            const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
+                            hipStream_t s);
+size_t k2_table_bytes(int n_markers);
+hipError_t launch_k2_prep(const SolveParams& sp, double* tab, hipStream_t s);
+hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
+                          uint32_t* hist, int splits, int n_det_hint, hipStream_t s);
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
                           mpe_result* results, uint32_t* corr_out, hipStream_t s);
 hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int n_frames, int roi_x,

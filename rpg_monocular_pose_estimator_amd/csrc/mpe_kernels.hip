@@ -121,11 +121,6 @@ hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame
 // on its own in a small LDS window (thresholded pixels + three bitmaps), and the blobs are put
 // back into raster order of their start pixels at the end.
 // =============================================================================================
-#define K1B_SEG_CAP 1024   // bright segments per frame kept in LDS
-#define K1B_PIX_CAP 8192   // bytes of thresholded pixels per island window
-#define K1B_BM_CAP 320     // u64 words per island bitmap
-#define K1B_KEPT_CAP 64    // blobs that pass the shape filter (> MPE_MAX_DETECTIONS -> status)
-
 struct BlobRec {
   long long a00, a10, a01;  // polygon sums: sum dxy, sum dxy*(x_{i-1}+x_i), sum dxy*(y_{i-1}+y_i)
   int xmin, xmax, ymin, ymax;
@@ -179,8 +174,12 @@ __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, in
   for (int i = 0; i < KS; ++i) {
     const int yb = reflect101(y + i - R, rows) - w.ylo;
     if ((unsigned)yb >= (unsigned)w.H) continue;  // rows outside the band hold no bright pixel
-    const uint4* p = reinterpret_cast<const uint4*>(w.pix + (size_t)yb * w.PW + 16 * (c - 1 - w.pwc0));
-    const uint4 q0 = p[0], q1 = p[1], q2 = p[2];
+    const int sc = c - 1 - w.pwc0, nsw = w.PW >> 4;  // window segment index of column c-1
+    const uint4* p = reinterpret_cast<const uint4*>(w.pix + (size_t)yb * w.PW);
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    const uint4 q0 = ((unsigned)sc < (unsigned)nsw) ? p[sc] : z4;
+    const uint4 q1 = ((unsigned)(sc + 1) < (unsigned)nsw) ? p[sc + 1] : z4;
+    const uint4 q2 = ((unsigned)(sc + 2) < (unsigned)nsw) ? p[sc + 2] : z4;
     const unsigned q[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
     int t[16 + 2 * R];
 #pragma unroll
@@ -377,16 +376,142 @@ __device__ __forceinline__ bool blob_filter(const BlobRec& b, const DetectParams
          fabs(1 - (area / (pi * (hw * hw)))) <= dp.max_circ && fabs(1 - (area / (pi * (hh * hh)))) <= dp.max_circ;
 }
 
+// ---- shared by the fast (LDS) and the general (global scratch) blob kernels -------------------
+
+// raster scan of one window for external contours: OpenCV's cvFindNextContour in RETR_EXTERNAL
+// mode.  Window rows are bitmap slots 1..H (slot 0 and H+1 are zero separators), bit index
+// xb = x - xw0 + 1.  For every traced outer border the polygon sums go through the shape filter;
+// blobs that pass are handed to emit(mcx, mcy, key) with key = raster position of the start pixel.
+template <class Emit>
+__device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, int H, int ylo, int xw0,
+                                            const DetectParams& dp, int* over, Emit emit) {
+  for (int slot = 1; slot <= H; ++slot) {
+    u64* nzrow = nz + (size_t)slot * W;
+    u64* pmrow = pm + (size_t)slot * W;
+    u64* ngrow = ng + (size_t)slot * W;
+    int last_sign = 0;  // sign of the nearest marked pixel to the left (lnbd), 0 = none yet
+    for (int w = 0; w < W - 1; ++w) {
+      const u64 nzw = nzrow[w];
+      if (!nzw) continue;
+      const u64 leftnz = (nzw << 1) | (w ? (nzrow[w - 1] >> 63) : 0);
+      u64 done = 0;
+      for (;;) {
+        const u64 pw_ = pmrow[w], gw = ngrow[w];
+        const u64 cand = nzw & ~(pw_ | gw) & ~leftnz & ~done;  // unmarked 1 with a 0 on its left
+        if (!cand) break;
+        const int bb = __builtin_ctzll(cand);
+        done |= (bb == 63) ? ~0ull : ((2ull << bb) - 1);
+        const u64 below = (pw_ | gw) & ((1ull << bb) - 1);
+        int sign = last_sign;
+        if (below) {
+          const int hb = 63 - __builtin_clzll(below);
+          sign = ((gw >> hb) & 1) ? -1 : 1;
+        }
+        if (sign > 0) continue;  // inside an already traced outer border: not external
+        PolyAcc acc;
+        const int xb = w * 64 + bb;
+        if (!trace_outer_border(nz, pm, ng, W, slot, xb, xw0 - 1, ylo - 1, acc)) *over = 1;
+        BlobRec br;
+        br.a00 = acc.a00;
+        br.a10 = acc.a10;
+        br.a01 = acc.a01;
+        br.xmin = acc.xmin;
+        br.xmax = acc.xmax;
+        br.ymin = acc.ymin;
+        br.ymax = acc.ymax;
+        float mcx, mcy;
+        if (blob_filter(br, dp, mcx, mcy)) emit(mcx, mcy, ((unsigned)(ylo + slot - 1) << 12) | (unsigned)(xb + xw0 - 1));
+      }
+      const u64 mk = pmrow[w] | ngrow[w];
+      if (mk) {
+        const int hb = 63 - __builtin_clzll(mk);
+        last_sign = ((ngrow[w] >> hb) & 1) ? -1 : 1;
+      }
+    }
+  }
+}
+
+// blurred-mask bits of the 16 outputs of segment column c in image row y -> OR into the bitmap
+__device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, const FrameGeom& g, const DetectParams& dp, int y, int c,
+                                               u64* nzrow, int xw0) {
+  const int r = dp.ksize / 2;
+  const int x0 = 16 * c;
+  if (x0 >= g.cols) return;
+  unsigned m;
+  const bool interior = (x0 - r >= 0) && (x0 + 15 + r < g.cols);
+  if (interior && dp.ksize == 5)
+    m = blur_item_fast<5>(pw, g.rows, g.cols, y, c, dp.taps);
+  else if (interior && dp.ksize == 3)
+    m = blur_item_fast<3>(pw, g.rows, g.cols, y, c, dp.taps);
+  else
+    m = blur_item_generic(pw, g.rows, g.cols, y, c, dp.taps, dp.ksize);
+  if (m) {
+    const int xb0 = x0 - xw0 + 1, wi = xb0 >> 6, shb = xb0 & 63;
+    atomicOr(&nzrow[wi], (u64)m << shb);
+    if (shb > 48) atomicOr(&nzrow[wi + 1], (u64)m >> (64 - shb));
+  }
+}
+
+// final stage: kept blobs -> OpenCV's contour order (newest first = descending raster order of
+// the start pixel), float32 centroid -> undistortPoints, write the detection record
+__device__ __forceinline__ void write_detections(const float* kx, const float* ky, const unsigned* kkey, int nk_all,
+                                                 int kept_cap, int over, const DetectParams& dp, mpe_detections* out,
+                                                 int lane) {
+  const int nk = min(nk_all, kept_cap);
+  for (int i = lane; i < nk; i += 64) {
+    const unsigned key = kkey[i];
+    int pos = 0;
+    for (int j = 0; j < nk; ++j) pos += (kkey[j] > key) ? 1 : 0;
+    if (pos < MPE_MAX_DETECTIONS) {
+      const float mcx = kx[i], mcy = ky[i];
+      float ux, uy;
+      undistort_point(mcx, mcy, dp, ux, uy);
+      out->dist_xy[2 * pos] = mcx;
+      out->dist_xy[2 * pos + 1] = mcy;
+      out->undist_xy[2 * pos] = (double)ux;
+      out->undist_xy[2 * pos + 1] = (double)uy;
+    }
+  }
+  if (lane == 0) {
+    out->n = min(nk_all, MPE_MAX_DETECTIONS);
+    int st = 0;
+    if (nk_all > MPE_MAX_DETECTIONS) st = MPE_FRAME_TOO_MANY_DETECTIONS;
+    if (over) st = MPE_FRAME_TOO_MANY_ROWS;
+    out->status = st;
+  }
+}
+
+// =============================================================================================
+// K1b fast path: one wave per frame, everything in ~17 KB of LDS.
+// =============================================================================================
+#define K1B_SEG_CAP 512     // bright segments per frame
+#define K1B_BAND_CAP 32     // bands per frame
+#define K1B_ISL_CAP 32      // islands per frame
+#define K1B_PIX_POOL 6144   // bytes of thresholded pixels, all islands of the frame
+#define K1B_BM_POOL 288     // u64 words per bitmap, all islands of the frame
+#define K1B_KEPT_CAP 64     // blobs that pass the shape filter (> MPE_MAX_DETECTIONS -> status)
+
+struct Island {
+  short ylo, yhi;      // band rows
+  short clo, chi;      // output segment columns
+  short cfirst, clast; // bright segment columns (pixel window)
+  int pix_off, bm_off; // offsets into the pools
+  int stage_end, blur_end;  // inclusive prefix sums of the flattened work-item counts
+};
+
 __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
-                                               FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_pix[K1B_PIX_CAP];
-  __shared__ u64 s_nz[K1B_BM_CAP], s_pm[K1B_BM_CAP], s_ng[K1B_BM_CAP];
+                                               FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
+                                               int* __restrict__ worklist) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_pix[K1B_PIX_POOL];
+  __shared__ u64 s_nz[K1B_BM_POOL], s_pm[K1B_BM_POOL], s_ng[K1B_BM_POOL];
   __shared__ unsigned s_seg[K1B_SEG_CAP];  // y << 16 | segment column
   __shared__ u64 s_rowact[64];
-  __shared__ u64 s_colocc[4];
+  __shared__ u64 s_colocc[K1B_BAND_CAP][4];
+  __shared__ short s_bandlo[K1B_BAND_CAP], s_bandhi[K1B_BAND_CAP];
+  __shared__ Island s_isl[K1B_ISL_CAP];
   __shared__ float s_kx[K1B_KEPT_CAP], s_ky[K1B_KEPT_CAP];
   __shared__ unsigned s_kkey[K1B_KEPT_CAP];
-  __shared__ int s_nseg, s_nkept, s_over;
+  __shared__ int s_nseg, s_nkept, s_over, s_nband, s_nisl;
 
   const int lane = threadIdx.x;
   const int f = blockIdx.x;
@@ -398,10 +523,13 @@ __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ fram
   const unsigned add = (unsigned)(255 - dp.thr) * 0x00010001u;
 
   s_rowact[lane] = 0;
+  for (int i = lane; i < K1B_BAND_CAP * 4; i += 64) (&s_colocc[0][0])[i] = 0;
   if (lane == 0) {
     s_nseg = 0;
     s_nkept = 0;
     s_over = 0;
+    s_nband = 0;
+    s_nisl = 0;
   }
   __syncthreads();
 
@@ -440,249 +568,355 @@ __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ fram
     }
   }
   __syncthreads();
-  const int nseg_all = s_nseg;
-  if (nseg_all == 0 || nseg_all > K1B_SEG_CAP) {
+  const int nseg = s_nseg;
+  if (nseg == 0) {
     if (lane == 0) {
       out->n = 0;
-      out->status = nseg_all == 0 ? 0 : MPE_FRAME_TOO_MANY_ROWS;
+      out->status = 0;
     }
     return;
   }
-  const int nseg = nseg_all;
+  bool fallback = nseg > K1B_SEG_CAP;
 
-  // ---- B: bands (maximal runs of active rows), then islands (runs of occupied segment columns)
-  for (int rwi = 0; rwi < g.rw; ++rwi) {
-    u64 act = s_rowact[rwi];
-    while (act) {
-      // band start inside this word (or continuing from the previous one is handled below)
-      const int b0 = __builtin_ctzll(act);
-      int ylo = rwi * 64 + b0;
-      // extend downwards across words
-      int yhi = ylo;
-      {
-        int wi = rwi;
-        u64 run = act >> b0;  // bit 0 = row ylo
-        int base = ylo;
-        for (;;) {
-          const u64 inv = ~run;
-          const int len = inv ? __builtin_ctzll(inv) : 64;
-          const int avail = 64 - (base & 63);
-          if (len < avail) {
-            yhi = base + len - 1;
+  // ---- B1: bands = maximal runs of active rows (lane 0)
+  if (!fallback && lane == 0) {
+    int nb = 0;
+    int run_lo = -1;
+    for (int wi = 0; wi < g.rw; ++wi) {
+      u64 act = s_rowact[wi];
+      int pos = 0;
+      while (pos < 64) {
+        if (run_lo < 0) {  // looking for a band start
+          const u64 rest = pos ? (act >> pos) : act;
+          if (!rest) break;
+          pos += __builtin_ctzll(rest);
+          run_lo = wi * 64 + pos;
+        } else {  // inside a band: find its end
+          const u64 rest = ~(pos ? (act >> pos) : act);
+          const u64 lim = pos ? (rest & ((1ull << (64 - pos)) - 1)) : rest;
+          if (!lim) break;  // runs to the end of this word
+          pos += __builtin_ctzll(lim);
+          if (nb < K1B_BAND_CAP) {
+            s_bandlo[nb] = (short)run_lo;
+            s_bandhi[nb] = (short)(wi * 64 + pos - 1);
+          }
+          ++nb;
+          run_lo = -1;
+        }
+      }
+    }
+    if (run_lo >= 0) {
+      if (nb < K1B_BAND_CAP) {
+        s_bandlo[nb] = (short)run_lo;
+        s_bandhi[nb] = (short)(g.rows - 1);
+      }
+      ++nb;
+    }
+    s_nband = nb;
+  }
+  __syncthreads();
+  const int nband = s_nband;
+  fallback = fallback || nband > K1B_BAND_CAP;
+
+  // ---- B2: segment-column occupancy per band
+  if (!fallback) {
+    for (int i = lane; i < nseg; i += 64) {
+      const unsigned sg = s_seg[i];
+      const int y = (int)(sg >> 16), c = (int)(sg & 0xFFFF);
+      int b = 0;
+      while (b < nband - 1 && y > s_bandhi[b]) ++b;
+      atomicOr(&s_colocc[b][c >> 6], 1ull << (c & 63));
+    }
+  }
+  __syncthreads();
+
+  // ---- B3: islands = runs of occupied columns (dilated by dc) inside a band; lane b owns band b
+  if (!fallback && lane < nband) {
+    const int ylo = s_bandlo[lane], yhi = s_bandhi[lane];
+    for (int cstart = 0; cstart < spr;) {
+      int cfirst = -1;
+      for (int wi = cstart >> 6; wi < 4 && wi * 64 < spr; ++wi) {
+        u64 w = s_colocc[lane][wi];
+        if (wi == (cstart >> 6)) w &= ~0ull << (cstart & 63);
+        if (w) {
+          cfirst = wi * 64 + __builtin_ctzll(w);
+          break;
+        }
+      }
+      if (cfirst < 0) break;
+      int clast = cfirst;
+      for (;;) {  // extend while the dilated runs touch: gap <= 2*dc
+        int nxt = -1;
+        for (int c = clast + 1; c <= min(spr - 1, clast + 2 * dc + 1); ++c)
+          if ((s_colocc[lane][c >> 6] >> (c & 63)) & 1) {
+            nxt = c;
             break;
           }
-          // run reaches the end of this word: continue in the next one
-          yhi = base + avail - 1;
-          ++wi;
-          if (wi >= g.rw) break;
-          run = s_rowact[wi];
-          base = wi * 64;
-          if (!(run & 1)) break;
-        }
+        if (nxt < 0) break;
+        clast = nxt;
       }
-      // clear the band's bits in the loop state (only those inside word rwi matter for `act`)
-      {
-        const int end_in_word = min(yhi, rwi * 64 + 63) - rwi * 64;
-        const u64 m = (end_in_word == 63 ? ~0ull : ((2ull << end_in_word) - 1)) & (~0ull << b0);
-        act &= ~m;
+      cstart = clast + 2 * dc + 2;
+      const int idx = atomicAdd(&s_nisl, 1);
+      if (idx < K1B_ISL_CAP) {
+        Island is;
+        is.ylo = (short)ylo;
+        is.yhi = (short)yhi;
+        is.cfirst = (short)cfirst;
+        is.clast = (short)clast;
+        is.clo = (short)max(0, cfirst - dc);
+        is.chi = (short)min(spr - 1, clast + dc);
+        is.pix_off = is.bm_off = is.stage_end = is.blur_end = 0;
+        s_isl[idx] = is;
       }
-      const bool crosses = yhi > rwi * 64 + 63;
+    }
+  }
+  __syncthreads();
+  const int nisl = s_nisl;
+  fallback = fallback || nisl > K1B_ISL_CAP;
 
-      // segment-column occupancy of the band
-      if (lane < 4) s_colocc[lane] = 0;
-      __syncthreads();
-      for (int i = lane; i < nseg; i += 64) {
-        const unsigned sg = s_seg[i];
-        const int y = (int)(sg >> 16), c = (int)(sg & 0xFFFF);
-        if (y >= ylo && y <= yhi) atomicOr(&s_colocc[c >> 6], 1ull << (c & 63));
+  // ---- B4: pool offsets and work-item prefix sums (lane i owns island i; nisl <= 32)
+  if (!fallback) {
+    int pixb = 0, bmw = 0, nst = 0, nbl = 0;
+    if (lane < nisl) {
+      const Island is = s_isl[lane];
+      const int H = is.yhi - is.ylo + 1;
+      const int xhi = min(g.cols - 1, 16 * is.chi + 15);
+      const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64 + 1;
+      const int nbs = is.clast - is.cfirst + 1;
+      pixb = H * 16 * nbs;
+      bmw = (H + 2) * W;
+      nst = H * nbs;
+      nbl = H * (is.chi - is.clo + 1);
+    }
+    int ip = pixb, ib = bmw, is_ = nst, il = nbl;  // inclusive scans
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const int a = __shfl_up(ip, d), b = __shfl_up(ib, d), c = __shfl_up(is_, d), e = __shfl_up(il, d);
+      if (lane >= d) {
+        ip += a;
+        ib += b;
+        is_ += c;
+        il += e;
       }
-      __syncthreads();
+    }
+    if (lane < nisl) {
+      s_isl[lane].pix_off = ip - pixb;
+      s_isl[lane].bm_off = ib - bmw;
+      s_isl[lane].stage_end = is_;
+      s_isl[lane].blur_end = il;
+    }
+    const int tot_pix = __shfl(ip, nisl - 1), tot_bm = __shfl(ib, nisl - 1);
+    fallback = tot_pix > K1B_PIX_POOL || tot_bm > K1B_BM_POOL;
+  }
+  if (fallback) {  // hand the frame to the general kernel
+    if (lane == 0) {
+      out->n = 0;
+      out->status = MPE_FRAME_TOO_MANY_ROWS;  // overwritten by the general kernel
+      if (worklist) {
+        const int k = atomicAdd(&worklist[0], 1);
+        worklist[1 + k] = f;
+      }
+    }
+    return;
+  }
+  __syncthreads();
 
-      // islands: runs of set bits in the occupancy dilated by dc
-      for (int cstart = 0; cstart < spr;) {
-        // find next occupied column >= cstart
-        int cfirst = -1;
-        for (int wi = cstart >> 6; wi < 4 && wi * 64 < spr; ++wi) {
-          u64 w = s_colocc[wi];
-          if (wi == (cstart >> 6)) w &= ~0ull << (cstart & 63);
-          if (w) {
-            cfirst = wi * 64 + __builtin_ctzll(w);
-            break;
-          }
-        }
-        if (cfirst < 0) break;
-        // extend while the gap to the next occupied column is <= 2*dc (dilated runs touch)
-        int clast = cfirst;
-        for (;;) {
-          int nxt = -1;
-          for (int c = clast + 1; c <= min(spr - 1, clast + 2 * dc + 1); ++c)
-            if ((s_colocc[c >> 6] >> (c & 63)) & 1) {
-              nxt = c;
-              break;
-            }
-          if (nxt < 0) break;
-          clast = nxt;
-        }
-        cstart = clast + 2 * dc + 2;
-        const int clo = max(0, cfirst - dc), chi = min(spr - 1, clast + dc);  // output segment columns
+  // ---- C: clear the bitmaps, stage the thresholded pixels of every island (16-byte loads)
+  {
+    const int tot_bm = s_isl[nisl - 1].bm_off +
+                       (s_isl[nisl - 1].yhi - s_isl[nisl - 1].ylo + 3) *
+                           (((min(g.cols - 1, 16 * s_isl[nisl - 1].chi + 15) - 16 * s_isl[nisl - 1].clo + 1) + 2 + 63) / 64 + 1);
+    for (int i = lane; i < tot_bm; i += 64) {
+      s_nz[i] = 0;
+      s_pm[i] = 0;
+      s_ng[i] = 0;
+    }
+    const int tot_stage = s_isl[nisl - 1].stage_end;
+    for (int i = lane; i < tot_stage; i += 64) {
+      int k = 0;
+      while (i >= s_isl[k].stage_end) ++k;
+      const Island is = s_isl[k];
+      const int li = i - (k ? s_isl[k - 1].stage_end : 0);
+      const int nbs = is.clast - is.cfirst + 1;
+      const int yb = li / nbs, sc = li - yb * nbs;
+      uint4 v = *reinterpret_cast<const uint4*>(frame + (size_t)(is.ylo + yb) * g.pitch + 16 * (is.cfirst + sc));
+      v.x = tozero4(v.x, add);
+      v.y = tozero4(v.y, add);
+      v.z = tozero4(v.z, add);
+      v.w = tozero4(v.w, add);
+      *reinterpret_cast<uint4*>(s_pix + is.pix_off + (size_t)yb * 16 * nbs + 16 * sc) = v;
+    }
+  }
+  __syncthreads();
 
-        // ---- island window
-        const int H = yhi - ylo + 1, S = H + 2;
-        const int xw0 = 16 * clo;
-        const int xhi = min(g.cols - 1, 16 * chi + 15);
-        const int W = ((xhi - xw0 + 1) + 2 + 63) / 64 + 1;
-        const int pwc0 = clo - 1, nps = chi - clo + 3, PW = 16 * nps;
-        if (S * W > K1B_BM_CAP || H * PW > K1B_PIX_CAP) {
-          if (lane == 0) s_over = 1;
-          continue;
-        }
-        for (int i = lane; i < S * W; i += 64) {
-          s_nz[i] = 0;
-          s_pm[i] = 0;
-          s_ng[i] = 0;
-        }
-        // stage the thresholded pixels (coalesced 16-byte loads)
-        for (int i = lane; i < H * nps; i += 64) {
-          const int yb = i / nps, sc = i - yb * nps;
-          const int cg = pwc0 + sc;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (cg >= 0 && cg < spr) {
-            v = *reinterpret_cast<const uint4*>(frame + (size_t)(ylo + yb) * g.pitch + 16 * cg);
-            v.x = tozero4(v.x, add);
-            v.y = tozero4(v.y, add);
-            v.z = tozero4(v.z, add);
-            v.w = tozero4(v.w, add);
-          }
-          *reinterpret_cast<uint4*>(s_pix + (size_t)yb * PW + 16 * sc) = v;
-        }
-        __syncthreads();
-        // blurred mask
-        const PixWin pw = {s_pix, ylo, H, pwc0, PW};
-        const int ncols = chi - clo + 1;
-        for (int i = lane; i < H * ncols; i += 64) {
-          const int yb = i / ncols, c = clo + (i - yb * ncols);
-          const int x0 = 16 * c;
-          if (x0 >= g.cols) continue;
-          unsigned m;
-          const bool interior = (x0 - r >= 0) && (x0 + 15 + r < g.cols);
-          if (interior && dp.ksize == 5)
-            m = blur_item_fast<5>(pw, g.rows, g.cols, ylo + yb, c, dp.taps);
-          else if (interior && dp.ksize == 3)
-            m = blur_item_fast<3>(pw, g.rows, g.cols, ylo + yb, c, dp.taps);
-          else
-            m = blur_item_generic(pw, g.rows, g.cols, ylo + yb, c, dp.taps, dp.ksize);
-          if (m) {
-            const int xb0 = x0 - xw0 + 1, wi = xb0 >> 6, shb = xb0 & 63;
-            atomicOr(&s_nz[(size_t)(yb + 1) * W + wi], (u64)m << shb);
-            if (shb > 48) atomicOr(&s_nz[(size_t)(yb + 1) * W + wi + 1], (u64)m >> (64 - shb));
-          }
-        }
-        __syncthreads();
+  // ---- D: blurred mask of every island
+  {
+    const int tot_blur = s_isl[nisl - 1].blur_end;
+    for (int i = lane; i < tot_blur; i += 64) {
+      int k = 0;
+      while (i >= s_isl[k].blur_end) ++k;
+      const Island is = s_isl[k];
+      const int li = i - (k ? s_isl[k - 1].blur_end : 0);
+      const int ncols = is.chi - is.clo + 1;
+      const int yb = li / ncols, c = is.clo + (li - yb * ncols);
+      const int H = is.yhi - is.ylo + 1;
+      const int xhi = min(g.cols - 1, 16 * is.chi + 15);
+      const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64 + 1;
+      const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1)};
+      blur_to_bitmap(pw, g, dp, is.ylo + yb, c, s_nz + is.bm_off + (size_t)(yb + 1) * W, 16 * is.clo);
+    }
+  }
+  __syncthreads();
 
-        // ---- OpenCV's raster scan for external contours (cvFindNextContour, RETR_EXTERNAL);
-        //      sequential by construction: lane 0 walks the island's bitmap rows in raster order
-        if (lane == 0) {
-          int nk = s_nkept;
-          for (int slot = 1; slot <= H; ++slot) {
-            u64* nzrow = s_nz + (size_t)slot * W;
-            u64* pmrow = s_pm + (size_t)slot * W;
-            u64* ngrow = s_ng + (size_t)slot * W;
-            int last_sign = 0;  // sign of the nearest marked pixel to the left (lnbd), 0 = none yet
-            for (int w = 0; w < W - 1; ++w) {
-              const u64 nzw = nzrow[w];
-              if (!nzw) continue;
-              const u64 leftnz = (nzw << 1) | (w ? (nzrow[w - 1] >> 63) : 0);
-              u64 done = 0;
-              for (;;) {
-                const u64 pw_ = pmrow[w], gw = ngrow[w];
-                const u64 cand = nzw & ~(pw_ | gw) & ~leftnz & ~done;  // unmarked 1 with a 0 on its left
-                if (!cand) break;
-                const int bb = __builtin_ctzll(cand);
-                done |= (bb == 63) ? ~0ull : ((2ull << bb) - 1);
-                const u64 below = (pw_ | gw) & ((1ull << bb) - 1);
-                int sign = last_sign;
-                if (below) {
-                  const int hb = 63 - __builtin_clzll(below);
-                  sign = ((gw >> hb) & 1) ? -1 : 1;
-                }
-                if (sign > 0) continue;  // inside an already traced outer border: not external
-                PolyAcc acc;
-                const int xb = w * 64 + bb;
-                if (!trace_outer_border(s_nz, s_pm, s_ng, W, slot, xb, xw0 - 1, ylo - 1, acc)) s_over = 1;
-                BlobRec br;
-                br.a00 = acc.a00;
-                br.a10 = acc.a10;
-                br.a01 = acc.a01;
-                br.xmin = acc.xmin;
-                br.xmax = acc.xmax;
-                br.ymin = acc.ymin;
-                br.ymax = acc.ymax;
-                float mcx, mcy;
-                if (blob_filter(br, dp, mcx, mcy)) {
-                  if (nk < K1B_KEPT_CAP) {
-                    s_kx[nk] = mcx;
-                    s_ky[nk] = mcy;
-                    s_kkey[nk] = ((unsigned)(ylo + slot - 1) << 12) | (unsigned)(xb + xw0 - 1);
+  // ---- E: lane i scans island i (the islands are independent, see the header comment)
+  if (lane < nisl) {
+    const Island is = s_isl[lane];
+    const int H = is.yhi - is.ylo + 1;
+    const int xhi = min(g.cols - 1, 16 * is.chi + 15);
+    const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64 + 1;
+    scan_window(s_nz + is.bm_off, s_pm + is.bm_off, s_ng + is.bm_off, W, H, is.ylo, 16 * is.clo, dp, &s_over,
+                [&](float mcx, float mcy, unsigned key) {
+                  const int k = atomicAdd(&s_nkept, 1);
+                  if (k < K1B_KEPT_CAP) {
+                    s_kx[k] = mcx;
+                    s_ky[k] = mcy;
+                    s_kkey[k] = key;
                   }
-                  ++nk;
-                }
-              }
-              const u64 mk = pmrow[w] | ngrow[w];
-              if (mk) {
-                const int hb = 63 - __builtin_clzll(mk);
-                last_sign = ((ngrow[w] >> hb) & 1) ? -1 : 1;
-              }
-            }
-          }
-          s_nkept = nk;
+                });
+  }
+  __syncthreads();
+  write_detections(s_kx, s_ky, s_kkey, s_nkept, K1B_KEPT_CAP, s_over, dp, out, lane);
+}
+
+// =============================================================================================
+// K1b general path: frames the fast path handed over (too many bright segments / rows for its
+// LDS pools).  One wave per frame, whole-frame window in a global scratch slab: thresholded copy
+// of the frame, three full-frame bitmaps and a segment todo bitset.  Slow but exact on any frame.
+// =============================================================================================
+#define K1B_GEN_KEPT 512
+
+__host__ __device__ inline size_t k1b_gen_scratch_bytes(const FrameGeom& g) {
+  const size_t pix = (size_t)g.rows * g.pitch;
+  const size_t bm = (size_t)(g.rows + 2) * g.wb * 8;
+  const size_t todo = (size_t)g.rows * g.tw * 8;
+  const size_t kept = (size_t)K1B_GEN_KEPT * 12;
+  return ((pix + 3 * bm + todo + kept + 255) / 256) * 256;
+}
+
+__global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
+                                                 FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
+                                                 const int* __restrict__ worklist, uint8_t* __restrict__ scratch) {
+  __shared__ int s_nkept, s_over;
+  const int lane = threadIdx.x;
+  const int count = worklist[0];
+  const size_t slab = k1b_gen_scratch_bytes(g);
+  uint8_t* base = scratch + (size_t)blockIdx.x * slab;
+  uint8_t* pix = base;
+  const size_t bm_words = (size_t)(g.rows + 2) * g.wb;
+  u64* nz = reinterpret_cast<u64*>(base + (size_t)g.rows * g.pitch);
+  u64* pm = nz + bm_words;
+  u64* ng = pm + bm_words;
+  u64* todo = ng + bm_words;
+  float* kx = reinterpret_cast<float*>(todo + (size_t)g.rows * g.tw);
+  float* ky = kx + K1B_GEN_KEPT;
+  unsigned* kkey = reinterpret_cast<unsigned*>(ky + K1B_GEN_KEPT);
+  const int r = dp.ksize / 2;
+  const int dc = (r + 15) / 16;
+  const int spr = g.segs_per_row;
+  const unsigned add = (unsigned)(255 - dp.thr) * 0x00010001u;
+
+  for (int wi = blockIdx.x; wi < count; wi += gridDim.x) {
+    const int f = worklist[1 + wi];
+    const uint8_t* frame = frames + (size_t)f * g.rows * g.pitch;
+    if (lane == 0) {
+      s_nkept = 0;
+      s_over = 0;
+    }
+    for (size_t i = lane; i < bm_words; i += 64) {
+      nz[i] = 0;
+      pm[i] = 0;
+      ng[i] = 0;
+    }
+    for (size_t i = lane; i < (size_t)g.rows * g.tw; i += 64) todo[i] = 0;
+    // thresholded copy of the frame
+    for (size_t i = lane; i < (size_t)g.rows * spr; i += 64) {
+      uint4 v = *reinterpret_cast<const uint4*>(frame + i * 16);
+      v.x = tozero4(v.x, add);
+      v.y = tozero4(v.y, add);
+      v.z = tozero4(v.z, add);
+      v.w = tozero4(v.w, add);
+      *reinterpret_cast<uint4*>(pix + i * 16) = v;
+    }
+    __syncthreads();
+    // todo segments: neighbourhood of every bright segment
+    {
+      const size_t G0 = (size_t)f * g.segs_per_frame;
+      const int nwin = (g.segs_per_frame + 63) >> 6;
+      const size_t w0 = G0 >> 6;
+      const int sh = (int)(G0 & 63);
+      for (int i = lane; i < nwin; i += 64) {
+        const u64 a = flags[w0 + i], b = flags[w0 + i + 1];
+        u64 v = sh ? ((a >> sh) | (b << (64 - sh))) : a;
+        const int rem = g.segs_per_frame - i * 64;
+        if (rem < 64) v &= (1ull << rem) - 1;
+        while (v) {
+          const int s = i * 64 + __builtin_ctzll(v);
+          v &= v - 1;
+          const int y0 = s / spr, c0 = s - y0 * spr;
+          for (int yy = max(0, y0 - r); yy <= min(g.rows - 1, y0 + r); ++yy)
+            for (int cc = max(0, c0 - dc); cc <= min(spr - 1, c0 + dc); ++cc)
+              atomicOr(&todo[(size_t)yy * g.tw + (cc >> 6)], 1ull << (cc & 63));
         }
-        __syncthreads();
-      }  // islands
-      if (crosses) {
-        // the band continued into later words: drop its rows from them so they are not revisited
-        for (int wi = rwi + 1; wi <= (yhi >> 6) && wi < g.rw; ++wi) {
-          const int last = min(yhi, wi * 64 + 63) - wi * 64;
-          const u64 m = last == 63 ? ~0ull : ((2ull << last) - 1);
-          if (lane == 0) s_rowact[wi] &= ~m;
-        }
-        __syncthreads();
       }
     }
-  }
-
-  // ---- C: output in OpenCV's contour order (newest first = descending raster order of the
-  //         start pixel), float32 centroid -> undistortPoints
-  const int nk_all = s_nkept;
-  const int nk = min(nk_all, K1B_KEPT_CAP);
-  if (lane < nk) {
-    const unsigned key = s_kkey[lane];
-    int pos = 0;
-    for (int j = 0; j < nk; ++j) pos += (s_kkey[j] > key) ? 1 : 0;
-    if (pos < MPE_MAX_DETECTIONS) {
-      const float mcx = s_kx[lane], mcy = s_ky[lane];
-      float ux, uy;
-      undistort_point(mcx, mcy, dp, ux, uy);
-      out->dist_xy[2 * pos] = mcx;
-      out->dist_xy[2 * pos + 1] = mcy;
-      out->undist_xy[2 * pos] = (double)ux;
-      out->undist_xy[2 * pos + 1] = (double)uy;
+    __threadfence_block();
+    __syncthreads();
+    // blur
+    const PixWin pw = {pix, 0, g.rows, 0, g.pitch};
+    for (int y = lane; y < g.rows; y += 64)
+      for (int tw = 0; tw < g.tw; ++tw) {
+        u64 tb = todo[(size_t)y * g.tw + tw];
+        while (tb) {
+          const int c = tw * 64 + __builtin_ctzll(tb);
+          tb &= tb - 1;
+          blur_to_bitmap(pw, g, dp, y, c, nz + (size_t)(y + 1) * g.wb, 0);
+        }
+      }
+    __threadfence_block();
+    __syncthreads();
+    if (lane == 0) {
+      int nk = 0;
+      scan_window(nz, pm, ng, g.wb, g.rows, 0, 0, dp, &s_over, [&](float mcx, float mcy, unsigned key) {
+        if (nk < K1B_GEN_KEPT) {
+          kx[nk] = mcx;
+          ky[nk] = mcy;
+          kkey[nk] = key;
+        }
+        ++nk;
+      });
+      s_nkept = nk;
     }
-  }
-  if (lane == 0) {
-    out->n = min(nk_all, MPE_MAX_DETECTIONS);
-    int st = 0;
-    if (nk_all > MPE_MAX_DETECTIONS) st = MPE_FRAME_TOO_MANY_DETECTIONS;
-    if (s_over) st = MPE_FRAME_TOO_MANY_ROWS;
-    out->status = st;
+    __threadfence_block();
+    __syncthreads();
+    write_detections(kx, ky, kkey, s_nkept, K1B_GEN_KEPT, s_over, dp, dets + f, lane);
+    __syncthreads();
   }
 }
 
-size_t k1b_lds_bytes(const FrameGeom&) { return 0; }
+#define K1B_GEN_BLOCKS 32
+size_t k1b_scratch_bytes(const FrameGeom& g) { return k1b_gen_scratch_bytes(g) * K1B_GEN_BLOCKS; }
 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
-                            const DetectParams& dp, mpe_detections* dets, hipStream_t s) {
+                            const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
+                            hipStream_t s) {
   if (n_frames <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k1b_blobs, dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets);
+  hipError_t e = hipMemsetAsync(worklist, 0, sizeof(int), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k1b_blobs, dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets, worklist);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k1b_general, dim3(K1B_GEN_BLOCKS), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
+                     (const int*)worklist, scratch);
   return hipGetLastError();
 }
 
@@ -717,21 +951,107 @@ __device__ __forceinline__ double pick_root(const P3PCtx& c, int k) {
   return k == 0 ? c.root[0] : (k == 1 ? c.root[1] : (k == 2 ? c.root[2] : c.root[3]));
 }
 #define K2_THREADS 256
-__global__ __launch_bounds__(K2_THREADS) void k2_vote(const mpe_detections* __restrict__ dets, SolveParams sp,
-                                                      uint32_t* __restrict__ hist, int splits) {
+#define K2_TRI_CHUNK 64  // detection triples staged in LDS per pass
+
+// ---- marker-permutation table (frame independent) -------------------------------------------
+// One entry per ordered marker triple (P1,P2,P3), in the reference's permutation order
+// (combinations.cpp:131-244).  Holds everything of P3P::computePoses that depends on the world
+// points only (p3p.cpp:124-141): the eta frame N, P1, p_1, p_2, d_12, the collinearity verdict,
+// and the unused markers expressed in the eta frame, N (m - P1), ascending marker index.
+//   [0..8] N rows, [9..11] P1, [12] p_1, [13] p_2, [14] d_12, [15] valid (1/0), [16 + 3u ..] m_eta[u]
+__host__ __device__ inline int k2_entry_doubles(int n_m) { return 16 + 3 * (n_m - 3); }
+
+__device__ __forceinline__ void perm_from_index(int pj, int n_m, int& p0, int& p1, int& p2) {
+  int ma, mb, mc;
+  unrank_combo3(pj / 6, n_m, ma, mb, mc);
+  switch (pj % 6) {  // block rows [c b a],[c a b],[b c a],[b a c],[a b c],[a c b]
+    case 0: p0 = mc; p1 = mb; p2 = ma; break;
+    case 1: p0 = mc; p1 = ma; p2 = mb; break;
+    case 2: p0 = mb; p1 = mc; p2 = ma; break;
+    case 3: p0 = mb; p1 = ma; p2 = mc; break;
+    case 4: p0 = ma; p1 = mb; p2 = mc; break;
+    default: p0 = ma; p1 = mc; p2 = mb; break;
+  }
+}
+
+__global__ void k2_prep_markers(SolveParams sp, double* __restrict__ tab) {
+  const int n_m = sp.n_markers;
+  const int n_perms = n_m * (n_m - 1) * (n_m - 2);
+  const int esz = k2_entry_doubles(n_m);
+  for (int pj = blockIdx.x * blockDim.x + threadIdx.x; pj < n_perms; pj += gridDim.x * blockDim.x) {
+    int p0, p1, p2;
+    perm_from_index(pj, n_m, p0, p1, p2);
+    const V3 P1 = {sp.markers[3 * p0], sp.markers[3 * p0 + 1], sp.markers[3 * p0 + 2]};
+    const V3 P2 = {sp.markers[3 * p1], sp.markers[3 * p1 + 1], sp.markers[3 * p1 + 2]};
+    const V3 P3 = {sp.markers[3 * p2], sp.markers[3 * p2 + 1], sp.markers[3 * p2 + 2]};
+    double* e = tab + (size_t)pj * esz;
+    const bool valid = norm(cross(P2 - P1, P3 - P1)) != 0.0;  // p3p.cpp:77-80
+    V3 n1 = P2 - P1;
+    n1 = vdiv(n1, norm(n1));
+    V3 n3 = cross(n1, P3 - P1);
+    n3 = vdiv(n3, norm(n3));
+    const V3 n2 = cross(n3, n1);
+    const M3 N = {n1, n2, n3};
+    const V3 P3n = mul(N, P3 - P1);
+    e[0] = n1.x; e[1] = n1.y; e[2] = n1.z;
+    e[3] = n2.x; e[4] = n2.y; e[5] = n2.z;
+    e[6] = n3.x; e[7] = n3.y; e[8] = n3.z;
+    e[9] = P1.x; e[10] = P1.y; e[11] = P1.z;
+    e[12] = P3n.x;
+    e[13] = P3n.y;
+    e[14] = norm(P2 - P1);
+    e[15] = valid ? 1.0 : 0.0;
+    int u = 0;
+    for (int m = 0; m < n_m; ++m) {
+      if (m == p0 || m == p1 || m == p2) continue;
+      const V3 mm = {sp.markers[3 * m], sp.markers[3 * m + 1], sp.markers[3 * m + 2]};
+      const V3 me = mul(N, mm - P1);
+      e[16 + 3 * u] = me.x;
+      e[16 + 3 * u + 1] = me.y;
+      e[16 + 3 * u + 2] = me.z;
+      ++u;
+    }
+  }
+}
+
+hipError_t launch_k2_prep(const SolveParams& sp, double* tab, hipStream_t s) {
+  if (sp.n_markers < 4) return hipSuccess;
+  const int n_perms = sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2);
+  hipLaunchKernelGGL(k2_prep_markers, dim3((n_perms + 127) / 128), dim3(128), 0, s, sp, tab);
+  return hipGetLastError();
+}
+size_t k2_table_bytes(int n_markers) {
+  if (n_markers < 4) return 64;
+  return (size_t)n_markers * (n_markers - 1) * (n_markers - 2) * k2_entry_doubles(n_markers) * sizeof(double);
+}
+
+// Voting kernel.  Work item = (detection triple, marker permutation).  Everything that depends
+// only on the detection triple (tau frame T, f_1, f_2, b and the swap of p3p.cpp:100-121) is
+// computed once per triple into LDS; everything that depends only on the marker permutation comes
+// from the table above.  Per item: quartic coefficients (p3p.cpp:171-185), Ferrari, and for each
+// root the back-projection of the unused markers WITHOUT forming [R|C]:
+//     X_cam = R^T (m - C) = T^T Rm (N (m - P1) - C_eta),   Rm = the matrix of p3p.cpp:215-224,
+// which is the same point as project2d(m, inverse(H)) of pose_estimator.cpp:660 up to rounding.
+#ifndef K2_MIN_WAVES
+#define K2_MIN_WAVES 3
+#endif
+__global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_detections* __restrict__ dets, SolveParams sp,
+                                                      const double* __restrict__ tab, uint32_t* __restrict__ hist,
+                                                      int splits) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double s_px[MPE_MAX_DETECTIONS][2];
   __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
-  __shared__ double s_mk[MPE_MAX_MARKERS][3];
+  __shared__ double s_tri[K2_TRI_CHUNK][12];  // T rows (9), f_1, f_2, b
+  __shared__ unsigned s_trii[K2_TRI_CHUNK];   // c0 | c1 << 8 | c2 << 16 | swap << 24
   __shared__ unsigned s_hist[MPE_HIST_STRIDE];
 
   const int f = blockIdx.x / splits, part = blockIdx.x - f * splits;
   const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
   const mpe_detections* d = dets + f;
   const int n_d = d->n, n_m = sp.n_markers;
   if (n_d < 4 || d->status != 0 || n_m < 4) return;  // min_num_leds_detected_ (pose_estimator.h:78)
 
-  const int nthr = blockDim.x;
   for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) s_hist[i] = 0;
   if (tid < n_d) {
     const double u = d->undist_xy[2 * tid], v = d->undist_xy[2 * tid + 1];
@@ -742,92 +1062,157 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote(const mpe_detections* __re
     s_iv[tid][1] = b.y;
     s_iv[tid][2] = b.z;
   }
-  if (tid < n_m) {
-    s_mk[tid][0] = sp.markers[3 * tid];
-    s_mk[tid][1] = sp.markers[3 * tid + 1];
-    s_mk[tid][2] = sp.markers[3 * tid + 2];
-  }
   __syncthreads();
 
   double* s_q = reinterpret_cast<double*>(smem);  // back-projections: [2*j + {0,1}][tid]
   const int n_combos = n_d * (n_d - 1) * (n_d - 2) / 6;
-  const int n_mcombos = n_m * (n_m - 1) * (n_m - 2) / 6;
-  const int n_perms = n_mcombos * 6;
-  const long long total = (long long)n_combos * n_perms;
+  const int n_perms = n_m * (n_m - 1) * (n_m - 2);
   const int nuo = n_m - 3;
+  const int esz = k2_entry_doubles(n_m);
+  const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
+  static const unsigned char kSwapRow[6] = {2, 5, 0, 4, 3, 1};  // block row with P1 <-> P2 exchanged
 
-  for (long long t = (long long)part * nthr + tid; t < total; t += (long long)splits * nthr) {
-    const int ci = (int)(t / n_perms), pj = (int)(t - (long long)ci * n_perms);
-    int c0, c1, c2;
-    unrank_combo3(ci, n_d, c0, c1, c2);
-    int ma, mb, mc;
-    unrank_combo3(pj / 6, n_m, ma, mb, mc);
-    // combinations.cpp:131-244: block rows [c b a],[c a b],[b c a],[b a c],[a b c],[a c b]
-    int p0, p1, p2;
-    switch (pj % 6) {
-      case 0: p0 = mc; p1 = mb; p2 = ma; break;
-      case 1: p0 = mc; p1 = ma; p2 = mb; break;
-      case 2: p0 = mb; p1 = mc; p2 = ma; break;
-      case 3: p0 = mb; p1 = ma; p2 = mc; break;
-      case 4: p0 = ma; p1 = mb; p2 = mc; break;
-      default: p0 = ma; p1 = mc; p2 = mb; break;
-    }
-    const V3 fa = {s_iv[c0][0], s_iv[c0][1], s_iv[c0][2]}, fb = {s_iv[c1][0], s_iv[c1][1], s_iv[c1][2]},
-             fc = {s_iv[c2][0], s_iv[c2][1], s_iv[c2][2]};
-    const V3 wa = {s_mk[p0][0], s_mk[p0][1], s_mk[p0][2]}, wb = {s_mk[p1][0], s_mk[p1][1], s_mk[p1][2]},
-             wc = {s_mk[p2][0], s_mk[p2][1], s_mk[p2][2]};
-    P3PCtx ctx;
-    if (!p3p_prepare(fa, fb, fc, wa, wb, wc, ctx)) continue;
-#pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-      M3 R;
-      V3 C;
-      p3p_solution(ctx, pick_root(ctx, k), R, C);
-      if (!rc_finite(R, C)) continue;
-      const Proj P = make_projection(R, C, sp.fx, sp.fy, sp.cx, sp.cy);
-      // back-project the unused markers (ascending marker index)
-      int j = 0;
-      for (int m = 0; m < n_m; ++m) {
-        if (m == p0 || m == p1 || m == p2) continue;
-        double u, v;
-        project(P, V3{s_mk[m][0], s_mk[m][1], s_mk[m][2]}, u, v);
-        s_q[(2 * j) * nthr + tid] = u;
-        s_q[(2 * j + 1) * nthr + tid] = v;
-        ++j;
+  for (int tc0 = 0; tc0 < n_combos; tc0 += K2_TRI_CHUNK) {
+    const int ntri = min(K2_TRI_CHUNK, n_combos - tc0);
+    if (tc0) __syncthreads();
+    // ---- per-triple part of computePoses (p3p.cpp:82-121, 143-154)
+    if (tid < ntri) {
+      int c0, c1, c2;
+      unrank_combo3(tc0 + tid, n_d, c0, c1, c2);
+      const V3 fa = {s_iv[c0][0], s_iv[c0][1], s_iv[c0][2]}, fb = {s_iv[c1][0], s_iv[c1][1], s_iv[c1][2]},
+               fc = {s_iv[c2][0], s_iv[c2][1], s_iv[c2][2]};
+      V3 f1 = fa, f2 = fb;
+      V3 e1 = f1;
+      V3 e3 = cross(f1, f2);
+      e3 = vdiv(e3, norm(e3));
+      V3 e2 = cross(e3, e1);
+      M3 T = {e1, e2, e3};
+      V3 f3 = mul(T, fc);
+      unsigned swap = 0;
+      if (f3.z > 0.0) {
+        swap = 1;
+        f1 = fb;
+        f2 = fa;
+        e1 = f1;
+        e3 = cross(f1, f2);
+        e3 = vdiv(e3, norm(e3));
+        e2 = cross(e3, e1);
+        T = {e1, e2, e3};
+        f3 = mul(T, fc);
       }
-      // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
-      bool any = false;
-      for (int a = 0; a < n_d; ++a) {
-        if (a == c0 || a == c1 || a == c2) continue;
-        const double au = s_px[a][0], av = s_px[a][1];
-        double best = INFINITY;
-        int bj = 0;
-        for (int jj = 0; jj < nuo; ++jj) {
-          const double du = au - s_q[(2 * jj) * nthr + tid], dv = av - s_q[(2 * jj + 1) * nthr + tid];
-          const double d2 = du * du + dv * dv;
-          if (d2 < best) {
-            best = d2;
-            bj = jj;
-          }
+      const double cos_beta = dot(f1, f2);
+      double b = 1 / (1 - cos_beta * cos_beta) - 1;
+      b = (cos_beta < 0) ? -sqrt(b) : sqrt(b);
+      double* t = s_tri[tid];
+      t[0] = T.r0.x; t[1] = T.r0.y; t[2] = T.r0.z;
+      t[3] = T.r1.x; t[4] = T.r1.y; t[5] = T.r1.z;
+      t[6] = T.r2.x; t[7] = T.r2.y; t[8] = T.r2.z;
+      t[9] = f3.x / f3.z;
+      t[10] = f3.y / f3.z;
+      t[11] = b;
+      s_trii[tid] = (unsigned)c0 | ((unsigned)c1 << 8) | ((unsigned)c2 << 16) | (swap << 24);
+    }
+    __syncthreads();
+
+    const long long total = (long long)ntri * n_perms;
+    for (long long t = (long long)part * nthr + tid; t < total; t += (long long)splits * nthr) {
+      const int ti = (int)(t / n_perms), pj = (int)(t - (long long)ti * n_perms);
+      const unsigned ii = s_trii[ti];
+      const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
+      const bool swap = (ii >> 24) & 1;
+      int p0, p1, p2;
+      perm_from_index(pj, n_m, p0, p1, p2);
+      const int pjs = swap ? (pj - pj % 6 + kSwapRow[pj % 6]) : pj;
+      const double* e = tab + (size_t)pjs * esz;
+      if (e[15] == 0.0) continue;  // collinear world points: computePoses returns -1
+      const double p_1 = e[12], p_2 = e[13], d_12 = e[14];
+      const double* tr = s_tri[ti];
+      const double f_1 = tr[9], f_2 = tr[10], b = tr[11];
+
+      const double f_1_pw2 = f_1 * f_1, f_2_pw2 = f_2 * f_2;
+      const double p_1_pw2 = p_1 * p_1, p_1_pw3 = p_1_pw2 * p_1, p_1_pw4 = p_1_pw3 * p_1;
+      const double p_2_pw2 = p_2 * p_2, p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2;
+      const double d_12_pw2 = d_12 * d_12, b_pw2 = b * b;
+      const double F0 = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
+      const double F1 = 2 * p_2_pw3 * d_12 * b + 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * f_2 * p_2_pw3 * f_1 * d_12;
+      const double F2 = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 -
+                        f_2_pw2 * p_2_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw4 + p_2_pw4 * f_1_pw2 +
+                        2 * p_1 * p_2_pw2 * d_12 + 2 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b -
+                        p_2_pw2 * p_1_pw2 * f_1_pw2 + 2 * p_1 * p_2_pw2 * f_2_pw2 * d_12 -
+                        p_2_pw2 * d_12_pw2 * b_pw2 - 2 * p_1_pw2 * p_2_pw2;
+      const double F3 = 2 * p_1_pw2 * p_2 * d_12 * b + 2 * f_2 * p_2_pw3 * f_1 * d_12 -
+                        2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * p_1 * p_2 * d_12_pw2 * b;
+      const double F4 = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 +
+                        2 * p_1_pw3 * d_12 - p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 -
+                        2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 + p_2_pw2 * f_1_pw2 * p_1_pw2 +
+                        f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
+      double root[4];
+      solve_quartic(F0, F1, F2, F3, F4, root);
+
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {
+        const double rt = k == 0 ? root[0] : (k == 1 ? root[1] : (k == 2 ? root[2] : root[3]));
+        // back-substitution, p3p.cpp:193-213
+        const double cot_alpha = (-f_1 * p_1 / f_2 - rt * p_2 + d_12 * b) / (-f_1 * rt * p_2 / f_2 + p_1 - d_12);
+        const double cos_theta = rt;
+        const double sin_theta = sqrt(1 - rt * rt);
+        const double sin_alpha = sqrt(1 / (cot_alpha * cot_alpha + 1));
+        double cos_alpha = sqrt(1 - sin_alpha * sin_alpha);
+        if (cot_alpha < 0) cos_alpha = -cos_alpha;
+        const double kk = sin_alpha * b + cos_alpha;
+        const double Cx = d_12 * cos_alpha * kk, Cy = cos_theta * d_12 * sin_alpha * kk,
+                     Cz = sin_theta * d_12 * sin_alpha * kk;
+        // isFinite([R C]) (pose_estimator.cpp:653): R and C are finite iff these are
+        const double z = (cos_alpha - cos_alpha) + (sin_alpha - sin_alpha) + (sin_theta - sin_theta) +
+                         (cos_theta - cos_theta) + (Cx - Cx) + (Cy - Cy) + (Cz - Cz);
+        if (!(z == 0.0)) continue;
+        const double T00 = tr[0], T01 = tr[1], T02 = tr[2], T10 = tr[3], T11 = tr[4], T12 = tr[5], T20 = tr[6],
+                     T21 = tr[7], T22 = tr[8];
+        for (int j = 0; j < nuo; ++j) {
+          const double v0 = e[16 + 3 * j] - Cx, v1 = e[16 + 3 * j + 1] - Cy, v2 = e[16 + 3 * j + 2] - Cz;
+          const double g = cos_theta * v1 + sin_theta * v2;
+          const double w0 = -cos_alpha * v0 - sin_alpha * g;
+          const double w1 = sin_alpha * v0 - cos_alpha * g;
+          const double w2 = -sin_theta * v1 + cos_theta * v2;
+          const double X = T00 * w0 + T10 * w1 + T20 * w2;  // T^T w
+          const double Y = T01 * w0 + T11 * w1 + T21 * w2;
+          const double Z = T02 * w0 + T12 * w1 + T22 * w2;
+          s_q[(2 * j) * nthr + tid] = (fx * X + cx * Z) / Z;
+          s_q[(2 * j + 1) * nthr + tid] = (fy * Y + cy * Z) / Z;
         }
-        if (sqrt(best) < sp.back_tol) {  // strict <, pose_estimator.cpp:689
-          // bj-th unused marker -> marker index
-          int mi = -1, cnt = -1;
-          for (int m = 0; m < n_m; ++m) {
-            if (m == p0 || m == p1 || m == p2) continue;
-            if (++cnt == bj) {
-              mi = m;
-              break;
+        // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
+        bool any = false;
+        for (int a = 0; a < n_d; ++a) {
+          if (a == c0 || a == c1 || a == c2) continue;
+          const double au = s_px[a][0], av = s_px[a][1];
+          double best = INFINITY;
+          int bj = 0;
+          for (int jj = 0; jj < nuo; ++jj) {
+            const double du = au - s_q[(2 * jj) * nthr + tid], dv = av - s_q[(2 * jj + 1) * nthr + tid];
+            const double d2 = du * du + dv * dv;
+            if (d2 < best) {
+              best = d2;
+              bj = jj;
             }
           }
-          atomicAdd(&s_hist[a * MPE_MAX_MARKERS + mi], 1u);
-          any = true;
+          if (sqrt(best) < sp.back_tol) {  // strict <, pose_estimator.cpp:689
+            int mi = -1, cnt = -1;         // bj-th unused marker -> marker index
+            for (int m = 0; m < n_m; ++m) {
+              if (m == p0 || m == p1 || m == p2) continue;
+              if (++cnt == bj) {
+                mi = m;
+                break;
+              }
+            }
+            atomicAdd(&s_hist[a * MPE_MAX_MARKERS + mi], 1u);
+            any = true;
+          }
         }
-      }
-      if (any) {  // pose_estimator.cpp:676-685
-        atomicAdd(&s_hist[c0 * MPE_MAX_MARKERS + p0], 1u);
-        atomicAdd(&s_hist[c1 * MPE_MAX_MARKERS + p1], 1u);
-        atomicAdd(&s_hist[c2 * MPE_MAX_MARKERS + p2], 1u);
+        if (any) {  // pose_estimator.cpp:676-685
+          atomicAdd(&s_hist[c0 * MPE_MAX_MARKERS + p0], 1u);
+          atomicAdd(&s_hist[c1 * MPE_MAX_MARKERS + p1], 1u);
+          atomicAdd(&s_hist[c2 * MPE_MAX_MARKERS + p2], 1u);
+        }
       }
     }
   }
@@ -839,16 +1224,18 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote(const mpe_detections* __re
   }
 }
 
-hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist, int splits,
-                          int n_det_hint, hipStream_t s) {
-  if (n_frames <= 0) return hipSuccess;
+hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
+                          uint32_t* hist, int splits, int n_det_hint, hipStream_t s) {
+  if (n_frames <= 0 || sp.n_markers < 4) return hipSuccess;
   if (splits < 1) splits = 1;
-  const int nuo = sp.n_markers > 3 ? sp.n_markers - 3 : 1;
+  const int nuo = sp.n_markers - 3;
   // block size: the multiple of 64 (<= 256) that wastes the fewest lanes on the expected item count
   int threads = K2_THREADS;
   if (n_det_hint >= 4) {
     const long long nm = sp.n_markers;
-    const long long items = (long long)n_det_hint * (n_det_hint - 1) * (n_det_hint - 2) / 6 * nm * (nm - 1) * (nm - 2);
+    long long ntri = (long long)n_det_hint * (n_det_hint - 1) * (n_det_hint - 2) / 6;
+    if (ntri > K2_TRI_CHUNK) ntri = K2_TRI_CHUNK;
+    const long long items = ntri * nm * (nm - 1) * (nm - 2);
     double best = 1e30;
     for (int t = 64; t <= K2_THREADS; t += 64) {
       const long long per = (items + (long long)splits * t - 1) / ((long long)splits * t);
@@ -860,7 +1247,8 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
     }
   }
   const size_t lds = (size_t)nuo * 2 * threads * sizeof(double);
-  hipLaunchKernelGGL(k2_vote, dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, hist, splits);
+  hipLaunchKernelGGL(k2_vote, dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
+                     splits);
   return hipGetLastError();
 }
 

@@ -112,12 +112,28 @@ def test_find_leds_roi(hip, orc):
         assert np.array_equal(do, dh) and np.array_equal(uo, uh)
 
 
-def test_capacity_is_loud(hip):
-    """A fully bright frame exceeds the LDS row capacity: reported per frame, never silent."""
+def test_pathological_frames_take_the_general_path(hip, orc):
+    """Frames that overflow the fast kernel's LDS pools (fully bright, dense salt noise, one huge
+    ring around the LEDs) are re-done by the general kernel — same results as the oracle."""
     K, D = synth.camera_for(480, 752)
-    frames = np.full((1, 480, 752), 255, np.uint8)
-    got = hip.detect_batch(frames, K, D, mpe.demo_params())
-    assert got["status"][0] < 0
+    Po, Ph = orc.make_params(), mpe.demo_params()
+    rng = np.random.default_rng(6)
+    frames = np.zeros((4, 480, 752), np.uint8)
+    frames[0] = 255
+    frames[1] = (rng.random((480, 752)) > 0.99).astype(np.uint8) * 200
+    d = synth.make_frames("C2", 2, seed=31)
+    frames[2] = d["frames"][0]
+    yy, xx = np.mgrid[0:480, 0:752]
+    ring = np.abs(np.hypot(xx - 376, yy - 240) - 230) < 3       # a bright ring enclosing every LED:
+    frames[2][ring] = 250                                         # RETR_EXTERNAL drops what is inside
+    frames[3] = d["frames"][1]
+    frames[3][::7, ::5] = np.maximum(frames[3][::7, ::5], 180)    # LEDs inside a dense dot grid
+    got = hip.detect_batch(frames, K, D, Ph)
+    for i in range(len(frames)):
+        und, dist = orc.find_leds(frames[i], Po, K, D)
+        assert got["status"][i] == 0, i
+        assert got["n"][i] == len(und), (i, got["n"][i], len(und))
+        assert np.array_equal(got["dist_xy"][i][:2 * len(und)].reshape(-1, 2), dist), i
 
 
 def test_pose_estimator_facade(hip, orc):
