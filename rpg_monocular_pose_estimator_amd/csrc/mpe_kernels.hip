@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double s_px[MPE_MAX_DETECTIONS][2];
   __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
-  __shared__ double s_tri[K2_TRI_CHUNK][12];  // T rows (9), f_1, f_2, b
+  __shared__ double s_tri[K2_TRI_CHUNK][13];  // T rows (9), f_1, f_2, b, f_1/f_2
   __shared__ unsigned s_trii[K2_TRI_CHUNK];   // c0 | c1 << 8 | c2 << 16 | swap << 24
   __shared__ unsigned s_hist[MPE_HIST_STRIDE];
 
@@ -1110,6 +1110,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
       t[9] = f3.x / f3.z;
       t[10] = f3.y / f3.z;
       t[11] = b;
+      t[12] = t[9] / t[10];
       s_trii[tid] = (unsigned)c0 | ((unsigned)c1 << 8) | ((unsigned)c2 << 16) | (swap << 24);
     }
     __syncthreads();
@@ -1127,7 +1128,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
       if (e[15] == 0.0) continue;  // collinear world points: computePoses returns -1
       const double p_1 = e[12], p_2 = e[13], d_12 = e[14];
       const double* tr = s_tri[ti];
-      const double f_1 = tr[9], f_2 = tr[10], b = tr[11];
+      const double f_1 = tr[9], f_2 = tr[10], b = tr[11], f12 = tr[12];
 
       const double f_1_pw2 = f_1 * f_1, f_2_pw2 = f_2 * f_2;
       const double p_1_pw2 = p_1 * p_1, p_1_pw3 = p_1_pw2 * p_1, p_1_pw4 = p_1_pw3 * p_1;
@@ -1147,13 +1148,16 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
                         2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 + p_2_pw2 * f_1_pw2 * p_1_pw2 +
                         f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
       double root[4];
-      solve_quartic(F0, F1, F2, F3, F4, root);
+      solve_quartic_fast(F0, F1, F2, F3, F4, root);
+      // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
+      const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
+      const double tol2 = sp.back_tol * sp.back_tol;
 
 #pragma unroll 1
       for (int k = 0; k < 4; ++k) {
         const double rt = k == 0 ? root[0] : (k == 1 ? root[1] : (k == 2 ? root[2] : root[3]));
         // back-substitution, p3p.cpp:193-213
-        const double cot_alpha = (-f_1 * p_1 / f_2 - rt * p_2 + d_12 * b) / (-f_1 * rt * p_2 / f_2 + p_1 - d_12);
+        const double cot_alpha = (g1 - rt * p_2) / (g2 * rt + g3);
         const double cos_theta = rt;
         const double sin_theta = sqrt(1 - rt * rt);
         const double sin_alpha = sqrt(1 / (cot_alpha * cot_alpha + 1));
@@ -1177,8 +1181,9 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           const double X = T00 * w0 + T10 * w1 + T20 * w2;  // T^T w
           const double Y = T01 * w0 + T11 * w1 + T21 * w2;
           const double Z = T02 * w0 + T12 * w1 + T22 * w2;
-          s_q[(2 * j) * nthr + tid] = (fx * X + cx * Z) / Z;
-          s_q[(2 * j + 1) * nthr + tid] = (fy * Y + cy * Z) / Z;
+          const double iZ = 1.0 / Z;
+          s_q[(2 * j) * nthr + tid] = (fx * X + cx * Z) * iZ;
+          s_q[(2 * j + 1) * nthr + tid] = (fy * Y + cy * Z) * iZ;
         }
         // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
         bool any = false;
@@ -1195,7 +1200,11 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
               bj = jj;
             }
           }
-          if (sqrt(best) < sp.back_tol) {  // strict <, pose_estimator.cpp:689
+          // sqrt(best) < tol (strict, pose_estimator.cpp:689) decided on the squares; the square
+          // root is only taken inside the rounding band around tol^2
+          bool within = best < tol2 * (1.0 - 1e-14);
+          if (!within && best < tol2 * (1.0 + 1e-14)) within = sqrt(best) < sp.back_tol;
+          if (within) {
             int mi = -1, cnt = -1;         // bj-th unused marker -> marker index
             for (int m = 0; m < n_m; ++m) {
               if (m == p0 || m == p1 || m == p2) continue;
@@ -1399,9 +1408,15 @@ __device__ __forceinline__ double group_sum(double v) {
 __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__ dets,
                                               const uint32_t* __restrict__ hist, int n_frames, SolveParams sp,
                                               mpe_result* __restrict__ results, uint32_t* __restrict__ corr_out) {
-  __shared__ double s_part[K3_FRAMES_PER_BLOCK][K3_GROUP][MPE_MAX_MARKERS * 3];
+  // dynamic LDS, sized for the actual marker count: partial sums [4][16][3 n_m] and
+  // back-projections [2 (n_m - 3)][64]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  const int nm3 = 3 * sp.n_markers;
+  double* s_part_ = reinterpret_cast<double*>(smem3);
+  double* s_q_ = s_part_ + K3_FRAMES_PER_BLOCK * K3_GROUP * nm3;
+#define s_part(g_, l_, i_) s_part_[((g_)*K3_GROUP + (l_)) * nm3 + (i_)]
+#define s_q(j_, t_) s_q_[(j_)*64 + (t_)]
   __shared__ double s_mean[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS * 3];
-  __shared__ double s_q[2 * K3_NU_MAX][64];  // back-projections, [2*j + {0,1}][lane]
   __shared__ double s_det[K3_FRAMES_PER_BLOCK][MPE_MAX_DETECTIONS][2];
   __shared__ double s_mk[MPE_MAX_MARKERS][3];
   __shared__ unsigned s_valid[K3_FRAMES_PER_BLOCK][K3_GROUP];
@@ -1435,7 +1450,7 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
     if (corr_out)
       for (int i = l; i < 2 * MPE_MAX_MARKERS; i += K3_GROUP) corr_out[(size_t)f * 2 * MPE_MAX_MARKERS + i] = 0;
   }
-  for (int i = 0; i < 3 * MPE_MAX_MARKERS; ++i) s_part[grp][l][i] = 0.0;
+  for (int i = 0; i < nm3; ++i) s_part(grp, l, i) = 0.0;
 
   // ---- lane 0 of the group: initialise()'s all-zero test (pose_estimator.cpp:704) and
   //      correspondencesFromHistogram (pose_estimator.cpp:344-370)
@@ -1527,8 +1542,8 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
         const int mi = s_cm[grp][row] - 1;
         double u, v;
         project(P, V3{s_mk[mi][0], s_mk[mi][1], s_mk[mi][2]}, u, v);
-        s_q[2 * q][tid] = u;
-        s_q[2 * q + 1][tid] = v;
+        s_q(2 * q, tid) = u;
+        s_q(2 * q + 1, tid) = v;
       }
       // calculateSquaredReprojectionErrorAndCertainty (pose_estimator.cpp:303-342): greedy
       // global-minimum matching, column-major first minimum, rows = image points
@@ -1540,7 +1555,7 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
         int ri = 0, cj0 = 0;
         bool first = true;
         for (int cj = 0; cj < nu; ++cj) {
-          const double bu = s_q[2 * cj][tid], bv = s_q[2 * cj + 1][tid];
+          const double bu = s_q(2 * cj, tid), bv = s_q(2 * cj + 1, tid);
           for (int rr = 0; rr < nu; ++rr) {
             double v;
             if (((rowdone >> rr) & 1) || ((coldone >> cj) & 1))
@@ -1589,17 +1604,17 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
     for (int jj = 0; jj < n_m; ++jj) {
       const V3 mk = {s_mk[jj][0] - C.x, s_mk[jj][1] - C.y, s_mk[jj][2] - C.z};
       const V3 pc = mulT(R, mk);  // R^T (m - C)
-      s_part[grp][l][3 * jj] += pc.x;
-      s_part[grp][l][3 * jj + 1] += pc.y;
-      s_part[grp][l][3 * jj + 2] += pc.z;
+      s_part(grp, l, 3 * jj) += pc.x;
+      s_part(grp, l, 3 * jj + 1) += pc.y;
+      s_part(grp, l, 3 * jj + 2) += pc.z;
     }
   }
   s_valid[grp][l] = my_valid;
   __syncthreads();
   // ordered reduction over the lanes (= combination order while C(n_c,3) <= 16)
-  for (int v = l; v < 3 * MPE_MAX_MARKERS; v += K3_GROUP) {
+  for (int v = l; v < nm3; v += K3_GROUP) {
     double sacc = 0.0;
-    for (int q = 0; q < K3_GROUP; ++q) sacc += s_part[grp][q][v];
+    for (int q = 0; q < K3_GROUP; ++q) sacc += s_part(grp, q, v);
     s_mean[grp][v] = sacc;
   }
   unsigned num_valid = 0;
@@ -1731,10 +1746,14 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
   }
 }
 
+#undef s_part
+#undef s_q
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
                           mpe_result* results, uint32_t* corr_out, hipStream_t s) {
   if (n_frames <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k3_tail, dim3((n_frames + K3_FRAMES_PER_BLOCK - 1) / K3_FRAMES_PER_BLOCK), dim3(64), 0, s, dets,
+  const int nu = sp.n_markers > 3 ? sp.n_markers - 3 : 1;
+  const size_t lds = ((size_t)K3_FRAMES_PER_BLOCK * K3_GROUP * 3 * sp.n_markers + (size_t)2 * nu * 64) * sizeof(double);
+  hipLaunchKernelGGL(k3_tail, dim3((n_frames + K3_FRAMES_PER_BLOCK - 1) / K3_FRAMES_PER_BLOCK), dim3(64), lds, s, dets,
                      hist, n_frames, sp, results, corr_out);
   return hipGetLastError();
 }

@@ -142,6 +142,72 @@ __device__ __forceinline__ void solve_quartic(double A, double B, double C, doub
   rr[3] = off + 0.5 * (-w.re - s2.re);
 }
 
+// ---- voting-kernel variant of the quartic ------------------------------------------------------
+// Same algorithm and branches as solve_quartic above; the eleven real divisions by A, A^2.. and by
+// the constants 12, 27, 108, 6 are folded into one reciprocal and multiplications, and |z| is
+// sqrt(re^2 + im^2) without hypot's range scaling.  Results differ from solve_quartic by rounding
+// only (a few ulp on the coefficients of the depressed quartic).
+__device__ __forceinline__ double hypot_fast(double a, double b) { return sqrt(a * a + b * b); }
+__device__ __forceinline__ C2 csqrt_fast(C2 z) {
+  if (z.im == 0.0) {
+    if (z.re < 0.0) return {0.0, copysign(sqrt(-z.re), z.im)};
+    return {fabs(sqrt(z.re)), z.im};
+  }
+  const double d = hypot_fast(z.re, z.im);
+  double r, s;
+  if (z.re > 0.0) {
+    r = sqrt(0.5 * (d + z.re));
+    s = 0.5 * (z.im / r);
+  } else {
+    s = sqrt(0.5 * (d - z.re));
+    r = fabs(0.5 * (z.im / s));
+  }
+  return {r, copysign(s, z.im)};
+}
+__device__ __forceinline__ C2 cpow_third_fast(C2 z) {
+  if (z.im == 0.0 && z.re > 0.0) return {cbrt(z.re), 0.0};
+  const double rho = cbrt(hypot_fast(z.re, z.im));
+  const double phi = (1.0 / 3.0) * atan2(z.im, z.re);
+  double s, c;
+  sincos(phi, &s, &c);
+  return {rho * c, rho * s};
+}
+__device__ __forceinline__ void solve_quartic_fast(double A, double B, double C, double D, double E, double rr[4]) {
+  const double iA = 1.0 / A;
+  const double b1 = B * iA, c1 = C * iA, d1 = D * iA, e1 = E * iA;  // monic coefficients
+  const double b2 = b1 * b1;
+  const double alpha = -0.375 * b2 + c1;
+  const double beta = 0.125 * b2 * b1 - 0.5 * b1 * c1 + d1;
+  const double gamma = -0.01171875 * b2 * b2 + 0.0625 * b2 * c1 - 0.25 * b1 * d1 + e1;
+  const double alpha_pw2 = alpha * alpha, alpha_pw3 = alpha_pw2 * alpha;
+  const double Pr = -alpha_pw2 * (1.0 / 12.0) - gamma;
+  const double Qr = -alpha_pw3 * (1.0 / 108.0) + alpha * gamma * (1.0 / 3.0) - (beta * beta) * 0.125;
+  const C2 q2 = cpow2_real(Qr), p3 = cpow3_real(Pr);
+  const C2 disc = {q2.re * 0.25 + p3.re * (1.0 / 27.0), q2.im * 0.25 + p3.im * (1.0 / 27.0)};
+  const C2 sq = csqrt_fast(disc);
+  const C2 R = {-Qr * 0.5 + sq.re, sq.im};
+  const C2 U = cpow_third_fast(R);
+  C2 y;
+  const double a56 = -5.0 * alpha * (1.0 / 6.0);
+  if (U.re == 0.0) {
+    const C2 qc = cpow_third_fast(C2{Qr, 0.0});
+    y = {a56 - qc.re, -qc.im};
+  } else {
+    const C2 t = cdiv(C2{Pr, 0.0}, cscale(U, 3.0));
+    y = {a56 - t.re + U.re, -t.im + U.im};
+  }
+  const C2 w = csqrt_fast(C2{alpha + 2.0 * y.re, 2.0 * y.im});
+  const C2 bw = cdiv(C2{2.0 * beta, 0.0}, w);
+  const C2 base = {3.0 * alpha + 2.0 * y.re, 2.0 * y.im};
+  const C2 s1 = csqrt_fast(C2{-(base.re + bw.re), -(base.im + bw.im)});
+  const C2 s2 = csqrt_fast(C2{-(base.re - bw.re), -(base.im - bw.im)});
+  const double off = -0.25 * b1;
+  rr[0] = off + 0.5 * (w.re + s1.re);
+  rr[1] = off + 0.5 * (w.re - s1.re);
+  rr[2] = off + 0.5 * (-w.re + s2.re);
+  rr[3] = off + 0.5 * (-w.re - s2.re);
+}
+
 // Everything of computePoses that does not depend on the root index.  p3p.cpp:65-190
 struct P3PCtx {
   M3 T, N;

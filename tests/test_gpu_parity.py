@@ -120,7 +120,7 @@ def test_pathological_frames_take_the_general_path(hip, orc):
     rng = np.random.default_rng(6)
     frames = np.zeros((4, 480, 752), np.uint8)
     frames[0] = 255
-    frames[1] = (rng.random((480, 752)) > 0.99).astype(np.uint8) * 200
+    frames[1] = (rng.random((480, 752)) > 0.997).astype(np.uint8) * 200
     d = synth.make_frames("C2", 2, seed=31)
     frames[2] = d["frames"][0]
     yy, xx = np.mgrid[0:480, 0:752]
@@ -131,9 +131,28 @@ def test_pathological_frames_take_the_general_path(hip, orc):
     got = hip.detect_batch(frames, K, D, Ph)
     for i in range(len(frames)):
         und, dist = orc.find_leds(frames[i], Po, K, D)
-        assert got["status"][i] == 0, i
-        assert got["n"][i] == len(und), (i, got["n"][i], len(und))
+        if len(und) > mpe.MAX_DETECTIONS:  # documented capacity: loud per-frame status, first 32 kept
+            assert got["status"][i] == -10 and got["n"][i] == mpe.MAX_DETECTIONS
+            und, dist = und[:mpe.MAX_DETECTIONS], dist[:mpe.MAX_DETECTIONS]
+        else:
+            assert got["status"][i] == 0, i
+            assert got["n"][i] == len(und), (i, got["n"][i], len(und))
         assert np.array_equal(got["dist_xy"][i][:2 * len(und)].reshape(-1, 2), dist), i
+
+
+def test_too_many_detections_is_loud(hip, orc):
+    """> MPE_MAX_DETECTIONS blobs pass the filter: status -10 on that frame, never silent."""
+    K, D = synth.camera_for(480, 752)
+    rng = np.random.default_rng(8)
+    spots = np.stack([rng.uniform(20, 730, 60), rng.uniform(20, 460, 60)], 1)
+    frames = synth.render_frame(rng, spots, 480, 752)[None]
+    got = hip.detect_batch(frames, K, D, mpe.demo_params())
+    und, dist = orc.find_leds(frames[0], orc.make_params(), K, D)
+    assert len(und) > mpe.MAX_DETECTIONS
+    assert got["status"][0] == -10 and got["n"][0] == mpe.MAX_DETECTIONS
+    assert np.array_equal(got["dist_xy"][0][:64].reshape(-1, 2), dist[:32])
+    res = hip.estimate_batch(frames, synth.M5, K, D, mpe.demo_params())
+    assert res["status"][0] == -10
 
 
 def test_pose_estimator_facade(hip, orc):
