@@ -5,7 +5,7 @@ on synthetic 752x480 frames with 5 LEDs (BASELINE.json configs[1] = "C2"), N GPU
 A "step" is one pass of the hot path (image scan -> blob extraction -> P3P voting -> validate +
 Gauss-Newton refine) over one batch of B device-resident frames per GPU; frames shard
 embarrassingly across ranks (weak scaling: B per GPU fixed), the only collective is the gather of
-the per-frame pose records (RCCL all_gather, 440 B/frame).
+the per-frame pose records (RCCL all_gather, 432 B/frame).
 
 Prints ONE JSON line (rank 0): metric/value as BASELINE.json, plus
   roofline      — image-scan kernel (HBM bound): algorithmic bytes (rows*cols per frame) / HIP-event time
@@ -28,16 +28,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=8192, help="frames per GPU per step (device-resident batch)")
+    ap.add_argument("--frames", type=int, default=16384, help="frames per GPU per step (device-resident batch)")
     ap.add_argument("--config", default="C2")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=4, help="sub-batches per step on separate HIP streams (1 = off)")
+    ap.add_argument("--pipeline", type=int, default=1, help="sub-batches per step on separate HIP streams (1 = off)")
     args = ap.parse_args()
 
     import torch
     import rpg_monocular_pose_estimator_amd as mpe
-    from rpg_monocular_pose_estimator_amd import synth
+    from rpg_monocular_pose_estimator_amd import synth, parallel
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -58,7 +58,7 @@ def main():
     B = args.frames
 
     # ---- synthetic batch, resident in HBM before the timed region (data: synthetic) ----------
-    _, spots = synth.make_scenes(cfg, B, seed=1000 + rank)
+    _, spots = synth.make_scenes_batch(cfg, B, seed=1000 + rank)
     frames = synth.render_frames_torch(spots, rows, cols, cfg["spot_sigma"], dev, seed=77 + rank)
     results = torch.zeros(B * mpe.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     gathered = torch.zeros(world * B * mpe.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) if world > 1 else None
@@ -72,7 +72,7 @@ def main():
     def step():
         h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, results)
+            parallel.gather_records(results, world, out=gathered)
 
     def barrier():
         if world > 1:
@@ -110,7 +110,7 @@ def main():
 
     out = None
     if rank == 0:
-        res_host = np.frombuffer(results.cpu().numpy().tobytes(), dtype=mpe.RESULT_DTYPE)
+        res_host = parallel.records_from_bytes(results)
         n_pose = int((res_host["status"] == 0).sum())
         out = {
             "metric": "frames/sec at 752x480, 5 LEDs, brute-force init; pose RMSE vs CPU ref",
@@ -137,7 +137,7 @@ def main():
             t1 = time.perf_counter()
             ref = oracle.estimate_batch(sample, markers, K, D, oracle.make_params(), n_threads=cores)
             cpu_dt = time.perf_counter() - t1
-            n1 = min(256, ns)
+            n1 = min(512, ns)
             t2 = time.perf_counter()
             oracle.estimate_batch(sample[:n1], markers, K, D, oracle.make_params(), n_threads=1)
             cpu1_dt = time.perf_counter() - t2

@@ -1,0 +1,32 @@
+"""Multi-GPU sharding of the hot path: frames are independent in brute-force-every-frame mode
+(pose_estimator.cpp:68-91 reads no state when it_since_initialized_ < 1), so a batch is split into
+contiguous chunks, one per rank (one process per GPU), and the only collective is the gather of
+the fixed-size per-frame pose records (432 B/frame) — RCCL over xGMI on GPUs (backend "nccl"),
+gloo on CPU for the tests."""
+import numpy as np
+
+from .binding import RESULT_DTYPE
+
+
+def shard_bounds(n_frames, rank, world):
+    """Contiguous chunk [lo, hi) of rank `rank`: sizes differ by at most one frame."""
+    base, rem = divmod(int(n_frames), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_records(local_bytes, world, out=None):
+    """all_gather of equally sized uint8 record buffers (torch tensors, CPU/gloo or CUDA/nccl)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local_bytes
+    if out is None:
+        out = torch.empty(world * local_bytes.numel(), dtype=torch.uint8, device=local_bytes.device)
+    dist.all_gather_into_tensor(out, local_bytes)
+    return out
+
+
+def records_from_bytes(t):
+    """uint8 torch tensor (any device) -> numpy structured array of mpe_result records."""
+    return np.frombuffer(t.detach().cpu().numpy().tobytes(), dtype=RESULT_DTYPE)

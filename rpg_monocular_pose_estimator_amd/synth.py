@@ -134,6 +134,54 @@ def make_scenes(config, n, seed):
     return np.array(Ts), np.array(sp)
 
 
+def make_scenes_batch(config, n, seed, min_sep=12.0, margin=12.0):
+    """Vectorised scene sampler for large bench batches (same distribution and acceptance rule as
+    sample_scene, different random stream).  -> T (n,4,4), spots (n,S,2)."""
+    cfg = CONFIGS[config] if isinstance(config, str) else config
+    K, D = camera_for(cfg["rows"], cfg["cols"])
+    rows, cols, M, nd = cfg["rows"], cfg["cols"], np.asarray(cfg["markers"]), cfg["n_distractors"]
+    rng = np.random.default_rng(seed)
+    Ts, sp = [], []
+    need = n
+    while need > 0:
+        m = max(256, int(need * 1.6))
+        axis = rng.normal(size=(m, 3))
+        axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+        ang = rng.uniform(0.0, 0.8, m)
+        Kx = np.zeros((m, 3, 3))
+        Kx[:, 0, 1], Kx[:, 0, 2] = -axis[:, 2], axis[:, 1]
+        Kx[:, 1, 0], Kx[:, 1, 2] = axis[:, 2], -axis[:, 0]
+        Kx[:, 2, 0], Kx[:, 2, 1] = -axis[:, 1], axis[:, 0]
+        R = np.eye(3)[None] + np.sin(ang)[:, None, None] * Kx + (1 - np.cos(ang))[:, None, None] * (Kx @ Kx)
+        t = np.stack([rng.uniform(-0.3, 0.3, m), rng.uniform(-0.2, 0.2, m), rng.uniform(0.8, 2.5, m)], 1)
+        pc = np.einsum("mij,kj->mki", R, M) + t[:, None, :]
+        px = np.stack([K[0, 0] * pc[..., 0] / pc[..., 2] + K[0, 2], K[1, 1] * pc[..., 1] / pc[..., 2] + K[1, 2]], -1)
+        px = distort_px(px, K, D)
+        ok = ((px[..., 0].min(1) >= margin) & (px[..., 0].max(1) <= cols - 1 - margin) &
+              (px[..., 1].min(1) >= margin) & (px[..., 1].max(1) <= rows - 1 - margin))
+        dd = np.linalg.norm(px[:, :, None, :] - px[:, None, :, :], axis=-1) + np.eye(len(M))[None] * 1e9
+        ok &= dd.min((1, 2)) >= min_sep
+        idx = np.nonzero(ok)[0]
+        for i in idx:
+            if need == 0:
+                break
+            spots = px[i]
+            tries = 0
+            while len(spots) < len(M) + nd and tries < 1000:
+                tries += 1
+                c = np.array([rng.uniform(margin, cols - 1 - margin), rng.uniform(margin, rows - 1 - margin)])
+                if np.linalg.norm(spots - c, axis=1).min() >= min_sep:
+                    spots = np.vstack([spots, c])
+            if len(spots) < len(M) + nd:
+                continue
+            T = np.eye(4)
+            T[:3, :3], T[:3, 3] = R[i], t[i]
+            Ts.append(T)
+            sp.append(spots)
+            need -= 1
+    return np.array(Ts), np.array(sp)
+
+
 def make_frames(config, n, seed):
     """-> dict(frames (n,rows,cols) u8, T_true (n,4,4), spots (n,S,2), K, D, markers)."""
     cfg = CONFIGS[config] if isinstance(config, str) else config

@@ -7,6 +7,7 @@ import pytest
 from rpg_monocular_pose_estimator_amd import synth
 import rpg_monocular_pose_estimator_amd as mpe
 from util import pose_diff, POS_TOL_M, ROT_TOL_RAD
+from golden_util import golden_cases, load as load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -171,3 +172,28 @@ def test_pose_estimator_facade(hip, orc):
         if ok:
             dp, dr = pose_diff(pe.getPredictedPose(), ro["T"][0])
             assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_hip_against_committed_golden_vectors(hip, name):
+    """HIP path vs tests/golden/*.npz: detections bit-equal, vote histogram and correspondences
+    integer-equal, status equal, pose within the north_star tolerance."""
+    g, d = load_golden(name)
+    P = mpe.demo_params(back_projection_pixel_tolerance=float(g["tol"]))
+    n, n_m = int(g["n"]), len(d["markers"])
+    det = hip.detect_batch(d["frames"], d["K"], d["D"], P)
+    res = hip.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], P)
+    for i in range(n):
+        k = int(g["n_det"][i])
+        assert det["n"][i] == k and det["status"][i] == 0
+        assert np.array_equal(det["dist_xy"][i][:2 * k].reshape(-1, 2), g["dist_xy"][i, :k])
+        assert np.array_equal(det["undist_xy"][i][:2 * k].reshape(-1, 2), g["undist_xy"][i, :k])
+        r = hip.solve_bruteforce(g["undist_xy"][i, :k], d["markers"], d["K"], P)
+        assert np.array_equal(r["hist"], g["hist"][i, :k, :n_m]), i
+        assert r["status"] == g["status"][i] == res["status"][i]
+        assert r["n_corr"] == g["n_corr"][i] and np.array_equal(r["corr"], g["corr"][i, :r["n_corr"]])
+        if g["status"][i] == 0:
+            for T in (r["T"], res["T"][i]):
+                dp, dr = pose_diff(T, g["T"][i])
+                assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (i, dp, dr)
+            assert np.allclose(r["cov"], g["cov"][i], rtol=1e-6, atol=1e-12)

@@ -3,8 +3,8 @@ import numpy as np
 
 def rot_angle(Ra, Rb):
     """Geodesic angle between two rotation matrices (rad)."""
-    c = (np.trace(Ra.T @ Rb) - 1.0) / 2.0
-    return float(np.arccos(np.clip(c, -1.0, 1.0)))
+    # ||Ra - Rb||_F = 2*sqrt(2)*sin(angle/2): accurate for tiny angles (arccos of the trace is not)
+    return float(2.0 * np.arcsin(min(1.0, np.linalg.norm(Ra - Rb) / (2.0 * np.sqrt(2.0)))))
 
 
 def pose_diff(Ta, Tb):
