@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="extra leg: frames streamed from PINNED host memory every step (PCIe-inclusive rate; "
+                         "reported as host_streamed_fps, never as value)")
     ap.add_argument("--pipeline", type=int, default=1, help="sub-batches per step on separate HIP streams (1 = off)")
     args = ap.parse_args()
 
@@ -108,6 +111,20 @@ def main():
                 "frac": achieved / 8000.0, "traffic": None,
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": kavg["scan"]}
 
+    host_fps = None
+    if args.host_frames and rank == 0:
+        nh = min(B, 4096)
+        pinned = torch.empty((nh, rows, cols), dtype=torch.uint8, pin_memory=True)
+        pinned.copy_(frames[:nh])
+        harr = pinned.numpy()
+        h.estimate_batch(harr, markers, K, D, P)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            h.estimate_batch(harr, markers, K, D, P)
+        torch.cuda.synchronize()
+        host_fps = 5 * nh / (time.perf_counter() - t1)
+
     out = None
     if rank == 0:
         res_host = parallel.records_from_bytes(results)
@@ -127,6 +144,8 @@ def main():
             "kernel_ms": kavg,
             "roofline": roofline,
         }
+        if host_fps is not None:
+            out["host_streamed_fps"] = host_fps
         # ---- CPU baseline + parity on a bounded sample (oracle = test infrastructure / checker) ----
         if not args.no_cpu and args.cpu_sample > 0:
             import oracle

@@ -486,7 +486,11 @@ int blur_roi(const uint8_t* img, size_t stride, int rx, int ry, int rw, int rh, 
   if (rw <= 0 || rh <= 0) return 0;
   // thresholded ROI, padded by r with REFLECT_101 (the ROI clone is a stand-alone matrix)
   const int pw = rw + 2 * r, ph = rh + 2 * r;
-  std::vector<uint8_t> pad((size_t)pw * ph);
+  // scratch buffers are thread_local and only grow: a frame-parallel run (orc_estimate_batch) then
+  // does not mmap/munmap megabytes per frame, which would serialise the threads in the kernel
+  static thread_local std::vector<uint8_t> pad;
+  static thread_local std::vector<int> rowf, acc;
+  if (pad.size() < (size_t)pw * ph) pad.resize((size_t)pw * ph);
   for (int y = 0; y < ph; ++y) {
     int sy = reflect101(y - r, rh);
     const uint8_t* src = img + (size_t)(ry + sy) * stride + rx;
@@ -505,7 +509,7 @@ int blur_roi(const uint8_t* img, size_t stride, int rx, int ry, int rw, int rh, 
       std::memcpy(&blurred[(size_t)y * rw], &pad[(size_t)(y + r) * pw + r], rw);
     return 0;
   }
-  std::vector<int> rowf((size_t)rw * ph);
+  if (rowf.size() < (size_t)rw * ph) rowf.resize((size_t)rw * ph);
   for (int y = 0; y < ph; ++y) {
     const uint8_t* s = &pad[(size_t)y * pw];
     int* d = &rowf[(size_t)y * rw];
@@ -516,7 +520,7 @@ int blur_roi(const uint8_t* img, size_t stride, int rx, int ry, int rw, int rh, 
       for (int x = 0; x < rw; ++x) d[x] += k * sj[x];
     }
   }
-  std::vector<int> acc(rw);
+  if (acc.size() < (size_t)rw) acc.resize(rw);
   for (int y = 0; y < rh; ++y) {
     for (int x = 0; x < rw; ++x) acc[x] = 0;
     for (int i = 0; i < n; ++i) {
@@ -585,7 +589,8 @@ void external_contours(const uint8_t* mask, int h, int w, std::vector<std::vecto
   out.clear();
   if (h <= 0 || w <= 0) return;
   const int W = w + 2, H = h + 2;
-  std::vector<signed char> im((size_t)W * H, 0);
+  static thread_local std::vector<signed char> im;
+  im.assign((size_t)W * H, 0);
   for (int y = 0; y < h; ++y)
     for (int x = 0; x < w; ++x) im[(size_t)(y + 1) * W + x + 1] = mask[(size_t)y * w + x] ? 1 : 0;
   std::vector<std::vector<Pt>> found;
@@ -675,7 +680,7 @@ int find_leds(const uint8_t* img, int rows, int cols, size_t stride, int rx, int
   undist.clear();
   dist.clear();
   if (rx < 0 || ry < 0 || rw < 0 || rh < 0 || rx + rw > cols || ry + rh > rows) return -1;
-  std::vector<uint8_t> g;
+  static thread_local std::vector<uint8_t> g;
   if (blur_roi(img, stride, rx, ry, rw, rh, p.threshold_value, p.gaussian_sigma, g) != 0) return -2;
   std::vector<std::vector<Pt>> contours;
   external_contours(g.data(), rh, rw, contours);  // LED.cpp:56-57

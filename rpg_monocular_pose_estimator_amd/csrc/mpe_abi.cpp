@@ -167,9 +167,9 @@ int make_geom(const mpe_handle* h, int rows, int cols, FrameGeom& g) {
   return 0;
 }
 
-size_t flag_words(size_t n_bytes) {
+size_t flag_words(size_t n_bytes) {  // K1a writes whole chunks of up to 8 words
   const size_t n_seg = n_bytes / 16;
-  return ((n_seg + 255) / 256) * 4 + 4;
+  return ((n_seg + 511) / 512) * 8 + 8;
 }
 
 // Bring `n_frames` frames into the packed device layout.  Returns the device pointer to use.
