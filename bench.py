@@ -23,6 +23,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def effective_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +165,7 @@ def main():
             oracle.build()
             ns = min(args.cpu_sample, B)
             sample = frames[:ns].cpu().numpy()
-            cores = os.cpu_count() or 1
+            cores = effective_cores()
             t1 = time.perf_counter()
             ref = oracle.estimate_batch(sample, markers, K, D, oracle.make_params(), n_threads=cores)
             cpu_dt = time.perf_counter() - t1

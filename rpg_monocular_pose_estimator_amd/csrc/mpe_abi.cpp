@@ -228,7 +228,8 @@ int run_chain(mpe_handle* h, hipStream_t st, bool prof, int chain, int chain_fra
   if (prof) rec(h, 1);
   HIP_TRY(h, launch_k1b_blobs(d_frames, d_flags, n_frames, g, dp, d_dets,
                               static_cast<int*>(h->work.p) + (size_t)chain * (chain_frames + 1),
-                              static_cast<uint8_t*>(h->scratch.p) + (size_t)chain * k1b_scratch_bytes(g), st));
+                              static_cast<uint8_t*>(h->scratch.p) + (size_t)chain * k1b_scratch_bytes(g),
+                              sp ? sp->n_markers : 0, st));
   if (prof) rec(h, 2);
   if (sp) {
     HIP_TRY(h, hipMemsetAsync(d_hist, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), st));

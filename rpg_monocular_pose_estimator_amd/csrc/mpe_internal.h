@@ -52,7 +52,7 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
                            hipStream_t s);
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
-                            hipStream_t s);
+                            int blob_hint, hipStream_t s);
 size_t k2_table_bytes(int n_markers);
 hipError_t launch_k2_prep(const SolveParams& sp, double* tab, hipStream_t s);
 hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,

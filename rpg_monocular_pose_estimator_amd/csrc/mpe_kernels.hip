@@ -402,7 +402,7 @@ __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, in
     u64* pmrow = pm + (size_t)slot * W;
     u64* ngrow = ng + (size_t)slot * W;
     int last_sign = 0;  // sign of the nearest marked pixel to the left (lnbd), 0 = none yet
-    for (int w = 0; w < W - 1; ++w) {
+    for (int w = 0; w < W; ++w) {
       const u64 nzw = nzrow[w];
       if (!nzw) continue;
       const u64 leftnz = (nzw << 1) | (w ? (nzrow[w - 1] >> 63) : 0);
@@ -499,8 +499,9 @@ __device__ __forceinline__ void write_detections(const float* kx, const float* k
 #define K1B_SEG_CAP 512     // bright segments per frame
 #define K1B_BAND_CAP 32     // bands per frame
 #define K1B_ISL_CAP 32      // islands per frame
-#define K1B_PIX_POOL 6144   // bytes of thresholded pixels, all islands of the frame
-#define K1B_BM_POOL 288     // u64 words per bitmap, all islands of the frame
+// LDS pools (thresholded pixels / bitmap words for all islands of a frame) come in two sizes,
+// picked per launch from the expected number of blobs: <PIX_POOL, BM_POOL> = <6144, 288> keeps
+// 8 waves per CU for the 4-6 LED case, <12288, 704> covers ~16 blobs per frame at 5 waves per CU.
 #define K1B_KEPT_CAP 64     // blobs that pass the shape filter (> MPE_MAX_DETECTIONS -> status)
 
 struct Island {
@@ -511,11 +512,12 @@ struct Island {
   int stage_end, blur_end;  // inclusive prefix sums of the flattened work-item counts
 };
 
+template <int K1B_PIX_POOL, int K1B_BM_POOL>
 __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
                                                FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
                                                int* __restrict__ worklist) {
   __shared__ __attribute__((aligned(16))) uint8_t s_pix[K1B_PIX_POOL];
-  __shared__ u64 s_nz[K1B_BM_POOL], s_pm[K1B_BM_POOL], s_ng[K1B_BM_POOL];
+  __shared__ u64 s_nz[K1B_BM_POOL + 1], s_pm[K1B_BM_POOL + 1], s_ng[K1B_BM_POOL + 1];
   __shared__ unsigned s_seg[K1B_SEG_CAP];  // y << 16 | segment column
   __shared__ u64 s_rowact[64];
   __shared__ u64 s_colocc[K1B_BAND_CAP][4];
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ fram
       const Island is = s_isl[lane];
       const int H = is.yhi - is.ylo + 1;
       const int xhi = min(g.cols - 1, 16 * is.chi + 15);
-      const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64 + 1;
+      const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
       const int nbs = is.clast - is.cfirst + 1;
       pixb = H * 16 * nbs;
       bmw = (H + 2) * W;
@@ -737,7 +739,7 @@ __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ fram
   {
     const int tot_bm = s_isl[nisl - 1].bm_off +
                        (s_isl[nisl - 1].yhi - s_isl[nisl - 1].ylo + 3) *
-                           (((min(g.cols - 1, 16 * s_isl[nisl - 1].chi + 15) - 16 * s_isl[nisl - 1].clo + 1) + 2 + 63) / 64 + 1);
+                           (((min(g.cols - 1, 16 * s_isl[nisl - 1].chi + 15) - 16 * s_isl[nisl - 1].clo + 1) + 2 + 63) / 64);
     for (int i = lane; i < tot_bm; i += 64) {
       s_nz[i] = 0;
       s_pm[i] = 0;
@@ -773,7 +775,7 @@ __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ fram
       const int yb = li / ncols, c = is.clo + (li - yb * ncols);
       const int H = is.yhi - is.ylo + 1;
       const int xhi = min(g.cols - 1, 16 * is.chi + 15);
-      const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64 + 1;
+      const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
       const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1)};
       blur_to_bitmap(pw, g, dp, is.ylo + yb, c, s_nz + is.bm_off + (size_t)(yb + 1) * W, 16 * is.clo);
     }
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ fram
     const Island is = s_isl[lane];
     const int H = is.yhi - is.ylo + 1;
     const int xhi = min(g.cols - 1, 16 * is.chi + 15);
-    const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64 + 1;
+    const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
     scan_window(s_nz + is.bm_off, s_pm + is.bm_off, s_ng + is.bm_off, W, H, is.ylo, 16 * is.clo, dp, &s_over,
                 [&](float mcx, float mcy, unsigned key) {
                   const int k = atomicAdd(&s_nkept, 1);
@@ -920,11 +922,16 @@ size_t k1b_scratch_bytes(const FrameGeom& g) { return k1b_gen_scratch_bytes(g) *
 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
-                            hipStream_t s) {
+                            int blob_hint, hipStream_t s) {
   if (n_frames <= 0) return hipSuccess;
   hipError_t e = hipMemsetAsync(worklist, 0, sizeof(int), s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k1b_blobs, dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets, worklist);
+  if (blob_hint > 0 && blob_hint <= 6)
+    hipLaunchKernelGGL((k1b_blobs<6144, 288>), dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
+                       worklist);
+  else
+    hipLaunchKernelGGL((k1b_blobs<12288, 704>), dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
+                       dets, worklist);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k1b_general, dim3(K1B_GEN_BLOCKS), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
