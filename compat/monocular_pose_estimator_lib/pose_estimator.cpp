@@ -1,0 +1,122 @@
+// pose_estimator.cpp — facade implementation: parameter marshalling + calls into the C ABI.
+#include "pose_estimator.h"
+
+#include <stdexcept>
+
+namespace monocular_pose_estimator {
+
+static void check(mpe_handle* h, int rc, const char* what) {
+  if (rc != MPE_OK) throw std::runtime_error(std::string(what) + ": " + (h ? mpe_last_error(h) : "no handle"));
+}
+
+PoseEstimator::PoseEstimator()
+    : detection_threshold_value_(0), gaussian_sigma_(0), min_blob_area_(0), max_blob_area_(0),
+      max_width_height_distortion_(0), max_circular_distortion_(0), roi_border_thickness_(0), handle_(0),
+      predicted_time_(0), pose_updated_(false) {
+  mpe_default_params(&params_);
+  params_.back_projection_pixel_tolerance = 3;    // pose_estimator.cpp:36
+  params_.nearest_neighbour_pixel_tolerance = 5;  // :37
+  params_.certainty_threshold = 0.75;             // :38
+  params_.valid_correspondence_threshold = 0.7;   // :39
+  params_.histogram_threshold = 0;
+  predicted_pose_ = Matrix4d::Identity();
+  int rc = mpe_create(&handle_, -1);
+  if (rc != MPE_OK) throw std::runtime_error("mpe_create failed: no HIP device (there is no CPU fallback)");
+}
+
+PoseEstimator::~PoseEstimator() { mpe_destroy(handle_); }
+
+void PoseEstimator::syncParams() {
+  params_.threshold_value = detection_threshold_value_;
+  params_.gaussian_sigma = gaussian_sigma_;
+  params_.min_blob_area = min_blob_area_;
+  params_.max_blob_area = max_blob_area_;
+  params_.max_width_height_distortion = max_width_height_distortion_;
+  params_.max_circular_distortion = max_circular_distortion_;
+  params_.roi_border_thickness = roi_border_thickness_;
+}
+
+void PoseEstimator::setMarkerPositions(const List4DPoints& p) {
+  markers_xyz_.resize(3 * p.size());
+  for (size_t i = 0; i < p.size(); ++i)
+    for (int k = 0; k < 3; ++k) markers_xyz_[3 * i + k] = p[i](k);
+  params_.histogram_threshold = 0;  // numCombinations(n, 3) is applied inside the library
+}
+
+List4DPoints PoseEstimator::getMarkerPositions() {
+  List4DPoints out(markers_xyz_.size() / 3);
+  for (size_t i = 0; i < out.size(); ++i) {
+    for (int k = 0; k < 3; ++k) out[i](k) = markers_xyz_[3 * i + k];
+    out[i](3) = 1.0;
+  }
+  return out;
+}
+
+unsigned PoseEstimator::getHistogramThreshold() {
+  if (params_.histogram_threshold) return params_.histogram_threshold;
+  unsigned n = (unsigned)(markers_xyz_.size() / 3), f = 1, f3 = 6, fn3 = 1;  // 32-bit factorials (combinations.cpp:34-45)
+  for (unsigned i = 2; i <= n; ++i) f *= i;
+  for (unsigned i = 2; i + 3 <= n; ++i) fn3 *= i;
+  const unsigned den = f3 * fn3;
+  return den != 0u ? f / den : 0u;
+}
+
+unsigned PoseEstimator::initialise() {
+  syncParams();
+  std::vector<double> det(2 * image_points_.size());
+  for (size_t i = 0; i < image_points_.size(); ++i) {
+    det[2 * i] = image_points_[i](0);
+    det[2 * i + 1] = image_points_[i](1);
+  }
+  const int n_m = (int)(markers_xyz_.size() / 3);
+  mpe_result res;
+  std::vector<uint32_t> corr(2 * (n_m > 0 ? n_m : 1));
+  check(handle_, mpe_solve_bruteforce(handle_, det.data(), (int)image_points_.size(), markers_xyz_.data(), n_m,
+                                      camera_matrix_K_.data(), &params_, &res, 0, corr.data()),
+        "mpe_solve_bruteforce");
+  if (res.status < 0) throw std::runtime_error("frame exceeded a device capacity");
+  correspondences_.clear();
+  for (int i = 0; i < res.n_corr; ++i) correspondences_.push_back({{corr[2 * i], corr[2 * i + 1]}});
+  if (res.status != MPE_FRAME_POSE) return 0;
+  for (int i = 0; i < 16; ++i) predicted_pose_(i) = res.T[i];
+  for (int i = 0; i < 36; ++i) pose_covariance_(i) = res.cov[i];
+  return 1;
+}
+
+bool PoseEstimator::estimateBodyPose(const ImageView& image, double time_to_predict) {
+  pose_updated_ = false;
+  setPredictedTime(time_to_predict);  // pose_estimator.cpp:70
+  syncParams();
+  double und[2 * MPE_MAX_DETECTIONS];
+  float dist[2 * MPE_MAX_DETECTIONS];
+  int n = 0;
+  const double* D = camera_distortion_coeffs_.empty() ? 0 : camera_distortion_coeffs_.data();
+  check(handle_, mpe_find_leds(handle_, image.data, image.rows, image.cols, image.step, 0, 0, image.cols, image.rows,
+                               &params_, camera_matrix_K_.data(), D, (int)camera_distortion_coeffs_.size(), und, dist,
+                               MPE_MAX_DETECTIONS, &n),
+        "mpe_find_leds");
+  distorted_detection_centers_.resize(n);
+  image_points_.resize(n);
+  for (int i = 0; i < n; ++i) {
+    distorted_detection_centers_[i] = {dist[2 * i], dist[2 * i + 1]};
+    image_points_[i](0) = und[2 * i];
+    image_points_[i](1) = und[2 * i + 1];
+  }
+  if (n >= 4) {  // min_num_leds_detected_ (pose_estimator.h:78)
+    if (initialise() == 1) pose_updated_ = true;  // optimiseAndUpdatePose is part of mpe_solve_bruteforce
+  }
+  return pose_updated_;
+}
+
+void PoseEstimator::estimateBodyPoseBatch(const uint8_t* frames, int n_frames, int rows, int cols,
+                                          bool frames_on_device, mpe_result* results) {
+  syncParams();
+  const double* D = camera_distortion_coeffs_.empty() ? 0 : camera_distortion_coeffs_.data();
+  check(handle_, mpe_estimate_batch(handle_, frames, n_frames, rows, cols, (size_t)cols, (size_t)rows * cols,
+                                    frames_on_device ? 1 : 0, markers_xyz_.data(), (int)(markers_xyz_.size() / 3),
+                                    camera_matrix_K_.data(), D, (int)camera_distortion_coeffs_.size(), &params_,
+                                    results),
+        "mpe_estimate_batch");
+}
+
+}  // namespace monocular_pose_estimator

@@ -1,0 +1,94 @@
+// pose_estimator.h — source-compatible facade of monocular_pose_estimator::PoseEstimator
+// (reference: lib/include/monocular_pose_estimator_lib/pose_estimator.h:52-803) whose compute
+// back-end is the MI355X library libmpe_hip.so (include/mpe.h).
+//
+// Same class name, namespace, public data members and method names as the reference, so that the
+// only caller (MPENode, monocular_pose_estimator/src/monocular_pose_estimator.cpp) keeps compiling
+// after the type substitutions listed in INTEGRATION.md (cv::Mat -> ImageView or the OpenCV
+// adapter, Eigen types -> datatypes.h or the Eigen adapter).
+//
+// Round-1 scope: the uninitialised branch of estimateBodyPose (pose_estimator.cpp:62-96) — every
+// call is a brute-force initialisation, i.e. the estimator behaves like a fresh object per frame
+// (BASELINE configs "brute-force init every frame").  The tracking path (predictPose,
+// findCorrespondences, determineROI ...) is SURVEY §8f "next #1".
+#ifndef MPE_COMPAT_POSE_ESTIMATOR_H_
+#define MPE_COMPAT_POSE_ESTIMATOR_H_
+
+#include <string>
+#include <vector>
+
+#include "datatypes.h"
+#include "mpe.h"
+
+namespace monocular_pose_estimator {
+
+class PoseEstimator {
+ public:
+  // public members of the reference (pose_estimator.h:82-91)
+  Matrix3d camera_matrix_K_;
+  std::vector<double> camera_distortion_coeffs_;
+  int detection_threshold_value_;
+  double gaussian_sigma_;
+  double min_blob_area_;
+  double max_blob_area_;
+  double max_width_height_distortion_;
+  double max_circular_distortion_;
+  unsigned roi_border_thickness_;
+
+  PoseEstimator();  //!< tolerances 3 / 5 / 0.75 / 0.7 as pose_estimator.cpp:34-42
+  ~PoseEstimator();
+
+  void setMarkerPositions(const List4DPoints& positions_of_markers_on_object);  // pose_estimator.cpp:50-55
+  List4DPoints getMarkerPositions();
+  //! pose_estimator.cpp:62-96; throws std::runtime_error on a HIP / usage error (the reference's
+  //! OpenCV calls throw cv::Exception in the same situations), returns pose_updated_ otherwise
+  bool estimateBodyPose(const ImageView& image, double time_to_predict);
+
+  void setPredictedTime(double time) { predicted_time_ = time; }
+  double getPredictedTime() { return predicted_time_; }
+  void setPredictedPose(const Matrix4d& pose, double time) {
+    predicted_pose_ = pose;
+    predicted_time_ = time;
+  }
+  Matrix4d getPredictedPose() { return predicted_pose_; }
+  Matrix6d getPoseCovariance() { return pose_covariance_; }
+  List2DPoints getImagePoints() { return image_points_; }
+  VectorXuPairs getCorrespondences() { return correspondences_; }
+  const std::vector<Point2f>& getDistortedDetectionCenters() const { return distorted_detection_centers_; }
+
+  void setBackProjectionPixelTolerance(double t) { params_.back_projection_pixel_tolerance = t; }
+  double getBackProjectionPixelTolerance() { return params_.back_projection_pixel_tolerance; }
+  void setNearestNeighbourPixelTolerance(double t) { params_.nearest_neighbour_pixel_tolerance = t; }
+  double getNearestNeighbourPixelTolerance() { return params_.nearest_neighbour_pixel_tolerance; }
+  void setCertaintyThreshold(double t) { params_.certainty_threshold = t; }
+  double getCertaintyThreshold() { return params_.certainty_threshold; }
+  void setValidCorrespondenceThreshold(double t) { params_.valid_correspondence_threshold = t; }
+  double getValidCorrespondenceThreshold() { return params_.valid_correspondence_threshold; }
+  void setHistogramThreshold(unsigned t) { params_.histogram_threshold = t; }
+  unsigned getHistogramThreshold();
+
+  //! initialise() + optimiseAndUpdatePose() on explicit image points (pose_estimator.h:425,749,773)
+  void setImagePoints(const List2DPoints& points) { image_points_ = points; }
+  unsigned initialise();
+
+  //! Batched extension: estimateBodyPose on a fresh estimator for each of n packed frames
+  //! (host or device memory); results[i].status == 0 <=> estimateBodyPose returned true.
+  void estimateBodyPoseBatch(const uint8_t* frames, int n_frames, int rows, int cols, bool frames_on_device,
+                             mpe_result* results);
+
+ private:
+  void syncParams();
+  mpe_handle* handle_;
+  mpe_params params_;
+  std::vector<double> markers_xyz_;
+  Matrix4d predicted_pose_;
+  Matrix6d pose_covariance_;
+  double predicted_time_;
+  List2DPoints image_points_;
+  VectorXuPairs correspondences_;
+  std::vector<Point2f> distorted_detection_centers_;
+  bool pose_updated_;
+};
+
+}  // namespace monocular_pose_estimator
+#endif

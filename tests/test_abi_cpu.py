@@ -122,3 +122,15 @@ def test_two_process_gloo_shard_and_gather(orc, tmp_path):
     assert len(got) == 8
     assert np.array_equal(got["status"], ref["status"])
     assert np.array_equal(got["T"], ref["T"]) and np.array_equal(got["cov"], ref["cov"])
+
+
+def test_cpp_facade_builds(lib):
+    """compat/: the PoseEstimator facade (reference class / method names) and the ROS-free example
+    compile with plain g++ against include/mpe.h and link the HIP library."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "compat")])
+    out = subprocess.check_output(["nm", "-DC", "--defined-only",
+                                   os.path.join(ROOT, "compat", "libmonocular_pose_estimator_compat.so")], text=True)
+    for sym in ("monocular_pose_estimator::PoseEstimator::estimateBodyPose",
+                "monocular_pose_estimator::PoseEstimator::setMarkerPositions",
+                "monocular_pose_estimator::PoseEstimator::initialise"):
+        assert sym in out, sym

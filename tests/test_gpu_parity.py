@@ -197,3 +197,25 @@ def test_hip_against_committed_golden_vectors(hip, name):
                 dp, dr = pose_diff(T, g["T"][i])
                 assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (i, dp, dr)
             assert np.allclose(r["cov"], g["cov"][i], rtol=1e-6, atol=1e-12)
+
+
+def test_cpp_facade_example_node(orc, tmp_path):
+    """The C++ facade (compat/) driven like MPENode::imageCallback, on a raw frame file."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "compat")])
+    d = synth.make_frames("C2", 3, seed=808)
+    ref = orc.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], orc.make_params())
+    for i in range(3):
+        path = str(tmp_path / ("f%d.raw" % i))
+        d["frames"][i].tofile(path)
+        out = subprocess.run([os.path.join(root, "compat", "example_node"), path, "480", "752"],
+                             capture_output=True, text=True)
+        if ref["status"][i] == 0:
+            assert out.returncode == 0, out.stderr
+            T = np.array([float(x) for x in out.stdout.splitlines()[0].split()[1:]]).reshape(4, 4)
+            dp, dr = pose_diff(T, ref["T"][i])
+            assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD
+        else:
+            assert out.returncode == 1
