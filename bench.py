@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--host-frames", action="store_true",
                     help="extra leg: frames streamed from PINNED host memory every step (PCIe-inclusive rate; "
                          "reported as host_streamed_fps, never as value)")
+    ap.add_argument("--k1a-lds", type=int, default=0, help="experiment: dummy LDS per scan block (caps its occupancy)")
     ap.add_argument("--pipeline", type=int, default=1, help="sub-batches per step on separate HIP streams (1 = off)")
     args = ap.parse_args()
 
@@ -84,6 +85,8 @@ def main():
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     P = mpe.demo_params()
     h.set_option("pipeline", args.pipeline)
+    if args.k1a_lds:
+        h.set_option("k1a_dummy_lds", args.k1a_lds)
 
     def step():
         h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())

@@ -14,6 +14,9 @@
 #include "mpe_internal.h"
 
 using namespace mpe;
+namespace mpe {
+extern int g_k1a_dummy_lds;
+}
 
 namespace {
 
@@ -217,20 +220,23 @@ void rec(mpe_handle* h, int i) {
   if (h->profiling && h->ev[i]) (void)hipEventRecord(h->ev[i], h->stream);
 }
 
-// the per-batch pipeline on device-resident, packed frames, all kernels on stream `st`
-int run_chain(mpe_handle* h, hipStream_t st, bool prof, int chain, int chain_frames, const uint8_t* d_frames, int n_frames,
-              const FrameGeom& g, const DetectParams& dp, const SolveParams* sp, unsigned long long* d_flags,
-              mpe_detections* d_dets,
-              uint32_t* d_hist, mpe_result* d_results, uint32_t* d_corr) {
+// front half (image scan + blob extraction) and back half (voting + tail) of the per-batch chain
+int run_front(mpe_handle* h, hipStream_t st, bool prof, int chain, int chain_frames, const uint8_t* d_frames,
+              int n_frames, const FrameGeom& g, const DetectParams& dp, const SolveParams* sp,
+              unsigned long long* d_flags, mpe_detections* d_dets) {
   const size_t bytes = (size_t)n_frames * g.rows * g.pitch;
   if (prof) rec(h, 0);
   HIP_TRY(h, launch_k1a_scan(d_frames, bytes, d_flags, dp.thr, st));
   if (prof) rec(h, 1);
   HIP_TRY(h, launch_k1b_blobs(d_frames, d_flags, n_frames, g, dp, d_dets,
                               static_cast<int*>(h->work.p) + (size_t)chain * (chain_frames + 1),
-                              static_cast<uint8_t*>(h->scratch.p) + (size_t)chain * k1b_scratch_bytes(g),
-                              sp ? sp->n_markers : 0, st));
+                              static_cast<uint8_t*>(h->scratch.p), sp ? sp->n_markers : 0, st));
   if (prof) rec(h, 2);
+  return MPE_OK;
+}
+
+int run_back(mpe_handle* h, hipStream_t st, bool prof, int n_frames, const SolveParams* sp, mpe_detections* d_dets,
+             uint32_t* d_hist, mpe_result* d_results, uint32_t* d_corr) {
   if (sp) {
     HIP_TRY(h, hipMemsetAsync(d_hist, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), st));
     HIP_TRY(h, launch_k2_vote(d_dets, n_frames, *sp, static_cast<const double*>(h->mtab.p), d_hist,
@@ -252,45 +258,51 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     HIP_TRY(h, h->mtab.reserve(k2_table_bytes(sp->n_markers)));
     HIP_TRY(h, launch_k2_prep(*sp, static_cast<double*>(h->mtab.p), h->stream));
   }
-  int nsub = h->profiling ? 1 : h->pipeline;
+  int nsub = (h->profiling || !sp) ? 1 : h->pipeline;
   if (nsub > mpe_handle::kMaxSub) nsub = mpe_handle::kMaxSub;
   if (n_frames < 512 * nsub) nsub = 1;  // small batches: one chain
   h->have_ms = false;
+  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
   if (nsub <= 1) {
     HIP_TRY(h, h->flags.reserve(flag_words(frame_bytes * n_frames) * 8));
     HIP_TRY(h, h->work.reserve((size_t)(n_frames + 1) * sizeof(int)));
-    HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
-    int rc = run_chain(h, h->stream, h->profiling, 0, n_frames, d_frames, n_frames, g, dp, sp,
-                       static_cast<unsigned long long*>(h->flags.p), d_dets, d_hist, d_results, d_corr);
+    int rc = run_front(h, h->stream, h->profiling, 0, n_frames, d_frames, n_frames, g, dp, sp,
+                       static_cast<unsigned long long*>(h->flags.p), d_dets);
+    if (rc) return rc;
+    rc = run_back(h, h->stream, h->profiling, n_frames, sp, d_dets, d_hist, d_results, d_corr);
     h->have_ms = (rc == MPE_OK) && h->profiling;
     return rc;
   }
+  // Two-stage software pipeline over nsub sub-batches: stream A runs scan + blobs of sub-batch i+1
+  // (HBM / latency bound) while stream B runs voting + tail of sub-batch i (FP64 VALU bound).
   // frames per sub-batch: multiple of 64 so every sub-batch starts on a 16-byte / flag-word boundary
-  int per = ((n_frames + nsub - 1) / nsub + 63) & ~63;
+  const int per = ((n_frames + nsub - 1) / nsub + 63) & ~63;
   const size_t fw_per = flag_words(frame_bytes * per);
   HIP_TRY(h, h->flags.reserve(fw_per * nsub * 8));
   HIP_TRY(h, h->work.reserve((size_t)(per + 1) * nsub * sizeof(int)));
-  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g) * nsub));
+  for (int i = 0; i < 2; ++i)
+    if (!h->sub_stream[i]) HIP_TRY(h, hipStreamCreateWithFlags(&h->sub_stream[i], hipStreamNonBlocking));
   if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+  hipStream_t sa = h->sub_stream[0], sb = h->sub_stream[1];
   HIP_TRY(h, hipEventRecord(h->fork_ev, h->stream));
-  int used = 0;
+  HIP_TRY(h, hipStreamWaitEvent(sa, h->fork_ev, 0));
+  HIP_TRY(h, hipStreamWaitEvent(sb, h->fork_ev, 0));
   for (int s = 0; s < nsub; ++s) {
     const int f0 = s * per;
     if (f0 >= n_frames) break;
     const int nf = std::min(per, n_frames - f0);
-    if (!h->sub_stream[s]) HIP_TRY(h, hipStreamCreateWithFlags(&h->sub_stream[s], hipStreamNonBlocking));
     if (!h->sub_done[s]) HIP_TRY(h, hipEventCreateWithFlags(&h->sub_done[s], hipEventDisableTiming));
-    hipStream_t st = h->sub_stream[s];
-    HIP_TRY(h, hipStreamWaitEvent(st, h->fork_ev, 0));
-    int rc = run_chain(h, st, false, s, per, d_frames + (size_t)f0 * frame_bytes, nf, g, dp, sp,
-                       static_cast<unsigned long long*>(h->flags.p) + fw_per * s, d_dets + f0,
-                       d_hist ? d_hist + (size_t)f0 * MPE_HIST_STRIDE : nullptr, d_results ? d_results + f0 : nullptr,
-                       d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr);
+    int rc = run_front(h, sa, false, s, per, d_frames + (size_t)f0 * frame_bytes, nf, g, dp, sp,
+                       static_cast<unsigned long long*>(h->flags.p) + fw_per * s, d_dets + f0);
     if (rc) return rc;
-    HIP_TRY(h, hipEventRecord(h->sub_done[s], st));
-    used = s + 1;
+    HIP_TRY(h, hipEventRecord(h->sub_done[s], sa));
+    HIP_TRY(h, hipStreamWaitEvent(sb, h->sub_done[s], 0));
+    rc = run_back(h, sb, false, nf, sp, d_dets + f0, d_hist + (size_t)f0 * MPE_HIST_STRIDE, d_results + f0,
+                  d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr);
+    if (rc) return rc;
   }
-  for (int s = 0; s < used; ++s) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->sub_done[s], 0));
+  HIP_TRY(h, hipEventRecord(h->fork_ev, sb));  // B finishes last: it waited for every front half
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, h->fork_ev, 0));
   return MPE_OK;
 }
 
@@ -412,6 +424,10 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   if (!std::strcmp(name, "lds_budget")) {
     if (value < 8 * 1024 || value > 160 * 1024) return fail(h, MPE_ERR_ARG, "lds_budget out of range");
     h->lds_budget = value;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "k1a_dummy_lds")) {
+    g_k1a_dummy_lds = value;
     return MPE_OK;
   }
   if (!std::strcmp(name, "pipeline")) {

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void k1a_scan(const uint4* __restrict__ px, u6
   }
 }
 
+int g_k1a_dummy_lds = 0;  // experiment knob: dynamic LDS per block, only to cap K1a's blocks per CU
 hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long long* flags, int thr,
                            hipStream_t s) {
   const size_t n_seg = n_bytes / 16;
@@ -93,8 +94,8 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
   size_t blocks = (n_chunks + 3) / 4;  // 4 waves per block
   const size_t max_blocks = 256 * K1A_BLOCKS_PER_CU;  // 256 CUs x blocks per CU, grid-stride beyond
   if (blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL(k1a_scan, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(frames),
-                     (u64*)flags, n_seg, add);
+  hipLaunchKernelGGL(k1a_scan, dim3((unsigned)blocks), dim3(256), (size_t)g_k1a_dummy_lds, s,
+                     reinterpret_cast<const uint4*>(frames), (u64*)flags, n_seg, add);
   return hipGetLastError();
 }
 
@@ -302,7 +303,7 @@ __device__ __forceinline__ void set_bit(u64* bm, int wb, int slot, int xb) {
 // visited pixels are marked "positive" (pm) or, when the east neighbour was examined and is 0,
 // "negative" (ng, takes precedence).  (xoff, yoff) turn window coordinates into image
 // coordinates.  Returns false if the step bound was hit.
-__device__ bool trace_outer_border(const u64* nz, u64* pm, u64* ng, int wb, int slot0, int xb0, int xoff, int yoff,
+__device__ __forceinline__ bool trace_outer_border(const u64* nz, u64* pm, u64* ng, int wb, int slot0, int xb0, int xoff, int yoff,
                                    PolyAcc& acc) {
   acc.init();
   unsigned nb = neighbours(nz, wb, slot0, xb0);
@@ -444,19 +445,19 @@ __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, in
 }
 
 // blurred-mask bits of the 16 outputs of segment column c in image row y -> OR into the bitmap
-__device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, const FrameGeom& g, const DetectParams& dp, int y, int c,
-                                               u64* nzrow, int xw0) {
-  const int r = dp.ksize / 2;
+__device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int cols, const int* taps, int ksize, int y,
+                                               int c, u64* nzrow, int xw0) {
+  const int r = ksize / 2;
   const int x0 = 16 * c;
-  if (x0 >= g.cols) return;
+  if (x0 >= cols) return;
   unsigned m;
-  const bool interior = (x0 - r >= 0) && (x0 + 15 + r < g.cols);
-  if (interior && dp.ksize == 5)
-    m = blur_item_fast<5>(pw, g.rows, g.cols, y, c, dp.taps);
-  else if (interior && dp.ksize == 3)
-    m = blur_item_fast<3>(pw, g.rows, g.cols, y, c, dp.taps);
+  const bool interior = (x0 - r >= 0) && (x0 + 15 + r < cols);
+  if (interior && ksize == 5)
+    m = blur_item_fast<5>(pw, rows, cols, y, c, taps);
+  else if (interior && ksize == 3)
+    m = blur_item_fast<3>(pw, rows, cols, y, c, taps);
   else
-    m = blur_item_generic(pw, g.rows, g.cols, y, c, dp.taps, dp.ksize);
+    m = blur_item_generic(pw, rows, cols, y, c, taps, ksize);
   if (m) {
     const int xb0 = x0 - xw0 + 1, wi = xb0 >> 6, shb = xb0 & 63;
     atomicOr(&nzrow[wi], (u64)m << shb);
@@ -526,9 +527,12 @@ __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ fram
   __shared__ float s_kx[K1B_KEPT_CAP], s_ky[K1B_KEPT_CAP];
   __shared__ unsigned s_kkey[K1B_KEPT_CAP];
   __shared__ int s_nseg, s_nkept, s_over, s_nband, s_nisl;
+  __shared__ int s_taps[MPE_MAX_KSIZE];  // (taking the address of the by-value kernel argument would
+                                         //  make the compiler copy all of it to scratch)
 
   const int lane = threadIdx.x;
   const int f = blockIdx.x;
+  if (lane < MPE_MAX_KSIZE) s_taps[lane] = dp.taps[lane < dp.ksize ? lane : 0];
   const uint8_t* frame = frames + (size_t)f * g.rows * g.pitch;
   mpe_detections* out = dets + f;
   const int r = dp.ksize / 2;
@@ -777,7 +781,8 @@ __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ fram
       const int xhi = min(g.cols - 1, 16 * is.chi + 15);
       const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
       const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1)};
-      blur_to_bitmap(pw, g, dp, is.ylo + yb, c, s_nz + is.bm_off + (size_t)(yb + 1) * W, 16 * is.clo);
+      blur_to_bitmap(pw, g.rows, g.cols, s_taps, dp.ksize, is.ylo + yb, c, s_nz + is.bm_off + (size_t)(yb + 1) * W,
+                     16 * is.clo);
     }
   }
   __syncthreads();
@@ -821,7 +826,10 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
                                                  FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
                                                  const int* __restrict__ worklist, uint8_t* __restrict__ scratch) {
   __shared__ int s_nkept, s_over;
+  __shared__ int s_taps[MPE_MAX_KSIZE];
   const int lane = threadIdx.x;
+  if (lane < MPE_MAX_KSIZE) s_taps[lane] = dp.taps[lane < dp.ksize ? lane : 0];
+  __syncthreads();
   const int count = worklist[0];
   const size_t slab = k1b_gen_scratch_bytes(g);
   uint8_t* base = scratch + (size_t)blockIdx.x * slab;
@@ -893,7 +901,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
         while (tb) {
           const int c = tw * 64 + __builtin_ctzll(tb);
           tb &= tb - 1;
-          blur_to_bitmap(pw, g, dp, y, c, nz + (size_t)(y + 1) * g.wb, 0);
+          blur_to_bitmap(pw, g.rows, g.cols, s_taps, dp.ksize, y, c, nz + (size_t)(y + 1) * g.wb, 0);
         }
       }
     __threadfence_block();
@@ -1176,12 +1184,14 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
       for (int k = 0; k < 4; ++k) {
         const double rt = k == 0 ? root[0] : (k == 1 ? root[1] : (k == 2 ? root[2] : root[3]));
         // back-substitution, p3p.cpp:193-213
-        const double cot_alpha = (g1 - rt * p_2) / (g2 * rt + g3);
+        // cot_alpha = cn / cd;  sin_alpha = sqrt(1 / (cot^2 + 1)) = |cd| / hypot(cn, cd),
+        // cos_alpha = sign(cot) sqrt(1 - sin^2) = cn sign(cd) / hypot(cn, cd)
+        const double cn = g1 - rt * p_2, cd = g2 * rt + g3;
+        const double ih = rsqrt_nr(cn * cn + cd * cd);
         const double cos_theta = rt;
-        const double sin_theta = sqrt(1 - rt * rt);
-        const double sin_alpha = sqrt(1 / (cot_alpha * cot_alpha + 1));
-        double cos_alpha = sqrt(1 - sin_alpha * sin_alpha);
-        if (cot_alpha < 0) cos_alpha = -cos_alpha;
+        const double sin_theta = sqrt_nr(1 - rt * rt);
+        const double sin_alpha = fabs(cd) * ih;
+        const double cos_alpha = (cd < 0 ? -cn : cn) * ih;
         const double kk = sin_alpha * b + cos_alpha;
         const double Cx = d_12 * cos_alpha * kk, Cy = cos_theta * d_12 * sin_alpha * kk,
                      Cz = sin_theta * d_12 * sin_alpha * kk;
@@ -1200,7 +1210,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           const double X = T00 * w0 + T10 * w1 + T20 * w2;  // T^T w
           const double Y = T01 * w0 + T11 * w1 + T21 * w2;
           const double Z = T02 * w0 + T12 * w1 + T22 * w2;
-          const double iZ = 1.0 / Z;
+          const double iZ = rcp_nr(Z);
           s_q[(2 * j) * nthr + tid] = (fx * X + cx * Z) * iZ;
           s_q[(2 * j + 1) * nthr + tid] = (fy * Y + cy * Z) * iZ;
         }
