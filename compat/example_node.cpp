@@ -57,6 +57,7 @@ int main(int argc, char** argv) {
   trackable_object_.setCertaintyThreshold(0.75);
   trackable_object_.setValidCorrespondenceThreshold(0.7);
 
+  trackable_object_.setBruteForceEveryFrame(true);
   // imageCallback (ROS.cpp:159-190)
   const bool found_body_pose = trackable_object_.estimateBodyPose(ImageView(img.data(), rows, cols, cols), 0.0);
   if (!found_body_pose) {

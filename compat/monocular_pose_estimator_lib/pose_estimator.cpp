@@ -12,7 +12,7 @@ static void check(mpe_handle* h, int rc, const char* what) {
 PoseEstimator::PoseEstimator()
     : detection_threshold_value_(0), gaussian_sigma_(0), min_blob_area_(0), max_blob_area_(0),
       max_width_height_distortion_(0), max_circular_distortion_(0), roi_border_thickness_(0), handle_(0),
-      predicted_time_(0), pose_updated_(false) {
+      tracker_(0), bruteforce_every_frame_(false), predicted_time_(0), pose_updated_(false) {
   mpe_default_params(&params_);
   params_.back_projection_pixel_tolerance = 3;    // pose_estimator.cpp:36
   params_.nearest_neighbour_pixel_tolerance = 5;  // :37
@@ -22,9 +22,13 @@ PoseEstimator::PoseEstimator()
   predicted_pose_ = Matrix4d::Identity();
   int rc = mpe_create(&handle_, -1);
   if (rc != MPE_OK) throw std::runtime_error("mpe_create failed: no HIP device (there is no CPU fallback)");
+  check(handle_, mpe_tracker_create(handle_, &tracker_), "mpe_tracker_create");
 }
 
-PoseEstimator::~PoseEstimator() { mpe_destroy(handle_); }
+PoseEstimator::~PoseEstimator() {
+  mpe_tracker_destroy(tracker_);
+  mpe_destroy(handle_);
+}
 
 void PoseEstimator::syncParams() {
   params_.threshold_value = detection_threshold_value_;
@@ -41,6 +45,7 @@ void PoseEstimator::setMarkerPositions(const List4DPoints& p) {
   for (size_t i = 0; i < p.size(); ++i)
     for (int k = 0; k < 3; ++k) markers_xyz_[3 * i + k] = p[i](k);
   params_.histogram_threshold = 0;  // numCombinations(n, 3) is applied inside the library
+  check(handle_, mpe_tracker_set_markers(tracker_, markers_xyz_.data(), (int)p.size()), "mpe_tracker_set_markers");
 }
 
 List4DPoints PoseEstimator::getMarkerPositions() {
@@ -84,26 +89,31 @@ unsigned PoseEstimator::initialise() {
 }
 
 bool PoseEstimator::estimateBodyPose(const ImageView& image, double time_to_predict) {
-  pose_updated_ = false;
-  setPredictedTime(time_to_predict);  // pose_estimator.cpp:70
   syncParams();
-  double und[2 * MPE_MAX_DETECTIONS];
-  float dist[2 * MPE_MAX_DETECTIONS];
-  int n = 0;
   const double* D = camera_distortion_coeffs_.empty() ? 0 : camera_distortion_coeffs_.data();
-  check(handle_, mpe_find_leds(handle_, image.data, image.rows, image.cols, image.step, 0, 0, image.cols, image.rows,
-                               &params_, camera_matrix_K_.data(), D, (int)camera_distortion_coeffs_.size(), und, dist,
-                               MPE_MAX_DETECTIONS, &n),
-        "mpe_find_leds");
-  distorted_detection_centers_.resize(n);
-  image_points_.resize(n);
-  for (int i = 0; i < n; ++i) {
-    distorted_detection_centers_[i] = {dist[2 * i], dist[2 * i + 1]};
-    image_points_[i](0) = und[2 * i];
-    image_points_[i](1) = und[2 * i + 1];
+  check(handle_, mpe_tracker_set_params(tracker_, &params_), "mpe_tracker_set_params");
+  check(handle_, mpe_tracker_set_camera(tracker_, camera_matrix_K_.data(), D, (int)camera_distortion_coeffs_.size()),
+        "mpe_tracker_set_camera");
+  if (bruteforce_every_frame_) mpe_tracker_reset(tracker_);
+  predicted_time_ = time_to_predict;
+  mpe_result r;
+  const int rc = mpe_tracker_estimate(tracker_, image.data, image.rows, image.cols, image.step, time_to_predict, &r, 0);
+  if (rc < 0) throw std::runtime_error(std::string("mpe_tracker_estimate: ") + mpe_last_error(handle_));
+  pose_updated_ = rc == 1;
+  double xy[2 * MPE_MAX_DETECTIONS];
+  const int nd = mpe_tracker_get_image_points(tracker_, xy, MPE_MAX_DETECTIONS);
+  image_points_.resize(nd > 0 ? nd : 0);
+  for (int i = 0; i < nd; ++i) {
+    image_points_[i](0) = xy[2 * i];
+    image_points_[i](1) = xy[2 * i + 1];
   }
-  if (n >= 4) {  // min_num_leds_detected_ (pose_estimator.h:78)
-    if (initialise() == 1) pose_updated_ = true;  // optimiseAndUpdatePose is part of mpe_solve_bruteforce
+  uint32_t corr[2 * MPE_MAX_MARKERS];
+  const int nc = mpe_tracker_get_correspondences(tracker_, corr, MPE_MAX_MARKERS);
+  correspondences_.clear();
+  for (int i = 0; i < nc; ++i) correspondences_.push_back({{corr[2 * i], corr[2 * i + 1]}});
+  if (pose_updated_) {
+    for (int i = 0; i < 16; ++i) predicted_pose_(i) = r.T[i];
+    for (int i = 0; i < 36; ++i) pose_covariance_(i) = r.cov[i];
   }
   return pose_updated_;
 }

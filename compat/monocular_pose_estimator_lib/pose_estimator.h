@@ -7,10 +7,11 @@
 // after the type substitutions listed in INTEGRATION.md (cv::Mat -> ImageView or the OpenCV
 // adapter, Eigen types -> datatypes.h or the Eigen adapter).
 //
-// Round-1 scope: the uninitialised branch of estimateBodyPose (pose_estimator.cpp:62-96) — every
-// call is a brute-force initialisation, i.e. the estimator behaves like a fresh object per frame
-// (BASELINE configs "brute-force init every frame").  The tracking path (predictPose,
-// findCorrespondences, determineROI ...) is SURVEY §8f "next #1".
+// estimateBodyPose runs the reference's whole state machine (pose_estimator.cpp:62-147) through the
+// stateful mpe_tracker_* ABI: brute-force initialisation while not initialised, then constant-
+// velocity prediction, ROI detection with whole-image retry, nearest-neighbour correspondences and
+// fallback to brute force.  setBruteForceEveryFrame(true) resets the state before every call (the
+// BASELINE configs' mode; the reference itself has no reset).
 #ifndef MPE_COMPAT_POSE_ESTIMATOR_H_
 #define MPE_COMPAT_POSE_ESTIMATOR_H_
 
@@ -43,6 +44,7 @@ class PoseEstimator {
   //! pose_estimator.cpp:62-96; throws std::runtime_error on a HIP / usage error (the reference's
   //! OpenCV calls throw cv::Exception in the same situations), returns pose_updated_ otherwise
   bool estimateBodyPose(const ImageView& image, double time_to_predict);
+  void setBruteForceEveryFrame(bool on) { bruteforce_every_frame_ = on; }  //!< extension, see header comment
 
   void setPredictedTime(double time) { predicted_time_ = time; }
   double getPredictedTime() { return predicted_time_; }
@@ -79,6 +81,8 @@ class PoseEstimator {
  private:
   void syncParams();
   mpe_handle* handle_;
+  mpe_tracker* tracker_;
+  bool bruteforce_every_frame_;
   mpe_params params_;
   std::vector<double> markers_xyz_;
   Matrix4d predicted_pose_;

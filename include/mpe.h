@@ -133,6 +133,38 @@ int mpe_estimate_batch_device(mpe_handle* h, const uint8_t* d_frames, int n_fram
                               const double K[9], const double* D, int nD, const mpe_params* p,
                               mpe_result* d_results);
 
+/* ≙ PoseEstimator::setCorrespondences + checkCorrespondences + optimiseAndUpdatePose
+ * (pose_estimator.h:463,724,773; pose_estimator.cpp:394-542,733-812) — the tracking path's
+ * validate-and-refine step for correspondences found by nearest neighbour.  corr: n_corr rows
+ * (marker, detection), 1-based.  out->status: 0 pose, 1 correspondences rejected. */
+int mpe_check_and_refine(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz,
+                         int n_markers, const double K[9], const mpe_params* p, const uint32_t* corr,
+                         int n_corr, mpe_result* out);
+
+/* ---- stateful estimator: the whole PoseEstimator::estimateBodyPose state machine, i.e. the
+ * uninitialised branch AND the tracking path (pose_estimator.cpp:62-147): pose prediction by the
+ * constant-velocity model (predictPose :232-244), ROI from the predicted LED pixels
+ * (LEDDetector::determineROI, led_detector.cpp:114-179), ROI detection with whole-image retry,
+ * nearest-neighbour correspondences (findCorrespondences :372-392), validation + refinement,
+ * fallback to brute-force initialisation (:831-848).  One tracker = one PoseEstimator object. */
+typedef struct mpe_tracker mpe_tracker;
+int mpe_tracker_create(mpe_handle* h, mpe_tracker** out);              /* PoseEstimator() */
+void mpe_tracker_destroy(mpe_tracker* t);
+int mpe_tracker_set_markers(mpe_tracker* t, const double* xyz, int n); /* setMarkerPositions */
+int mpe_tracker_set_camera(mpe_tracker* t, const double K[9], const double* D, int nD);
+int mpe_tracker_set_params(mpe_tracker* t, const mpe_params* p);       /* tuning members / setters */
+int mpe_tracker_reset(mpe_tracker* t); /* back to "not initialised" (the reference has no reset) */
+/* estimateBodyPose(image, time_to_predict): returns 1 pose updated, 0 not, <0 error.  out (optional)
+ * gets getPredictedPose / getPoseCovariance; info (optional, 8 ints) = region_of_interest_
+ * x,y,w,h, it_since_initialized_, detections, correspondences, 1 if brute force ran. */
+int mpe_tracker_estimate(mpe_tracker* t, const uint8_t* img, int rows, int cols, size_t stride_bytes,
+                         double time_to_predict, mpe_result* out, int info[8]);
+
+/* getCorrespondences() / getImagePoints() of the tracker object: copy up to cap rows / points,
+ * return the number available (or <0). */
+int mpe_tracker_get_correspondences(mpe_tracker* t, uint32_t* corr, int cap_rows);
+int mpe_tracker_get_image_points(mpe_tracker* t, double* xy, int cap_points);
+
 /* Stage-level batch entry points (used by the parity tests at every stage boundary). */
 /* detection only (a1): dets is a HOST array of n_frames records */
 int mpe_detect_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int rows, int cols,

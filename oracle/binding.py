@@ -309,3 +309,50 @@ def estimate_batch(frames, markers, K, D, params, n_threads=1):
     if rc < 0:
         raise ValueError("orc_estimate_batch rc=%d" % rc)
     return out
+
+
+def logarithm_map(T):
+    T = _f64(T).reshape(16)
+    xi = np.zeros(6)
+    lib().orc_logarithm_map(_p(T, C.c_double), _p(xi, C.c_double))
+    return xi
+
+
+class Tracker:
+    """Stateful estimator = the reference's PoseEstimator object driven frame after frame
+    (uninitialised branch, then ROI tracking with fallback to brute force)."""
+
+    def __init__(self, markers, K, D, params):
+        self._lib = lib()
+        self._lib.orc_tracker_create.restype = C.c_void_p
+        self._lib.orc_tracker_estimate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double,
+                                                   C.POINTER(OrcResult), C.POINTER(C.c_int)]
+        self._lib.orc_tracker_destroy.argtypes = [C.c_void_p]
+        markers = _f64(markers).reshape(-1, 3)
+        K = _f64(K).reshape(9)
+        D = _f64(D).reshape(-1)
+        self._t = C.c_void_p(self._lib.orc_tracker_create(_p(markers, C.c_double), len(markers), _p(K, C.c_double),
+                                                          _p(D, C.c_double), len(D), C.byref(params)))
+
+    def estimate(self, img, time):
+        img = np.ascontiguousarray(img, np.uint8)
+        res = OrcResult()
+        info = (C.c_int * 8)()
+        rc = self._lib.orc_tracker_estimate(self._t, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0],
+                                            float(time), C.byref(res), info)
+        if rc < 0:
+            raise ValueError("orc_tracker_estimate rc=%d" % rc)
+        return dict(updated=bool(rc), T=np.array(res.T).reshape(4, 4), cov=np.array(res.cov).reshape(6, 6),
+                    roi=tuple(info[0:4]), it_since_initialized=info[4], n_det=info[5], n_corr=info[6],
+                    used_bruteforce=bool(info[7]))
+
+    def close(self):
+        if self._t:
+            self._lib.orc_tracker_destroy(self._t)
+            self._t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

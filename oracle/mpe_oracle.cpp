@@ -1223,6 +1223,231 @@ class Estimator {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Stateful estimator: the full estimateBodyPose state machine incl. the tracking path
+// (PE.cpp:62-147, 232-244, 270-276, 372-392, 794-848, 996-1064; LED.cpp:114-179)
+// ---------------------------------------------------------------------------------------------
+struct RectI {
+  int x, y, width, height;
+};
+
+class Tracker {
+ public:
+  Estimator e;
+  orc_params p;
+  double Kc[9];
+  std::vector<double> D;
+  M4 current_pose_, previous_pose_;
+  double current_time_ = 0, previous_time_ = 0, predicted_time_ = 0;
+  unsigned it_since_initialized_ = 0;  // PE.cpp:41
+  RectI roi_ = {0, 0, 0, 0};
+  bool pose_updated_ = false;
+  std::vector<V2> predicted_pixel_positions_;
+  std::vector<double> det_;    // detected_led_positions of the current call
+  std::vector<float> dist_;
+  int last_used_bruteforce_ = 0;
+
+  Tracker() {
+    current_pose_ = identity4();
+    previous_pose_ = identity4();
+  }
+
+  // PE.cpp:996-1064
+  static void logarithmMap(const M4& trans, double xi[6]) {
+    double R[3][3], t[3];
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) R[i][j] = trans.m[i][j];
+      t[i] = trans.m[i][3];
+    }
+    double w_hat[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    double phi = 0;
+    // R.isApprox(Identity, 1e-10): ||R - I||_F^2 <= prec^2 * min(||R||_F^2, ||I||_F^2)
+    double dn = 0, rn = 0;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double dI = R[i][j] - (i == j ? 1.0 : 0.0);
+        dn += dI * dI;
+        rn += R[i][j] * R[i][j];
+      }
+    const bool is_identity = dn <= 1e-10 * 1e-10 * std::min(rn, 3.0);
+    if (!is_identity) {
+      double temp = (R[0][0] + R[1][1] + R[2][2] - 1) / 2;
+      if (temp > 1)
+        temp = 1;
+      else if (temp < -1)
+        temp = -1;
+      phi = std::acos(temp);
+      if (phi != 0) {
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) w_hat[i][j] = (R[i][j] - R[j][i]) / (2 * std::sin(phi)) * phi;
+      }
+    }
+    double w[3] = {w_hat[2][1], w_hat[0][2], w_hat[1][0]};
+    double w_norm = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    double A_inv[3][3];
+    // t.isApproxToConstant(0, 1e-10): |t_i - 0| <= min(|t_i|, 0) * prec  <=>  t == 0 exactly
+    const bool t_zero = (t[0] == 0 && t[1] == 0 && t[2] == 0);
+    if (t_zero) {
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A_inv[i][j] = 0;
+    } else if (w_norm == 0 || std::sin(w_norm) == 0) {
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A_inv[i][j] = (i == j) ? 1.0 : 0.0;
+    } else {
+      double w2[3][3];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          double s = w_hat[i][0] * w_hat[0][j];
+          s += w_hat[i][1] * w_hat[1][j];
+          s += w_hat[i][2] * w_hat[2][j];
+          w2[i][j] = s;
+        }
+      const double c = (2 * std::sin(w_norm) - w_norm * (1 + std::cos(w_norm))) / (2 * w_norm * w_norm * std::sin(w_norm));
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A_inv[i][j] = ((i == j) ? 1.0 : 0.0) - w_hat[i][j] / 2 + c * w2[i][j];
+    }
+    for (int i = 0; i < 3; ++i) {
+      double s = A_inv[i][0] * t[0];
+      s += A_inv[i][1] * t[1];
+      s += A_inv[i][2] * t[2];
+      xi[i] = s;
+      xi[3 + i] = w[i];
+    }
+  }
+
+  void predictPose(double time_to_predict) {  // PE.cpp:232-244
+    predicted_time_ = time_to_predict;
+    double delta[6], delta_hat[6];
+    logarithmMap(mul(inverse4(previous_pose_), current_pose_), delta);
+    for (int i = 0; i < 6; ++i) delta_hat[i] = delta[i] / (current_time_ - previous_time_) * (predicted_time_ - current_time_);
+    e.predicted_pose_ = mul(current_pose_, Estimator::exponentialMap(delta_hat));
+  }
+
+  void predictMarkerPositionsInImage() {  // PE.cpp:270-276
+    predicted_pixel_positions_.resize(e.object_points_.size());
+    for (size_t i = 0; i < e.object_points_.size(); ++i)
+      predicted_pixel_positions_[i] = e.project2d(e.object_points_[i], e.predicted_pose_);
+  }
+
+  RectI determineROI(int rows, int cols) const {  // LED.cpp:114-179
+    double x_min = INFINITY, x_max = 0, y_min = INFINITY, y_max = 0;
+    for (const V2& q : predicted_pixel_positions_) {
+      if (q.x < x_min) x_min = q.x;
+      if (q.x > x_max) x_max = q.x;
+      if (q.y < y_min) y_min = q.y;
+      if (q.y > y_max) y_max = q.y;
+    }
+    float und[4] = {(float)x_min, (float)y_min, (float)x_max, (float)y_max};  // cv::Point2f
+    float dst[4];
+    distort_points(und, dst, 2, Kc, D.data(), (int)D.size());
+    const double x_min_dist = dst[0], y_min_dist = dst[1], x_max_dist = dst[2], y_max_dist = dst[3];
+    const int border_size = (int)p.roi_border_thickness;
+    const double x0 = std::max(0.0, std::min((double)cols, x_min_dist - border_size));
+    const double x1 = std::max(0.0, std::min((double)cols, x_max_dist + border_size));
+    const double y0 = std::max(0.0, std::min((double)rows, y_min_dist - border_size));
+    const double y1 = std::max(0.0, std::min((double)rows, y_max_dist + border_size));
+    RectI r;
+    if (x1 - x0 < 1 || y1 - y0 < 1) {
+      r = {0, 0, cols, rows};
+    } else {
+      r.x = (int)x0;
+      r.y = (int)y0;
+      r.width = (int)(x1 - x0);
+      r.height = (int)(y1 - y0);
+    }
+    return r;
+  }
+
+  void findCorrespondences() {  // PE.cpp:372-392
+    std::vector<unsigned> pairs1;
+    std::vector<double> mind;
+    e.calculateMinDistancesAndPairs(predicted_pixel_positions_, e.image_points_, pairs1, mind);
+    e.corr_.clear();
+    for (size_t i = 0; i < pairs1.size(); ++i)
+      if (mind[i] <= p.nearest_neighbour_pixel_tolerance) {
+        e.corr_.push_back((unsigned)i + 1);
+        e.corr_.push_back(pairs1[i]);
+      }
+  }
+
+  void updatePose() {  // PE.cpp:794-800
+    previous_pose_ = current_pose_;
+    current_pose_ = e.predicted_pose_;
+    previous_time_ = current_time_;
+    current_time_ = predicted_time_;
+  }
+  void optimiseAndUpdatePose() {  // PE.cpp:802-812
+    e.optimisePose();
+    if (it_since_initialized_ < 2) it_since_initialized_++;
+    updatePose();
+    pose_updated_ = true;
+  }
+  void findCorrespondencesAndPredictPose() {  // PE.cpp:831-848
+    findCorrespondences();
+    last_used_bruteforce_ = 0;
+    if (e.checkCorrespondences() == 1) {
+      optimiseAndUpdatePose();
+    } else {
+      last_used_bruteforce_ = 1;
+      if (e.initialise(nullptr) == 1) optimiseAndUpdatePose();
+    }
+  }
+
+  int detect(const uint8_t* img, int rows, int cols, size_t stride) {
+    std::vector<double> u;
+    std::vector<float> d;
+    int n = find_leds(img, rows, cols, stride, roi_.x, roi_.y, roi_.width, roi_.height, p, Kc, D.data(), (int)D.size(), u, d);
+    if (n < 0) return n;
+    dist_ = d;                // distorted_detection_centers = distorted_points (LED.cpp:89)
+    if (n > 0) det_ = u;      // pixel_positions is only resized/filled when numPoints > 0 (LED.cpp:91-111)
+    return n;
+  }
+
+  // PE.cpp:62-147
+  int estimateBodyPose(const uint8_t* img, int rows, int cols, size_t stride, double time_to_predict) {
+    pose_updated_ = false;
+    last_used_bruteforce_ = 0;
+    det_.clear();
+    if (it_since_initialized_ < 1) {
+      predicted_time_ = time_to_predict;
+      roi_ = {0, 0, cols, rows};
+      if (detect(img, rows, cols, stride) < 0) return -1;
+      if (det_.size() / 2 >= 4) {
+        e.setImagePoints(det_.data(), (int)det_.size() / 2);
+        last_used_bruteforce_ = 1;
+        if (e.initialise(nullptr) == 1) optimiseAndUpdatePose();
+      }
+    } else {
+      // predictWithROI, PE.cpp:814-829
+      if (it_since_initialized_ >= 2)
+        predictPose(time_to_predict);
+      else
+        predicted_time_ = time_to_predict;
+      predictMarkerPositionsInImage();
+      roi_ = determineROI(rows, cols);
+      if (detect(img, rows, cols, stride) < 0) return -1;
+      bool repeat_check = true;
+      unsigned num_loops = 0;
+      do {
+        num_loops++;
+        if (det_.size() / 2 >= 4) {
+          e.setImagePoints(det_.data(), (int)det_.size() / 2);
+          findCorrespondencesAndPredictPose();
+          repeat_check = false;
+        } else {
+          if (num_loops < 2) {
+            roi_ = {0, 0, cols, rows};
+            if (detect(img, rows, cols, stride) < 0) return -1;
+          } else {
+            repeat_check = false;
+          }
+        }
+      } while (repeat_check);
+    }
+    return pose_updated_ ? 1 : 0;
+  }
+};
+
 void fill_params(Estimator& e, const orc_params* p, int n_markers) {
   e.back_projection_pixel_tolerance_ = p->back_projection_pixel_tolerance;
   e.nearest_neighbour_pixel_tolerance_ = p->nearest_neighbour_pixel_tolerance;
@@ -1538,6 +1763,52 @@ int orc_estimate_batch(const uint8_t* frames, int n_frames, int rows, int cols, 
   for (int r : rc)
     if (r < 0) return r;
   return 0;
+}
+
+
+// ---- stateful estimator (tracking path) ----
+struct orc_tracker {
+  Tracker t;
+};
+
+orc_tracker* orc_tracker_create(const double* markers, int n_markers, const double K[9], const double* D, int nD,
+                                const orc_params* p) {
+  orc_tracker* tr = new orc_tracker();
+  tr->t.p = *p;
+  for (int i = 0; i < 9; ++i) tr->t.Kc[i] = K[i];
+  tr->t.D.assign(D, D + nD);
+  tr->t.e.setCamera(K);
+  tr->t.e.setMarkerPositions(markers, n_markers);
+  fill_params(tr->t.e, p, n_markers);
+  return tr;
+}
+void orc_tracker_destroy(orc_tracker* tr) { delete tr; }
+
+/* returns 1 (pose updated), 0 (not), <0 error.  info[8] = {roi x,y,w,h, it_since_initialized, n_det, n_corr,
+ * used_bruteforce} */
+int orc_tracker_estimate(orc_tracker* tr, const uint8_t* img, int rows, int cols, size_t stride, double time,
+                         orc_result* out, int* info) {
+  Tracker& t = tr->t;
+  int rc = t.estimateBodyPose(img, rows, cols, stride, time);
+  if (rc < 0) return rc;
+  if (out) write_result(t.e, rc == 1, (int)t.det_.size() / 2, out);
+  if (info) {
+    info[0] = t.roi_.x;
+    info[1] = t.roi_.y;
+    info[2] = t.roi_.width;
+    info[3] = t.roi_.height;
+    info[4] = (int)t.it_since_initialized_;
+    info[5] = (int)t.det_.size() / 2;
+    info[6] = (int)t.e.corr_.size() / 2;
+    info[7] = t.last_used_bruteforce_;
+  }
+  return rc;
+}
+
+void orc_logarithm_map(const double T[16], double xi[6]) {
+  M4 M;
+  std::memcpy(M.m, T, sizeof(M.m));
+  Tracker::logarithmMap(M, xi);
 }
 
 }  // extern "C"

@@ -127,6 +127,18 @@ int orc_estimate_batch(const uint8_t* frames, int n_frames, int rows, int cols, 
                        const double K[9], const double* D, int nD, const orc_params* p,
                        orc_result* out, int n_threads);
 
+/* ---- stateful estimator: the whole estimateBodyPose state machine incl. the tracking path
+ * (PE.cpp:62-147, 232-244, 372-392, 794-848, 996-1064; LED.cpp:114-179) ---- */
+typedef struct orc_tracker orc_tracker;
+orc_tracker* orc_tracker_create(const double* markers, int n_markers, const double K[9], const double* D,
+                                int nD, const orc_params* p);
+void orc_tracker_destroy(orc_tracker* tr);
+/* returns 1 pose updated / 0 not / <0 error; info[8] = roi x,y,w,h, it_since_initialized, n_det,
+ * n_corr, used_bruteforce */
+int orc_tracker_estimate(orc_tracker* tr, const uint8_t* img, int rows, int cols, size_t stride,
+                         double time, orc_result* out, int* info);
+void orc_logarithm_map(const double T[16], double xi[6]); /* PE.cpp:996-1064 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,6 +119,17 @@ def load_library():
                                      dp, dp, C.c_int, C.POINTER(MpeParams), C.c_void_p]
     lib.mpe_vote_batch.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int), C.c_int, dp, C.c_int, dp, C.c_double,
                                    C.POINTER(C.c_uint32)]
+    lib.mpe_check_and_refine.argtypes = [C.c_void_p, dp, C.c_int, dp, C.c_int, dp, C.POINTER(MpeParams),
+                                         C.POINTER(C.c_uint32), C.c_int, C.POINTER(MpeResult)]
+    lib.mpe_tracker_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.mpe_tracker_destroy.argtypes = [C.c_void_p]
+    lib.mpe_tracker_destroy.restype = None
+    lib.mpe_tracker_set_markers.argtypes = [C.c_void_p, dp, C.c_int]
+    lib.mpe_tracker_set_camera.argtypes = [C.c_void_p, dp, dp, C.c_int]
+    lib.mpe_tracker_set_params.argtypes = [C.c_void_p, C.POINTER(MpeParams)]
+    lib.mpe_tracker_reset.argtypes = [C.c_void_p]
+    lib.mpe_tracker_estimate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double,
+                                         C.POINTER(MpeResult), C.POINTER(C.c_int)]
     _lib = lib
     return lib
 
@@ -221,6 +232,20 @@ class Handle:
                     n_det=res.n_det, n_corr=res.n_corr, gn_iterations=res.gn_iterations,
                     hist=hist[:len(det)].copy(), corr=corr[:res.n_corr].copy())
 
+    # ---- setCorrespondences + checkCorrespondences + optimiseAndUpdatePose ----------------------
+    def check_and_refine(self, det, markers, K, params, corr):
+        det = _f64(det).reshape(-1, 2)
+        markers = _f64(markers).reshape(-1, 3)
+        K = _f64(K).reshape(9)
+        corr = np.ascontiguousarray(corr, np.uint32).reshape(-1, 2)
+        res = MpeResult()
+        rc = self._lib.mpe_check_and_refine(self._h, _dp(det), len(det), _dp(markers), len(markers), _dp(K),
+                                            C.byref(params), corr.ctypes.data_as(C.POINTER(C.c_uint32)), len(corr),
+                                            C.byref(res))
+        self._check(rc, "mpe_check_and_refine")
+        return dict(status=res.status, T=np.array(res.T).reshape(4, 4), cov=np.array(res.cov).reshape(6, 6),
+                    n_corr=res.n_corr, gn_iterations=res.gn_iterations)
+
     # ---- estimateBodyPose on a fresh estimator per frame -------------------------------------
     def estimate_batch(self, frames, markers, K, D, params):
         """frames: numpy (n,rows,cols) uint8 on the host, or a torch uint8 CUDA tensor (n,rows,cols)."""
@@ -285,3 +310,50 @@ class Handle:
                                       len(markers), _dp(K), float(tol), hist.ctypes.data_as(C.POINTER(C.c_uint32)))
         self._check(rc, "mpe_vote_batch")
         return [hist[i, :nd[i], :len(markers)].copy() for i in range(n)]
+
+
+class Tracker:
+    """mpe_tracker: one stateful PoseEstimator object (uninitialised branch + tracking path)."""
+
+    def __init__(self, handle, markers, K, D, params):
+        self._handle = handle
+        self._lib = load_library()
+        self._t = C.c_void_p()
+        rc = self._lib.mpe_tracker_create(handle._h, C.byref(self._t))
+        if rc != 0:
+            raise MpeError("mpe_tracker_create failed (%d)" % rc)
+        markers = _f64(markers).reshape(-1, 3)
+        K = _f64(K).reshape(9)
+        D = _f64(D).reshape(-1)
+        handle._check(self._lib.mpe_tracker_set_markers(self._t, _dp(markers), len(markers)), "mpe_tracker_set_markers")
+        handle._check(self._lib.mpe_tracker_set_camera(self._t, _dp(K), _dp(D), len(D)), "mpe_tracker_set_camera")
+        self.set_params(params)
+
+    def set_params(self, params):
+        self._handle._check(self._lib.mpe_tracker_set_params(self._t, C.byref(params)), "mpe_tracker_set_params")
+
+    def reset(self):
+        self._lib.mpe_tracker_reset(self._t)
+
+    def estimate(self, img, time):
+        img = np.ascontiguousarray(img, np.uint8)
+        res = MpeResult()
+        info = (C.c_int * 8)()
+        rc = self._lib.mpe_tracker_estimate(self._t, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0],
+                                            float(time), C.byref(res), info)
+        if rc < 0:
+            raise MpeError("mpe_tracker_estimate failed (%d): %s" % (rc, self._lib.mpe_last_error(self._handle._h).decode()))
+        return dict(updated=bool(rc), T=np.array(res.T).reshape(4, 4), cov=np.array(res.cov).reshape(6, 6),
+                    roi=tuple(info[0:4]), it_since_initialized=info[4], n_det=info[5], n_corr=info[6],
+                    used_bruteforce=bool(info[7]))
+
+    def close(self):
+        if getattr(self, "_t", None):
+            self._lib.mpe_tracker_destroy(self._t)
+            self._t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

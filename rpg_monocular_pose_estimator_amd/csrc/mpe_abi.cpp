@@ -242,7 +242,7 @@ int run_back(mpe_handle* h, hipStream_t st, bool prof, int n_frames, const Solve
     HIP_TRY(h, launch_k2_vote(d_dets, n_frames, *sp, static_cast<const double*>(h->mtab.p), d_hist,
                               auto_splits(h, n_frames, sp->n_markers), sp->n_markers, st));
     if (prof) rec(h, 3);
-    HIP_TRY(h, launch_k3_tail(d_dets, d_hist, n_frames, *sp, d_results, d_corr, st));
+    HIP_TRY(h, launch_k3_tail(d_dets, d_hist, n_frames, *sp, d_results, d_corr, nullptr, st));
   } else if (prof) {
     rec(h, 3);
   }
@@ -561,7 +561,8 @@ int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const d
   HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), 1, sp, static_cast<const double*>(h->mtab.p),
                             static_cast<uint32_t*>(h->hist.p), auto_splits(h, 1, n_markers), n_det, h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
-                            static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), h->stream));
+                            static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), nullptr,
+                            h->stream));
   uint32_t hh[MPE_HIST_STRIDE], hc[2 * MPE_MAX_MARKERS];
   HIP_TRY(h, hipMemcpyAsync(out, h->results.p, sizeof(mpe_result), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(hh, h->hist.p, sizeof(hh), hipMemcpyDeviceToHost, h->stream));
@@ -571,6 +572,38 @@ int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const d
     for (int r = 0; r < n_det; ++r)
       for (int c = 0; c < n_markers; ++c) hist[r * n_markers + c] = hh[r * MPE_MAX_MARKERS + c];
   if (corr) std::memcpy(corr, hc, sizeof(uint32_t) * 2 * n_markers);
+  return MPE_OK;
+}
+
+int mpe_check_and_refine(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
+                         const double K[9], const mpe_params* p, const uint32_t* corr, int n_corr, mpe_result* out) {
+  if (!h || (!det_xy && n_det > 0) || !markers_xyz || !K || !p || !out || n_det < 0 || n_corr < 0 || (!corr && n_corr > 0))
+    return fail(h, MPE_ERR_ARG, "bad argument");
+  if (n_det > MPE_MAX_DETECTIONS || n_corr > MPE_MAX_MARKERS) return fail(h, MPE_ERR_UNSUPPORTED, "too many points");
+  HIP_TRY(h, hipSetDevice(h->device));
+  SolveParams sp;
+  if (make_solve_params(p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
+  for (int i = 0; i < n_corr; ++i)
+    if (corr[2 * i] < 1 || corr[2 * i] > (uint32_t)n_markers || corr[2 * i + 1] < 1 || corr[2 * i + 1] > (uint32_t)n_det)
+      return fail(h, MPE_ERR_ARG, "correspondence index out of range");
+  mpe_detections hd;
+  std::memset(&hd, 0, sizeof(hd));
+  hd.n = n_det;
+  if (n_det) std::memcpy(hd.undist_xy, det_xy, sizeof(double) * 2 * n_det);
+  uint32_t hc[2 * MPE_MAX_MARKERS];
+  std::memset(hc, 0, sizeof(hc));
+  if (n_corr) std::memcpy(hc, corr, sizeof(uint32_t) * 2 * n_corr);
+  HIP_TRY(h, h->dets.reserve(sizeof(mpe_detections)));
+  HIP_TRY(h, h->hist.reserve(MPE_HIST_STRIDE * sizeof(uint32_t)));
+  HIP_TRY(h, h->results.reserve(sizeof(mpe_result)));
+  HIP_TRY(h, h->corr.reserve(2 * MPE_MAX_MARKERS * sizeof(uint32_t)));
+  HIP_TRY(h, hipMemcpyAsync(h->dets.p, &hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->corr.p, hc, sizeof(hc), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
+                            static_cast<mpe_result*>(h->results.p), nullptr, static_cast<uint32_t*>(h->corr.p),
+                            h->stream));
+  HIP_TRY(h, hipMemcpyAsync(out, h->results.p, sizeof(mpe_result), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPE_OK;
 }
 

@@ -1436,7 +1436,8 @@ __device__ __forceinline__ double group_sum(double v) {
 
 __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__ dets,
                                               const uint32_t* __restrict__ hist, int n_frames, SolveParams sp,
-                                              mpe_result* __restrict__ results, uint32_t* __restrict__ corr_out) {
+                                              mpe_result* __restrict__ results, uint32_t* __restrict__ corr_out,
+                                              const uint32_t* __restrict__ corr_in) {
   // dynamic LDS, sized for the actual marker count: partial sums [4][16][3 n_m] and
   // back-projections [2 (n_m - 3)][64]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
@@ -1486,6 +1487,17 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
   if (l == 0) {
     int n_c = 0;
     bool go0 = live && dstatus == 0 && n_d >= 4 && n_m >= 4;
+    if (go0 && corr_in) {
+      // tracking path: correspondences come from findCorrespondences (pose_estimator.cpp:372-392),
+      // rows (marker, detection) terminated by a 0 marker; checkCorrespondences starts from them
+      const uint32_t* ci = corr_in + (size_t)f * 2 * MPE_MAX_MARKERS;
+      while (n_c < MPE_MAX_MARKERS && ci[2 * n_c] != 0) {
+        s_cm[grp][n_c] = (unsigned char)ci[2 * n_c];
+        s_cd[grp][n_c] = (unsigned char)ci[2 * n_c + 1];
+        ++n_c;
+      }
+      go0 = false;
+    }
     if (go0) {
       bool any = false;
       for (int r = 0; r < n_d; ++r)
@@ -1778,12 +1790,12 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
 #undef s_part
 #undef s_q
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
-                          mpe_result* results, uint32_t* corr_out, hipStream_t s) {
+                          mpe_result* results, uint32_t* corr_out, const uint32_t* corr_in, hipStream_t s) {
   if (n_frames <= 0) return hipSuccess;
   const int nu = sp.n_markers > 3 ? sp.n_markers - 3 : 1;
   const size_t lds = ((size_t)K3_FRAMES_PER_BLOCK * K3_GROUP * 3 * sp.n_markers + (size_t)2 * nu * 64) * sizeof(double);
   hipLaunchKernelGGL(k3_tail, dim3((n_frames + K3_FRAMES_PER_BLOCK - 1) / K3_FRAMES_PER_BLOCK), dim3(64), lds, s, dets,
-                     hist, n_frames, sp, results, corr_out);
+                     hist, n_frames, sp, results, corr_out, corr_in);
   return hipGetLastError();
 }
 

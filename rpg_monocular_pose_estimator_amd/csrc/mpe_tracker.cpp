@@ -1,0 +1,425 @@
+// mpe_tracker.cpp — the stateful PoseEstimator state machine (tracking path) on top of the HIP
+// stages.  Host side only: a few 4x4 / 6-vector operations per frame; all image and pose compute
+// runs in the kernels through the public C ABI (mpe_find_leds with a ROI, mpe_check_and_refine,
+// mpe_solve_bruteforce).
+//
+// Reference: PoseEstimator::estimateBodyPose (pose_estimator.cpp:62-147), predictPose (:232-244),
+// predictMarkerPositionsInImage (:270-276), findCorrespondences (:372-392), updatePose /
+// optimiseAndUpdatePose / predictWithROI / findCorrespondencesAndPredictPose (:794-848),
+// logarithmMap / exponentialMap (:962-1064), LEDDetector::determineROI / distortPoints
+// (led_detector.cpp:114-224).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "../../include/mpe.h"
+
+namespace {
+
+struct Mat4 {
+  double a[4][4];
+};
+
+Mat4 eye4() {
+  Mat4 m;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) m.a[i][j] = i == j ? 1.0 : 0.0;
+  return m;
+}
+
+Mat4 matmul(const Mat4& x, const Mat4& y) {
+  Mat4 r;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += x.a[i][k] * y.a[k][j];
+      r.a[i][j] = s;
+    }
+  return r;
+}
+
+// general inverse (Gauss-Jordan, partial pivoting) — Eigen's Matrix4d::inverse() in the reference
+Mat4 inverse(const Mat4& m) {
+  double w[4][8];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      w[i][j] = m.a[i][j];
+      w[i][4 + j] = i == j ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < 4; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 4; ++r)
+      if (std::fabs(w[r][c]) > std::fabs(w[piv][c])) piv = r;
+    if (piv != c)
+      for (int j = 0; j < 8; ++j) std::swap(w[c][j], w[piv][j]);
+    const double d = w[c][c];
+    for (int j = 0; j < 8; ++j) w[c][j] /= d;
+    for (int r = 0; r < 4; ++r) {
+      if (r == c) continue;
+      const double f = w[r][c];
+      for (int j = 0; j < 8; ++j) w[r][j] -= f * w[c][j];
+    }
+  }
+  Mat4 out;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) out.a[i][j] = w[i][4 + j];
+  return out;
+}
+
+// pose_estimator.cpp:962-994
+Mat4 exp_se3(const double tw[6]) {
+  const double wx = tw[3], wy = tw[4], wz = tw[5];
+  const double theta = std::sqrt(wx * wx + wy * wy + wz * wz), th2 = theta * theta;
+  const double O[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+  double O2[3][3], R[3][3], V[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) O2[i][j] = O[i][0] * O[0][j] + O[i][1] * O[1][j] + O[i][2] * O[2][j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double I = i == j ? 1.0 : 0.0;
+      if (theta == 0) {
+        R[i][j] = V[i][j] = I;
+      } else {
+        R[i][j] = I + O[i][j] / theta * std::sin(theta) + O2[i][j] / th2 * (1 - std::cos(theta));
+        V[i][j] = I + (1 - std::cos(theta)) / th2 * O[i][j] + (theta - std::sin(theta)) / (th2 * theta) * O2[i][j];
+      }
+    }
+  Mat4 T = eye4();
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T.a[i][j] = R[i][j];
+    T.a[i][3] = V[i][0] * tw[0] + V[i][1] * tw[1] + V[i][2] * tw[2];
+  }
+  return T;
+}
+
+// pose_estimator.cpp:996-1064
+void log_se3(const Mat4& T, double xi[6]) {
+  double what[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  double dev = 0, nr = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const double e = T.a[i][j] - (i == j ? 1.0 : 0.0);
+      dev += e * e;
+      nr += T.a[i][j] * T.a[i][j];
+    }
+  // Eigen isApprox(Identity, 1e-10): squared distance <= prec^2 * min(squared norms)
+  if (!(dev <= 1e-20 * std::min(nr, 3.0))) {
+    double c = (T.a[0][0] + T.a[1][1] + T.a[2][2] - 1) / 2;
+    c = c > 1 ? 1 : (c < -1 ? -1 : c);
+    const double phi = std::acos(c);
+    if (phi != 0)
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) what[i][j] = (T.a[i][j] - T.a[j][i]) / (2 * std::sin(phi)) * phi;
+  }
+  const double w[3] = {what[2][1], what[0][2], what[1][0]};
+  const double wn = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  const double t[3] = {T.a[0][3], T.a[1][3], T.a[2][3]};
+  double Ai[3][3];
+  if (t[0] == 0 && t[1] == 0 && t[2] == 0) {  // isApproxToConstant(0, 1e-10) holds only for exact zeros
+    std::memset(Ai, 0, sizeof(Ai));
+  } else if (wn == 0 || std::sin(wn) == 0) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) Ai[i][j] = i == j ? 1.0 : 0.0;
+  } else {
+    const double k = (2 * std::sin(wn) - wn * (1 + std::cos(wn))) / (2 * wn * wn * std::sin(wn));
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        const double sq = what[i][0] * what[0][j] + what[i][1] * what[1][j] + what[i][2] * what[2][j];
+        Ai[i][j] = (i == j ? 1.0 : 0.0) - what[i][j] / 2 + k * sq;
+      }
+  }
+  for (int i = 0; i < 3; ++i) {
+    xi[i] = Ai[i][0] * t[0] + Ai[i][1] * t[1] + Ai[i][2] * t[2];
+    xi[3 + i] = w[i];
+  }
+}
+
+}  // namespace
+
+struct mpe_tracker {
+  mpe_handle* h = nullptr;
+  mpe_params p;
+  double K[9];
+  std::vector<double> D;
+  std::vector<double> markers;  // n x 3
+  Mat4 current, previous, predicted;
+  double cov[36];
+  double t_current = 0, t_previous = 0, t_predicted = 0;
+  unsigned it_since_initialized = 0;
+  int roi[4] = {0, 0, 0, 0};
+  bool pose_updated = false;
+  std::vector<double> predicted_px;  // n_markers x 2
+  std::vector<double> det;           // detected_led_positions of the current call
+  std::vector<uint32_t> corr;        // rows (marker, detection)
+  int n_corr = 0, gn_iterations = 0;
+  bool used_bruteforce = false;
+};
+
+namespace {
+
+int n_markers(const mpe_tracker* t) { return (int)(t->markers.size() / 3); }
+
+// project2d, pose_estimator.cpp:251-268
+void project(const mpe_tracker* t, const Mat4& T, const double* m, double& u, double& v) {
+  double pc[3];
+  for (int i = 0; i < 3; ++i) pc[i] = T.a[i][0] * m[0] + T.a[i][1] * m[1] + T.a[i][2] * m[2] + T.a[i][3];
+  const double x = t->K[0] * pc[0] + t->K[1] * pc[1] + t->K[2] * pc[2];
+  const double y = t->K[3] * pc[0] + t->K[4] * pc[1] + t->K[5] * pc[2];
+  const double z = t->K[6] * pc[0] + t->K[7] * pc[1] + t->K[8] * pc[2];
+  u = x / z;
+  v = y / z;
+}
+
+// LEDDetector::distortPoints for one point, float in / float out (led_detector.cpp:181-224)
+void distort(const mpe_tracker* t, float sx, float sy, float& ox, float& oy) {
+  const double fx = t->K[0], fy = t->K[4], cx = t->K[2], cy = t->K[5];
+  const size_t n = t->D.size();
+  const double k1 = n > 0 ? t->D[0] : 0, k2 = n > 1 ? t->D[1] : 0, p1 = n > 2 ? t->D[2] : 0, p2 = n > 3 ? t->D[3] : 0,
+               k3 = n > 4 ? t->D[4] : 0;
+  const double x = ((double)sx - cx) / fx, y = ((double)sy - cy) / fy;
+  const double r2 = x * x + y * y;
+  double xc = x * (1. + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2);
+  double yc = y * (1. + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2);
+  xc = xc + (2. * p1 * x * y + p2 * (r2 + 2. * x * x));
+  yc = yc + (p1 * (r2 + 2. * y * y) + 2. * p2 * x * y);
+  ox = (float)(xc * fx + cx);
+  oy = (float)(yc * fy + cy);
+}
+
+// LEDDetector::determineROI (led_detector.cpp:114-179)
+void determine_roi(mpe_tracker* t, int rows, int cols) {
+  double x_min = std::numeric_limits<double>::infinity(), x_max = 0, y_min = x_min, y_max = 0;
+  for (int i = 0; i < n_markers(t); ++i) {
+    const double u = t->predicted_px[2 * i], v = t->predicted_px[2 * i + 1];
+    if (u < x_min) x_min = u;
+    if (u > x_max) x_max = u;
+    if (v < y_min) y_min = v;
+    if (v > y_max) y_max = v;
+  }
+  float ax, ay, bx, by;
+  distort(t, (float)x_min, (float)y_min, ax, ay);
+  distort(t, (float)x_max, (float)y_max, bx, by);
+  const int border = (int)t->p.roi_border_thickness;
+  const double x0 = std::max(0.0, std::min((double)cols, (double)ax - border));
+  const double x1 = std::max(0.0, std::min((double)cols, (double)bx + border));
+  const double y0 = std::max(0.0, std::min((double)rows, (double)ay - border));
+  const double y1 = std::max(0.0, std::min((double)rows, (double)by + border));
+  if (x1 - x0 < 1 || y1 - y0 < 1) {
+    t->roi[0] = 0;
+    t->roi[1] = 0;
+    t->roi[2] = cols;
+    t->roi[3] = rows;
+  } else {
+    t->roi[0] = (int)x0;
+    t->roi[1] = (int)y0;
+    t->roi[2] = (int)(x1 - x0);
+    t->roi[3] = (int)(y1 - y0);
+  }
+}
+
+int detect(mpe_tracker* t, const uint8_t* img, int rows, int cols, size_t stride) {
+  double und[2 * MPE_MAX_DETECTIONS];
+  float dist[2 * MPE_MAX_DETECTIONS];
+  int n = 0;
+  int rc = mpe_find_leds(t->h, img, rows, cols, stride, t->roi[0], t->roi[1], t->roi[2], t->roi[3], &t->p, t->K,
+                         t->D.empty() ? nullptr : t->D.data(), (int)t->D.size(), und, dist, MPE_MAX_DETECTIONS, &n);
+  if (rc != MPE_OK) return rc;
+  if (n > 0) t->det.assign(und, und + 2 * n);  // pixel_positions is only rewritten when something was found
+  return MPE_OK;
+}
+
+void take_result(mpe_tracker* t, const mpe_result& r) {
+  std::memcpy(t->predicted.a, r.T, sizeof(r.T));
+  std::memcpy(t->cov, r.cov, sizeof(r.cov));
+  t->gn_iterations = r.gn_iterations;
+  // optimiseAndUpdatePose (pose_estimator.cpp:802-812) + updatePose (:794-800)
+  if (t->it_since_initialized < 2) t->it_since_initialized++;
+  t->previous = t->current;
+  t->current = t->predicted;
+  t->t_previous = t->t_current;
+  t->t_current = t->t_predicted;
+  t->pose_updated = true;
+}
+
+int bruteforce(mpe_tracker* t) {  // initialise() + optimiseAndUpdatePose()
+  mpe_result r;
+  std::vector<uint32_t> c(2 * MPE_MAX_MARKERS, 0);
+  t->used_bruteforce = true;
+  int rc = mpe_solve_bruteforce(t->h, t->det.data(), (int)t->det.size() / 2, t->markers.data(), n_markers(t), t->K,
+                                &t->p, &r, nullptr, c.data());
+  if (rc != MPE_OK) return rc;
+  if (r.status < 0) return r.status;
+  t->n_corr = r.n_corr;
+  t->corr.assign(c.begin(), c.begin() + 2 * r.n_corr);
+  if (r.status == MPE_FRAME_POSE) take_result(t, r);
+  return MPE_OK;
+}
+
+// findCorrespondencesAndPredictPose (pose_estimator.cpp:831-848)
+int track(mpe_tracker* t) {
+  // findCorrespondences: nearest detection of every predicted marker pixel, kept if <= tolerance
+  const int nm = n_markers(t), nd = (int)t->det.size() / 2;
+  t->corr.clear();
+  for (int i = 0; i < nm; ++i) {
+    double best = std::numeric_limits<double>::infinity();
+    unsigned bj = 0;
+    for (int j = 0; j < nd; ++j) {
+      const double du = t->predicted_px[2 * i] - t->det[2 * j], dv = t->predicted_px[2 * i + 1] - t->det[2 * j + 1];
+      const double d2 = du * du + dv * dv;
+      if (d2 < best) {
+        best = d2;
+        bj = (unsigned)j + 1;
+      }
+    }
+    if (std::sqrt(best) <= t->p.nearest_neighbour_pixel_tolerance) {
+      t->corr.push_back((unsigned)i + 1);
+      t->corr.push_back(bj);
+    }
+  }
+  t->n_corr = (int)t->corr.size() / 2;
+  mpe_result r;
+  int rc = mpe_check_and_refine(t->h, t->det.data(), nd, t->markers.data(), nm, t->K, &t->p, t->corr.data(), t->n_corr,
+                                &r);
+  if (rc != MPE_OK) return rc;
+  if (r.status < 0) return r.status;
+  if (r.status == MPE_FRAME_POSE) {
+    take_result(t, r);
+    return MPE_OK;
+  }
+  return bruteforce(t);  // reinitialise if the correspondences were not valid
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpe_tracker_create(mpe_handle* h, mpe_tracker** out) {
+  if (!h || !out) return MPE_ERR_ARG;
+  mpe_tracker* t = new mpe_tracker();
+  t->h = h;
+  mpe_default_params(&t->p);
+  t->p.back_projection_pixel_tolerance = 3;    // constructor defaults, pose_estimator.cpp:34-42
+  t->p.nearest_neighbour_pixel_tolerance = 5;
+  t->p.certainty_threshold = 0.75;
+  t->p.valid_correspondence_threshold = 0.7;
+  std::memset(t->K, 0, sizeof(t->K));
+  t->current = t->previous = t->predicted = eye4();
+  std::memset(t->cov, 0, sizeof(t->cov));
+  *out = t;
+  return MPE_OK;
+}
+
+void mpe_tracker_destroy(mpe_tracker* t) { delete t; }
+
+int mpe_tracker_set_markers(mpe_tracker* t, const double* xyz, int n) {
+  if (!t || (!xyz && n > 0) || n < 0 || n > MPE_MAX_MARKERS) return MPE_ERR_ARG;
+  t->markers.assign(xyz, xyz + 3 * n);
+  t->predicted_px.assign(2 * n, 0.0);
+  t->p.histogram_threshold = 0;  // numCombinations(n,3), pose_estimator.cpp:54
+  return MPE_OK;
+}
+
+int mpe_tracker_set_camera(mpe_tracker* t, const double K[9], const double* D, int nD) {
+  if (!t || !K || nD < 0) return MPE_ERR_ARG;
+  std::memcpy(t->K, K, sizeof(t->K));
+  t->D.assign(D, D + nD);
+  return MPE_OK;
+}
+
+int mpe_tracker_set_params(mpe_tracker* t, const mpe_params* p) {
+  if (!t || !p) return MPE_ERR_ARG;
+  t->p = *p;
+  return MPE_OK;
+}
+
+int mpe_tracker_reset(mpe_tracker* t) {
+  if (!t) return MPE_ERR_ARG;
+  t->it_since_initialized = 0;
+  return MPE_OK;
+}
+
+int mpe_tracker_get_correspondences(mpe_tracker* t, uint32_t* corr, int cap_rows) {  // getCorrespondences()
+  if (!t || (!corr && cap_rows > 0)) return MPE_ERR_ARG;
+  const int n = std::min<int>((int)t->corr.size() / 2, cap_rows);
+  for (int i = 0; i < 2 * n; ++i) corr[i] = t->corr[i];
+  return (int)t->corr.size() / 2;
+}
+
+int mpe_tracker_get_image_points(mpe_tracker* t, double* xy, int cap_points) {  // getImagePoints()
+  if (!t || (!xy && cap_points > 0)) return MPE_ERR_ARG;
+  const int n = std::min<int>((int)t->det.size() / 2, cap_points);
+  for (int i = 0; i < 2 * n; ++i) xy[i] = t->det[i];
+  return (int)t->det.size() / 2;
+}
+
+int mpe_tracker_estimate(mpe_tracker* t, const uint8_t* img, int rows, int cols, size_t stride_bytes, double time,
+                         mpe_result* out, int info[8]) {
+  if (!t || !img) return MPE_ERR_ARG;
+  t->pose_updated = false;
+  t->used_bruteforce = false;
+  t->det.clear();
+  // correspondences_ is a member of the reference object: it keeps its last value when a frame has
+  // too few detections (getCorrespondences() then returns the stale rows) — same here
+  int rc = MPE_OK;
+  if (t->it_since_initialized < 1) {  // pose_estimator.cpp:68-96
+    t->t_predicted = time;
+    t->roi[0] = t->roi[1] = 0;
+    t->roi[2] = cols;
+    t->roi[3] = rows;
+    if ((rc = detect(t, img, rows, cols, stride_bytes)) != MPE_OK) return rc;
+    if (t->det.size() / 2 >= 4)
+      if ((rc = bruteforce(t)) != MPE_OK) return rc;
+  } else {  // pose_estimator.cpp:98-144
+    // predictWithROI (:814-829)
+    if (t->it_since_initialized >= 2) {
+      // predictPose (:232-244)
+      t->t_predicted = time;
+      double delta[6], dh[6];
+      log_se3(matmul(inverse(t->previous), t->current), delta);
+      for (int i = 0; i < 6; ++i) dh[i] = delta[i] / (t->t_current - t->t_previous) * (t->t_predicted - t->t_current);
+      t->predicted = matmul(t->current, exp_se3(dh));
+    } else {
+      t->t_predicted = time;
+    }
+    for (int i = 0; i < n_markers(t); ++i)
+      project(t, t->predicted, &t->markers[3 * i], t->predicted_px[2 * i], t->predicted_px[2 * i + 1]);
+    determine_roi(t, rows, cols);
+    if ((rc = detect(t, img, rows, cols, stride_bytes)) != MPE_OK) return rc;
+    bool repeat_check = true;
+    unsigned num_loops = 0;
+    do {
+      num_loops++;
+      if (t->det.size() / 2 >= 4) {
+        if ((rc = track(t)) != MPE_OK) return rc;
+        repeat_check = false;
+      } else if (num_loops < 2) {  // too few LEDs in the ROI: search the whole image once
+        t->roi[0] = t->roi[1] = 0;
+        t->roi[2] = cols;
+        t->roi[3] = rows;
+        if ((rc = detect(t, img, rows, cols, stride_bytes)) != MPE_OK) return rc;
+      } else {
+        repeat_check = false;
+      }
+    } while (repeat_check);
+  }
+  if (out) {
+    std::memcpy(out->T, t->predicted.a, sizeof(out->T));
+    std::memcpy(out->cov, t->cov, sizeof(out->cov));
+    out->status = t->pose_updated ? MPE_FRAME_POSE : MPE_FRAME_NO_POSE;
+    out->n_det = (int)t->det.size() / 2;
+    out->n_corr = t->n_corr;
+    out->gn_iterations = t->gn_iterations;
+  }
+  if (info) {
+    for (int i = 0; i < 4; ++i) info[i] = t->roi[i];
+    info[4] = (int)t->it_since_initialized;
+    info[5] = (int)t->det.size() / 2;
+    info[6] = t->n_corr;
+    info[7] = t->used_bruteforce ? 1 : 0;
+  }
+  return t->pose_updated ? 1 : 0;
+}
+
+}  // extern "C"

@@ -2,16 +2,20 @@
 (monocular_pose_estimator_lib/include/monocular_pose_estimator_lib/pose_estimator.h:52-803) on top
 of the HIP C ABI, so parity tests read like code written against the reference class.
 
-Only the uninitialised branch of estimateBodyPose (pose_estimator.cpp:62-96) is provided in this
-round: every call is a fresh brute-force initialisation, as the BASELINE configs require.
+estimateBodyPose runs the reference's whole state machine (pose_estimator.cpp:62-147): brute-force
+initialisation while not initialised, then prediction + ROI detection + nearest-neighbour
+correspondences with fallback to brute force (mpe_tracker_* in include/mpe.h).
+``bruteforce_every_frame=True`` resets the state before every call (the BASELINE configs' mode).
 """
 import numpy as np
 
-from .binding import Handle, demo_params
+from .binding import Handle, Tracker, demo_params
 
 
 class PoseEstimator:
-    def __init__(self, handle=None):
+    def __init__(self, handle=None, bruteforce_every_frame=False):
+        self._bf_every_frame = bruteforce_every_frame
+        self._tracker = None
         # constructor defaults, pose_estimator.cpp:34-42
         self._h = handle if handle is not None else Handle()
         self._p = demo_params()
@@ -46,6 +50,7 @@ class PoseEstimator:
     def setMarkerPositions(self, positions):  # pose_estimator.cpp:50-55
         m = np.asarray(positions, np.float64)
         self._markers = m[:, :3].copy()
+        self._tracker = None
         self._p.histogram_threshold = 0  # -> numCombinations(n,3) inside the library
 
     def getMarkerPositions(self):
@@ -97,17 +102,17 @@ class PoseEstimator:
         return self._time
 
     def estimateBodyPose(self, image, time_to_predict):
-        """pose_estimator.cpp:62-96 (uninitialised branch): True iff a pose was found."""
+        """pose_estimator.cpp:62-147: True iff the pose was updated."""
         K = np.asarray(self.camera_matrix_K_, np.float64)
         D = np.asarray(self.camera_distortion_coeffs_, np.float64)
+        if self._tracker is None:
+            self._tracker = Tracker(self._h, self._markers, K, D, self._p)
+        self._tracker.set_params(self._p)
+        if self._bf_every_frame:
+            self._tracker.reset()
         self._time = float(time_to_predict)
-        und, dist = self._h.find_leds(image, self._p, K, D)
-        self._image_points, self._distorted = und, dist
-        if len(und) < 4:  # min_num_leds_detected_
-            return False
-        r = self._h.solve_bruteforce(und, self._markers, K, self._p)
-        self._correspondences = r["corr"]
-        if r["status"] != 0:
-            return False
-        self._pose, self._cov = r["T"], r["cov"]
-        return True
+        r = self._tracker.estimate(image, time_to_predict)
+        self._last = r
+        if r["updated"]:
+            self._pose, self._cov = r["T"], r["cov"]
+        return r["updated"]

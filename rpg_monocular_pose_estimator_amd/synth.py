@@ -195,6 +195,44 @@ def make_frames(config, n, seed):
                 rows=cfg["rows"], cols=cfg["cols"])
 
 
+def make_sequence(config, n, seed, dt=0.02, lin_speed=0.15, ang_speed=0.6, dropout=()):
+    """A smooth trajectory (constant body twist + small jitter) for the tracking path: frame k is at
+    time k*dt.  Frames listed in `dropout` are rendered with only 2 LEDs (forces the retry /
+    re-initialisation logic).  -> dict(frames, T_true, times, K, D, markers)"""
+    cfg = CONFIGS[config] if isinstance(config, str) else config
+    K, D = camera_for(cfg["rows"], cfg["cols"])
+    rows, cols, M = cfg["rows"], cfg["cols"], np.asarray(cfg["markers"])
+    rng = np.random.default_rng([seed, 7])
+    while True:
+        T0, _ = sample_scene(rng, M, K, D, rows, cols, 0, margin=80.0)
+        v = rng.normal(size=3)
+        v *= lin_speed / np.linalg.norm(v)
+        w = rng.normal(size=3)
+        w *= ang_speed / np.linalg.norm(w)
+        Ts, ok = [], True
+        for k in range(n):
+            t = k * dt
+            Tk = np.eye(4)
+            Tk[:3, :3] = rodrigues(w, np.linalg.norm(w) * t) @ T0[:3, :3]
+            Tk[:3, 3] = T0[:3, 3] + v * t + 0.0005 * rng.normal(size=3)
+            px = distort_px(project(Tk, M, K), K, D)
+            d = np.linalg.norm(px[:, None, :] - px[None, :, :], axis=-1) + np.eye(len(M)) * 1e9
+            if (px[:, 0].min() < 20 or px[:, 0].max() > cols - 21 or px[:, 1].min() < 20 or px[:, 1].max() > rows - 21
+                    or Tk[2, 3] < 0.5 or d.min() < 12.0):
+                ok = False
+                break
+            Ts.append(Tk)
+        if ok:
+            break
+    frames = np.empty((n, rows, cols), np.uint8)
+    for k in range(n):
+        px = distort_px(project(Ts[k], M, K), K, D)
+        if k in dropout:
+            px = px[:2]
+        frames[k] = render_frame(np.random.default_rng([seed, k, 3]), px, rows, cols, cfg["spot_sigma"])
+    return dict(frames=frames, T_true=np.array(Ts), times=np.arange(n) * dt, K=K, D=D, markers=M, rows=rows, cols=cols)
+
+
 def render_frames_torch(spots, rows, cols, spot_sigma, device, seed=0, peak=400.0, bg_max=30, out=None):
     """Render scenes on a torch device (bench plumbing): same image model as render_frame, noise
     from torch's generator.  spots: (n,S,2) numpy.  -> uint8 tensor (n,rows,cols)."""

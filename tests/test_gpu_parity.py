@@ -159,7 +159,7 @@ def test_too_many_detections_is_loud(hip, orc):
 def test_pose_estimator_facade(hip, orc):
     d = synth.make_frames("C2", 6, seed=77)
     for i in range(6):
-        pe = mpe.PoseEstimator(hip)
+        pe = mpe.PoseEstimator(hip, bruteforce_every_frame=True)
         pe.setMarkerPositions(d["markers"])
         pe.camera_matrix_K_ = d["K"]
         pe.camera_distortion_coeffs_ = list(d["D"])
@@ -219,3 +219,47 @@ def test_cpp_facade_example_node(orc, tmp_path):
             assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD
         else:
             assert out.returncode == 1
+
+
+@pytest.mark.parametrize("config,seed,dropout", [("C2", 3, (15, 16, 30)), ("C1", 11, (8,)), ("C2", 21, ())])
+def test_tracking_path_matches_oracle(hip, orc, config, seed, dropout):
+    """The stateful estimator (uninitialised branch, then prediction + ROI + nearest-neighbour
+    correspondences with fallback to brute force, pose_estimator.cpp:62-147) frame by frame
+    against the oracle's restatement of the same state machine."""
+    d = synth.make_sequence(config, 36, seed=seed, dropout=dropout)
+    to = orc.Tracker(d["markers"], d["K"], d["D"], orc.make_params())
+    th = mpe.Tracker(hip, d["markers"], d["K"], d["D"], mpe.demo_params())
+    n_tracked = 0
+    for k in range(len(d["frames"])):
+        ro = to.estimate(d["frames"][k], d["times"][k])
+        rh = th.estimate(d["frames"][k], d["times"][k])
+        for key in ("updated", "roi", "it_since_initialized", "n_det", "n_corr", "used_bruteforce"):
+            assert rh[key] == ro[key], (k, key, rh[key], ro[key])
+        if ro["updated"]:
+            dp, dr = pose_diff(rh["T"], ro["T"])
+            assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (k, dp, dr)
+            assert np.allclose(rh["cov"], ro["cov"], rtol=1e-5, atol=1e-12)
+            n_tracked += (not ro["used_bruteforce"])
+    assert n_tracked >= 20   # the ROI tracking branch really ran
+
+
+def test_check_and_refine_parity(hip, orc):
+    d = synth.make_frames("C2", 8, seed=123)
+    Po, Ph = orc.make_params(), mpe.demo_params()
+    for i in range(8):
+        und, _ = orc.find_leds(d["frames"][i], Po, d["K"], d["D"])
+        r = orc.solve_bruteforce(und, d["markers"], d["K"], Po)
+        if r["n_corr"] < 4:
+            continue
+        ok, T0 = orc.check_correspondences(und, d["markers"], d["K"], Po, r["corr"])
+        rh = hip.check_and_refine(und, d["markers"], d["K"], Ph, r["corr"])
+        assert (rh["status"] == 0) == bool(ok)
+        if ok:
+            Topt, cov, it = orc.optimise_pose(und, d["markers"], d["K"], r["corr"], T0)
+            dp, dr = pose_diff(rh["T"], Topt)
+            assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD
+        # wrong correspondences (shifted) must be rejected the same way
+        bad = r["corr"].copy()
+        bad[:, 1] = np.roll(bad[:, 1], 1)
+        ok2, _ = orc.check_correspondences(und, d["markers"], d["K"], Po, bad)
+        assert (hip.check_and_refine(und, d["markers"], d["K"], Ph, bad)["status"] == 0) == bool(ok2)

@@ -358,3 +358,41 @@ def test_fewer_than_four_leds_gives_no_pose(orc):
     img = synth.render_frame(rng, np.array([[100.5, 100.2], [300.1, 200.7], [500.9, 400.3]]), 480, 752)
     r = orc.estimate_batch(img[None], synth.M5, K, D, orc.make_params())
     assert r["status"][0] == 1 and r["n_det"][0] == 3 and r["n_corr"][0] == 0
+
+
+# ---- tracking path (pose_estimator.cpp:232-244, 372-392, 996-1064; led_detector.cpp:114-179) ----
+def test_logarithm_map_inverts_exponential_map(orc):
+    from scipy.linalg import logm
+    assert np.array_equal(orc.logarithm_map(np.eye(4)), np.zeros(6))
+    for _ in range(30):
+        tw = RNG.normal(size=6) * RNG.choice([1e-6, 1e-2, 0.3, 1.0])
+        T = witness.se3_exp(tw)
+        xi = orc.logarithm_map(T)
+        assert np.allclose(xi, tw, atol=1e-9), (xi, tw)
+        L = np.real(logm(T))
+        assert np.allclose(xi[:3], L[:3, 3], atol=1e-8)
+        assert np.allclose(xi[3:], [L[2, 1], L[0, 2], L[1, 0]], atol=1e-8)
+    # pure translation: w = 0 -> A_inv = I
+    T = np.eye(4)
+    T[:3, 3] = [0.1, -0.2, 0.3]
+    assert np.allclose(orc.logarithm_map(T), [0.1, -0.2, 0.3, 0, 0, 0])
+
+
+def test_tracker_state_machine(orc):
+    d = synth.make_sequence("C2", 24, seed=3, dropout=(10, 11))
+    tr = orc.Tracker(d["markers"], d["K"], d["D"], orc.make_params())
+    rs = [tr.estimate(d["frames"][k], d["times"][k]) for k in range(24)]
+    assert rs[0]["updated"] and rs[0]["used_bruteforce"] and rs[0]["roi"] == (0, 0, 752, 480)
+    assert rs[0]["it_since_initialized"] == 1 and rs[1]["it_since_initialized"] == 2
+    for k in range(1, 10):   # ROI tracking: small ROI around the LEDs (+20 px border), no brute force
+        assert rs[k]["updated"] and not rs[k]["used_bruteforce"]
+        x, y, w, h = rs[k]["roi"]
+        assert w < 200 and h < 200
+        px = d["T_true"][k]
+        assert rs[k]["n_corr"] == 5
+    for k in (10, 11):       # 2 LEDs only: ROI search fails, whole image retried, no pose
+        assert not rs[k]["updated"] and rs[k]["roi"] == (0, 0, 752, 480) and rs[k]["n_det"] == 2
+    assert rs[12]["updated"]  # recovers (prediction from the last two poses still lands on the LEDs)
+    for k in range(24):
+        if rs[k]["updated"]:
+            assert np.linalg.norm(rs[k]["T"][:3, 3] - d["T_true"][k][:3, 3]) < 0.03
