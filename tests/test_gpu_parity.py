@@ -263,3 +263,61 @@ def test_check_and_refine_parity(hip, orc):
         bad[:, 1] = np.roll(bad[:, 1], 1)
         ok2, _ = orc.check_correspondences(und, d["markers"], d["K"], Po, bad)
         assert (hip.check_and_refine(und, d["markers"], d["K"], Ph, bad)["status"] == 0) == bool(ok2)
+
+
+@pytest.mark.parametrize("sigma", [0.3, 0.6, 1.0, 2.0, 6.0])
+def test_detection_other_gaussian_sigmas(hip, orc, sigma):
+    """Kernel sizes 3 (fast path), 5, 7, 13 and 37 (generic blur path, dc = 2 at sigma 6)."""
+    d = synth.make_frames("C2", 6, seed=61)
+    frames = d["frames"].copy()
+    frames[0][:6, :] = 200          # bright band on the top border (BORDER_REFLECT_101 rows)
+    frames[1][:, -5:] = 220         # and on the right border
+    kw = dict(gaussian_sigma=sigma, max_blob_area=100000.0, min_blob_area=0.0, max_circular_distortion=1.0,
+              max_width_height_distortion=1.0)
+    got = hip.detect_batch(frames, d["K"], d["D"], mpe.demo_params(**kw))
+    Po = orc.make_params(**kw)
+    for i in range(len(frames)):
+        und, dist = orc.find_leds(frames[i], Po, d["K"], d["D"])
+        assert got["status"][i] == 0 and got["n"][i] == len(und), (i, got["n"][i], len(und))
+        # NaN centroids (zero-area contours pass the filter when min_blob_area = 0) compare equal
+        assert np.array_equal(got["dist_xy"][i][:2 * len(und)].reshape(-1, 2), dist, equal_nan=True), i
+
+
+@pytest.mark.parametrize("rows,cols", [(479, 750), (100, 33), (17, 200), (480, 752)])
+def test_detection_odd_sizes_and_strides(hip, orc, rows, cols):
+    """cols % 16 != 0 and strided host frames go through the repack path; results unchanged."""
+    big = synth.make_frames("C2", 3, seed=71)
+    K, D = big["K"], big["D"]
+    Po, Ph = orc.make_params(), mpe.demo_params()
+    for i in range(3):
+        s = big["spots"][i]
+        x0 = int(np.clip(s[:, 0].mean() - cols / 2, 0, 752 - cols))
+        y0 = int(np.clip(s[:, 1].mean() - rows / 2, 0, 480 - rows))
+        view = big["frames"][i][y0:y0 + rows, x0:x0 + cols]        # non-contiguous view (stride 752)
+        uo, do = orc.find_leds(np.ascontiguousarray(view), Po, K, D)
+        uh, dh = hip.find_leds(np.ascontiguousarray(view), Ph, K, D)
+        assert np.array_equal(do, dh) and np.array_equal(uo, uh), (i, len(do), len(dh))
+        # the same region addressed as an ROI of the big frame
+        uh2, dh2 = hip.find_leds(big["frames"][i], Ph, K, D, roi=(x0, y0, cols, rows))
+        uo2, do2 = orc.find_leds(big["frames"][i], Po, K, D, roi=(x0, y0, cols, rows))
+        assert np.array_equal(do2, dh2) and np.array_equal(uo2, uh2)
+    # a whole batch with cols % 16 != 0
+    crop = np.ascontiguousarray(big["frames"][:, 1:1 + min(rows, 479), 1:1 + min(cols, 751)])
+    got = hip.detect_batch(crop, K, D, Ph)
+    for i in range(3):
+        uo, do = orc.find_leds(crop[i], Po, K, D)
+        assert got["n"][i] == len(uo) and np.array_equal(got["dist_xy"][i][:2 * len(uo)].reshape(-1, 2), do)
+
+
+def test_threshold_extremes_and_no_distortion(hip, orc):
+    d = synth.make_frames("C2", 2, seed=81)
+    for thr in (0, 30, 254, 255):
+        kw = dict(threshold_value=thr)
+        got = hip.detect_batch(d["frames"], d["K"], np.zeros(0), mpe.demo_params(**kw))
+        for i in range(2):
+            uo, do = orc.find_leds(d["frames"][i], orc.make_params(**kw), d["K"], np.zeros(0))
+            if len(uo) > mpe.MAX_DETECTIONS:
+                assert got["status"][i] == -10
+                continue
+            assert got["status"][i] == 0 and got["n"][i] == len(uo), (thr, i, got["n"][i], len(uo))
+            assert np.array_equal(got["undist_xy"][i][:2 * len(uo)].reshape(-1, 2), uo)
