@@ -229,7 +229,7 @@ int run_front(mpe_handle* h, hipStream_t st, bool prof, int chain, int chain_fra
   HIP_TRY(h, launch_k1a_scan(d_frames, bytes, d_flags, dp.thr, st));
   if (prof) rec(h, 1);
   HIP_TRY(h, launch_k1b_blobs(d_frames, d_flags, n_frames, g, dp, d_dets,
-                              static_cast<int*>(h->work.p) + (size_t)chain * (chain_frames + 1),
+                              static_cast<int*>(h->work.p) + (size_t)chain * 2 * (chain_frames + 1),
                               static_cast<uint8_t*>(h->scratch.p), sp ? sp->n_markers : 0, st));
   if (prof) rec(h, 2);
   return MPE_OK;
@@ -265,7 +265,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
   if (nsub <= 1) {
     HIP_TRY(h, h->flags.reserve(flag_words(frame_bytes * n_frames) * 8));
-    HIP_TRY(h, h->work.reserve((size_t)(n_frames + 1) * sizeof(int)));
+    HIP_TRY(h, h->work.reserve((size_t)2 * (n_frames + 1) * sizeof(int)));
     int rc = run_front(h, h->stream, h->profiling, 0, n_frames, d_frames, n_frames, g, dp, sp,
                        static_cast<unsigned long long*>(h->flags.p), d_dets);
     if (rc) return rc;
@@ -279,7 +279,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   const int per = ((n_frames + nsub - 1) / nsub + 63) & ~63;
   const size_t fw_per = flag_words(frame_bytes * per);
   HIP_TRY(h, h->flags.reserve(fw_per * nsub * 8));
-  HIP_TRY(h, h->work.reserve((size_t)(per + 1) * nsub * sizeof(int)));
+  HIP_TRY(h, h->work.reserve((size_t)2 * (per + 1) * nsub * sizeof(int)));
   for (int i = 0; i < 2; ++i)
     if (!h->sub_stream[i]) HIP_TRY(h, hipStreamCreateWithFlags(&h->sub_stream[i], hipStreamNonBlocking));
   if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));

@@ -243,8 +243,8 @@ __device__ __noinline__ unsigned blur_item_generic(const PixWin& w, int rows, in
 // three bits (x-1, x, x+1) of a bitmap row at bit index xb (>= 1)
 __device__ __forceinline__ unsigned bits3(const u64* row, int xb) {
   const int lo = xb - 1, wi = lo >> 6, sh = lo & 63;
-  const u64 a = row[wi], b = row[wi + 1];
-  const u64 v = sh ? ((a >> sh) | (b << (64 - sh))) : a;
+  u64 v = row[wi] >> sh;
+  if (sh >= 62) v |= row[wi + 1] << (64 - sh);  // the three bits straddle a word boundary (rare)
   return (unsigned)(v & 7);
 }
 // 8-neighbourhood occupancy, bit d = direction d non-zero; directions as OpenCV's chain codes:
@@ -501,8 +501,8 @@ __device__ __forceinline__ void write_detections(const float* kx, const float* k
 #define K1B_BAND_CAP 32     // bands per frame
 #define K1B_ISL_CAP 32      // islands per frame
 // LDS pools (thresholded pixels / bitmap words for all islands of a frame) come in two sizes,
-// picked per launch from the expected number of blobs: <PIX_POOL, BM_POOL> = <6144, 288> keeps
-// 8 waves per CU for the 4-6 LED case, <12288, 704> covers ~16 blobs per frame at 5 waves per CU.
+// tried in turn (device work-lists chain the tiers): <PIX_POOL, BM_POOL> = <4096, 208> keeps
+// 12 waves per CU for the 4-6 LED case, <12288, 704> covers ~16 blobs per frame at 4 waves per CU.
 #define K1B_KEPT_CAP 64     // blobs that pass the shape filter (> MPE_MAX_DETECTIONS -> status)
 
 struct Island {
@@ -514,9 +514,9 @@ struct Island {
 };
 
 template <int K1B_PIX_POOL, int K1B_BM_POOL>
-__global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
-                                               FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
-                                               int* __restrict__ worklist) {
+__device__ __forceinline__ void k1b_frame(const int f, const uint8_t* __restrict__ frames,
+                                          const u64* __restrict__ flags, const FrameGeom& g, const DetectParams& dp,
+                                          mpe_detections* __restrict__ dets, int* __restrict__ worklist) {
   __shared__ __attribute__((aligned(16))) uint8_t s_pix[K1B_PIX_POOL];
   __shared__ u64 s_nz[K1B_BM_POOL + 1], s_pm[K1B_BM_POOL + 1], s_ng[K1B_BM_POOL + 1];
   __shared__ unsigned s_seg[K1B_SEG_CAP];  // y << 16 | segment column
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ fram
                                          //  make the compiler copy all of it to scratch)
 
   const int lane = threadIdx.x;
-  const int f = blockIdx.x;
+  __syncthreads();  // (list mode: the previous frame of this block is completely done)
   if (lane < MPE_MAX_KSIZE) s_taps[lane] = dp.taps[lane < dp.ksize ? lane : 0];
   const uint8_t* frame = frames + (size_t)f * g.rows * g.pitch;
   mpe_detections* out = dets + f;
@@ -596,41 +596,40 @@ __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ fram
   }
   bool fallback = nseg > K1B_SEG_CAP;
 
-  // ---- B1: bands = maximal runs of active rows (lane 0)
-  if (!fallback && lane == 0) {
-    int nb = 0;
-    int run_lo = -1;
-    for (int wi = 0; wi < g.rw; ++wi) {
-      u64 act = s_rowact[wi];
-      int pos = 0;
-      while (pos < 64) {
-        if (run_lo < 0) {  // looking for a band start
-          const u64 rest = pos ? (act >> pos) : act;
-          if (!rest) break;
-          pos += __builtin_ctzll(rest);
-          run_lo = wi * 64 + pos;
-        } else {  // inside a band: find its end
-          const u64 rest = ~(pos ? (act >> pos) : act);
-          const u64 lim = pos ? (rest & ((1ull << (64 - pos)) - 1)) : rest;
-          if (!lim) break;  // runs to the end of this word
-          pos += __builtin_ctzll(lim);
-          if (nb < K1B_BAND_CAP) {
-            s_bandlo[nb] = (short)run_lo;
-            s_bandhi[nb] = (short)(wi * 64 + pos - 1);
-          }
-          ++nb;
-          run_lo = -1;
-        }
+  // ---- B1: bands = maximal runs of active rows.  Lane w owns word w of the row bitset: band starts
+  //      / ends are bit tricks, their ranks a wave prefix sum (starts and ends pair up in order).
+  {
+    const u64 act = (lane < g.rw) ? s_rowact[lane] : 0;
+    const u64 prevw = (lane > 0 && lane < g.rw) ? s_rowact[lane - 1] : 0;
+    const u64 nextw = (lane + 1 < g.rw) ? s_rowact[lane + 1] : 0;
+    u64 st = act & ~((act << 1) | (prevw >> 63));   // row active, row above not
+    u64 en = act & ~((act >> 1) | (nextw << 63));   // row active, row below not
+    const int cs = __builtin_popcountll(st), ce = __builtin_popcountll(en);
+    int ps = cs, pe = ce;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int a = __shfl_up(ps, d), b = __shfl_up(pe, d);
+      if (lane >= d) {
+        ps += a;
+        pe += b;
       }
     }
-    if (run_lo >= 0) {
-      if (nb < K1B_BAND_CAP) {
-        s_bandlo[nb] = (short)run_lo;
-        s_bandhi[nb] = (short)(g.rows - 1);
+    int is_ = ps - cs, ie = pe - ce;  // exclusive ranks
+    if (!fallback) {
+      while (st) {
+        const int b = __builtin_ctzll(st);
+        st &= st - 1;
+        if (is_ < K1B_BAND_CAP) s_bandlo[is_] = (short)(lane * 64 + b);
+        ++is_;
       }
-      ++nb;
+      while (en) {
+        const int b = __builtin_ctzll(en);
+        en &= en - 1;
+        if (ie < K1B_BAND_CAP) s_bandhi[ie] = (short)(lane * 64 + b);
+        ++ie;
+      }
     }
-    s_nband = nb;
+    if (lane == 63) s_nband = ps;
   }
   __syncthreads();
   const int nband = s_nband;
@@ -807,6 +806,23 @@ __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ fram
   write_detections(s_kx, s_ky, s_kkey, s_nkept, K1B_KEPT_CAP, s_over, dp, out, lane);
 }
 
+// one wave per frame, frame = block index
+template <int PIX, int BM>
+__global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
+                                               FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
+                                               int* __restrict__ worklist) {
+  k1b_frame<PIX, BM>(blockIdx.x, frames, flags, g, dp, dets, worklist);
+}
+// frames taken from a device work-list (those the smaller-pool kernel handed over)
+template <int PIX, int BM>
+__global__ __launch_bounds__(64) void k1b_blobs_list(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
+                                                    FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
+                                                    const int* __restrict__ in_list, int* __restrict__ worklist) {
+  const int count = in_list[0];
+  for (int wi = blockIdx.x; wi < count; wi += gridDim.x)
+    k1b_frame<PIX, BM>(in_list[1 + wi], frames, flags, g, dp, dets, worklist);
+}
+
 // =============================================================================================
 // K1b general path: frames the fast path handed over (too many bright segments / rows for its
 // LDS pools).  One wave per frame, whole-frame window in a global scratch slab: thresholded copy
@@ -931,19 +947,29 @@ size_t k1b_scratch_bytes(const FrameGeom& g) { return k1b_gen_scratch_bytes(g) *
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
                             int blob_hint, hipStream_t s) {
+  // Three tiers, chained through device work-lists (no host round trip):
+  //   small LDS pools (3 waves/SIMD) -> large LDS pools -> whole-frame window in global scratch
   if (n_frames <= 0) return hipSuccess;
-  hipError_t e = hipMemsetAsync(worklist, 0, sizeof(int), s);
+  int* list_a = worklist;                   // small -> large
+  int* list_b = worklist + (n_frames + 1);  // large -> general
+  hipError_t e = hipMemsetAsync(list_a, 0, sizeof(int), s);
   if (e != hipSuccess) return e;
-  if (blob_hint > 0 && blob_hint <= 6)
-    hipLaunchKernelGGL((k1b_blobs<6144, 288>), dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
-                       worklist);
-  else
+  e = hipMemsetAsync(list_b, 0, sizeof(int), s);
+  if (e != hipSuccess) return e;
+  if (blob_hint > 0 && blob_hint <= 6) {
+    hipLaunchKernelGGL((k1b_blobs<4096, 208>), dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
+                       list_a);
+    const int grid = n_frames < 2048 ? n_frames : 2048;
+    hipLaunchKernelGGL((k1b_blobs_list<12288, 704>), dim3(grid), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
+                       dets, (const int*)list_a, list_b);
+  } else {
     hipLaunchKernelGGL((k1b_blobs<12288, 704>), dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
-                       dets, worklist);
+                       dets, list_b);
+  }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k1b_general, dim3(K1B_GEN_BLOCKS), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
-                     (const int*)worklist, scratch);
+                     (const int*)list_b, scratch);
   return hipGetLastError();
 }
 
