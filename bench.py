@@ -65,6 +65,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -123,9 +124,21 @@ def main():
     bytes_per_launch = B * rows * cols  # algorithmic: every pixel read once
     scan_s = kavg["scan"] * 1e-3
     achieved = bytes_per_launch / scan_s / 1e9
+    # HBM traffic of the same kernel from the PMC pass committed under profiles/ (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
+    # coalesced reads on gfx950), scaled from bytes per frame to this launch
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_k1a_scan_pmc.json")) as fh:
+            pmc = json.load(fh)
+        if pmc.get("rows") == rows and pmc.get("cols") == cols:
+            traffic = pmc["hbm_bytes_per_frame"] * B
+    except Exception:
+        pass
     roofline = {"kernel": "k1a_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": None,
-                "bytes_per_launch": bytes_per_launch, "avg_launch_ms": kavg["scan"]}
+                "frac": achieved / 8000.0, "traffic": traffic,
+                "bytes_per_launch": bytes_per_launch, "avg_launch_ms": kavg["scan"],
+                "measured": "HIP events on the launch stream, profiled steps without stream pipelining"}
 
     host_fps = None
     if args.host_frames and rank == 0:

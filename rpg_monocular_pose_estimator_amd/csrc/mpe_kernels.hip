@@ -1011,8 +1011,9 @@ __device__ __forceinline__ double pick_root(const P3PCtx& c, int k) {
 // (combinations.cpp:131-244).  Holds everything of P3P::computePoses that depends on the world
 // points only (p3p.cpp:124-141): the eta frame N, P1, p_1, p_2, d_12, the collinearity verdict,
 // and the unused markers expressed in the eta frame, N (m - P1), ascending marker index.
-//   [0..8] N rows, [9..11] P1, [12] p_1, [13] p_2, [14] d_12, [15] valid (1/0), [16 + 3u ..] m_eta[u]
-__host__ __device__ inline int k2_entry_doubles(int n_m) { return 16 + 3 * (n_m - 3); }
+//   [0..8] N rows, [9..11] P1, [12] p_1, [13] p_2, [14] d_12, [15] valid (1/0),
+//   [16] p0 | p1 << 8 | p2 << 16 (as a double), [17] pad, [18 + 3u ..] m_eta[u]
+__host__ __device__ inline int k2_entry_doubles(int n_m) { return 18 + 3 * (n_m - 3); }
 
 __device__ __forceinline__ void perm_from_index(int pj, int n_m, int& p0, int& p1, int& p2) {
   int ma, mb, mc;
@@ -1054,14 +1055,16 @@ __global__ void k2_prep_markers(SolveParams sp, double* __restrict__ tab) {
     e[13] = P3n.y;
     e[14] = norm(P2 - P1);
     e[15] = valid ? 1.0 : 0.0;
+    e[16] = (double)(p0 | (p1 << 8) | (p2 << 16));
+    e[17] = 0.0;
     int u = 0;
     for (int m = 0; m < n_m; ++m) {
       if (m == p0 || m == p1 || m == p2) continue;
       const V3 mm = {sp.markers[3 * m], sp.markers[3 * m + 1], sp.markers[3 * m + 2]};
       const V3 me = mul(N, mm - P1);
-      e[16 + 3 * u] = me.x;
-      e[16 + 3 * u + 1] = me.y;
-      e[16 + 3 * u + 2] = me.z;
+      e[18 + 3 * u] = me.x;
+      e[18 + 3 * u + 1] = me.y;
+      e[18 + 3 * u + 2] = me.z;
       ++u;
     }
   }
@@ -1123,7 +1126,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   const int nuo = n_m - 3;
   const int esz = k2_entry_doubles(n_m);
   const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
-  static const unsigned char kSwapRow[6] = {2, 5, 0, 4, 3, 1};  // block row with P1 <-> P2 exchanged
+  // block row with P1 <-> P2 exchanged: {2, 5, 0, 4, 3, 1}, packed 4 bits per row as 0x134052
 
   for (int tc0 = 0; tc0 < n_combos; tc0 += K2_TRI_CHUNK) {
     const int ntri = min(K2_TRI_CHUNK, n_combos - tc0);
@@ -1168,15 +1171,24 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
     }
     __syncthreads();
 
-    const long long total = (long long)ntri * n_perms;
-    for (long long t = (long long)part * nthr + tid; t < total; t += (long long)splits * nthr) {
-      const int ti = (int)(t / n_perms), pj = (int)(t - (long long)ti * n_perms);
+    // flattened (triple, permutation) index, advanced without divisions
+    const int total = ntri * n_perms;  // <= 64 * 3360
+    const int stride = splits * nthr;
+    int t = part * nthr + tid;
+    int ti = t / n_perms, pj = t - ti * n_perms;
+    const int dti = stride / n_perms, dpj = stride - dti * n_perms;
+    for (; t < total; t += stride, ti += dti, pj += dpj) {
+      if (pj >= n_perms) {
+        pj -= n_perms;
+        ++ti;
+      }
       const unsigned ii = s_trii[ti];
       const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
       const bool swap = (ii >> 24) & 1;
-      int p0, p1, p2;
-      perm_from_index(pj, n_m, p0, p1, p2);
-      const int pjs = swap ? (pj - pj % 6 + kSwapRow[pj % 6]) : pj;
+      const int packed = (int)tab[(size_t)pj * esz + 16];  // marker indices of this permutation
+      const int p0 = packed & 0xFF, p1 = (packed >> 8) & 0xFF, p2 = (packed >> 16) & 0xFF;
+      const int r6 = pj % 6;
+      const int pjs = swap ? (pj - r6 + (int)((0x134052u >> (4 * r6)) & 7u)) : pj;  // kSwapRow packed
       const double* e = tab + (size_t)pjs * esz;
       if (e[15] == 0.0) continue;  // collinear world points: computePoses returns -1
       const double p_1 = e[12], p_2 = e[13], d_12 = e[14];
@@ -1228,7 +1240,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
         const double T00 = tr[0], T01 = tr[1], T02 = tr[2], T10 = tr[3], T11 = tr[4], T12 = tr[5], T20 = tr[6],
                      T21 = tr[7], T22 = tr[8];
         for (int j = 0; j < nuo; ++j) {
-          const double v0 = e[16 + 3 * j] - Cx, v1 = e[16 + 3 * j + 1] - Cy, v2 = e[16 + 3 * j + 2] - Cz;
+          const double v0 = e[18 + 3 * j] - Cx, v1 = e[18 + 3 * j + 1] - Cy, v2 = e[18 + 3 * j + 2] - Cz;
           const double g = cos_theta * v1 + sin_theta * v2;
           const double w0 = -cos_alpha * v0 - sin_alpha * g;
           const double w1 = sin_alpha * v0 - cos_alpha * g;
