@@ -59,7 +59,39 @@ def build(name, config, n, seed, tol):
     print(name, "poses", int((out["status"] == 0).sum()), "/", n)
 
 
+SEQUENCES = [  # name, config, frames, seed, drop-out frames
+    ("seq_c1_demo_replay", "C1", 40, 9101, (12, 13, 27)),
+    ("seq_c2_tracking", "C2", 30, 9102, (9,)),
+]
+
+
+def build_sequence(name, config, n, seed, dropout):
+    """The stateful estimator (tracking path) over a smooth synthetic trajectory = the ROS-free
+    counterpart of the demo.launch bag replay (BASELINE config C1)."""
+    d = synth.make_sequence(config, n, seed=seed, dropout=dropout)
+    tr = oracle.Tracker(d["markers"], d["K"], d["D"], oracle.make_params())
+    out = dict(config=config, seed=seed, n=n, dropout=np.array(dropout, np.int32), times=d["times"],
+               sha1=np.array([hashlib.sha1(f.tobytes()).hexdigest() for f in d["frames"]]),
+               updated=np.zeros(n, np.int32), roi=np.zeros((n, 4), np.int32), it=np.zeros(n, np.int32),
+               n_det=np.zeros(n, np.int32), n_corr=np.zeros(n, np.int32), bruteforce=np.zeros(n, np.int32),
+               T=np.zeros((n, 4, 4)), cov=np.zeros((n, 6, 6)))
+    for k in range(n):
+        r = tr.estimate(d["frames"][k], d["times"][k])
+        out["updated"][k] = r["updated"]
+        out["roi"][k] = r["roi"]
+        out["it"][k] = r["it_since_initialized"]
+        out["n_det"][k] = r["n_det"]
+        out["n_corr"][k] = r["n_corr"]
+        out["bruteforce"][k] = r["used_bruteforce"]
+        out["T"][k] = r["T"]
+        out["cov"][k] = r["cov"]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "poses", int(out["updated"].sum()), "/", n, "tracked", int((out["updated"] & (1 - out["bruteforce"])).sum()))
+
+
 if __name__ == "__main__":
     oracle.build()
     for c in CASES:
         build(*c)
+    for c in SEQUENCES:
+        build_sequence(*c)

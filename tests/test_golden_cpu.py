@@ -3,7 +3,7 @@ tests/golden/make_golden.py): guards the oracle itself against regressions.  CPU
 import numpy as np
 import pytest
 
-from golden_util import golden_cases, load
+from golden_util import golden_cases, golden_sequences, load, load_sequence
 from util import pose_diff
 
 
@@ -25,3 +25,17 @@ def test_oracle_reproduces_golden(orc, name):
             dp, dr = pose_diff(r["T"], g["T"][i])
             assert dp < 1e-9 and dr < 1e-9
             assert np.allclose(r["cov"], g["cov"][i], rtol=1e-6, atol=1e-14)
+
+
+@pytest.mark.parametrize("name", golden_sequences())
+def test_oracle_tracker_reproduces_golden_sequence(orc, name):
+    g, d = load_sequence(name)
+    tr = orc.Tracker(d["markers"], d["K"], d["D"], orc.make_params())
+    for k in range(int(g["n"])):
+        r = tr.estimate(d["frames"][k], d["times"][k])
+        assert r["updated"] == bool(g["updated"][k]) and r["roi"] == tuple(g["roi"][k]), k
+        assert (r["it_since_initialized"], r["n_det"], r["n_corr"], int(r["used_bruteforce"])) == \
+               (g["it"][k], g["n_det"][k], g["n_corr"][k], g["bruteforce"][k]), k
+        if r["updated"]:
+            dp, dr = pose_diff(r["T"], g["T"][k])
+            assert dp < 1e-9 and dr < 1e-9

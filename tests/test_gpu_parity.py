@@ -7,7 +7,7 @@ import pytest
 from rpg_monocular_pose_estimator_amd import synth
 import rpg_monocular_pose_estimator_amd as mpe
 from util import pose_diff, POS_TOL_M, ROT_TOL_RAD
-from golden_util import golden_cases, load as load_golden
+from golden_util import golden_cases, golden_sequences, load as load_golden, load_sequence
 
 pytestmark = pytest.mark.gpu
 
@@ -321,3 +321,39 @@ def test_threshold_extremes_and_no_distortion(hip, orc):
                 continue
             assert got["status"][i] == 0 and got["n"][i] == len(uo), (thr, i, got["n"][i], len(uo))
             assert np.array_equal(got["undist_xy"][i][:2 * len(uo)].reshape(-1, 2), uo)
+
+
+@pytest.mark.parametrize("name", golden_sequences())
+def test_replay_cli_against_golden_sequence(name, tmp_path):
+    """compat/replay (ROS-free counterpart of demo.launch, BASELINE config C1): the C++ facade with the
+    whole state machine over a frame-sequence file + the marker YAML, vs the golden per-frame records."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "compat")])
+    g, d = load_sequence(name)
+    raw = str(tmp_path / "seq.raw")
+    d["frames"].tofile(raw)
+    yaml = str(tmp_path / "markers.yaml")
+    with open(yaml, "w") as fh:
+        fh.write("marker_positions:\n")
+        for m in d["markers"]:
+            fh.write("  - x: %.10g\n    y: %.10g\n    z: %.10g\n" % tuple(m))
+    if str(g["config"]) == "C1":   # the shipped 4-LED file is the C1 marker set
+        yaml = os.path.join(root, "tests", "data", "demo_marker_positions.yaml")
+    dt = float(d["times"][1] - d["times"][0])
+    out = subprocess.run([os.path.join(root, "compat", "replay"), "--markers", yaml, "--frames", raw, "--rows",
+                          str(d["rows"]), "--cols", str(d["cols"]), "--dt", repr(dt)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == int(g["n"])
+    for k, ln in enumerate(lines):
+        tok = ln.split()
+        assert int(tok[0]) == k
+        if g["updated"][k]:
+            assert tok[2] == "pose", (k, ln[:60])
+            T = np.array([float(x) for x in tok[3:19]]).reshape(4, 4)
+            dp, dr = pose_diff(T, g["T"][k])
+            assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (k, dp, dr)
+        else:
+            assert tok[2] == "none", (k, ln[:60])
