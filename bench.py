@@ -41,15 +41,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=16384, help="frames per GPU per step (device-resident batch)")
+    ap.add_argument("--frames", type=int, default=131072, help="frames per GPU per step (device-resident batch, 47 GB)")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--host-frames", action="store_true",
                     help="extra leg: frames streamed from PINNED host memory every step (PCIe-inclusive rate; "
                          "reported as host_streamed_fps, never as value)")
-    ap.add_argument("--k1a-lds", type=int, default=0, help="experiment: dummy LDS per scan block (caps its occupancy)")
-    ap.add_argument("--pipeline", type=int, default=1, help="sub-batches per step on separate HIP streams (1 = off)")
+    ap.add_argument("--k1a-lds", type=int, default=-1, help="tuning: dummy LDS per scan block (-1 = automatic)")
+    ap.add_argument("--pipeline", type=int, default=8, help="sub-batches per step on separate HIP streams (1 = off)")
     args = ap.parse_args()
 
     import torch
@@ -86,7 +86,7 @@ def main():
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     P = mpe.demo_params()
     h.set_option("pipeline", args.pipeline)
-    if args.k1a_lds:
+    if args.k1a_lds >= 0:
         h.set_option("k1a_dummy_lds", args.k1a_lds)
 
     def step():
@@ -116,7 +116,7 @@ def main():
     # ---- per-kernel time with HIP events on the launch stream (separate, profiled steps) ------
     h.set_profiling(True)
     kms = []
-    for _ in range(min(10, max(3, args.steps))):
+    for _ in range(min(5, max(3, args.steps))):
         h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
         kms.append(h.last_kernel_ms())
     h.set_profiling(False)
@@ -194,12 +194,17 @@ def main():
                                              "cores (oracle = restated reference CPU path, not the upstream "
                                              "OpenCV/Eigen binary)" % (ns, cores),
                                    "single_thread_fps": n1 / cpu1_dt}
-            same = bool(np.array_equal(ref["status"], res_host["status"][:ns]))
-            ok = ref["status"] == 0
-            dpos = np.linalg.norm(ref["T"][ok][:, [3, 7, 11]] - res_host["T"][:ns][ok][:, [3, 7, 11]], axis=1)
-            out["parity"] = {"frames": ns, "status_equal": same,
+            got = res_host[:ns]
+            n_status = int((ref["status"] != got["status"]).sum())
+            ok = (ref["status"] == 0) & (got["status"] == 0)
+            dpos = np.linalg.norm(ref["T"][ok][:, [3, 7, 11]] - got["T"][ok][:, [3, 7, 11]], axis=1)
+            out["parity"] = {"frames": ns, "status_equal": n_status == 0, "status_mismatches": n_status,
+                             "poses_compared": int(ok.sum()),
+                             "pose_mismatches_gt_1e-4m": int((dpos > 1e-4).sum()),
                              "pos_rmse_m": float(np.sqrt(np.mean(dpos ** 2))) if len(dpos) else None,
-                             "pos_max_m": float(dpos.max()) if len(dpos) else None}
+                             "pos_max_m": float(dpos.max()) if len(dpos) else None,
+                             "note": "a status mismatch can only come from a hypothesis in the unstable corner of "
+                                     "the reference's Ferrari solver (DESIGN.md section 8; ~1 frame in 1e5)"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

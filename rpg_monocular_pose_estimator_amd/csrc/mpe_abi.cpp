@@ -52,11 +52,13 @@ struct mpe_handle {
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
   int vote_splits = 0;         // 0 = auto
   bool profiling = false;
-  int pipeline = 1;  // sub-batches run on separate streams so that the HBM-bound scan of one overlaps
-                     // the VALU/latency-bound blob, vote and tail kernels of another (1 = off)
-  static const int kMaxSub = 8;
-  hipStream_t sub_stream[kMaxSub] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t sub_done[kMaxSub] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int pipeline = 8;  // up to this many sub-batches (each >= 8192 frames) in a two-stream software
+                     // pipeline: the HBM-bound scan of sub-batch i+1 runs beside the FP64-bound voting
+                     // of sub-batch i (+10-13 % at >= 64k frames per call; 1 = off)
+  static const int kMaxSub = 16;
+  hipStream_t sub_stream[kMaxSub] = {};
+  hipEvent_t sub_done[kMaxSub] = {};
+  hipEvent_t vote_done[kMaxSub] = {};
   hipEvent_t fork_ev = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float last_ms[5] = {0, 0, 0, 0, 0};
@@ -226,7 +228,7 @@ int run_front(mpe_handle* h, hipStream_t st, bool prof, int chain, int chain_fra
               unsigned long long* d_flags, mpe_detections* d_dets) {
   const size_t bytes = (size_t)n_frames * g.rows * g.pitch;
   if (prof) rec(h, 0);
-  HIP_TRY(h, launch_k1a_scan(d_frames, bytes, d_flags, dp.thr, st));
+  HIP_TRY(h, launch_k1a_scan(d_frames, bytes, d_flags, dp.thr, false, st));
   if (prof) rec(h, 1);
   HIP_TRY(h, launch_k1b_blobs(d_frames, d_flags, n_frames, g, dp, d_dets,
                               static_cast<int*>(h->work.p) + (size_t)chain * 2 * (chain_frames + 1),
@@ -260,7 +262,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   }
   int nsub = (h->profiling || !sp) ? 1 : h->pipeline;
   if (nsub > mpe_handle::kMaxSub) nsub = mpe_handle::kMaxSub;
-  if (n_frames < 512 * nsub) nsub = 1;  // small batches: one chain
+  while (nsub > 1 && n_frames < 8192 * nsub) nsub /= 2;  // sub-batches below ~8k frames lose more than overlap gains
   h->have_ms = false;
   HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
   if (nsub <= 1) {
@@ -273,8 +275,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     h->have_ms = (rc == MPE_OK) && h->profiling;
     return rc;
   }
-  // Two-stage software pipeline over nsub sub-batches: stream A runs scan + blobs of sub-batch i+1
-  // (HBM / latency bound) while stream B runs voting + tail of sub-batch i (FP64 VALU bound).
+  // Software pipeline over nsub sub-batches on two streams: A runs scan + blobs, B voting + tail.
   // frames per sub-batch: multiple of 64 so every sub-batch starts on a 16-byte / flag-word boundary
   const int per = ((n_frames + nsub - 1) / nsub + 63) & ~63;
   const size_t fw_per = flag_words(frame_bytes * per);
@@ -287,19 +288,32 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   HIP_TRY(h, hipEventRecord(h->fork_ev, h->stream));
   HIP_TRY(h, hipStreamWaitEvent(sa, h->fork_ev, 0));
   HIP_TRY(h, hipStreamWaitEvent(sb, h->fork_ev, 0));
+  // Staggered schedule: scan(i+1) runs beside vote(i) (HBM-bound beside FP64-bound), blobs(i+1)
+  // beside tail(i) (two latency-bound kernels): blobs(i+1) is held back until vote(i) has finished.
+  if (!h->vote_done[0])
+    for (int i = 0; i < mpe_handle::kMaxSub; ++i)
+      HIP_TRY(h, hipEventCreateWithFlags(&h->vote_done[i], hipEventDisableTiming));
   for (int s = 0; s < nsub; ++s) {
     const int f0 = s * per;
     if (f0 >= n_frames) break;
     const int nf = std::min(per, n_frames - f0);
     if (!h->sub_done[s]) HIP_TRY(h, hipEventCreateWithFlags(&h->sub_done[s], hipEventDisableTiming));
-    int rc = run_front(h, sa, false, s, per, d_frames + (size_t)f0 * frame_bytes, nf, g, dp, sp,
-                       static_cast<unsigned long long*>(h->flags.p) + fw_per * s, d_dets + f0);
-    if (rc) return rc;
+    const uint8_t* fr = d_frames + (size_t)f0 * frame_bytes;
+    unsigned long long* fl = static_cast<unsigned long long*>(h->flags.p) + fw_per * s;
+    HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, true, sa));
+    if (s > 0) HIP_TRY(h, hipStreamWaitEvent(sa, h->vote_done[s - 1], 0));
+    HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
+                                static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
+                                static_cast<uint8_t*>(h->scratch.p), sp->n_markers, sa));
     HIP_TRY(h, hipEventRecord(h->sub_done[s], sa));
     HIP_TRY(h, hipStreamWaitEvent(sb, h->sub_done[s], 0));
-    rc = run_back(h, sb, false, nf, sp, d_dets + f0, d_hist + (size_t)f0 * MPE_HIST_STRIDE, d_results + f0,
-                  d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr);
-    if (rc) return rc;
+    uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
+    HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), sb));
+    HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, *sp, static_cast<const double*>(h->mtab.p), hs,
+                              auto_splits(h, nf, sp->n_markers), sp->n_markers, sb));
+    HIP_TRY(h, hipEventRecord(h->vote_done[s], sb));
+    HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
+                              d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, sb));
   }
   HIP_TRY(h, hipEventRecord(h->fork_ev, sb));  // B finishes last: it waited for every front half
   HIP_TRY(h, hipStreamWaitEvent(h->stream, h->fork_ev, 0));
@@ -377,6 +391,8 @@ void mpe_destroy(mpe_handle* h) {
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : h->sub_done)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->vote_done)
     if (e) (void)hipEventDestroy(e);
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   for (auto& st : h->sub_stream)

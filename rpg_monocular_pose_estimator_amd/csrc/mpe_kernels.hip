@@ -83,9 +83,13 @@ __global__ __launch_bounds__(256) void k1a_scan(const uint4* __restrict__ px, u6
   }
 }
 
-int g_k1a_dummy_lds = 0;  // experiment knob: dynamic LDS per block, only to cap K1a's blocks per CU
+// co_resident: the scan is about to run beside the FP64 voting kernel of another sub-batch (stream
+// pipeline).  Then it is capped to 4 blocks = 4 waves per SIMD (via an otherwise unused dynamic LDS
+// allocation of 40 KB per block) so that its 44-VGPR waves leave room for two 167-VGPR voting
+// waves per SIMD; HBM throughput is unchanged at that occupancy (measured).
+int g_k1a_dummy_lds = -1;  // tuning override (-1 = automatic)
 hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long long* flags, int thr,
-                           hipStream_t s) {
+                           bool co_resident, hipStream_t s) {
   const size_t n_seg = n_bytes / 16;
   if (n_seg == 0) return hipSuccess;
   int t = thr < -1 ? -1 : (thr > 255 ? 255 : thr);
@@ -94,7 +98,8 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
   size_t blocks = (n_chunks + 3) / 4;  // 4 waves per block
   const size_t max_blocks = 256 * K1A_BLOCKS_PER_CU;  // 256 CUs x blocks per CU, grid-stride beyond
   if (blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL(k1a_scan, dim3((unsigned)blocks), dim3(256), (size_t)g_k1a_dummy_lds, s,
+  const size_t dummy_lds = g_k1a_dummy_lds >= 0 ? (size_t)g_k1a_dummy_lds : (co_resident ? 40000 : 0);
+  hipLaunchKernelGGL(k1a_scan, dim3((unsigned)blocks), dim3(256), dummy_lds, s,
                      reinterpret_cast<const uint4*>(frames), (u64*)flags, n_seg, add);
   return hipGetLastError();
 }
@@ -1213,7 +1218,16 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
                         2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 + p_2_pw2 * f_1_pw2 * p_1_pw2 +
                         f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
       double root[4];
+#ifdef MPE_K2_LITERAL_QUARTIC
+      solve_quartic(F0, F1, F2, F3, F4, root);
+#else
       solve_quartic_fast(F0, F1, F2, F3, F4, root);
+#endif
+#ifdef MPE_K2_DEBUG
+      if (tc0 + ti == MPE_K2_DEBUG_TRI && pj == MPE_K2_DEBUG_PERM)
+        printf("DBG swap %d pjs %d f_1 %.17g f_2 %.17g b %.17g p_1 %.17g p_2 %.17g d_12 %.17g\nF %.17g %.17g %.17g %.17g %.17g\nroots %.17g %.17g %.17g %.17g\n",
+               (int)swap, pjs, f_1, f_2, b, p_1, p_2, d_12, F0, F1, F2, F3, F4, root[0], root[1], root[2], root[3]);
+#endif
       // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
       const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
       const double tol2 = sp.back_tol * sp.back_tol;
@@ -1236,6 +1250,11 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
         // isFinite([R C]) (pose_estimator.cpp:653): R and C are finite iff these are
         const double z = (cos_alpha - cos_alpha) + (sin_alpha - sin_alpha) + (sin_theta - sin_theta) +
                          (cos_theta - cos_theta) + (Cx - Cx) + (Cy - Cy) + (Cz - Cz);
+#ifdef MPE_K2_DEBUG
+        if (tc0 + ti == MPE_K2_DEBUG_TRI && pj == MPE_K2_DEBUG_PERM)
+          printf("DBG k %d rt %.17g cn %.17g cd %.17g sa %.17g ca %.17g st %.17g C %.17g %.17g %.17g z %g\n", k, rt, cn, cd,
+                 sin_alpha, cos_alpha, sin_theta, Cx, Cy, Cz, z);
+#endif
         if (!(z == 0.0)) continue;
         const double T00 = tr[0], T01 = tr[1], T02 = tr[2], T10 = tr[3], T11 = tr[4], T12 = tr[5], T20 = tr[6],
                      T21 = tr[7], T22 = tr[8];
@@ -1251,6 +1270,11 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           const double iZ = rcp_nr(Z);
           s_q[(2 * j) * nthr + tid] = (fx * X + cx * Z) * iZ;
           s_q[(2 * j + 1) * nthr + tid] = (fy * Y + cy * Z) * iZ;
+#ifdef MPE_K2_DEBUG
+          if (tc0 + ti == MPE_K2_DEBUG_TRI && pj == MPE_K2_DEBUG_PERM)
+            printf("DBG   k %d j %d meta %.17g %.17g %.17g XYZ %.17g %.17g %.17g uv %.17g %.17g\n", k, j, e[18 + 3 * j],
+                   e[18 + 3 * j + 1], e[18 + 3 * j + 2], X, Y, Z, (fx * X + cx * Z) * iZ, (fy * Y + cy * Z) * iZ);
+#endif
         }
         // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
         bool any = false;
@@ -1271,6 +1295,11 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           // root is only taken inside the rounding band around tol^2
           bool within = best < tol2 * (1.0 - 1e-14);
           if (!within && best < tol2 * (1.0 + 1e-14)) within = sqrt(best) < sp.back_tol;
+#ifdef MPE_K2_DEBUG
+          if (tc0 + ti == MPE_K2_DEBUG_TRI && pj == MPE_K2_DEBUG_PERM)
+            printf("DBG     k %d a %d au %.6f av %.6f best %.6f bj %d within %d tol2 %.6f nuo %d n_d %d c %d %d %d p %d %d %d tid %d nthr %d\n", k, a, au, av, best, bj,
+                   (int)within, tol2, nuo, n_d, c0, c1, c2, p0, p1, p2, tid, nthr);
+#endif
           if (within) {
             int mi = -1, cnt = -1;         // bj-th unused marker -> marker index
             for (int m = 0; m < n_m; ++m) {

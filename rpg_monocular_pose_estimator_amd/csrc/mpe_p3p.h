@@ -151,6 +151,12 @@ __device__ __forceinline__ void solve_quartic(double A, double B, double C, doub
 // range scaling and fix-up of the IEEE expansions (12 / 22 VALU ops each): ~7 / 9 ops, <= 1 ulp for
 // normal-range operands; NaN in -> NaN out, negative radicand -> NaN (the voting kernel relies on
 // that to drop |root| > 1), sqrt(0) = 0.
+#ifdef MPE_K2_IEEE  // debugging aid: IEEE division / square root instead of the Newton-Raphson forms
+__device__ __forceinline__ double rcp_nr(double b) { return 1.0 / b; }
+__device__ __forceinline__ double div_nr(double a, double b) { return a / b; }
+__device__ __forceinline__ double sqrt_nr(double a) { return sqrt(a); }
+__device__ __forceinline__ double rsqrt_nr(double a) { return 1.0 / sqrt(a); }
+#else
 __device__ __forceinline__ double rcp_nr(double b) {
   double x = __builtin_amdgcn_rcp(b);
   double e = __builtin_fma(-b, x, 1.0);
@@ -189,6 +195,7 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
   h = __builtin_fma(h, r, h);
   return 2.0 * h;
 }
+#endif
 __device__ __forceinline__ double hypot_fast(double a, double b) { return sqrt_nr(a * a + b * b); }
 // (a + ib) / (c + id), Smith's algorithm with the Newton-Raphson division
 __device__ __forceinline__ C2 cdiv_fast(C2 n, C2 d) {

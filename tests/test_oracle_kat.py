@@ -396,3 +396,25 @@ def test_tracker_state_machine(orc):
     for k in range(24):
         if rs[k]["updated"]:
             assert np.linalg.norm(rs[k]["T"][:3, 3] - d["T_true"][k][:3, 3]) < 0.03
+
+
+def test_reference_ferrari_is_unstable_when_w_vanishes(orc):
+    """A well-conditioned quartic taken from a real hypothesis (tests/data/vote_regression_det_0.npy,
+    detections 0,2,3 <-> markers 3,2,1) on which the reference's Ferrari formulas (p3p.cpp:238-286) lose
+    ~14 digits: alpha + 2y ~ 0 makes w tiny and 2*beta/w huge.  The literal restatement is off by 1.7e-2
+    from the true roots, and a 1-ulp change of one coefficient moves its answer by > 1e-4 — so in such
+    (rare, ~1e-7 of all hypotheses) cases no two builds of the reference agree with each other, and the
+    HIP path cannot be vote-identical either."""
+    F = np.array([-2.6726739687181578, 0.16730140900912122, 2.3718487024017842, -0.14465695719931068,
+                  0.17769794483556164])
+    true = np.sort([z.real for z in witness.quartic_roots_mp(F)])
+    got = np.sort(orc.solve_quartic(F))
+    assert np.allclose(true, [-0.97555999, 0.02847635, 0.02847635, 0.98120430], atol=1e-7)
+    assert 5e-3 < np.abs(got - true).max() < 5e-2          # the reference algorithm itself is this far off
+    moved = 0.0
+    for k in range(5):
+        for sgn in (-1, 1):
+            G = F.copy()
+            G[k] = np.nextafter(G[k], sgn * np.inf)
+            moved = max(moved, np.abs(np.sort(orc.solve_quartic(G)) - got).max())
+    assert moved > 1e-4                                     # 1 ulp in -> 1e-4 .. 1e-2 out
