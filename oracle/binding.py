@@ -356,3 +356,16 @@ class Tracker:
             self.close()
         except Exception:
             pass
+
+
+def vote_batch(det, n_det, markers, K, tol, n_threads=1):
+    """det: (n, max_det, 2) float64, n_det: (n,) int32 -> (n, max_det, n_markers) uint32."""
+    det = _f64(det)
+    n, max_det, _ = det.shape
+    nd = np.ascontiguousarray(n_det, np.int32)
+    markers = _f64(markers).reshape(-1, 3)
+    K = _f64(K).reshape(9)
+    h = np.zeros((n, max_det, len(markers)), np.uint32)
+    lib().orc_vote_batch(_p(det, C.c_double), _p(nd, C.c_int), n, max_det, _p(markers, C.c_double), len(markers),
+                         _p(K, C.c_double), C.c_double(tol), _p(h, C.c_uint32), int(n_threads))
+    return h

@@ -1811,4 +1811,23 @@ void orc_logarithm_map(const double T[16], double xi[6]) {
   Tracker::logarithmMap(M, xi);
 }
 
+
+/* voting histograms for a batch of detection sets (det: n x max_det x 2, hist: n x max_det x n_markers),
+ * frame-parallel */
+int orc_vote_batch(const double* det, const int* n_det, int n, int max_det, const double* markers, int n_markers,
+                   const double K[9], double tol, uint32_t* hist, int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; ++t)
+    th.emplace_back([=]() {
+      for (int f = t; f < n; f += n_threads) {
+        uint32_t* h = hist + (size_t)f * max_det * n_markers;
+        std::memset(h, 0, sizeof(uint32_t) * (size_t)max_det * n_markers);
+        if (n_det[f] >= 4) orc_vote_histogram(det + (size_t)f * max_det * 2, n_det[f], markers, n_markers, K, tol, h);
+      }
+    });
+  for (auto& x : th) x.join();
+  return 0;
+}
+
 }  // extern "C"

@@ -138,6 +138,9 @@ void orc_tracker_destroy(orc_tracker* tr);
 int orc_tracker_estimate(orc_tracker* tr, const uint8_t* img, int rows, int cols, size_t stride,
                          double time, orc_result* out, int* info);
 void orc_logarithm_map(const double T[16], double xi[6]); /* PE.cpp:996-1064 */
+/* frame-parallel orc_vote_histogram: det n x max_det x 2, hist n x max_det x n_markers */
+int orc_vote_batch(const double* det, const int* n_det, int n, int max_det, const double* markers,
+                   int n_markers, const double K[9], double tol, uint32_t* hist, int n_threads);
 
 #ifdef __cplusplus
 }

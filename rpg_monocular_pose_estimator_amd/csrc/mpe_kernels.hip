@@ -1218,10 +1218,12 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
                         2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 + p_2_pw2 * f_1_pw2 * p_1_pw2 +
                         f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
       double root[4];
-#ifdef MPE_K2_LITERAL_QUARTIC
+#if defined(MPE_K2_LITERAL_QUARTIC)
       solve_quartic(F0, F1, F2, F3, F4, root);
-#else
+#elif defined(MPE_K2_FAST_QUARTIC)
       solve_quartic_fast(F0, F1, F2, F3, F4, root);
+#else
+      solve_quartic_lit(F0, F1, F2, F3, F4, root);
 #endif
 #ifdef MPE_K2_DEBUG
       if (tc0 + ti == MPE_K2_DEBUG_TRI && pj == MPE_K2_DEBUG_PERM)

@@ -267,6 +267,91 @@ __device__ __forceinline__ void solve_quartic_fast(double A, double B, double C,
   rr[3] = off + 0.5 * (-w.re - s2.re);
 }
 
+// ---- voting-kernel quartic, literal operation order -----------------------------------------------
+// Same sequence of operations as solve_quartic (= p3p.cpp:238-286 statement by statement), with the
+// divisions / square roots in their Newton-Raphson forms (correctly rounded in all but rare cases) and
+// |z| from a compensated x^2 + y^2.  Keeping the ORDER matters more than the cost of the operations:
+// in the unstable corner of Ferrari's method (alpha + 2y ~ 0) every rounding is amplified ~1e14 times,
+// and the reformulated solve_quartic_fast disagreed with the CPU path's votes 4x more often.
+__device__ __forceinline__ double hypot_acc(double x, double y) {
+  const double s = x * x, t = y * y;
+  const double es = __builtin_fma(x, x, -s), et = __builtin_fma(y, y, -t);
+  const double sum = s + t;
+  const double bb = sum - s;
+  const double err = ((s - (sum - bb)) + (t - bb)) + (es + et);  // two-sum residue + product residues
+  const double r = sqrt_nr(sum);
+  return r + 0.5 * err * rcp_nr(r);  // first-order correction of sqrt(sum + err)
+}
+__device__ __forceinline__ C2 csqrt_lit(C2 z) {
+  if (z.im == 0.0) {
+    if (z.re < 0.0) return {0.0, copysign(sqrt_nr(-z.re), z.im)};
+    return {fabs(sqrt_nr(z.re)), z.im};
+  }
+  const double d = hypot_acc(z.re, z.im);
+  double r, s;
+  if (z.re > 0.0) {
+    r = sqrt_nr(0.5 * (d + z.re));
+    s = 0.5 * div_nr(z.im, r);
+  } else {
+    s = sqrt_nr(0.5 * (d - z.re));
+    r = fabs(0.5 * div_nr(z.im, s));
+  }
+  return {r, copysign(s, z.im)};
+}
+__device__ __forceinline__ C2 cdiv_lit(C2 n, C2 d) {  // Smith, as cdiv
+  const double a = n.re, b = n.im, c = d.re, e = d.im;
+  if (fabs(c) < fabs(e)) {
+    const double ratio = div_nr(c, e), denom = c * ratio + e;
+    return {div_nr(a * ratio + b, denom), div_nr(b * ratio - a, denom)};
+  }
+  const double ratio = div_nr(e, c), denom = e * ratio + c;
+  return {div_nr(b * ratio + a, denom), div_nr(b - a * ratio, denom)};
+}
+__device__ __forceinline__ C2 cpow_third_lit(C2 z) {
+  if (z.im == 0.0 && z.re > 0.0) return {cbrt(z.re), 0.0};
+  const double rho = cbrt(hypot_acc(z.re, z.im));
+  const double phi = (1.0 / 3.0) * atan2(z.im, z.re);
+  double s, c;
+  sincos(phi, &s, &c);
+  return {rho * c, rho * s};
+}
+__device__ __forceinline__ void solve_quartic_lit(double A, double B, double C, double D, double E, double rr[4]) {
+  const double A_pw2 = A * A, B_pw2 = B * B;
+  const double A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B;
+  const double A_pw4 = A_pw3 * A, B_pw4 = B_pw3 * B;
+  const double alpha = div_nr(-3 * B_pw2, 8 * A_pw2) + div_nr(C, A);
+  const double beta = div_nr(B_pw3, 8 * A_pw3) - div_nr(B * C, 2 * A_pw2) + div_nr(D, A);
+  const double gamma = div_nr(-3 * B_pw4, 256 * A_pw4) + div_nr(B_pw2 * C, 16 * A_pw3) - div_nr(B * D, 4 * A_pw2) +
+                       div_nr(E, A);
+  const double alpha_pw2 = alpha * alpha, alpha_pw3 = alpha_pw2 * alpha;
+  const double Pr = div_nr(-alpha_pw2, 12.0) - gamma;
+  const double Qr = div_nr(-alpha_pw3, 108.0) + div_nr(alpha * gamma, 3.0) - (beta * beta) * 0.125;
+  const C2 q2 = cpow2_real(Qr), p3 = cpow3_real(Pr);
+  const C2 disc = {q2.re * 0.25 + div_nr(p3.re, 27.0), q2.im * 0.25 + div_nr(p3.im, 27.0)};
+  const C2 sq = csqrt_lit(disc);
+  const C2 R = {-Qr * 0.5 + sq.re, sq.im};
+  const C2 U = cpow_third_lit(R);
+  C2 y;
+  const double a56 = div_nr(-5.0 * alpha, 6.0);
+  if (U.re == 0.0) {
+    const C2 qc = cpow_third_lit(C2{Qr, 0.0});
+    y = {a56 - qc.re, -qc.im};
+  } else {
+    const C2 t = cdiv_lit(C2{Pr, 0.0}, cscale(U, 3.0));
+    y = {a56 - t.re + U.re, -t.im + U.im};
+  }
+  const C2 w = csqrt_lit(C2{alpha + 2.0 * y.re, 2.0 * y.im});
+  const C2 bw = cdiv_lit(C2{2.0 * beta, 0.0}, w);
+  const C2 base = {3.0 * alpha + 2.0 * y.re, 2.0 * y.im};
+  const C2 s1 = csqrt_lit(C2{-(base.re + bw.re), -(base.im + bw.im)});
+  const C2 s2 = csqrt_lit(C2{-(base.re - bw.re), -(base.im - bw.im)});
+  const double off = div_nr(-B, 4.0 * A);
+  rr[0] = off + 0.5 * (w.re + s1.re);
+  rr[1] = off + 0.5 * (w.re - s1.re);
+  rr[2] = off + 0.5 * (-w.re + s2.re);
+  rr[3] = off + 0.5 * (-w.re - s2.re);
+}
+
 // Everything of computePoses that does not depend on the root index.  p3p.cpp:65-190
 struct P3PCtx {
   M3 T, N;
