@@ -113,7 +113,9 @@ def main():
         dt = float(tmax.item())
     fps = world * B * args.steps / dt
 
-    # ---- per-kernel time with HIP events on the launch stream (separate, profiled steps) ------
+    # ---- per-kernel time with HIP events on the launch streams: extra steps in exactly the same mode
+    #      and launch shape as the timed region (a big batch runs as sub-batches, every kernel is launched
+    #      once per sub-batch; the numbers are AVERAGES PER LAUNCH, like rocprofv3 --stats reports them)
     h.set_profiling(True)
     kms = []
     for _ in range(min(5, max(3, args.steps))):
@@ -121,9 +123,25 @@ def main():
         kms.append(h.last_kernel_ms())
     h.set_profiling(False)
     kavg = {k: float(np.mean([m[k] for m in kms])) for k in kms[0]}
-    bytes_per_launch = B * rows * cols  # algorithmic: every pixel read once
+    launches, fpl = int(kms[0]["launches"]), int(kms[0]["frames_per_launch"])
+    kavg["launches"], kavg["frames_per_launch"] = launches, fpl
+    bytes_per_launch = min(fpl, B) * rows * cols  # algorithmic: every pixel read once
     scan_s = kavg["scan"] * 1e-3
     achieved = bytes_per_launch / scan_s / 1e9
+    # the same kernels one launch per step and back to back (no sub-batch pipelining): what each kernel
+    # does when it has the chip to itself
+    kiso = None
+    if launches > 1:
+        h.set_option("pipeline", 1)
+        h.set_profiling(True)
+        kk = []
+        for _ in range(3):
+            h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
+            kk.append(h.last_kernel_ms())
+        h.set_profiling(False)
+        h.set_option("pipeline", args.pipeline)
+        kiso = {k: float(np.mean([m[k] for m in kk])) for k in kk[0]}
+
     # HBM traffic of the same kernel from the PMC pass committed under profiles/ (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
     # coalesced reads on gfx950), scaled from bytes per frame to this launch
@@ -132,13 +150,16 @@ def main():
         with open(os.path.join(ROOT, "profiles", "round1_k1a_scan_pmc.json")) as fh:
             pmc = json.load(fh)
         if pmc.get("rows") == rows and pmc.get("cols") == cols:
-            traffic = pmc["hbm_bytes_per_frame"] * B
+            traffic = pmc["hbm_bytes_per_frame"] * min(fpl, B)
     except Exception:
         pass
     roofline = {"kernel": "k1a_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic,
                 "bytes_per_launch": bytes_per_launch, "avg_launch_ms": kavg["scan"],
-                "measured": "HIP events on the launch stream, profiled steps without stream pipelining"}
+                "launches_per_step": launches, "frames_per_launch": fpl,
+                "measured": "HIP events around every k1a_scan launch on its stream, steps in the same mode as the "
+                            "timed region (with >1 launches per step the scan of sub-batch i+1 runs beside the "
+                            "FP64 voting of sub-batch i and shares the chip with it)"}
 
     host_fps = None
     if args.host_frames and rank == 0:
@@ -173,6 +194,14 @@ def main():
             "kernel_ms": kavg,
             "roofline": roofline,
         }
+        if kiso is not None:
+            out["kernel_ms_isolated"] = kiso
+            out["roofline_isolated"] = {"kernel": "k1a_scan", "bound": "hbm",
+                                        "achieved": B * rows * cols / (kiso["scan"] * 1e-3) / 1e9, "peak": 8000.0,
+                                        "unit": "GB/s", "frac": B * rows * cols / (kiso["scan"] * 1e-3) / 1e9 / 8000.0,
+                                        "bytes_per_launch": B * rows * cols, "avg_launch_ms": kiso["scan"],
+                                        "measured": "one launch per kernel per step, kernels back to back "
+                                                    "(--pipeline 1), HIP events on the launch stream"}
         if host_fps is not None:
             out["host_streamed_fps"] = host_fps
         # ---- CPU baseline + parity on a bounded sample (oracle = test infrastructure / checker) ----

@@ -182,10 +182,15 @@ int mpe_vote_batch(mpe_handle* h, const double* det_xy, const int* n_det, int n_
  * Only valid after mpe_set_profiling(h, 1); profiling adds event records to the stream. */
 int mpe_set_profiling(mpe_handle* h, int enable);
 int mpe_last_kernel_ms(mpe_handle* h, float ms[5]);
+/* A large batch runs as several sub-batches (option "pipeline"): every kernel is then launched once
+ * per sub-batch and mpe_last_kernel_ms reports the AVERAGE PER LAUNCH.  This returns the number of
+ * launches per kernel and the frames each one processed for the last profiled call. */
+int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
 
 /* Tuning knobs that are not part of the reference surface: "lds_budget" (bytes of LDS per frame
  * for the blob bitmaps, 8192..163840) and "vote_splits" (workgroups per frame in the voting
- * kernel, 0 = auto). */
+ * kernel, 0 = auto), "pipeline" (max sub-batches of >= 8192 frames run as a two-stream software
+ * pipeline, default 8, 1 = off). */
 int mpe_set_option(mpe_handle* h, const char* name, int value);
 
 /* library / device introspection */

@@ -102,6 +102,7 @@ def load_library():
     lib.mpe_synchronize.argtypes = [C.c_void_p]
     lib.mpe_set_profiling.argtypes = [C.c_void_p, C.c_int]
     lib.mpe_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.mpe_last_launch_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.mpe_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.mpe_default_params.argtypes = [C.POINTER(MpeParams)]
     lib.mpe_default_params.restype = None
@@ -197,7 +198,10 @@ class Handle:
     def last_kernel_ms(self):
         ms = (C.c_float * 5)()
         self._check(self._lib.mpe_last_kernel_ms(self._h, ms), "mpe_last_kernel_ms")
-        return dict(scan=ms[0], blobs=ms[1], vote=ms[2], tail=ms[3], total=ms[4])
+        nl, fpl = C.c_int(0), C.c_int(0)
+        self._check(self._lib.mpe_last_launch_shape(self._h, C.byref(nl), C.byref(fpl)), "mpe_last_launch_shape")
+        return dict(scan=ms[0], blobs=ms[1], vote=ms[2], tail=ms[3], total=ms[4], launches=nl.value,
+                    frames_per_launch=fpl.value)
 
     # ---- LEDDetector::findLeds ----------------------------------------------------------------
     def find_leds(self, img, params, K, D, roi=None, cap=MAX_DETECTIONS):

@@ -61,7 +61,12 @@ struct mpe_handle {
   hipEvent_t vote_done[kMaxSub] = {};
   hipEvent_t fork_ev = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  float last_ms[5] = {0, 0, 0, 0, 0};
+  // per-sub-batch kernel brackets for the pipelined mode: [s][0..1] scan, [2..3] blobs (all tiers),
+  // [4..5] vote, [6..7] tail
+  hipEvent_t pev[kMaxSub][8] = {};
+  int prof_launches = 0;       // sub-batches (= launches per kernel) of the last profiled call
+  int prof_frames_per_launch = 0;
+  bool prof_pipelined = false;
   bool have_ms = false;
 };
 
@@ -260,7 +265,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     HIP_TRY(h, h->mtab.reserve(k2_table_bytes(sp->n_markers)));
     HIP_TRY(h, launch_k2_prep(*sp, static_cast<double*>(h->mtab.p), h->stream));
   }
-  int nsub = (h->profiling || !sp) ? 1 : h->pipeline;
+  int nsub = !sp ? 1 : h->pipeline;
   if (nsub > mpe_handle::kMaxSub) nsub = mpe_handle::kMaxSub;
   while (nsub > 1 && n_frames < 8192 * nsub) nsub /= 2;  // sub-batches below ~8k frames lose more than overlap gains
   h->have_ms = false;
@@ -273,8 +278,16 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (rc) return rc;
     rc = run_back(h, h->stream, h->profiling, n_frames, sp, d_dets, d_hist, d_results, d_corr);
     h->have_ms = (rc == MPE_OK) && h->profiling;
+    h->prof_pipelined = false;
+    h->prof_launches = 1;
+    h->prof_frames_per_launch = n_frames;
     return rc;
   }
+  const bool prof = h->profiling;
+  if (prof)
+    for (int s = 0; s < nsub; ++s)
+      for (int k = 0; k < 8; ++k)
+        if (!h->pev[s][k]) HIP_TRY(h, hipEventCreate(&h->pev[s][k]));
   // Software pipeline over nsub sub-batches on two streams: A runs scan + blobs, B voting + tail.
   // frames per sub-batch: multiple of 64 so every sub-batch starts on a 16-byte / flag-word boundary
   const int per = ((n_frames + nsub - 1) / nsub + 63) & ~63;
@@ -300,23 +313,37 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (!h->sub_done[s]) HIP_TRY(h, hipEventCreateWithFlags(&h->sub_done[s], hipEventDisableTiming));
     const uint8_t* fr = d_frames + (size_t)f0 * frame_bytes;
     unsigned long long* fl = static_cast<unsigned long long*>(h->flags.p) + fw_per * s;
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][0], sa));
     HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, true, sa));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][1], sa));
     if (s > 0) HIP_TRY(h, hipStreamWaitEvent(sa, h->vote_done[s - 1], 0));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], sa));
     HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
                                 static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
                                 static_cast<uint8_t*>(h->scratch.p), sp->n_markers, sa));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], sa));
     HIP_TRY(h, hipEventRecord(h->sub_done[s], sa));
     HIP_TRY(h, hipStreamWaitEvent(sb, h->sub_done[s], 0));
     uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
     HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), sb));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], sb));
     HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, *sp, static_cast<const double*>(h->mtab.p), hs,
                               auto_splits(h, nf, sp->n_markers), sp->n_markers, sb));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], sb));
     HIP_TRY(h, hipEventRecord(h->vote_done[s], sb));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], sb));
     HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
                               d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, sb));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], sb));
+    if (prof) h->prof_launches = s + 1;
   }
   HIP_TRY(h, hipEventRecord(h->fork_ev, sb));  // B finishes last: it waited for every front half
   HIP_TRY(h, hipStreamWaitEvent(h->stream, h->fork_ev, 0));
+  if (prof) {
+    h->have_ms = true;
+    h->prof_pipelined = true;
+    h->prof_frames_per_launch = per;
+  }
   return MPE_OK;
 }
 
@@ -394,6 +421,9 @@ void mpe_destroy(mpe_handle* h) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : h->vote_done)
     if (e) (void)hipEventDestroy(e);
+  for (auto& row : h->pev)
+    for (auto& e : row)
+      if (e) (void)hipEventDestroy(e);
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   for (auto& st : h->sub_stream)
     if (st) (void)hipStreamDestroy(st);
@@ -428,9 +458,30 @@ int mpe_set_profiling(mpe_handle* h, int enable) {
 int mpe_last_kernel_ms(mpe_handle* h, float ms[5]) {
   if (!h || !ms) return MPE_ERR_ARG;
   if (!h->have_ms) return fail(h, MPE_ERR_ARG, "profiling not enabled for the last batch");
-  HIP_TRY(h, hipEventSynchronize(h->ev[4]));
-  for (int i = 0; i < 4; ++i) HIP_TRY(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
-  HIP_TRY(h, hipEventElapsedTime(&ms[4], h->ev[0], h->ev[4]));
+  if (!h->prof_pipelined) {
+    HIP_TRY(h, hipEventSynchronize(h->ev[4]));
+    for (int i = 0; i < 4; ++i) HIP_TRY(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+    HIP_TRY(h, hipEventElapsedTime(&ms[4], h->ev[0], h->ev[4]));
+    return MPE_OK;
+  }
+  // pipelined call: average duration PER LAUNCH of each kernel over the sub-batches; ms[4] = their sum
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < 5; ++i) ms[i] = 0.f;
+  for (int s = 0; s < h->prof_launches; ++s)
+    for (int k = 0; k < 4; ++k) {
+      float t = 0.f;
+      HIP_TRY(h, hipEventElapsedTime(&t, h->pev[s][2 * k], h->pev[s][2 * k + 1]));
+      ms[k] += t / (float)h->prof_launches;
+    }
+  ms[4] = ms[0] + ms[1] + ms[2] + ms[3];
+  return MPE_OK;
+}
+
+/* launches per kernel and frames per launch of the last profiled batch (1 / n_frames when not pipelined) */
+int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch) {
+  if (!h || !h->have_ms) return MPE_ERR_ARG;
+  if (launches) *launches = h->prof_launches;
+  if (frames_per_launch) *frames_per_launch = h->prof_frames_per_launch;
   return MPE_OK;
 }
 
