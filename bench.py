@@ -49,6 +49,7 @@ def main():
                     help="extra leg: frames streamed from PINNED host memory every step (PCIe-inclusive rate; "
                          "reported as host_streamed_fps, never as value)")
     ap.add_argument("--k1a-lds", type=int, default=-1, help="tuning: dummy LDS per scan block (-1 = automatic)")
+    ap.add_argument("--pipeline-mode", type=int, default=0, help="experiment knob")
     ap.add_argument("--pipeline", type=int, default=8, help="sub-batches per step on separate HIP streams (1 = off)")
     args = ap.parse_args()
 
@@ -86,6 +87,7 @@ def main():
     h.set_stream(torch.cuda.current_stream().cuda_stream)
     P = mpe.demo_params()
     h.set_option("pipeline", args.pipeline)
+    h.set_option("pipeline_mode", args.pipeline_mode)
     if args.k1a_lds >= 0:
         h.set_option("k1a_dummy_lds", args.k1a_lds)
 
@@ -205,7 +207,7 @@ def main():
         if host_fps is not None:
             out["host_streamed_fps"] = host_fps
         # ---- CPU baseline + parity on a bounded sample (oracle = test infrastructure / checker) ----
-        if not args.no_cpu and args.cpu_sample > 0:
+        if not args.no_cpu and args.cpu_sample > 0 and world == 1:  # CPU baseline: rank 0 at N = 1 only
             import oracle
             oracle.build()
             ns = min(args.cpu_sample, B)

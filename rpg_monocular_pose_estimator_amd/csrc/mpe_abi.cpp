@@ -51,6 +51,7 @@ struct mpe_handle {
   DevBuf frames, flags, dets, hist, results, corr, mtab, work, scratch;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
   int vote_splits = 0;         // 0 = auto
+  int pipeline_mode = 0;       // experiment knob: 0 staggered, 1 not staggered, 2 three streams
   bool profiling = false;
   int pipeline = 8;  // up to this many sub-batches (each >= 8192 frames) in a two-stream software
                      // pipeline: the HBM-bound scan of sub-batch i+1 runs beside the FP64-bound voting
@@ -59,6 +60,7 @@ struct mpe_handle {
   hipStream_t sub_stream[kMaxSub] = {};
   hipEvent_t sub_done[kMaxSub] = {};
   hipEvent_t vote_done[kMaxSub] = {};
+  hipEvent_t scan_done[kMaxSub] = {};
   hipEvent_t fork_ev = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // per-sub-batch kernel brackets for the pipelined mode: [s][0..1] scan, [2..3] blobs (all tiers),
@@ -294,13 +296,18 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   const size_t fw_per = flag_words(frame_bytes * per);
   HIP_TRY(h, h->flags.reserve(fw_per * nsub * 8));
   HIP_TRY(h, h->work.reserve((size_t)2 * (per + 1) * nsub * sizeof(int)));
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 3; ++i)
     if (!h->sub_stream[i]) HIP_TRY(h, hipStreamCreateWithFlags(&h->sub_stream[i], hipStreamNonBlocking));
   if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
-  hipStream_t sa = h->sub_stream[0], sb = h->sub_stream[1];
+  hipStream_t sa = h->sub_stream[0], sb = h->sub_stream[1], sc = h->sub_stream[2];
+  const int mode = h->pipeline_mode;
   HIP_TRY(h, hipEventRecord(h->fork_ev, h->stream));
   HIP_TRY(h, hipStreamWaitEvent(sa, h->fork_ev, 0));
   HIP_TRY(h, hipStreamWaitEvent(sb, h->fork_ev, 0));
+  HIP_TRY(h, hipStreamWaitEvent(sc, h->fork_ev, 0));
+  if (!h->scan_done[0])
+    for (int i = 0; i < mpe_handle::kMaxSub; ++i)
+      HIP_TRY(h, hipEventCreateWithFlags(&h->scan_done[i], hipEventDisableTiming));
   // Staggered schedule: scan(i+1) runs beside vote(i) (HBM-bound beside FP64-bound), blobs(i+1)
   // beside tail(i) (two latency-bound kernels): blobs(i+1) is held back until vote(i) has finished.
   if (!h->vote_done[0])
@@ -316,13 +323,19 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][0], sa));
     HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, true, sa));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][1], sa));
-    if (s > 0) HIP_TRY(h, hipStreamWaitEvent(sa, h->vote_done[s - 1], 0));
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], sa));
+    hipStream_t sblob = sa;
+    if (mode == 2) {  // blobs (and tail) on a third stream
+      HIP_TRY(h, hipEventRecord(h->scan_done[s], sa));
+      HIP_TRY(h, hipStreamWaitEvent(sc, h->scan_done[s], 0));
+      sblob = sc;
+    }
+    if (mode == 0 && s > 0) HIP_TRY(h, hipStreamWaitEvent(sblob, h->vote_done[s - 1], 0));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], sblob));
     HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
                                 static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
-                                static_cast<uint8_t*>(h->scratch.p), sp->n_markers, sa));
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], sa));
-    HIP_TRY(h, hipEventRecord(h->sub_done[s], sa));
+                                static_cast<uint8_t*>(h->scratch.p), sp->n_markers, sblob));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], sblob));
+    HIP_TRY(h, hipEventRecord(h->sub_done[s], sblob));
     HIP_TRY(h, hipStreamWaitEvent(sb, h->sub_done[s], 0));
     uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
     HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), sb));
@@ -331,14 +344,23 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
                               auto_splits(h, nf, sp->n_markers), sp->n_markers, sb));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], sb));
     HIP_TRY(h, hipEventRecord(h->vote_done[s], sb));
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], sb));
+    hipStream_t stail = sb;
+    if (mode == 2) {
+      HIP_TRY(h, hipStreamWaitEvent(sc, h->vote_done[s], 0));
+      stail = sc;
+    }
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], stail));
     HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
-                              d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, sb));
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], sb));
+                              d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, stail));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], stail));
     if (prof) h->prof_launches = s + 1;
   }
-  HIP_TRY(h, hipEventRecord(h->fork_ev, sb));  // B finishes last: it waited for every front half
+  HIP_TRY(h, hipEventRecord(h->fork_ev, sb));  // B waited for every front half
   HIP_TRY(h, hipStreamWaitEvent(h->stream, h->fork_ev, 0));
+  if (mode == 2) {
+    HIP_TRY(h, hipEventRecord(h->fork_ev, sc));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->fork_ev, 0));
+  }
   if (prof) {
     h->have_ms = true;
     h->prof_pipelined = true;
@@ -421,6 +443,8 @@ void mpe_destroy(mpe_handle* h) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : h->vote_done)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->scan_done)
+    if (e) (void)hipEventDestroy(e);
   for (auto& row : h->pev)
     for (auto& e : row)
       if (e) (void)hipEventDestroy(e);
@@ -495,6 +519,10 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   }
   if (!std::strcmp(name, "k1a_dummy_lds")) {
     g_k1a_dummy_lds = value;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "pipeline_mode")) {
+    h->pipeline_mode = value;
     return MPE_OK;
   }
   if (!std::strcmp(name, "pipeline")) {
