@@ -374,3 +374,65 @@ def test_known_divergence_on_an_unstable_quartic(hip, orc):
     for cell in ((0, 2), (1, 4), (2, 1), (3, 0)):
         allowed[cell] = True
     assert np.all(diff[~allowed] == 0) and np.all(np.abs(diff) <= 1)
+
+
+def test_abi_error_paths_are_loud(hip):
+    """Usage errors come back as negative return codes with a message — nothing is silently ignored."""
+    K, D = synth.camera_for(480, 752)
+    img = np.zeros((480, 752), np.uint8)
+    P = mpe.demo_params()
+    with pytest.raises(mpe.MpeError):            # ROI outside the image (cv::Mat::operator() would assert)
+        hip.find_leds(img, P, K, D, roi=(700, 400, 100, 100))
+    with pytest.raises(mpe.MpeError):            # GaussianBlur(ksize=0) needs sigma > 0
+        hip.find_leds(img, mpe.demo_params(gaussian_sigma=0.0), K, D)
+    with pytest.raises(mpe.MpeError):            # sigma beyond the dynamic-reconfigure range (cfg:13)
+        hip.find_leds(img, mpe.demo_params(gaussian_sigma=7.0), K, D)
+    det = np.random.default_rng(0).uniform(100, 400, (5, 2))
+    with pytest.raises(mpe.MpeError):            # > MPE_MAX_MARKERS
+        hip.solve_bruteforce(det, np.random.default_rng(1).normal(size=(17, 3)), K, P)
+    with pytest.raises(mpe.MpeError):            # > MPE_MAX_DETECTIONS
+        hip.solve_bruteforce(np.random.default_rng(2).uniform(0, 400, (33, 2)), synth.M5, K, P)
+    with pytest.raises(mpe.MpeError):            # correspondence index out of range
+        hip.check_and_refine(det, synth.M5, K, P, np.array([[1, 1], [2, 2], [3, 3], [9, 4]], np.uint32))
+
+
+def test_degenerate_inputs_match_oracle(hip, orc):
+    """Few detections / markers, collinear markers (P3P returns -1 for every permutation), duplicate
+    detections: same status, histogram and correspondences as the CPU path."""
+    K, _ = synth.camera_for(480, 752)
+    Po, Ph = orc.make_params(), mpe.demo_params()
+    rng = np.random.default_rng(4)
+    T = np.eye(4)
+    T[:3, 3] = [0.05, -0.02, 1.2]
+    cases = []
+    cases.append((synth.project(T, synth.M4, K), synth.M4))                       # 4 LEDs / 4 detections (C1)
+    cases.append((synth.project(T, synth.M5, K)[:3], synth.M5))                   # 3 detections: below the minimum
+    cases.append((np.zeros((0, 2)), synth.M5))                                    # none
+    line = np.array([[0.0, 0, 0], [0.05, 0, 0], [0.1, 0, 0], [0.15, 0, 0], [0.2, 0, 0]])
+    cases.append((synth.project(T, line, K), line))                               # collinear markers
+    d5 = synth.project(T, synth.M5, K)
+    cases.append((np.vstack([d5, d5[:2]]), synth.M5))                             # duplicated detections
+    cases.append((rng.uniform(50, 400, (9, 2)), synth.M8))                        # random detections, 8 markers
+    for det, M in cases:
+        ro = orc.solve_bruteforce(det, M, K, Po)
+        rh = hip.solve_bruteforce(det, M, K, Ph)
+        assert rh["status"] == ro["status"] and rh["n_corr"] == ro["n_corr"], (len(det), len(M))
+        if len(det):
+            assert np.array_equal(rh["hist"], ro["hist"])
+        assert np.array_equal(rh["corr"], ro["corr"])
+        if ro["status"] == 0:
+            dp, dr = pose_diff(rh["T"], ro["T"])
+            assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD
+
+
+def test_tracking_1920x1200(hip, orc):
+    d = synth.make_sequence("C4", 10, seed=5)
+    to = orc.Tracker(d["markers"], d["K"], d["D"], orc.make_params())
+    th = mpe.Tracker(hip, d["markers"], d["K"], d["D"], mpe.demo_params())
+    for k in range(10):
+        ro = to.estimate(d["frames"][k], d["times"][k])
+        rh = th.estimate(d["frames"][k], d["times"][k])
+        assert (rh["updated"], rh["roi"], rh["n_det"], rh["n_corr"]) == (ro["updated"], ro["roi"], ro["n_det"], ro["n_corr"]), k
+        if ro["updated"]:
+            dp, dr = pose_diff(rh["T"], ro["T"])
+            assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD
