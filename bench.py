@@ -204,6 +204,17 @@ def main():
                                         "bytes_per_launch": B * rows * cols, "avg_launch_ms": kiso["scan"],
                                         "measured": "one launch per kernel per step, kernels back to back "
                                                     "(--pipeline 1), HIP events on the launch stream"}
+        # voting-kernel rates next to fps (P3P solves = detection triples x marker 3-permutations)
+        nd = res_host["n_det"].astype(np.int64)
+        nd = np.where(res_host["status"] >= 0, nd, 0)
+        nm = len(markers)
+        solves = int((nd * (nd - 1) * (nd - 2) // 6).sum()) * nm * (nm - 1) * (nm - 2)
+        vote_ms = (kiso or kavg)["vote"] * (1 if kiso is not None else launches)
+        out["k2_rates"] = {"p3p_solves_per_step": solves, "p3p_solves_per_s": solves / (vote_ms * 1e-3),
+                           "hypotheses_per_s": 4 * solves / (vote_ms * 1e-3),
+                           "vote_ms_per_step": vote_ms,
+                           "timing": "isolated launch" if kiso is not None else "launches inside the pipelined step",
+                           "valu_utilisation": "see profiles/round1_pmc_sq_k2_vote.csv and DESIGN.md section 5"}
         if host_fps is not None:
             out["host_streamed_fps"] = host_fps
         # ---- CPU baseline + parity on a bounded sample (oracle = test infrastructure / checker) ----

@@ -1,0 +1,136 @@
+#!/usr/bin/env python
+"""bench_streams.py — BASELINE.json configs[4]: independent 752x480 camera streams with the STATEFUL
+estimator (tracking path: prediction, ROI detection, nearest-neighbour correspondences, fallback to
+brute force), streams sharded over the GPUs of one node.  Not the headline bench (that is bench.py).
+
+Every stream is one mpe_handle + mpe_tracker driven by its own host thread through
+mpe_tracker_run_sequence (frames arrive in pageable HOST memory, like a camera driver delivers them);
+a stream is latency bound (each frame needs the previous pose), so the figure of merit is the
+per-frame latency and how many streams one GPU carries at once.  8 streams over N ranks: rank r
+takes streams r, r+N, ...; there is no exchange step, rank 0 only gathers the counts.
+
+  python bench_streams.py [--streams 8] [--frames 400] [--gpus N]   (torchrun for N > 1)
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=8, help="camera streams in total (sharded over ranks)")
+    ap.add_argument("--frames", type=int, default=400, help="frames per stream")
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import rpg_monocular_pose_estimator_amd as mpe
+    from rpg_monocular_pose_estimator_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    local_rank = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+
+    mine = list(range(rank, args.streams, world))
+    # a smooth 36-frame trajectory played forwards and backwards keeps the target inside the image for any length
+    seqs = []
+    for s in mine:
+        d = synth.make_sequence(args.config, 40, seed=900 + s)
+        order = np.concatenate([np.arange(40), np.arange(38, 0, -1)])
+        idx = np.resize(order, args.frames)
+        seqs.append(dict(frames=np.ascontiguousarray(d["frames"][idx]), times=np.arange(args.frames) * 0.02,
+                         markers=d["markers"], K=d["K"], D=d["D"]))
+    handles = [mpe.Handle(local_rank) for _ in mine]
+    trackers = [mpe.Tracker(handles[i], seqs[i]["markers"], seqs[i]["K"], seqs[i]["D"], mpe.demo_params())
+                for i in range(len(mine))]
+    out = [None] * len(mine)
+    lat = [0.0] * len(mine)
+
+    def work(i):
+        t0 = time.perf_counter()
+        out[i] = trackers[i].run_sequence(seqs[i]["frames"], seqs[i]["times"])
+        lat[i] = (time.perf_counter() - t0) / args.frames
+
+    for i in range(len(mine)):  # warm-up: first frames of every stream, then back to "not initialised"
+        trackers[i].run_sequence(seqs[i]["frames"][:8], seqs[i]["times"][:8])
+        trackers[i].reset()
+    # one stream alone (latency), then all streams of this rank at once (throughput)
+    solo = None
+    if mine:
+        t0 = time.perf_counter()
+        trackers[0].run_sequence(seqs[0]["frames"], seqs[0]["times"])
+        solo = (time.perf_counter() - t0) / args.frames
+        trackers[0].reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(mine))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    n_frames = len(mine) * args.frames
+    n_pose = sum(int((o[0]["status"] == 0).sum()) for o in out)
+    n_brute = sum(int(o[1][:, 7].sum()) for o in out)
+    if world > 1:
+        v = torch.tensor([dt, n_frames, n_pose, n_brute], dtype=torch.float64, device="cuda")
+        vmax = v.clone()
+        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        dt, n_frames, n_pose, n_brute = float(vmax[0]), int(v[1]), int(v[2]), int(v[3])
+    if rank == 0:
+        res = {"metric": "frames/sec over independent 752x480 camera streams, stateful estimator (tracking path)",
+               "value": n_frames / dt, "unit": "frames/s", "n_gpus": world, "streams": args.streams,
+               "streams_per_gpu": len(mine), "frames_per_stream": args.frames, "higher_is_better": True,
+               "data": "synthetic", "dtype": "f64", "frames_in": "pageable host memory",
+               "latency_ms_per_frame_one_stream_alone": solo * 1e3 if solo else None,
+               "latency_ms_per_frame_streams_concurrent": float(np.mean(lat)) * 1e3 if lat else None,
+               "poses_found_frac": n_pose / max(1, n_frames), "bruteforce_frac": n_brute / max(1, n_frames),
+               "config": {"workload": "%s sequences (constant twist + jitter, 50 Hz), demo.launch parameters" % args.config}}
+        if not args.no_cpu and mine:
+            import oracle
+            oracle.build()
+            from oracle import binding as orc
+            to = orc.Tracker(seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], orc.make_params())
+            nchk = min(args.frames, 200)
+            t1 = time.perf_counter()
+            ref = [to.estimate(seqs[0]["frames"][k], seqs[0]["times"][k]) for k in range(nchk)]
+            cpu_dt = time.perf_counter() - t1
+            rec, info = out[0]
+            bad = sum(int((rec["status"][k] == 0) != r["updated"]) for k, r in enumerate(ref))
+            dpos = [np.linalg.norm(rec["T"][k].reshape(4, 4)[:3, 3] - r["T"][:3, 3]) for k, r in enumerate(ref) if r["updated"]]
+            res["cpu_baseline"] = {"value": nchk / cpu_dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": "stream 0, first %d frames, oracle state machine, one thread" % nchk}
+            res["parity"] = {"frames": nchk, "status_mismatches": bad,
+                             "pos_max_m": float(max(dpos)) if dpos else None}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+    for t in trackers:
+        t.close()
+    for h in handles:
+        h.close()
+
+
+if __name__ == "__main__":
+    main()

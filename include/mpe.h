@@ -141,6 +141,21 @@ int mpe_check_and_refine(mpe_handle* h, const double* det_xy, int n_det, const d
                          int n_markers, const double K[9], const mpe_params* p, const uint32_t* corr,
                          int n_corr, mpe_result* out);
 
+/* One frame of the tracking branch as ONE device submission (pose_estimator.cpp:98-110 + 831-839):
+ * LEDDetector::findLeds inside the ROI, then — when at least 4 LEDs were found — findCorrespondences
+ * (nearest detection of every predicted marker pixel within nearest_neighbour_pixel_tolerance,
+ * pose_estimator.cpp:372-392), checkCorrespondences and optimisePose.  img is a HOST image; the ROI is
+ * packed into pinned memory and sent with the predicted pixels in one copy, the detections,
+ * correspondences and pose come back in one copy.  predicted_px: n_markers x 2 (undistorted pixels).
+ * dets_out: what findLeds found (always written); corr_out: 2*MPE_MAX_MARKERS uint32, rows
+ * (marker, detection) 1-based, out->n_corr rows valid; out->status 0 = pose refined, 1 = fewer than
+ * 4 LEDs or correspondences rejected (the caller then retries / re-initialises as the reference does),
+ * <0 = a device capacity was exceeded.  mpe_tracker_estimate uses this for every tracked frame. */
+int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t stride_bytes, int roi_x,
+                   int roi_y, int roi_w, int roi_h, const mpe_params* p, const double K[9], const double* D,
+                   int nD, const double* markers_xyz, int n_markers, const double* predicted_px,
+                   mpe_detections* dets_out, uint32_t* corr_out, mpe_result* out);
+
 /* ---- stateful estimator: the whole PoseEstimator::estimateBodyPose state machine, i.e. the
  * uninitialised branch AND the tracking path (pose_estimator.cpp:62-147): pose prediction by the
  * constant-velocity model (predictPose :232-244), ROI from the predicted LED pixels
@@ -159,6 +174,14 @@ int mpe_tracker_reset(mpe_tracker* t); /* back to "not initialised" (the referen
  * x,y,w,h, it_since_initialized_, detections, correspondences, 1 if brute force ran. */
 int mpe_tracker_estimate(mpe_tracker* t, const uint8_t* img, int rows, int cols, size_t stride_bytes,
                          double time_to_predict, mpe_result* out, int info[8]);
+
+/* The image callback loop (MPENode::imageCallback -> estimateBodyPose, monocular_pose_estimator.cpp:
+ * 125-190) over a recorded sequence: frame f at frames + f*frame_stride_bytes with time stamp
+ * times[f].  out (optional) n_frames records, info (optional) n_frames x 8 ints as above.  Returns
+ * the number of frames whose pose was updated, or <0 on the first error. */
+int mpe_tracker_run_sequence(mpe_tracker* t, const uint8_t* frames, int n_frames, int rows, int cols,
+                             size_t stride_bytes, size_t frame_stride_bytes, const double* times,
+                             mpe_result* out, int* info);
 
 /* getCorrespondences() / getImagePoints() of the tracker object: copy up to cap rows / points,
  * return the number available (or <0). */

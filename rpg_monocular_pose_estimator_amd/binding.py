@@ -131,6 +131,8 @@ def load_library():
     lib.mpe_tracker_reset.argtypes = [C.c_void_p]
     lib.mpe_tracker_estimate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double,
                                          C.POINTER(MpeResult), C.POINTER(C.c_int)]
+    lib.mpe_tracker_run_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                             C.c_size_t, dp, C.c_void_p, C.c_void_p]
     _lib = lib
     return lib
 
@@ -350,6 +352,22 @@ class Tracker:
         return dict(updated=bool(rc), T=np.array(res.T).reshape(4, 4), cov=np.array(res.cov).reshape(6, 6),
                     roi=tuple(info[0:4]), it_since_initialized=info[4], n_det=info[5], n_corr=info[6],
                     used_bruteforce=bool(info[7]))
+
+    def run_sequence(self, frames, times):
+        """The image-callback loop in C over a recorded sequence (frames (n,rows,cols) uint8, C-contiguous).
+        -> (records [RESULT_DTYPE], info (n,8) int32).  ctypes drops the GIL for the duration."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        times = _f64(times).reshape(-1)
+        n = frames.shape[0]
+        rec = np.zeros(n, RESULT_DTYPE)
+        info = np.zeros((n, 8), np.int32)
+        rc = self._lib.mpe_tracker_run_sequence(self._t, frames.ctypes.data, n, frames.shape[1], frames.shape[2],
+                                                frames.strides[1], frames.strides[0], _dp(times), rec.ctypes.data,
+                                                info.ctypes.data)
+        if rc < 0:
+            raise MpeError("mpe_tracker_run_sequence failed (%d): %s"
+                           % (rc, self._lib.mpe_last_error(self._handle._h).decode()))
+        return rec, info
 
     def close(self):
         if getattr(self, "_t", None):

@@ -48,7 +48,9 @@ struct mpe_handle {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string err;
-  DevBuf frames, flags, dets, hist, results, corr, mtab, work, scratch;
+  DevBuf frames, flags, dets, hist, results, corr, mtab, work, scratch, track;
+  void* mailbox = nullptr;  // pinned host memory for the single-frame tracking step (ROI in, record out)
+  size_t mailbox_cap = 0;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
   int vote_splits = 0;         // 0 = auto
   int pipeline_mode = 0;       // experiment knob: 0 staggered, 1 not staggered, 2 three streams
@@ -251,7 +253,7 @@ int run_back(mpe_handle* h, hipStream_t st, bool prof, int n_frames, const Solve
     HIP_TRY(h, launch_k2_vote(d_dets, n_frames, *sp, static_cast<const double*>(h->mtab.p), d_hist,
                               auto_splits(h, n_frames, sp->n_markers), sp->n_markers, st));
     if (prof) rec(h, 3);
-    HIP_TRY(h, launch_k3_tail(d_dets, d_hist, n_frames, *sp, d_results, d_corr, nullptr, st));
+    HIP_TRY(h, launch_k3_tail(d_dets, d_hist, n_frames, *sp, d_results, d_corr, nullptr, nullptr, 0.0, st));
   } else if (prof) {
     rec(h, 3);
   }
@@ -351,7 +353,8 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     }
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], stail));
     HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
-                              d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, stail));
+                              d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0,
+                              stail));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], stail));
     if (prof) h->prof_launches = s + 1;
   }
@@ -437,6 +440,8 @@ void mpe_destroy(mpe_handle* h) {
   h->mtab.release();
   h->work.release();
   h->scratch.release();
+  h->track.release();
+  if (h->mailbox) (void)hipHostFree(h->mailbox);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : h->sub_done)
@@ -657,7 +662,7 @@ int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const d
                             static_cast<uint32_t*>(h->hist.p), auto_splits(h, 1, n_markers), n_det, h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
                             static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), nullptr,
-                            h->stream));
+                            nullptr, 0.0, h->stream));
   uint32_t hh[MPE_HIST_STRIDE], hc[2 * MPE_MAX_MARKERS];
   HIP_TRY(h, hipMemcpyAsync(out, h->results.p, sizeof(mpe_result), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(hh, h->hist.p, sizeof(hh), hipMemcpyDeviceToHost, h->stream));
@@ -696,9 +701,79 @@ int mpe_check_and_refine(mpe_handle* h, const double* det_xy, int n_det, const d
   HIP_TRY(h, hipMemcpyAsync(h->corr.p, hc, sizeof(hc), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
                             static_cast<mpe_result*>(h->results.p), nullptr, static_cast<uint32_t*>(h->corr.p),
-                            h->stream));
+                            nullptr, 0.0, h->stream));
   HIP_TRY(h, hipMemcpyAsync(out, h->results.p, sizeof(mpe_result), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPE_OK;
+}
+
+// Device-side record of one tracking step; fetched with ONE copy.
+namespace {
+struct TrackRecord {
+  mpe_detections det;
+  uint32_t corr[2 * MPE_MAX_MARKERS];
+  mpe_result res;
+};
+const size_t kTrackHeader = 2 * MPE_MAX_MARKERS * sizeof(double);  // predicted pixels in front of the ROI
+}  // namespace
+
+int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t stride_bytes, int roi_x, int roi_y,
+                   int roi_w, int roi_h, const mpe_params* p, const double K[9], const double* D, int nD,
+                   const double* markers_xyz, int n_markers, const double* predicted_px, mpe_detections* dets_out,
+                   uint32_t* corr_out, mpe_result* out) {
+  if (!h || !img || !p || !K || !markers_xyz || !predicted_px || !dets_out || !corr_out || !out)
+    return fail(h, MPE_ERR_ARG, "bad argument");
+  if (roi_x < 0 || roi_y < 0 || roi_w <= 0 || roi_h <= 0 || roi_x + roi_w > cols || roi_y + roi_h > rows)
+    return fail(h, MPE_ERR_ARG, "ROI outside the image");
+  HIP_TRY(h, hipSetDevice(h->device));
+  FrameGeom g;
+  if (make_geom(h, roi_h, roi_w, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
+  DetectParams dp;
+  if (make_detect_params(p, K, D, nD, roi_x, roi_y, dp)) return fail(h, MPE_ERR_ARG, "gaussian_sigma must be in (0, 6]");
+  SolveParams sp;
+  if (make_solve_params(p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
+  const size_t roi_bytes = (size_t)g.rows * g.pitch;
+  const size_t in_bytes = kTrackHeader + roi_bytes;
+  const size_t need = in_bytes + sizeof(TrackRecord);
+  if (need > h->mailbox_cap) {
+    if (h->mailbox) (void)hipHostFree(h->mailbox);
+    h->mailbox = nullptr;
+    h->mailbox_cap = 0;
+    const size_t want = std::max(need + need / 4, (size_t)1 << 16);
+    HIP_TRY(h, hipHostMalloc(&h->mailbox, want, hipHostMallocDefault));
+    h->mailbox_cap = want;
+  }
+  // pack [predicted pixels | ROI rows, zero padded to the pitch] into pinned memory -> one H2D copy
+  uint8_t* mb = static_cast<uint8_t*>(h->mailbox);
+  double* pred = reinterpret_cast<double*>(mb);
+  for (int i = 0; i < 2 * MPE_MAX_MARKERS; ++i) pred[i] = i < 2 * n_markers ? predicted_px[i] : 0.0;
+  for (int y = 0; y < roi_h; ++y) {
+    uint8_t* dst = mb + kTrackHeader + (size_t)y * g.pitch;
+    std::memcpy(dst, img + (size_t)(roi_y + y) * stride_bytes + roi_x, (size_t)roi_w);
+    if (g.pitch > roi_w) std::memset(dst + roi_w, 0, (size_t)(g.pitch - roi_w));
+  }
+  TrackRecord* host_rec = reinterpret_cast<TrackRecord*>(mb + ((h->mailbox_cap - sizeof(TrackRecord)) & ~(size_t)63));
+  HIP_TRY(h, h->frames.reserve(in_bytes + 16));
+  HIP_TRY(h, h->flags.reserve(flag_words(roi_bytes) * 8));
+  HIP_TRY(h, h->work.reserve(4 * sizeof(int)));
+  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
+  HIP_TRY(h, h->hist.reserve(MPE_HIST_STRIDE * sizeof(uint32_t)));
+  HIP_TRY(h, h->track.reserve(sizeof(TrackRecord)));
+  uint8_t* d_in = static_cast<uint8_t*>(h->frames.p);
+  TrackRecord* d_rec = static_cast<TrackRecord*>(h->track.p);
+  h->have_ms = false;
+  HIP_TRY(h, hipMemcpyAsync(d_in, mb, in_bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, launch_k1a_scan(d_in + kTrackHeader, roi_bytes, static_cast<unsigned long long*>(h->flags.p), dp.thr, false,
+                             h->stream));
+  HIP_TRY(h, launch_k1b_blobs(d_in + kTrackHeader, static_cast<unsigned long long*>(h->flags.p), 1, g, dp, &d_rec->det,
+                              static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), 0, h->stream));
+  HIP_TRY(h, launch_k3_tail(&d_rec->det, static_cast<uint32_t*>(h->hist.p), 1, sp, &d_rec->res, d_rec->corr, nullptr,
+                            reinterpret_cast<const double*>(d_in), p->nearest_neighbour_pixel_tolerance, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(host_rec, d_rec, sizeof(TrackRecord), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  *dets_out = host_rec->det;
+  std::memcpy(corr_out, host_rec->corr, sizeof(host_rec->corr));
+  *out = host_rec->res;
   return MPE_OK;
 }
 

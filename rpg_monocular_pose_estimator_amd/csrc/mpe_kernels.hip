@@ -1506,7 +1506,8 @@ __device__ __forceinline__ double group_sum(double v) {
 __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__ dets,
                                               const uint32_t* __restrict__ hist, int n_frames, SolveParams sp,
                                               mpe_result* __restrict__ results, uint32_t* __restrict__ corr_out,
-                                              const uint32_t* __restrict__ corr_in) {
+                                              const uint32_t* __restrict__ corr_in,
+                                              const double* __restrict__ nn_pred, double nn_tol) {
   // dynamic LDS, sized for the actual marker count: partial sums [4][16][3 n_m] and
   // back-projections [2 (n_m - 3)][64]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
@@ -1564,6 +1565,31 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
         s_cm[grp][n_c] = (unsigned char)ci[2 * n_c];
         s_cd[grp][n_c] = (unsigned char)ci[2 * n_c + 1];
         ++n_c;
+      }
+      go0 = false;
+    }
+    if (go0 && nn_pred) {
+      // tracking path, correspondences found here: findCorrespondences (pose_estimator.cpp:372-392) —
+      // nearest detection of every predicted marker pixel (first minimum wins), kept if within
+      // nearest_neighbour_pixel_tolerance_
+      const double* pp = nn_pred + (size_t)f * 2 * MPE_MAX_MARKERS;
+      for (int i = 0; i < n_m; ++i) {
+        double best = __builtin_huge_val();
+        int bj = 0;
+        const double pu = pp[2 * i], pv = pp[2 * i + 1];
+        for (int j = 0; j < n_d; ++j) {
+          const double du = pu - d->undist_xy[2 * j], dv = pv - d->undist_xy[2 * j + 1];
+          const double d2 = du * du + dv * dv;
+          if (d2 < best) {
+            best = d2;
+            bj = j + 1;
+          }
+        }
+        if (sqrt(best) <= nn_tol) {
+          s_cm[grp][n_c] = (unsigned char)(i + 1);
+          s_cd[grp][n_c] = (unsigned char)bj;
+          ++n_c;
+        }
       }
       go0 = false;
     }
@@ -1859,12 +1885,13 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
 #undef s_part
 #undef s_q
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
-                          mpe_result* results, uint32_t* corr_out, const uint32_t* corr_in, hipStream_t s) {
+                          mpe_result* results, uint32_t* corr_out, const uint32_t* corr_in, const double* nn_pred,
+                          double nn_tol, hipStream_t s) {
   if (n_frames <= 0) return hipSuccess;
   const int nu = sp.n_markers > 3 ? sp.n_markers - 3 : 1;
   const size_t lds = ((size_t)K3_FRAMES_PER_BLOCK * K3_GROUP * 3 * sp.n_markers + (size_t)2 * nu * 64) * sizeof(double);
   hipLaunchKernelGGL(k3_tail, dim3((n_frames + K3_FRAMES_PER_BLOCK - 1) / K3_FRAMES_PER_BLOCK), dim3(64), lds, s, dets,
-                     hist, n_frames, sp, results, corr_out, corr_in);
+                     hist, n_frames, sp, results, corr_out, corr_in, nn_pred, nn_tol);
   return hipGetLastError();
 }
 

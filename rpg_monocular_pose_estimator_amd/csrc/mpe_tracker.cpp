@@ -155,6 +155,11 @@ struct mpe_tracker {
   std::vector<uint32_t> corr;        // rows (marker, detection)
   int n_corr = 0, gn_iterations = 0;
   bool used_bruteforce = false;
+  // result of the speculative nearest-neighbour + refine pass that mpe_track_step ran together with
+  // the detection; only meaningful while fused_valid (>= 4 fresh detections)
+  bool fused_valid = false;
+  mpe_result fused_res;
+  uint32_t fused_corr[2 * MPE_MAX_MARKERS];
 };
 
 namespace {
@@ -230,6 +235,21 @@ int detect(mpe_tracker* t, const uint8_t* img, int rows, int cols, size_t stride
   return MPE_OK;
 }
 
+// Tracking branch: detection in the ROI and, in the same device submission, the nearest-neighbour
+// correspondences + validation + refinement the reference would run next if >= 4 LEDs are found.
+int detect_and_try(mpe_tracker* t, const uint8_t* img, int rows, int cols, size_t stride) {
+  mpe_detections d;
+  t->fused_valid = false;
+  int rc = mpe_track_step(t->h, img, rows, cols, stride, t->roi[0], t->roi[1], t->roi[2], t->roi[3], &t->p, t->K,
+                          t->D.empty() ? nullptr : t->D.data(), (int)t->D.size(), t->markers.data(), n_markers(t),
+                          t->predicted_px.data(), &d, t->fused_corr, &t->fused_res);
+  if (rc != MPE_OK) return rc;
+  if (d.status != 0) return d.status;
+  if (d.n > 0) t->det.assign(d.undist_xy, d.undist_xy + 2 * d.n);  // as in detect(): kept when nothing was found
+  t->fused_valid = d.n >= 4;
+  return MPE_OK;
+}
+
 void take_result(mpe_tracker* t, const mpe_result& r) {
   std::memcpy(t->predicted.a, r.T, sizeof(r.T));
   std::memcpy(t->cov, r.cov, sizeof(r.cov));
@@ -259,6 +279,18 @@ int bruteforce(mpe_tracker* t) {  // initialise() + optimiseAndUpdatePose()
 
 // findCorrespondencesAndPredictPose (pose_estimator.cpp:831-848)
 int track(mpe_tracker* t) {
+  if (t->fused_valid) {  // already done on the device together with the detection
+    t->fused_valid = false;
+    const mpe_result& r = t->fused_res;
+    if (r.status < 0) return r.status;
+    t->n_corr = r.n_corr;
+    t->corr.assign(t->fused_corr, t->fused_corr + 2 * r.n_corr);
+    if (r.status == MPE_FRAME_POSE) {
+      take_result(t, r);
+      return MPE_OK;
+    }
+    return bruteforce(t);
+  }
   // findCorrespondences: nearest detection of every predicted marker pixel, kept if <= tolerance
   const int nm = n_markers(t), nd = (int)t->det.size() / 2;
   t->corr.clear();
@@ -386,7 +418,7 @@ int mpe_tracker_estimate(mpe_tracker* t, const uint8_t* img, int rows, int cols,
     for (int i = 0; i < n_markers(t); ++i)
       project(t, t->predicted, &t->markers[3 * i], t->predicted_px[2 * i], t->predicted_px[2 * i + 1]);
     determine_roi(t, rows, cols);
-    if ((rc = detect(t, img, rows, cols, stride_bytes)) != MPE_OK) return rc;
+    if ((rc = detect_and_try(t, img, rows, cols, stride_bytes)) != MPE_OK) return rc;
     bool repeat_check = true;
     unsigned num_loops = 0;
     do {
@@ -398,7 +430,7 @@ int mpe_tracker_estimate(mpe_tracker* t, const uint8_t* img, int rows, int cols,
         t->roi[0] = t->roi[1] = 0;
         t->roi[2] = cols;
         t->roi[3] = rows;
-        if ((rc = detect(t, img, rows, cols, stride_bytes)) != MPE_OK) return rc;
+        if ((rc = detect_and_try(t, img, rows, cols, stride_bytes)) != MPE_OK) return rc;
       } else {
         repeat_check = false;
       }
@@ -420,6 +452,20 @@ int mpe_tracker_estimate(mpe_tracker* t, const uint8_t* img, int rows, int cols,
     info[7] = t->used_bruteforce ? 1 : 0;
   }
   return t->pose_updated ? 1 : 0;
+}
+
+int mpe_tracker_run_sequence(mpe_tracker* t, const uint8_t* frames, int n_frames, int rows, int cols,
+                             size_t stride_bytes, size_t frame_stride_bytes, const double* times, mpe_result* out,
+                             int* info) {
+  if (!t || !frames || !times || n_frames < 0) return MPE_ERR_ARG;
+  int updated = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    const int rc = mpe_tracker_estimate(t, frames + (size_t)f * frame_stride_bytes, rows, cols, stride_bytes, times[f],
+                                        out ? out + f : nullptr, info ? info + 8 * f : nullptr);
+    if (rc < 0) return rc;
+    updated += rc;
+  }
+  return updated;
 }
 
 }  // extern "C"

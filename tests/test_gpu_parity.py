@@ -436,3 +436,40 @@ def test_tracking_1920x1200(hip, orc):
         if ro["updated"]:
             dp, dr = pose_diff(rh["T"], ro["T"])
             assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD
+
+
+@pytest.mark.gpu
+def test_run_sequence_and_concurrent_streams(orc):
+    """mpe_tracker_run_sequence = the per-frame calls in a C loop; and BASELINE configs[4] in small:
+    several independent camera streams, one handle + tracker + host thread each, on one GPU at the
+    same time — every stream must equal the oracle's state machine on its own frames."""
+    import threading
+    n_streams, n = 4, 24
+    seqs = [synth.make_sequence("C2", n, seed=40 + s, dropout=(9,) if s == 1 else ()) for s in range(n_streams)]
+    handles = [mpe.Handle(0) for _ in range(n_streams)]
+    trackers = [mpe.Tracker(handles[s], seqs[s]["markers"], seqs[s]["K"], seqs[s]["D"], mpe.demo_params())
+                for s in range(n_streams)]
+    got = [None] * n_streams
+
+    def work(s):
+        got[s] = trackers[s].run_sequence(seqs[s]["frames"], seqs[s]["times"])
+
+    threads = [threading.Thread(target=work, args=(s,)) for s in range(n_streams)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    for s in range(n_streams):
+        assert got[s] is not None
+        rec, info = got[s]
+        to = orc.Tracker(seqs[s]["markers"], seqs[s]["K"], seqs[s]["D"], orc.make_params())
+        for k in range(n):
+            ro = to.estimate(seqs[s]["frames"][k], seqs[s]["times"][k])
+            assert (rec["status"][k] == 0) == ro["updated"], (s, k)
+            assert tuple(info[k, 0:4]) == ro["roi"] and info[k, 4] == ro["it_since_initialized"], (s, k)
+            assert info[k, 5] == ro["n_det"] and info[k, 6] == ro["n_corr"] and bool(info[k, 7]) == ro["used_bruteforce"]
+            if ro["updated"]:
+                dp, dr = pose_diff(rec["T"][k].reshape(4, 4), ro["T"])
+                assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (s, k, dp, dr)
+    for t in trackers:
+        t.close()
+    for h in handles:
+        h.close()
