@@ -141,6 +141,38 @@ int mpe_check_and_refine(mpe_handle* h, const double* det_xy, int n_det, const d
                          int n_markers, const double K[9], const mpe_params* p, const uint32_t* corr,
                          int n_corr, mpe_result* out);
 
+/* The two halves of the call above as separate stage entry points (same kernel, other instantiations):
+ * PoseEstimator::checkCorrespondences (pose_estimator.h:724, pose_estimator.cpp:394-542) — out->status 0
+ * and out->T = the UNREFINED pose of computeTransformation when the correspondences validate, else 1;
+ * PoseEstimator::optimisePose (pose_estimator.h:773, pose_estimator.cpp:733-792) — Gauss-Newton from
+ * T_init on the given correspondences (no validation): out->T, out->cov, out->gn_iterations; status 1
+ * when fewer than 3 correspondences were given (singular normal equations). */
+int mpe_check_correspondences(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz,
+                              int n_markers, const double K[9], const mpe_params* p, const uint32_t* corr,
+                              int n_corr, mpe_result* out);
+int mpe_optimise_pose(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
+                      const double K[9], const mpe_params* p, const uint32_t* corr, int n_corr,
+                      const double T_init[16], mpe_result* out);
+
+/* ---- static primitives of the reference, batched (n independent problems, one GPU lane each) ----
+ * P3P::computePoses (p3p.h:110, p3p.cpp:65-236): feature_vectors / world_points n x 9, point i of a
+ * problem at [3i..3i+2] (= column i of the reference's 3x3 matrices); solutions n x 48 = 4 solutions
+ * x 3x4 row-major [R|C]; status[i] 0, or -1 for collinear world points (solutions[i] untouched). */
+int mpe_p3p_batch(mpe_handle* h, const double* feature_vectors, const double* world_points, int n,
+                  double* solutions, int* status);
+/* P3P::solveQuartic (p3p.h:127, p3p.cpp:238-286): factors n x 5 (highest power first), real_roots n x 4
+ * (real parts of the four complex Ferrari roots, like the reference).  variant 0 = IEEE operators
+ * (as the validation kernel uses it), 1 = the voting kernel's literal-order variant. */
+int mpe_solve_quartic_batch(mpe_handle* h, const double* factors, int n, int variant, double* real_roots);
+
+/* LEDDetector::determineROI (led_detector.h:105, led_detector.cpp:114-179): bounding box of the predicted
+ * (undistorted) pixel positions, its two corners distorted, grown by border_size, clipped to the
+ * image; the whole image when the box degenerates.  Host arithmetic (a dozen flops), no device. */
+int mpe_determine_roi(const double* pixel_positions, int n_points, int rows, int cols, int border_size,
+                      const double K[9], const double* D, int nD, int roi_xywh[4]);
+/* LEDDetector::distortPoints (led_detector.h:135, led_detector.cpp:181-224), float in / float out. */
+int mpe_distort_points(const float* src_xy, float* dst_xy, int n, const double K[9], const double* D, int nD);
+
 /* One frame of the tracking branch as ONE device submission (pose_estimator.cpp:98-110 + 831-839):
  * LEDDetector::findLeds inside the ROI, then — when at least 4 LEDs were found — findCorrespondences
  * (nearest detection of every predicted marker pixel within nearest_neighbour_pixel_tolerance,

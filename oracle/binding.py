@@ -185,6 +185,16 @@ def distort_points(xy, K, D):
     return d
 
 
+def determine_roi(px, rows, cols, border, K, D):
+    px = _f64(px).reshape(-1, 2)
+    K = _f64(K).reshape(9)
+    D = _f64(D).reshape(-1)
+    roi = np.zeros(4, np.int32)
+    lib().orc_determine_roi(_p(px, C.c_double), len(px), int(rows), int(cols), int(border), _p(K, C.c_double),
+                            _p(D, C.c_double), len(D), _p(roi, C.c_int))
+    return tuple(int(v) for v in roi)
+
+
 def undistort_points(xy, K, D):
     s = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
     d = np.zeros_like(s)

@@ -1330,32 +1330,15 @@ class Tracker {
   }
 
   RectI determineROI(int rows, int cols) const {  // LED.cpp:114-179
-    double x_min = INFINITY, x_max = 0, y_min = INFINITY, y_max = 0;
+    std::vector<double> px;
     for (const V2& q : predicted_pixel_positions_) {
-      if (q.x < x_min) x_min = q.x;
-      if (q.x > x_max) x_max = q.x;
-      if (q.y < y_min) y_min = q.y;
-      if (q.y > y_max) y_max = q.y;
+      px.push_back(q.x);
+      px.push_back(q.y);
     }
-    float und[4] = {(float)x_min, (float)y_min, (float)x_max, (float)y_max};  // cv::Point2f
-    float dst[4];
-    distort_points(und, dst, 2, Kc, D.data(), (int)D.size());
-    const double x_min_dist = dst[0], y_min_dist = dst[1], x_max_dist = dst[2], y_max_dist = dst[3];
-    const int border_size = (int)p.roi_border_thickness;
-    const double x0 = std::max(0.0, std::min((double)cols, x_min_dist - border_size));
-    const double x1 = std::max(0.0, std::min((double)cols, x_max_dist + border_size));
-    const double y0 = std::max(0.0, std::min((double)rows, y_min_dist - border_size));
-    const double y1 = std::max(0.0, std::min((double)rows, y_max_dist + border_size));
-    RectI r;
-    if (x1 - x0 < 1 || y1 - y0 < 1) {
-      r = {0, 0, cols, rows};
-    } else {
-      r.x = (int)x0;
-      r.y = (int)y0;
-      r.width = (int)(x1 - x0);
-      r.height = (int)(y1 - y0);
-    }
-    return r;
+    int r[4];
+    orc_determine_roi(px.data(), (int)predicted_pixel_positions_.size(), rows, cols, (int)p.roi_border_thickness, Kc,
+                      D.data(), (int)D.size(), r);
+    return RectI{r[0], r[1], r[2], r[3]};
   }
 
   void findCorrespondences() {  // PE.cpp:372-392
@@ -1545,6 +1528,37 @@ int orc_permutations3(unsigned N, unsigned* out) {
 
 int orc_solve_quartic(const double factors[5], double real_roots[4]) {
   return solve_quartic(factors, real_roots);
+}
+
+// LED.cpp:114-179 — bounding box of the predicted pixels, corners distorted, border added, clipped
+void orc_determine_roi(const double* px, int n, int rows, int cols, int border_size, const double K[9],
+                       const double* D, int nD, int roi[4]) {
+  double x_min = INFINITY, x_max = 0, y_min = INFINITY, y_max = 0;
+  for (int i = 0; i < n; ++i) {
+    if (px[2 * i] < x_min) x_min = px[2 * i];
+    if (px[2 * i] > x_max) x_max = px[2 * i];
+    if (px[2 * i + 1] < y_min) y_min = px[2 * i + 1];
+    if (px[2 * i + 1] > y_max) y_max = px[2 * i + 1];
+  }
+  float und[4] = {(float)x_min, (float)y_min, (float)x_max, (float)y_max};  // cv::Point2f
+  float dst[4];
+  distort_points(und, dst, 2, K, D, nD);
+  const double x_min_dist = dst[0], y_min_dist = dst[1], x_max_dist = dst[2], y_max_dist = dst[3];
+  const double x0 = std::max(0.0, std::min((double)cols, x_min_dist - border_size));
+  const double x1 = std::max(0.0, std::min((double)cols, x_max_dist + border_size));
+  const double y0 = std::max(0.0, std::min((double)rows, y_min_dist - border_size));
+  const double y1 = std::max(0.0, std::min((double)rows, y_max_dist + border_size));
+  if (x1 - x0 < 1 || y1 - y0 < 1) {
+    roi[0] = 0;
+    roi[1] = 0;
+    roi[2] = cols;
+    roi[3] = rows;
+  } else {
+    roi[0] = (int)x0;
+    roi[1] = (int)y0;
+    roi[2] = (int)(x1 - x0);
+    roi[3] = (int)(y1 - y0);
+  }
 }
 
 int orc_p3p(const double fv[9], const double wp[9], double sol[48]) {

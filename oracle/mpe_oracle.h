@@ -93,6 +93,10 @@ void orc_distort_points(const float* src_xy, float* dst_xy, int n, const double 
 int orc_undistort_points(const float* src_xy, float* dst_xy, int n, const double K[9],
                          const double* D, int nD);
 
+/* LED.cpp:114-179; roi = x, y, width, height */
+void orc_determine_roi(const double* px, int n, int rows, int cols, int border_size, const double K[9],
+                       const double* D, int nD, int roi[4]);
+
 /* ---- pose (PE.cpp) ---- */
 void orc_image_vectors(const double* det, int n_det, const double K[9], double* vec3); /* PE.cpp:288-301 */
 void orc_project2d(const double p4[4], const double T[16], const double K[9], double out[2]); /* PE.cpp:251-268 */

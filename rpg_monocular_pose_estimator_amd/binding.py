@@ -137,6 +137,33 @@ def load_library():
     return lib
 
 
+def determine_roi(px, rows, cols, border, K, D):
+    """LEDDetector::determineROI (host arithmetic inside libmpe_hip.so; needs no device)."""
+    lib = load_library()
+    px = _f64(px).reshape(-1, 2)
+    K = _f64(K).reshape(9)
+    D = _f64(D).reshape(-1)
+    roi = (C.c_int * 4)()
+    rc = lib.mpe_determine_roi(_dp(px), len(px), int(rows), int(cols), int(border), _dp(K), _dp(D), len(D), roi)
+    if rc != 0:
+        raise MpeError("mpe_determine_roi failed (%d)" % rc)
+    return tuple(roi)
+
+
+def distort_points(xy, K, D):
+    """LEDDetector::distortPoints, float32 in / out (host arithmetic)."""
+    lib = load_library()
+    s = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    d = np.zeros_like(s)
+    K = _f64(K).reshape(9)
+    D = _f64(D).reshape(-1)
+    rc = lib.mpe_distort_points(s.ctypes.data_as(C.POINTER(C.c_float)), d.ctypes.data_as(C.POINTER(C.c_float)), len(s),
+                                _dp(K), _dp(D), len(D))
+    if rc != 0:
+        raise MpeError("mpe_distort_points failed (%d)" % rc)
+    return d
+
+
 def demo_params(**kw):
     """Parameter set of launch/demo.launch:12-22 (overridable by keyword)."""
     p = MpeParams()
@@ -251,6 +278,74 @@ class Handle:
         self._check(rc, "mpe_check_and_refine")
         return dict(status=res.status, T=np.array(res.T).reshape(4, 4), cov=np.array(res.cov).reshape(6, 6),
                     n_corr=res.n_corr, gn_iterations=res.gn_iterations)
+
+    def check_correspondences(self, det, markers, K, params, corr):
+        """checkCorrespondences alone -> (ok, unrefined T)."""
+        det = _f64(det).reshape(-1, 2)
+        markers = _f64(markers).reshape(-1, 3)
+        K = _f64(K).reshape(9)
+        corr = np.ascontiguousarray(corr, np.uint32).reshape(-1, 2)
+        res = MpeResult()
+        rc = self._lib.mpe_check_correspondences(self._h, _dp(det), len(det), _dp(markers), len(markers), _dp(K),
+                                                 C.byref(params), corr.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                 len(corr), C.byref(res))
+        self._check(rc, "mpe_check_correspondences")
+        return res.status == 0, np.array(res.T).reshape(4, 4)
+
+    def optimise_pose(self, det, markers, K, params, corr, T_init):
+        """optimisePose alone from T_init -> dict(status, T, cov, gn_iterations)."""
+        det = _f64(det).reshape(-1, 2)
+        markers = _f64(markers).reshape(-1, 3)
+        K = _f64(K).reshape(9)
+        T0 = _f64(T_init).reshape(16)
+        corr = np.ascontiguousarray(corr, np.uint32).reshape(-1, 2)
+        res = MpeResult()
+        rc = self._lib.mpe_optimise_pose(self._h, _dp(det), len(det), _dp(markers), len(markers), _dp(K),
+                                         C.byref(params), corr.ctypes.data_as(C.POINTER(C.c_uint32)), len(corr),
+                                         _dp(T0), C.byref(res))
+        self._check(rc, "mpe_optimise_pose")
+        return dict(status=res.status, T=np.array(res.T).reshape(4, 4), cov=np.array(res.cov).reshape(6, 6),
+                    gn_iterations=res.gn_iterations)
+
+    # ---- one tracked frame: findLeds(ROI) + findCorrespondences + checkCorrespondences + optimisePose ----
+    def track_step(self, img, roi, params, K, D, markers, predicted_px):
+        img = np.ascontiguousarray(img, np.uint8)
+        markers = _f64(markers).reshape(-1, 3)
+        K = _f64(K).reshape(9)
+        D = _f64(D).reshape(-1)
+        pred = _f64(predicted_px).reshape(-1, 2)
+        assert len(pred) == len(markers)
+        det = MpeDetections()
+        corr = np.zeros((MAX_MARKERS, 2), np.uint32)
+        res = MpeResult()
+        rc = self._lib.mpe_track_step(self._h, C.c_void_p(img.ctypes.data), img.shape[0], img.shape[1],
+                                      C.c_size_t(img.strides[0]), int(roi[0]), int(roi[1]), int(roi[2]), int(roi[3]),
+                                      C.byref(params), _dp(K), _dp(D), len(D), _dp(markers), len(markers), _dp(pred),
+                                      C.byref(det), C.c_void_p(corr.ctypes.data), C.byref(res))
+        self._check(rc, "mpe_track_step")
+        n = max(det.n, 0)
+        return dict(status=res.status, T=np.array(res.T).reshape(4, 4), cov=np.array(res.cov).reshape(6, 6),
+                    n_corr=res.n_corr, corr=corr[:max(res.n_corr, 0)].copy(), det_status=det.status,
+                    undist=np.array(det.undist_xy[:2 * n]).reshape(-1, 2), gn_iterations=res.gn_iterations)
+
+    # ---- static primitives, batched ----------------------------------------------------------------
+    def p3p_batch(self, fv, wp):
+        """fv, wp: (n,3,3), ROWS = bearings / world points.  -> (status (n,), solutions (n,4,3,4) [R|C])."""
+        fv = _f64(fv).reshape(-1, 9)
+        wp = _f64(wp).reshape(-1, 9)
+        n = len(fv)
+        sol = np.zeros((n, 4, 3, 4))
+        st = np.zeros(n, np.int32)
+        self._check(self._lib.mpe_p3p_batch(self._h, _dp(fv), _dp(wp), n, _dp(sol), C.c_void_p(st.ctypes.data)),
+                    "mpe_p3p_batch")
+        return st, sol
+
+    def solve_quartic_batch(self, factors, variant=0):
+        f = _f64(factors).reshape(-1, 5)
+        r = np.zeros((len(f), 4))
+        self._check(self._lib.mpe_solve_quartic_batch(self._h, _dp(f), len(f), int(variant), _dp(r)),
+                    "mpe_solve_quartic_batch")
+        return r
 
     # ---- estimateBodyPose on a fresh estimator per frame -------------------------------------
     def estimate_batch(self, frames, markers, K, D, params):

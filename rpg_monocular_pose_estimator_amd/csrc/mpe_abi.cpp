@@ -675,8 +675,12 @@ int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const d
   return MPE_OK;
 }
 
-int mpe_check_and_refine(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
-                         const double K[9], const mpe_params* p, const uint32_t* corr, int n_corr, mpe_result* out) {
+namespace {
+// one frame through the tail kernel from explicit correspondences: mode 0 check + refine, 1 check only,
+// 2 refine only from T_init
+int run_tail_single(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
+                    const double K[9], const mpe_params* p, const uint32_t* corr, int n_corr, int mode,
+                    const double* T_init, mpe_result* out) {
   if (!h || (!det_xy && n_det > 0) || !markers_xyz || !K || !p || !out || n_det < 0 || n_corr < 0 || (!corr && n_corr > 0))
     return fail(h, MPE_ERR_ARG, "bad argument");
   if (n_det > MPE_MAX_DETECTIONS || n_corr > MPE_MAX_MARKERS) return fail(h, MPE_ERR_UNSUPPORTED, "too many points");
@@ -699,10 +703,74 @@ int mpe_check_and_refine(mpe_handle* h, const double* det_xy, int n_det, const d
   HIP_TRY(h, h->corr.reserve(2 * MPE_MAX_MARKERS * sizeof(uint32_t)));
   HIP_TRY(h, hipMemcpyAsync(h->dets.p, &hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->corr.p, hc, sizeof(hc), hipMemcpyHostToDevice, h->stream));
+  if (mode == 2) {
+    mpe_result seed;
+    std::memset(&seed, 0, sizeof(seed));
+    std::memcpy(seed.T, T_init, sizeof(seed.T));
+    HIP_TRY(h, hipMemcpyAsync(h->results.p, &seed, sizeof(seed), hipMemcpyHostToDevice, h->stream));
+  }
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
                             static_cast<mpe_result*>(h->results.p), nullptr, static_cast<uint32_t*>(h->corr.p),
-                            nullptr, 0.0, h->stream));
+                            nullptr, 0.0, h->stream, mode));
   HIP_TRY(h, hipMemcpyAsync(out, h->results.p, sizeof(mpe_result), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPE_OK;
+}
+}  // namespace
+
+int mpe_check_and_refine(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
+                         const double K[9], const mpe_params* p, const uint32_t* corr, int n_corr, mpe_result* out) {
+  return run_tail_single(h, det_xy, n_det, markers_xyz, n_markers, K, p, corr, n_corr, 0, nullptr, out);
+}
+
+int mpe_check_correspondences(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
+                              const double K[9], const mpe_params* p, const uint32_t* corr, int n_corr,
+                              mpe_result* out) {
+  return run_tail_single(h, det_xy, n_det, markers_xyz, n_markers, K, p, corr, n_corr, 1, nullptr, out);
+}
+
+int mpe_optimise_pose(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
+                      const double K[9], const mpe_params* p, const uint32_t* corr, int n_corr, const double T_init[16],
+                      mpe_result* out) {
+  if (!T_init) return fail(h, MPE_ERR_ARG, "bad argument");
+  return run_tail_single(h, det_xy, n_det, markers_xyz, n_markers, K, p, corr, n_corr, 2, T_init, out);
+}
+
+int mpe_p3p_batch(mpe_handle* h, const double* feature_vectors, const double* world_points, int n, double* solutions,
+                  int* status) {
+  if (!h || n < 0 || (n > 0 && (!feature_vectors || !world_points || !solutions || !status)))
+    return fail(h, MPE_ERR_ARG, "bad argument");
+  if (n == 0) return MPE_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t in = (size_t)n * 9 * sizeof(double), out = (size_t)n * 48 * sizeof(double);
+  HIP_TRY(h, h->scratch.reserve(2 * in + out + (size_t)n * sizeof(int) + 64));
+  uint8_t* base = static_cast<uint8_t*>(h->scratch.p);
+  double* d_fv = reinterpret_cast<double*>(base);
+  double* d_wp = reinterpret_cast<double*>(base + in);
+  double* d_sol = reinterpret_cast<double*>(base + 2 * in);
+  int* d_st = reinterpret_cast<int*>(base + 2 * in + out);
+  HIP_TRY(h, hipMemcpyAsync(d_fv, feature_vectors, in, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d_wp, world_points, in, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(d_sol, solutions, out, hipMemcpyHostToDevice, h->stream));  // collinear: kept as passed
+  HIP_TRY(h, launch_p3p_batch(d_fv, d_wp, n, d_sol, d_st, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(solutions, d_sol, out, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(status, d_st, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPE_OK;
+}
+
+int mpe_solve_quartic_batch(mpe_handle* h, const double* factors, int n, int variant, double* real_roots) {
+  if (!h || n < 0 || (n > 0 && (!factors || !real_roots)) || (variant != 0 && variant != 1))
+    return fail(h, MPE_ERR_ARG, "bad argument");
+  if (n == 0) return MPE_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t in = (size_t)n * 5 * sizeof(double), out = (size_t)n * 4 * sizeof(double);
+  HIP_TRY(h, h->scratch.reserve(in + out + 64));
+  double* d_f = static_cast<double*>(h->scratch.p);
+  double* d_r = d_f + (size_t)n * 5;
+  HIP_TRY(h, hipMemcpyAsync(d_f, factors, in, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, launch_quartic_batch(d_f, n, variant, d_r, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(real_roots, d_r, out, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPE_OK;
 }

@@ -59,8 +59,11 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
                           uint32_t* hist, int splits, int n_det_hint, hipStream_t s);
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
                           mpe_result* results, uint32_t* corr_out, const uint32_t* corr_in, const double* nn_pred,
-                          double nn_tol, hipStream_t s);
+                          double nn_tol, hipStream_t s, int mode = 0);
 hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int n_frames, int roi_x,
                          int roi_y, int roi_w, int roi_h, uint8_t* dst, int dst_pitch, hipStream_t s);
+
+hipError_t launch_p3p_batch(const double* fv, const double* wp, int n, double* sol, int* status, hipStream_t s);
+hipError_t launch_quartic_batch(const double* factors, int n, int variant, double* roots, hipStream_t s);
 
 }  // namespace mpe

@@ -1503,6 +1503,11 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
+// MODE 0: the whole tail (batch path).  MODE 1: checkCorrespondences only — the pose of
+// computeTransformation is returned unrefined (stage entry point mpe_check_correspondences).
+// MODE 2: optimisePose only, started from the pose found in results[f].T, on corr_in as given
+// (mpe_optimise_pose).  Separate instantiations: the batch kernel's code is not affected.
+template <int MODE>
 __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__ dets,
                                               const uint32_t* __restrict__ hist, int n_frames, SolveParams sp,
                                               mpe_result* __restrict__ results, uint32_t* __restrict__ corr_out,
@@ -1544,6 +1549,12 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
     s_det[grp][i][0] = d->undist_xy[2 * i];
     s_det[grp][i][1] = d->undist_xy[2 * i + 1];
   }
+  T34 T;
+  if (MODE == 2) {  // start pose (read by every lane before the default output overwrites it)
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) T.m[r][c] = live ? res->T[r * 4 + c] : ((r == c) ? 1.0 : 0.0);
+    __syncthreads();
+  }
   if (live) {
     for (int i = l; i < 16; i += K3_GROUP) res->T[i] = (i % 5 == 0) ? 1.0 : 0.0;
     for (int i = l; i < 36; i += K3_GROUP) res->cov[i] = 0.0;
@@ -1557,6 +1568,7 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
   if (l == 0) {
     int n_c = 0;
     bool go0 = live && dstatus == 0 && n_d >= 4 && n_m >= 4;
+    if (MODE == 2) go0 = live && dstatus == 0 && n_d >= 1 && n_m >= 1;
     if (go0 && corr_in) {
       // tracking path: correspondences come from findCorrespondences (pose_estimator.cpp:372-392),
       // rows (marker, detection) terminated by a 0 marker; checkCorrespondences starts from them
@@ -1637,7 +1649,7 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
   }
   __syncthreads();
   const int n_c = s_nc[grp];
-  const bool go = n_c >= 4;
+  const bool go = (MODE != 2) && n_c >= 4;
 
   // ---- checkCorrespondences (pose_estimator.cpp:394-542): the C(n_c,3) P3P validations are
   //      spread over the 16 lanes; each lane sums inverse(H_best) * markers for its combinations
@@ -1757,10 +1769,10 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
   for (int q = 0; q < K3_GROUP; ++q) num_valid += s_valid[grp][q];
   __syncthreads();
   bool active = go && ((double)num_valid / (double)N >= sp.valid_corr_thr);
+  if (MODE == 2) active = n_c >= 3;  // fewer rows leave the 6x6 normal equations singular
 
   // ---- computeTransformation (pose_estimator.cpp:908-930); evaluated by every lane of the group
-  T34 T;
-  if (active) {
+  if (MODE != 2 && active) {
     double mo[3] = {0, 0, 0}, mr[3] = {0, 0, 0};
     for (int i = 0; i < n_m; ++i)
       for (int k = 0; k < 3; ++k) {
@@ -1807,7 +1819,7 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
     for (int c = 0; c < 6; ++c) A[r][c] = 0;
   int iters = 0;
   bool running = active;
-  for (int it = 0; it < 500; ++it) {
+  for (int it = 0; it < (MODE == 1 ? 0 : 500); ++it) {
     if (!__any(running)) break;
     double J0[6] = {0, 0, 0, 0, 0, 0}, J1[6] = {0, 0, 0, 0, 0, 0}, e0 = 0, e1 = 0;
     if (running && has) {
@@ -1862,7 +1874,7 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
   if (!active) return;
   // pose_covariance_ = A.inverse() with the A of the last iteration (pose_estimator.cpp:790);
   // lane c of the group solves for column c
-  {
+  if (MODE != 1) {
     LDL6 F;
     ldl6_factor(A, F);
     if (l < 6) {
@@ -1886,12 +1898,76 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
 #undef s_q
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
                           mpe_result* results, uint32_t* corr_out, const uint32_t* corr_in, const double* nn_pred,
-                          double nn_tol, hipStream_t s) {
+                          double nn_tol, hipStream_t s, int mode) {
   if (n_frames <= 0) return hipSuccess;
   const int nu = sp.n_markers > 3 ? sp.n_markers - 3 : 1;
   const size_t lds = ((size_t)K3_FRAMES_PER_BLOCK * K3_GROUP * 3 * sp.n_markers + (size_t)2 * nu * 64) * sizeof(double);
-  hipLaunchKernelGGL(k3_tail, dim3((n_frames + K3_FRAMES_PER_BLOCK - 1) / K3_FRAMES_PER_BLOCK), dim3(64), lds, s, dets,
-                     hist, n_frames, sp, results, corr_out, corr_in, nn_pred, nn_tol);
+  const dim3 grid((n_frames + K3_FRAMES_PER_BLOCK - 1) / K3_FRAMES_PER_BLOCK);
+  if (mode == 1)
+    hipLaunchKernelGGL(k3_tail<1>, grid, dim3(64), lds, s, dets, hist, n_frames, sp, results, corr_out, corr_in, nn_pred,
+                       nn_tol);
+  else if (mode == 2)
+    hipLaunchKernelGGL(k3_tail<2>, grid, dim3(64), lds, s, dets, hist, n_frames, sp, results, corr_out, corr_in, nn_pred,
+                       nn_tol);
+  else
+    hipLaunchKernelGGL(k3_tail<0>, grid, dim3(64), lds, s, dets, hist, n_frames, sp, results, corr_out, corr_in, nn_pred,
+                       nn_tol);
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// Primitive batches — P3P::computePoses / P3P::solveQuartic (p3p.h:110-127) for n independent
+// problems, one lane each.  Not on the batch path (K2 / K3 inline the same device functions); they
+// exist for callers of the static primitives and for stage-level parity tests of mpe_p3p.h.
+// =============================================================================================
+__global__ __launch_bounds__(64) void k_p3p_batch(const double* __restrict__ fv, const double* __restrict__ wp, int n,
+                                                 double* __restrict__ sol, int* __restrict__ status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* f = fv + (size_t)i * 9;
+  const double* w = wp + (size_t)i * 9;
+  const V3 f0 = {f[0], f[1], f[2]}, f1 = {f[3], f[4], f[5]}, f2 = {f[6], f[7], f[8]};
+  const V3 w0 = {w[0], w[1], w[2]}, w1 = {w[3], w[4], w[5]}, w2 = {w[6], w[7], w[8]};
+  P3PCtx c;
+  if (!p3p_prepare(f0, f1, f2, w0, w1, w2, c)) {
+    status[i] = -1;  // collinear world points, p3p.cpp:77-80; solutions left untouched like the reference
+    return;
+  }
+  double* o = sol + (size_t)i * 48;
+  for (int k = 0; k < 4; ++k) {
+    M3 R;
+    V3 C;
+    p3p_solution(c, pick_root(c, k), R, C);
+    double* q = o + 12 * k;
+    q[0] = R.r0.x; q[1] = R.r0.y; q[2] = R.r0.z; q[3] = C.x;
+    q[4] = R.r1.x; q[5] = R.r1.y; q[6] = R.r1.z; q[7] = C.y;
+    q[8] = R.r2.x; q[9] = R.r2.y; q[10] = R.r2.z; q[11] = C.z;
+  }
+  status[i] = 0;
+}
+
+__global__ __launch_bounds__(64) void k_quartic_batch(const double* __restrict__ factors, int n, int variant,
+                                                     double* __restrict__ roots) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* a = factors + (size_t)i * 5;
+  double r[4];
+  if (variant == 1)
+    solve_quartic_lit(a[0], a[1], a[2], a[3], a[4], r);  // the voting kernel's division / sqrt sequences
+  else
+    solve_quartic(a[0], a[1], a[2], a[3], a[4], r);  // IEEE operators (validation kernel)
+  for (int k = 0; k < 4; ++k) roots[(size_t)i * 4 + k] = r[k];
+}
+
+hipError_t launch_p3p_batch(const double* fv, const double* wp, int n, double* sol, int* status, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_p3p_batch, dim3((n + 63) / 64), dim3(64), 0, s, fv, wp, n, sol, status);
+  return hipGetLastError();
+}
+
+hipError_t launch_quartic_batch(const double* factors, int n, int variant, double* roots, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_quartic_batch, dim3((n + 63) / 64), dim3(64), 0, s, factors, n, variant, roots);
   return hipGetLastError();
 }
 

@@ -178,11 +178,10 @@ void project(const mpe_tracker* t, const Mat4& T, const double* m, double& u, do
 }
 
 // LEDDetector::distortPoints for one point, float in / float out (led_detector.cpp:181-224)
-void distort(const mpe_tracker* t, float sx, float sy, float& ox, float& oy) {
-  const double fx = t->K[0], fy = t->K[4], cx = t->K[2], cy = t->K[5];
-  const size_t n = t->D.size();
-  const double k1 = n > 0 ? t->D[0] : 0, k2 = n > 1 ? t->D[1] : 0, p1 = n > 2 ? t->D[2] : 0, p2 = n > 3 ? t->D[3] : 0,
-               k3 = n > 4 ? t->D[4] : 0;
+void distort_point(const double K[9], const double* D, int nD, float sx, float sy, float& ox, float& oy) {
+  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  const double k1 = nD > 0 ? D[0] : 0, k2 = nD > 1 ? D[1] : 0, p1 = nD > 2 ? D[2] : 0, p2 = nD > 3 ? D[3] : 0,
+               k3 = nD > 4 ? D[4] : 0;
   const double x = ((double)sx - cx) / fx, y = ((double)sy - cy) / fy;
   const double r2 = x * x + y * y;
   double xc = x * (1. + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2);
@@ -194,34 +193,39 @@ void distort(const mpe_tracker* t, float sx, float sy, float& ox, float& oy) {
 }
 
 // LEDDetector::determineROI (led_detector.cpp:114-179)
-void determine_roi(mpe_tracker* t, int rows, int cols) {
+void determine_roi_impl(const double* px, int n, int rows, int cols, int border, const double K[9], const double* D,
+                        int nD, int roi[4]) {
   double x_min = std::numeric_limits<double>::infinity(), x_max = 0, y_min = x_min, y_max = 0;
-  for (int i = 0; i < n_markers(t); ++i) {
-    const double u = t->predicted_px[2 * i], v = t->predicted_px[2 * i + 1];
+  for (int i = 0; i < n; ++i) {
+    const double u = px[2 * i], v = px[2 * i + 1];
     if (u < x_min) x_min = u;
     if (u > x_max) x_max = u;
     if (v < y_min) y_min = v;
     if (v > y_max) y_max = v;
   }
   float ax, ay, bx, by;
-  distort(t, (float)x_min, (float)y_min, ax, ay);
-  distort(t, (float)x_max, (float)y_max, bx, by);
-  const int border = (int)t->p.roi_border_thickness;
+  distort_point(K, D, nD, (float)x_min, (float)y_min, ax, ay);
+  distort_point(K, D, nD, (float)x_max, (float)y_max, bx, by);
   const double x0 = std::max(0.0, std::min((double)cols, (double)ax - border));
   const double x1 = std::max(0.0, std::min((double)cols, (double)bx + border));
   const double y0 = std::max(0.0, std::min((double)rows, (double)ay - border));
   const double y1 = std::max(0.0, std::min((double)rows, (double)by + border));
   if (x1 - x0 < 1 || y1 - y0 < 1) {
-    t->roi[0] = 0;
-    t->roi[1] = 0;
-    t->roi[2] = cols;
-    t->roi[3] = rows;
+    roi[0] = 0;
+    roi[1] = 0;
+    roi[2] = cols;
+    roi[3] = rows;
   } else {
-    t->roi[0] = (int)x0;
-    t->roi[1] = (int)y0;
-    t->roi[2] = (int)(x1 - x0);
-    t->roi[3] = (int)(y1 - y0);
+    roi[0] = (int)x0;
+    roi[1] = (int)y0;
+    roi[2] = (int)(x1 - x0);
+    roi[3] = (int)(y1 - y0);
   }
+}
+
+void determine_roi(mpe_tracker* t, int rows, int cols) {
+  determine_roi_impl(t->predicted_px.data(), n_markers(t), rows, cols, (int)t->p.roi_border_thickness, t->K,
+                     t->D.empty() ? nullptr : t->D.data(), (int)t->D.size(), t->roi);
 }
 
 int detect(mpe_tracker* t, const uint8_t* img, int rows, int cols, size_t stride) {
@@ -326,6 +330,20 @@ int track(mpe_tracker* t) {
 }  // namespace
 
 extern "C" {
+
+int mpe_determine_roi(const double* pixel_positions, int n_points, int rows, int cols, int border_size, const double K[9],
+                      const double* D, int nD, int roi_xywh[4]) {
+  if (!pixel_positions || n_points <= 0 || !K || !roi_xywh || rows <= 0 || cols <= 0 || nD < 0 || (nD > 0 && !D))
+    return MPE_ERR_ARG;
+  determine_roi_impl(pixel_positions, n_points, rows, cols, border_size, K, D, nD, roi_xywh);
+  return MPE_OK;
+}
+
+int mpe_distort_points(const float* src_xy, float* dst_xy, int n, const double K[9], const double* D, int nD) {
+  if (n < 0 || (n > 0 && (!src_xy || !dst_xy)) || !K || nD < 0 || (nD > 0 && !D)) return MPE_ERR_ARG;
+  for (int i = 0; i < n; ++i) distort_point(K, D, nD, src_xy[2 * i], src_xy[2 * i + 1], dst_xy[2 * i], dst_xy[2 * i + 1]);
+  return MPE_OK;
+}
 
 int mpe_tracker_create(mpe_handle* h, mpe_tracker** out) {
   if (!h || !out) return MPE_ERR_ARG;
