@@ -42,6 +42,38 @@ typedef std::vector<Vector2d> List2DPoints;  //!< detections, undistorted pixels
 typedef std::vector<Vector4d> List4DPoints;  //!< marker positions, homogeneous
 typedef std::vector<std::array<unsigned, 2> > VectorXuPairs;  //!< rows (marker, detection), 1-based
 
+typedef Matrix<3, 4> Matrix3x4d;
+typedef Matrix<5, 1> Vector5d;
+typedef std::vector<unsigned> RowXu;  //!< dynamic row of unsigned
+
+//! Dynamic matrix of unsigned (the reference's MatrixXYu), row-major, (r,c) access like Eigen
+class MatrixXYu {
+ public:
+  MatrixXYu() : rows_(0), cols_(0) {}
+  MatrixXYu(size_t r, size_t c) : rows_(r), cols_(c), v_(r * c, 0u) {}
+  unsigned& operator()(size_t r, size_t c) { return v_[r * cols_ + c]; }
+  unsigned operator()(size_t r, size_t c) const { return v_[r * cols_ + c]; }
+  size_t rows() const { return rows_; }
+  size_t cols() const { return cols_; }
+  const unsigned* data() const { return v_.data(); }
+
+ private:
+  size_t rows_, cols_;
+  std::vector<unsigned> v_;
+};
+
+//! cv::Rect / cv::Size stand-ins
+struct Rect {
+  int x, y, width, height;
+  Rect() : x(0), y(0), width(0), height(0) {}
+  Rect(int x_, int y_, int w_, int h_) : x(x_), y(y_), width(w_), height(h_) {}
+};
+struct Size {
+  int width, height;
+  Size() : width(0), height(0) {}
+  Size(int w_, int h_) : width(w_), height(h_) {}
+};
+
 //! What the reference passes as cv::Mat (CV_8UC1): a view of a mono8 frame, never written.
 struct ImageView {
   const uint8_t* data;

@@ -19,7 +19,9 @@
 #include <vector>
 
 #include "datatypes.h"
+#include "led_detector.h"
 #include "mpe.h"
+#include "visualization.h"
 
 namespace monocular_pose_estimator {
 
@@ -46,11 +48,15 @@ class PoseEstimator {
   bool estimateBodyPose(const ImageView& image, double time_to_predict);
   void setBruteForceEveryFrame(bool on) { bruteforce_every_frame_ = on; }  //!< extension, see header comment
 
-  void setPredictedTime(double time) { predicted_time_ = time; }
+  void setPredictedTime(double time) {
+    predicted_time_ = time;
+    pushState();
+  }
   double getPredictedTime() { return predicted_time_; }
   void setPredictedPose(const Matrix4d& pose, double time) {
     predicted_pose_ = pose;
     predicted_time_ = time;
+    pushState();
   }
   Matrix4d getPredictedPose() { return predicted_pose_; }
   Matrix6d getPoseCovariance() { return pose_covariance_; }
@@ -69,9 +75,26 @@ class PoseEstimator {
   void setHistogramThreshold(unsigned t) { params_.histogram_threshold = t; }
   unsigned getHistogramThreshold();
 
-  //! initialise() + optimiseAndUpdatePose() on explicit image points (pose_estimator.h:425,749,773)
+  // ---- the step methods of the reference class (public there, uncalled from outside the class;
+  //      pose_estimator.h:425-801).  They operate on this object's state, which estimateBodyPose shares
+  //      with the library-side state machine, so the two styles can be mixed.
   void setImagePoints(const List2DPoints& points) { image_points_ = points; }
-  unsigned initialise();
+  void setPredictedPixels(const List2DPoints& points) { predicted_pixel_positions_ = points; }
+  List2DPoints getPredictedPixelPositions() { return predicted_pixel_positions_; }
+  void setCorrespondences(const VectorXuPairs& corrs) { correspondences_ = corrs; }
+  void predictPose(double time_to_predict);        //!< pose_estimator.cpp:232-244
+  void predictMarkerPositionsInImage();            //!< :270-276
+  void findCorrespondences();                      //!< :372-392
+  unsigned checkCorrespondences();                 //!< :394-542, 1 = valid (predicted pose = unrefined pose)
+  unsigned initialise();                           //!< :544-721, 1 = pose found (not yet refined)
+  void optimisePose();                             //!< :733-792, refines the predicted pose, sets the covariance
+  void updatePose();                               //!< :794-800
+  void optimiseAndUpdatePose(double& time_to_predict);                       //!< :802-812
+  void predictWithROI(double& time_to_predict, const ImageView& image);      //!< :814-829
+  void findCorrespondencesAndPredictPose(double& time_to_predict);           //!< :831-848
+  Rect getRegionOfInterest() const { return region_of_interest_; }
+  //! Visualization::createVisualizationImage on an interleaved 3-channel image (pose_estimator.cpp:44-48)
+  void augmentImage(ColorImageView& image);
 
   //! Batched extension: estimateBodyPose on a fresh estimator for each of n packed frames
   //! (host or device memory); results[i].status == 0 <=> estimateBodyPose returned true.
@@ -80,15 +103,22 @@ class PoseEstimator {
 
  private:
   void syncParams();
+  void pushState();  //!< this object's poses / times / counters -> library-side state machine
+  void pullState();  //!< and back
+  std::vector<double> flatImagePoints() const;
+  std::vector<uint32_t> flatCorrespondences() const;
   mpe_handle* handle_;
   mpe_tracker* tracker_;
   bool bruteforce_every_frame_;
   mpe_params params_;
   std::vector<double> markers_xyz_;
-  Matrix4d predicted_pose_;
+  Matrix4d current_pose_, previous_pose_, predicted_pose_;
   Matrix6d pose_covariance_;
-  double predicted_time_;
+  double current_time_, previous_time_, predicted_time_;
+  unsigned it_since_initialized_;
+  Rect region_of_interest_;
   List2DPoints image_points_;
+  List2DPoints predicted_pixel_positions_;
   VectorXuPairs correspondences_;
   std::vector<Point2f> distorted_detection_centers_;
   bool pose_updated_;

@@ -19,38 +19,10 @@
 #include <string>
 #include <vector>
 
+#include "marker_yaml.h"
 #include "monocular_pose_estimator_lib/pose_estimator.h"
 
 using namespace monocular_pose_estimator;
-
-static bool read_markers(const char* path, List4DPoints& out) {
-  std::ifstream in(path);
-  if (!in) return false;
-  std::string line;
-  double cur[3] = {0, 0, 0};
-  int have = 0;
-  while (std::getline(in, line)) {
-    const size_t hash = line.find('#');
-    if (hash != std::string::npos) line = line.substr(0, hash);
-    for (int k = 0; k < 3; ++k) {
-      const char key[3] = {"xyz"[k], ':', 0};
-      const size_t p = line.find(key);
-      if (p == std::string::npos) continue;
-      cur[k] = std::atof(line.c_str() + p + 2);
-      have |= 1 << k;
-    }
-    if (have == 7) {
-      Vector4d v;
-      v(0) = cur[0];
-      v(1) = cur[1];
-      v(2) = cur[2];
-      v(3) = 1.0;
-      out.push_back(v);
-      have = 0;
-    }
-  }
-  return !out.empty();
-}
 
 int main(int argc, char** argv) {
   const char *markers = 0, *frames = 0;

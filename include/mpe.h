@@ -113,6 +113,11 @@ int mpe_find_leds(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t 
 int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz,
                          int n_markers, const double K[9], const mpe_params* p, mpe_result* out,
                          uint32_t* hist, uint32_t* corr);
+/* PoseEstimator::initialise() alone (pose_estimator.h:749, pose_estimator.cpp:544-721): voting,
+ * correspondencesFromHistogram and checkCorrespondences WITHOUT the Gauss-Newton refinement — out->T is
+ * the pose of computeTransformation, out->cov zero.  Same arguments as mpe_solve_bruteforce. */
+int mpe_initialise(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
+                   const double K[9], const mpe_params* p, mpe_result* out, uint32_t* hist, uint32_t* corr);
 
 /* ≙ PoseEstimator::estimateBodyPose (pose_estimator.h:366, pose_estimator.cpp:62-96) on a FRESH
  * estimator per frame (it_since_initialized_ == 0: whole-image detection + brute-force
@@ -207,6 +212,33 @@ int mpe_tracker_reset(mpe_tracker* t); /* back to "not initialised" (the referen
 int mpe_tracker_estimate(mpe_tracker* t, const uint8_t* img, int rows, int cols, size_t stride_bytes,
                          double time_to_predict, mpe_result* out, int info[8]);
 
+/* The estimator's private state (pose_estimator.h:56-62, 74-79), for callers that drive the public
+ * step methods of the class (predictPose, findCorrespondences, ... — see compat/) between calls of
+ * mpe_tracker_estimate.  Poses row-major 4x4. */
+typedef struct mpe_tracker_state {
+  double current_pose[16], previous_pose[16], predicted_pose[16];
+  double pose_covariance[36];
+  double current_time, previous_time, predicted_time;
+  unsigned it_since_initialized;
+  int roi[4]; /* region_of_interest_ x, y, width, height */
+} mpe_tracker_state;
+int mpe_tracker_get_state(const mpe_tracker* t, mpe_tracker_state* st);
+int mpe_tracker_set_state(mpe_tracker* t, const mpe_tracker_state* st);
+
+/* Host arithmetic of the state machine, exported so that the facade and the tracker share ONE
+ * implementation (no device involved): predictPose (pose_estimator.cpp:232-244: constant-velocity
+ * extrapolation through logarithmMap / exponentialMap), exponentialMap (:962-994), logarithmMap
+ * (:996-1064), project2d for a list of marker positions (:251-276; markers n x 3, px n x 2). */
+int mpe_predict_pose(const double current_pose[16], const double previous_pose[16], double current_time,
+                     double previous_time, double time_to_predict, double predicted_pose[16]);
+int mpe_exponential_map(const double twist[6], double T[16]);
+int mpe_logarithm_map(const double T[16], double twist[6]);
+int mpe_project_points(const double T[16], const double* markers_xyz, int n, const double K[9], double* px);
+/* findCorrespondences (pose_estimator.cpp:372-392): corr gets up to n_markers rows (marker, detection),
+ * 1-based; returns the number of rows (>= 0) or MPE_ERR_ARG. */
+int mpe_find_correspondences(const double* predicted_px, int n_markers, const double* det_xy, int n_det,
+                             double nearest_neighbour_pixel_tolerance, uint32_t* corr);
+
 /* The image callback loop (MPENode::imageCallback -> estimateBodyPose, monocular_pose_estimator.cpp:
  * 125-190) over a recorded sequence: frame f at frames + f*frame_stride_bytes with time stamp
  * times[f].  out (optional) n_frames records, info (optional) n_frames x 8 ints as above.  Returns
@@ -219,6 +251,8 @@ int mpe_tracker_run_sequence(mpe_tracker* t, const uint8_t* frames, int n_frames
  * return the number available (or <0). */
 int mpe_tracker_get_correspondences(mpe_tracker* t, uint32_t* corr, int cap_rows);
 int mpe_tracker_get_image_points(mpe_tracker* t, double* xy, int cap_points);
+/* distorted_detection_centers_ of the last detection (what the overlay circles, pose_estimator.cpp:44-48) */
+int mpe_tracker_get_distorted_centers(mpe_tracker* t, float* xy, int cap_points);
 
 /* Stage-level batch entry points (used by the parity tests at every stage boundary). */
 /* detection only (a1): dets is a HOST array of n_frames records */

@@ -164,6 +164,50 @@ def distort_points(xy, K, D):
     return d
 
 
+def exponential_map(twist):
+    T = np.zeros(16)
+    load_library().mpe_exponential_map(_dp(_f64(twist).reshape(6)), _dp(T))
+    return T.reshape(4, 4)
+
+
+def logarithm_map(T):
+    xi = np.zeros(6)
+    load_library().mpe_logarithm_map(_dp(_f64(T).reshape(16)), _dp(xi))
+    return xi
+
+
+def predict_pose(current, previous, t_current, t_previous, t_predict):
+    """predictPose (pose_estimator.cpp:232-244), host arithmetic."""
+    out = np.zeros(16)
+    lib = load_library()
+    lib.mpe_predict_pose.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double,
+                                     C.POINTER(C.c_double)]
+    lib.mpe_predict_pose(_dp(_f64(current).reshape(16)), _dp(_f64(previous).reshape(16)), t_current, t_previous,
+                         t_predict, _dp(out))
+    return out.reshape(4, 4)
+
+
+def project_points(T, markers, K):
+    markers = _f64(markers).reshape(-1, 3)
+    px = np.zeros((len(markers), 2))
+    load_library().mpe_project_points(_dp(_f64(T).reshape(16)), _dp(markers), len(markers), _dp(_f64(K).reshape(9)),
+                                      _dp(px))
+    return px
+
+
+def find_correspondences(pred_px, det, tol):
+    pred = _f64(pred_px).reshape(-1, 2)
+    det = _f64(det).reshape(-1, 2)
+    corr = np.zeros((len(pred) + 1, 2), np.uint32)
+    lib = load_library()
+    lib.mpe_find_correspondences.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double,
+                                             C.c_void_p]
+    n = lib.mpe_find_correspondences(_dp(pred), len(pred), _dp(det), len(det), float(tol), C.c_void_p(corr.ctypes.data))
+    if n < 0:
+        raise MpeError("mpe_find_correspondences failed (%d)" % n)
+    return corr[:n].copy()
+
+
 def demo_params(**kw):
     """Parameter set of launch/demo.launch:12-22 (overridable by keyword)."""
     p = MpeParams()

@@ -638,8 +638,10 @@ int mpe_vote_batch(mpe_handle* h, const double* det_xy, const int* n_det, int n_
   return MPE_OK;
 }
 
-int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
-                         const double K[9], const mpe_params* p, mpe_result* out, uint32_t* hist, uint32_t* corr) {
+namespace {
+int solve_bruteforce_impl(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
+                          const double K[9], const mpe_params* p, mpe_result* out, uint32_t* hist, uint32_t* corr,
+                          int tail_mode) {
   if (!h || (!det_xy && n_det > 0) || !markers_xyz || !K || !p || !out || n_det < 0)
     return fail(h, MPE_ERR_ARG, "bad argument");
   if (n_det > MPE_MAX_DETECTIONS) return fail(h, MPE_ERR_UNSUPPORTED, "n_det > MPE_MAX_DETECTIONS");
@@ -662,7 +664,7 @@ int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const d
                             static_cast<uint32_t*>(h->hist.p), auto_splits(h, 1, n_markers), n_det, h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
                             static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), nullptr,
-                            nullptr, 0.0, h->stream));
+                            nullptr, 0.0, h->stream, tail_mode));
   uint32_t hh[MPE_HIST_STRIDE], hc[2 * MPE_MAX_MARKERS];
   HIP_TRY(h, hipMemcpyAsync(out, h->results.p, sizeof(mpe_result), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(hh, h->hist.p, sizeof(hh), hipMemcpyDeviceToHost, h->stream));
@@ -673,6 +675,17 @@ int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const d
       for (int c = 0; c < n_markers; ++c) hist[r * n_markers + c] = hh[r * MPE_MAX_MARKERS + c];
   if (corr) std::memcpy(corr, hc, sizeof(uint32_t) * 2 * n_markers);
   return MPE_OK;
+}
+}  // namespace
+
+int mpe_solve_bruteforce(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
+                         const double K[9], const mpe_params* p, mpe_result* out, uint32_t* hist, uint32_t* corr) {
+  return solve_bruteforce_impl(h, det_xy, n_det, markers_xyz, n_markers, K, p, out, hist, corr, 0);
+}
+
+int mpe_initialise(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,
+                   const double K[9], const mpe_params* p, mpe_result* out, uint32_t* hist, uint32_t* corr) {
+  return solve_bruteforce_impl(h, det_xy, n_det, markers_xyz, n_markers, K, p, out, hist, corr, 1);
 }
 
 namespace {

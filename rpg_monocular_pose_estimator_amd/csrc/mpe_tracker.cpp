@@ -136,6 +136,61 @@ void log_se3(const Mat4& T, double xi[6]) {
   }
 }
 
+// predictPose, pose_estimator.cpp:232-244
+Mat4 predict_pose(const Mat4& current, const Mat4& previous, double t_current, double t_previous, double t_predicted) {
+  double delta[6], dh[6];
+  log_se3(matmul(inverse(previous), current), delta);
+  for (int i = 0; i < 6; ++i) dh[i] = delta[i] / (t_current - t_previous) * (t_predicted - t_current);
+  return matmul(current, exp_se3(dh));
+}
+
+// project2d, pose_estimator.cpp:251-268: (K [I|0] * T) * point, evaluated left to right like the reference
+void project_point(const double K[9], const Mat4& T, const double* m, double& u, double& v) {
+  double t[3];
+  for (int i = 0; i < 3; ++i) {
+    double ct[4];
+    for (int j = 0; j < 4; ++j) {
+      double s = K[3 * i] * T.a[0][j];
+      s += K[3 * i + 1] * T.a[1][j];
+      s += K[3 * i + 2] * T.a[2][j];
+      s += 0.0 * T.a[3][j];
+      ct[j] = s;
+    }
+    double s = ct[0] * m[0];
+    s += ct[1] * m[1];
+    s += ct[2] * m[2];
+    s += ct[3] * 1.0;
+    t[i] = s;
+  }
+  u = t[0] / t[2];
+  v = t[1] / t[2];
+}
+
+// findCorrespondences, pose_estimator.cpp:372-392: nearest detection of every predicted marker pixel
+// (first minimum wins), kept if within the tolerance.  corr: rows (marker, detection), 1-based.
+int find_correspondences(const double* pred_px, int n_markers, const double* det_xy, int n_det, double tol,
+                         uint32_t* corr) {
+  int nc = 0;
+  for (int i = 0; i < n_markers; ++i) {
+    double best = std::numeric_limits<double>::infinity();
+    unsigned bj = 0;
+    for (int j = 0; j < n_det; ++j) {
+      const double du = pred_px[2 * i] - det_xy[2 * j], dv = pred_px[2 * i + 1] - det_xy[2 * j + 1];
+      const double d2 = du * du + dv * dv;
+      if (d2 < best) {
+        best = d2;
+        bj = (unsigned)j + 1;
+      }
+    }
+    if (std::sqrt(best) <= tol) {
+      corr[2 * nc] = (unsigned)i + 1;
+      corr[2 * nc + 1] = bj;
+      ++nc;
+    }
+  }
+  return nc;
+}
+
 }  // namespace
 
 struct mpe_tracker {
@@ -152,6 +207,7 @@ struct mpe_tracker {
   bool pose_updated = false;
   std::vector<double> predicted_px;  // n_markers x 2
   std::vector<double> det;           // detected_led_positions of the current call
+  std::vector<float> det_dist;       // distorted_detection_centers_ (always rewritten by a detection)
   std::vector<uint32_t> corr;        // rows (marker, detection)
   int n_corr = 0, gn_iterations = 0;
   bool used_bruteforce = false;
@@ -166,15 +222,8 @@ namespace {
 
 int n_markers(const mpe_tracker* t) { return (int)(t->markers.size() / 3); }
 
-// project2d, pose_estimator.cpp:251-268
 void project(const mpe_tracker* t, const Mat4& T, const double* m, double& u, double& v) {
-  double pc[3];
-  for (int i = 0; i < 3; ++i) pc[i] = T.a[i][0] * m[0] + T.a[i][1] * m[1] + T.a[i][2] * m[2] + T.a[i][3];
-  const double x = t->K[0] * pc[0] + t->K[1] * pc[1] + t->K[2] * pc[2];
-  const double y = t->K[3] * pc[0] + t->K[4] * pc[1] + t->K[5] * pc[2];
-  const double z = t->K[6] * pc[0] + t->K[7] * pc[1] + t->K[8] * pc[2];
-  u = x / z;
-  v = y / z;
+  project_point(t->K, T, m, u, v);
 }
 
 // LEDDetector::distortPoints for one point, float in / float out (led_detector.cpp:181-224)
@@ -235,6 +284,7 @@ int detect(mpe_tracker* t, const uint8_t* img, int rows, int cols, size_t stride
   int rc = mpe_find_leds(t->h, img, rows, cols, stride, t->roi[0], t->roi[1], t->roi[2], t->roi[3], &t->p, t->K,
                          t->D.empty() ? nullptr : t->D.data(), (int)t->D.size(), und, dist, MPE_MAX_DETECTIONS, &n);
   if (rc != MPE_OK) return rc;
+  t->det_dist.assign(dist, dist + 2 * n);
   if (n > 0) t->det.assign(und, und + 2 * n);  // pixel_positions is only rewritten when something was found
   return MPE_OK;
 }
@@ -249,6 +299,7 @@ int detect_and_try(mpe_tracker* t, const uint8_t* img, int rows, int cols, size_
                           t->predicted_px.data(), &d, t->fused_corr, &t->fused_res);
   if (rc != MPE_OK) return rc;
   if (d.status != 0) return d.status;
+  t->det_dist.assign(d.dist_xy, d.dist_xy + 2 * d.n);
   if (d.n > 0) t->det.assign(d.undist_xy, d.undist_xy + 2 * d.n);  // as in detect(): kept when nothing was found
   t->fused_valid = d.n >= 4;
   return MPE_OK;
@@ -295,25 +346,11 @@ int track(mpe_tracker* t) {
     }
     return bruteforce(t);
   }
-  // findCorrespondences: nearest detection of every predicted marker pixel, kept if <= tolerance
   const int nm = n_markers(t), nd = (int)t->det.size() / 2;
-  t->corr.clear();
-  for (int i = 0; i < nm; ++i) {
-    double best = std::numeric_limits<double>::infinity();
-    unsigned bj = 0;
-    for (int j = 0; j < nd; ++j) {
-      const double du = t->predicted_px[2 * i] - t->det[2 * j], dv = t->predicted_px[2 * i + 1] - t->det[2 * j + 1];
-      const double d2 = du * du + dv * dv;
-      if (d2 < best) {
-        best = d2;
-        bj = (unsigned)j + 1;
-      }
-    }
-    if (std::sqrt(best) <= t->p.nearest_neighbour_pixel_tolerance) {
-      t->corr.push_back((unsigned)i + 1);
-      t->corr.push_back(bj);
-    }
-  }
+  t->corr.assign(2 * (size_t)nm, 0u);
+  const int nc = find_correspondences(t->predicted_px.data(), nm, t->det.data(), nd,
+                                      t->p.nearest_neighbour_pixel_tolerance, t->corr.data());
+  t->corr.resize(2 * (size_t)nc);
   t->n_corr = (int)t->corr.size() / 2;
   mpe_result r;
   int rc = mpe_check_and_refine(t->h, t->det.data(), nd, t->markers.data(), nm, t->K, &t->p, t->corr.data(), t->n_corr,
@@ -342,6 +379,75 @@ int mpe_determine_roi(const double* pixel_positions, int n_points, int rows, int
 int mpe_distort_points(const float* src_xy, float* dst_xy, int n, const double K[9], const double* D, int nD) {
   if (n < 0 || (n > 0 && (!src_xy || !dst_xy)) || !K || nD < 0 || (nD > 0 && !D)) return MPE_ERR_ARG;
   for (int i = 0; i < n; ++i) distort_point(K, D, nD, src_xy[2 * i], src_xy[2 * i + 1], dst_xy[2 * i], dst_xy[2 * i + 1]);
+  return MPE_OK;
+}
+
+int mpe_exponential_map(const double twist[6], double T[16]) {
+  if (!twist || !T) return MPE_ERR_ARG;
+  const Mat4 m = exp_se3(twist);
+  std::memcpy(T, m.a, sizeof(m.a));
+  return MPE_OK;
+}
+
+int mpe_logarithm_map(const double T[16], double twist[6]) {
+  if (!twist || !T) return MPE_ERR_ARG;
+  Mat4 m;
+  std::memcpy(m.a, T, sizeof(m.a));
+  log_se3(m, twist);
+  return MPE_OK;
+}
+
+int mpe_predict_pose(const double current_pose[16], const double previous_pose[16], double current_time,
+                     double previous_time, double time_to_predict, double predicted_pose[16]) {
+  if (!current_pose || !previous_pose || !predicted_pose) return MPE_ERR_ARG;
+  Mat4 c, pr;
+  std::memcpy(c.a, current_pose, sizeof(c.a));
+  std::memcpy(pr.a, previous_pose, sizeof(pr.a));
+  const Mat4 out = predict_pose(c, pr, current_time, previous_time, time_to_predict);
+  std::memcpy(predicted_pose, out.a, sizeof(out.a));
+  return MPE_OK;
+}
+
+int mpe_project_points(const double T[16], const double* markers_xyz, int n, const double K[9], double* px) {
+  if (!T || !K || n < 0 || (n > 0 && (!markers_xyz || !px))) return MPE_ERR_ARG;
+  Mat4 m;
+  std::memcpy(m.a, T, sizeof(m.a));
+  for (int i = 0; i < n; ++i) project_point(K, m, markers_xyz + 3 * i, px[2 * i], px[2 * i + 1]);
+  return MPE_OK;
+}
+
+int mpe_find_correspondences(const double* predicted_px, int n_markers, const double* det_xy, int n_det,
+                             double nearest_neighbour_pixel_tolerance, uint32_t* corr) {
+  if (n_markers < 0 || n_det < 0 || (n_markers > 0 && (!predicted_px || !corr)) || (n_det > 0 && !det_xy))
+    return MPE_ERR_ARG;
+  return find_correspondences(predicted_px, n_markers, det_xy, n_det, nearest_neighbour_pixel_tolerance, corr);
+}
+
+int mpe_tracker_get_state(const mpe_tracker* t, mpe_tracker_state* st) {
+  if (!t || !st) return MPE_ERR_ARG;
+  std::memcpy(st->current_pose, t->current.a, sizeof(st->current_pose));
+  std::memcpy(st->previous_pose, t->previous.a, sizeof(st->previous_pose));
+  std::memcpy(st->predicted_pose, t->predicted.a, sizeof(st->predicted_pose));
+  std::memcpy(st->pose_covariance, t->cov, sizeof(st->pose_covariance));
+  st->current_time = t->t_current;
+  st->previous_time = t->t_previous;
+  st->predicted_time = t->t_predicted;
+  st->it_since_initialized = t->it_since_initialized;
+  for (int i = 0; i < 4; ++i) st->roi[i] = t->roi[i];
+  return MPE_OK;
+}
+
+int mpe_tracker_set_state(mpe_tracker* t, const mpe_tracker_state* st) {
+  if (!t || !st) return MPE_ERR_ARG;
+  std::memcpy(t->current.a, st->current_pose, sizeof(st->current_pose));
+  std::memcpy(t->previous.a, st->previous_pose, sizeof(st->previous_pose));
+  std::memcpy(t->predicted.a, st->predicted_pose, sizeof(st->predicted_pose));
+  std::memcpy(t->cov, st->pose_covariance, sizeof(st->pose_covariance));
+  t->t_current = st->current_time;
+  t->t_previous = st->previous_time;
+  t->t_predicted = st->predicted_time;
+  t->it_since_initialized = st->it_since_initialized;
+  for (int i = 0; i < 4; ++i) t->roi[i] = st->roi[i];
   return MPE_OK;
 }
 
@@ -404,6 +510,13 @@ int mpe_tracker_get_image_points(mpe_tracker* t, double* xy, int cap_points) {  
   return (int)t->det.size() / 2;
 }
 
+int mpe_tracker_get_distorted_centers(mpe_tracker* t, float* xy, int cap_points) {  // distorted_detection_centers_
+  if (!t || (!xy && cap_points > 0)) return MPE_ERR_ARG;
+  const int n = std::min<int>((int)t->det_dist.size() / 2, cap_points);
+  for (int i = 0; i < 2 * n; ++i) xy[i] = t->det_dist[i];
+  return (int)t->det_dist.size() / 2;
+}
+
 int mpe_tracker_estimate(mpe_tracker* t, const uint8_t* img, int rows, int cols, size_t stride_bytes, double time,
                          mpe_result* out, int info[8]) {
   if (!t || !img) return MPE_ERR_ARG;
@@ -426,10 +539,7 @@ int mpe_tracker_estimate(mpe_tracker* t, const uint8_t* img, int rows, int cols,
     if (t->it_since_initialized >= 2) {
       // predictPose (:232-244)
       t->t_predicted = time;
-      double delta[6], dh[6];
-      log_se3(matmul(inverse(t->previous), t->current), delta);
-      for (int i = 0; i < 6; ++i) dh[i] = delta[i] / (t->t_current - t->t_previous) * (t->t_predicted - t->t_current);
-      t->predicted = matmul(t->current, exp_se3(dh));
+      t->predicted = predict_pose(t->current, t->previous, t->t_current, t->t_previous, t->t_predicted);
     } else {
       t->t_predicted = time;
     }

@@ -156,3 +156,76 @@ def test_host_side_roi_primitives_match_oracle():
     assert np.array_equal(mpe.distort_points(pts, K, D), orc.distort_points(pts, K, D))
     # degenerate box (all predicted pixels far outside) -> whole image
     assert mpe.determine_roi([[5000.0, 5000.0]], 480, 752, 20, K, D) == (0, 0, 752, 480)
+
+
+def _facade_combos(n, k):
+    exe = os.path.join(ROOT, "compat", "facade_selftest")
+    out = subprocess.run([exe, "combos", str(n), str(k)], capture_output=True, text=True, check=True).stdout
+    a, b, c = out.split("--\n")
+    parse = lambda t: np.array([[int(v) for v in ln.split()] for ln in t.strip().splitlines()], np.uint32)
+    return parse(a), parse(b), [int(v) for v in c.split()]
+
+
+def test_facade_combinations_tables():
+    """compat Combinations (host tables, reference combinations.cpp): K = 3 rows equal the oracle's tables in
+    order; other K: every subset / arrangement exactly once, combinations lexicographic; 32-bit factorial."""
+    import itertools
+    import oracle
+    oracle.build()
+    from oracle import binding as orc
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "compat"), "facade_selftest"])
+    for n in range(4, 9):
+        comb, perm, nums = _facade_combos(n, 3)
+        assert np.array_equal(comb, orc.combinations3(n)), n
+        assert np.array_equal(perm, orc.permutations3(n)), n
+        assert nums[0] == orc.num_combinations(n, 3)
+    for n, k in [(5, 2), (6, 4), (4, 4), (5, 1), (7, 5)]:
+        comb, perm, nums = _facade_combos(n, k)
+        comb = comb.reshape(-1, k)
+        perm = perm.reshape(-1, k)
+        assert [tuple(r) for r in comb] == list(itertools.combinations(range(1, n + 1), k))
+        assert sorted(tuple(r) for r in perm) == sorted(itertools.permutations(range(1, n + 1), k))
+    assert _facade_combos(13, 3)[2][2] == 1932053504   # 13! mod 2^32, the reference's wrap-around
+
+
+def test_host_side_state_machine_math_matches_oracle():
+    """The host arithmetic of the tracking state machine that libmpe_hip.so exports (exponentialMap,
+    logarithmMap, predictPose, project2d, findCorrespondences) against the oracle — no device needed."""
+    import oracle
+    oracle.build()
+    from oracle import binding as orc
+    from rpg_monocular_pose_estimator_amd import synth
+    rng = np.random.default_rng(17)
+    K, _ = synth.camera_for(480, 752)
+    for trial in range(200):
+        tw = rng.normal(size=6) * rng.choice([1e-9, 1e-3, 0.3, 2.0])
+        if trial == 0:
+            tw[:] = 0
+        if trial == 1:
+            tw[3:] = 0
+        T = orc.exponential_map(tw)
+        assert np.array_equal(mpe.exponential_map(tw), T), trial
+        assert np.array_equal(mpe.logarithm_map(T), orc.logarithm_map(T)), trial
+        # predictPose = current * exp(log(previous^-1 current) / (tc - tp) * (t - tc)), assembled from the oracle's maps
+        prev = orc.exponential_map(rng.normal(size=6) * 0.2)
+        cur = prev @ orc.exponential_map(rng.normal(size=6) * 0.02)
+        tp, tc, t = 0.1, 0.15, 0.22
+        delta = orc.logarithm_map(np.linalg.inv(prev) @ cur)
+        want = cur @ orc.exponential_map(delta / (tc - tp) * (t - tc))
+        got = mpe.predict_pose(cur, prev, tc, tp, t)
+        assert np.allclose(got, want, rtol=0, atol=1e-12), trial
+        Tm = orc.exponential_map(np.r_[rng.uniform(-0.2, 0.2, 2), rng.uniform(0.8, 2), rng.normal(size=3) * 0.3])
+        px = mpe.project_points(Tm, synth.M5, K)
+        for i, m in enumerate(synth.M5):
+            assert np.array_equal(px[i], orc.project2d(np.r_[m, 1.0], Tm, K))
+        det = px[rng.permutation(5)[:int(rng.integers(0, 6))]] + rng.normal(0, 3.0, (1, 2))
+        corr = mpe.find_correspondences(px, det, 7.0)
+        want_c = []
+        for i in range(5):
+            if len(det) == 0:
+                break
+            d = np.sqrt(((det - px[i]) ** 2).sum(axis=1))
+            j = int(np.argmin(d))
+            if d[j] <= 7.0:
+                want_c.append((i + 1, j + 1))
+        assert [tuple(r) for r in corr] == want_c, trial

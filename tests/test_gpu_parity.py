@@ -611,3 +611,26 @@ def test_check_and_optimise_stage_entry_points(hip, orc):
     assert n >= 6
     # fewer than 3 correspondences: no refinement
     assert hip.optimise_pose(und, d["markers"], d["K"], Ph, r["corr"][:2], np.eye(4))["status"] == 1
+
+
+@pytest.mark.gpu
+def test_facade_step_methods_static_primitives_and_overlay(tmp_path):
+    """compat/facade_selftest steps: estimateBodyPose vs the same state machine driven through the class's
+    public step methods (initialise, checkCorrespondences, optimisePose, predictWithROI, ...) and the static
+    LEDDetector / P3P classes; then the overlay.  The binary checks equality itself."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "compat")])
+    d = synth.make_sequence("C2", 30, seed=77, dropout=(12, 13))
+    raw = str(tmp_path / "seq.raw")
+    d["frames"].tofile(raw)
+    yaml = str(tmp_path / "markers.yaml")
+    with open(yaml, "w") as fh:
+        fh.write("marker_positions:\n")
+        for m in d["markers"]:
+            fh.write("  - x: %.17g\n    y: %.17g\n    z: %.17g\n" % tuple(m))
+    out = subprocess.run([os.path.join(root, "compat", "facade_selftest"), "steps", "--markers", yaml, "--frames", raw,
+                          "--rows", str(d["rows"]), "--cols", str(d["cols"]), "--dt", "0.02"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0 and "selftest ok" in out.stdout, (out.returncode, out.stdout[-800:], out.stderr[-800:])
