@@ -3,6 +3,9 @@
 //   facade_selftest combos N K
 //       prints Combinations::combinationsNoReplacement(N,K), a line "--", then
 //       Combinations::permutationsNoReplacement(N,K) (host only, no GPU needed)
+//   facade_selftest message < 16+36 doubles per line
+//       pose (row-major 4x4) + covariance (row-major 6x6) -> "px py pz qx qy qz qw c0 .. c35" per line, the
+//       PoseWithCovarianceStamped fields as compat/ros/message_conversions.h packs them (host only)
 //   facade_selftest steps --markers <yaml> --frames <file.raw> --rows R --cols C [--dt s]
 //       object A: estimateBodyPose per frame.  object B: the same state machine written out with the
 //       class's public step methods exactly as pose_estimator.cpp:62-147 strings them together
@@ -16,6 +19,7 @@
 #include <vector>
 
 #include "marker_yaml.h"
+#include "ros/message_conversions.h"
 #include "monocular_pose_estimator_lib/combinations.h"
 #include "monocular_pose_estimator_lib/p3p.h"
 #include "monocular_pose_estimator_lib/pose_estimator.h"
@@ -112,6 +116,21 @@ int main(int argc, char** argv) {
     std::printf("--\n%u %u %u\n", Combinations::numCombinations(N, K), Combinations::numPermutations(N, K),
                 Combinations::factorial((int)N));
     return 0;
+  }
+  if (argc >= 2 && !std::strcmp(argv[1], "message")) {
+    for (;;) {
+      Matrix4d T;
+      Matrix6d cov;
+      for (int i = 0; i < 16; ++i)
+        if (std::scanf("%lf", &T(i)) != 1) return 0;
+      for (int i = 0; i < 36; ++i)
+        if (std::scanf("%lf", &cov(i)) != 1) return 1;
+      const PoseMessageFields m = poseToMessageFields(T, cov);
+      std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %.17g", m.position[0], m.position[1], m.position[2],
+                  m.orientation[0], m.orientation[1], m.orientation[2], m.orientation[3]);
+      for (int i = 0; i < 36; ++i) std::printf(" %.17g", m.covariance[i]);
+      std::printf("\n");
+    }
   }
   if (argc < 2 || std::strcmp(argv[1], "steps")) {
     std::fprintf(stderr, "usage: facade_selftest combos N K | steps --markers y --frames f --rows R --cols C\n");

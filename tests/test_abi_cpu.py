@@ -229,3 +229,48 @@ def test_host_side_state_machine_math_matches_oracle():
             if d[j] <= 7.0:
                 want_c.append((i + 1, j + 1))
         assert [tuple(r) for r in corr] == want_c, trial
+
+
+def test_ros_message_conversions():
+    """compat/ros/message_conversions.h (the ROS-independent half of the node glue): position = T(0:3,3),
+    orientation = Eigen::Quaterniond(R) — checked against scipy incl. rotations near pi where the trace is
+    negative and each of the three diagonal branches is taken — covariance row-major."""
+    from scipy.spatial.transform import Rotation
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "compat"), "facade_selftest"])
+    rng = np.random.default_rng(9)
+    rows, Ts, covs = [], [], []
+    for trial in range(120):
+        if trial < 60:
+            R = Rotation.from_rotvec(rng.normal(size=3) * rng.uniform(0, 1.5)).as_matrix()
+        else:  # angle close to pi about an axis dominated by x, y or z
+            ax = np.eye(3)[trial % 3] + 0.2 * rng.normal(size=3)
+            ax /= np.linalg.norm(ax)
+            R = Rotation.from_rotvec(ax * (np.pi - rng.uniform(0, 0.3))).as_matrix()
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = rng.normal(size=3)
+        cov = rng.normal(size=(6, 6))
+        Ts.append(T)
+        covs.append(cov)
+        rows.append(" ".join(repr(float(v)) for v in np.r_[T.ravel(), cov.ravel()]))
+    out = subprocess.run([os.path.join(ROOT, "compat", "facade_selftest"), "message"], input="\n".join(rows) + "\n",
+                         capture_output=True, text=True, check=True).stdout
+    got = np.array([[float(v) for v in ln.split()] for ln in out.strip().splitlines()])
+    assert got.shape == (120, 43)
+    branches = set()
+    for T, cov, g in zip(Ts, covs, got):
+        assert np.array_equal(g[:3], T[:3, 3])
+        q = g[3:7]
+        want = Rotation.from_matrix(T[:3, :3]).as_quat()   # x y z w, sign free
+        assert min(np.abs(q - want).max(), np.abs(q + want).max()) < 1e-12
+        assert abs(np.linalg.norm(q) - 1) < 1e-12
+        tr = np.trace(T[:3, :3])
+        if tr > 0:
+            assert q[3] > 0
+            branches.add("w")
+        else:
+            i = int(np.argmax(np.diag(T[:3, :3])))
+            assert q[i] > 0          # Eigen's rule: the component of the largest diagonal element is the positive root
+            branches.add("xyz"[i])
+        assert np.array_equal(g[7:], cov.ravel())
+    assert branches == {"w", "x", "y", "z"}
