@@ -84,7 +84,11 @@ def main():
     torch.cuda.synchronize()
 
     h = mpe.Handle(local_rank)
-    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    # one explicit (non-default) stream carries the library's kernels AND the pose gather: the collective is then
+    # ordered after the tail kernel by the stream itself (torch's legacy default stream is 0, which the library
+    # reads as "use the handle's own stream" and which would not be ordered with it)
+    work_stream = torch.cuda.Stream(device=dev)
+    h.set_stream(work_stream.cuda_stream)
     P = mpe.demo_params()
     h.set_option("pipeline", args.pipeline)
     h.set_option("pipeline_mode", args.pipeline_mode)
@@ -92,9 +96,10 @@ def main():
         h.set_option("k1a_dummy_lds", args.k1a_lds)
 
     def step():
-        h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
-        if world > 1:
-            parallel.gather_records(results, world, out=gathered)
+        with torch.cuda.stream(work_stream):
+            h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
+            if world > 1:
+                parallel.gather_records(results, world, out=gathered)
 
     def barrier():
         if world > 1:

@@ -94,7 +94,8 @@ void mpe_default_params(mpe_params* p);
 int mpe_create(mpe_handle** out, int device);
 void mpe_destroy(mpe_handle* h);
 const char* mpe_last_error(const mpe_handle* h);
-/* Use an existing hipStream_t (e.g. torch's current stream); NULL restores the handle's own. */
+/* Use an existing hipStream_t (e.g. a torch.cuda.Stream); NULL restores the handle's own non-blocking
+ * stream (it does NOT select the legacy default stream). */
 int mpe_set_stream(mpe_handle* h, void* hip_stream);
 void* mpe_get_stream(mpe_handle* h);
 int mpe_synchronize(mpe_handle* h);
@@ -132,7 +133,12 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
 /* Fully asynchronous variant for device-resident pipelines: frames AND results are device
  * pointers, nothing is copied, the call only enqueues kernels on the handle's stream.
  * frames must be 16-byte aligned with cols % 16 == 0, stride_bytes == cols and
- * frame_stride_bytes == rows*cols (the packed layout). */
+ * frame_stride_bytes == rows*cols (the packed layout).
+ * Ordering: the call behaves like ONE operation on the handle's stream — its kernels start after
+ * everything enqueued on that stream before the call (large batches fork onto internal side
+ * streams and join back) and d_results is complete for anything enqueued on it afterwards.  Work
+ * on OTHER streams, including the legacy default stream 0, is not ordered with it: share a real
+ * stream through mpe_set_stream (a NULL argument means the handle's own stream, NOT stream 0). */
 int mpe_estimate_batch_device(mpe_handle* h, const uint8_t* d_frames, int n_frames, int rows,
                               int cols, const double* markers_xyz, int n_markers,
                               const double K[9], const double* D, int nD, const mpe_params* p,
