@@ -88,7 +88,8 @@ def main():
     # ordered after the tail kernel by the stream itself (torch's legacy default stream is 0, which the library
     # reads as "use the handle's own stream" and which would not be ordered with it)
     work_stream = torch.cuda.Stream(device=dev)
-    h.set_stream(work_stream.cuda_stream)
+    if os.environ.get("MPE_BENCH_OWN_STREAM") != "1":
+        h.set_stream(work_stream.cuda_stream)
     P = mpe.demo_params()
     h.set_option("pipeline", args.pipeline)
     h.set_option("pipeline_mode", args.pipeline_mode)
@@ -196,6 +197,7 @@ def main():
                                                                       cfg["n_distractors"]),
                        "frames_per_gpu_per_step": B, "frames_resident_in_hbm": True,
                        "streams_per_gpu": args.pipeline,
+                       "side_streams_concurrent": h.get_option("streams_concurrent"),
                        "parallelism": "frames sharded over %d GPU(s), all_gather of pose records" % world},
             "poses_found_frac": n_pose / B,
             "kernel_ms": kavg,

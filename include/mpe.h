@@ -287,6 +287,10 @@ int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
  * kernel, 0 = auto), "pipeline" (max sub-batches of >= 8192 frames run as a two-stream software
  * pipeline, default 8, 1 = off). */
 int mpe_set_option(mpe_handle* h, const char* name, int value);
+/* Read an option back.  Also "streams_concurrent": 1 once the library has verified (spin-kernel probe at
+ * the first large batch) that its two pipeline side streams execute concurrently, 0 if no concurrent
+ * pair was found (the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues), -1 not probed yet. */
+int mpe_get_option(mpe_handle* h, const char* name, int* value);
 
 /* library / device introspection */
 int mpe_device_count(void);

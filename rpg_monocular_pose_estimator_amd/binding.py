@@ -262,6 +262,11 @@ class Handle:
     def synchronize(self):
         self._check(self._lib.mpe_synchronize(self._h), "mpe_synchronize")
 
+    def get_option(self, name):
+        v = C.c_int(0)
+        self._check(self._lib.mpe_get_option(self._h, name.encode(), C.byref(v)), "mpe_get_option")
+        return v.value
+
     def set_option(self, name, value):
         self._check(self._lib.mpe_set_option(self._h, name.encode(), int(value)), "mpe_set_option")
 

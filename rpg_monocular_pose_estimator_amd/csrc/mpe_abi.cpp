@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -60,6 +61,8 @@ struct mpe_handle {
                      // of sub-batch i (+10-13 % at >= 64k frames per call; 1 = off)
   static const int kMaxSub = 16;
   hipStream_t sub_stream[kMaxSub] = {};
+  bool streams_probed = false;  // sub_stream[0] / [1] verified to execute concurrently
+  int streams_concurrent = -1;  // result of the probe: 1 yes, 0 no pair found, -1 not probed
   hipEvent_t sub_done[kMaxSub] = {};
   hipEvent_t vote_done[kMaxSub] = {};
   hipEvent_t scan_done[kMaxSub] = {};
@@ -261,6 +264,65 @@ int run_back(mpe_handle* h, hipStream_t st, bool prof, int n_frames, const Solve
   return MPE_OK;
 }
 
+// The two-stream software pipeline only pays when its side streams sit on DIFFERENT hardware queues.  The
+// runtime multiplexes streams onto a few queues (GPU_MAX_HW_QUEUES, default 4) in an order that depends on
+// which other streams the process created (e.g. torch's stream pool), so two fresh streams can end up
+// serialised.  Probe once per handle: a 1 ms spin kernel on each candidate — concurrent streams finish both
+// in ~1 ms, serialised ones in ~2 ms — and keep the first pair that overlaps.
+int pick_concurrent_streams(mpe_handle* h) {
+  if (h->streams_probed) return MPE_OK;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // once per handle: time the probe on an idle device
+  const int kCandidates = 8;
+  hipStream_t cand[kCandidates] = {};
+  for (int i = 0; i < kCandidates; ++i) HIP_TRY(h, hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking));
+  const unsigned long long ticks = 100000;  // 1 ms at 100 MHz
+  auto both_ms = [&](hipStream_t a, hipStream_t b, double& ms) -> hipError_t {
+    hipError_t e = hipStreamSynchronize(a);
+    if (e != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(b)) != hipSuccess) return e;
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((e = launch_spin(ticks, a)) != hipSuccess) return e;
+    if ((e = launch_spin(ticks, b)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(a)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(b)) != hipSuccess) return e;
+    ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return hipSuccess;
+  };
+  double warm = 0;
+  HIP_TRY(h, both_ms(cand[0], cand[0], warm));  // first launch of the kernel (code object load) is not timed
+  int ia = -1, ib = -1;
+  for (int i = 0; i < kCandidates && ia < 0; ++i)
+    for (int j = i + 1; j < kCandidates; ++j) {
+      double ms = 0;
+      HIP_TRY(h, both_ms(cand[i], cand[j], ms));
+      if (ms < 1.6) {
+        ia = i;
+        ib = j;
+        break;
+      }
+    }
+  h->streams_concurrent = ia >= 0 ? 1 : 0;
+  if (ia < 0) {
+    ia = 0;
+    ib = 1;
+  }
+  int ic = -1;
+  for (int i = 0; i < kCandidates; ++i)
+    if (i != ia && i != ib) {
+      ic = i;
+      break;
+    }
+  for (int i = 0; i < 3; ++i)
+    if (h->sub_stream[i]) (void)hipStreamDestroy(h->sub_stream[i]);
+  h->sub_stream[0] = cand[ia];
+  h->sub_stream[1] = cand[ib];
+  h->sub_stream[2] = cand[ic];
+  for (int i = 0; i < kCandidates; ++i)
+    if (i != ia && i != ib && i != ic) (void)hipStreamDestroy(cand[i]);
+  h->streams_probed = true;
+  return MPE_OK;
+}
+
 int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const FrameGeom& g, const DetectParams& dp,
                  const SolveParams* sp, mpe_detections* d_dets, uint32_t* d_hist, mpe_result* d_results,
                  uint32_t* d_corr) {
@@ -298,8 +360,10 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   const size_t fw_per = flag_words(frame_bytes * per);
   HIP_TRY(h, h->flags.reserve(fw_per * nsub * 8));
   HIP_TRY(h, h->work.reserve((size_t)2 * (per + 1) * nsub * sizeof(int)));
-  for (int i = 0; i < 3; ++i)
-    if (!h->sub_stream[i]) HIP_TRY(h, hipStreamCreateWithFlags(&h->sub_stream[i], hipStreamNonBlocking));
+  {
+    const int rc = pick_concurrent_streams(h);
+    if (rc) return rc;
+  }
   if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
   hipStream_t sa = h->sub_stream[0], sb = h->sub_stream[1], sc = h->sub_stream[2];
   const int mode = h->pipeline_mode;
@@ -515,6 +579,18 @@ int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch) 
 }
 
 // tuning knobs (not part of the reference surface; used by bench / tests)
+int mpe_get_option(mpe_handle* h, const char* name, int* value) {
+  if (!h || !name || !value) return MPE_ERR_ARG;
+  const std::string n(name);
+  if (n == "pipeline") *value = h->pipeline;
+  else if (n == "pipeline_mode") *value = h->pipeline_mode;
+  else if (n == "lds_budget") *value = h->lds_budget;
+  else if (n == "vote_splits") *value = h->vote_splits;
+  else if (n == "streams_concurrent") *value = h->streams_concurrent;
+  else return fail(h, MPE_ERR_ARG, "unknown option");
+  return MPE_OK;
+}
+
 int mpe_set_option(mpe_handle* h, const char* name, int value) {
   if (!h || !name) return MPE_ERR_ARG;
   if (!std::strcmp(name, "lds_budget")) {

@@ -63,6 +63,7 @@ hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int 
 hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int n_frames, int roi_x,
                          int roi_y, int roi_w, int roi_h, uint8_t* dst, int dst_pitch, hipStream_t s);
 
+hipError_t launch_spin(unsigned long long ticks_100mhz, hipStream_t s);
 hipError_t launch_p3p_batch(const double* fv, const double* wp, int n, double* sol, int* status, hipStream_t s);
 hipError_t launch_quartic_batch(const double* factors, int n, int variant, double* roots, hipStream_t s);
 

@@ -99,6 +99,11 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
   const size_t max_blocks = 256 * K1A_BLOCKS_PER_CU;  // 256 CUs x blocks per CU, grid-stride beyond
   if (blocks > max_blocks) blocks = max_blocks;
   const size_t dummy_lds = g_k1a_dummy_lds >= 0 ? (size_t)g_k1a_dummy_lds : (co_resident ? 40000 : 0);
+  if (dummy_lds > 65536) {  // tuning experiments only: more than the default dynamic-LDS limit
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)dummy_lds);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL(k1a_scan, dim3((unsigned)blocks), dim3(256), dummy_lds, s,
                      reinterpret_cast<const uint4*>(frames), (u64*)flags, n_seg, add);
   return hipGetLastError();
@@ -1957,6 +1962,23 @@ __global__ __launch_bounds__(64) void k_quartic_batch(const double* __restrict__
   else
     solve_quartic(a[0], a[1], a[2], a[3], a[4], r);  // IEEE operators (validation kernel)
   for (int k = 0; k < 4; ++k) roots[(size_t)i * 4 + k] = r[k];
+}
+
+// one wave that keeps a CU slot busy for `ticks` of the constant-rate counter (100 MHz): used once per
+// handle to find two side streams that really run concurrently (see pick_concurrent_streams)
+__global__ void k_spin(unsigned long long ticks, unsigned long long* sink) {
+  const unsigned long long t0 = wall_clock64();
+  unsigned long long t = t0;
+  while (t - t0 < ticks) {
+    __builtin_amdgcn_s_sleep(32);
+    t = wall_clock64();
+  }
+  if (sink && threadIdx.x == 0) *sink = t - t0;
+}
+
+hipError_t launch_spin(unsigned long long ticks, hipStream_t s) {
+  hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, ticks, (unsigned long long*)nullptr);
+  return hipGetLastError();
 }
 
 hipError_t launch_p3p_batch(const double* fv, const double* wp, int n, double* sol, int* status, hipStream_t s) {

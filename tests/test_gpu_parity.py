@@ -670,7 +670,9 @@ def test_full_size_batch_properties(orc):
         stream.synchronize()
         return out
 
+    assert h.get_option("streams_concurrent") == -1
     piped = run(frames, 8)
+    assert h.get_option("streams_concurrent") in (0, 1)   # probed at the first pipelined call (1 = overlap verified)
     plain = run(frames, 1)
     assert torch.equal(piped, plain)
     flipped = torch.flip(frames, dims=[0]).contiguous()
