@@ -505,16 +505,17 @@ __device__ __forceinline__ void write_detections(const float* kx, const float* k
 }
 
 // =============================================================================================
-// K1b fast path: one wave per frame, everything in ~17 KB of LDS.
+// K1b fast path.  A wave works on C::FRAMES frames: the front phases (A-D: flag bits -> bands ->
+// islands -> thresholded pixels -> blurred mask bitmaps) run frame after frame with all 64 lanes and
+// share one pixel pool (which also hosts the front phases' scratch lists); the contour phase (E), where
+// one lane owns one island, runs over the islands of all the wave's frames at once.
+// Two capacity tiers, tried in turn (device work-lists chain them): K1bSmall covers the 4-6 LED case in
+// 9.6 KB per wave (16 waves per CU), K1bLarge ~16 blobs per frame.
+// Measured on MI355X (16 384 C2 frames, kernel alone): 0.34 ms with the former 14.4 KB layout ->
+// 0.26 ms; FRAMES = 2 / 4 / 8 (busier lanes in phase E, but 10 / 18 / 34 KB per wave) 0.25 / 0.29 /
+// 0.47 ms alone and slower than FRAMES = 1 when the kernel shares the chip with the tail kernel, so
+// one frame per wave stays the default.
 // =============================================================================================
-#define K1B_SEG_CAP 512     // bright segments per frame
-#define K1B_BAND_CAP 32     // bands per frame
-#define K1B_ISL_CAP 32      // islands per frame
-// LDS pools (thresholded pixels / bitmap words for all islands of a frame) come in two sizes,
-// tried in turn (device work-lists chain the tiers): <PIX_POOL, BM_POOL> = <4096, 208> keeps
-// 12 waves per CU for the 4-6 LED case, <12288, 704> covers ~16 blobs per frame at 4 waves per CU.
-#define K1B_KEPT_CAP 64     // blobs that pass the shape filter (> MPE_MAX_DETECTIONS -> status)
-
 struct Island {
   short ylo, yhi;      // band rows
   short clo, chi;      // output segment columns
@@ -523,26 +524,65 @@ struct Island {
   int stage_end, blur_end;  // inclusive prefix sums of the flattened work-item counts
 };
 
-template <int K1B_PIX_POOL, int K1B_BM_POOL>
-__device__ __forceinline__ void k1b_frame(const int f, const uint8_t* __restrict__ frames,
-                                          const u64* __restrict__ flags, const FrameGeom& g, const DetectParams& dp,
-                                          mpe_detections* __restrict__ dets, int* __restrict__ worklist) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_pix[K1B_PIX_POOL];
-  __shared__ u64 s_nz[K1B_BM_POOL + 1], s_pm[K1B_BM_POOL + 1], s_ng[K1B_BM_POOL + 1];
-  __shared__ unsigned s_seg[K1B_SEG_CAP];  // y << 16 | segment column
-  __shared__ u64 s_rowact[64];
-  __shared__ u64 s_colocc[K1B_BAND_CAP][4];
-  __shared__ short s_bandlo[K1B_BAND_CAP], s_bandhi[K1B_BAND_CAP];
-  __shared__ Island s_isl[K1B_ISL_CAP];
-  __shared__ float s_kx[K1B_KEPT_CAP], s_ky[K1B_KEPT_CAP];
-  __shared__ unsigned s_kkey[K1B_KEPT_CAP];
-  __shared__ int s_nseg, s_nkept, s_over, s_nband, s_nisl;
-  __shared__ int s_taps[MPE_MAX_KSIZE];  // (taking the address of the by-value kernel argument would
-                                         //  make the compiler copy all of it to scratch)
+// capacities: thresholded-pixel pool [bytes], bitmap pool [u64 words per bitmap], bright segments, bands,
+// islands, blobs kept per frame, frames per wave
+#ifndef K1B_SMALL_FRAMES
+#define K1B_SMALL_FRAMES 1
+#endif
+#ifndef K1B_SMALL_PIX
+#define K1B_SMALL_PIX 4096
+#endif
+#ifndef K1B_SMALL_BM
+#define K1B_SMALL_BM 208
+#endif
+struct K1bSmall {
+  enum { PIX = K1B_SMALL_PIX, BM = K1B_SMALL_BM, SEG = 64, BAND = 8, ISL = 8, KEPT = 16, FRAMES = K1B_SMALL_FRAMES };
+};
+struct K1bLarge {
+  enum { PIX = 12288, BM = 704, SEG = 512, BAND = 32, ISL = 32, KEPT = 64, FRAMES = 1 };
+};
 
+template <class C>
+struct K1bWaveLds {  // shared by the frames of a wave (front phases are sequential)
+  enum { SCRATCH = 4 * C::SEG + 512 + 32 * C::BAND + 4 * C::BAND, POOL = C::PIX > SCRATCH ? C::PIX : SCRATCH };
+  __attribute__((aligned(16))) uint8_t pool[POOL];
+  int taps[MPE_MAX_KSIZE];  // (taking the address of the by-value kernel argument would make the
+                            //  compiler copy all of it to scratch)
+  int nseg, nband;
+};
+template <class C>
+struct K1bFrameLds {  // what the contour phase needs of one frame
+  u64 nz[C::BM + 1], pm[C::BM + 1], ng[C::BM + 1];
+  Island isl[C::ISL];
+  float kx[C::KEPT], ky[C::KEPT];
+  unsigned kkey[C::KEPT];
+  int nkept, over, nisl;
+};
+
+// Front phases of frame f.  Returns true when the island bitmaps in S are ready for the contour phase,
+// false when the frame is finished (no bright pixel) or was handed to the next tier's work-list.
+template <class C>
+__device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict__ frames,
+                                          const u64* __restrict__ flags, const FrameGeom& g, const DetectParams& dp,
+                                          mpe_detections* __restrict__ dets, int* __restrict__ worklist,
+                                          K1bWaveLds<C>& W, K1bFrameLds<C>& S) {
   const int lane = threadIdx.x;
-  __syncthreads();  // (list mode: the previous frame of this block is completely done)
-  if (lane < MPE_MAX_KSIZE) s_taps[lane] = dp.taps[lane < dp.ksize ? lane : 0];
+  // front-phase scratch lives in the pixel pool (dead before the pool is filled in phase C)
+  unsigned* s_seg = reinterpret_cast<unsigned*>(W.pool);  // y << 16 | segment column
+  u64* s_rowact = reinterpret_cast<u64*>(W.pool + 4 * C::SEG);
+  u64(*s_colocc)[4] = reinterpret_cast<u64(*)[4]>(W.pool + 4 * C::SEG + 512);
+  short* s_bandlo = reinterpret_cast<short*>(W.pool + 4 * C::SEG + 512 + 32 * C::BAND);
+  short* s_bandhi = s_bandlo + C::BAND;
+  uint8_t* s_pix = W.pool;
+  const int* s_taps = W.taps;
+  int& s_nseg = W.nseg;
+  int& s_nband = W.nband;
+  u64 *s_nz = S.nz, *s_pm = S.pm, *s_ng = S.ng;
+  Island* s_isl = S.isl;
+  int& s_nkept = S.nkept;
+  int& s_over = S.over;
+  int& s_nisl = S.nisl;
+  __syncthreads();  // the previous user of the pool (frame before this one) is completely done
   const uint8_t* frame = frames + (size_t)f * g.rows * g.pitch;
   mpe_detections* out = dets + f;
   const int r = dp.ksize / 2;
@@ -551,7 +591,7 @@ __device__ __forceinline__ void k1b_frame(const int f, const uint8_t* __restrict
   const unsigned add = (unsigned)(255 - dp.thr) * 0x00010001u;
 
   s_rowact[lane] = 0;
-  for (int i = lane; i < K1B_BAND_CAP * 4; i += 64) (&s_colocc[0][0])[i] = 0;
+  for (int i = lane; i < C::BAND * 4; i += 64) (&s_colocc[0][0])[i] = 0;
   if (lane == 0) {
     s_nseg = 0;
     s_nkept = 0;
@@ -589,7 +629,7 @@ __device__ __forceinline__ void k1b_frame(const int f, const uint8_t* __restrict
           vv &= vv - 1;
           const int y0 = s / spr, c0 = s - y0 * spr;
           const int slot = atomicAdd(&s_nseg, 1);
-          if (slot < K1B_SEG_CAP) s_seg[slot] = ((unsigned)y0 << 16) | (unsigned)c0;
+          if (slot < C::SEG) s_seg[slot] = ((unsigned)y0 << 16) | (unsigned)c0;
           lds_set_range(s_rowact, max(0, y0 - r), min(g.rows - 1, y0 + r));
         }
       }
@@ -602,9 +642,9 @@ __device__ __forceinline__ void k1b_frame(const int f, const uint8_t* __restrict
       out->n = 0;
       out->status = 0;
     }
-    return;
+    return false;
   }
-  bool fallback = nseg > K1B_SEG_CAP;
+  bool fallback = nseg > C::SEG;
 
   // ---- B1: bands = maximal runs of active rows.  Lane w owns word w of the row bitset: band starts
   //      / ends are bit tricks, their ranks a wave prefix sum (starts and ends pair up in order).
@@ -629,13 +669,13 @@ __device__ __forceinline__ void k1b_frame(const int f, const uint8_t* __restrict
       while (st) {
         const int b = __builtin_ctzll(st);
         st &= st - 1;
-        if (is_ < K1B_BAND_CAP) s_bandlo[is_] = (short)(lane * 64 + b);
+        if (is_ < C::BAND) s_bandlo[is_] = (short)(lane * 64 + b);
         ++is_;
       }
       while (en) {
         const int b = __builtin_ctzll(en);
         en &= en - 1;
-        if (ie < K1B_BAND_CAP) s_bandhi[ie] = (short)(lane * 64 + b);
+        if (ie < C::BAND) s_bandhi[ie] = (short)(lane * 64 + b);
         ++ie;
       }
     }
@@ -643,7 +683,7 @@ __device__ __forceinline__ void k1b_frame(const int f, const uint8_t* __restrict
   }
   __syncthreads();
   const int nband = s_nband;
-  fallback = fallback || nband > K1B_BAND_CAP;
+  fallback = fallback || nband > C::BAND;
 
   // ---- B2: segment-column occupancy per band
   if (!fallback) {
@@ -684,7 +724,7 @@ __device__ __forceinline__ void k1b_frame(const int f, const uint8_t* __restrict
       }
       cstart = clast + 2 * dc + 2;
       const int idx = atomicAdd(&s_nisl, 1);
-      if (idx < K1B_ISL_CAP) {
+      if (idx < C::ISL) {
         Island is;
         is.ylo = (short)ylo;
         is.yhi = (short)yhi;
@@ -699,7 +739,7 @@ __device__ __forceinline__ void k1b_frame(const int f, const uint8_t* __restrict
   }
   __syncthreads();
   const int nisl = s_nisl;
-  fallback = fallback || nisl > K1B_ISL_CAP;
+  fallback = fallback || nisl > C::ISL;
 
   // ---- B4: pool offsets and work-item prefix sums (lane i owns island i; nisl <= 32)
   if (!fallback) {
@@ -733,7 +773,7 @@ __device__ __forceinline__ void k1b_frame(const int f, const uint8_t* __restrict
       s_isl[lane].blur_end = il;
     }
     const int tot_pix = __shfl(ip, nisl - 1), tot_bm = __shfl(ib, nisl - 1);
-    fallback = tot_pix > K1B_PIX_POOL || tot_bm > K1B_BM_POOL;
+    fallback = tot_pix > C::PIX || tot_bm > C::BM;
   }
   if (fallback) {  // hand the frame to the general kernel
     if (lane == 0) {
@@ -744,7 +784,7 @@ __device__ __forceinline__ void k1b_frame(const int f, const uint8_t* __restrict
         worklist[1 + k] = f;
       }
     }
-    return;
+    return false;
   }
   __syncthreads();
 
@@ -795,42 +835,96 @@ __device__ __forceinline__ void k1b_frame(const int f, const uint8_t* __restrict
     }
   }
   __syncthreads();
+  return true;
+}
 
-  // ---- E: lane i scans island i (the islands are independent, see the header comment)
-  if (lane < nisl) {
-    const Island is = s_isl[lane];
+// hand a frame to the next tier
+__device__ __forceinline__ void k1b_hand_over(int f, mpe_detections* __restrict__ dets, int* __restrict__ worklist) {
+  dets[f].n = 0;
+  dets[f].status = MPE_FRAME_TOO_MANY_ROWS;  // overwritten by the next tier
+  if (worklist) {
+    const int k = atomicAdd(&worklist[0], 1);
+    worklist[1 + k] = f;
+  }
+}
+
+// The frames fr[0..nf) of one wave: front phases one after the other, contour phase together.
+template <class C>
+__device__ __forceinline__ void k1b_wave(const int* fr, int nf, const uint8_t* __restrict__ frames,
+                                         const u64* __restrict__ flags, const FrameGeom& g, const DetectParams& dp,
+                                         mpe_detections* __restrict__ dets, int* __restrict__ worklist) {
+  __shared__ K1bWaveLds<C> W;
+  __shared__ K1bFrameLds<C> S[C::FRAMES];
+  const int lane = threadIdx.x;
+  __syncthreads();  // (list mode: the previous group of this block is completely done)
+  if (lane < MPE_MAX_KSIZE) W.taps[lane] = dp.taps[lane < dp.ksize ? lane : 0];
+  bool ready[C::FRAMES];
+  int base[C::FRAMES + 1];
+  base[0] = 0;
+#pragma unroll
+  for (int i = 0; i < C::FRAMES; ++i) {
+    ready[i] = false;
+    if (i < nf) ready[i] = k1b_front<C>(fr[i], frames, flags, g, dp, dets, worklist, W, S[i]);
+    base[i + 1] = base[i] + (ready[i] ? S[i].nisl : 0);
+  }
+  __syncthreads();
+
+  // ---- E: one lane per island, over the islands of all frames of the wave (the islands are
+  //      independent, see the header comment)
+  for (int it = lane; it < base[C::FRAMES]; it += 64) {
+    int fi = 0;
+#pragma unroll
+    for (int i = 1; i < C::FRAMES; ++i) fi += (it >= base[i]) ? 1 : 0;
+    K1bFrameLds<C>& F = S[fi];
+    const Island is = F.isl[it - base[fi]];
     const int H = is.yhi - is.ylo + 1;
     const int xhi = min(g.cols - 1, 16 * is.chi + 15);
-    const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
-    scan_window(s_nz + is.bm_off, s_pm + is.bm_off, s_ng + is.bm_off, W, H, is.ylo, 16 * is.clo, dp, &s_over,
+    const int Wd = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
+    scan_window(F.nz + is.bm_off, F.pm + is.bm_off, F.ng + is.bm_off, Wd, H, is.ylo, 16 * is.clo, dp, &F.over,
                 [&](float mcx, float mcy, unsigned key) {
-                  const int k = atomicAdd(&s_nkept, 1);
-                  if (k < K1B_KEPT_CAP) {
-                    s_kx[k] = mcx;
-                    s_ky[k] = mcy;
-                    s_kkey[k] = key;
+                  const int k = atomicAdd(&F.nkept, 1);
+                  if (k < C::KEPT) {
+                    F.kx[k] = mcx;
+                    F.ky[k] = mcy;
+                    F.kkey[k] = key;
                   }
                 });
   }
   __syncthreads();
-  write_detections(s_kx, s_ky, s_kkey, s_nkept, K1B_KEPT_CAP, s_over, dp, out, lane);
+#pragma unroll
+  for (int i = 0; i < C::FRAMES; ++i) {
+    if (!ready[i]) continue;
+    if (C::KEPT < 2 * MPE_MAX_DETECTIONS && S[i].nkept > C::KEPT) {  // more blobs than this tier records
+      if (lane == 0) k1b_hand_over(fr[i], dets, worklist);
+      continue;
+    }
+    write_detections(S[i].kx, S[i].ky, S[i].kkey, S[i].nkept, C::KEPT, S[i].over, dp, dets + fr[i], lane);
+  }
 }
 
-// one wave per frame, frame = block index
-template <int PIX, int BM>
+// block b works on frames b * C::FRAMES ...
+template <class C>
 __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
                                                FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
-                                               int* __restrict__ worklist) {
-  k1b_frame<PIX, BM>(blockIdx.x, frames, flags, g, dp, dets, worklist);
+                                               int* __restrict__ worklist, int n_frames) {
+  int fr[C::FRAMES];
+  const int f0 = blockIdx.x * C::FRAMES;
+#pragma unroll
+  for (int i = 0; i < C::FRAMES; ++i) fr[i] = f0 + i;
+  k1b_wave<C>(fr, min((int)C::FRAMES, n_frames - f0), frames, flags, g, dp, dets, worklist);
 }
-// frames taken from a device work-list (those the smaller-pool kernel handed over)
-template <int PIX, int BM>
+// frames taken from a device work-list (those the smaller tier handed over)
+template <class C>
 __global__ __launch_bounds__(64) void k1b_blobs_list(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
                                                     FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
                                                     const int* __restrict__ in_list, int* __restrict__ worklist) {
   const int count = in_list[0];
-  for (int wi = blockIdx.x; wi < count; wi += gridDim.x)
-    k1b_frame<PIX, BM>(in_list[1 + wi], frames, flags, g, dp, dets, worklist);
+  for (int w0 = blockIdx.x * C::FRAMES; w0 < count; w0 += gridDim.x * C::FRAMES) {
+    int fr[C::FRAMES];
+#pragma unroll
+    for (int i = 0; i < C::FRAMES; ++i) fr[i] = (w0 + i < count) ? in_list[1 + w0 + i] : 0;
+    k1b_wave<C>(fr, min((int)C::FRAMES, count - w0), frames, flags, g, dp, dets, worklist);
+  }
 }
 
 // =============================================================================================
@@ -967,14 +1061,15 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
   e = hipMemsetAsync(list_b, 0, sizeof(int), s);
   if (e != hipSuccess) return e;
   if (blob_hint > 0 && blob_hint <= 6) {
-    hipLaunchKernelGGL((k1b_blobs<4096, 208>), dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
-                       list_a);
+    const int blocks = (n_frames + K1bSmall::FRAMES - 1) / K1bSmall::FRAMES;
+    hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
+                       list_a, n_frames);
     const int grid = n_frames < 2048 ? n_frames : 2048;
-    hipLaunchKernelGGL((k1b_blobs_list<12288, 704>), dim3(grid), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
+    hipLaunchKernelGGL((k1b_blobs_list<K1bLarge>), dim3(grid), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
                        dets, (const int*)list_a, list_b);
   } else {
-    hipLaunchKernelGGL((k1b_blobs<12288, 704>), dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
-                       dets, list_b);
+    hipLaunchKernelGGL((k1b_blobs<K1bLarge>), dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
+                       dets, list_b, n_frames);
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
