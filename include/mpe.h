@@ -280,6 +280,11 @@ int mpe_last_kernel_ms(mpe_handle* h, float ms[5]);
 /* A large batch runs as several sub-batches (option "pipeline"): every kernel is then launched once
  * per sub-batch and mpe_last_kernel_ms reports the AVERAGE PER LAUNCH.  This returns the number of
  * launches per kernel and the frames each one processed for the last profiled call. */
+/* Same for ONE sub-batch of a pipelined call (0 <= sub_batch < launches): scan, blobs, vote, tail.  With
+ * pipeline_mode 3 ("fused") the scan of sub-batch s + 1 runs INSIDE the voting kernel of sub-batch s: the
+ * vote time of every sub-batch but the last then includes that scan, and scan = the stand-alone scan
+ * launches only (the whole first sub-batch, afterwards only remainders of less than one chunk). */
+int mpe_last_kernel_ms_sub(mpe_handle* h, int sub_batch, float ms[4]);
 int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
 
 /* Tuning knobs that are not part of the reference surface: "lds_budget" (bytes of LDS per frame

@@ -273,6 +273,11 @@ class Handle:
     def set_profiling(self, on):
         self._check(self._lib.mpe_set_profiling(self._h, 1 if on else 0), "mpe_set_profiling")
 
+    def last_kernel_ms_sub(self, sub_batch):
+        ms = (C.c_float * 4)()
+        self._check(self._lib.mpe_last_kernel_ms_sub(self._h, int(sub_batch), ms), "mpe_last_kernel_ms_sub")
+        return dict(scan=ms[0], blobs=ms[1], vote=ms[2], tail=ms[3])
+
     def last_kernel_ms(self):
         ms = (C.c_float * 5)()
         self._check(self._lib.mpe_last_kernel_ms(self._h, ms), "mpe_last_kernel_ms")

@@ -54,7 +54,8 @@ struct mpe_handle {
   size_t mailbox_cap = 0;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
   int vote_splits = 0;         // 0 = auto
-  int pipeline_mode = 0;       // experiment knob: 0 staggered, 1 not staggered, 2 three streams
+  int pipeline_mode = 0;       // 0 two-stream staggered pipeline, 3 fused single stream (scan rides in the voting
+                               // kernel); 1 / 2 experiment variants of the two-stream schedule
   bool profiling = false;
   int pipeline = 8;  // up to this many sub-batches (each >= 8192 frames) in a two-stream software
                      // pipeline: the HBM-bound scan of sub-batch i+1 runs beside the FP64-bound voting
@@ -360,6 +361,76 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   const size_t fw_per = flag_words(frame_bytes * per);
   HIP_TRY(h, h->flags.reserve(fw_per * nsub * 8));
   HIP_TRY(h, h->work.reserve((size_t)2 * (per + 1) * nsub * sizeof(int)));
+  // schedule: 0 two-stream software pipeline (default); 3 fused single stream.  If the probe found no pair of
+  // concurrently executing side streams the two-stream pipeline cannot overlap anything -> fused schedule.
+  int schedule = h->pipeline_mode;
+  if (schedule == 0 && sp && sp->n_markers <= 5) {
+    const int rc = pick_concurrent_streams(h);
+    if (rc) return rc;
+    if (h->streams_concurrent == 0) schedule = 3;
+  }
+  if (schedule == 3) {
+    // Fused schedule, ONE stream: the voting kernel of sub-batch s carries the image scan of sub-batch
+    // s + 1 on its idle memory pipeline (ScanRider in mpe_kernels.hip).
+    //   scan(0) | blobs(0) vote(0)+scan(1) tail(0) | blobs(1) vote(1)+scan(2) tail(1) | ...
+    hipStream_t st = h->stream;
+    auto sub_ptrs = [&](int s, int& f0, int& nf, const uint8_t*& fr, unsigned long long*& fl) {
+      f0 = s * per;
+      nf = std::min(per, n_frames - f0);
+      fr = d_frames + (size_t)f0 * frame_bytes;
+      fl = static_cast<unsigned long long*>(h->flags.p) + fw_per * s;
+    };
+    int f0, nf;
+    const uint8_t* fr;
+    unsigned long long* fl;
+    sub_ptrs(0, f0, nf, fr, fl);
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][0], st));
+    HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, false, st));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][1], st));
+    int used = 0;
+    for (int s = 0; s < nsub; ++s) {
+      sub_ptrs(s, f0, nf, fr, fl);
+      if (f0 >= n_frames) break;
+      used = s + 1;
+      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], st));
+      HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
+                                  static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
+                                  static_cast<uint8_t*>(h->scratch.p), sp->n_markers, st));
+      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], st));
+      uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
+      HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), st));
+      const uint8_t* nfr = nullptr;
+      unsigned long long* nfl = nullptr;
+      size_t nbytes = 0, scanned = 0;
+      if ((s + 1) * per < n_frames) {
+        int nf0, nnf;
+        sub_ptrs(s + 1, nf0, nnf, nfr, nfl);
+        nbytes = (size_t)nnf * frame_bytes;
+      }
+      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], st));
+      HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, *sp, static_cast<const double*>(h->mtab.p), hs,
+                                auto_splits(h, nf, sp->n_markers), sp->n_markers, st, nfr, nbytes, nfl, dp.thr,
+                                &scanned));
+      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], st));
+      if (nbytes > 0) {  // what the riders left over: less than one chunk, or everything if they could not run
+        if (prof) HIP_TRY(h, hipEventRecord(h->pev[s + 1][0], st));
+        if (nbytes > scanned)
+          HIP_TRY(h, launch_k1a_scan(nfr + scanned, nbytes - scanned, nfl + scanned / 1024, dp.thr, false, st));
+        if (prof) HIP_TRY(h, hipEventRecord(h->pev[s + 1][1], st));
+      }
+      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], st));
+      HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
+                                d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0, st));
+      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], st));
+    }
+    if (prof) {
+      h->prof_launches = used;
+      h->have_ms = true;
+      h->prof_pipelined = true;
+      h->prof_frames_per_launch = per;
+    }
+    return MPE_OK;
+  }
   {
     const int rc = pick_concurrent_streams(h);
     if (rc) return rc;
@@ -571,6 +642,15 @@ int mpe_last_kernel_ms(mpe_handle* h, float ms[5]) {
 }
 
 /* launches per kernel and frames per launch of the last profiled batch (1 / n_frames when not pipelined) */
+int mpe_last_kernel_ms_sub(mpe_handle* h, int sub_batch, float ms[4]) {
+  if (!h || !ms) return MPE_ERR_ARG;
+  if (!h->have_ms || !h->prof_pipelined || sub_batch < 0 || sub_batch >= h->prof_launches)
+    return fail(h, MPE_ERR_ARG, "no per-sub-batch timing for the last batch");
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int k = 0; k < 4; ++k) HIP_TRY(h, hipEventElapsedTime(&ms[k], h->pev[sub_batch][2 * k], h->pev[sub_batch][2 * k + 1]));
+  return MPE_OK;
+}
+
 int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch) {
   if (!h || !h->have_ms) return MPE_ERR_ARG;
   if (launches) *launches = h->prof_launches;

@@ -55,8 +55,12 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
                             int blob_hint, hipStream_t s);
 size_t k2_table_bytes(int n_markers);
 hipError_t launch_k2_prep(const SolveParams& sp, double* tab, hipStream_t s);
+// scan_px != nullptr: the voting waves also scan scan_bytes of pixels (the next sub-batch) into scan_flags;
+// *scanned_bytes = the prefix they cover (whole chunks), the caller scans the rest with launch_k1a_scan
 hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
-                          uint32_t* hist, int splits, int n_det_hint, hipStream_t s);
+                          uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px = nullptr,
+                          size_t scan_bytes = 0, unsigned long long* scan_flags = nullptr, int scan_thr = 0,
+                          size_t* scanned_bytes = nullptr);
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
                           mpe_result* results, uint32_t* corr_out, const uint32_t* corr_in, const double* nn_pred,
                           double nn_tol, hipStream_t s, int mode = 0);

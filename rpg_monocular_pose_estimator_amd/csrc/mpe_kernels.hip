@@ -19,6 +19,8 @@
 //
 // FP64 everywhere on the geometry path (the reference is double; vote thresholds are knife
 // edges), no MFMA (no dense contraction on this path), compiled with -ffp-contract=off.
+#include <type_traits>
+
 #include "mpe_internal.h"
 #include "mpe_p3p.h"
 
@@ -30,14 +32,35 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // =============================================================================================
 // K1a — image scan
 // =============================================================================================
-// bytes > thr  <=>  byte + (255 - thr) carries into bit 8 of its 16-bit lane
-__device__ __forceinline__ unsigned any_gt16(const uint4& v, unsigned add) {
-  unsigned r = 0;
-  r |= ((v.x & 0x00FF00FFu) + add) | (((v.x >> 8) & 0x00FF00FFu) + add);
-  r |= ((v.y & 0x00FF00FFu) + add) | (((v.y >> 8) & 0x00FF00FFu) + add);
-  r |= ((v.z & 0x00FF00FFu) + add) | (((v.z >> 8) & 0x00FF00FFu) + add);
-  r |= ((v.w & 0x00FF00FFu) + add) | (((v.w >> 8) & 0x00FF00FFu) + add);
-  return r & 0x01000100u;
+// "any of the 16 bytes > thr" with 3 VALU ops per 32-bit word.  For thr >= 128 a byte exceeds thr iff its
+// top bit is set AND its low 7 bits exceed thr - 128; for thr < 128 iff the top bit is set OR the low 7 bits
+// exceed thr.  "low 7 bits > n" is the classic SWAR carry test: (b & 0x7F) + (127 - n) sets bit 7 (no carry
+// leaves the byte).  kk = (127 - n) * 0x01010101, sel = ~0 for the AND form, 0 for the OR form; the select
+// t&w / t|w is one v_bitop3_b32 on gfx950.  thr = 255 -> AND form with kk = 0 (never), thr = -1 -> OR form with
+// kk = 128 * 0x01010101 (always).
+struct ThrTest {
+  unsigned kk, sel;
+};
+__host__ __device__ inline ThrTest make_thr_test(int thr) {
+  const int t = thr < -1 ? -1 : (thr > 255 ? 255 : thr);
+  ThrTest r;
+  if (t >= 128) {
+    r.kk = (unsigned)(255 - t) * 0x01010101u;
+    r.sel = 0xFFFFFFFFu;
+  } else {
+    r.kk = (unsigned)(127 - t) * 0x01010101u;
+    r.sel = 0u;
+  }
+  return r;
+}
+__device__ __forceinline__ unsigned gt_word(unsigned w, unsigned kk, unsigned sel) {
+  const unsigned t = (w & 0x7F7F7F7Fu) + kk;
+  return (sel & (t & w)) | (~sel & (t | w));
+}
+__device__ __forceinline__ unsigned any_gt16(const uint4& v, ThrTest q) {
+  const unsigned r = gt_word(v.x, q.kk, q.sel) | gt_word(v.y, q.kk, q.sel) | gt_word(v.z, q.kk, q.sel) |
+                     gt_word(v.w, q.kk, q.sel);
+  return r & 0x80808080u;
 }
 
 #ifndef K1A_UNROLL
@@ -50,7 +73,7 @@ __device__ __forceinline__ unsigned any_gt16(const uint4& v, unsigned add) {
 #define K1A_BLOCKS_PER_CU 32
 #endif
 __global__ __launch_bounds__(256) void k1a_scan(const uint4* __restrict__ px, u64* __restrict__ flags, size_t n_seg,
-                                                unsigned add) {
+                                                ThrTest thr) {
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -74,7 +97,7 @@ __global__ __launch_bounds__(256) void k1a_scan(const uint4* __restrict__ px, u6
     }
     u64 b[K1A_UNROLL];
 #pragma unroll
-    for (int k = 0; k < K1A_UNROLL; ++k) b[k] = __ballot(any_gt16(v[k], add) != 0);
+    for (int k = 0; k < K1A_UNROLL; ++k) b[k] = __ballot(any_gt16(v[k], thr) != 0);
     if (lane == 0) {
       ulonglong2* out = reinterpret_cast<ulonglong2*>(flags + c * K1A_UNROLL);
 #pragma unroll
@@ -92,8 +115,7 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
                            bool co_resident, hipStream_t s) {
   const size_t n_seg = n_bytes / 16;
   if (n_seg == 0) return hipSuccess;
-  int t = thr < -1 ? -1 : (thr > 255 ? 255 : thr);
-  const unsigned add = (unsigned)(255 - t) * 0x00010001u;
+  const ThrTest q = make_thr_test(thr);
   const size_t n_chunks = (n_seg + 64 * K1A_UNROLL - 1) / (64 * K1A_UNROLL);
   size_t blocks = (n_chunks + 3) / 4;  // 4 waves per block
   const size_t max_blocks = 256 * K1A_BLOCKS_PER_CU;  // 256 CUs x blocks per CU, grid-stride beyond
@@ -105,7 +127,7 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(k1a_scan, dim3((unsigned)blocks), dim3(256), dummy_lds, s,
-                     reinterpret_cast<const uint4*>(frames), (u64*)flags, n_seg, add);
+                     reinterpret_cast<const uint4*>(frames), (u64*)flags, n_seg, q);
   return hipGetLastError();
 }
 
@@ -1110,6 +1132,8 @@ __device__ __forceinline__ double pick_root(const P3PCtx& c, int k) {
 }
 #define K2_THREADS 256
 #define K2_TRI_CHUNK 64  // detection triples staged in LDS per pass
+#define K2_TRI_CHUNK_SCAN 16
+#define K2_LTAB 11  // doubles per marker permutation in the LDS copy of the table (scan-carrying variant)
 
 // ---- marker-permutation table (frame independent) -------------------------------------------
 // One entry per ordered marker triple (P1,P2,P3), in the reference's permutation order
@@ -1186,6 +1210,90 @@ size_t k2_table_bytes(int n_markers) {
   return (size_t)n_markers * (n_markers - 1) * (n_markers - 2) * k2_entry_doubles(n_markers) * sizeof(double);
 }
 
+// ---- image scan riding inside the voting kernel ----------------------------------------------
+// The voting kernel is FP64-VALU bound and leaves the memory pipeline idle; the image scan is HBM
+// bound and needs almost no VALU.  Instead of running the two side by side as separate kernels
+// (their waves then fight for VGPR space: three 168-VGPR voting waves fill a SIMD), every voting
+// wave also streams a share of the NEXT sub-batch's pixels: `global_load_lds_dwordx4` (gfx950 LDS
+// DMA) moves 16 B per lane straight from HBM into a per-wave LDS staging area — no VGPRs are held
+// while the loads are in flight — and at a few "service points" between pieces of P3P arithmetic the
+// wave tests the staged segments against the threshold (SWAR + ballot, the same arithmetic as
+// k1a_scan), writes the flag words and starts the next round of loads.
+#ifndef K2_SCAN_R
+#define K2_SCAN_R 6  // 1 KiB wave-loads per round = KiB of staging LDS per wave
+#endif
+struct ScanArgs {
+  const uint4* px;   // pixels of the region to scan, 16-byte segments
+  u64* flags;        // one bit per segment
+  int n_chunks;      // full chunks of 64 * K2_SCAN_R segments (the caller scans the remainder separately)
+  ThrTest thr;       // threshold test constants (make_thr_test)
+};
+struct ScanRider {
+  const uint4* px;
+  u64* flags;
+  uint4* stage;  // this wave's staging area in LDS: [K2_SCAN_R][64] segments
+  int c, stride, n_chunks;
+  ThrTest thr;
+  bool pending;
+  __device__ __forceinline__ void init(const ScanArgs& a, unsigned char* lds_stage) {
+    const int waves_per_block = blockDim.x >> 6;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform -> SGPRs
+    px = a.px;
+    flags = a.flags;
+    thr = a.thr;
+    n_chunks = a.n_chunks;
+    stage = reinterpret_cast<uint4*>(lds_stage) + (size_t)wave_in_block * (K2_SCAN_R * 64);
+    c = (int)blockIdx.x * waves_per_block + wave_in_block;
+    stride = (int)gridDim.x * waves_per_block;
+    pending = false;
+  }
+  // start the next round.  vmcnt counts in order, so an ordinary global load issued behind a round would wait
+  // for the round's HBM latency: the voting loop therefore reads its tables from LDS only.
+  __device__ __forceinline__ void issue() {
+    if (pending || c >= n_chunks) return;
+    asm volatile("" ::: "memory");
+    const uint4* p = px + (size_t)c * (K2_SCAN_R * 64) + (threadIdx.x & 63);
+#pragma unroll
+    for (int k = 0; k < K2_SCAN_R; ++k)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 64 * k),
+                                       (__attribute__((address_space(3))) void*)(stage + 64 * k), 16, 0, 0);
+    asm volatile("" ::: "memory");
+    pending = true;
+  }
+  // test the staged round and write its flag words
+  __device__ __forceinline__ void consume() {
+    if (!pending) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA writes have landed in LDS
+    const int lane = threadIdx.x & 63;
+    u64 b[K2_SCAN_R];
+#pragma unroll
+    for (int k = 0; k < K2_SCAN_R; ++k) {
+      const uint4 v = stage[64 * k + lane];
+      b[k] = __ballot(any_gt16(v, thr) != 0);
+    }
+    asm volatile("" ::: "memory");  // staging reads are done before the next round overwrites them
+    if (lane == 0) {
+      u64* out = flags + (size_t)c * K2_SCAN_R;
+#pragma unroll
+      for (int k = 0; k < K2_SCAN_R; ++k) out[k] = b[k];
+    }
+    pending = false;
+    c += stride;
+  }
+  __device__ __forceinline__ void drain() {  // the rest of this wave's share, nothing to hide behind any more
+    for (;;) {
+      issue();
+      if (!pending) break;
+      consume();
+    }
+  }
+};
+struct NoRider {
+  __device__ __forceinline__ void consume() {}
+  __device__ __forceinline__ void issue() {}
+  __device__ __forceinline__ void drain() {}
+};
+
 // Voting kernel.  Work item = (detection triple, marker permutation).  Everything that depends
 // only on the detection triple (tau frame T, f_1, f_2, b and the swap of p3p.cpp:100-121) is
 // computed once per triple into LDS; everything that depends only on the marker permutation comes
@@ -1196,14 +1304,18 @@ size_t k2_table_bytes(int n_markers) {
 #ifndef K2_MIN_WAVES
 #define K2_MIN_WAVES 3
 #endif
+template <bool SCAN>
 __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_detections* __restrict__ dets, SolveParams sp,
                                                       const double* __restrict__ tab, uint32_t* __restrict__ hist,
-                                                      int splits) {
+                                                      int splits, ScanArgs scan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double s_px[MPE_MAX_DETECTIONS][2];
   __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
-  __shared__ double s_tri[K2_TRI_CHUNK][13];  // T rows (9), f_1, f_2, b, f_1/f_2
-  __shared__ unsigned s_trii[K2_TRI_CHUNK];   // c0 | c1 << 8 | c2 << 16 | swap << 24
+  // detection triples staged per pass: 64, or 16 in the scan-carrying variant (LDS goes to the scan staging
+  // and to an LDS copy of the marker table instead; more triples simply take more passes)
+  constexpr int TRI = SCAN ? K2_TRI_CHUNK_SCAN : K2_TRI_CHUNK;
+  __shared__ double s_tri[TRI][13];  // T rows (9), f_1, f_2, b, f_1/f_2
+  __shared__ unsigned s_trii[TRI];   // c0 | c1 << 8 | c2 << 16 | swap << 24
   __shared__ unsigned s_hist[MPE_HIST_STRIDE];
 
   const int f = blockIdx.x / splits, part = blockIdx.x - f * splits;
@@ -1211,7 +1323,12 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   const int nthr = blockDim.x;
   const mpe_detections* d = dets + f;
   const int n_d = d->n, n_m = sp.n_markers;
-  if (n_d < 4 || d->status != 0 || n_m < 4) return;  // min_num_leds_detected_ (pose_estimator.h:78)
+  typename std::conditional<SCAN, ScanRider, NoRider>::type rider;
+  if constexpr (SCAN) rider.init(scan, smem + (size_t)(n_m - 3) * 2 * blockDim.x * sizeof(double));
+  if (n_d < 4 || d->status != 0 || n_m < 4) {  // min_num_leds_detected_ (pose_estimator.h:78)
+    rider.drain();
+    return;
+  }
 
   for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) s_hist[i] = 0;
   if (tid < n_d) {
@@ -1233,8 +1350,23 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
   // block row with P1 <-> P2 exchanged: {2, 5, 0, 4, 3, 1}, packed 4 bits per row as 0x134052
 
-  for (int tc0 = 0; tc0 < n_combos; tc0 += K2_TRI_CHUNK) {
-    const int ntri = min(K2_TRI_CHUNK, n_combos - tc0);
+  // Scan-carrying variant: the voting loop must not touch global memory (vmcnt counts in order, so any
+  // ordinary load issued behind a scan round would wait for that round's HBM latency) -> the per-permutation
+  // table values the loop needs are copied to LDS once per block:
+  //   [0] p_1 [1] p_2 [2] d_12 [3] valid [4] packed marker indices [5..10] eta-frame unused markers (<= 2)
+  double* s_tab = nullptr;
+  if constexpr (SCAN) {
+    s_tab = reinterpret_cast<double*>(smem + (size_t)nuo * 2 * blockDim.x * sizeof(double) +
+                                      (size_t)(blockDim.x >> 6) * (K2_SCAN_R * 1024));
+    for (int i = tid; i < n_perms * K2_LTAB; i += nthr) {
+      const int pe = i / K2_LTAB, fld = i - pe * K2_LTAB;
+      const int src = fld < 5 ? 12 + fld : 13 + fld;  // 12..16, 18..23
+      s_tab[i] = (fld < 5 + 3 * nuo) ? tab[(size_t)pe * esz + src] : 0.0;
+    }
+    __syncthreads();
+  }
+  for (int tc0 = 0; tc0 < n_combos; tc0 += TRI) {
+    const int ntri = min(TRI, n_combos - tc0);
     if (tc0) __syncthreads();
     // ---- per-triple part of computePoses (p3p.cpp:82-121, 143-154)
     if (tid < ntri) {
@@ -1282,20 +1414,43 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
     int t = part * nthr + tid;
     int ti = t / n_perms, pj = t - ti * n_perms;
     const int dti = stride / n_perms, dpj = stride - dti * n_perms;
-    for (; t < total; t += stride, ti += dti, pj += dpj) {
+    // With the scan rider on board the loop nest must stay wave-uniform (the rider's LDS-DMA rounds need all
+    // 64 lanes at every call): every lane then runs the iteration count of the slowest one and lanes without
+    // a valid item — past the end, collinear marker triple, non-finite root — compute on harmlessly and are
+    // merely barred from voting (`live`).  Without a rider those lanes skip ahead as before.
+    const int n_iter = (total - part * nthr + stride - 1) / stride;
+    for (int it = 0; SCAN ? (it < n_iter) : (t < total); ++it, t += stride, ti += dti, pj += dpj) {
       if (pj >= n_perms) {
         pj -= n_perms;
         ++ti;
       }
+      bool live = true;
+      const int ti_keep = ti, pj_keep = pj;
+      if constexpr (SCAN) {
+        if (t >= total) {
+          live = false;
+          ti = 0;
+          pj = 0;
+        }
+      }
       const unsigned ii = s_trii[ti];
       const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
       const bool swap = (ii >> 24) & 1;
-      const int packed = (int)tab[(size_t)pj * esz + 16];  // marker indices of this permutation
+      const int packed = SCAN ? (int)s_tab[pj * K2_LTAB + 4]
+                              : (int)tab[(size_t)pj * esz + 16];  // marker indices of this permutation
       const int p0 = packed & 0xFF, p1 = (packed >> 8) & 0xFF, p2 = (packed >> 16) & 0xFF;
       const int r6 = pj % 6;
       const int pjs = swap ? (pj - r6 + (int)((0x134052u >> (4 * r6)) & 7u)) : pj;  // kSwapRow packed
-      const double* e = tab + (size_t)pjs * esz;
-      if (e[15] == 0.0) continue;  // collinear world points: computePoses returns -1
+      // e[12..] of the global table entry; in the scan-carrying variant e points into the LDS copy, shifted so
+      // that the SAME indices work for p_1 p_2 d_12 valid (12..15), and the markers are read through lt below
+      const double* lt = SCAN ? s_tab + pjs * K2_LTAB : nullptr;
+      const double* e = SCAN ? lt - 12 : tab + (size_t)pjs * esz;
+      if (e[15] == 0.0) {  // collinear world points: computePoses returns -1
+        if constexpr (SCAN)
+          live = false;
+        else
+          continue;
+      }
       const double p_1 = e[12], p_2 = e[13], d_12 = e[14];
       const double* tr = s_tri[ti];
       const double f_1 = tr[9], f_2 = tr[10], b = tr[11], f12 = tr[12];
@@ -1317,6 +1472,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
                         2 * p_1_pw3 * d_12 - p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 -
                         2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 + p_2_pw2 * f_1_pw2 * p_1_pw2 +
                         f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
+      rider.issue();  // P0: first scan round of the item (nothing is staged here: P6 consumed the last one)
       double root[4];
 #if defined(MPE_K2_LITERAL_QUARTIC)
       solve_quartic(F0, F1, F2, F3, F4, root);
@@ -1330,12 +1486,16 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
         printf("DBG swap %d pjs %d f_1 %.17g f_2 %.17g b %.17g p_1 %.17g p_2 %.17g d_12 %.17g\nF %.17g %.17g %.17g %.17g %.17g\nroots %.17g %.17g %.17g %.17g\n",
                (int)swap, pjs, f_1, f_2, b, p_1, p_2, d_12, F0, F1, F2, F3, F4, root[0], root[1], root[2], root[3]);
 #endif
+      rider.consume();  // P1
       // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
       const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
       const double tol2 = sp.back_tol * sp.back_tol;
 
 #pragma unroll 1
       for (int k = 0; k < 4; ++k) {
+        rider.consume();  // P2..P5 (no-op when nothing is staged)
+        // next scan round: nothing of the voting loop waits on vmcnt (table and triples are in LDS)
+        rider.issue();
         const double rt = k == 0 ? root[0] : (k == 1 ? root[1] : (k == 2 ? root[2] : root[3]));
         // back-substitution, p3p.cpp:193-213
         // cot_alpha = cn / cd;  sin_alpha = sqrt(1 / (cot^2 + 1)) = |cd| / hypot(cn, cd),
@@ -1357,11 +1517,19 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           printf("DBG k %d rt %.17g cn %.17g cd %.17g sa %.17g ca %.17g st %.17g C %.17g %.17g %.17g z %g\n", k, rt, cn, cd,
                  sin_alpha, cos_alpha, sin_theta, Cx, Cy, Cz, z);
 #endif
-        if (!(z == 0.0)) continue;
+        bool finite_pose = true;
+        if (!(z == 0.0)) {
+          if constexpr (SCAN)
+            finite_pose = false;
+          else
+            continue;
+        }
+        const bool may_vote = live && finite_pose;
         const double T00 = tr[0], T01 = tr[1], T02 = tr[2], T10 = tr[3], T11 = tr[4], T12 = tr[5], T20 = tr[6],
                      T21 = tr[7], T22 = tr[8];
         for (int j = 0; j < nuo; ++j) {
-          const double v0 = e[18 + 3 * j] - Cx, v1 = e[18 + 3 * j + 1] - Cy, v2 = e[18 + 3 * j + 2] - Cz;
+          const double* mk = SCAN ? lt + 5 + 3 * j : e + 18 + 3 * j;
+          const double v0 = mk[0] - Cx, v1 = mk[1] - Cy, v2 = mk[2] - Cz;
           const double g = cos_theta * v1 + sin_theta * v2;
           const double w0 = -cos_alpha * v0 - sin_alpha * g;
           const double w1 = sin_alpha * v0 - cos_alpha * g;
@@ -1402,7 +1570,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
             printf("DBG     k %d a %d au %.6f av %.6f best %.6f bj %d within %d tol2 %.6f nuo %d n_d %d c %d %d %d p %d %d %d tid %d nthr %d\n", k, a, au, av, best, bj,
                    (int)within, tol2, nuo, n_d, c0, c1, c2, p0, p1, p2, tid, nthr);
 #endif
-          if (within) {
+          if (within && may_vote) {
             int mi = -1, cnt = -1;         // bj-th unused marker -> marker index
             for (int m = 0; m < n_m; ++m) {
               if (m == p0 || m == p1 || m == p2) continue;
@@ -1421,8 +1589,12 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           atomicAdd(&s_hist[c2 * MPE_MAX_MARKERS + p2], 1u);
         }
       }
+      rider.consume();  // P6: nothing of the scan is in flight while the next item fetches its table values
+      ti = ti_keep;
+      pj = pj_keep;
     }
   }
+  rider.drain();
   __syncthreads();
   uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
   for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) {
@@ -1432,7 +1604,9 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
 }
 
 hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
-                          uint32_t* hist, int splits, int n_det_hint, hipStream_t s) {
+                          uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px,
+                          size_t scan_bytes, unsigned long long* scan_flags, int scan_thr, size_t* scanned_bytes) {
+  if (scanned_bytes) *scanned_bytes = 0;
   if (n_frames <= 0 || sp.n_markers < 4) return hipSuccess;
   if (splits < 1) splits = 1;
   const int nuo = sp.n_markers - 3;
@@ -1441,7 +1615,8 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
   if (n_det_hint >= 4) {
     const long long nm = sp.n_markers;
     long long ntri = (long long)n_det_hint * (n_det_hint - 1) * (n_det_hint - 2) / 6;
-    if (ntri > K2_TRI_CHUNK) ntri = K2_TRI_CHUNK;
+    const long long chunk = (scan_px && nuo <= 2) ? K2_TRI_CHUNK_SCAN : K2_TRI_CHUNK;
+    if (ntri > chunk) ntri = chunk;
     const long long items = ntri * nm * (nm - 1) * (nm - 2);
     double best = 1e30;
     for (int t = 64; t <= K2_THREADS; t += 64) {
@@ -1453,9 +1628,23 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
       }
     }
   }
-  const size_t lds = (size_t)nuo * 2 * threads * sizeof(double);
-  hipLaunchKernelGGL(k2_vote, dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
-                     splits);
+  size_t lds = (size_t)nuo * 2 * threads * sizeof(double);
+  ScanArgs sa = {nullptr, nullptr, 0, {0u, 0u}};
+  const size_t chunk_bytes = (size_t)K2_SCAN_R * 1024;
+  if (scan_px && nuo <= 2 && scan_bytes >= chunk_bytes && scan_bytes / chunk_bytes < 0x7fffffffull) {
+    sa.px = reinterpret_cast<const uint4*>(scan_px);
+    sa.flags = (u64*)scan_flags;
+    sa.n_chunks = (int)(scan_bytes / chunk_bytes);
+    sa.thr = make_thr_test(scan_thr);
+    lds += (size_t)(threads / 64) * chunk_bytes +
+           (size_t)sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2) * K2_LTAB * sizeof(double);
+    if (scanned_bytes) *scanned_bytes = (size_t)sa.n_chunks * chunk_bytes;
+    hipLaunchKernelGGL(k2_vote<true>, dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
+                       splits, sa);
+  } else {
+    hipLaunchKernelGGL(k2_vote<false>, dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
+                       splits, sa);
+  }
   return hipGetLastError();
 }
 

@@ -675,6 +675,11 @@ def test_full_size_batch_properties(orc):
     assert h.get_option("streams_concurrent") in (0, 1)   # probed at the first pipelined call (1 = overlap verified)
     plain = run(frames, 1)
     assert torch.equal(piped, plain)
+    # fused schedule: the image scan of sub-batch s + 1 rides inside the voting kernel of sub-batch s (LDS DMA)
+    h.set_option("pipeline_mode", 3)
+    fused = run(frames, 8)
+    h.set_option("pipeline_mode", 0)
+    assert torch.equal(fused, plain)
     flipped = torch.flip(frames, dims=[0]).contiguous()
     torch.cuda.synchronize()
     rev = run(flipped, 8)
@@ -694,4 +699,51 @@ def test_full_size_batch_properties(orc):
         if ref["status"][j] == 0:
             dp, dr = pose_diff(T[i], ref["T"][j].reshape(4, 4))
             assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (i, dp, dr)
+    h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("thr", [-1, 0, 1, 100, 126, 127, 128, 129, 200, 254, 255])
+def test_fused_scan_flags_at_every_threshold_form(orc, thr):
+    """The fused schedule's scan (SWAR byte test in its AND form for thr >= 128, OR form below, LDS-DMA staging)
+    against the plain schedule and the oracle on frames whose pixel values straddle the threshold."""
+    import torch
+    B = 16384 + 100   # two sub-batches of >= 8192 frames: the second one is scanned by the voting kernel's riders
+    rows, cols = 64, 112  # (its size is not a multiple of the riders' chunk: the stand-alone scan takes the rest)
+    K, D = synth.camera_for(rows, cols)
+    rng = np.random.default_rng(thr + 5)
+    t = max(0, min(255, thr))
+    base = np.empty((257, rows, cols), np.uint8)
+    for i in range(257):   # background at / just below thr, six 3x3 spots just above it
+        base[i] = np.clip(rng.integers(t - 2, t + 1, (rows, cols)), 0, 255).astype(np.uint8)
+        for k in range(6):
+            y, x = 6 + 9 * k, int(rng.integers(4, cols - 8))
+            base[i, y:y + 3, x:x + 3] = min(255, t + 1 + (k & 1))
+    frames_np = base[np.arange(B) % 257]
+    dev = torch.device("cuda", 0)
+    frames = torch.as_tensor(frames_np, device=dev)
+    P = mpe.demo_params(threshold_value=thr, min_blob_area=1.0, max_blob_area=1e9, max_width_height_distortion=1e9,
+                        max_circular_distortion=1e9)
+    h = mpe.Handle(0)
+    stream = torch.cuda.Stream(device=dev)
+    h.set_stream(stream.cuda_stream)
+    h.set_option("pipeline", 2)
+    out = {}
+    for mode in (0, 3):
+        h.set_option("pipeline_mode", mode)
+        with torch.cuda.stream(stream):
+            res = torch.zeros(B * mpe.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            h.estimate_batch_device(frames.data_ptr(), B, rows, cols, synth.M5, K, D, P, res.data_ptr())
+        stream.synchronize()
+        out[mode] = np.frombuffer(res.cpu().numpy().tobytes(), mpe.RESULT_DTYPE)
+    assert out[0].tobytes() == out[3].tobytes()
+    Po = orc.make_params(threshold_value=thr, min_blob_area=1.0, max_blob_area=1e9, max_width_height_distortion=1e9,
+                         max_circular_distortion=1e9)
+    for i in list(range(0, 257, 16)) + [B - 1]:
+        und, _ = orc.find_leds(frames_np[i], Po, K, D)
+        got = out[3][i]
+        if len(und) > mpe.MAX_DETECTIONS:
+            assert got["status"] == -10
+        else:
+            assert got["n_det"] == len(und), (thr, i, got["n_det"], len(und))
     h.close()
