@@ -49,7 +49,8 @@ def main():
                     help="extra leg: frames streamed from PINNED host memory every step (PCIe-inclusive rate; "
                          "reported as host_streamed_fps, never as value)")
     ap.add_argument("--k1a-lds", type=int, default=-1, help="tuning: dummy LDS per scan block (-1 = automatic)")
-    ap.add_argument("--pipeline-mode", type=int, default=0, help="experiment knob")
+    ap.add_argument("--pipeline-mode", type=int, default=-1,
+                    help="-1 automatic (fused single-stream schedule for <= 5 markers), 0 two-stream pipeline, 3 fused")
     ap.add_argument("--pipeline", type=int, default=8, help="sub-batches per step on separate HIP streams (1 = off)")
     args = ap.parse_args()
 
@@ -125,16 +126,30 @@ def main():
     #      and launch shape as the timed region (a big batch runs as sub-batches, every kernel is launched
     #      once per sub-batch; the numbers are AVERAGES PER LAUNCH, like rocprofv3 --stats reports them)
     h.set_profiling(True)
-    kms = []
+    kms, subs = [], []
     for _ in range(min(5, max(3, args.steps))):
         h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
         kms.append(h.last_kernel_ms())
+        if int(kms[-1]["launches"]) > 1:
+            subs.append([h.last_kernel_ms_sub(i) for i in range(int(kms[-1]["launches"]))])
     h.set_profiling(False)
+    schedule = h.get_option("last_schedule") if int(kms[0]["launches"]) > 1 else 0
     kavg = {k: float(np.mean([m[k] for m in kms])) for k in kms[0]}
     launches, fpl = int(kms[0]["launches"]), int(kms[0]["frames_per_launch"])
     kavg["launches"], kavg["frames_per_launch"] = launches, fpl
     bytes_per_launch = min(fpl, B) * rows * cols  # algorithmic: every pixel read once
-    scan_s = kavg["scan"] * 1e-3
+    fused = schedule == 3 and launches > 1
+    if fused:
+        # fused schedule: the scan of sub-batch s+1 runs INSIDE the voting kernel of sub-batch s; only the first
+        # sub-batch is scanned by a stand-alone k1a_scan launch.  Average the launches that do the same thing.
+        vote_scan_ms = float(np.mean([sub[i]["vote"] for sub in subs for i in range(launches - 1)]))
+        vote_plain_ms = float(np.mean([sub[launches - 1]["vote"] for sub in subs]))
+        scan_alone_ms = float(np.mean([sub[0]["scan"] for sub in subs]))
+        kavg.update({"scan_standalone_first_sub_batch": scan_alone_ms, "vote_with_scan": vote_scan_ms,
+                     "vote_last_sub_batch_without_scan": vote_plain_ms})
+        scan_s = vote_scan_ms * 1e-3
+    else:
+        scan_s = kavg["scan"] * 1e-3
     achieved = bytes_per_launch / scan_s / 1e9
     # the same kernels one launch per step and back to back (no sub-batch pipelining): what each kernel
     # does when it has the chip to itself
@@ -155,19 +170,32 @@ def main():
     # coalesced reads on gfx950), scaled from bytes per frame to this launch
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "round1_k1a_scan_pmc.json")) as fh:
+        name = "round1_k2_vote_scan_pmc.json" if fused else "round1_k1a_scan_pmc.json"
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
             pmc = json.load(fh)
         if pmc.get("rows") == rows and pmc.get("cols") == cols:
             traffic = pmc["hbm_bytes_per_frame"] * min(fpl, B)
     except Exception:
         pass
-    roofline = {"kernel": "k1a_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": traffic,
-                "bytes_per_launch": bytes_per_launch, "avg_launch_ms": kavg["scan"],
-                "launches_per_step": launches, "frames_per_launch": fpl,
-                "measured": "HIP events around every k1a_scan launch on its stream, steps in the same mode as the "
-                            "timed region (with >1 launches per step the scan of sub-batch i+1 runs beside the "
-                            "FP64 voting of sub-batch i and shares the chip with it)"}
+    if fused:
+        roofline = {"kernel": "k2_vote<scan>", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": traffic, "bytes_per_launch": bytes_per_launch,
+                    "avg_launch_ms": vote_scan_ms, "launches_per_step": launches - 1, "frames_per_launch": fpl,
+                    "measured": "HIP events around every k2_vote<scan> launch on its stream in steps of the same "
+                                "mode as the timed region.  This kernel is the image pass AND the FP64 voting: each "
+                                "voting wave streams its share of the next sub-batch's pixels through LDS DMA "
+                                "(global_load_lds) between pieces of P3P arithmetic; bytes = the pixels it scans, "
+                                "time = the whole fused launch (the voting alone takes kernel_ms."
+                                "vote_last_sub_batch_without_scan).  roofline_isolated = the stand-alone scan "
+                                "kernel, which the first sub-batch of every step still uses."}
+    else:
+        roofline = {"kernel": "k1a_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": traffic,
+                    "bytes_per_launch": bytes_per_launch, "avg_launch_ms": kavg["scan"],
+                    "launches_per_step": launches, "frames_per_launch": fpl,
+                    "measured": "HIP events around every k1a_scan launch on its stream, steps in the same mode as "
+                                "the timed region (with >1 launches per step the scan of sub-batch i+1 runs beside "
+                                "the FP64 voting of sub-batch i and shares the chip with it)"}
 
     host_fps = None
     if args.host_frames and rank == 0:
@@ -197,6 +225,7 @@ def main():
                                                                       cfg["n_distractors"]),
                        "frames_per_gpu_per_step": B, "frames_resident_in_hbm": True,
                        "streams_per_gpu": args.pipeline,
+                       "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel"}.get(schedule, schedule),
                        "side_streams_concurrent": h.get_option("streams_concurrent"),
                        "parallelism": "frames sharded over %d GPU(s), all_gather of pose records" % world},
             "poses_found_frac": n_pose / B,

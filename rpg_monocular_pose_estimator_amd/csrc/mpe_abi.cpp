@@ -54,7 +54,8 @@ struct mpe_handle {
   size_t mailbox_cap = 0;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
   int vote_splits = 0;         // 0 = auto
-  int pipeline_mode = 0;       // 0 two-stream staggered pipeline, 3 fused single stream (scan rides in the voting
+  int last_schedule = 0;       // schedule the last large batch actually ran with
+  int pipeline_mode = -1;      // -1 automatic; 0 two-stream staggered pipeline, 3 fused single stream (scan rides in the voting
                                // kernel); 1 / 2 experiment variants of the two-stream schedule
   bool profiling = false;
   int pipeline = 8;  // up to this many sub-batches (each >= 8192 frames) in a two-stream software
@@ -363,12 +364,17 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   HIP_TRY(h, h->work.reserve((size_t)2 * (per + 1) * nsub * sizeof(int)));
   // schedule: 0 two-stream software pipeline (default); 3 fused single stream.  If the probe found no pair of
   // concurrently executing side streams the two-stream pipeline cannot overlap anything -> fused schedule.
+  // pipeline_mode -1 (default) = automatic: the fused single-stream schedule whenever the voting kernel can carry
+  // the scan (its LDS copy of the marker table exists for <= 5 markers), else the two-stream pipeline — unless the
+  // probe finds no pair of concurrently executing side streams, in which case it could not overlap anything.
   int schedule = h->pipeline_mode;
+  if (schedule < 0) schedule = (sp && sp->n_markers <= 5) ? 3 : 0;
   if (schedule == 0 && sp && sp->n_markers <= 5) {
     const int rc = pick_concurrent_streams(h);
     if (rc) return rc;
     if (h->streams_concurrent == 0) schedule = 3;
   }
+  h->last_schedule = schedule;
   if (schedule == 3) {
     // Fused schedule, ONE stream: the voting kernel of sub-batch s carries the image scan of sub-batch
     // s + 1 on its idle memory pipeline (ScanRider in mpe_kernels.hip).
@@ -437,7 +443,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   }
   if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
   hipStream_t sa = h->sub_stream[0], sb = h->sub_stream[1], sc = h->sub_stream[2];
-  const int mode = h->pipeline_mode;
+  const int mode = schedule;
   HIP_TRY(h, hipEventRecord(h->fork_ev, h->stream));
   HIP_TRY(h, hipStreamWaitEvent(sa, h->fork_ev, 0));
   HIP_TRY(h, hipStreamWaitEvent(sb, h->fork_ev, 0));
@@ -667,6 +673,7 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "lds_budget") *value = h->lds_budget;
   else if (n == "vote_splits") *value = h->vote_splits;
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
+  else if (n == "last_schedule") *value = h->last_schedule;
   else return fail(h, MPE_ERR_ARG, "unknown option");
   return MPE_OK;
 }

@@ -57,6 +57,11 @@ __device__ __forceinline__ unsigned gt_word(unsigned w, unsigned kk, unsigned se
   const unsigned t = (w & 0x7F7F7F7Fu) + kk;
   return (sel & (t & w)) | (~sel & (t | w));
 }
+// Cheap necessary condition: the bytewise OR of the four words is >= every byte, so if no byte of the OR
+// exceeds thr none of the 16 does (no false negative; a hit is confirmed with any_gt16).
+__device__ __forceinline__ unsigned maybe_gt16(const uint4& v, ThrTest q) {
+  return gt_word(v.x | v.y | v.z | v.w, q.kk, q.sel) & 0x80808080u;
+}
 __device__ __forceinline__ unsigned any_gt16(const uint4& v, ThrTest q) {
   const unsigned r = gt_word(v.x, q.kk, q.sel) | gt_word(v.y, q.kk, q.sel) | gt_word(v.z, q.kk, q.sel) |
                      gt_word(v.w, q.kk, q.sel);
@@ -97,7 +102,10 @@ __global__ __launch_bounds__(256) void k1a_scan(const uint4* __restrict__ px, u6
     }
     u64 b[K1A_UNROLL];
 #pragma unroll
-    for (int k = 0; k < K1A_UNROLL; ++k) b[k] = __ballot(any_gt16(v[k], thr) != 0);
+    for (int k = 0; k < K1A_UNROLL; ++k) {
+      b[k] = __ballot(maybe_gt16(v[k], thr) != 0);
+      if (b[k]) b[k] = __ballot(any_gt16(v[k], thr) != 0);  // wave-uniform, rare on dark frames
+    }
     if (lane == 0) {
       ulonglong2* out = reinterpret_cast<ulonglong2*>(flags + c * K1A_UNROLL);
 #pragma unroll
@@ -1269,7 +1277,8 @@ struct ScanRider {
 #pragma unroll
     for (int k = 0; k < K2_SCAN_R; ++k) {
       const uint4 v = stage[64 * k + lane];
-      b[k] = __ballot(any_gt16(v, thr) != 0);
+      b[k] = __ballot(maybe_gt16(v, thr) != 0);
+      if (b[k]) b[k] = __ballot(any_gt16(v, thr) != 0);  // wave-uniform, rare on dark frames
     }
     asm volatile("" ::: "memory");  // staging reads are done before the next round overwrites them
     if (lane == 0) {

@@ -671,15 +671,19 @@ def test_full_size_batch_properties(orc):
         return out
 
     assert h.get_option("streams_concurrent") == -1
+    h.set_option("pipeline_mode", 0)                       # two-stream software pipeline
     piped = run(frames, 8)
-    assert h.get_option("streams_concurrent") in (0, 1)   # probed at the first pipelined call (1 = overlap verified)
+    assert h.get_option("streams_concurrent") in (0, 1)   # probed at the first two-stream call (1 = overlap verified)
     plain = run(frames, 1)
     assert torch.equal(piped, plain)
     # fused schedule: the image scan of sub-batch s + 1 rides inside the voting kernel of sub-batch s (LDS DMA)
     h.set_option("pipeline_mode", 3)
     fused = run(frames, 8)
-    h.set_option("pipeline_mode", 0)
+    assert h.get_option("last_schedule") == 3
     assert torch.equal(fused, plain)
+    h.set_option("pipeline_mode", -1)                      # automatic = fused for a 5-marker object
+    piped = run(frames, 8)
+    assert h.get_option("last_schedule") == 3 and torch.equal(piped, plain)
     flipped = torch.flip(frames, dims=[0]).contiguous()
     torch.cuda.synchronize()
     rev = run(flipped, 8)
