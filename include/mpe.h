@@ -288,13 +288,18 @@ int mpe_last_kernel_ms_sub(mpe_handle* h, int sub_batch, float ms[4]);
 int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
 
 /* Tuning knobs that are not part of the reference surface: "lds_budget" (bytes of LDS per frame
- * for the blob bitmaps, 8192..163840) and "vote_splits" (workgroups per frame in the voting
- * kernel, 0 = auto), "pipeline" (max sub-batches of >= 8192 frames run as a two-stream software
- * pipeline, default 8, 1 = off). */
+ * for the blob bitmaps, 8192..163840), "vote_splits" (workgroups per frame in the voting kernel,
+ * 0 = auto), "pipeline" (a large call is cut into up to this many sub-batches of >= 8192 frames,
+ * default 8, 1 = one chain of four kernels), "pipeline_mode" (how the sub-batches are scheduled:
+ * -1 automatic (default) = 3 for marker sets of <= 5 markers, else 0;  0 = two-stream software
+ * pipeline, the scan of sub-batch s+1 beside the voting of sub-batch s;  3 = fused, one stream: the
+ * scan of sub-batch s+1 rides inside the voting kernel of sub-batch s), "k1a_dummy_lds" (occupancy cap
+ * of the stand-alone scan kernel in mode 0).  Results are bit-identical in every mode. */
 int mpe_set_option(mpe_handle* h, const char* name, int value);
 /* Read an option back.  Also "streams_concurrent": 1 once the library has verified (spin-kernel probe at
  * the first large batch) that its two pipeline side streams execute concurrently, 0 if no concurrent
- * pair was found (the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues), -1 not probed yet. */
+ * pair was found (the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues), -1 not probed yet;
+ * "last_schedule": the pipeline_mode the last large batch actually ran with. */
 int mpe_get_option(mpe_handle* h, const char* name, int* value);
 
 /* library / device introspection */
