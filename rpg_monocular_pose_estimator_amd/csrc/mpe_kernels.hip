@@ -13,6 +13,9 @@
 //   K2   k2_vote    : one workgroup per frame; every (detection triple, marker permutation) P3P
 //                     problem is one work item; FP64 Kneip P3P + reprojection voting with LDS
 //                     integer atomics.  (reference: pose_estimator.cpp:544-702)
+//                     k2_vote<true> additionally carries the image scan of the NEXT sub-batch on
+//                     its idle memory pipeline (ScanRider: global_load_lds LDS-DMA rounds served
+//                     between pieces of P3P arithmetic) — the default schedule for <= 5 markers.
 //   K3   k3_tail    : one lane per frame; histogram peeling, checkCorrespondences, Kabsch,
 //                     Gauss-Newton refine + covariance.  (pose_estimator.cpp:344-370, 394-542,
 //                     733-792, 908-994)
@@ -1260,13 +1263,22 @@ struct ScanRider {
   __device__ __forceinline__ void issue() {
     if (pending || c >= n_chunks) return;
     asm volatile("" ::: "memory");
-    const uint4* p = px + (size_t)c * (K2_SCAN_R * 64) + (threadIdx.x & 63);
-#pragma unroll
-    for (int k = 0; k < K2_SCAN_R; ++k)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 64 * k),
-                                       (__attribute__((address_space(3))) void*)(stage + 64 * k), 16, 0, 0);
+    // one global base address and one LDS base (M0) per round: the instruction's immediate offset moves BOTH
+    // the memory address and the LDS address, and chunk layout == staging layout (1 KiB per load)
+    const uint4* p = px + (size_t)c * (K2_SCAN_R * 64) + (threadIdx.x & 63) + 64 * (K2_SCAN_R / 2);
+    uint4* l = stage + 64 * (K2_SCAN_R / 2);
+    dma_rounds<0>(p, l);
     asm volatile("" ::: "memory");
     pending = true;
+  }
+  template <int K>
+  static __device__ __forceinline__ void dma_rounds(const uint4* p, uint4* l) {
+    if constexpr (K < K2_SCAN_R) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                       (__attribute__((address_space(3))) void*)l, 16,
+                                       (K - K2_SCAN_R / 2) * 1024, 0);
+      dma_rounds<K + 1>(p, l);
+    }
   }
   // test the staged round and write its flag words
   __device__ __forceinline__ void consume() {
