@@ -1286,11 +1286,22 @@ struct ScanRider {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA writes have landed in LDS
     const int lane = threadIdx.x & 63;
     u64 b[K2_SCAN_R];
+    // Three levels, each a necessary condition for the next (bytewise OR >= every operand byte): the OR of the
+    // whole round's words (most rounds of a dark frame stop here), then per segment, then the exact test.
+    uint4 v[K2_SCAN_R];
+    unsigned all = 0;
 #pragma unroll
     for (int k = 0; k < K2_SCAN_R; ++k) {
-      const uint4 v = stage[64 * k + lane];
-      b[k] = __ballot(maybe_gt16(v, thr) != 0);
-      if (b[k]) b[k] = __ballot(any_gt16(v, thr) != 0);  // wave-uniform, rare on dark frames
+      v[k] = stage[64 * k + lane];
+      all |= v[k].x | v[k].y | v[k].z | v[k].w;
+      b[k] = 0;
+    }
+    if (__ballot((gt_word(all, thr.kk, thr.sel) & 0x80808080u) != 0)) {  // wave-uniform
+#pragma unroll
+      for (int k = 0; k < K2_SCAN_R; ++k) {
+        b[k] = __ballot(maybe_gt16(v[k], thr) != 0);
+        if (b[k]) b[k] = __ballot(any_gt16(v[k], thr) != 0);
+      }
     }
     asm volatile("" ::: "memory");  // staging reads are done before the next round overwrites them
     if (lane == 0) {
