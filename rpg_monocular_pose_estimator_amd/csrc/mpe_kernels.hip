@@ -1510,8 +1510,10 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
       solve_quartic(F0, F1, F2, F3, F4, root);
 #elif defined(MPE_K2_FAST_QUARTIC)
       solve_quartic_fast(F0, F1, F2, F3, F4, root);
-#else
+#elif defined(MPE_K2_QUARTIC_V1)
       solve_quartic_lit(F0, F1, F2, F3, F4, root);
+#else
+      solve_quartic_lit2(F0, F1, F2, F3, F4, root);
 #endif
 #ifdef MPE_K2_DEBUG
       if (tc0 + ti == MPE_K2_DEBUG_TRI && pj == MPE_K2_DEBUG_PERM)
@@ -2274,7 +2276,7 @@ __global__ __launch_bounds__(64) void k_quartic_batch(const double* __restrict__
   const double* a = factors + (size_t)i * 5;
   double r[4];
   if (variant == 1)
-    solve_quartic_lit(a[0], a[1], a[2], a[3], a[4], r);  // the voting kernel's division / sqrt sequences
+    solve_quartic_lit2(a[0], a[1], a[2], a[3], a[4], r);  // the voting kernel's variant
   else
     solve_quartic(a[0], a[1], a[2], a[3], a[4], r);  // IEEE operators (validation kernel)
   for (int k = 0; k < 4; ++k) roots[(size_t)i * 4 + k] = r[k];

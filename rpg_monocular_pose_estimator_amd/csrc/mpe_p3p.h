@@ -315,6 +315,95 @@ __device__ __forceinline__ C2 cpow_third_lit(C2 z) {
   sincos(phi, &s, &c);
   return {rho * c, rho * s};
 }
+// ---- cheaper forms of the same operations (MPE_K2_QUARTIC_V2) -----------------------------------------
+// x / c for a compile-time constant c: reciprocal constant + one residual correction (3 ops, <= 1 ulp)
+__device__ __forceinline__ double div_const(double a, double c, double rc) {
+  const double q = a * rc;
+  const double r = __builtin_fma(-c, q, a);
+  return __builtin_fma(r, rc, q);
+}
+// a / den with a ready approximation rden of 1/den (relative error ~1e-16): residual-corrected product
+__device__ __forceinline__ double div_with_rcp(double a, double den, double rden) {
+  const double q = a * rden;
+  const double r = __builtin_fma(-den, q, a);
+  return __builtin_fma(r, rden, q);
+}
+// (a + ib) / (c + id), Smith's algorithm as cdiv_lit; the two quotients share one reciprocal of denom
+__device__ __forceinline__ C2 cdiv_lit2(C2 n, C2 d) {
+  const double a = n.re, b = n.im, c = d.re, e = d.im;
+  if (fabs(c) < fabs(e)) {
+    const double ratio = div_nr(c, e), denom = c * ratio + e, x = rcp_nr(denom);
+    return {div_with_rcp(a * ratio + b, denom, x), div_with_rcp(b * ratio - a, denom, x)};
+  }
+  const double ratio = div_nr(e, c), denom = e * ratio + c, x = rcp_nr(denom);
+  return {div_with_rcp(b * ratio + a, denom, x), div_with_rcp(b - a * ratio, denom, x)};
+}
+// Principal complex cube root (= std::pow(z, 1/3.) of p3p.cpp:262,266 through its polar form) without the
+// double-precision atan2 / sincos / cbrt (~330 VALU ops): a single-precision polar seed (relative error
+// ~1e-6) refined by two Newton steps w <- (2w + z / w^2) / 3 in double (quadratic: 1e-6 -> 1e-12 -> rounding).
+// z is first scaled by a power of 8 into [1/8, 8) so that the float seed cannot overflow or flush.
+__device__ __forceinline__ C2 cpow_third_newton(C2 z) {
+  if (z.im == 0.0 && z.re > 0.0) return {cbrt(z.re), 0.0};
+  const double m = fmax(fabs(z.re), fabs(z.im));
+  if (m == 0.0) return {0.0, 0.0};  // pow(0, 1/3): rho = 0
+  const int e = ilogb(m);                       // NaN / inf propagate through the arithmetic below
+  const int k = (e >= 0 ? e : e - 2) / 3;       // floor(e / 3)
+  const double a = ldexp(z.re, -3 * k), b = ldexp(z.im, -3 * k);
+  const float af = (float)a, bf = (float)b;
+  const float rho = cbrtf(sqrtf(af * af + bf * bf));
+  const float phi = atan2f(bf, af) * (1.0f / 3.0f);
+  double wr = (double)(rho * __cosf(phi)), wi = (double)(rho * __sinf(phi));
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double sr = wr * wr - wi * wi, si = 2.0 * wr * wi;  // w^2
+    const double in = rcp_nr(sr * sr + si * si);
+    const double tr = (a * sr + b * si) * in, ti = (b * sr - a * si) * in;  // z / w^2
+    wr = (2.0 * wr + tr) * (1.0 / 3.0);
+    wi = (2.0 * wi + ti) * (1.0 / 3.0);
+  }
+  return {ldexp(wr, k), ldexp(wi, k)};
+}
+__device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C, double D, double E, double rr[4]) {
+  const double A_pw2 = A * A, B_pw2 = B * B;
+  const double A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B;
+  const double A_pw4 = A_pw3 * A, B_pw4 = B_pw3 * B;
+  // one reciprocal of A serves all ten divisions by A, 2A^2 .. 256A^4 (the factors are powers of two: exact)
+  const double r1 = rcp_nr(A), r2 = r1 * r1, r3 = r2 * r1, r4 = r2 * r2;
+  const double alpha = div_with_rcp(-3 * B_pw2, 8 * A_pw2, 0.125 * r2) + div_with_rcp(C, A, r1);
+  const double beta = div_with_rcp(B_pw3, 8 * A_pw3, 0.125 * r3) - div_with_rcp(B * C, 2 * A_pw2, 0.5 * r2) +
+                      div_with_rcp(D, A, r1);
+  const double gamma = div_with_rcp(-3 * B_pw4, 256 * A_pw4, 0.00390625 * r4) +
+                       div_with_rcp(B_pw2 * C, 16 * A_pw3, 0.0625 * r3) - div_with_rcp(B * D, 4 * A_pw2, 0.25 * r2) +
+                       div_with_rcp(E, A, r1);
+  const double alpha_pw2 = alpha * alpha, alpha_pw3 = alpha_pw2 * alpha;
+  const double Pr = div_const(-alpha_pw2, 12.0, 1.0 / 12.0) - gamma;
+  const double Qr = div_const(-alpha_pw3, 108.0, 1.0 / 108.0) + div_const(alpha * gamma, 3.0, 1.0 / 3.0) -
+                    (beta * beta) * 0.125;
+  const C2 q2 = cpow2_real(Qr), p3 = cpow3_real(Pr);
+  const C2 disc = {q2.re * 0.25 + div_const(p3.re, 27.0, 1.0 / 27.0), q2.im * 0.25 + div_const(p3.im, 27.0, 1.0 / 27.0)};
+  const C2 sq = csqrt_lit(disc);
+  const C2 R = {-Qr * 0.5 + sq.re, sq.im};
+  const C2 U = cpow_third_newton(R);
+  C2 y;
+  const double a56 = div_const(-5.0 * alpha, 6.0, 1.0 / 6.0);
+  if (U.re == 0.0) {
+    const C2 qc = cpow_third_newton(C2{Qr, 0.0});
+    y = {a56 - qc.re, -qc.im};
+  } else {
+    const C2 t = cdiv_lit2(C2{Pr, 0.0}, cscale(U, 3.0));
+    y = {a56 - t.re + U.re, -t.im + U.im};
+  }
+  const C2 w = csqrt_lit(C2{alpha + 2.0 * y.re, 2.0 * y.im});
+  const C2 bw = cdiv_lit2(C2{2.0 * beta, 0.0}, w);
+  const C2 base = {3.0 * alpha + 2.0 * y.re, 2.0 * y.im};
+  const C2 s1 = csqrt_lit(C2{-(base.re + bw.re), -(base.im + bw.im)});
+  const C2 s2 = csqrt_lit(C2{-(base.re - bw.re), -(base.im - bw.im)});
+  const double off = div_with_rcp(-B, 4.0 * A, 0.25 * r1);
+  rr[0] = off + 0.5 * (w.re + s1.re);
+  rr[1] = off + 0.5 * (w.re - s1.re);
+  rr[2] = off + 0.5 * (-w.re + s2.re);
+  rr[3] = off + 0.5 * (-w.re - s2.re);
+}
 __device__ __forceinline__ void solve_quartic_lit(double A, double B, double C, double D, double E, double rr[4]) {
   const double A_pw2 = A * A, B_pw2 = B * B;
   const double A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B;
