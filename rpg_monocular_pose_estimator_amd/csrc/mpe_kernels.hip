@@ -1231,7 +1231,7 @@ size_t k2_table_bytes(int n_markers) {
 // wave tests the staged segments against the threshold (SWAR + ballot, the same arithmetic as
 // k1a_scan), writes the flag words and starts the next round of loads.
 #ifndef K2_SCAN_R
-#define K2_SCAN_R 6  // 1 KiB wave-loads per round = KiB of staging LDS per wave
+#define K2_SCAN_R 4  // 1 KiB wave-loads per round = KiB of staging LDS per wave
 #endif
 struct ScanArgs {
   const uint4* px;   // pixels of the region to scan, 16-byte segments
@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   const mpe_detections* d = dets + f;
   const int n_d = d->n, n_m = sp.n_markers;
   typename std::conditional<SCAN, ScanRider, NoRider>::type rider;
-  if constexpr (SCAN) rider.init(scan, smem + (size_t)(n_m - 3) * 2 * blockDim.x * sizeof(double));
+  if constexpr (SCAN) rider.init(scan, smem);  // (this variant keeps the back-projections in registers)
   if (n_d < 4 || d->status != 0 || n_m < 4) {  // min_num_leds_detected_ (pose_estimator.h:78)
     rider.drain();
     return;
@@ -1388,8 +1388,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   //   [0] p_1 [1] p_2 [2] d_12 [3] valid [4] packed marker indices [5..10] eta-frame unused markers (<= 2)
   double* s_tab = nullptr;
   if constexpr (SCAN) {
-    s_tab = reinterpret_cast<double*>(smem + (size_t)nuo * 2 * blockDim.x * sizeof(double) +
-                                      (size_t)(blockDim.x >> 6) * (K2_SCAN_R * 1024));
+    s_tab = reinterpret_cast<double*>(smem + (size_t)(blockDim.x >> 6) * (K2_SCAN_R * 1024));
     for (int i = tid; i < n_perms * K2_LTAB; i += nthr) {
       const int pe = i / K2_LTAB, fld = i - pe * K2_LTAB;
       const int src = fld < 5 ? 12 + fld : 13 + fld;  // 12..16, 18..23
@@ -1513,7 +1512,10 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
 #elif defined(MPE_K2_QUARTIC_V1)
       solve_quartic_lit(F0, F1, F2, F3, F4, root);
 #else
-      solve_quartic_lit2(F0, F1, F2, F3, F4, root);
+      solve_quartic_lit2(F0, F1, F2, F3, F4, root, [&]() {
+        rider.consume();
+        rider.issue();
+      });
 #endif
 #ifdef MPE_K2_DEBUG
       if (tc0 + ti == MPE_K2_DEBUG_TRI && pj == MPE_K2_DEBUG_PERM)
@@ -1521,6 +1523,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
                (int)swap, pjs, f_1, f_2, b, p_1, p_2, d_12, F0, F1, F2, F3, F4, root[0], root[1], root[2], root[3]);
 #endif
       rider.consume();  // P1
+      rider.issue();
       // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
       const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
       const double tol2 = sp.back_tol * sp.back_tol;
@@ -1561,6 +1564,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
         const bool may_vote = live && finite_pose;
         const double T00 = tr[0], T01 = tr[1], T02 = tr[2], T10 = tr[3], T11 = tr[4], T12 = tr[5], T20 = tr[6],
                      T21 = tr[7], T22 = tr[8];
+        double q0u = 0, q0v = 0, q1u = 0, q1v = 0;
         for (int j = 0; j < nuo; ++j) {
           const double* mk = SCAN ? lt + 5 + 3 * j : e + 18 + 3 * j;
           const double v0 = mk[0] - Cx, v1 = mk[1] - Cy, v2 = mk[2] - Cz;
@@ -1572,8 +1576,19 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           const double Y = T01 * w0 + T11 * w1 + T21 * w2;
           const double Z = T02 * w0 + T12 * w1 + T22 * w2;
           const double iZ = rcp_nr(Z);
-          s_q[(2 * j) * nthr + tid] = (fx * X + cx * Z) * iZ;
-          s_q[(2 * j + 1) * nthr + tid] = (fy * Y + cy * Z) * iZ;
+          const double qu = (fx * X + cx * Z) * iZ, qv = (fy * Y + cy * Z) * iZ;
+          if constexpr (SCAN) {  // <= 2 unused markers in this variant: registers instead of the LDS columns
+            if (j == 0) {
+              q0u = qu;
+              q0v = qv;
+            } else {
+              q1u = qu;
+              q1v = qv;
+            }
+          } else {
+            s_q[(2 * j) * nthr + tid] = qu;
+            s_q[(2 * j + 1) * nthr + tid] = qv;
+          }
 #ifdef MPE_K2_DEBUG
           if (tc0 + ti == MPE_K2_DEBUG_TRI && pj == MPE_K2_DEBUG_PERM)
             printf("DBG   k %d j %d meta %.17g %.17g %.17g XYZ %.17g %.17g %.17g uv %.17g %.17g\n", k, j, e[18 + 3 * j],
@@ -1588,7 +1603,9 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           double best = INFINITY;
           int bj = 0;
           for (int jj = 0; jj < nuo; ++jj) {
-            const double du = au - s_q[(2 * jj) * nthr + tid], dv = av - s_q[(2 * jj + 1) * nthr + tid];
+            const double bu = SCAN ? (jj == 0 ? q0u : q1u) : s_q[(2 * jj) * nthr + tid];
+            const double bv = SCAN ? (jj == 0 ? q0v : q1v) : s_q[(2 * jj + 1) * nthr + tid];
+            const double du = au - bu, dv = av - bv;
             const double d2 = du * du + dv * dv;
             if (d2 < best) {
               best = d2;
@@ -1670,8 +1687,8 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
     sa.flags = (u64*)scan_flags;
     sa.n_chunks = (int)(scan_bytes / chunk_bytes);
     sa.thr = make_thr_test(scan_thr);
-    lds += (size_t)(threads / 64) * chunk_bytes +
-           (size_t)sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2) * K2_LTAB * sizeof(double);
+    lds = (size_t)(threads / 64) * chunk_bytes +
+          (size_t)sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2) * K2_LTAB * sizeof(double);
     if (scanned_bytes) *scanned_bytes = (size_t)sa.n_chunks * chunk_bytes;
     hipLaunchKernelGGL(k2_vote<true>, dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
                        splits, sa);

@@ -363,7 +363,14 @@ __device__ __forceinline__ C2 cpow_third_newton(C2 z) {
   }
   return {ldexp(wr, k), ldexp(wi, k)};
 }
-__device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C, double D, double E, double rr[4]) {
+struct NoService {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `service` is called at two points inside (after the cube root, after w): the voting kernel's scan rider uses
+// them to retire / start LDS-DMA rounds behind the arithmetic; a no-op everywhere else.
+template <class Service = NoService>
+__device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C, double D, double E, double rr[4],
+                                                   Service service = Service()) {
   const double A_pw2 = A * A, B_pw2 = B * B;
   const double A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B;
   const double A_pw4 = A_pw3 * A, B_pw4 = B_pw3 * B;
@@ -384,6 +391,7 @@ __device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C,
   const C2 sq = csqrt_lit(disc);
   const C2 R = {-Qr * 0.5 + sq.re, sq.im};
   const C2 U = cpow_third_newton(R);
+  service();
   C2 y;
   const double a56 = div_const(-5.0 * alpha, 6.0, 1.0 / 6.0);
   if (U.re == 0.0) {
@@ -395,6 +403,7 @@ __device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C,
   }
   const C2 w = csqrt_lit(C2{alpha + 2.0 * y.re, 2.0 * y.im});
   const C2 bw = cdiv_lit2(C2{2.0 * beta, 0.0}, w);
+  service();
   const C2 base = {3.0 * alpha + 2.0 * y.re, 2.0 * y.im};
   const C2 s1 = csqrt_lit(C2{-(base.re + bw.re), -(base.im + bw.im)});
   const C2 s2 = csqrt_lit(C2{-(base.re - bw.re), -(base.im - bw.im)});
