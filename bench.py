@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=131072, help="frames per GPU per step (device-resident batch, 47 GB)")
+    ap.add_argument("--frames", type=int, default=262144, help="frames per GPU per step (device-resident batch, 95 GB)")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--k1a-lds", type=int, default=-1, help="tuning: dummy LDS per scan block (-1 = automatic)")
     ap.add_argument("--pipeline-mode", type=int, default=-1,
                     help="-1 automatic (fused single-stream schedule for <= 5 markers), 0 two-stream pipeline, 3 fused")
-    ap.add_argument("--pipeline", type=int, default=8, help="sub-batches per step on separate HIP streams (1 = off)")
+    ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
     args = ap.parse_args()
 
     import torch

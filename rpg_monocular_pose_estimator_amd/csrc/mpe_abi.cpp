@@ -58,9 +58,8 @@ struct mpe_handle {
   int pipeline_mode = -1;      // -1 automatic; 0 two-stream staggered pipeline, 3 fused single stream (scan rides in the voting
                                // kernel); 1 / 2 experiment variants of the two-stream schedule
   bool profiling = false;
-  int pipeline = 8;  // up to this many sub-batches (each >= 8192 frames) in a two-stream software
-                     // pipeline: the HBM-bound scan of sub-batch i+1 runs beside the FP64-bound voting
-                     // of sub-batch i (+10-13 % at >= 64k frames per call; 1 = off)
+  int pipeline = 16;  // a large call is cut into up to this many sub-batches (about 16384 frames each, never
+                      // below 8192) that the schedules pipeline against each other; 1 = one chain of kernels
   static const int kMaxSub = 16;
   hipStream_t sub_stream[kMaxSub] = {};
   bool streams_probed = false;  // sub_stream[0] / [1] verified to execute concurrently
@@ -333,9 +332,13 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     HIP_TRY(h, h->mtab.reserve(k2_table_bytes(sp->n_markers)));
     HIP_TRY(h, launch_k2_prep(*sp, static_cast<double*>(h->mtab.p), h->stream));
   }
-  int nsub = !sp ? 1 : h->pipeline;
+  // sub-batches of about 16384 frames (measured sweet spot at 752x480: 8192 and 32768 are 3-5 % slower), never
+  // below 8192 (tail effects then cost more than the overlap gains)
+  int nsub = n_frames / 16384;
+  if (nsub < 2) nsub = n_frames / 8192;
+  if (nsub > h->pipeline) nsub = h->pipeline;
   if (nsub > mpe_handle::kMaxSub) nsub = mpe_handle::kMaxSub;
-  while (nsub > 1 && n_frames < 8192 * nsub) nsub /= 2;  // sub-batches below ~8k frames lose more than overlap gains
+  if (nsub < 1 || !sp) nsub = 1;
   h->have_ms = false;
   HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
   if (nsub <= 1) {
