@@ -16,7 +16,8 @@ def shard_bounds(n_frames, rank, world):
 
 
 def gather_records(local_bytes, world, out=None):
-    """all_gather of equally sized uint8 record buffers (torch tensors, CPU/gloo or CUDA/nccl)."""
+    """all_gather of equally sized uint8 record buffers (torch tensors, CPU/gloo or CUDA/nccl): every rank
+    ends up with every record.  Costs world x the traffic of gather_records_to_root."""
     import torch
     import torch.distributed as dist
     if world == 1:
@@ -25,6 +26,24 @@ def gather_records(local_bytes, world, out=None):
         out = torch.empty(world * local_bytes.numel(), dtype=torch.uint8, device=local_bytes.device)
     dist.all_gather_into_tensor(out, local_bytes)
     return out
+
+
+def gather_records_to_root(local_bytes, rank, world, out=None, dst=0, async_op=False):
+    """The per-rank pose gather: rank `dst` receives the record buffers of all ranks (in rank order) into `out`
+    (world * len bytes; allocated if None), the others only send theirs — point-to-point traffic over xGMI,
+    432 B per frame and rank.  async_op=True returns (out, work): the transfer then runs beside the next batch's
+    kernels; call work.wait() before reading `out` on `dst` / before overwriting `local_bytes`."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return (local_bytes, None) if async_op else local_bytes
+    pieces = None
+    if rank == dst:
+        if out is None:
+            out = torch.empty(world * local_bytes.numel(), dtype=torch.uint8, device=local_bytes.device)
+        pieces = list(out.view(world, -1).unbind(0))
+    work = dist.gather(local_bytes, pieces, dst=dst, async_op=async_op)
+    return (out, work) if async_op else out
 
 
 def records_from_bytes(t):

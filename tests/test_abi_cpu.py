@@ -105,8 +105,15 @@ def _gloo_worker(rank, world, port, tmpdir):
         rec[k] = local[k]
     t = torch.from_numpy(np.frombuffer(rec.tobytes(), np.uint8).copy())
     g = par.gather_records(t, world)
+    # the bench's pattern: gather to rank 0 only, asynchronously, double-buffered
+    root, work = par.gather_records_to_root(t, rank, world, async_op=True)
+    work.wait()
+    root_sync = par.gather_records_to_root(t, rank, world)
     if rank == 0:
-        np.save(os.path.join(tmpdir, "gathered.npy"), par.records_from_bytes(g))
+        assert torch.equal(root, g) and torch.equal(root_sync, g)
+        np.save(os.path.join(tmpdir, "gathered.npy"), par.records_from_bytes(root))
+    else:
+        assert root is None and root_sync is None
     dist.barrier()
     dist.destroy_process_group()
 
