@@ -1517,11 +1517,6 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
         rider.issue();
       });
 #endif
-#ifdef MPE_K2_DEBUG
-      if (tc0 + ti == MPE_K2_DEBUG_TRI && pj == MPE_K2_DEBUG_PERM)
-        printf("DBG swap %d pjs %d f_1 %.17g f_2 %.17g b %.17g p_1 %.17g p_2 %.17g d_12 %.17g\nF %.17g %.17g %.17g %.17g %.17g\nroots %.17g %.17g %.17g %.17g\n",
-               (int)swap, pjs, f_1, f_2, b, p_1, p_2, d_12, F0, F1, F2, F3, F4, root[0], root[1], root[2], root[3]);
-#endif
       rider.consume();  // P1
       rider.issue();
       // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
@@ -1549,11 +1544,6 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
         // isFinite([R C]) (pose_estimator.cpp:653): R and C are finite iff these are
         const double z = (cos_alpha - cos_alpha) + (sin_alpha - sin_alpha) + (sin_theta - sin_theta) +
                          (cos_theta - cos_theta) + (Cx - Cx) + (Cy - Cy) + (Cz - Cz);
-#ifdef MPE_K2_DEBUG
-        if (tc0 + ti == MPE_K2_DEBUG_TRI && pj == MPE_K2_DEBUG_PERM)
-          printf("DBG k %d rt %.17g cn %.17g cd %.17g sa %.17g ca %.17g st %.17g C %.17g %.17g %.17g z %g\n", k, rt, cn, cd,
-                 sin_alpha, cos_alpha, sin_theta, Cx, Cy, Cz, z);
-#endif
         bool finite_pose = true;
         if (!(z == 0.0)) {
           if constexpr (SCAN)
@@ -1589,11 +1579,6 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
             s_q[(2 * j) * nthr + tid] = qu;
             s_q[(2 * j + 1) * nthr + tid] = qv;
           }
-#ifdef MPE_K2_DEBUG
-          if (tc0 + ti == MPE_K2_DEBUG_TRI && pj == MPE_K2_DEBUG_PERM)
-            printf("DBG   k %d j %d meta %.17g %.17g %.17g XYZ %.17g %.17g %.17g uv %.17g %.17g\n", k, j, e[18 + 3 * j],
-                   e[18 + 3 * j + 1], e[18 + 3 * j + 2], X, Y, Z, (fx * X + cx * Z) * iZ, (fy * Y + cy * Z) * iZ);
-#endif
         }
         // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
         bool any = false;
@@ -1616,11 +1601,6 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           // root is only taken inside the rounding band around tol^2
           bool within = best < tol2 * (1.0 - 1e-14);
           if (!within && best < tol2 * (1.0 + 1e-14)) within = sqrt(best) < sp.back_tol;
-#ifdef MPE_K2_DEBUG
-          if (tc0 + ti == MPE_K2_DEBUG_TRI && pj == MPE_K2_DEBUG_PERM)
-            printf("DBG     k %d a %d au %.6f av %.6f best %.6f bj %d within %d tol2 %.6f nuo %d n_d %d c %d %d %d p %d %d %d tid %d nthr %d\n", k, a, au, av, best, bj,
-                   (int)within, tol2, nuo, n_d, c0, c1, c2, p0, p1, p2, tid, nthr);
-#endif
           if (within && may_vote) {
             int mi = -1, cnt = -1;         // bj-th unused marker -> marker index
             for (int m = 0; m < n_m; ++m) {
