@@ -5,10 +5,12 @@ on synthetic 752x480 frames with 5 LEDs (BASELINE.json configs[1] = "C2"), N GPU
 A "step" is one pass of the hot path (image scan -> blob extraction -> P3P voting -> validate +
 Gauss-Newton refine) over one batch of B device-resident frames per GPU; frames shard
 embarrassingly across ranks (weak scaling: B per GPU fixed), the only collective is the gather of
-the per-frame pose records (RCCL all_gather, 432 B/frame).
+the per-frame pose records to rank 0 (RCCL point-to-point, 432 B/frame, asynchronous, double-buffered).
 
 Prints ONE JSON line (rank 0): metric/value as BASELINE.json, plus
-  roofline      — image-scan kernel (HBM bound): algorithmic bytes (rows*cols per frame) / HIP-event time
+  roofline      — the kernel that moves the image bytes in the timed mode (by default the voting kernel that
+                  carries the scan of the next sub-batch, else k1a_scan): algorithmic bytes (rows*cols per
+                  frame scanned) / HIP-event time of its launches; roofline_isolated = k1a_scan alone
   cpu_baseline  — the CPU oracle (restated reference path, "port") on this box's host cores, bounded sample
 """
 import argparse
