@@ -751,3 +751,53 @@ def test_fused_scan_flags_at_every_threshold_form(orc, thr):
         else:
             assert got["n_det"] == len(und), (thr, i, got["n_det"], len(und))
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["C1", "C2-distractors"])
+def test_fused_schedule_other_shapes(orc, config):
+    """The fused schedule (scan riding in the voting kernel) with 4 markers (one unused marker: the other
+    layout of the LDS table) and with 5 markers + distractor blobs (more detection triples than one 16-entry
+    chunk): bit-identical to the plain chain of kernels, and equal to the oracle on a sample."""
+    import torch
+    B = 32768 + 64
+    if config == "C1":
+        cfg = dict(synth.CONFIGS["C1"])
+    else:
+        cfg = dict(synth.CONFIGS["C2"])
+        cfg["n_distractors"] = 3        # up to 8 detections -> C(8,3) = 56 triples
+    rows, cols = cfg["rows"], cfg["cols"]
+    K, D = synth.camera_for(rows, cols)
+    markers = np.asarray(cfg["markers"])
+    _, spots = synth.make_scenes_batch(cfg, B, seed=77)
+    dev = torch.device("cuda", 0)
+    frames = synth.render_frames_torch(spots, rows, cols, cfg["spot_sigma"], dev, seed=12)
+    torch.cuda.synchronize()
+    P = mpe.demo_params()
+    h = mpe.Handle(0)
+    stream = torch.cuda.Stream(device=dev)
+    h.set_stream(stream.cuda_stream)
+    out = {}
+    for mode, pipeline in ((3, 16), (0, 1)):
+        h.set_option("pipeline_mode", mode)
+        h.set_option("pipeline", pipeline)
+        with torch.cuda.stream(stream):
+            res = torch.zeros(B * mpe.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, res.data_ptr())
+        stream.synchronize()
+        out[mode] = np.frombuffer(res.cpu().numpy().tobytes(), mpe.RESULT_DTYPE)
+        if mode == 3:
+            assert h.get_option("last_schedule") == 3
+    assert out[0].tobytes() == out[3].tobytes()
+    idx = np.random.default_rng(1).choice(B, 64, replace=False)
+    sample = frames[torch.as_tensor(idx, device=dev)].cpu().numpy()
+    ref = orc.estimate_batch(sample, markers, K, D, orc.make_params(), n_threads=8)
+    n_pose = 0
+    for j, i in enumerate(idx):
+        assert out[3]["status"][i] == ref["status"][j], (config, i)
+        if ref["status"][j] == 0:
+            dp, dr = pose_diff(out[3]["T"][i].reshape(4, 4), ref["T"][j].reshape(4, 4))
+            assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (config, i, dp, dr)
+            n_pose += 1
+    assert n_pose >= 20
+    h.close()
