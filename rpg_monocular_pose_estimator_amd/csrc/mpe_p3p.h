@@ -328,15 +328,30 @@ __device__ __forceinline__ double div_with_rcp(double a, double den, double rden
   const double r = __builtin_fma(-den, q, a);
   return __builtin_fma(r, rden, q);
 }
-// (a + ib) / (c + id), Smith's algorithm as cdiv_lit; the two quotients share one reciprocal of denom
+// (a + ib) / (c + id), Smith's algorithm as cdiv_lit with the two cases folded into operand selects (lanes of a
+// wave take both cases, a branch would run both sides): the same operations on the same operands, and the two
+// quotients share one reciprocal of denom.
 __device__ __forceinline__ C2 cdiv_lit2(C2 n, C2 d) {
-  const double a = n.re, b = n.im, c = d.re, e = d.im;
-  if (fabs(c) < fabs(e)) {
-    const double ratio = div_nr(c, e), denom = c * ratio + e, x = rcp_nr(denom);
-    return {div_with_rcp(a * ratio + b, denom, x), div_with_rcp(b * ratio - a, denom, x)};
+  const bool swap = fabs(d.re) < fabs(d.im);
+  const double big = swap ? d.im : d.re, small = swap ? d.re : d.im;
+  const double p = swap ? n.re : n.im, q = swap ? n.im : n.re;
+  const double ratio = div_nr(small, big), denom = small * ratio + big, x = rcp_nr(denom);
+  // swap: (a ratio + b, b ratio - a);  else: (b ratio + a, b - a ratio) = (p ratio + q, -(q ratio - p))
+  const double t = q * ratio - p;
+  return {div_with_rcp(p * ratio + q, denom, x), div_with_rcp(swap ? t : -t, denom, x)};
+}
+// csqrt_lit with its two half-planes folded the same way: t = sqrt((|z| + |re|) / 2), u = im / (2 t);
+// re > 0: (t, u), else (|u|, copysign(t, im)).
+__device__ __forceinline__ C2 csqrt_lit2(C2 z) {
+  if (z.im == 0.0) {
+    if (z.re < 0.0) return {0.0, copysign(sqrt_nr(-z.re), z.im)};
+    return {fabs(sqrt_nr(z.re)), z.im};
   }
-  const double ratio = div_nr(e, c), denom = e * ratio + c, x = rcp_nr(denom);
-  return {div_with_rcp(b * ratio + a, denom, x), div_with_rcp(b - a * ratio, denom, x)};
+  const double d = hypot_acc(z.re, z.im);
+  const double t = sqrt_nr(0.5 * (d + fabs(z.re)));
+  const double u = 0.5 * div_nr(z.im, t);
+  const bool right = z.re > 0.0;
+  return {right ? t : fabs(u), right ? copysign(u, z.im) : copysign(t, z.im)};
 }
 // Principal complex cube root (= std::pow(z, 1/3.) of p3p.cpp:262,266 through its polar form) without the
 // double-precision atan2 / sincos / cbrt (~330 VALU ops): a single-precision polar seed (relative error
@@ -388,7 +403,7 @@ __device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C,
                     (beta * beta) * 0.125;
   const C2 q2 = cpow2_real(Qr), p3 = cpow3_real(Pr);
   const C2 disc = {q2.re * 0.25 + div_const(p3.re, 27.0, 1.0 / 27.0), q2.im * 0.25 + div_const(p3.im, 27.0, 1.0 / 27.0)};
-  const C2 sq = csqrt_lit(disc);
+  const C2 sq = csqrt_lit2(disc);
   const C2 R = {-Qr * 0.5 + sq.re, sq.im};
   const C2 U = cpow_third_newton(R);
   service();
@@ -401,12 +416,12 @@ __device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C,
     const C2 t = cdiv_lit2(C2{Pr, 0.0}, cscale(U, 3.0));
     y = {a56 - t.re + U.re, -t.im + U.im};
   }
-  const C2 w = csqrt_lit(C2{alpha + 2.0 * y.re, 2.0 * y.im});
+  const C2 w = csqrt_lit2(C2{alpha + 2.0 * y.re, 2.0 * y.im});
   const C2 bw = cdiv_lit2(C2{2.0 * beta, 0.0}, w);
   service();
   const C2 base = {3.0 * alpha + 2.0 * y.re, 2.0 * y.im};
-  const C2 s1 = csqrt_lit(C2{-(base.re + bw.re), -(base.im + bw.im)});
-  const C2 s2 = csqrt_lit(C2{-(base.re - bw.re), -(base.im - bw.im)});
+  const C2 s1 = csqrt_lit2(C2{-(base.re + bw.re), -(base.im + bw.im)});
+  const C2 s2 = csqrt_lit2(C2{-(base.re - bw.re), -(base.im - bw.im)});
   const double off = div_with_rcp(-B, 4.0 * A, 0.25 * r1);
   rr[0] = off + 0.5 * (w.re + s1.re);
   rr[1] = off + 0.5 * (w.re - s1.re);
