@@ -1582,8 +1582,13 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
         }
         // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
         bool any = false;
-        for (int a = 0; a < n_d; ++a) {
-          if (a == c0 || a == c1 || a == c2) continue;
+        // the detections that are not part of the triple, ascending (c0 < c1 < c2): the u-th one is found by
+        // skipping over the three used indices — a uniform trip count for the frame and no lane sits out
+        for (int u = 0; u < n_d - 3; ++u) {
+          int a = u;
+          a += (a >= c0);
+          a += (a >= c1);
+          a += (a >= c2);
           const double au = s_px[a][0], av = s_px[a][1];
           double best = INFINITY;
           int bj = 0;
@@ -1602,14 +1607,12 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           bool within = best < tol2 * (1.0 - 1e-14);
           if (!within && best < tol2 * (1.0 + 1e-14)) within = sqrt(best) < sp.back_tol;
           if (within && may_vote) {
-            int mi = -1, cnt = -1;         // bj-th unused marker -> marker index
-            for (int m = 0; m < n_m; ++m) {
-              if (m == p0 || m == p1 || m == p2) continue;
-              if (++cnt == bj) {
-                mi = m;
-                break;
-              }
-            }
+            // bj-th unused marker (ascending) -> marker index: skip over the sorted used indices
+            const int lo = min(p0, min(p1, p2)), hi = max(p0, max(p1, p2)), mid = p0 + p1 + p2 - lo - hi;
+            int mi = bj;
+            mi += (mi >= lo);
+            mi += (mi >= mid);
+            mi += (mi >= hi);
             atomicAdd(&s_hist[a * MPE_MAX_MARKERS + mi], 1u);
             any = true;
           }
