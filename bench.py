@@ -83,10 +83,8 @@ def main():
     _, spots = synth.make_scenes_batch(cfg, B, seed=1000 + rank)
     frames = synth.render_frames_torch(spots, rows, cols, cfg["spot_sigma"], dev, seed=77 + rank)
     # two result buffers: while the records of step k travel to rank 0, step k+1 already writes the other one
-    results2 = [torch.zeros(B * mpe.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
-    results = results2[0]
-    gathered = [torch.zeros(world * B * mpe.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(2)] \
-        if (world > 1 and rank == 0) else [None, None]
+    pipe = parallel.RootGatherPipeline(rank, world, B * mpe.RESULT_DTYPE.itemsize, dev)
+    results = pipe.local(0)
     torch.cuda.synchronize()
 
     h = mpe.Handle(local_rank)
@@ -102,26 +100,19 @@ def main():
     if args.k1a_lds >= 0:
         h.set_option("k1a_dummy_lds", args.k1a_lds)
 
-    pending = [None, None]   # outstanding gather of each buffer
     step_no = [0]
 
     def step():
-        b = step_no[0] & 1 if world > 1 else 0
+        k = step_no[0]
         step_no[0] += 1
         with torch.cuda.stream(work_stream):
-            if pending[b] is not None:      # this buffer's previous gather must have left before it is overwritten
-                pending[b].wait()
-                pending[b] = None
-            h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results2[b].data_ptr())
-            if world > 1:   # the only collective: pose records -> rank 0, asynchronous (runs beside the next step)
-                _, pending[b] = parallel.gather_records_to_root(results2[b], rank, world, out=gathered[b], async_op=True)
+            buf = pipe.local(k)             # (waits until this buffer's previous transfer has left)
+            h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, buf.data_ptr())
+            pipe.submit(k)                  # the only collective: pose records -> rank 0, asynchronous
 
     def barrier():
         with torch.cuda.stream(work_stream):
-            for b in range(2):
-                if pending[b] is not None:
-                    pending[b].wait()
-                    pending[b] = None
+            pipe.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

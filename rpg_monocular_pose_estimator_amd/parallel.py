@@ -46,6 +46,50 @@ def gather_records_to_root(local_bytes, rank, world, out=None, dst=0, async_op=F
     return (out, work) if async_op else out
 
 
+class RootGatherPipeline:
+    """Double-buffered, asynchronous gather of per-step record buffers to rank `dst` (what bench.py does every
+    step): step k writes its records into `local(k)`, `submit(k)` starts the transfer, and the kernels of step
+    k+1 — which write the OTHER local buffer — run beside it.  A buffer is only handed out again after its
+    previous transfer has been waited for.  On `dst`, `gathered(k)` is valid after `wait(k)` / `finish()`."""
+
+    def __init__(self, rank, world, nbytes, device, dst=0):
+        import torch
+        self.rank, self.world, self.dst = rank, world, dst
+        n = 2 if world > 1 else 1
+        self._local = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(n)]
+        self._out = [torch.zeros(world * nbytes, dtype=torch.uint8, device=device) if (world > 1 and rank == dst)
+                     else None for _ in range(n)]
+        self._work = [None] * n
+
+    def _slot(self, step):
+        return step % len(self._local)
+
+    def local(self, step):
+        """Result buffer for `step`; waits (stream-level on CUDA) until its previous transfer has left."""
+        self.wait(step)
+        return self._local[self._slot(step)]
+
+    def submit(self, step):
+        if self.world == 1:
+            return
+        b = self._slot(step)
+        _, self._work[b] = gather_records_to_root(self._local[b], self.rank, self.world, out=self._out[b],
+                                                  dst=self.dst, async_op=True)
+
+    def wait(self, step):
+        b = self._slot(step)
+        if self._work[b] is not None:
+            self._work[b].wait()
+            self._work[b] = None
+
+    def finish(self):
+        for b in range(len(self._work)):
+            self.wait(b)
+
+    def gathered(self, step):
+        return self._local[0] if self.world == 1 else self._out[self._slot(step)]
+
+
 def records_from_bytes(t):
     """uint8 torch tensor (any device) -> numpy structured array of mpe_result records."""
     return np.frombuffer(t.detach().cpu().numpy().tobytes(), dtype=RESULT_DTYPE)

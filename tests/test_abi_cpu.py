@@ -114,6 +114,24 @@ def _gloo_worker(rank, world, port, tmpdir):
         np.save(os.path.join(tmpdir, "gathered.npy"), par.records_from_bytes(root))
     else:
         assert root is None and root_sync is None
+    # several steps through the double-buffered pipeline: every step's records must arrive on rank 0 intact even
+    # though the next step already overwrites the other buffer
+    pipe = par.RootGatherPipeline(rank, world, t.numel(), torch.device("cpu"))
+    seen = []
+    for k in range(5):
+        buf = pipe.local(k)
+        buf.copy_(t)
+        buf[0] = k                       # step marker
+        buf[1] = rank
+        pipe.submit(k)
+        if k >= 1 and rank == 0:         # the PREVIOUS step's gather, read while this step's one is in flight
+            pipe.wait(k - 1)
+            seen.append(pipe.gathered(k - 1).view(world, -1)[:, :2].clone())
+    pipe.finish()
+    if rank == 0:
+        seen.append(pipe.gathered(4).view(world, -1)[:, :2].clone())
+        for k, m in enumerate(seen):
+            assert m[:, 0].tolist() == [k] * world and m[:, 1].tolist() == list(range(world)), (k, m)
     dist.barrier()
     dist.destroy_process_group()
 
