@@ -1,6 +1,7 @@
-"""End-to-end parity soak: N frames through the HIP path (fused schedule) and through the oracle."""
+"""End-to-end parity soak: N frames through the HIP path (default fused schedule) and through the oracle.
+usage (on an MI355X): python tests/soak_parity.py 1048576   — result committed as profiles/round1_parity_soak.json"""
 import os, sys, time, json
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import rpg_monocular_pose_estimator_amd as mpe
 from rpg_monocular_pose_estimator_amd import synth
