@@ -1,5 +1,6 @@
 """End-to-end parity soak: N frames through the HIP path (default fused schedule) and through the oracle.
-usage (on an MI355X): python tests/soak_parity.py 1048576   — result committed as profiles/round1_parity_soak.json"""
+usage (on an MI355X): python tests/soak_parity.py [frames [config [chunk]]]
+python tests/soak_parity.py 1048576   -> profiles/round1_parity_soak.json"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,8 +10,9 @@ import oracle
 oracle.build()
 from oracle import binding as orc
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1048576
-CH = 65536
-cfg = synth.CONFIGS["C2"]; rows, cols = cfg["rows"], cfg["cols"]
+CONFIG = sys.argv[2] if len(sys.argv) > 2 else "C2"
+CH = min(N, int(sys.argv[3]) if len(sys.argv) > 3 else 65536)
+cfg = synth.CONFIGS[CONFIG]; rows, cols = cfg["rows"], cfg["cols"]
 K, D = synth.camera_for(rows, cols); markers = np.asarray(cfg["markers"])
 dev = torch.device("cuda", 0)
 h = mpe.Handle(0); P = mpe.demo_params()
@@ -36,5 +38,5 @@ for part in range(N // CH):
     pose_mis += int((d > 1e-4).sum())
     worst = max(worst, float(d.max()) if len(d) else 0.0)
     print(part, tot, st_mis, pose_mis, worst, round(time.time() - t0), flush=True)
-print(json.dumps({"frames": tot, "status_mismatches": st_mis, "poses_compared": n_pose, "pose_mismatches_gt_1e-4m": pose_mis,
+print(json.dumps({"config": CONFIG, "frames": tot, "status_mismatches": st_mis, "poses_compared": n_pose, "pose_mismatches_gt_1e-4m": pose_mis,
                   "worst_position_difference_m": worst, "schedule": h.get_option("last_schedule")}))
