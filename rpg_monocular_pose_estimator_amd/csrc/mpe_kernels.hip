@@ -346,10 +346,21 @@ __device__ __forceinline__ void set_bit(u64* bm, int wb, int slot, int xb) {
 // visited pixels are marked "positive" (pm) or, when the east neighbour was examined and is 0,
 // "negative" (ng, takes precedence).  (xoff, yoff) turn window coordinates into image
 // coordinates.  Returns false if the step bound was hit.
+__device__ __forceinline__ unsigned bits3_at(const u64* rowp, int xb) {  // branch-free bits3: always two words
+  const int lo = xb - 1, wi = lo >> 6, sh = lo & 63;
+  const u64 v = (rowp[wi] >> sh) | ((rowp[wi + 1] << 1) << (63 - sh));  // (the pools end in a pad word)
+  return (unsigned)v & 7u;
+}
+__device__ __forceinline__ unsigned neighbours_at(const u64* nz, int ro, int wb, int xb) {  // ro = slot * wb
+  const unsigned u3 = bits3_at(nz + ro - wb, xb), m3 = bits3_at(nz + ro, xb), d3 = bits3_at(nz + ro + wb, xb);
+  const unsigned urev = ((u3 & 1u) << 2) | (u3 & 2u) | (u3 >> 2);
+  return (m3 >> 2) | (urev << 1) | ((m3 & 1u) << 4) | (d3 << 5);  // 0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE
+}
 __device__ __forceinline__ bool trace_outer_border(const u64* nz, u64* pm, u64* ng, int wb, int slot0, int xb0, int xoff, int yoff,
                                    PolyAcc& acc) {
   acc.init();
-  unsigned nb = neighbours(nz, wb, slot0, xb0);
+  int ro = slot0 * wb;  // word offset of the current row, advanced by +-wb (no multiplication per step)
+  unsigned nb = neighbours_at(nz, ro, wb, xb0);
   int s = 4;
   const int s_end0 = 4;
   bool hit;
@@ -365,25 +376,48 @@ __device__ __forceinline__ bool trace_outer_border(const u64* nz, u64* pm, u64* 
   }
   const int x1b = xb0 + dir_dx(s), s1 = slot0 + dir_dy(s);
   int xb = xb0, slot = slot0;
+  long long a00 = 0, a10 = 0, a01 = 0;
+  int xmin = xb, xmax = xb, ymin = slot, ymax = slot;  // window coordinates, shifted at the end
+  // Straight-line loop body (lanes of different blobs stay in lock step).  The polygon sums take the edge to the
+  // NEXT border pixel every step: for b = a + (dx, dy), a_x b_y - b_x a_y = a_x dy - a_y dx; at the last step the
+  // next pixel is the start pixel, i.e. that edge closes the polygon.
   for (int step = 0; step < (1 << 20); ++step) {
     const int s_end = s;
     const unsigned m16 = nb | (nb << 8);
     const int k = __builtin_ctz(m16 >> (s + 1));
     const int sn = (s + 1 + k) & 7;
-    if ((unsigned)(sn - 1) < (unsigned)s_end)
-      set_bit(ng, wb, slot, xb);
-    else
-      set_bit(pm, wb, slot, xb);
-    acc.emit(xb + xoff, slot + yoff);
-    const int nxb = xb + dir_dx(sn), nslot = slot + dir_dy(sn);
-    if (nxb == xb0 && nslot == slot0 && xb == x1b && slot == s1) {
-      acc.close();
+    const bool negative = (unsigned)(sn - 1) < (unsigned)s_end;
+    const u64 bit = 1ull << (xb & 63);
+    const int wi = ro + (xb >> 6);
+    atomicOr(&ng[wi], negative ? bit : 0ull);
+    atomicOr(&pm[wi], negative ? 0ull : bit);
+    const int dx = dir_dx(sn), dy = dir_dy(sn);
+    const int nxb = xb + dx, nslot = slot + dy;
+    const bool done = (nxb == xb0) & (nslot == slot0) & (xb == x1b) & (slot == s1);
+    const int X = xb + xoff, Y = slot + yoff;
+    const int dxy = X * dy - Y * dx;
+    a00 += dxy;
+    a10 += (long long)dxy * (2 * X + dx);
+    a01 += (long long)dxy * (2 * Y + dy);
+    xmin = min(xmin, xb);
+    xmax = max(xmax, xb);
+    ymin = min(ymin, slot);
+    ymax = max(ymax, slot);
+    if (done) {
+      acc.a00 = a00;
+      acc.a10 = a10;
+      acc.a01 = a01;
+      acc.xmin = xmin + xoff;
+      acc.xmax = xmax + xoff;
+      acc.ymin = ymin + yoff;
+      acc.ymax = ymax + yoff;
       return true;
     }
     slot = nslot;
     xb = nxb;
+    ro += dy * wb;
     s = (sn + 4) & 7;
-    nb = neighbours(nz, wb, slot, xb);
+    nb = neighbours_at(nz, ro, wb, xb);
   }
   return false;
 }
