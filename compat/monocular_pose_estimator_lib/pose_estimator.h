@@ -40,6 +40,10 @@ class PoseEstimator {
 
   PoseEstimator();  //!< tolerances 3 / 5 / 0.75 / 0.7 as pose_estimator.cpp:34-42
   ~PoseEstimator();
+  // The object owns a device handle and the library-side state machine: not copyable (the reference
+  // class is plain state and its only user, MPENode, holds one instance by value and never copies it).
+  PoseEstimator(const PoseEstimator&) = delete;
+  PoseEstimator& operator=(const PoseEstimator&) = delete;
 
   void setMarkerPositions(const List4DPoints& positions_of_markers_on_object);  // pose_estimator.cpp:50-55
   List4DPoints getMarkerPositions();

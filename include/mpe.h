@@ -130,6 +130,29 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
                        const double* markers_xyz, int n_markers, const double K[9],
                        const double* D, int nD, const mpe_params* p, mpe_result* results);
 
+/* ---- the same entry point over SEVERAL GPUs of one node, from ONE host process ----
+ * Frames are independent on this branch (pose_estimator.cpp:68-91 reads no estimator state when
+ * it_since_initialized_ < 1), so the batch shards into contiguous chunks — shard d of n_dev gets frames
+ * [lo, hi) as mpe_shard_bounds says (sizes differ by at most one frame) — with NO exchange step between the
+ * devices; the only "gather" is that every shard's pose records land in the caller's ONE host array, in
+ * frame order.  handles[d]: n_dev DISTINCT handles (normally created on n_dev different devices; several
+ * handles on one device work too).  One host thread per shard drives that handle's mpe_estimate_batch.
+ * Returns 0, or the first failing shard's error code (text: mpe_last_error of that shard's handle).
+ * (One process per GPU + a pose gather over RCCL, as bench.py and rpg_monocular_pose_estimator_amd/parallel.py
+ * do it, is the other way to use N GPUs; results are identical.) */
+void mpe_shard_bounds(int n_frames, int shard, int n_shards, int* lo, int* hi);
+/* host frames: frame f at frames + f*frame_stride_bytes, copied to the shard's device by its own thread */
+int mpe_estimate_batch_multi(mpe_handle* const* handles, int n_dev, const uint8_t* frames, int n_frames,
+                             int rows, int cols, size_t stride_bytes, size_t frame_stride_bytes,
+                             const double* markers_xyz, int n_markers, const double K[9], const double* D,
+                             int nD, const mpe_params* p, mpe_result* results);
+/* device-resident shards: d_frames[d] = n_frames[d] packed frames (cols % 16 == 0, 16-byte aligned) in the
+ * memory of handles[d]'s device; results = one HOST array of sum(n_frames) records, shard after shard */
+int mpe_estimate_batch_multi_device(mpe_handle* const* handles, int n_dev, const uint8_t* const* d_frames,
+                                    const int* n_frames, int rows, int cols, const double* markers_xyz,
+                                    int n_markers, const double K[9], const double* D, int nD,
+                                    const mpe_params* p, mpe_result* results);
+
 /* Fully asynchronous variant for device-resident pipelines: frames AND results are device
  * pointers, nothing is copied, the call only enqueues kernels on the handle's stream.
  * frames must be 16-byte aligned with cols % 16 == 0, stride_bytes == cols and
@@ -248,7 +271,9 @@ int mpe_find_correspondences(const double* predicted_px, int n_markers, const do
 /* The image callback loop (MPENode::imageCallback -> estimateBodyPose, monocular_pose_estimator.cpp:
  * 125-190) over a recorded sequence: frame f at frames + f*frame_stride_bytes with time stamp
  * times[f].  out (optional) n_frames records, info (optional) n_frames x 8 ints as above.  Returns
- * the number of frames whose pose was updated, or <0 on the first error. */
+ * the number of frames whose pose was updated, or <0 on the first usage / HIP error.  A frame that exceeds
+ * a device capacity (MPE_FRAME_TOO_MANY_*) does not end the sequence: its record is zeroed, out[f].status
+ * holds the code, the estimator state is as that frame's failed call left it, and the replay continues. */
 int mpe_tracker_run_sequence(mpe_tracker* t, const uint8_t* frames, int n_frames, int rows, int cols,
                              size_t stride_bytes, size_t frame_stride_bytes, const double* times,
                              mpe_result* out, int* info);
@@ -294,7 +319,12 @@ int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
  * -1 automatic (default) = 3 for marker sets of <= 5 markers, else 0;  0 = two-stream software
  * pipeline, the scan of sub-batch s+1 beside the voting of sub-batch s;  3 = fused, one stream: the
  * scan of sub-batch s+1 rides inside the voting kernel of sub-batch s), "k1a_dummy_lds" (occupancy cap
- * of the stand-alone scan kernel in mode 0).  Results are bit-identical in every mode. */
+ * of the stand-alone scan kernel in mode 0, per handle), "vote_arith" (arithmetic of the voting kernel: 1 (default)
+ * = fast — Newton-Raphson division / square root, Newton cube root, per-permutation tables, [R|C]-free
+ * back-projection; 0 = strict — the validation kernel's P3P functions with IEEE operators in the reference's
+ * statement order, so that voting and validation share one quartic solver; slower, never fused with the scan.
+ * The two differ only in the unstable corner of the reference's Ferrari solver).
+ * Results are bit-identical in every pipeline mode (for a given vote_arith). */
 int mpe_set_option(mpe_handle* h, const char* name, int value);
 /* Read an option back.  Also "streams_concurrent": 1 once the library has verified (spin-kernel probe at
  * the first large batch) that its two pipeline side streams execute concurrently, 0 if no concurrent

@@ -210,6 +210,13 @@ void inverse6(const double Ain[36], double out[36]) {
 // One-sided (Hestenes) Jacobi SVD of a 3x3: H = U diag(s) V^T.  Stands in for
 // Eigen::JacobiSVD(ThinU|ThinV) at PE.cpp:916-920; only V*U^T (the orthogonal polar factor,
 // unique for full-rank H) is consumed.
+// Rank-deficient H (coplanar markers: H = A B^T with a rank-2 A): the third singular value is a
+// rounding residue (~1e-17 relative) and Eigen's JacobiSVD gives U.col(2) the SIGN of that residue
+// (JacobiSVD.h "m_matrixU.col(i) *= m_workMatrix(i,i) / a"), so whether the reference returns the
+// proper rotation or its mirror image through the marker plane is decided by the last bit of H —
+// two builds of the reference do not agree with each other there.  The restatement (and the HIP
+// tail kernel, same algorithm) resolves every sigma_3 <= 1e-12 sigma_1 to the completion
+// u_3 = u_1 x u_2, i.e. det(U) = +1: one of the reference's two outcomes, deterministically.
 void svd3(const M3& H, M3& U, double s[3], M3& V) {
   double G[3][3], Vm[3][3];
   for (int i = 0; i < 3; ++i)
@@ -250,7 +257,7 @@ void svd3(const M3& H, M3& U, double s[3], M3& V) {
   }
   double smax = std::max(s[0], std::max(s[1], s[2]));
   for (int j = 0; j < 3; ++j) {
-    if (s[j] > smax * 1e-300 && s[j] > 0) {
+    if (s[j] > smax * 1e-12 && s[j] > 0) {
       for (int i = 0; i < 3; ++i) U.m[i][j] = G[i][j] / s[j];
     } else {
       zero_col = j;

@@ -7,17 +7,14 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
-#include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mpe_internal.h"
 
 using namespace mpe;
-namespace mpe {
-extern int g_k1a_dummy_lds;
-}
 
 namespace {
 
@@ -54,6 +51,9 @@ struct mpe_handle {
   size_t mailbox_cap = 0;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
   int vote_splits = 0;         // 0 = auto
+  int vote_arith = 1;          // 1 = fast voting arithmetic (default), 0 = strict: IEEE operators, the validation
+                               //     kernel's P3P (same quartic in K2 and K3)
+  int k1a_dummy_lds = -1;      // tuning: dummy LDS per scan block in the two-stream schedule (-1 = automatic)
   int last_schedule = 0;       // schedule the last large batch actually ran with
   int pipeline_mode = -1;      // -1 automatic; 0 two-stream staggered pipeline, 3 fused single stream (scan rides in the voting
                                // kernel); 1 / 2 experiment variants of the two-stream schedule
@@ -149,7 +149,8 @@ int make_detect_params(const mpe_params* p, const double K[9], const double* D, 
   return 0;
 }
 
-int make_solve_params(const mpe_params* p, const double* markers, int n_markers, const double K[9], SolveParams& sp) {
+int make_solve_params(const mpe_handle* h, const mpe_params* p, const double* markers, int n_markers, const double K[9],
+                      SolveParams& sp) {
   if (n_markers < 0 || n_markers > MPE_MAX_MARKERS) return -1;
   std::memset(&sp, 0, sizeof(sp));
   sp.n_markers = n_markers;
@@ -162,6 +163,7 @@ int make_solve_params(const mpe_params* p, const double* markers, int n_markers,
   sp.certainty_thr = p->certainty_threshold;
   sp.valid_corr_thr = p->valid_correspondence_threshold;
   sp.hist_thr = p->histogram_threshold ? p->histogram_threshold : num_combinations_u32((unsigned)n_markers, 3);
+  sp.vote_arith = h->vote_arith;
   return 0;
 }
 
@@ -231,6 +233,13 @@ int auto_splits(const mpe_handle* h, int n_frames, int n_markers) {
   return std::max(1, std::min(s, 64));
 }
 
+// dummy LDS per block of the stand-alone scan kernel: the handle's tuning override, else 40 KB when the scan is
+// about to share the chip with the voting kernel of another sub-batch (two-stream schedule), else none
+int scan_lds(const mpe_handle* h, bool co_resident) {
+  if (h->k1a_dummy_lds >= 0) return h->k1a_dummy_lds;
+  return co_resident ? 40000 : 0;
+}
+
 void rec(mpe_handle* h, int i) {
   if (h->profiling && h->ev[i]) (void)hipEventRecord(h->ev[i], h->stream);
 }
@@ -241,7 +250,7 @@ int run_front(mpe_handle* h, hipStream_t st, bool prof, int chain, int chain_fra
               unsigned long long* d_flags, mpe_detections* d_dets) {
   const size_t bytes = (size_t)n_frames * g.rows * g.pitch;
   if (prof) rec(h, 0);
-  HIP_TRY(h, launch_k1a_scan(d_frames, bytes, d_flags, dp.thr, false, st));
+  HIP_TRY(h, launch_k1a_scan(d_frames, bytes, d_flags, dp.thr, scan_lds(h, false), st));
   if (prof) rec(h, 1);
   HIP_TRY(h, launch_k1b_blobs(d_frames, d_flags, n_frames, g, dp, d_dets,
                               static_cast<int*>(h->work.p) + (size_t)chain * 2 * (chain_frames + 1),
@@ -277,16 +286,27 @@ int pick_concurrent_streams(mpe_handle* h) {
   hipStream_t cand[kCandidates] = {};
   for (int i = 0; i < kCandidates; ++i) HIP_TRY(h, hipStreamCreateWithFlags(&cand[i], hipStreamNonBlocking));
   const unsigned long long ticks = 100000;  // 1 ms at 100 MHz
+  // device time from the first launch to the end of both spins, by HIP events: t0 is recorded on a, b waits for it
+  // (so neither spin starts early), t1 on a after b's completion event has been joined into a
+  hipEvent_t t0 = nullptr, t1 = nullptr, eb = nullptr;
+  HIP_TRY(h, hipEventCreate(&t0));
+  HIP_TRY(h, hipEventCreate(&t1));
+  HIP_TRY(h, hipEventCreateWithFlags(&eb, hipEventDisableTiming));
   auto both_ms = [&](hipStream_t a, hipStream_t b, double& ms) -> hipError_t {
     hipError_t e = hipStreamSynchronize(a);
     if (e != hipSuccess) return e;
     if ((e = hipStreamSynchronize(b)) != hipSuccess) return e;
-    const auto t0 = std::chrono::steady_clock::now();
+    if ((e = hipEventRecord(t0, a)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(b, t0, 0)) != hipSuccess) return e;
     if ((e = launch_spin(ticks, a)) != hipSuccess) return e;
     if ((e = launch_spin(ticks, b)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(a)) != hipSuccess) return e;
-    if ((e = hipStreamSynchronize(b)) != hipSuccess) return e;
-    ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if ((e = hipEventRecord(eb, b)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(a, eb, 0)) != hipSuccess) return e;
+    if ((e = hipEventRecord(t1, a)) != hipSuccess) return e;
+    if ((e = hipEventSynchronize(t1)) != hipSuccess) return e;
+    float fms = 0.f;
+    if ((e = hipEventElapsedTime(&fms, t0, t1)) != hipSuccess) return e;
+    ms = fms;
     return hipSuccess;
   };
   double warm = 0;
@@ -302,6 +322,9 @@ int pick_concurrent_streams(mpe_handle* h) {
         break;
       }
     }
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  (void)hipEventDestroy(eb);
   h->streams_concurrent = ia >= 0 ? 1 : 0;
   if (ia < 0) {
     ia = 0;
@@ -339,6 +362,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   if (nsub > h->pipeline) nsub = h->pipeline;
   if (nsub > mpe_handle::kMaxSub) nsub = mpe_handle::kMaxSub;
   if (nsub < 1 || !sp) nsub = 1;
+  if (sp && sp->vote_arith == 0) nsub = 1;  // strict voting arithmetic: one plain chain of kernels (no scan rider)
   h->have_ms = false;
   HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
   if (nsub <= 1) {
@@ -394,7 +418,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     unsigned long long* fl;
     sub_ptrs(0, f0, nf, fr, fl);
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][0], st));
-    HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, false, st));
+    HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, scan_lds(h, false), st));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][1], st));
     int used = 0;
     for (int s = 0; s < nsub; ++s) {
@@ -424,7 +448,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       if (nbytes > 0) {  // what the riders left over: less than one chunk, or everything if they could not run
         if (prof) HIP_TRY(h, hipEventRecord(h->pev[s + 1][0], st));
         if (nbytes > scanned)
-          HIP_TRY(h, launch_k1a_scan(nfr + scanned, nbytes - scanned, nfl + scanned / 1024, dp.thr, false, st));
+          HIP_TRY(h, launch_k1a_scan(nfr + scanned, nbytes - scanned, nfl + scanned / 1024, dp.thr, scan_lds(h, false), st));
         if (prof) HIP_TRY(h, hipEventRecord(h->pev[s + 1][1], st));
       }
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], st));
@@ -467,7 +491,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     const uint8_t* fr = d_frames + (size_t)f0 * frame_bytes;
     unsigned long long* fl = static_cast<unsigned long long*>(h->flags.p) + fw_per * s;
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][0], sa));
-    HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, true, sa));
+    HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, scan_lds(h, true), sa));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][1], sa));
     hipStream_t sblob = sa;
     if (mode == 2) {  // blobs (and tail) on a third stream
@@ -516,6 +540,30 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   return MPE_OK;
 }
 
+}  // namespace
+
+namespace {
+template <class Fn>
+int run_shards(mpe_handle* const* handles, int n_dev, Fn fn) {
+  if (!handles || n_dev < 1) return MPE_ERR_ARG;
+  for (int d = 0; d < n_dev; ++d) {
+    if (!handles[d]) return MPE_ERR_ARG;
+    for (int e = 0; e < d; ++e)
+      if (handles[e] == handles[d]) return fail(handles[d], MPE_ERR_ARG, "the same handle was passed for two shards");
+  }
+  std::vector<int> rc((size_t)n_dev, MPE_OK);
+  if (n_dev == 1) {
+    rc[0] = fn(0);
+  } else {
+    std::vector<std::thread> th;
+    th.reserve((size_t)n_dev);
+    for (int d = 0; d < n_dev; ++d) th.emplace_back([&rc, &fn, d]() { rc[(size_t)d] = fn(d); });
+    for (auto& t : th) t.join();
+  }
+  for (int d = 0; d < n_dev; ++d)
+    if (rc[(size_t)d] != MPE_OK) return rc[(size_t)d];  // message: mpe_last_error(handles[d])
+  return MPE_OK;
+}
 }  // namespace
 
 // =============================================================================================
@@ -675,6 +723,8 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "pipeline_mode") *value = h->pipeline_mode;
   else if (n == "lds_budget") *value = h->lds_budget;
   else if (n == "vote_splits") *value = h->vote_splits;
+  else if (n == "vote_arith") *value = h->vote_arith;
+  else if (n == "k1a_dummy_lds") *value = h->k1a_dummy_lds;
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
   else return fail(h, MPE_ERR_ARG, "unknown option");
@@ -689,7 +739,7 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
     return MPE_OK;
   }
   if (!std::strcmp(name, "k1a_dummy_lds")) {
-    g_k1a_dummy_lds = value;
+    h->k1a_dummy_lds = value;
     return MPE_OK;
   }
   if (!std::strcmp(name, "pipeline_mode")) {
@@ -703,6 +753,11 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   }
   if (!std::strcmp(name, "vote_splits")) {
     h->vote_splits = value;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "vote_arith")) {
+    if (value != 0 && value != 1) return fail(h, MPE_ERR_ARG, "vote_arith must be 0 (strict) or 1 (fast)");
+    h->vote_arith = value;
     return MPE_OK;
   }
   return fail(h, MPE_ERR_ARG, "unknown option");
@@ -780,7 +835,7 @@ int mpe_vote_batch(mpe_handle* h, const double* det_xy, const int* n_det, int n_
   mpe_default_params(&p);
   p.back_projection_pixel_tolerance = back_projection_pixel_tolerance;
   SolveParams sp;
-  if (make_solve_params(&p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_ARG, "too many markers");
+  if (make_solve_params(h, &p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_ARG, "too many markers");
   std::vector<mpe_detections> hd(n_frames);
   for (int f = 0; f < n_frames; ++f) {
     std::memset(&hd[f], 0, sizeof(mpe_detections));
@@ -813,7 +868,7 @@ int solve_bruteforce_impl(mpe_handle* h, const double* det_xy, int n_det, const 
   if (n_det > MPE_MAX_DETECTIONS) return fail(h, MPE_ERR_UNSUPPORTED, "n_det > MPE_MAX_DETECTIONS");
   HIP_TRY(h, hipSetDevice(h->device));
   SolveParams sp;
-  if (make_solve_params(p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
+  if (make_solve_params(h, p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
   mpe_detections hd;
   std::memset(&hd, 0, sizeof(hd));
   hd.n = n_det;
@@ -865,7 +920,7 @@ int run_tail_single(mpe_handle* h, const double* det_xy, int n_det, const double
   if (n_det > MPE_MAX_DETECTIONS || n_corr > MPE_MAX_MARKERS) return fail(h, MPE_ERR_UNSUPPORTED, "too many points");
   HIP_TRY(h, hipSetDevice(h->device));
   SolveParams sp;
-  if (make_solve_params(p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
+  if (make_solve_params(h, p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
   for (int i = 0; i < n_corr; ++i)
     if (corr[2 * i] < 1 || corr[2 * i] > (uint32_t)n_markers || corr[2 * i + 1] < 1 || corr[2 * i + 1] > (uint32_t)n_det)
       return fail(h, MPE_ERR_ARG, "correspondence index out of range");
@@ -978,7 +1033,7 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   DetectParams dp;
   if (make_detect_params(p, K, D, nD, roi_x, roi_y, dp)) return fail(h, MPE_ERR_ARG, "gaussian_sigma must be in (0, 6]");
   SolveParams sp;
-  if (make_solve_params(p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
+  if (make_solve_params(h, p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
   const size_t roi_bytes = (size_t)g.rows * g.pitch;
   const size_t in_bytes = kTrackHeader + roi_bytes;
   const size_t need = in_bytes + sizeof(TrackRecord);
@@ -1010,7 +1065,7 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   TrackRecord* d_rec = static_cast<TrackRecord*>(h->track.p);
   h->have_ms = false;
   HIP_TRY(h, hipMemcpyAsync(d_in, mb, in_bytes, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, launch_k1a_scan(d_in + kTrackHeader, roi_bytes, static_cast<unsigned long long*>(h->flags.p), dp.thr, false,
+  HIP_TRY(h, launch_k1a_scan(d_in + kTrackHeader, roi_bytes, static_cast<unsigned long long*>(h->flags.p), dp.thr, 0,
                              h->stream));
   HIP_TRY(h, launch_k1b_blobs(d_in + kTrackHeader, static_cast<unsigned long long*>(h->flags.p), 1, g, dp, &d_rec->det,
                               static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), 0, h->stream));
@@ -1038,7 +1093,7 @@ int mpe_estimate_batch_device(mpe_handle* h, const uint8_t* d_frames, int n_fram
   DetectParams dp;
   if (make_detect_params(p, K, D, nD, 0, 0, dp)) return fail(h, MPE_ERR_ARG, "gaussian_sigma must be in (0, 6]");
   SolveParams sp;
-  if (make_solve_params(p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
+  if (make_solve_params(h, p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
   HIP_TRY(h, h->dets.reserve((size_t)n_frames * sizeof(mpe_detections)));
   HIP_TRY(h, h->hist.reserve((size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t)));
   return run_pipeline(h, d_frames, n_frames, g, dp, &sp, static_cast<mpe_detections*>(h->dets.p),
@@ -1056,7 +1111,7 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
   DetectParams dp;
   if (make_detect_params(p, K, D, nD, 0, 0, dp)) return fail(h, MPE_ERR_ARG, "gaussian_sigma must be in (0, 6]");
   SolveParams sp;
-  if (make_solve_params(p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
+  if (make_solve_params(h, p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
   const uint8_t* d_frames = nullptr;
   int rc = stage_frames(h, frames, n_frames, rows, cols, stride_bytes, frame_stride_bytes, frames_on_device, 0, 0, cols,
                         rows, g, &d_frames);
@@ -1071,6 +1126,51 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
                             h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPE_OK;
+}
+
+// ---- one host process, several GPUs -----------------------------------------------------------
+// Frames are independent on the uninitialised branch (pose_estimator.cpp:68-91 reads no estimator state), so
+// a batch shards into contiguous chunks, one per handle / device, with no exchange step: one host thread per
+// shard drives that handle's ordinary single-device entry point and writes its slice of the one result array.
+void mpe_shard_bounds(int n_frames, int shard, int n_shards, int* lo, int* hi) {
+  if (n_shards < 1) n_shards = 1;
+  if (n_frames < 0) n_frames = 0;
+  const int base = n_frames / n_shards, rem = n_frames % n_shards;
+  const int a = shard * base + std::min(shard, rem);
+  if (lo) *lo = a;
+  if (hi) *hi = a + base + (shard < rem ? 1 : 0);
+}
+
+
+int mpe_estimate_batch_multi(mpe_handle* const* handles, int n_dev, const uint8_t* frames, int n_frames, int rows,
+                             int cols, size_t stride_bytes, size_t frame_stride_bytes, const double* markers_xyz,
+                             int n_markers, const double K[9], const double* D, int nD, const mpe_params* p,
+                             mpe_result* results) {
+  if (!frames || !results || n_frames < 0) return MPE_ERR_ARG;
+  return run_shards(handles, n_dev, [&](int d) -> int {
+    int lo, hi;
+    mpe_shard_bounds(n_frames, d, n_dev, &lo, &hi);
+    if (hi <= lo) return MPE_OK;
+    return mpe_estimate_batch(handles[d], frames + (size_t)lo * frame_stride_bytes, hi - lo, rows, cols, stride_bytes,
+                              frame_stride_bytes, 0, markers_xyz, n_markers, K, D, nD, p, results + lo);
+  });
+}
+
+int mpe_estimate_batch_multi_device(mpe_handle* const* handles, int n_dev, const uint8_t* const* d_frames,
+                                    const int* n_frames, int rows, int cols, const double* markers_xyz, int n_markers,
+                                    const double K[9], const double* D, int nD, const mpe_params* p,
+                                    mpe_result* results) {
+  if (!d_frames || !n_frames || !results) return MPE_ERR_ARG;
+  std::vector<size_t> off((size_t)std::max(n_dev, 1) + 1, 0);
+  for (int d = 0; d < n_dev; ++d) {
+    if (n_frames[d] < 0 || (n_frames[d] > 0 && !d_frames[d])) return MPE_ERR_ARG;
+    off[(size_t)d + 1] = off[(size_t)d] + (size_t)n_frames[d];
+  }
+  return run_shards(handles, n_dev, [&](int d) -> int {
+    if (n_frames[d] == 0) return MPE_OK;
+    return mpe_estimate_batch(handles[d], d_frames[d], n_frames[d], rows, cols, (size_t)cols, (size_t)rows * cols, 1,
+                              markers_xyz, n_markers, K, D, nD, p, results + off[(size_t)d]);
+  });
 }
 
 }  // extern "C"

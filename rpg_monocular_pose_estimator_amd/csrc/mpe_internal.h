@@ -42,6 +42,7 @@ struct SolveParams {
   double certainty_thr;   // certainty_threshold_
   double valid_corr_thr;  // valid_correspondence_threshold_
   unsigned hist_thr;      // histogram_threshold_
+  int vote_arith;         // option "vote_arith": 1 fast voting arithmetic (default), 0 strict (IEEE, literal order)
 };
 
 #define MPE_HIST_STRIDE (MPE_MAX_DETECTIONS * MPE_MAX_MARKERS)
@@ -49,12 +50,14 @@ struct SolveParams {
 // launchers (mpe_kernels.hip)
 size_t k1b_scratch_bytes(const FrameGeom& g);
 hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long long* flags, int thr,
-                           bool co_resident, hipStream_t s);
+                           int dummy_lds_bytes, hipStream_t s);
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
                             int blob_hint, hipStream_t s);
 size_t k2_table_bytes(int n_markers);
 hipError_t launch_k2_prep(const SolveParams& sp, double* tab, hipStream_t s);
+// sp.vote_arith: 1 = the fast voting kernel (tables, Newton-Raphson division / square root, Newton cube root),
+// 0 = the strict kernel (the validation kernel's P3P with IEEE operators; never carries a scan: *scanned_bytes = 0).
 // scan_px != nullptr: the voting waves also scan scan_bytes of pixels (the next sub-batch) into scan_flags;
 // *scanned_bytes = the prefix they cover (whole chunks), the caller scans the rest with launch_k1a_scan
 hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,

@@ -117,13 +117,12 @@ __global__ __launch_bounds__(256) void k1a_scan(const uint4* __restrict__ px, u6
   }
 }
 
-// co_resident: the scan is about to run beside the FP64 voting kernel of another sub-batch (stream
-// pipeline).  Then it is capped to 4 blocks = 4 waves per SIMD (via an otherwise unused dynamic LDS
-// allocation of 40 KB per block) so that its 44-VGPR waves leave room for two 167-VGPR voting
-// waves per SIMD; HBM throughput is unchanged at that occupancy (measured).
-int g_k1a_dummy_lds = -1;  // tuning override (-1 = automatic)
+// dummy_lds > 0: the scan is about to run beside the FP64 voting kernel of another sub-batch (two-stream
+// schedule).  It is then capped to 4 blocks = 4 waves per SIMD (via an otherwise unused dynamic LDS allocation,
+// 40 KB per block by default) so that its 44-VGPR waves leave room for the voting waves; HBM throughput is
+// unchanged at that occupancy (measured).  The value is a per-handle setting (option "k1a_dummy_lds").
 hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long long* flags, int thr,
-                           bool co_resident, hipStream_t s) {
+                           int dummy_lds_bytes, hipStream_t s) {
   const size_t n_seg = n_bytes / 16;
   if (n_seg == 0) return hipSuccess;
   const ThrTest q = make_thr_test(thr);
@@ -131,7 +130,7 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
   size_t blocks = (n_chunks + 3) / 4;  // 4 waves per block
   const size_t max_blocks = 256 * K1A_BLOCKS_PER_CU;  // 256 CUs x blocks per CU, grid-stride beyond
   if (blocks > max_blocks) blocks = max_blocks;
-  const size_t dummy_lds = g_k1a_dummy_lds >= 0 ? (size_t)g_k1a_dummy_lds : (co_resident ? 40000 : 0);
+  const size_t dummy_lds = dummy_lds_bytes > 0 ? (size_t)dummy_lds_bytes : 0;
   if (dummy_lds > 65536) {  // tuning experiments only: more than the default dynamic-LDS limit
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1a_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)dummy_lds);
@@ -147,22 +146,23 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
 // Used for host frames with odd strides / widths and for ROI detection (the reference clones the
 // ROI into a stand-alone matrix, led_detector.cpp:44).
 // =============================================================================================
-__global__ void repack_kernel(const uint8_t* __restrict__ src, size_t src_stride, size_t src_frame_stride,
+__global__ void repack_kernel(const uint8_t* __restrict__ src, size_t src_stride, size_t src_frame_stride, int n_frames,
                               int roi_x, int roi_y, int roi_w, int roi_h, uint8_t* __restrict__ dst, int dst_pitch) {
-  const int f = blockIdx.z;
   const int y = blockIdx.y;
-  const uint8_t* s = src + (size_t)f * src_frame_stride + (size_t)(roi_y + y) * src_stride + roi_x;
-  uint8_t* d = dst + ((size_t)f * roi_h + y) * dst_pitch;
-  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < dst_pitch; x += gridDim.x * blockDim.x)
-    d[x] = (x < roi_w) ? s[x] : (uint8_t)0;
+  for (int f = blockIdx.z; f < n_frames; f += gridDim.z) {  // gridDim.z is limited to 65535: stride over the frames
+    const uint8_t* s = src + (size_t)f * src_frame_stride + (size_t)(roi_y + y) * src_stride + roi_x;
+    uint8_t* d = dst + ((size_t)f * roi_h + y) * dst_pitch;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < dst_pitch; x += gridDim.x * blockDim.x)
+      d[x] = (x < roi_w) ? s[x] : (uint8_t)0;
+  }
 }
 
 hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int n_frames, int roi_x,
                          int roi_y, int roi_w, int roi_h, uint8_t* dst, int dst_pitch, hipStream_t s) {
   if (n_frames <= 0 || roi_h <= 0) return hipSuccess;
-  dim3 grid((dst_pitch + 255) / 256, roi_h, n_frames);
-  hipLaunchKernelGGL(repack_kernel, grid, dim3(256), 0, s, src, src_stride, src_frame_stride, roi_x, roi_y, roi_w,
-                     roi_h, dst, dst_pitch);
+  dim3 grid((dst_pitch + 255) / 256, roi_h, n_frames < 65535 ? n_frames : 65535);
+  hipLaunchKernelGGL(repack_kernel, grid, dim3(256), 0, s, src, src_stride, src_frame_stride, n_frames, roi_x, roi_y,
+                     roi_w, roi_h, dst, dst_pitch);
   return hipGetLastError();
 }
 
@@ -1539,18 +1539,10 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
                         f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
       rider.issue();  // P0: first scan round of the item (nothing is staged here: P6 consumed the last one)
       double root[4];
-#if defined(MPE_K2_LITERAL_QUARTIC)
-      solve_quartic(F0, F1, F2, F3, F4, root);
-#elif defined(MPE_K2_FAST_QUARTIC)
-      solve_quartic_fast(F0, F1, F2, F3, F4, root);
-#elif defined(MPE_K2_QUARTIC_V1)
-      solve_quartic_lit(F0, F1, F2, F3, F4, root);
-#else
       solve_quartic_lit2(F0, F1, F2, F3, F4, root, [&]() {
         rider.consume();
         rider.issue();
       });
-#endif
       rider.consume();  // P1
       rider.issue();
       // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
@@ -1671,6 +1663,105 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   }
 }
 
+// Strict voting kernel (option "vote_arith" = 0): initialise()'s loop nest (pose_estimator.cpp:565-702) with the
+// SAME device functions the validation kernel uses — p3p_prepare / solve_quartic / p3p_solution / make_projection
+// / project, IEEE division and square root, the reference's statement order, [R|C] formed for every solution.
+// No tables, no scan rider, about 2.5x the instructions of k2_vote: the reference point for the fast kernel's
+// divergence rate, selectable at run time.
+__global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detections* __restrict__ dets, SolveParams sp,
+                                                             uint32_t* __restrict__ hist, int splits) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ double s_px[MPE_MAX_DETECTIONS][2];
+  __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
+  __shared__ unsigned s_hist[MPE_HIST_STRIDE];
+  const int f = blockIdx.x / splits, part = blockIdx.x - f * splits;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const mpe_detections* d = dets + f;
+  const int n_d = d->n, n_m = sp.n_markers;
+  if (n_d < 4 || d->status != 0 || n_m < 4) return;
+  for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) s_hist[i] = 0;
+  if (tid < n_d) {
+    const double u = d->undist_xy[2 * tid], v = d->undist_xy[2 * tid + 1];
+    s_px[tid][0] = u;
+    s_px[tid][1] = v;
+    const V3 b = bearing(u, v, sp.fx, sp.fy, sp.cx, sp.cy);
+    s_iv[tid][0] = b.x;
+    s_iv[tid][1] = b.y;
+    s_iv[tid][2] = b.z;
+  }
+  __syncthreads();
+  double* s_q = reinterpret_cast<double*>(smem);  // back-projections: [2*j + {0,1}][tid]
+  const int n_combos = n_d * (n_d - 1) * (n_d - 2) / 6;
+  const int n_perms = n_m * (n_m - 1) * (n_m - 2);
+  const int nuo = n_m - 3;
+  const long long total = (long long)n_combos * n_perms;
+  for (long long t = (long long)part * nthr + tid; t < total; t += (long long)splits * nthr) {
+    const int ti = (int)(t / n_perms), pj = (int)(t - (long long)ti * n_perms);
+    int c0, c1, c2, p0, p1, p2;
+    unrank_combo3(ti, n_d, c0, c1, c2);
+    perm_from_index(pj, n_m, p0, p1, p2);
+    const V3 fa = {s_iv[c0][0], s_iv[c0][1], s_iv[c0][2]}, fb = {s_iv[c1][0], s_iv[c1][1], s_iv[c1][2]},
+             fc = {s_iv[c2][0], s_iv[c2][1], s_iv[c2][2]};
+    const V3 wa = {sp.markers[3 * p0], sp.markers[3 * p0 + 1], sp.markers[3 * p0 + 2]},
+             wb = {sp.markers[3 * p1], sp.markers[3 * p1 + 1], sp.markers[3 * p1 + 2]},
+             wc = {sp.markers[3 * p2], sp.markers[3 * p2 + 1], sp.markers[3 * p2 + 2]};
+    P3PCtx ctx;
+    if (!p3p_prepare(fa, fb, fc, wa, wb, wc, ctx)) continue;  // computePoses returned -1
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      M3 R;
+      V3 C;
+      p3p_solution(ctx, pick_root(ctx, k), R, C);
+      if (!rc_finite(R, C)) continue;  // pose_estimator.cpp:653
+      const Proj P = make_projection(R, C, sp.fx, sp.fy, sp.cx, sp.cy);
+      int j = 0;
+      for (int m = 0; m < n_m; ++m) {  // unused markers, ascending (pose_estimator.cpp:621-661)
+        if (m == p0 || m == p1 || m == p2) continue;
+        double u, v;
+        project(P, V3{sp.markers[3 * m], sp.markers[3 * m + 1], sp.markers[3 * m + 2]}, u, v);
+        s_q[(2 * j) * nthr + tid] = u;
+        s_q[(2 * j + 1) * nthr + tid] = v;
+        ++j;
+      }
+      bool any = false;
+      for (int a = 0; a < n_d; ++a) {  // unused detections, ascending (pose_estimator.cpp:576-597, 862-906)
+        if (a == c0 || a == c1 || a == c2) continue;
+        double best = INFINITY;
+        int bj = 0;
+        for (int jj = 0; jj < nuo; ++jj) {
+          const double du = s_px[a][0] - s_q[(2 * jj) * nthr + tid], dv = s_px[a][1] - s_q[(2 * jj + 1) * nthr + tid];
+          const double d2 = du * du + dv * dv;
+          if (d2 < best) {
+            best = d2;
+            bj = jj;
+          }
+        }
+        if (sqrt(best) < sp.back_tol) {  // strict <, pose_estimator.cpp:671,689
+          int mi = -1, cnt = 0;
+          for (int m = 0; m < n_m; ++m) {
+            if (m == p0 || m == p1 || m == p2) continue;
+            if (cnt == bj) mi = m;
+            ++cnt;
+          }
+          atomicAdd(&s_hist[a * MPE_MAX_MARKERS + mi], 1u);
+          any = true;
+        }
+      }
+      if (any) {  // pose_estimator.cpp:676-685
+        atomicAdd(&s_hist[c0 * MPE_MAX_MARKERS + p0], 1u);
+        atomicAdd(&s_hist[c1 * MPE_MAX_MARKERS + p1], 1u);
+        atomicAdd(&s_hist[c2 * MPE_MAX_MARKERS + p2], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
+  for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) {
+    const unsigned v = s_hist[i];
+    if (v) atomicAdd(&gh[i], v);
+  }
+}
+
 hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
                           uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px,
                           size_t scan_bytes, unsigned long long* scan_flags, int scan_thr, size_t* scanned_bytes) {
@@ -1678,6 +1769,12 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
   if (n_frames <= 0 || sp.n_markers < 4) return hipSuccess;
   if (splits < 1) splits = 1;
   const int nuo = sp.n_markers - 3;
+  if (sp.vote_arith == 0) {  // strict arithmetic: the validation kernel's P3P, no tables, no scan rider
+    const size_t lds_strict = (size_t)nuo * 2 * K2_THREADS * sizeof(double);
+    hipLaunchKernelGGL(k2_vote_strict, dim3((unsigned)(n_frames * splits)), dim3(K2_THREADS), lds_strict, s, dets, sp,
+                       hist, splits);
+    return hipGetLastError();
+  }
   // block size: the multiple of 64 (<= 256) that wastes the fewest lanes on the expected item count
   int threads = K2_THREADS;
   if (n_det_hint >= 4) {
@@ -1732,40 +1829,93 @@ __device__ __forceinline__ void project_T(const T34& T, const double* mk, double
   v = (fy * Y + cy * Z) / Z;
 }
 
-// orthogonal polar factor of the 3x3 matrix X (scaled Newton iteration); for H = U S V^T this is
-// V U^T when X = H^T — the rotation Eigen's JacobiSVD route produces at pose_estimator.cpp:916-922
-// (no reflection guard: a negative determinant is kept, as in the reference).
-__device__ void polar3(double X[3][3]) {
-  for (int it = 0; it < 60; ++it) {
-    // inverse transpose via cofactors
-    double c00 = X[1][1] * X[2][2] - X[1][2] * X[2][1];
-    double c01 = X[1][2] * X[2][0] - X[1][0] * X[2][2];
-    double c02 = X[1][0] * X[2][1] - X[1][1] * X[2][0];
-    double c10 = X[0][2] * X[2][1] - X[0][1] * X[2][2];
-    double c11 = X[0][0] * X[2][2] - X[0][2] * X[2][0];
-    double c12 = X[0][1] * X[2][0] - X[0][0] * X[2][1];
-    double c20 = X[0][1] * X[1][2] - X[0][2] * X[1][1];
-    double c21 = X[0][2] * X[1][0] - X[0][0] * X[1][2];
-    double c22 = X[0][0] * X[1][1] - X[0][1] * X[1][0];
-    double det = X[0][0] * c00 + X[0][1] * c01 + X[0][2] * c02;
-    double id = 1.0 / det;
-    double Y[3][3] = {{c00 * id, c01 * id, c02 * id}, {c10 * id, c11 * id, c12 * id}, {c20 * id, c21 * id, c22 * id}};
-    double nx = 0, ny = 0;
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) {
-        nx += X[i][j] * X[i][j];
-        ny += Y[i][j] * Y[i][j];
+// R = V U^T of H = U S V^T (computeTransformation, pose_estimator.cpp:916-922: JacobiSVD, no reflection
+// guard) by a one-sided (Hestenes) Jacobi SVD: the columns of G = H V are rotated pairwise until they are
+// orthogonal, U = G with normalised columns.  Same sweeps, thresholds and operation order as the CPU
+// oracle's svd3.  A rank-deficient H (coplanar markers) leaves one column of G at rounding level; the
+// reference's JacobiSVD gives that column of U the sign of its rounding residue (a coin flip between the
+// rotation and its mirror image through the marker plane) — here, as in the oracle, every sigma <= 1e-12
+// sigma_max is completed with the cross product of the other two columns (det U = +1).
+__device__ void kabsch_rotation(const double Hm[3][3], double R[3][3]) {
+  double G[3][3], V[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      G[i][j] = Hm[i][j];
+      V[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    bool rotated = false;
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;  // (0,1) (0,2) (1,2)
+      double alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        alpha += G[i][p] * G[i][p];
+        beta += G[i][q] * G[i][q];
+        gamma += G[i][p] * G[i][q];
       }
-    double gam = sqrt(sqrt(ny / nx));
-    double diff = 0;
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) {
-        double xn = 0.5 * (gam * X[i][j] + Y[i][j] / gam);
-        diff += (xn - X[i][j]) * (xn - X[i][j]);
-        X[i][j] = xn;
+      if (gamma == 0.0 || fabs(gamma) <= 1e-300 + 2.3e-16 * sqrt(alpha * beta)) continue;
+      rotated = true;
+      const double zeta = (beta - alpha) / (2.0 * gamma);
+      const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+      const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double gp = G[i][p], gq = G[i][q];
+        G[i][p] = c * gp - sn * gq;
+        G[i][q] = sn * gp + c * gq;
+        const double vp = V[i][p], vq = V[i][q];
+        V[i][p] = c * vp - sn * vq;
+        V[i][q] = sn * vp + c * vq;
       }
-    if (!(diff > 1e-30)) break;  // also leaves on NaN
+    }
+    if (!rotated) break;
   }
+  double sv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) sv[j] = sqrt(G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j]);
+  const double smax = fmax(sv[0], fmax(sv[1], sv[2]));
+  double U[3][3];
+  int zero_col = -1, nzero = 0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (sv[j] > smax * 1e-12 && sv[j] > 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) U[i][j] = G[i][j] / sv[j];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) U[i][j] = 0.0;
+      zero_col = j;
+      ++nzero;
+    }
+  }
+  if (nzero == 1) {  // rank 2: u_zero = u_a x u_b, (zero, a, b) cyclic
+#pragma unroll
+    for (int z = 0; z < 3; ++z)
+      if (z == zero_col) {
+        const int a = (z + 1) % 3, b = (z + 2) % 3;
+        U[0][z] = U[1][a] * U[2][b] - U[2][a] * U[1][b];
+        U[1][z] = U[2][a] * U[0][b] - U[0][a] * U[2][b];
+        U[2][z] = U[0][a] * U[1][b] - U[1][a] * U[0][b];
+      }
+  } else if (nzero > 1) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) U[i][j] = (i == j) ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double acc = V[i][0] * U[j][0];  // (V U^T)(i,j) = sum_k V(i,k) U(j,k), k ascending like the oracle's mul()
+      acc += V[i][1] * U[j][1];
+      acc += V[i][2] * U[j][2];
+      R[i][j] = acc;
+    }
 }
 
 // unpivoted LDL^T of a symmetric positive definite 6x6 (normal equations of GN)
@@ -1918,7 +2068,6 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
     if (corr_out)
       for (int i = l; i < 2 * MPE_MAX_MARKERS; i += K3_GROUP) corr_out[(size_t)f * 2 * MPE_MAX_MARKERS + i] = 0;
   }
-  for (int i = 0; i < nm3; ++i) s_part(grp, l, i) = 0.0;
 
   // ---- lane 0 of the group: initialise()'s all-zero test (pose_estimator.cpp:704) and
   //      correspondencesFromHistogram (pose_estimator.cpp:344-370)
@@ -2008,123 +2157,129 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
   const int n_c = s_nc[grp];
   const bool go = (MODE != 2) && n_c >= 4;
 
-  // ---- checkCorrespondences (pose_estimator.cpp:394-542): the C(n_c,3) P3P validations are
-  //      spread over the 16 lanes; each lane sums inverse(H_best) * markers for its combinations
-  unsigned my_valid = 0;
+  // ---- checkCorrespondences (pose_estimator.cpp:394-542): the C(n_c,3) P3P validations run 16 at a time,
+  //      one per lane of the group; after every round the lanes' inverse(H_best) * markers are added to the
+  //      running sums IN COMBINATION ORDER (lane 0 first), i.e. in the reference's summation order for any n_c
   const int nu = n_c - 3;
   const int N = go ? n_c * (n_c - 1) * (n_c - 2) / 6 : 0;
-  for (int ci = l; ci < N; ci += K3_GROUP) {
-    int a, b, c;
-    unrank_combo3(ci, n_c, a, b, c);
-    V3 fv[3], wp[3];
-    {
-      const int rows3[3] = {a, b, c};
+  for (int v = l; v < nm3; v += K3_GROUP) s_mean[grp][v] = 0.0;
+  unsigned num_valid = 0;
+  for (int r0 = 0; __any(r0 < N); r0 += K3_GROUP) {  // wave-uniform trip count (the barriers below)
+    const int ci = r0 + l;
+    bool contributes = false;
+    do {
+      if (ci >= N) break;
+      int a, b, c;
+      unrank_combo3(ci, n_c, a, b, c);
+      V3 fv[3], wp[3];
+      {
+        const int rows3[3] = {a, b, c};
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int mi = s_cm[grp][rows3[k]] - 1, di = s_cd[grp][rows3[k]] - 1;
-        wp[k] = {s_mk[mi][0], s_mk[mi][1], s_mk[mi][2]};
-        fv[k] = bearing(s_det[grp][di][0], s_det[grp][di][1], fx, fy, cx, cy);
+        for (int k = 0; k < 3; ++k) {
+          const int mi = s_cm[grp][rows3[k]] - 1, di = s_cd[grp][rows3[k]] - 1;
+          wp[k] = {s_mk[mi][0], s_mk[mi][1], s_mk[mi][2]};
+          fv[k] = bearing(s_det[grp][di][0], s_det[grp][di][1], fx, fy, cx, cy);
+        }
       }
-    }
-    P3PCtx ctx;
-    if (!p3p_prepare(fv[0], fv[1], fv[2], wp[0], wp[1], wp[2], ctx)) continue;
-    double min_sq = INFINITY;
-    int best = -1;
-    bool found = false;
+      P3PCtx ctx;
+      if (!p3p_prepare(fv[0], fv[1], fv[2], wp[0], wp[1], wp[2], ctx)) break;
+      double min_sq = INFINITY;
+      int best = -1;
+      bool found = false;
 #pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-      M3 R;
-      V3 C;
-      p3p_solution(ctx, pick_root(ctx, k), R, C);
-      if (!rc_finite(R, C)) continue;
-      const Proj P = make_projection(R, C, fx, fy, cx, cy);
-      // back-project the unused correspondences' markers, ascending row index
-      for (int q = 0; q < nu; ++q) {
-        int row = q;
-        row += (row >= a);
-        row += (row >= b);
-        row += (row >= c);
-        const int mi = s_cm[grp][row] - 1;
-        double u, v;
-        project(P, V3{s_mk[mi][0], s_mk[mi][1], s_mk[mi][2]}, u, v);
-        s_q(2 * q, tid) = u;
-        s_q(2 * q + 1, tid) = v;
-      }
-      // calculateSquaredReprojectionErrorAndCertainty (pose_estimator.cpp:303-342): greedy
-      // global-minimum matching, column-major first minimum, rows = image points
-      unsigned rowdone = 0, coldone = 0;
-      double sq = 0;
-      unsigned ncorr = 0;
-      for (int it = 0; it < nu; ++it) {
-        double mv = 0;
-        int ri = 0, cj0 = 0;
-        bool first = true;
-        for (int cj = 0; cj < nu; ++cj) {
-          const double bu = s_q(2 * cj, tid), bv = s_q(2 * cj + 1, tid);
-          for (int rr = 0; rr < nu; ++rr) {
-            double v;
-            if (((rowdone >> rr) & 1) || ((coldone >> cj) & 1))
-              v = INFINITY;
-            else {
-              int row = rr;
-              row += (row >= a);
-              row += (row >= b);
-              row += (row >= c);
-              const int di = s_cd[grp][row] - 1;
-              const double du = s_det[grp][di][0] - bu, dv = s_det[grp][di][1] - bv;
-              v = sqrt(du * du + dv * dv);
-            }
-            if (first || v < mv) {
-              mv = v;
-              ri = rr;
-              cj0 = cj;
-              first = false;
+      for (int k = 0; k < 4; ++k) {
+        M3 R;
+        V3 C;
+        p3p_solution(ctx, pick_root(ctx, k), R, C);
+        if (!rc_finite(R, C)) continue;
+        const Proj P = make_projection(R, C, fx, fy, cx, cy);
+        // back-project the unused correspondences' markers, ascending row index
+        for (int q = 0; q < nu; ++q) {
+          int row = q;
+          row += (row >= a);
+          row += (row >= b);
+          row += (row >= c);
+          const int mi = s_cm[grp][row] - 1;
+          double u, v;
+          project(P, V3{s_mk[mi][0], s_mk[mi][1], s_mk[mi][2]}, u, v);
+          s_q(2 * q, tid) = u;
+          s_q(2 * q + 1, tid) = v;
+        }
+        // calculateSquaredReprojectionErrorAndCertainty (pose_estimator.cpp:303-342): greedy
+        // global-minimum matching, column-major first minimum, rows = image points
+        unsigned rowdone = 0, coldone = 0;
+        double sq = 0;
+        unsigned ncorr = 0;
+        for (int it = 0; it < nu; ++it) {
+          double mv = 0;
+          int ri = 0, cj0 = 0;
+          bool first = true;
+          for (int cj = 0; cj < nu; ++cj) {
+            const double bu = s_q(2 * cj, tid), bv = s_q(2 * cj + 1, tid);
+            for (int rr = 0; rr < nu; ++rr) {
+              double v;
+              if (((rowdone >> rr) & 1) || ((coldone >> cj) & 1))
+                v = INFINITY;
+              else {
+                int row = rr;
+                row += (row >= a);
+                row += (row >= b);
+                row += (row >= c);
+                const int di = s_cd[grp][row] - 1;
+                const double du = s_det[grp][di][0] - bu, dv = s_det[grp][di][1] - bv;
+                v = sqrt(du * du + dv * dv);
+              }
+              if (first || v < mv) {
+                mv = v;
+                ri = rr;
+                cj0 = cj;
+                first = false;
+              }
             }
           }
+          if (mv <= sp.back_tol) {
+            sq += mv * mv;
+            ++ncorr;
+            rowdone |= 1u << ri;
+            coldone |= 1u << cj0;
+          } else
+            break;
         }
-        if (mv <= sp.back_tol) {
-          sq += mv * mv;
-          ++ncorr;
-          rowdone |= 1u << ri;
-          coldone |= 1u << cj0;
-        } else
-          break;
-      }
-      const double certainty = (double)ncorr / (double)nu;
-      if (certainty >= sp.certainty_thr) {  // pose_estimator.cpp:494-502
-        found = true;
-        if (sq < min_sq) {
-          min_sq = sq;
-          best = k;
+        const double certainty = (double)ncorr / (double)nu;
+        if (certainty >= sp.certainty_thr) {  // pose_estimator.cpp:494-502
+          found = true;
+          if (sq < min_sq) {
+            min_sq = sq;
+            best = k;
+          }
         }
       }
+      if (!found) break;
+      if (best < 0) best = 0;  // unreachable: sq is always finite
+      M3 R;
+      V3 C;
+      p3p_solution(ctx, pick_root(ctx, best), R, C);
+      // inverse(H) * marker for ALL markers (pose_estimator.cpp:513-517)
+      for (int jj = 0; jj < n_m; ++jj) {
+        const V3 mk = {s_mk[jj][0] - C.x, s_mk[jj][1] - C.y, s_mk[jj][2] - C.z};
+        const V3 pc = mulT(R, mk);  // R^T (m - C)
+        s_part(grp, l, 3 * jj) = pc.x;
+        s_part(grp, l, 3 * jj + 1) = pc.y;
+        s_part(grp, l, 3 * jj + 2) = pc.z;
+      }
+      contributes = true;
+    } while (false);
+    s_valid[grp][l] = contributes ? 1u : 0u;
+    __syncthreads();
+    for (int v = l; v < nm3; v += K3_GROUP) {
+      double sacc = s_mean[grp][v];
+      for (int q = 0; q < K3_GROUP; ++q)
+        if (s_valid[grp][q]) sacc += s_part(grp, q, v);
+      s_mean[grp][v] = sacc;
     }
-    if (!found) continue;
-    ++my_valid;
-    if (best < 0) best = 0;  // unreachable: sq is always finite
-    M3 R;
-    V3 C;
-    p3p_solution(ctx, pick_root(ctx, best), R, C);
-    // inverse(H) * marker for ALL markers (pose_estimator.cpp:513-517)
-    for (int jj = 0; jj < n_m; ++jj) {
-      const V3 mk = {s_mk[jj][0] - C.x, s_mk[jj][1] - C.y, s_mk[jj][2] - C.z};
-      const V3 pc = mulT(R, mk);  // R^T (m - C)
-      s_part(grp, l, 3 * jj) += pc.x;
-      s_part(grp, l, 3 * jj + 1) += pc.y;
-      s_part(grp, l, 3 * jj + 2) += pc.z;
-    }
+    for (int q = 0; q < K3_GROUP; ++q) num_valid += s_valid[grp][q];
+    __syncthreads();
   }
-  s_valid[grp][l] = my_valid;
-  __syncthreads();
-  // ordered reduction over the lanes (= combination order while C(n_c,3) <= 16)
-  for (int v = l; v < nm3; v += K3_GROUP) {
-    double sacc = 0.0;
-    for (int q = 0; q < K3_GROUP; ++q) sacc += s_part(grp, q, v);
-    s_mean[grp][v] = sacc;
-  }
-  unsigned num_valid = 0;
-  for (int q = 0; q < K3_GROUP; ++q) num_valid += s_valid[grp][q];
-  __syncthreads();
   bool active = go && ((double)num_valid / (double)N >= sp.valid_corr_thr);
   if (MODE == 2) active = n_c >= 3;  // fewer rows leave the 6x6 normal equations singular
 
@@ -2145,10 +2300,8 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c)
           Hm[r][c] += (s_mk[i][r] - mo[r]) * (s_mean[grp][3 * i + c] / (double)num_valid - mr[c]);
-    double X[3][3];  // H^T
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) X[r][c] = Hm[c][r];
-    polar3(X);  // R = V U^T
+    double X[3][3];
+    kabsch_rotation(Hm, X);  // R = V U^T
     for (int r = 0; r < 3; ++r) {
       for (int c = 0; c < 3; ++c) T.m[r][c] = X[r][c];
       T.m[r][3] = mr[r] - (X[r][0] * mo[0] + X[r][1] * mo[1] + X[r][2] * mo[2]);
@@ -2257,7 +2410,9 @@ hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int 
                           mpe_result* results, uint32_t* corr_out, const uint32_t* corr_in, const double* nn_pred,
                           double nn_tol, hipStream_t s, int mode) {
   if (n_frames <= 0) return hipSuccess;
-  const int nu = sp.n_markers > 3 ? sp.n_markers - 3 : 1;
+  // explicit correspondences (corr_in) may hold up to MPE_MAX_MARKERS rows, also more than n_markers (repeated
+  // markers are defined input for checkCorrespondences): size the back-projection buffer for the row capacity
+  const int nu = corr_in ? MPE_MAX_MARKERS - 3 : (sp.n_markers > 3 ? sp.n_markers - 3 : 1);
   const size_t lds = ((size_t)K3_FRAMES_PER_BLOCK * K3_GROUP * 3 * sp.n_markers + (size_t)2 * nu * 64) * sizeof(double);
   const dim3 grid((n_frames + K3_FRAMES_PER_BLOCK - 1) / K3_FRAMES_PER_BLOCK);
   if (mode == 1)

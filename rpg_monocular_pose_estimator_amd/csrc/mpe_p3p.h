@@ -142,21 +142,11 @@ __device__ __forceinline__ void solve_quartic(double A, double B, double C, doub
   rr[3] = off + 0.5 * (-w.re - s2.re);
 }
 
-// ---- voting-kernel variant of the quartic ------------------------------------------------------
-// Same algorithm and branches as solve_quartic above; the eleven real divisions by A, A^2.. and by
-// the constants 12, 27, 108, 6 are folded into one reciprocal and multiplications, and |z| is
-// sqrt(re^2 + im^2) without hypot's range scaling.  Results differ from solve_quartic by rounding
-// only (a few ulp on the coefficients of the depressed quartic).
+// ---- fast arithmetic of the voting kernel (option "vote_arith" = 1, the default) -----------------
 // Newton-Raphson reciprocal / division / square root on top of v_rcp_f64 / v_rsq_f64, without the
 // range scaling and fix-up of the IEEE expansions (12 / 22 VALU ops each): ~7 / 9 ops, <= 1 ulp for
 // normal-range operands; NaN in -> NaN out, negative radicand -> NaN (the voting kernel relies on
 // that to drop |root| > 1), sqrt(0) = 0.
-#ifdef MPE_K2_IEEE  // debugging aid: IEEE division / square root instead of the Newton-Raphson forms
-__device__ __forceinline__ double rcp_nr(double b) { return 1.0 / b; }
-__device__ __forceinline__ double div_nr(double a, double b) { return a / b; }
-__device__ __forceinline__ double sqrt_nr(double a) { return sqrt(a); }
-__device__ __forceinline__ double rsqrt_nr(double a) { return 1.0 / sqrt(a); }
-#else
 __device__ __forceinline__ double rcp_nr(double b) {
   double x = __builtin_amdgcn_rcp(b);
   double e = __builtin_fma(-b, x, 1.0);
@@ -195,84 +185,13 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
   h = __builtin_fma(h, r, h);
   return 2.0 * h;
 }
-#endif
-__device__ __forceinline__ double hypot_fast(double a, double b) { return sqrt_nr(a * a + b * b); }
-// (a + ib) / (c + id), Smith's algorithm with the Newton-Raphson division
-__device__ __forceinline__ C2 cdiv_fast(C2 n, C2 d) {
-  const double a = n.re, b = n.im, c = d.re, e = d.im;
-  if (fabs(c) < fabs(e)) {
-    const double ratio = div_nr(c, e), idenom = rcp_nr(c * ratio + e);
-    return {(a * ratio + b) * idenom, (b * ratio - a) * idenom};
-  }
-  const double ratio = div_nr(e, c), idenom = rcp_nr(e * ratio + c);
-  return {(b * ratio + a) * idenom, (b - a * ratio) * idenom};
-}
-__device__ __forceinline__ C2 csqrt_fast(C2 z) {
-  if (z.im == 0.0) {
-    if (z.re < 0.0) return {0.0, copysign(sqrt_nr(-z.re), z.im)};
-    return {fabs(sqrt_nr(z.re)), z.im};
-  }
-  const double d = hypot_fast(z.re, z.im);
-  double r, s;
-  if (z.re > 0.0) {
-    r = sqrt_nr(0.5 * (d + z.re));
-    s = 0.5 * div_nr(z.im, r);
-  } else {
-    s = sqrt_nr(0.5 * (d - z.re));
-    r = fabs(0.5 * div_nr(z.im, s));
-  }
-  return {r, copysign(s, z.im)};
-}
-__device__ __forceinline__ C2 cpow_third_fast(C2 z) {
-  if (z.im == 0.0 && z.re > 0.0) return {cbrt(z.re), 0.0};
-  const double rho = cbrt(hypot_fast(z.re, z.im));
-  const double phi = (1.0 / 3.0) * atan2(z.im, z.re);
-  double s, c;
-  sincos(phi, &s, &c);
-  return {rho * c, rho * s};
-}
-__device__ __forceinline__ void solve_quartic_fast(double A, double B, double C, double D, double E, double rr[4]) {
-  const double iA = rcp_nr(A);
-  const double b1 = B * iA, c1 = C * iA, d1 = D * iA, e1 = E * iA;  // monic coefficients
-  const double b2 = b1 * b1;
-  const double alpha = -0.375 * b2 + c1;
-  const double beta = 0.125 * b2 * b1 - 0.5 * b1 * c1 + d1;
-  const double gamma = -0.01171875 * b2 * b2 + 0.0625 * b2 * c1 - 0.25 * b1 * d1 + e1;
-  const double alpha_pw2 = alpha * alpha, alpha_pw3 = alpha_pw2 * alpha;
-  const double Pr = -alpha_pw2 * (1.0 / 12.0) - gamma;
-  const double Qr = -alpha_pw3 * (1.0 / 108.0) + alpha * gamma * (1.0 / 3.0) - (beta * beta) * 0.125;
-  const C2 q2 = cpow2_real(Qr), p3 = cpow3_real(Pr);
-  const C2 disc = {q2.re * 0.25 + p3.re * (1.0 / 27.0), q2.im * 0.25 + p3.im * (1.0 / 27.0)};
-  const C2 sq = csqrt_fast(disc);
-  const C2 R = {-Qr * 0.5 + sq.re, sq.im};
-  const C2 U = cpow_third_fast(R);
-  C2 y;
-  const double a56 = -5.0 * alpha * (1.0 / 6.0);
-  if (U.re == 0.0) {
-    const C2 qc = cpow_third_fast(C2{Qr, 0.0});
-    y = {a56 - qc.re, -qc.im};
-  } else {
-    const C2 t = cdiv_fast(C2{Pr, 0.0}, cscale(U, 3.0));
-    y = {a56 - t.re + U.re, -t.im + U.im};
-  }
-  const C2 w = csqrt_fast(C2{alpha + 2.0 * y.re, 2.0 * y.im});
-  const C2 bw = cdiv_fast(C2{2.0 * beta, 0.0}, w);
-  const C2 base = {3.0 * alpha + 2.0 * y.re, 2.0 * y.im};
-  const C2 s1 = csqrt_fast(C2{-(base.re + bw.re), -(base.im + bw.im)});
-  const C2 s2 = csqrt_fast(C2{-(base.re - bw.re), -(base.im - bw.im)});
-  const double off = -0.25 * b1;
-  rr[0] = off + 0.5 * (w.re + s1.re);
-  rr[1] = off + 0.5 * (w.re - s1.re);
-  rr[2] = off + 0.5 * (-w.re + s2.re);
-  rr[3] = off + 0.5 * (-w.re - s2.re);
-}
-
 // ---- voting-kernel quartic, literal operation order -----------------------------------------------
 // Same sequence of operations as solve_quartic (= p3p.cpp:238-286 statement by statement), with the
 // divisions / square roots in their Newton-Raphson forms (correctly rounded in all but rare cases) and
 // |z| from a compensated x^2 + y^2.  Keeping the ORDER matters more than the cost of the operations:
 // in the unstable corner of Ferrari's method (alpha + 2y ~ 0) every rounding is amplified ~1e14 times,
-// and the reformulated solve_quartic_fast disagreed with the CPU path's votes 4x more often.
+// and a reformulated variant (monic coefficients, one reciprocal) disagreed with the CPU path's votes 4x
+// more often.
 __device__ __forceinline__ double hypot_acc(double x, double y) {
   const double s = x * x, t = y * y;
   const double es = __builtin_fma(x, x, -s), et = __builtin_fma(y, y, -t);
@@ -282,40 +201,7 @@ __device__ __forceinline__ double hypot_acc(double x, double y) {
   const double r = sqrt_nr(sum);
   return r + 0.5 * err * rcp_nr(r);  // first-order correction of sqrt(sum + err)
 }
-__device__ __forceinline__ C2 csqrt_lit(C2 z) {
-  if (z.im == 0.0) {
-    if (z.re < 0.0) return {0.0, copysign(sqrt_nr(-z.re), z.im)};
-    return {fabs(sqrt_nr(z.re)), z.im};
-  }
-  const double d = hypot_acc(z.re, z.im);
-  double r, s;
-  if (z.re > 0.0) {
-    r = sqrt_nr(0.5 * (d + z.re));
-    s = 0.5 * div_nr(z.im, r);
-  } else {
-    s = sqrt_nr(0.5 * (d - z.re));
-    r = fabs(0.5 * div_nr(z.im, s));
-  }
-  return {r, copysign(s, z.im)};
-}
-__device__ __forceinline__ C2 cdiv_lit(C2 n, C2 d) {  // Smith, as cdiv
-  const double a = n.re, b = n.im, c = d.re, e = d.im;
-  if (fabs(c) < fabs(e)) {
-    const double ratio = div_nr(c, e), denom = c * ratio + e;
-    return {div_nr(a * ratio + b, denom), div_nr(b * ratio - a, denom)};
-  }
-  const double ratio = div_nr(e, c), denom = e * ratio + c;
-  return {div_nr(b * ratio + a, denom), div_nr(b - a * ratio, denom)};
-}
-__device__ __forceinline__ C2 cpow_third_lit(C2 z) {
-  if (z.im == 0.0 && z.re > 0.0) return {cbrt(z.re), 0.0};
-  const double rho = cbrt(hypot_acc(z.re, z.im));
-  const double phi = (1.0 / 3.0) * atan2(z.im, z.re);
-  double s, c;
-  sincos(phi, &s, &c);
-  return {rho * c, rho * s};
-}
-// ---- cheaper forms of the same operations (MPE_K2_QUARTIC_V2) -----------------------------------------
+// ---- cheaper forms of the same operations ------------------------------------------------------------
 // x / c for a compile-time constant c: reciprocal constant + one residual correction (3 ops, <= 1 ulp)
 __device__ __forceinline__ double div_const(double a, double c, double rc) {
   const double q = a * rc;
@@ -328,7 +214,7 @@ __device__ __forceinline__ double div_with_rcp(double a, double den, double rden
   const double r = __builtin_fma(-den, q, a);
   return __builtin_fma(r, rden, q);
 }
-// (a + ib) / (c + id), Smith's algorithm as cdiv_lit with the two cases folded into operand selects (lanes of a
+// (a + ib) / (c + id), Smith's algorithm as cdiv with the two cases folded into operand selects (lanes of a
 // wave take both cases, a branch would run both sides): the same operations on the same operands, and the two
 // quotients share one reciprocal of denom.
 __device__ __forceinline__ C2 cdiv_lit2(C2 n, C2 d) {
@@ -340,7 +226,7 @@ __device__ __forceinline__ C2 cdiv_lit2(C2 n, C2 d) {
   const double t = q * ratio - p;
   return {div_with_rcp(p * ratio + q, denom, x), div_with_rcp(swap ? t : -t, denom, x)};
 }
-// csqrt_lit with its two half-planes folded the same way: t = sqrt((|z| + |re|) / 2), u = im / (2 t);
+// csqrt_ with its two half-planes folded the same way: t = sqrt((|z| + |re|) / 2), u = im / (2 t);
 // re > 0: (t, u), else (|u|, copysign(t, im)).
 __device__ __forceinline__ C2 csqrt_lit2(C2 z) {
   if (z.im == 0.0) {
@@ -423,42 +309,6 @@ __device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C,
   const C2 s1 = csqrt_lit2(C2{-(base.re + bw.re), -(base.im + bw.im)});
   const C2 s2 = csqrt_lit2(C2{-(base.re - bw.re), -(base.im - bw.im)});
   const double off = div_with_rcp(-B, 4.0 * A, 0.25 * r1);
-  rr[0] = off + 0.5 * (w.re + s1.re);
-  rr[1] = off + 0.5 * (w.re - s1.re);
-  rr[2] = off + 0.5 * (-w.re + s2.re);
-  rr[3] = off + 0.5 * (-w.re - s2.re);
-}
-__device__ __forceinline__ void solve_quartic_lit(double A, double B, double C, double D, double E, double rr[4]) {
-  const double A_pw2 = A * A, B_pw2 = B * B;
-  const double A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B;
-  const double A_pw4 = A_pw3 * A, B_pw4 = B_pw3 * B;
-  const double alpha = div_nr(-3 * B_pw2, 8 * A_pw2) + div_nr(C, A);
-  const double beta = div_nr(B_pw3, 8 * A_pw3) - div_nr(B * C, 2 * A_pw2) + div_nr(D, A);
-  const double gamma = div_nr(-3 * B_pw4, 256 * A_pw4) + div_nr(B_pw2 * C, 16 * A_pw3) - div_nr(B * D, 4 * A_pw2) +
-                       div_nr(E, A);
-  const double alpha_pw2 = alpha * alpha, alpha_pw3 = alpha_pw2 * alpha;
-  const double Pr = div_nr(-alpha_pw2, 12.0) - gamma;
-  const double Qr = div_nr(-alpha_pw3, 108.0) + div_nr(alpha * gamma, 3.0) - (beta * beta) * 0.125;
-  const C2 q2 = cpow2_real(Qr), p3 = cpow3_real(Pr);
-  const C2 disc = {q2.re * 0.25 + div_nr(p3.re, 27.0), q2.im * 0.25 + div_nr(p3.im, 27.0)};
-  const C2 sq = csqrt_lit(disc);
-  const C2 R = {-Qr * 0.5 + sq.re, sq.im};
-  const C2 U = cpow_third_lit(R);
-  C2 y;
-  const double a56 = div_nr(-5.0 * alpha, 6.0);
-  if (U.re == 0.0) {
-    const C2 qc = cpow_third_lit(C2{Qr, 0.0});
-    y = {a56 - qc.re, -qc.im};
-  } else {
-    const C2 t = cdiv_lit(C2{Pr, 0.0}, cscale(U, 3.0));
-    y = {a56 - t.re + U.re, -t.im + U.im};
-  }
-  const C2 w = csqrt_lit(C2{alpha + 2.0 * y.re, 2.0 * y.im});
-  const C2 bw = cdiv_lit(C2{2.0 * beta, 0.0}, w);
-  const C2 base = {3.0 * alpha + 2.0 * y.re, 2.0 * y.im};
-  const C2 s1 = csqrt_lit(C2{-(base.re + bw.re), -(base.im + bw.im)});
-  const C2 s2 = csqrt_lit(C2{-(base.re - bw.re), -(base.im - bw.im)});
-  const double off = div_nr(-B, 4.0 * A);
   rr[0] = off + 0.5 * (w.re + s1.re);
   rr[1] = off + 0.5 * (w.re - s1.re);
   rr[2] = off + 0.5 * (-w.re + s2.re);

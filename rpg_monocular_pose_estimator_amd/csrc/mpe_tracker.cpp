@@ -321,13 +321,20 @@ void take_result(mpe_tracker* t, const mpe_result& r) {
 int bruteforce(mpe_tracker* t) {  // initialise() + optimiseAndUpdatePose()
   mpe_result r;
   std::vector<uint32_t> c(2 * MPE_MAX_MARKERS, 0);
+  const int nd = (int)t->det.size() / 2, nm = n_markers(t);
+  std::vector<uint32_t> hist((size_t)std::max(1, nd * nm), 0);
   t->used_bruteforce = true;
-  int rc = mpe_solve_bruteforce(t->h, t->det.data(), (int)t->det.size() / 2, t->markers.data(), n_markers(t), t->K,
-                                &t->p, &r, nullptr, c.data());
+  int rc = mpe_solve_bruteforce(t->h, t->det.data(), nd, t->markers.data(), nm, t->K, &t->p, &r, hist.data(), c.data());
   if (rc != MPE_OK) return rc;
   if (r.status < 0) return r.status;
-  t->n_corr = r.n_corr;
-  t->corr.assign(c.begin(), c.begin() + 2 * r.n_corr);
+  // initialise() only assigns correspondences_ when the histogram holds a vote (pose_estimator.cpp:704-719);
+  // with an all-zero histogram the member keeps its previous rows
+  bool any_vote = false;
+  for (uint32_t v : hist) any_vote |= (v != 0);
+  if (any_vote) {
+    t->n_corr = r.n_corr;
+    t->corr.assign(c.begin(), c.begin() + 2 * r.n_corr);
+  }
   if (r.status == MPE_FRAME_POSE) take_result(t, r);
   return MPE_OK;
 }
@@ -478,9 +485,12 @@ int mpe_tracker_set_markers(mpe_tracker* t, const double* xyz, int n) {
 }
 
 int mpe_tracker_set_camera(mpe_tracker* t, const double K[9], const double* D, int nD) {
-  if (!t || !K || nD < 0) return MPE_ERR_ARG;
+  if (!t || !K || nD < 0 || (nD > 0 && !D)) return MPE_ERR_ARG;
   std::memcpy(t->K, K, sizeof(t->K));
-  t->D.assign(D, D + nD);
+  if (nD > 0)
+    t->D.assign(D, D + nD);
+  else
+    t->D.clear();
   return MPE_OK;
 }
 
@@ -590,7 +600,15 @@ int mpe_tracker_run_sequence(mpe_tracker* t, const uint8_t* frames, int n_frames
   for (int f = 0; f < n_frames; ++f) {
     const int rc = mpe_tracker_estimate(t, frames + (size_t)f * frame_stride_bytes, rows, cols, stride_bytes, times[f],
                                         out ? out + f : nullptr, info ? info + 8 * f : nullptr);
-    if (rc < 0) return rc;
+    if (rc <= MPE_FRAME_TOO_MANY_DETECTIONS) {  // this frame exceeded a device capacity: recorded, the sequence goes on
+      if (out) {
+        std::memset(&out[f], 0, sizeof(mpe_result));
+        out[f].status = rc;
+      }
+      if (info) std::memset(info + 8 * f, 0, 8 * sizeof(int));
+      continue;
+    }
+    if (rc < 0) return rc;  // usage / HIP error
     updated += rc;
   }
   return updated;
