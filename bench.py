@@ -7,6 +7,10 @@ Gauss-Newton refine) over one batch of B device-resident frames per GPU; frames 
 embarrassingly across ranks (weak scaling: B per GPU fixed), the only collective is the gather of
 the per-frame pose records to rank 0 (RCCL point-to-point, 432 B/frame, asynchronous, double-buffered).
 
+`python bench.py --gpus N` launches its own N ranks (re-executes itself under torch.distributed.run, one rank per
+GPU, rendezvous on 127.0.0.1) when it was not already started by a launcher (WORLD_SIZE unset); under a launcher it
+checks that WORLD_SIZE == N.  Fewer visible GPUs than ranks is a hard error, never a silent share.
+
 Prints ONE JSON line (rank 0): metric/value as BASELINE.json, plus
   roofline      — the kernel that moves the image bytes in the timed mode (by default the voting kernel that
                   carries the scan of the next sub-batch, else k1a_scan): algorithmic bytes (rows*cols per
@@ -38,6 +42,64 @@ def effective_cores():
     return n
 
 
+def plumbing_only(args, rank, world):
+    """The N-rank bench without GPU work (CPU, gloo): same launch path, sharding, double-buffered pose gather to
+    rank 0, barrier / max-over-ranks timing and JSON line as the real run; every rank's "kernels" are replaced by
+    writing recognisable records for its shard.  Lets the CPU test-suite drive the bench ENTRY with world size 2."""
+    import torch
+    import torch.distributed as dist
+    import rpg_monocular_pose_estimator_amd as mpe
+    from rpg_monocular_pose_estimator_amd import parallel
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = min(args.frames, 4096)
+    pipe = parallel.RootGatherPipeline(rank, world, B * mpe.RESULT_DTYPE.itemsize, torch.device("cpu"))
+    lo, hi = parallel.shard_bounds(world * B, rank, world)  # weak scaling: B frames per rank
+
+    def step(k):
+        buf = pipe.local(k)
+        rec = np.zeros(B, mpe.RESULT_DTYPE)
+        rec["n_det"] = np.arange(lo, hi)   # global frame index
+        rec["n_corr"] = k                  # step marker
+        rec["status"] = rank
+        buf.copy_(torch.from_numpy(np.frombuffer(rec.tobytes(), np.uint8).copy()))
+        pipe.submit(k)
+
+    def barrier():
+        pipe.finish()
+        if world > 1:
+            dist.barrier()
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        last = args.warmup + args.steps - 1
+        got = parallel.records_from_bytes(pipe.gathered(last))
+        ok = (len(got) == world * B and np.array_equal(got["n_det"], np.arange(world * B)) and
+              np.all(got["n_corr"] == last) and np.array_equal(got["status"], np.repeat(np.arange(world), B)))
+        print(json.dumps({"metric": "frames/sec at 752x480, 5 LEDs, brute-force init; pose RMSE vs CPU ref",
+                          "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f64", "data": "synthetic", "plumbing_only": True,
+                          "gather_intact": bool(ok), "records_on_rank0": int(len(got)),
+                          "config": {"workload": "plumbing only: no kernels", "frames_per_gpu_per_step": B}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,22 +116,48 @@ def main():
     ap.add_argument("--pipeline-mode", type=int, default=-1,
                     help="-1 automatic (fused single-stream schedule for <= 5 markers), 0 two-stream pipeline, 3 fused")
     ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
+    ap.add_argument("--vote-arith", type=int, default=1, help="1 fast voting arithmetic (default), 0 strict (IEEE)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="no GPU work: the launch / shard / pose-gather / timing plumbing of the N-rank bench on CPU "
+                         "(gloo), with synthetic records instead of kernels; used by the CPU test-suite")
     args = ap.parse_args()
 
     import torch
-    import rpg_monocular_pose_estimator_amd as mpe
-    from rpg_monocular_pose_estimator_amd import synth, parallel
+
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: start the N ranks ourselves (one process per GPU, RCCL rendezvous on 127.0.0.1)
+        if not args.plumbing_only and torch.cuda.device_count() < args.gpus:
+            sys.exit("bench.py: --gpus %d, but only %d GPU(s) are visible on this box" % (args.gpus, torch.cuda.device_count()))
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.plumbing_only:
+        return plumbing_only(args, rank, world)
+    if torch.cuda.device_count() < max(1, min(world, local_rank + 1)):
+        sys.exit("bench.py: rank %d needs GPU %d, but only %d GPU(s) are visible" % (rank, local_rank, torch.cuda.device_count()))
+
+    import rpg_monocular_pose_estimator_amd as mpe
+    from rpg_monocular_pose_estimator_amd import synth, parallel
+
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
-    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -97,6 +185,7 @@ def main():
     P = mpe.demo_params()
     h.set_option("pipeline", args.pipeline)
     h.set_option("pipeline_mode", args.pipeline_mode)
+    h.set_option("vote_arith", args.vote_arith)
     if args.k1a_lds >= 0:
         h.set_option("k1a_dummy_lds", args.k1a_lds)
 
@@ -120,11 +209,17 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # the K timed steps, bracketed by barrier + synchronize; an event between steps on the work stream gives the
+    # per-step durations as well (median reported next to the mean the bracket yields)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record(work_stream)
+    for i in range(args.steps):
         step()
+        marks[i + 1].record(work_stream)
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -227,7 +322,9 @@ def main():
         out = {
             "metric": "frames/sec at 752x480, 5 LEDs, brute-force init; pose RMSE vs CPU ref",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": float(np.median(step_ms)),
+            "value_at_median_step": world * B / (float(np.median(step_ms)) * 1e-3),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %dx%d synthetic frames, %d LEDs, %d distractors, brute-force P3P init every "
                                    "frame, demo.launch parameters" % (args.config, cols, rows, len(markers),

@@ -133,8 +133,52 @@ def load_library():
                                          C.POINTER(MpeResult), C.POINTER(C.c_int)]
     lib.mpe_tracker_run_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                              C.c_size_t, dp, C.c_void_p, C.c_void_p]
+    hp = C.POINTER(C.c_void_p)
+    lib.mpe_shard_bounds.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mpe_shard_bounds.restype = None
+    lib.mpe_estimate_batch_multi.argtypes = [hp, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                             dp, C.c_int, dp, dp, C.c_int, C.POINTER(MpeParams), C.c_void_p]
+    lib.mpe_estimate_batch_multi_device.argtypes = [hp, C.c_int, hp, C.POINTER(C.c_int), C.c_int, C.c_int, dp, C.c_int,
+                                                    dp, dp, C.c_int, C.POINTER(MpeParams), C.c_void_p]
     _lib = lib
     return lib
+
+
+def shard_bounds(n_frames, shard, n_shards):
+    """mpe_shard_bounds: contiguous chunk [lo, hi) of shard `shard` (host arithmetic, no device)."""
+    lo, hi = C.c_int(), C.c_int()
+    load_library().mpe_shard_bounds(int(n_frames), int(shard), int(n_shards), C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def estimate_batch_multi(handles, frames, markers, K, D, params):
+    """mpe_estimate_batch_multi: one host process, the batch sharded over several handles (= GPUs).
+    frames: numpy (n,rows,cols) uint8 on the host, or a LIST of torch uint8 CUDA tensors, one per handle, each
+    resident on its handle's device (mpe_estimate_batch_multi_device).  -> numpy records in frame order."""
+    lib = load_library()
+    markers = _f64(markers).reshape(-1, 3)
+    K = _f64(K).reshape(9)
+    D = _f64(D).reshape(-1)
+    hs = (C.c_void_p * len(handles))(*[h._h for h in handles])
+    if isinstance(frames, (list, tuple)):
+        assert len(frames) == len(handles)
+        rows, cols = frames[0].shape[1:]
+        ptrs = (C.c_void_p * len(frames))(*[f.data_ptr() for f in frames])
+        counts = (C.c_int * len(frames))(*[f.shape[0] for f in frames])
+        out = np.zeros(sum(f.shape[0] for f in frames), RESULT_DTYPE)
+        rc = lib.mpe_estimate_batch_multi_device(hs, len(handles), ptrs, counts, rows, cols, _dp(markers), len(markers),
+                                                 _dp(K), _dp(D), len(D), C.byref(params), C.c_void_p(out.ctypes.data))
+    else:
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, rows, cols = frames.shape
+        out = np.zeros(n, RESULT_DTYPE)
+        rc = lib.mpe_estimate_batch_multi(hs, len(handles), C.c_void_p(frames.ctypes.data), n, rows, cols,
+                                          frames.strides[1], frames.strides[0], _dp(markers), len(markers), _dp(K),
+                                          _dp(D), len(D), C.byref(params), C.c_void_p(out.ctypes.data))
+    if rc != 0:
+        msgs = [lib.mpe_last_error(h._h).decode() for h in handles]
+        raise MpeError("mpe_estimate_batch_multi failed (%d): %s" % (rc, "; ".join(m for m in msgs if m)))
+    return out
 
 
 def determine_roi(px, rows, cols, border, K, D):

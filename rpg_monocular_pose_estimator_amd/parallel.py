@@ -9,7 +9,8 @@ from .binding import RESULT_DTYPE
 
 
 def shard_bounds(n_frames, rank, world):
-    """Contiguous chunk [lo, hi) of rank `rank`: sizes differ by at most one frame."""
+    """Contiguous chunk [lo, hi) of rank `rank`: sizes differ by at most one frame (the same rule as the C
+    ABI's mpe_shard_bounds, which mpe_estimate_batch_multi uses for its per-device shards)."""
     base, rem = divmod(int(n_frames), int(world))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)

@@ -301,3 +301,75 @@ def test_ros_message_conversions():
             branches.add("xyz"[i])
         assert np.array_equal(g[7:], cov.ravel())
     assert branches == {"w", "x", "y", "z"}
+
+
+def test_c_shard_bounds_equal_python(lib):
+    """mpe_shard_bounds (what mpe_estimate_batch_multi shards by) == parallel.shard_bounds (what the
+    one-process-per-GPU path shards by)."""
+    for n in (0, 1, 7, 8, 4096, 4099, 262144):
+        for w in (1, 2, 3, 4, 8):
+            for r in range(w):
+                assert mpe.shard_bounds(n, r, w) == parallel.shard_bounds(n, r, w)
+
+
+def test_multi_entry_rejects_bad_usage_without_a_device(lib):
+    """The multi-device entry points validate their arguments before touching a device."""
+    p = mpe.demo_params()
+    z = np.zeros(9)
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    out = np.zeros(4, mpe.RESULT_DTYPE)
+    fr = np.zeros((4, 16, 16), np.uint8)
+    rc = lib.mpe_estimate_batch_multi(None, 1, ctypes.c_void_p(fr.ctypes.data), 4, 16, 16, 16, 256, dp(z), 3, dp(z), dp(z), 0,
+                                      ctypes.byref(p), ctypes.c_void_p(out.ctypes.data))
+    assert rc == -1
+    hs = (ctypes.c_void_p * 1)(None)
+    rc = lib.mpe_estimate_batch_multi(hs, 1, ctypes.c_void_p(fr.ctypes.data), 4, 16, 16, 16, 256, dp(z), 3, dp(z), dp(z), 0,
+                                      ctypes.byref(p), ctypes.c_void_p(out.ctypes.data))
+    assert rc == -1
+
+
+def _run_bench(args, env_extra=None, timeout=240):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                          env=env, timeout=timeout)
+
+
+def test_bench_entry_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` (no launcher) starts two ranks itself; on CPU the --plumbing-only mode runs the
+    same launch / shard / double-buffered pose gather / barrier / max-over-ranks path over gloo and rank 0 prints
+    ONE JSON line with n_gpus = 2 and every rank's records in frame order."""
+    import json
+    out = _run_bench(["--gpus", "2", "--plumbing-only", "--steps", "4", "--warmup", "1"])
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-1500:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["plumbing_only"] is True and rec["gather_intact"] is True
+    assert rec["records_on_rank0"] == 2 * rec["config"]["frames_per_gpu_per_step"]
+
+
+def test_bench_entry_under_a_launcher_and_error_paths(lib):
+    """Under torch.distributed.run (what the driver uses) the entry reads RANK / WORLD_SIZE; a WORLD_SIZE that
+    disagrees with --gpus and a --gpus larger than the visible GPU count are hard errors with a clear message."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only",
+           "--steps", "2", "--warmup", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stderr[-1500:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 2 and rec["gather_intact"] is True
+    bad = _run_bench(["--gpus", "2", "--plumbing-only"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr
+    if lib.mpe_device_count() < 2:
+        few = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+        assert few.returncode != 0 and "GPU(s) are visible" in few.stderr, (few.returncode, few.stderr[-400:])

@@ -979,3 +979,70 @@ def test_explicit_correspondences_with_repeated_markers(hip, orc):
         if ok:
             dp, dr = pose_diff(T0h, T0)
             assert dp <= 1e-9 and dr <= 1e-9, (i, dp, dr)
+
+
+@pytest.mark.gpu
+def test_multi_device_entry_from_one_process(hip, orc, tmp_path):
+    """mpe_estimate_batch_multi / _multi_device: the batch sharded over several handles from one host process
+    (on this 1-GPU box: several handles on GPU 0; on an 8-GPU node: one per GPU) gives exactly the records of a
+    single-handle call, in frame order — through ctypes AND from a plain C host program."""
+    import os
+    import subprocess
+    import torch
+    d = synth.make_frames("C2", 37, seed=1234)
+    P = mpe.demo_params()
+    one = hip.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], P)
+    ref = orc.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], orc.make_params(), n_threads=4)
+    assert np.array_equal(one["status"], ref["status"])
+    n_gpu = torch.cuda.device_count()
+    for n_dev in (1, 2, 3):
+        hs = [mpe.Handle(i % n_gpu) for i in range(n_dev)]
+        try:
+            got = mpe.estimate_batch_multi(hs, d["frames"], d["markers"], d["K"], d["D"], P)
+            assert got.tobytes() == one.tobytes(), n_dev
+            shards = []
+            for i in range(n_dev):
+                lo, hi = mpe.shard_bounds(len(d["frames"]), i, n_dev)
+                shards.append(torch.from_numpy(d["frames"][lo:hi].copy()).to("cuda:%d" % (i % n_gpu)))
+            got = mpe.estimate_batch_multi(hs, shards, d["markers"], d["K"], d["D"], P)
+            assert got.tobytes() == one.tobytes(), n_dev
+        finally:
+            for h in hs:
+                h.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_multi")
+    libdir = os.path.dirname(mpe.library_path())
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi_multi.c"), "-o", exe, "-L", libdir, "-lmpe_hip",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    raw, mk = str(tmp_path / "f.raw"), str(tmp_path / "m.txt")
+    d["frames"].tofile(raw)
+    np.savetxt(mk, d["markers"], fmt="%.17g")
+    for n_dev in (1, 2):
+        out = subprocess.run([exe, raw, str(len(d["frames"])), "480", "752", str(n_dev), mk], capture_output=True, text=True)
+        assert out.returncode == 0 and "multi ok" in out.stdout, (n_dev, out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+def test_bench_entry_on_the_gpu_box():
+    """bench.py end to end at a small batch (one JSON line, n_gpus 1, roofline + parity present); `--gpus 2` on a box
+    with fewer than 2 GPUs is a clean, loud error (never a silent single-rank run)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--frames", "32768", "--steps", "3", "--warmup", "1",
+                          "--cpu-sample", "256"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 1e6 and rec["roofline"]["frac"] > 0.3
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["parity"]["pose_mismatches_gt_1e-4m"] == 0
+    if torch.cuda.device_count() < 2:
+        few = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                             capture_output=True, text=True, env=env, timeout=300)
+        assert few.returncode != 0 and "GPU(s) are visible" in few.stderr
