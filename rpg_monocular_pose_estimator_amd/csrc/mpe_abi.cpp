@@ -46,7 +46,7 @@ struct mpe_handle {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string err;
-  DevBuf frames, flags, dets, hist, results, corr, mtab, work, scratch, track;
+  DevBuf frames, flags, dets, hist, results, corr, mtab, work, scratch, track, mid;
   void* mailbox = nullptr;  // pinned host memory for the single-frame tracking step (ROI in, record out)
   size_t mailbox_cap = 0;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
@@ -266,7 +266,7 @@ int run_back(mpe_handle* h, hipStream_t st, bool prof, int n_frames, const Solve
     HIP_TRY(h, launch_k2_vote(d_dets, n_frames, *sp, static_cast<const double*>(h->mtab.p), d_hist,
                               auto_splits(h, n_frames, sp->n_markers), sp->n_markers, st));
     if (prof) rec(h, 3);
-    HIP_TRY(h, launch_k3_tail(d_dets, d_hist, n_frames, *sp, d_results, d_corr, nullptr, nullptr, 0.0, st));
+    HIP_TRY(h, launch_k3_tail(d_dets, d_hist, n_frames, *sp, d_results, d_corr, nullptr, nullptr, 0.0, h->mid.p, st));
   } else if (prof) {
     rec(h, 3);
   }
@@ -365,6 +365,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   if (sp && sp->vote_arith == 0) nsub = 1;  // strict voting arithmetic: one plain chain of kernels (no scan rider)
   h->have_ms = false;
   HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
+  if (sp) HIP_TRY(h, h->mid.reserve(k3_mid_bytes(n_frames)));
   if (nsub <= 1) {
     HIP_TRY(h, h->flags.reserve(flag_words(frame_bytes * n_frames) * 8));
     HIP_TRY(h, h->work.reserve((size_t)2 * (n_frames + 1) * sizeof(int)));
@@ -453,7 +454,8 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       }
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], st));
       HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
-                                d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0, st));
+                                d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0,
+                                static_cast<uint8_t*>(h->mid.p) + k3_mid_bytes(1) * (size_t)f0, st));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], st));
     }
     if (prof) {
@@ -522,7 +524,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], stail));
     HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
                               d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0,
-                              stail));
+                              static_cast<uint8_t*>(h->mid.p) + k3_mid_bytes(1) * (size_t)f0, stail));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], stail));
     if (prof) h->prof_launches = s + 1;
   }
@@ -633,6 +635,7 @@ void mpe_destroy(mpe_handle* h) {
   h->work.release();
   h->scratch.release();
   h->track.release();
+  h->mid.release();
   if (h->mailbox) (void)hipHostFree(h->mailbox);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
@@ -877,6 +880,7 @@ int solve_bruteforce_impl(mpe_handle* h, const double* det_xy, int n_det, const 
   HIP_TRY(h, h->hist.reserve(MPE_HIST_STRIDE * sizeof(uint32_t)));
   HIP_TRY(h, h->results.reserve(sizeof(mpe_result)));
   HIP_TRY(h, h->corr.reserve(2 * MPE_MAX_MARKERS * sizeof(uint32_t)));
+  HIP_TRY(h, h->mid.reserve(k3_mid_bytes(1)));
   HIP_TRY(h, hipMemcpyAsync(h->dets.p, &hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
   HIP_TRY(h, h->mtab.reserve(k2_table_bytes(n_markers)));
@@ -885,7 +889,7 @@ int solve_bruteforce_impl(mpe_handle* h, const double* det_xy, int n_det, const 
                             static_cast<uint32_t*>(h->hist.p), auto_splits(h, 1, n_markers), n_det, h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
                             static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), nullptr,
-                            nullptr, 0.0, h->stream, tail_mode));
+                            nullptr, 0.0, h->mid.p, h->stream, tail_mode));
   uint32_t hh[MPE_HIST_STRIDE], hc[2 * MPE_MAX_MARKERS];
   HIP_TRY(h, hipMemcpyAsync(out, h->results.p, sizeof(mpe_result), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipMemcpyAsync(hh, h->hist.p, sizeof(hh), hipMemcpyDeviceToHost, h->stream));
@@ -935,6 +939,7 @@ int run_tail_single(mpe_handle* h, const double* det_xy, int n_det, const double
   HIP_TRY(h, h->hist.reserve(MPE_HIST_STRIDE * sizeof(uint32_t)));
   HIP_TRY(h, h->results.reserve(sizeof(mpe_result)));
   HIP_TRY(h, h->corr.reserve(2 * MPE_MAX_MARKERS * sizeof(uint32_t)));
+  HIP_TRY(h, h->mid.reserve(k3_mid_bytes(1)));
   HIP_TRY(h, hipMemcpyAsync(h->dets.p, &hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->corr.p, hc, sizeof(hc), hipMemcpyHostToDevice, h->stream));
   if (mode == 2) {
@@ -945,7 +950,7 @@ int run_tail_single(mpe_handle* h, const double* det_xy, int n_det, const double
   }
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
                             static_cast<mpe_result*>(h->results.p), nullptr, static_cast<uint32_t*>(h->corr.p),
-                            nullptr, 0.0, h->stream, mode));
+                            nullptr, 0.0, h->mid.p, h->stream, mode));
   HIP_TRY(h, hipMemcpyAsync(out, h->results.p, sizeof(mpe_result), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPE_OK;
@@ -1061,6 +1066,7 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
   HIP_TRY(h, h->hist.reserve(MPE_HIST_STRIDE * sizeof(uint32_t)));
   HIP_TRY(h, h->track.reserve(sizeof(TrackRecord)));
+  HIP_TRY(h, h->mid.reserve(k3_mid_bytes(1)));
   uint8_t* d_in = static_cast<uint8_t*>(h->frames.p);
   TrackRecord* d_rec = static_cast<TrackRecord*>(h->track.p);
   h->have_ms = false;
@@ -1070,7 +1076,8 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   HIP_TRY(h, launch_k1b_blobs(d_in + kTrackHeader, static_cast<unsigned long long*>(h->flags.p), 1, g, dp, &d_rec->det,
                               static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), 0, h->stream));
   HIP_TRY(h, launch_k3_tail(&d_rec->det, static_cast<uint32_t*>(h->hist.p), 1, sp, &d_rec->res, d_rec->corr, nullptr,
-                            reinterpret_cast<const double*>(d_in), p->nearest_neighbour_pixel_tolerance, h->stream));
+                            reinterpret_cast<const double*>(d_in), p->nearest_neighbour_pixel_tolerance, h->mid.p,
+                            h->stream));
   HIP_TRY(h, hipMemcpyAsync(host_rec, d_rec, sizeof(TrackRecord), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   *dets_out = host_rec->det;

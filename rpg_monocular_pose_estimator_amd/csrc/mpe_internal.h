@@ -64,9 +64,11 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
                           uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px = nullptr,
                           size_t scan_bytes = 0, unsigned long long* scan_flags = nullptr, int scan_thr = 0,
                           size_t* scanned_bytes = nullptr);
+// the tail = k3a_validate + k3b_refine; mid_buf: k3_mid_bytes(n_frames) of device memory handed from one to the other
+size_t k3_mid_bytes(int n_frames);
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
                           mpe_result* results, uint32_t* corr_out, const uint32_t* corr_in, const double* nn_pred,
-                          double nn_tol, hipStream_t s, int mode = 0);
+                          double nn_tol, void* mid_buf, hipStream_t s, int mode = 0);
 hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int n_frames, int roi_x,
                          int roi_y, int roi_w, int roi_h, uint8_t* dst, int dst_pitch, hipStream_t s);
 

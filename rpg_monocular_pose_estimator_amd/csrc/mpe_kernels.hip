@@ -16,9 +16,10 @@
 //                     k2_vote<true> additionally carries the image scan of the NEXT sub-batch on
 //                     its idle memory pipeline (ScanRider: global_load_lds LDS-DMA rounds served
 //                     between pieces of P3P arithmetic) — the default schedule for <= 5 markers.
-//   K3   k3_tail    : one lane per frame; histogram peeling, checkCorrespondences, Kabsch,
-//                     Gauss-Newton refine + covariance.  (pose_estimator.cpp:344-370, 394-542,
-//                     733-792, 908-994)
+//   K3a  k3a_validate : 16 lanes per frame; histogram peeling, the C(n_c,3) P3P validations of
+//                     checkCorrespondences summed in combination order.  (pose_estimator.cpp:344-370, 394-542)
+//   K3b  k3b_refine : one lane per frame; Kabsch, Gauss-Newton refine + covariance.
+//                     (pose_estimator.cpp:733-792, 908-994)
 //
 // FP64 everywhere on the geometry path (the reference is double; vote thresholds are knife
 // edges), no MFMA (no dense contraction on this path), compiled with -ffp-contract=off.
@@ -1997,31 +1998,36 @@ __device__ __forceinline__ void apply_exp(const double tw[6], T34& T) {
   T = N;
 }
 
-#define K3_GROUP 16                 // lanes cooperating on one frame
+#define K3_GROUP 16                 // lanes cooperating on one frame in the validation kernel
 #define K3_FRAMES_PER_BLOCK 4       // one wave = 4 frames
-#define K3_NU_MAX (MPE_MAX_MARKERS - 3)
+#define K3B_THREADS 64              // refinement kernel: one lane per frame
 
-// butterfly sum over the 16 lanes of a group; every lane ends with the same total
-__device__ __forceinline__ double group_sum(double v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
-  return v;
-}
+// What the validation kernel hands to the refinement kernel, one record per frame (global memory).
+struct TailMid {
+  int n_c;             // rows of correspondences_
+  int active;          // 1: computeTransformation / optimisePose run for this frame
+  unsigned num_valid;  // P3P triples with a valid solution (pose_estimator.cpp:506)
+  unsigned pad;
+  unsigned char cm[MPE_MAX_MARKERS], cd[MPE_MAX_MARKERS];  // rows (marker, detection), 1-based
+  double mean[3 * MPE_MAX_MARKERS];  // sum over the valid triples of inverse(H_best) * marker (not yet divided)
+};
+size_t k3_mid_bytes(int n_frames) { return (size_t)(n_frames > 0 ? n_frames : 1) * sizeof(TailMid); }
 
-// MODE 0: the whole tail (batch path).  MODE 1: checkCorrespondences only — the pose of
-// computeTransformation is returned unrefined (stage entry point mpe_check_correspondences).
-// MODE 2: optimisePose only, started from the pose found in results[f].T, on corr_in as given
-// (mpe_optimise_pose).  Separate instantiations: the batch kernel's code is not affected.
+// ---------------------------------------------------------------------------------------------
+// K3a  k3a_validate: 16 lanes per frame (4 frames per wave).  Lane 0 of a group builds the correspondences
+// (histogram peeling, given rows, or nearest neighbour), then the C(n_c,3) P3P validations of
+// checkCorrespondences run 16 at a time, one per lane, and are summed in combination order.
+// MODE 0 / 1: as described.  MODE 2 (optimisePose alone): only the rows are parsed, no validation.
+// ---------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__ dets,
-                                              const uint32_t* __restrict__ hist, int n_frames, SolveParams sp,
-                                              mpe_result* __restrict__ results, uint32_t* __restrict__ corr_out,
-                                              const uint32_t* __restrict__ corr_in,
-                                              const double* __restrict__ nn_pred, double nn_tol) {
-  // dynamic LDS, sized for the actual marker count: partial sums [4][16][3 n_m] and
-  // back-projections [2 (n_m - 3)][64]
+__global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restrict__ dets,
+                                                   const uint32_t* __restrict__ hist, int n_frames, SolveParams sp,
+                                                   mpe_result* __restrict__ results, uint32_t* __restrict__ corr_out,
+                                                   const uint32_t* __restrict__ corr_in,
+                                                   const double* __restrict__ nn_pred, double nn_tol,
+                                                   TailMid* __restrict__ mid) {
+  // dynamic LDS, sized for the actual marker count: per-lane contributions [4][16][3 n_m] and
+  // back-projections [2 (rows - 3)][64]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   const int nm3 = 3 * sp.n_markers;
   double* s_part_ = reinterpret_cast<double*>(smem3);
@@ -2056,14 +2062,10 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
     s_det[grp][i][0] = d->undist_xy[2 * i];
     s_det[grp][i][1] = d->undist_xy[2 * i + 1];
   }
-  T34 T;
-  if (MODE == 2) {  // start pose (read by every lane before the default output overwrites it)
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 4; ++c) T.m[r][c] = live ? res->T[r * 4 + c] : ((r == c) ? 1.0 : 0.0);
-    __syncthreads();
+  if (live && MODE != 2) {  // (MODE 2: results[f].T holds the start pose for the refinement kernel)
+    for (int i = l; i < 16; i += K3_GROUP) res->T[i] = (i % 5 == 0) ? 1.0 : 0.0;
   }
   if (live) {
-    for (int i = l; i < 16; i += K3_GROUP) res->T[i] = (i % 5 == 0) ? 1.0 : 0.0;
     for (int i = l; i < 36; i += K3_GROUP) res->cov[i] = 0.0;
     if (corr_out)
       for (int i = l; i < 2 * MPE_MAX_MARKERS; i += K3_GROUP) corr_out[(size_t)f * 2 * MPE_MAX_MARKERS + i] = 0;
@@ -2282,24 +2284,85 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
   }
   bool active = go && ((double)num_valid / (double)N >= sp.valid_corr_thr);
   if (MODE == 2) active = n_c >= 3;  // fewer rows leave the 6x6 normal equations singular
+  if (live) {
+    TailMid* m = mid + f;
+    if (l == 0) {
+      m->n_c = n_c;
+      m->active = active ? 1 : 0;
+      m->num_valid = num_valid;
+      m->pad = 0;
+    }
+    if (l < n_c) {
+      m->cm[l] = s_cm[grp][l];
+      m->cd[l] = s_cd[grp][l];
+    }
+    if (active)
+      for (int v = l; v < nm3; v += K3_GROUP) m->mean[v] = s_mean[grp][v];
+  }
+#undef s_part
+#undef s_q
+}
 
-  // ---- computeTransformation (pose_estimator.cpp:908-930); evaluated by every lane of the group
-  if (MODE != 2 && active) {
+// ---------------------------------------------------------------------------------------------
+// K3b  k3b_refine: ONE LANE PER FRAME.  computeTransformation (Kabsch, pose_estimator.cpp:908-930), then
+// optimisePose (pose_estimator.cpp:733-792): Gauss-Newton on SE(3), the normal equations accumulated over
+// the correspondences one after the other in row order — the reference's summation order —, unpivoted LDL^T,
+// exponentialMap update, covariance = inverse of the last iteration's A (pose_estimator.cpp:790).
+// Everything is lane-local: no shuffles, no barriers inside the iteration; lanes of frames without a pose
+// (or whose iteration has converged) idle.  A 16 384-frame sub-batch is 256 waves of ~8 k instructions.
+// MODE 0: Kabsch + GN.  MODE 1: Kabsch only (checkCorrespondences alone).  MODE 2: GN from results[f].T.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(K3B_THREADS) void k3b_refine(const mpe_detections* __restrict__ dets, int n_frames,
+                                                          SolveParams sp, mpe_result* __restrict__ results,
+                                                          const TailMid* __restrict__ mid, int row_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3b[];
+  // per-lane rows of (marker xyz, detection uv), [row][field][lane]: conflict-free, dynamic row index
+  double* s_row = reinterpret_cast<double*>(smem3b);
+#define ROW(r_, k_) s_row[((r_)*5 + (k_)) * K3B_THREADS + threadIdx.x]
+  const int f = blockIdx.x * K3B_THREADS + threadIdx.x;
+  if (f >= n_frames) return;
+  const TailMid* m = mid + f;
+  if (!m->active) return;
+  const mpe_detections* d = dets + f;
+  mpe_result* res = results + f;
+  const int n_m = sp.n_markers;
+  const int n_c = min(m->n_c, row_cap);
+  const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
+  for (int j = 0; j < n_c; ++j) {
+    const int mi = m->cm[j] - 1, di = m->cd[j] - 1;
+    ROW(j, 0) = sp.markers[3 * mi];
+    ROW(j, 1) = sp.markers[3 * mi + 1];
+    ROW(j, 2) = sp.markers[3 * mi + 2];
+    ROW(j, 3) = d->undist_xy[2 * di];
+    ROW(j, 4) = d->undist_xy[2 * di + 1];
+  }
+  T34 T;
+  if (MODE == 2) {
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) T.m[r][c] = res->T[r * 4 + c];
+  } else {
+    // ---- computeTransformation (pose_estimator.cpp:908-930)
+    const double nv = (double)m->num_valid;
     double mo[3] = {0, 0, 0}, mr[3] = {0, 0, 0};
     for (int i = 0; i < n_m; ++i)
       for (int k = 0; k < 3; ++k) {
-        mo[k] += s_mk[i][k];
-        mr[k] += s_mean[grp][3 * i + k] / (double)num_valid;
+        mo[k] += sp.markers[3 * i + k];
+        mr[k] += m->mean[3 * i + k] / nv;
       }
     for (int k = 0; k < 3; ++k) {
       mo[k] /= (double)n_m;
       mr[k] /= (double)n_m;
     }
     double Hm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (int i = 0; i < n_m; ++i)
+    for (int i = 0; i < n_m; ++i) {
+      const double a[3] = {sp.markers[3 * i] - mo[0], sp.markers[3 * i + 1] - mo[1], sp.markers[3 * i + 2] - mo[2]};
+      const double b[3] = {m->mean[3 * i] / nv - mr[0], m->mean[3 * i + 1] / nv - mr[1], m->mean[3 * i + 2] / nv - mr[2]};
+#pragma unroll
       for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c)
-          Hm[r][c] += (s_mk[i][r] - mo[r]) * (s_mean[grp][3 * i + c] / (double)num_valid - mr[c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Hm[r][c] += a[r] * b[c];
+    }
     double X[3][3];
     kabsch_rotation(Hm, X);  // R = V U^T
     for (int r = 0; r < 3; ++r) {
@@ -2308,64 +2371,49 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
     }
   }
 
-  // ---- optimisePose (pose_estimator.cpp:733-792): Gauss-Newton on SE(3).  Lane j of the group
-  //      evaluates correspondence j (J^T J and J^T e, upper triangle), a butterfly sum gives every
-  //      lane the normal equations, and all lanes take the same LDL^T / exp-map step.
-  double mkx = 0, mky = 0, mkz = 0, du_ = 0, dv_ = 0;
-  bool has = false;
-  if (active && l < n_c) {  // n_c <= MPE_MAX_MARKERS = K3_GROUP
-    const int mi = s_cm[grp][l] - 1, di = s_cd[grp][l] - 1;
-    mkx = s_mk[mi][0];
-    mky = s_mk[mi][1];
-    mkz = s_mk[mi][2];
-    du_ = s_det[grp][di][0];
-    dv_ = s_det[grp][di][1];
-    has = true;
-  }
+  // ---- optimisePose (pose_estimator.cpp:733-792)
   double A[6][6];
 #pragma unroll
   for (int r = 0; r < 6; ++r)
 #pragma unroll
     for (int c = 0; c < 6; ++c) A[r][c] = 0;
   int iters = 0;
-  bool running = active;
-  for (int it = 0; it < (MODE == 1 ? 0 : 500); ++it) {
-    if (!__any(running)) break;
-    double J0[6] = {0, 0, 0, 0, 0, 0}, J1[6] = {0, 0, 0, 0, 0, 0}, e0 = 0, e1 = 0;
-    if (running && has) {
-      const double mk[3] = {mkx, mky, mkz};
-      double u, v, x, y, z;
-      project_T(T, mk, fx, fy, cx, cy, u, v, x, y, z);
-      e0 = du_ - u;
-      e1 = dv_ - v;
-      const double z_2 = z * z;
-      // computeJacobian, pose_estimator.cpp:945-957
-      J0[0] = 1 / z * fx;
-      J0[2] = -x / z_2 * fx;
-      J0[3] = -x * y / z_2 * fx;
-      J0[4] = (1 + (x * x / z_2)) * fx;
-      J0[5] = -y / z * fx;
-      J1[1] = 1 / z * fy;
-      J1[2] = -y / z_2 * fy;
-      J1[3] = -(1 + y * y / z_2) * fy;
-      J1[4] = x * y / z_2 * fy;
-      J1[5] = x / z * fy;
-    }
-    double An[6][6], b[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-#pragma unroll
-      for (int c = r; c < 6; ++c) {
-        An[r][c] = group_sum(J0[r] * J0[c] + J1[r] * J1[c]);
-        An[c][r] = An[r][c];
-      }
-      b[r] = group_sum(J0[r] * e0 + J1[r] * e1);
-    }
-    if (running) {
+  if (MODE != 1) {
+    for (int it = 0; it < 500; ++it) {
+      double b[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c < 6; ++c) A[r][c] = An[r][c];
+        for (int c = 0; c < 6; ++c) A[r][c] = 0;
+      for (int j = 0; j < n_c; ++j) {
+        const double mk[3] = {ROW(j, 0), ROW(j, 1), ROW(j, 2)};
+        double u, v, x, y, z;
+        project_T(T, mk, fx, fy, cx, cy, u, v, x, y, z);
+        const double e0 = ROW(j, 3) - u, e1 = ROW(j, 4) - v;
+        const double z_2 = z * z;
+        // computeJacobian, pose_estimator.cpp:945-957
+        double J0[6] = {0, 0, 0, 0, 0, 0}, J1[6] = {0, 0, 0, 0, 0, 0};
+        J0[0] = 1 / z * fx;
+        J0[2] = -x / z_2 * fx;
+        J0[3] = -x * y / z_2 * fx;
+        J0[4] = (1 + (x * x / z_2)) * fx;
+        J0[5] = -y / z * fx;
+        J1[1] = 1 / z * fy;
+        J1[2] = -y / z_2 * fy;
+        J1[3] = -(1 + y * y / z_2) * fy;
+        J1[4] = x * y / z_2 * fy;
+        J1[5] = x / z * fy;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+          for (int c = r; c < 6; ++c) A[r][c] += J0[r] * J0[c] + J1[r] * J1[c];  // A += J^T J (upper triangle)
+          b[r] += J0[r] * e0 + J1[r] * e1;                                       // b += J^T e
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < r; ++c) A[r][c] = A[c][r];
       LDL6 F;
       ldl6_factor(A, F);
       double dT[6];
@@ -2378,52 +2426,59 @@ __global__ __launch_bounds__(64) void k3_tail(const mpe_detections* __restrict__
         const double av = fabs(dT[r]);
         if (av > mx) mx = av;
       }
-      if (mx <= 1e-13) running = false;
+      if (mx <= 1e-13) break;
     }
-  }
-  if (!active) return;
-  // pose_covariance_ = A.inverse() with the A of the last iteration (pose_estimator.cpp:790);
-  // lane c of the group solves for column c
-  if (MODE != 1) {
+    // pose_covariance_ = A.inverse() with the A of the last iteration (pose_estimator.cpp:790)
     LDL6 F;
     ldl6_factor(A, F);
-    if (l < 6) {
+#pragma unroll 1
+    for (int c = 0; c < 6; ++c) {
       double e[6], x[6];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) e[r] = (r == l) ? 1.0 : 0.0;
+      for (int r = 0; r < 6; ++r) e[r] = (r == c) ? 1.0 : 0.0;
       ldl6_solve(F, e, x);
 #pragma unroll
-      for (int r = 0; r < 6; ++r) res->cov[r * 6 + l] = x[r];
+      for (int r = 0; r < 6; ++r) res->cov[r * 6 + c] = x[r];
     }
   }
-  if (l == 0) {
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 4; ++c) res->T[r * 4 + c] = T.m[r][c];
-    res->gn_iterations = iters;
-    res->status = MPE_FRAME_POSE;
-  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) res->T[r * 4 + c] = T.m[r][c];
+  res->T[12] = 0.0;
+  res->T[13] = 0.0;
+  res->T[14] = 0.0;
+  res->T[15] = 1.0;
+  res->gn_iterations = iters;
+  res->status = MPE_FRAME_POSE;
+#undef ROW
 }
 
-#undef s_part
-#undef s_q
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
                           mpe_result* results, uint32_t* corr_out, const uint32_t* corr_in, const double* nn_pred,
-                          double nn_tol, hipStream_t s, int mode) {
+                          double nn_tol, void* mid_buf, hipStream_t s, int mode) {
   if (n_frames <= 0) return hipSuccess;
+  TailMid* mid = static_cast<TailMid*>(mid_buf);
   // explicit correspondences (corr_in) may hold up to MPE_MAX_MARKERS rows, also more than n_markers (repeated
-  // markers are defined input for checkCorrespondences): size the back-projection buffer for the row capacity
-  const int nu = corr_in ? MPE_MAX_MARKERS - 3 : (sp.n_markers > 3 ? sp.n_markers - 3 : 1);
-  const size_t lds = ((size_t)K3_FRAMES_PER_BLOCK * K3_GROUP * 3 * sp.n_markers + (size_t)2 * nu * 64) * sizeof(double);
-  const dim3 grid((n_frames + K3_FRAMES_PER_BLOCK - 1) / K3_FRAMES_PER_BLOCK);
+  // markers are defined input for checkCorrespondences): size the row buffers for the row capacity
+  const int rows = corr_in ? MPE_MAX_MARKERS : (sp.n_markers > 3 ? sp.n_markers : 4);
+  const int nu = rows - 3;
+  const size_t lds_a = ((size_t)K3_FRAMES_PER_BLOCK * K3_GROUP * 3 * sp.n_markers + (size_t)2 * nu * 64) * sizeof(double);
+  const size_t lds_b = (size_t)rows * 5 * K3B_THREADS * sizeof(double);
+  const dim3 grid_a((n_frames + K3_FRAMES_PER_BLOCK - 1) / K3_FRAMES_PER_BLOCK);
+  const dim3 grid_b((n_frames + K3B_THREADS - 1) / K3B_THREADS);
+#define K3_LAUNCH(M_)                                                                                              \
+  do {                                                                                                             \
+    hipLaunchKernelGGL(k3a_validate<M_>, grid_a, dim3(64), lds_a, s, dets, hist, n_frames, sp, results, corr_out,  \
+                       corr_in, nn_pred, nn_tol, mid);                                                             \
+    hipLaunchKernelGGL(k3b_refine<M_>, grid_b, dim3(K3B_THREADS), lds_b, s, dets, n_frames, sp, results,           \
+                       (const TailMid*)mid, rows);                                                                 \
+  } while (0)
   if (mode == 1)
-    hipLaunchKernelGGL(k3_tail<1>, grid, dim3(64), lds, s, dets, hist, n_frames, sp, results, corr_out, corr_in, nn_pred,
-                       nn_tol);
+    K3_LAUNCH(1);
   else if (mode == 2)
-    hipLaunchKernelGGL(k3_tail<2>, grid, dim3(64), lds, s, dets, hist, n_frames, sp, results, corr_out, corr_in, nn_pred,
-                       nn_tol);
+    K3_LAUNCH(2);
   else
-    hipLaunchKernelGGL(k3_tail<0>, grid, dim3(64), lds, s, dets, hist, n_frames, sp, results, corr_out, corr_in, nn_pred,
-                       nn_tol);
+    K3_LAUNCH(0);
+#undef K3_LAUNCH
   return hipGetLastError();
 }
 
