@@ -1309,9 +1309,11 @@ struct ScanRider {
   template <int K>
   static __device__ __forceinline__ void dma_rounds(const uint4* p, uint4* l) {
     if constexpr (K < K2_SCAN_R) {
+      // cache policy sc0 | nt (aux = 1 | 2): the pixels are read exactly once — streaming them past the caches
+      // took the fused kernel from 1.045 to 0.95 ms per 5.9 GB on MI355X (nt alone 0.98, sc0 alone 1.035)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                        (__attribute__((address_space(3))) void*)l, 16,
-                                       (K - K2_SCAN_R / 2) * 1024, 0);
+                                       (K - K2_SCAN_R / 2) * 1024, 3);
       dma_rounds<K + 1>(p, l);
     }
   }
