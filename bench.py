@@ -242,7 +242,7 @@ def main():
     launches, fpl = int(kms[0]["launches"]), int(kms[0]["frames_per_launch"])
     kavg["launches"], kavg["frames_per_launch"] = launches, fpl
     bytes_per_launch = min(fpl, B) * rows * cols  # algorithmic: every pixel read once
-    fused = schedule == 3 and launches > 1
+    fused = schedule in (3, 4) and launches > 1
     if fused:
         # fused schedule: the scan of sub-batch s+1 runs INSIDE the voting kernel of sub-batch s; only the first
         # sub-batch is scanned by a stand-alone k1a_scan launch.  Average the launches that do the same thing.
@@ -331,7 +331,7 @@ def main():
                                                                       cfg["n_distractors"]),
                        "frames_per_gpu_per_step": B, "frames_resident_in_hbm": True,
                        "streams_per_gpu": args.pipeline,
-                       "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel"}.get(schedule, schedule),
+                       "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel", 4: "fused + validate/refine on a side stream"}.get(schedule, schedule),
                        "side_streams_concurrent": h.get_option("streams_concurrent"),
                        "parallelism": "frames sharded over %d GPU(s), pose records gathered to rank 0 (async, double-buffered)" % world},
             "poses_found_frac": n_pose / B,

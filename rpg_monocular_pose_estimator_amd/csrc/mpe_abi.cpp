@@ -56,7 +56,8 @@ struct mpe_handle {
   int k1a_dummy_lds = -1;      // tuning: dummy LDS per scan block in the two-stream schedule (-1 = automatic)
   int last_schedule = 0;       // schedule the last large batch actually ran with
   int pipeline_mode = -1;      // -1 automatic; 0 two-stream staggered pipeline, 3 fused single stream (scan rides in the voting
-                               // kernel); 1 / 2 experiment variants of the two-stream schedule
+                               // kernel), 4 fused + validate / refine on a side stream; 1 / 2 experiment variants of the
+                               // two-stream schedule
   bool profiling = false;
   int pipeline = 16;  // a large call is cut into up to this many sub-batches (about 16384 frames each, never
                       // below 8192) that the schedules pipeline against each other; 1 = one chain of kernels
@@ -68,6 +69,8 @@ struct mpe_handle {
   hipEvent_t vote_done[kMaxSub] = {};
   hipEvent_t scan_done[kMaxSub] = {};
   hipEvent_t fork_ev = nullptr;
+  hipStream_t tail_stream = nullptr;  // fused schedule, mode 4: validate + refine of sub-batch s beside blobs(s + 1)
+  hipEvent_t tail_done = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // per-sub-batch kernel brackets for the pipelined mode: [s][0..1] scan, [2..3] blobs (all tiers),
   // [4..5] vote, [6..7] tail
@@ -396,14 +399,22 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   // the scan (its LDS copy of the marker table exists for <= 5 markers), else the two-stream pipeline — unless the
   // probe finds no pair of concurrently executing side streams, in which case it could not overlap anything.
   int schedule = h->pipeline_mode;
-  if (schedule < 0) schedule = (sp && sp->n_markers <= 5) ? 3 : 0;
+  if (schedule < 0) schedule = (sp && sp->n_markers <= 5) ? 4 : 0;
   if (schedule == 0 && sp && sp->n_markers <= 5) {
     const int rc = pick_concurrent_streams(h);
     if (rc) return rc;
-    if (h->streams_concurrent == 0) schedule = 3;
+    if (h->streams_concurrent == 0) schedule = 4;
   }
   h->last_schedule = schedule;
-  if (schedule == 3) {
+  if (schedule == 3 || schedule == 4) {
+    const bool side_tail = schedule == 4;
+    if (side_tail) {
+      if (!h->tail_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
+      if (!h->tail_done) HIP_TRY(h, hipEventCreateWithFlags(&h->tail_done, hipEventDisableTiming));
+      if (!h->vote_done[0])
+        for (int i = 0; i < mpe_handle::kMaxSub; ++i)
+          HIP_TRY(h, hipEventCreateWithFlags(&h->vote_done[i], hipEventDisableTiming));
+    }
     // Fused schedule, ONE stream: the voting kernel of sub-batch s carries the image scan of sub-batch
     // s + 1 on its idle memory pipeline (ScanRider in mpe_kernels.hip).
     //   scan(0) | blobs(0) vote(0)+scan(1) tail(0) | blobs(1) vote(1)+scan(2) tail(1) | ...
@@ -452,11 +463,23 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
           HIP_TRY(h, launch_k1a_scan(nfr + scanned, nbytes - scanned, nfl + scanned / 1024, dp.thr, scan_lds(h, false), st));
         if (prof) HIP_TRY(h, hipEventRecord(h->pev[s + 1][1], st));
       }
-      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], st));
+      // validate + refine of this sub-batch: on the caller's stream, or (mode 4) on a side stream so that its
+      // thin, latency-bound kernels run beside the blob extraction of the next sub-batch
+      hipStream_t tst = st;
+      if (side_tail) {
+        HIP_TRY(h, hipEventRecord(h->vote_done[s], st));
+        HIP_TRY(h, hipStreamWaitEvent(h->tail_stream, h->vote_done[s], 0));
+        tst = h->tail_stream;
+      }
+      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], tst));
       HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
                                 d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0,
-                                static_cast<uint8_t*>(h->mid.p) + k3_mid_bytes(1) * (size_t)f0, st));
-      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], st));
+                                static_cast<uint8_t*>(h->mid.p) + k3_mid_bytes(1) * (size_t)f0, tst));
+      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], tst));
+    }
+    if (side_tail) {  // join: the call behaves like one operation on the caller's stream
+      HIP_TRY(h, hipEventRecord(h->tail_done, h->tail_stream));
+      HIP_TRY(h, hipStreamWaitEvent(st, h->tail_done, 0));
     }
     if (prof) {
       h->prof_launches = used;
@@ -649,6 +672,8 @@ void mpe_destroy(mpe_handle* h) {
     for (auto& e : row)
       if (e) (void)hipEventDestroy(e);
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
+  if (h->tail_done) (void)hipEventDestroy(h->tail_done);
+  if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
   for (auto& st : h->sub_stream)
     if (st) (void)hipStreamDestroy(st);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);

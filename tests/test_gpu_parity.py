@@ -720,9 +720,12 @@ def test_full_size_batch_properties(orc):
     fused = run(frames, 8)
     assert h.get_option("last_schedule") == 3
     assert torch.equal(fused, plain)
-    h.set_option("pipeline_mode", -1)                      # automatic = fused for a 5-marker object
+    h.set_option("pipeline_mode", 4)                       # fused + validate / refine on a side stream
+    fused4 = run(frames, 8)
+    assert h.get_option("last_schedule") == 4 and torch.equal(fused4, plain)
+    h.set_option("pipeline_mode", -1)                      # automatic = fused (4) for a 5-marker object
     piped = run(frames, 8)
-    assert h.get_option("last_schedule") == 3 and torch.equal(piped, plain)
+    assert h.get_option("last_schedule") == 4 and torch.equal(piped, plain)
     flipped = torch.flip(frames, dims=[0]).contiguous()
     torch.cuda.synchronize()
     rev = run(flipped, 8)
