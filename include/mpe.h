@@ -316,7 +316,7 @@ int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
  * for the blob bitmaps, 8192..163840), "vote_splits" (workgroups per frame in the voting kernel,
  * 0 = auto), "pipeline" (a large call is cut into up to this many sub-batches of about 16384 frames,
  * default 16, 1 = one chain of four kernels), "pipeline_mode" (how the sub-batches are scheduled:
- * -1 automatic (default) = 4 for marker sets of <= 5 markers, else 0;  0 = two-stream software
+ * -1 automatic (default) = 4;  0 = two-stream software
  * pipeline, the scan of sub-batch s+1 beside the voting of sub-batch s;  3 = fused, one stream: the
  * scan of sub-batch s+1 rides inside the voting kernel of sub-batch s;  4 = as 3, with the validate /
  * refine kernels of sub-batch s on an internal side stream, beside the blob extraction of sub-batch

@@ -399,8 +399,11 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   // the scan (its LDS copy of the marker table exists for <= 5 markers), else the two-stream pipeline — unless the
   // probe finds no pair of concurrently executing side streams, in which case it could not overlap anything.
   int schedule = h->pipeline_mode;
-  if (schedule < 0) schedule = (sp && sp->n_markers <= 5) ? 4 : 0;
-  if (schedule == 0 && sp && sp->n_markers <= 5) {
+  // automatic: the fused schedule for every marker count.  For more than 5 markers the voting kernel cannot carry
+  // the scan (its LDS table would not fit) and launch_k2_vote falls back to the plain kernel + a stand-alone scan —
+  // the voting then takes > 95 % of a sub-batch anyway (C(n_d,3) P(n_m,3) P3P solves), so nothing is lost.
+  if (schedule < 0) schedule = 4;
+  if (schedule == 0) {
     const int rc = pick_concurrent_streams(h);
     if (rc) return rc;
     if (h->streams_concurrent == 0) schedule = 4;

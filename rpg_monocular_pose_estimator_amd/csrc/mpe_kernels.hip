@@ -32,6 +32,7 @@ namespace mpe {
 
 typedef unsigned long long u64;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // =============================================================================================
 // K1a — image scan
@@ -1386,6 +1387,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   __shared__ double s_tri[TRI][13];  // T rows (9), f_1, f_2, b, f_1/f_2
   __shared__ unsigned s_trii[TRI];   // c0 | c1 << 8 | c2 << 16 | swap << 24
   __shared__ unsigned s_hist[MPE_HIST_STRIDE];
+  __shared__ f32x2 s_pxf[MPE_MAX_DETECTIONS];  // the detections in single precision (nearest-neighbour prefilter)
 
   const int f = blockIdx.x / splits, part = blockIdx.x - f * splits;
   const int tid = threadIdx.x;
@@ -1404,6 +1406,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
     const double u = d->undist_xy[2 * tid], v = d->undist_xy[2 * tid + 1];
     s_px[tid][0] = u;
     s_px[tid][1] = v;
+    s_pxf[tid] = f32x2{(float)u, (float)v};
     const V3 b = bearing(u, v, sp.fx, sp.fy, sp.cx, sp.cy);
     s_iv[tid][0] = b.x;
     s_iv[tid][1] = b.y;
@@ -1415,6 +1418,14 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   const int n_combos = n_d * (n_d - 1) * (n_d - 2) / 6;
   const int n_perms = n_m * (n_m - 1) * (n_m - 2);
   const int nuo = n_m - 3;
+  // single-precision copies of the back-projections behind the double ones: [j][tid] (plain variant)
+  f32x2* s_qf = reinterpret_cast<f32x2*>(s_q + (size_t)2 * nuo * nthr);
+  // Nearest-neighbour prefilter: a detection can only vote if its exact distance to some back-projection is below
+  // tol; single precision places both points within 1e-3 px for any point that close to a detection (pixel
+  // coordinates < 4096), so "minimum single-precision distance <= tol (1 + 1e-4) + 0.05" is a safe necessary
+  // condition, and the exact double-precision search below only runs for the few detections that pass it.
+  const double tol_pre = sp.back_tol * (1.0 + 1e-4) + 0.05;
+  const float thr_pre = (float)(tol_pre * tol_pre * (1.0 + 1e-5));
   const int esz = k2_entry_doubles(n_m);
   const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
   // block row with P1 <-> P2 exchanged: {2, 5, 0, 4, 3, 1}, packed 4 bits per row as 0x134052
@@ -1584,6 +1595,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
         const double T00 = tr[0], T01 = tr[1], T02 = tr[2], T10 = tr[3], T11 = tr[4], T12 = tr[5], T20 = tr[6],
                      T21 = tr[7], T22 = tr[8];
         double q0u = 0, q0v = 0, q1u = 0, q1v = 0;
+        f32x2 q0f = {0.f, 0.f}, q1f = {0.f, 0.f};
         for (int j = 0; j < nuo; ++j) {
           const double* mk = SCAN ? lt + 5 + 3 * j : e + 18 + 3 * j;
           const double v0 = mk[0] - Cx, v1 = mk[1] - Cy, v2 = mk[2] - Cz;
@@ -1600,13 +1612,16 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
             if (j == 0) {
               q0u = qu;
               q0v = qv;
+              q0f = f32x2{(float)qu, (float)qv};
             } else {
               q1u = qu;
               q1v = qv;
+              q1f = f32x2{(float)qu, (float)qv};
             }
           } else {
             s_q[(2 * j) * nthr + tid] = qu;
             s_q[(2 * j + 1) * nthr + tid] = qv;
+            s_qf[j * nthr + tid] = f32x2{(float)qu, (float)qv};
           }
         }
         // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
@@ -1618,6 +1633,19 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           a += (a >= c0);
           a += (a >= c1);
           a += (a >= c2);
+          {  // single-precision prefilter (packed arithmetic: both coordinates per instruction)
+            const f32x2 af = s_pxf[a];
+            float mn = INFINITY;
+#pragma unroll 4
+            for (int jj = 0; jj < nuo; ++jj) {
+              const f32x2 qf = SCAN ? (jj == 0 ? q0f : q1f) : s_qf[jj * nthr + tid];
+              f32x2 df = af - qf;
+              df = df * df;
+              const float d2f = df.x + df.y;
+              mn = d2f < mn ? d2f : mn;  // (a NaN distance never wins, as in the exact search)
+            }
+            if (!(mn <= thr_pre)) continue;
+          }
           const double au = s_px[a][0], av = s_px[a][1];
           double best = INFINITY;
           int bj = 0;
@@ -1796,7 +1824,7 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
       }
     }
   }
-  size_t lds = (size_t)nuo * 2 * threads * sizeof(double);
+  size_t lds = (size_t)nuo * 2 * threads * sizeof(double) + (size_t)nuo * threads * sizeof(f32x2);
   ScanArgs sa = {nullptr, nullptr, 0, {0u, 0u}};
   const size_t chunk_bytes = (size_t)K2_SCAN_R * 1024;
   if (scan_px && nuo <= 2 && scan_bytes >= chunk_bytes && scan_bytes / chunk_bytes < 0x7fffffffull) {
