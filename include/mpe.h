@@ -222,6 +222,30 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
                    int nD, const double* markers_xyz, int n_markers, const double* predicted_px,
                    mpe_detections* dets_out, uint32_t* corr_out, mpe_result* out);
 
+/* ---- lock-step batches over N independent camera streams (BASELINE configs[4]) ----------------------
+ * mpe_track_step for frame k of N streams in ONE device submission: every stream's ROI goes into one slot of
+ * a uniform slot array (zero beyond the ROI; the blob kernels read the window size / origin per slot, so image
+ * borders and centroid offsets are those of the stand-alone clone of led_detector.cpp:44), one image scan, one
+ * blob extraction and one validate / refine kernel pair run over the N slots, one copy returns N records.
+ * All streams share rows / cols / stride, camera, marker set and parameters.  predicted_px == NULL for an
+ * item = detection only (out[i].status = 1).  Group items of very different ROI size into separate calls:
+ * the slot is as large as the largest ROI of the call.  dets_out n, corr_out n x 2*MPE_MAX_MARKERS, out n. */
+typedef struct mpe_track_item {
+  const uint8_t* img;          /* HOST image of this stream */
+  int roi_x, roi_y, roi_w, roi_h;
+  const double* predicted_px;  /* n_markers x 2 undistorted pixels, or NULL */
+} mpe_track_item;
+int mpe_track_step_batch(mpe_handle* h, const mpe_track_item* items, int n, int rows, int cols, size_t stride_bytes,
+                         const mpe_params* p, const double K[9], const double* D, int nD,
+                         const double* markers_xyz, int n_markers, mpe_detections* dets_out, uint32_t* corr_out,
+                         mpe_result* out);
+/* mpe_solve_bruteforce for N detection sets in one submission (the re-initialisations of a lock-step batch):
+ * det_xy n x MPE_MAX_DETECTIONS x 2 (n_det[i] valid rows); hist (optional) n x MPE_MAX_DETECTIONS x
+ * MPE_MAX_MARKERS, corr (optional) n x 2*MPE_MAX_MARKERS. */
+int mpe_solve_bruteforce_batch(mpe_handle* h, const double* det_xy, const int* n_det, int n,
+                               const double* markers_xyz, int n_markers, const double K[9], const mpe_params* p,
+                               mpe_result* out, uint32_t* hist, uint32_t* corr);
+
 /* ---- stateful estimator: the whole PoseEstimator::estimateBodyPose state machine, i.e. the
  * uninitialised branch AND the tracking path (pose_estimator.cpp:62-147): pose prediction by the
  * constant-velocity model (predictPose :232-244), ROI from the predicted LED pixels
@@ -240,6 +264,25 @@ int mpe_tracker_reset(mpe_tracker* t); /* back to "not initialised" (the referen
  * x,y,w,h, it_since_initialized_, detections, correspondences, 1 if brute force ran. */
 int mpe_tracker_estimate(mpe_tracker* t, const uint8_t* img, int rows, int cols, size_t stride_bytes,
                          double time_to_predict, mpe_result* out, int info[8]);
+
+/* estimateBodyPose for frame k of N trackers (N independent streams of the same camera model, marker set and
+ * parameters, all created on the SAME handle) in lock step: the per-stream state machines run on the host as in
+ * mpe_tracker_estimate, but every device step is ONE batched submission over the streams that need it
+ * (mpe_track_step_batch for the ROI / whole-image detections with their validate + refine,
+ * mpe_solve_bruteforce_batch for the re-initialisations): in steady state one submission per time step for all
+ * N streams.  imgs[i], times[i]: stream i's frame and time stamp; out (optional) n records, info (optional)
+ * n x 8 ints, updated (optional) n flags.  Results are identical to calling mpe_tracker_estimate per stream.
+ * Returns the number of streams whose pose was updated, or <0 (usage / HIP error; a per-stream capacity overrun
+ * is reported in out[i].status and that stream is left as its failed call leaves it). */
+int mpe_tracker_estimate_batch(mpe_tracker* const* trackers, int n, const uint8_t* const* imgs, int rows, int cols,
+                               size_t stride_bytes, const double* times, mpe_result* out, int* info, int* updated);
+
+/* The image-callback loops of N streams in lock step over recorded sequences: frames[i] = stream i's sequence
+ * (frame f at frames[i] + f*frame_stride_bytes), times[f] the common time stamps; out / info (optional):
+ * n x n_frames records / n x n_frames x 8 ints, stream-major.  Returns the number of pose updates or <0. */
+int mpe_tracker_run_sequences_batch(mpe_tracker* const* trackers, int n, const uint8_t* const* frames, int n_frames,
+                                    int rows, int cols, size_t stride_bytes, size_t frame_stride_bytes,
+                                    const double* times, mpe_result* out, int* info);
 
 /* The estimator's private state (pose_estimator.h:56-62, 74-79), for callers that drive the public
  * step methods of the class (predictPose, findCorrespondences, ... — see compat/) between calls of

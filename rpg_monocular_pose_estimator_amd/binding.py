@@ -134,6 +134,10 @@ def load_library():
     lib.mpe_tracker_run_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                              C.c_size_t, dp, C.c_void_p, C.c_void_p]
     hp = C.POINTER(C.c_void_p)
+    lib.mpe_tracker_estimate_batch.argtypes = [hp, C.c_int, hp, C.c_int, C.c_int, C.c_size_t, dp, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]
+    lib.mpe_tracker_run_sequences_batch.argtypes = [hp, C.c_int, hp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                                    dp, C.c_void_p, C.c_void_p]
     lib.mpe_shard_bounds.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.mpe_shard_bounds.restype = None
     lib.mpe_estimate_batch_multi.argtypes = [hp, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
@@ -142,6 +146,51 @@ def load_library():
                                                     dp, dp, C.c_int, C.POINTER(MpeParams), C.c_void_p]
     _lib = lib
     return lib
+
+
+def tracker_estimate_batch(trackers, imgs, times):
+    """mpe_tracker_estimate_batch: frame k of N trackers (same handle / camera / markers / parameters) in lock step,
+    one device submission per step in steady state.  imgs: list of (rows, cols) uint8 arrays; times: N floats.
+    -> (records [RESULT_DTYPE] (N), info (N,8) int32, updated (N) bool)."""
+    lib = load_library()
+    n = len(trackers)
+    imgs = [np.ascontiguousarray(im, np.uint8) for im in imgs]
+    rows, cols = imgs[0].shape
+    stride = imgs[0].strides[0]
+    assert all(im.shape == (rows, cols) and im.strides[0] == stride for im in imgs)
+    ts = (C.c_void_p * n)(*[t._t for t in trackers])
+    ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+    times = _f64(times).reshape(-1)
+    rec = np.zeros(n, RESULT_DTYPE)
+    info = np.zeros((n, 8), np.int32)
+    upd = np.zeros(n, np.int32)
+    rc = lib.mpe_tracker_estimate_batch(ts, n, ptrs, rows, cols, stride, _dp(times), rec.ctypes.data, info.ctypes.data,
+                                        upd.ctypes.data)
+    if rc < 0:
+        raise MpeError("mpe_tracker_estimate_batch failed (%d): %s"
+                       % (rc, lib.mpe_last_error(trackers[0]._handle._h).decode()))
+    return rec, info, upd.astype(bool)
+
+
+def tracker_run_sequences_batch(trackers, frames, times):
+    """mpe_tracker_run_sequences_batch: the lock-step loop in C.  frames: list of (n,rows,cols) uint8 arrays (one
+    sequence per tracker), times: n floats.  -> (records (N,n), info (N,n,8))."""
+    lib = load_library()
+    N = len(trackers)
+    frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+    n, rows, cols = frames[0].shape
+    assert all(f.shape == (n, rows, cols) for f in frames)
+    ts = (C.c_void_p * N)(*[t._t for t in trackers])
+    ptrs = (C.c_void_p * N)(*[f.ctypes.data for f in frames])
+    times = _f64(times).reshape(-1)
+    rec = np.zeros((N, n), RESULT_DTYPE)
+    info = np.zeros((N, n, 8), np.int32)
+    rc = lib.mpe_tracker_run_sequences_batch(ts, N, ptrs, n, rows, cols, frames[0].strides[1], frames[0].strides[0],
+                                             _dp(times), rec.ctypes.data, info.ctypes.data)
+    if rc < 0:
+        raise MpeError("mpe_tracker_run_sequences_batch failed (%d): %s"
+                       % (rc, lib.mpe_last_error(trackers[0]._handle._h).decode()))
+    return rec, info
 
 
 def shard_bounds(n_frames, shard, n_shards):

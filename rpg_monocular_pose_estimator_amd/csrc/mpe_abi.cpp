@@ -1163,6 +1163,150 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
   return MPE_OK;
 }
 
+// ---- lock-step batches: frame k of N independent camera streams in ONE device submission ---------------
+// (BASELINE configs[4]: N streams' steps are independent of each other, pose_estimator.cpp:98-147 is sequential only
+// within a stream.)  Every stream's ROI is cloned into one slot of a uniform slot array — zero beyond the ROI, the
+// window size and origin in a per-slot table that the blob kernels read, so borders and centroid offsets are those
+// of the stand-alone cv::Mat clone of led_detector.cpp:44 — then ONE k1a_scan + ONE blob extraction over the N
+// slots and ONE validate / refine over the N detection sets (nearest-neighbour correspondences from the stream's
+// predicted pixels) run, and one copy brings the N records back.
+int mpe_track_step_batch(mpe_handle* h, const mpe_track_item* items, int n, int rows, int cols, size_t stride_bytes,
+                         const mpe_params* p, const double K[9], const double* D, int nD, const double* markers_xyz,
+                         int n_markers, mpe_detections* dets_out, uint32_t* corr_out, mpe_result* out) {
+  if (!h || !items || n < 0 || !p || !K || !markers_xyz || !dets_out || !corr_out || !out)
+    return fail(h, MPE_ERR_ARG, "bad argument");
+  if (n == 0) return MPE_OK;
+  int rmax = 0, wmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const mpe_track_item& it = items[i];
+    if (!it.img || it.roi_x < 0 || it.roi_y < 0 || it.roi_w <= 0 || it.roi_h <= 0 || it.roi_x + it.roi_w > cols ||
+        it.roi_y + it.roi_h > rows)
+      return fail(h, MPE_ERR_ARG, "ROI outside the image");
+    rmax = std::max(rmax, it.roi_h);
+    wmax = std::max(wmax, it.roi_w);
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  FrameGeom g;
+  if (make_geom(h, rmax, wmax, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
+  DetectParams dp;
+  if (make_detect_params(p, K, D, nD, 0, 0, dp)) return fail(h, MPE_ERR_ARG, "gaussian_sigma must be in (0, 6]");
+  SolveParams sp;
+  if (make_solve_params(h, p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
+  const size_t slot = (size_t)g.rows * g.pitch;
+  const size_t pred_bytes = (size_t)n * 2 * MPE_MAX_MARKERS * sizeof(double);
+  const size_t win_bytes = ((size_t)n * 4 * sizeof(int) + 15) & ~(size_t)15;
+  const size_t in_bytes = pred_bytes + win_bytes + (size_t)n * slot;
+  const size_t rec_bytes = (size_t)n * (sizeof(mpe_detections) + 2 * MPE_MAX_MARKERS * sizeof(uint32_t) + sizeof(mpe_result));
+  const size_t need = in_bytes + rec_bytes + 256;
+  if (need > h->mailbox_cap) {
+    if (h->mailbox) (void)hipHostFree(h->mailbox);
+    h->mailbox = nullptr;
+    h->mailbox_cap = 0;
+    const size_t want = std::max(need + need / 4, (size_t)1 << 16);
+    HIP_TRY(h, hipHostMalloc(&h->mailbox, want, hipHostMallocDefault));
+    h->mailbox_cap = want;
+  }
+  uint8_t* mb = static_cast<uint8_t*>(h->mailbox);
+  double* pred = reinterpret_cast<double*>(mb);
+  int* wins = reinterpret_cast<int*>(mb + pred_bytes);
+  uint8_t* pix = mb + pred_bytes + win_bytes;
+  const double qnan = std::nan("");
+  for (int i = 0; i < n; ++i) {
+    const mpe_track_item& it = items[i];
+    // no predicted pixels = detection only: NaN predictions are nearest to nothing, the tail then reports "no pose"
+    for (int k = 0; k < 2 * MPE_MAX_MARKERS; ++k)
+      pred[(size_t)i * 2 * MPE_MAX_MARKERS + k] = (it.predicted_px && k < 2 * n_markers) ? it.predicted_px[k] : (it.predicted_px ? 0.0 : qnan);
+    wins[4 * i] = it.roi_h;
+    wins[4 * i + 1] = it.roi_w;
+    wins[4 * i + 2] = it.roi_x;
+    wins[4 * i + 3] = it.roi_y;
+    uint8_t* dst0 = pix + (size_t)i * slot;
+    for (int y = 0; y < g.rows; ++y) {
+      uint8_t* dst = dst0 + (size_t)y * g.pitch;
+      if (y < it.roi_h) {
+        std::memcpy(dst, it.img + (size_t)(it.roi_y + y) * stride_bytes + it.roi_x, (size_t)it.roi_w);
+        if (g.pitch > it.roi_w) std::memset(dst + it.roi_w, 0, (size_t)(g.pitch - it.roi_w));
+      } else {
+        std::memset(dst, 0, (size_t)g.pitch);
+      }
+    }
+  }
+  uint8_t* host_rec = mb + ((in_bytes + 255) & ~(size_t)255);
+  HIP_TRY(h, h->frames.reserve(in_bytes + 16));
+  HIP_TRY(h, h->flags.reserve(flag_words((size_t)n * slot) * 8));
+  HIP_TRY(h, h->work.reserve((size_t)2 * (n + 1) * sizeof(int)));
+  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
+  HIP_TRY(h, h->hist.reserve((size_t)n * MPE_HIST_STRIDE * sizeof(uint32_t)));
+  HIP_TRY(h, h->track.reserve(rec_bytes));
+  HIP_TRY(h, h->mid.reserve(k3_mid_bytes(n)));
+  uint8_t* d_in = static_cast<uint8_t*>(h->frames.p);
+  const double* d_pred = reinterpret_cast<const double*>(d_in);
+  const void* d_wins = d_in + pred_bytes;
+  const uint8_t* d_pix = d_in + pred_bytes + win_bytes;
+  mpe_detections* d_dets = static_cast<mpe_detections*>(h->track.p);
+  uint32_t* d_corr = reinterpret_cast<uint32_t*>(d_dets + n);
+  mpe_result* d_res = reinterpret_cast<mpe_result*>(d_corr + (size_t)n * 2 * MPE_MAX_MARKERS);
+  h->have_ms = false;
+  HIP_TRY(h, hipMemcpyAsync(d_in, mb, in_bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, launch_k1a_scan(d_pix, (size_t)n * slot, static_cast<unsigned long long*>(h->flags.p), dp.thr, 0, h->stream));
+  HIP_TRY(h, launch_k1b_blobs(d_pix, static_cast<unsigned long long*>(h->flags.p), n, g, dp, d_dets,
+                              static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), n_markers, h->stream, d_wins));
+  HIP_TRY(h, launch_k3_tail(d_dets, static_cast<uint32_t*>(h->hist.p), n, sp, d_res, d_corr, nullptr, d_pred,
+                            p->nearest_neighbour_pixel_tolerance, h->mid.p, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(host_rec, d_dets, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const mpe_detections* hd = reinterpret_cast<const mpe_detections*>(host_rec);
+  const uint32_t* hc = reinterpret_cast<const uint32_t*>(hd + n);
+  const mpe_result* hr = reinterpret_cast<const mpe_result*>(hc + (size_t)n * 2 * MPE_MAX_MARKERS);
+  std::memcpy(dets_out, hd, (size_t)n * sizeof(mpe_detections));
+  std::memcpy(corr_out, hc, (size_t)n * 2 * MPE_MAX_MARKERS * sizeof(uint32_t));
+  std::memcpy(out, hr, (size_t)n * sizeof(mpe_result));
+  return MPE_OK;
+}
+
+// setImagePoints + initialise + optimiseAndUpdatePose for N detection sets in one submission (the brute-force
+// re-initialisations of a lock-step batch): det_xy n x MPE_MAX_DETECTIONS x 2, n_det[i] valid rows each; hist
+// (optional) n x MPE_MAX_DETECTIONS x MPE_MAX_MARKERS, corr (optional) n x 2*MPE_MAX_MARKERS.
+int mpe_solve_bruteforce_batch(mpe_handle* h, const double* det_xy, const int* n_det, int n, const double* markers_xyz,
+                               int n_markers, const double K[9], const mpe_params* p, mpe_result* out, uint32_t* hist,
+                               uint32_t* corr) {
+  if (!h || !det_xy || !n_det || n < 0 || !markers_xyz || !K || !p || !out) return fail(h, MPE_ERR_ARG, "bad argument");
+  if (n == 0) return MPE_OK;
+  HIP_TRY(h, hipSetDevice(h->device));
+  SolveParams sp;
+  if (make_solve_params(h, p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
+  std::vector<mpe_detections> hd((size_t)n);
+  int nd_max = 0;
+  for (int f = 0; f < n; ++f) {
+    std::memset(&hd[f], 0, sizeof(mpe_detections));
+    if (n_det[f] < 0 || n_det[f] > MPE_MAX_DETECTIONS) return fail(h, MPE_ERR_ARG, "n_det out of range");
+    hd[f].n = n_det[f];
+    nd_max = std::max(nd_max, n_det[f]);
+    std::memcpy(hd[f].undist_xy, det_xy + (size_t)f * 2 * MPE_MAX_DETECTIONS, sizeof(double) * 2 * n_det[f]);
+  }
+  const size_t hist_bytes = (size_t)n * MPE_HIST_STRIDE * sizeof(uint32_t);
+  const size_t corr_bytes = (size_t)n * 2 * MPE_MAX_MARKERS * sizeof(uint32_t);
+  HIP_TRY(h, h->dets.reserve((size_t)n * sizeof(mpe_detections)));
+  HIP_TRY(h, h->hist.reserve(hist_bytes));
+  HIP_TRY(h, h->results.reserve((size_t)n * sizeof(mpe_result)));
+  HIP_TRY(h, h->corr.reserve(corr_bytes));
+  HIP_TRY(h, h->mid.reserve(k3_mid_bytes(n)));
+  HIP_TRY(h, h->mtab.reserve(k2_table_bytes(n_markers)));
+  HIP_TRY(h, hipMemcpyAsync(h->dets.p, hd.data(), (size_t)n * sizeof(mpe_detections), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, hist_bytes, h->stream));
+  HIP_TRY(h, launch_k2_prep(sp, static_cast<double*>(h->mtab.p), h->stream));
+  HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), n, sp, static_cast<const double*>(h->mtab.p),
+                            static_cast<uint32_t*>(h->hist.p), auto_splits(h, n, n_markers), nd_max, h->stream));
+  HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), n, sp,
+                            static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), nullptr, nullptr,
+                            0.0, h->mid.p, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(out, h->results.p, (size_t)n * sizeof(mpe_result), hipMemcpyDeviceToHost, h->stream));
+  if (hist) HIP_TRY(h, hipMemcpyAsync(hist, h->hist.p, hist_bytes, hipMemcpyDeviceToHost, h->stream));
+  if (corr) HIP_TRY(h, hipMemcpyAsync(corr, h->corr.p, corr_bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MPE_OK;
+}
+
 // ---- one host process, several GPUs -----------------------------------------------------------
 // Frames are independent on the uninitialised branch (pose_estimator.cpp:68-91 reads no estimator state), so
 // a batch shards into contiguous chunks, one per handle / device, with no exchange step: one host thread per

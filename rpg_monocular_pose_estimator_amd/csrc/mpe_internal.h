@@ -53,7 +53,10 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
                            int dummy_lds_bytes, hipStream_t s);
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
-                            int blob_hint, hipStream_t s);
+                            int blob_hint, hipStream_t s, const void* frame_windows = nullptr);
+// frame_windows: optional device array of n_frames x {rows, cols, roi_x, roi_y} ints — every frame then is a window
+// of that size in the top-left corner of its g.rows x g.pitch slot (zero beyond), as when LEDDetector::findLeds clones
+// image(ROI) (led_detector.cpp:44): borders follow the window, centroids get its ROI origin added.
 size_t k2_table_bytes(int n_markers);
 hipError_t launch_k2_prep(const SolveParams& sp, double* tab, hipStream_t s);
 // sp.vote_arith: 1 = the fast voting kernel (tables, Newton-Raphson division / square root, Newton cube root),

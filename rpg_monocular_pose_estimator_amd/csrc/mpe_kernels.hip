@@ -447,7 +447,8 @@ __device__ __forceinline__ void undistort_point(float sx, float sy, const Detect
 }
 
 // led_detector.cpp:65-86 for one contour given its exact polygon sums and bounding box
-__device__ __forceinline__ bool blob_filter(const BlobRec& b, const DetectParams& dp, float& mcx, float& mcy) {
+__device__ __forceinline__ bool blob_filter(const BlobRec& b, const DetectParams& dp, int roi_x, int roi_y, float& mcx,
+                                            float& mcy) {
   const double s00 = (double)b.a00, s10 = (double)b.a10, s01 = (double)b.a01;
   const double area = fabs(s00 * 0.5);  // cv::contourArea
   const int width = b.xmax - b.xmin + 1, height = b.ymax - b.ymin + 1;
@@ -459,8 +460,8 @@ __device__ __forceinline__ bool blob_filter(const BlobRec& b, const DetectParams
     m10 = s10 * db1_6;
     m01 = s01 * db1_6;
   }
-  mcx = (float)(m10 / m00) + (float)dp.roi_x;
-  mcy = (float)(m01 / m00) + (float)dp.roi_y;
+  mcx = (float)(m10 / m00) + (float)roi_x;
+  mcy = (float)(m01 / m00) + (float)roi_y;
   const double w = (double)width, h = (double)height;
   const double hw = (double)(width / 2), hh = (double)(height / 2);  // INTEGER halves (quirk A.6.2)
   const double pi = 3.1415926535897932384626433832795;
@@ -476,7 +477,7 @@ __device__ __forceinline__ bool blob_filter(const BlobRec& b, const DetectParams
 // blobs that pass are handed to emit(mcx, mcy, key) with key = raster position of the start pixel.
 template <class Emit>
 __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, int H, int ylo, int xw0,
-                                            const DetectParams& dp, int* over, Emit emit) {
+                                            const DetectParams& dp, int roi_x, int roi_y, int* over, Emit emit) {
   for (int slot = 1; slot <= H; ++slot) {
     u64* nzrow = nz + (size_t)slot * W;
     u64* pmrow = pm + (size_t)slot * W;
@@ -512,7 +513,7 @@ __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, in
         br.ymin = acc.ymin;
         br.ymax = acc.ymax;
         float mcx, mcy;
-        if (blob_filter(br, dp, mcx, mcy)) emit(mcx, mcy, ((unsigned)(ylo + slot - 1) << 12) | (unsigned)(xb + xw0 - 1));
+        if (blob_filter(br, dp, roi_x, roi_y, mcx, mcy)) emit(mcx, mcy, ((unsigned)(ylo + slot - 1) << 12) | (unsigned)(xb + xw0 - 1));
       }
       const u64 mk = pmrow[w] | ngrow[w];
       if (mk) {
@@ -585,6 +586,27 @@ __device__ __forceinline__ void write_detections(const float* kx, const float* k
 // 0.47 ms alone and slower than FRAMES = 1 when the kernel shares the chip with the tail kernel, so
 // one frame per wave stays the default.
 // =============================================================================================
+// Per-frame window inside a uniform frame slot (batched ROI detection: every stream's ROI is cloned into a slot of
+// g.rows x g.pitch bytes, zero beyond its own rows x cols; borders — BORDER_REFLECT_101, clipping — follow the
+// window, the centroid offset (led_detector.cpp:74) its ROI origin).  wins == nullptr: every frame fills its slot.
+struct FrameWin {
+  int rows, cols, roi_x, roi_y;
+};
+__device__ __forceinline__ FrameGeom window_geom(const FrameGeom& g, const FrameWin* wins, int f, const DetectParams& dp,
+                                                 int& roi_x, int& roi_y) {
+  FrameGeom gl = g;  // slot layout (pitch, segments, bitset words) stays; rows / cols become the window's
+  roi_x = dp.roi_x;
+  roi_y = dp.roi_y;
+  if (wins) {
+    const FrameWin w = wins[f];
+    gl.rows = w.rows;
+    gl.cols = w.cols;
+    roi_x = w.roi_x;
+    roi_y = w.roi_y;
+  }
+  return gl;
+}
+
 struct Island {
   short ylo, yhi;      // band rows
   short clo, chi;      // output segment columns
@@ -631,7 +653,7 @@ struct K1bFrameLds {  // what the contour phase needs of one frame
 // Front phases of frame f.  Returns true when the island bitmaps in S are ready for the contour phase,
 // false when the frame is finished (no bright pixel) or was handed to the next tier's work-list.
 template <class C>
-__device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict__ frames,
+__device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict__ frames, size_t slot_bytes,
                                           const u64* __restrict__ flags, const FrameGeom& g, const DetectParams& dp,
                                           mpe_detections* __restrict__ dets, int* __restrict__ worklist,
                                           K1bWaveLds<C>& W, K1bFrameLds<C>& S) {
@@ -652,7 +674,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   int& s_over = S.over;
   int& s_nisl = S.nisl;
   __syncthreads();  // the previous user of the pool (frame before this one) is completely done
-  const uint8_t* frame = frames + (size_t)f * g.rows * g.pitch;
+  const uint8_t* frame = frames + (size_t)f * slot_bytes;  // (g = the frame's window geometry, see window_geom)
   mpe_detections* out = dets + f;
   const int r = dp.ksize / 2;
   const int dc = (r + 15) / 16;  // segment columns a bright segment can influence on each side
@@ -920,20 +942,25 @@ __device__ __forceinline__ void k1b_hand_over(int f, mpe_detections* __restrict_
 // The frames fr[0..nf) of one wave: front phases one after the other, contour phase together.
 template <class C>
 __device__ __forceinline__ void k1b_wave(const int* fr, int nf, const uint8_t* __restrict__ frames,
-                                         const u64* __restrict__ flags, const FrameGeom& g, const DetectParams& dp,
-                                         mpe_detections* __restrict__ dets, int* __restrict__ worklist) {
+                                         const u64* __restrict__ flags, const FrameGeom& gslot, const DetectParams& dp,
+                                         mpe_detections* __restrict__ dets, int* __restrict__ worklist,
+                                         const FrameWin* __restrict__ wins) {
   __shared__ K1bWaveLds<C> W;
   __shared__ K1bFrameLds<C> S[C::FRAMES];
   const int lane = threadIdx.x;
   __syncthreads();  // (list mode: the previous group of this block is completely done)
   if (lane < MPE_MAX_KSIZE) W.taps[lane] = dp.taps[lane < dp.ksize ? lane : 0];
+  static_assert(C::FRAMES == 1, "per-frame windows assume one frame per wave");
+  const size_t slot_bytes = (size_t)gslot.rows * gslot.pitch;
+  int roi_x, roi_y;
+  const FrameGeom g = window_geom(gslot, wins, nf > 0 ? fr[0] : 0, dp, roi_x, roi_y);
   bool ready[C::FRAMES];
   int base[C::FRAMES + 1];
   base[0] = 0;
 #pragma unroll
   for (int i = 0; i < C::FRAMES; ++i) {
     ready[i] = false;
-    if (i < nf) ready[i] = k1b_front<C>(fr[i], frames, flags, g, dp, dets, worklist, W, S[i]);
+    if (i < nf) ready[i] = k1b_front<C>(fr[i], frames, slot_bytes, flags, g, dp, dets, worklist, W, S[i]);
     base[i + 1] = base[i] + (ready[i] ? S[i].nisl : 0);
   }
   __syncthreads();
@@ -949,7 +976,8 @@ __device__ __forceinline__ void k1b_wave(const int* fr, int nf, const uint8_t* _
     const int H = is.yhi - is.ylo + 1;
     const int xhi = min(g.cols - 1, 16 * is.chi + 15);
     const int Wd = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
-    scan_window(F.nz + is.bm_off, F.pm + is.bm_off, F.ng + is.bm_off, Wd, H, is.ylo, 16 * is.clo, dp, &F.over,
+    scan_window(F.nz + is.bm_off, F.pm + is.bm_off, F.ng + is.bm_off, Wd, H, is.ylo, 16 * is.clo, dp, roi_x, roi_y,
+                &F.over,
                 [&](float mcx, float mcy, unsigned key) {
                   const int k = atomicAdd(&F.nkept, 1);
                   if (k < C::KEPT) {
@@ -975,24 +1003,26 @@ __device__ __forceinline__ void k1b_wave(const int* fr, int nf, const uint8_t* _
 template <class C>
 __global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
                                                FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
-                                               int* __restrict__ worklist, int n_frames) {
+                                               int* __restrict__ worklist, int n_frames,
+                                               const FrameWin* __restrict__ wins) {
   int fr[C::FRAMES];
   const int f0 = blockIdx.x * C::FRAMES;
 #pragma unroll
   for (int i = 0; i < C::FRAMES; ++i) fr[i] = f0 + i;
-  k1b_wave<C>(fr, min((int)C::FRAMES, n_frames - f0), frames, flags, g, dp, dets, worklist);
+  k1b_wave<C>(fr, min((int)C::FRAMES, n_frames - f0), frames, flags, g, dp, dets, worklist, wins);
 }
 // frames taken from a device work-list (those the smaller tier handed over)
 template <class C>
 __global__ __launch_bounds__(64) void k1b_blobs_list(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
                                                     FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
-                                                    const int* __restrict__ in_list, int* __restrict__ worklist) {
+                                                    const int* __restrict__ in_list, int* __restrict__ worklist,
+                                                    const FrameWin* __restrict__ wins) {
   const int count = in_list[0];
   for (int w0 = blockIdx.x * C::FRAMES; w0 < count; w0 += gridDim.x * C::FRAMES) {
     int fr[C::FRAMES];
 #pragma unroll
     for (int i = 0; i < C::FRAMES; ++i) fr[i] = (w0 + i < count) ? in_list[1 + w0 + i] : 0;
-    k1b_wave<C>(fr, min((int)C::FRAMES, count - w0), frames, flags, g, dp, dets, worklist);
+    k1b_wave<C>(fr, min((int)C::FRAMES, count - w0), frames, flags, g, dp, dets, worklist, wins);
   }
 }
 
@@ -1012,8 +1042,10 @@ __host__ __device__ inline size_t k1b_gen_scratch_bytes(const FrameGeom& g) {
 }
 
 __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
-                                                 FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
-                                                 const int* __restrict__ worklist, uint8_t* __restrict__ scratch) {
+                                                 FrameGeom gslot, DetectParams dp, mpe_detections* __restrict__ dets,
+                                                 const int* __restrict__ worklist, uint8_t* __restrict__ scratch,
+                                                 const FrameWin* __restrict__ wins) {
+  const FrameGeom& g = gslot;  // slab layout and flag indexing: the slot; rows / cols of a frame: its window (gl below)
   __shared__ int s_nkept, s_over;
   __shared__ int s_taps[MPE_MAX_KSIZE];
   const int lane = threadIdx.x;
@@ -1039,6 +1071,8 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
   for (int wi = blockIdx.x; wi < count; wi += gridDim.x) {
     const int f = worklist[1 + wi];
     const uint8_t* frame = frames + (size_t)f * g.rows * g.pitch;
+    int roi_x, roi_y;
+    const FrameGeom gl = window_geom(gslot, wins, f, dp, roi_x, roi_y);
     if (lane == 0) {
       s_nkept = 0;
       s_over = 0;
@@ -1074,7 +1108,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
           const int s = i * 64 + __builtin_ctzll(v);
           v &= v - 1;
           const int y0 = s / spr, c0 = s - y0 * spr;
-          for (int yy = max(0, y0 - r); yy <= min(g.rows - 1, y0 + r); ++yy)
+          for (int yy = max(0, y0 - r); yy <= min(gl.rows - 1, y0 + r); ++yy)
             for (int cc = max(0, c0 - dc); cc <= min(spr - 1, c0 + dc); ++cc)
               atomicOr(&todo[(size_t)yy * g.tw + (cc >> 6)], 1ull << (cc & 63));
         }
@@ -1083,21 +1117,21 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     __threadfence_block();
     __syncthreads();
     // blur
-    const PixWin pw = {pix, 0, g.rows, 0, g.pitch};
-    for (int y = lane; y < g.rows; y += 64)
+    const PixWin pw = {pix, 0, gl.rows, 0, g.pitch};
+    for (int y = lane; y < gl.rows; y += 64)
       for (int tw = 0; tw < g.tw; ++tw) {
         u64 tb = todo[(size_t)y * g.tw + tw];
         while (tb) {
           const int c = tw * 64 + __builtin_ctzll(tb);
           tb &= tb - 1;
-          blur_to_bitmap(pw, g.rows, g.cols, s_taps, dp.ksize, y, c, nz + (size_t)(y + 1) * g.wb, 0);
+          blur_to_bitmap(pw, gl.rows, gl.cols, s_taps, dp.ksize, y, c, nz + (size_t)(y + 1) * g.wb, 0);
         }
       }
     __threadfence_block();
     __syncthreads();
     if (lane == 0) {
       int nk = 0;
-      scan_window(nz, pm, ng, g.wb, g.rows, 0, 0, dp, &s_over, [&](float mcx, float mcy, unsigned key) {
+      scan_window(nz, pm, ng, g.wb, gl.rows, 0, 0, dp, roi_x, roi_y, &s_over, [&](float mcx, float mcy, unsigned key) {
         if (nk < K1B_GEN_KEPT) {
           kx[nk] = mcx;
           ky[nk] = mcy;
@@ -1119,7 +1153,8 @@ size_t k1b_scratch_bytes(const FrameGeom& g) { return k1b_gen_scratch_bytes(g) *
 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
-                            int blob_hint, hipStream_t s) {
+                            int blob_hint, hipStream_t s, const void* frame_windows) {
+  const FrameWin* wins = static_cast<const FrameWin*>(frame_windows);
   // Three tiers, chained through device work-lists (no host round trip):
   //   small LDS pools (3 waves/SIMD) -> large LDS pools -> whole-frame window in global scratch
   if (n_frames <= 0) return hipSuccess;
@@ -1132,18 +1167,18 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
   if (blob_hint > 0 && blob_hint <= 6) {
     const int blocks = (n_frames + K1bSmall::FRAMES - 1) / K1bSmall::FRAMES;
     hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
-                       list_a, n_frames);
+                       list_a, n_frames, wins);
     const int grid = n_frames < 2048 ? n_frames : 2048;
     hipLaunchKernelGGL((k1b_blobs_list<K1bLarge>), dim3(grid), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
-                       dets, (const int*)list_a, list_b);
+                       dets, (const int*)list_a, list_b, wins);
   } else {
     hipLaunchKernelGGL((k1b_blobs<K1bLarge>), dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
-                       dets, list_b, n_frames);
+                       dets, list_b, n_frames, wins);
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k1b_general, dim3(K1B_GEN_BLOCKS), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
-                     (const int*)list_b, scratch);
+                     (const int*)list_b, scratch, wins);
   return hipGetLastError();
 }
 

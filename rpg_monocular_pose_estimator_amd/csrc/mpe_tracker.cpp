@@ -592,6 +592,247 @@ int mpe_tracker_estimate(mpe_tracker* t, const uint8_t* img, int rows, int cols,
   return t->pose_updated ? 1 : 0;
 }
 
+// ---- N trackers in lock step -----------------------------------------------------------------------
+// The state machine of mpe_tracker_estimate per stream, with the device steps of all streams that are at the same
+// point batched into one submission: DETECT = findLeds in the stream's ROI (+ nearest-neighbour correspondences,
+// validation and refinement when tracking), BRUTE = initialise() + optimisePose on the stream's detections.
+namespace {
+enum BatchOp { OP_DETECT, OP_BRUTE, OP_DONE };
+struct BatchLane {
+  BatchOp op = OP_DONE;
+  bool tracking = false;  // false: uninitialised branch (detection only, then brute force)
+  unsigned num_loops = 0;
+  int error = 0;          // per-stream capacity status (< 0) that ended this stream's frame
+};
+
+bool same_setup(const mpe_tracker* a, const mpe_tracker* b) {
+  return a->h == b->h && a->markers == b->markers && a->D == b->D && !std::memcmp(a->K, b->K, sizeof(a->K)) &&
+         !std::memcmp(&a->p, &b->p, sizeof(mpe_params));
+}
+}  // namespace
+
+int mpe_tracker_estimate_batch(mpe_tracker* const* ts, int n, const uint8_t* const* imgs, int rows, int cols,
+                               size_t stride_bytes, const double* times, mpe_result* out, int* info, int* updated) {
+  if (!ts || n < 0 || !imgs || !times) return MPE_ERR_ARG;
+  if (n == 0) return 0;
+  for (int i = 0; i < n; ++i) {
+    if (!ts[i] || !imgs[i]) return MPE_ERR_ARG;
+    if (!same_setup(ts[0], ts[i])) return MPE_ERR_ARG;  // one handle, one camera model, one marker set, one parameter set
+    for (int j = 0; j < i; ++j)
+      if (ts[j] == ts[i]) return MPE_ERR_ARG;
+  }
+  mpe_handle* h = ts[0]->h;
+  const int nm = n_markers(ts[0]);
+  const double* Dp = ts[0]->D.empty() ? nullptr : ts[0]->D.data();
+  const int nD = (int)ts[0]->D.size();
+  std::vector<BatchLane> L((size_t)n);
+  // ---- begin of frame: pose_estimator.cpp:62-72 / 98-103 (predictWithROI)
+  for (int i = 0; i < n; ++i) {
+    mpe_tracker* t = ts[i];
+    t->pose_updated = false;
+    t->used_bruteforce = false;
+    t->det.clear();
+    t->fused_valid = false;
+    t->t_predicted = times[i];
+    if (t->it_since_initialized < 1) {
+      t->roi[0] = t->roi[1] = 0;
+      t->roi[2] = cols;
+      t->roi[3] = rows;
+      L[i].tracking = false;
+    } else {
+      if (t->it_since_initialized >= 2)
+        t->predicted = predict_pose(t->current, t->previous, t->t_current, t->t_previous, t->t_predicted);
+      for (int k = 0; k < nm; ++k)
+        project(t, t->predicted, &t->markers[3 * k], t->predicted_px[2 * k], t->predicted_px[2 * k + 1]);
+      determine_roi(t, rows, cols);
+      L[i].tracking = true;
+    }
+    L[i].op = OP_DETECT;
+  }
+  std::vector<mpe_track_item> items;
+  std::vector<int> idx;
+  std::vector<mpe_detections> dets;
+  std::vector<uint32_t> corr;
+  std::vector<mpe_result> res;
+  for (;;) {
+    bool any_detect = false, any_brute = false;
+    for (int i = 0; i < n; ++i) {
+      any_detect |= L[i].op == OP_DETECT;
+      any_brute |= L[i].op == OP_BRUTE;
+    }
+    if (!any_detect && !any_brute) break;
+    if (any_detect) {
+      // two size classes, so that a few whole-image retries do not inflate every ROI slot of the batch
+      for (int big = 0; big < 2; ++big) {
+        items.clear();
+        idx.clear();
+        for (int i = 0; i < n; ++i) {
+          if (L[i].op != OP_DETECT) continue;
+          const mpe_tracker* t = ts[i];
+          const bool is_big = (long long)t->roi[2] * t->roi[3] * 4 > (long long)rows * cols;
+          if ((int)is_big != big) continue;
+          mpe_track_item it;
+          it.img = imgs[i];
+          it.roi_x = t->roi[0];
+          it.roi_y = t->roi[1];
+          it.roi_w = t->roi[2];
+          it.roi_h = t->roi[3];
+          it.predicted_px = L[i].tracking ? t->predicted_px.data() : nullptr;
+          items.push_back(it);
+          idx.push_back(i);
+        }
+        if (items.empty()) continue;
+        const int m = (int)items.size();
+        dets.resize((size_t)m);
+        corr.resize((size_t)m * 2 * MPE_MAX_MARKERS);
+        res.resize((size_t)m);
+        const int rc = mpe_track_step_batch(h, items.data(), m, rows, cols, stride_bytes, &ts[0]->p, ts[0]->K, Dp, nD,
+                                            ts[0]->markers.data(), nm, dets.data(), corr.data(), res.data());
+        if (rc != MPE_OK) return rc;
+        for (int k = 0; k < m; ++k) {
+          const int i = idx[(size_t)k];
+          mpe_tracker* t = ts[i];
+          const mpe_detections& d = dets[(size_t)k];
+          if (d.status != 0) {  // device capacity exceeded on this stream's frame
+            L[i].error = d.status;
+            L[i].op = OP_DONE;
+            continue;
+          }
+          t->det_dist.assign(d.dist_xy, d.dist_xy + 2 * d.n);
+          if (d.n > 0) t->det.assign(d.undist_xy, d.undist_xy + 2 * d.n);  // kept when nothing was found
+          if (!L[i].tracking) {  // pose_estimator.cpp:80-91
+            L[i].op = (t->det.size() / 2 >= 4) ? OP_BRUTE : OP_DONE;
+            continue;
+          }
+          L[i].num_loops++;  // pose_estimator.cpp:105-144
+          if (t->det.size() / 2 >= 4) {
+            if (d.n >= 4) {  // the device ran findCorrespondences + checkCorrespondences + optimisePose on them
+              const mpe_result& r = res[(size_t)k];
+              if (r.status < 0) {
+                L[i].error = r.status;
+                L[i].op = OP_DONE;
+                continue;
+              }
+              t->n_corr = r.n_corr;
+              t->corr.assign(corr.begin() + (size_t)k * 2 * MPE_MAX_MARKERS,
+                             corr.begin() + (size_t)k * 2 * MPE_MAX_MARKERS + 2 * r.n_corr);
+              if (r.status == MPE_FRAME_POSE) {
+                take_result(t, r);
+                L[i].op = OP_DONE;
+              } else {
+                L[i].op = OP_BRUTE;  // reinitialise if the correspondences were not valid
+              }
+            } else {
+              // stale detections of an earlier call with a fresh empty one (pixel_positions is not cleared,
+              // led_detector.cpp:91-111): the single-stream path handles this corner on the host
+              const int rc1 = track(t);
+              if (rc1 != MPE_OK) {
+                if (rc1 > MPE_FRAME_TOO_MANY_DETECTIONS) return rc1;
+                L[i].error = rc1;
+              }
+              L[i].op = OP_DONE;
+            }
+          } else if (L[i].num_loops < 2) {  // too few LEDs in the ROI: search the whole image once
+            t->roi[0] = t->roi[1] = 0;
+            t->roi[2] = cols;
+            t->roi[3] = rows;
+            L[i].op = OP_DETECT;
+          } else {
+            L[i].op = OP_DONE;
+          }
+        }
+      }
+    }
+    // brute-force (re-)initialisations requested so far, one submission
+    idx.clear();
+    for (int i = 0; i < n; ++i)
+      if (L[i].op == OP_BRUTE) idx.push_back(i);
+    if (!idx.empty()) {
+      const int m = (int)idx.size();
+      std::vector<double> det_xy((size_t)m * 2 * MPE_MAX_DETECTIONS, 0.0);
+      std::vector<int> nd((size_t)m);
+      for (int k = 0; k < m; ++k) {
+        const mpe_tracker* t = ts[idx[(size_t)k]];
+        nd[(size_t)k] = (int)t->det.size() / 2;
+        std::memcpy(&det_xy[(size_t)k * 2 * MPE_MAX_DETECTIONS], t->det.data(), t->det.size() * sizeof(double));
+      }
+      res.resize((size_t)m);
+      std::vector<uint32_t> hist((size_t)m * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS), bc((size_t)m * 2 * MPE_MAX_MARKERS);
+      const int rc = mpe_solve_bruteforce_batch(h, det_xy.data(), nd.data(), m, ts[0]->markers.data(), nm, ts[0]->K,
+                                                &ts[0]->p, res.data(), hist.data(), bc.data());
+      if (rc != MPE_OK) return rc;
+      for (int k = 0; k < m; ++k) {
+        const int i = idx[(size_t)k];
+        mpe_tracker* t = ts[i];
+        const mpe_result& r = res[(size_t)k];
+        t->used_bruteforce = true;
+        L[i].op = OP_DONE;
+        if (r.status < 0) {
+          L[i].error = r.status;
+          continue;
+        }
+        bool any_vote = false;  // initialise() keeps correspondences_ when the histogram is empty (:704-719)
+        for (size_t q = 0; q < (size_t)MPE_MAX_DETECTIONS * MPE_MAX_MARKERS; ++q)
+          any_vote |= hist[(size_t)k * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS + q] != 0;
+        if (any_vote) {
+          t->n_corr = r.n_corr;
+          t->corr.assign(bc.begin() + (size_t)k * 2 * MPE_MAX_MARKERS, bc.begin() + (size_t)k * 2 * MPE_MAX_MARKERS + 2 * r.n_corr);
+        }
+        if (r.status == MPE_FRAME_POSE) take_result(t, r);
+      }
+    }
+  }
+  int n_updated = 0;
+  for (int i = 0; i < n; ++i) {
+    mpe_tracker* t = ts[i];
+    if (out) {
+      mpe_result& o = out[i];
+      std::memcpy(o.T, t->predicted.a, sizeof(o.T));
+      std::memcpy(o.cov, t->cov, sizeof(o.cov));
+      o.status = L[i].error ? L[i].error : (t->pose_updated ? MPE_FRAME_POSE : MPE_FRAME_NO_POSE);
+      o.n_det = (int)t->det.size() / 2;
+      o.n_corr = t->n_corr;
+      o.gn_iterations = t->gn_iterations;
+    }
+    if (info) {
+      for (int k = 0; k < 4; ++k) info[8 * i + k] = t->roi[k];
+      info[8 * i + 4] = (int)t->it_since_initialized;
+      info[8 * i + 5] = (int)t->det.size() / 2;
+      info[8 * i + 6] = t->n_corr;
+      info[8 * i + 7] = t->used_bruteforce ? 1 : 0;
+    }
+    if (updated) updated[i] = t->pose_updated ? 1 : 0;
+    n_updated += t->pose_updated ? 1 : 0;
+  }
+  return n_updated;
+}
+
+int mpe_tracker_run_sequences_batch(mpe_tracker* const* ts, int n, const uint8_t* const* frames, int n_frames, int rows,
+                                    int cols, size_t stride_bytes, size_t frame_stride_bytes, const double* times,
+                                    mpe_result* out, int* info) {
+  if (!ts || n < 0 || !frames || !times || n_frames < 0) return MPE_ERR_ARG;
+  std::vector<const uint8_t*> imgs((size_t)n);
+  std::vector<double> tk((size_t)n);
+  std::vector<mpe_result> step_out((size_t)n);
+  std::vector<int> step_info((size_t)n * 8);
+  long long updated = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    for (int i = 0; i < n; ++i) {
+      imgs[(size_t)i] = frames[i] + (size_t)f * frame_stride_bytes;
+      tk[(size_t)i] = times[f];
+    }
+    const int rc = mpe_tracker_estimate_batch(ts, n, imgs.data(), rows, cols, stride_bytes, tk.data(), step_out.data(),
+                                              step_info.data(), nullptr);
+    if (rc < 0) return rc;
+    updated += rc;
+    for (int i = 0; i < n; ++i) {
+      if (out) out[(size_t)i * n_frames + f] = step_out[(size_t)i];
+      if (info) std::memcpy(info + ((size_t)i * n_frames + f) * 8, &step_info[(size_t)i * 8], 8 * sizeof(int));
+    }
+  }
+  return (int)std::min<long long>(updated, 0x7fffffff);
+}
+
 int mpe_tracker_run_sequence(mpe_tracker* t, const uint8_t* frames, int n_frames, int rows, int cols,
                              size_t stride_bytes, size_t frame_stride_bytes, const double* times, mpe_result* out,
                              int* info) {

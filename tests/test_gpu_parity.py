@@ -1052,3 +1052,54 @@ def test_bench_entry_on_the_gpu_box():
         few = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
                              capture_output=True, text=True, env=env, timeout=300)
         assert few.returncode != 0 and "GPU(s) are visible" in few.stderr
+
+
+@pytest.mark.gpu
+def test_lockstep_tracker_batch_matches_oracle(orc):
+    """BASELINE configs[4] as ONE submission per time step: N trackers on one handle driven in lock step
+    (mpe_tracker_estimate_batch / mpe_tracker_run_sequences_batch: one image scan + blob extraction over the N ROI
+    slots, one validate / refine over the N detection sets, brute-force re-initialisations batched too).  Every
+    stream must equal the oracle's state machine on its own frames — LED drop-outs (whole-image retry and
+    re-initialisation on some streams while others keep tracking), ROIs of different sizes, and the per-frame Python
+    entry point must give the same records as the C loop."""
+    n_streams, n = 6, 26
+    drop = {1: (9,), 3: (14, 15), 4: (5, 20)}
+    seqs = [synth.make_sequence("C2", n, seed=60 + s, dropout=drop.get(s, ())) for s in range(n_streams)]
+    h = mpe.Handle(0)
+    P = mpe.demo_params()
+    mk = lambda: [mpe.Tracker(h, seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], P) for _ in range(n_streams)]
+    trackers = mk()
+    rec, info = mpe.tracker_run_sequences_batch(trackers, [q["frames"] for q in seqs], seqs[0]["times"])
+    n_brute = n_roi = 0
+    for s in range(n_streams):
+        to = orc.Tracker(seqs[s]["markers"], seqs[s]["K"], seqs[s]["D"], orc.make_params())
+        for k in range(n):
+            ro = to.estimate(seqs[s]["frames"][k], seqs[s]["times"][k])
+            assert (rec["status"][s, k] == 0) == ro["updated"], (s, k)
+            assert tuple(info[s, k, 0:4]) == ro["roi"] and info[s, k, 4] == ro["it_since_initialized"], (s, k)
+            assert info[s, k, 5] == ro["n_det"] and info[s, k, 6] == ro["n_corr"], (s, k)
+            assert bool(info[s, k, 7]) == ro["used_bruteforce"], (s, k)
+            n_brute += int(info[s, k, 7])
+            n_roi += int(info[s, k, 2] < seqs[s]["cols"])
+            if ro["updated"]:
+                dp, dr = pose_diff(rec["T"][s, k].reshape(4, 4), ro["T"])
+                assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (s, k, dp, dr)
+    # every stream initialises by brute force, tracks in ROIs, and the drop-out frames force whole-image retries
+    n_retry = int(((info[:, 1:, 2] == seqs[0]["cols"]) & (info[:, 1:, 4] >= 1)).sum())
+    assert n_brute >= n_streams and n_roi >= n_streams * (n - 6) and n_retry >= 3, (n_brute, n_roi, n_retry)
+    # per-step entry point == the C loop; and == one tracker per stream driven alone
+    t2 = mk()
+    solo = [mpe.Tracker(h, seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], P) for _ in range(n_streams)]
+    for k in range(n):
+        r2, i2, upd = mpe.tracker_estimate_batch(t2, [q["frames"][k] for q in seqs], [seqs[0]["times"][k]] * n_streams)
+        assert r2.tobytes() == rec[:, k].tobytes() and np.array_equal(i2, info[:, k]), k
+        for s in range(n_streams):
+            r1 = solo[s].estimate(seqs[s]["frames"][k], seqs[s]["times"][k])
+            assert r1["updated"] == bool(upd[s]) and np.array_equal(r1["T"], r2["T"][s].reshape(4, 4)), (s, k)
+    # streams with different set-ups cannot share a lock-step batch
+    other = mpe.Tracker(h, seqs[0]["markers"][:4], seqs[0]["K"], seqs[0]["D"], P)
+    with pytest.raises(mpe.MpeError):
+        mpe.tracker_estimate_batch([t2[0], other], [seqs[0]["frames"][0]] * 2, [0.0, 0.0])
+    for t in trackers + t2 + solo + [other]:
+        t.close()
+    h.close()
