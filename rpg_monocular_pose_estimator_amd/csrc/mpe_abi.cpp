@@ -1250,7 +1250,7 @@ int mpe_track_step_batch(mpe_handle* h, const mpe_track_item* items, int n, int 
   HIP_TRY(h, hipMemcpyAsync(d_in, mb, in_bytes, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, launch_k1a_scan(d_pix, (size_t)n * slot, static_cast<unsigned long long*>(h->flags.p), dp.thr, 0, h->stream));
   HIP_TRY(h, launch_k1b_blobs(d_pix, static_cast<unsigned long long*>(h->flags.p), n, g, dp, d_dets,
-                              static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), n_markers, h->stream, d_wins));
+                              static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), 0, h->stream, d_wins));
   HIP_TRY(h, launch_k3_tail(d_dets, static_cast<uint32_t*>(h->hist.p), n, sp, d_res, d_corr, nullptr, d_pred,
                             p->nearest_neighbour_pixel_tolerance, h->mid.p, h->stream));
   HIP_TRY(h, hipMemcpyAsync(host_rec, d_dets, rec_bytes, hipMemcpyDeviceToHost, h->stream));

@@ -221,13 +221,19 @@ struct PixWin {
 
 // fixed-point Gaussian for the 16 outputs x0..x0+15 of image row y, reading the LDS window.
 // Returns the bit mask of outputs whose blurred value is non-zero: (sum + 2^15) >> 16 != 0.
-template <int KS>
+// Pixels outside the window count as zero here.  EDGE (segments within reach of the left / right image border):
+// BORDER_REFLECT_101 mirrors the pixels next to the border instead; that only matters if one of the mirrored pixels
+// — the `zone` bits over the taps' input positions j (pixel x0 - R + j) — is non-zero after the threshold, which
+// is reported in edge_or so that the caller can redo the item with the byte-wise border code.  LED spots sit well
+// inside the frame / the tracking ROI (20 px border), so the mirrored zone is almost always dark.
+template <int KS, bool EDGE>
 __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, int cols, int y, int c,
-                                                   const int* __restrict__ taps) {
+                                                   const int* __restrict__ taps, unsigned zone, unsigned& edge_or) {
   constexpr int R = KS / 2;
   int acc[16];
 #pragma unroll
   for (int x = 0; x < 16; ++x) acc[x] = 0;
+  unsigned eor = 0;
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
     const int yb = reflect101(y + i - R, rows) - w.ylo;
@@ -244,6 +250,7 @@ __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, in
     for (int j = 0; j < 16 + 2 * R; ++j) {
       const int k = 16 - R + j;
       t[j] = (int)((q[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+      if (EDGE) eor |= ((zone >> j) & 1u) ? (unsigned)t[j] : 0u;
     }
     const int ky = taps[i];
 #pragma unroll
@@ -258,6 +265,11 @@ __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, in
 #pragma unroll
   for (int x = 0; x < 16; ++x)
     if (acc[x] >= (1 << 15)) m |= 1u << x;
+  if (EDGE) {
+    edge_or = eor;
+    const int valid = cols - 16 * c;  // outputs at x >= cols do not exist
+    if (valid < 16) m &= (1u << valid) - 1u;
+  }
   return m;
 }
 
@@ -530,14 +542,27 @@ __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int c
   const int r = ksize / 2;
   const int x0 = 16 * c;
   if (x0 >= cols) return;
-  unsigned m;
+  unsigned m = 0;
   const bool interior = (x0 - r >= 0) && (x0 + 15 + r < cols);
-  if (interior && ksize == 5)
-    m = blur_item_fast<5>(pw, rows, cols, y, c, taps);
-  else if (interior && ksize == 3)
-    m = blur_item_fast<3>(pw, rows, cols, y, c, taps);
-  else
+  unsigned edge_or = 0;
+  if (interior && ksize == 5) {
+    m = blur_item_fast<5, false>(pw, rows, cols, y, c, taps, 0u, edge_or);
+  } else if (interior && ksize == 3) {
+    m = blur_item_fast<3, false>(pw, rows, cols, y, c, taps, 0u, edge_or);
+  } else if ((ksize == 5 || ksize == 3) && cols >= 2 * r + 2) {
+    // border segment: mirrored input positions j (pixel x = x0 - r + j): left border x in [1, r], right border
+    // x in [cols - 1 - r, cols - 2]
+    unsigned zone = 0;
+    for (int j = 0; j < 16 + 2 * r; ++j) {
+      const int x = x0 - r + j;
+      if ((x0 - r < 0 && x >= 1 && x <= r) || (x0 + 15 + r >= cols && x >= cols - 1 - r && x <= cols - 2)) zone |= 1u << j;
+    }
+    m = ksize == 5 ? blur_item_fast<5, true>(pw, rows, cols, y, c, taps, zone, edge_or)
+                   : blur_item_fast<3, true>(pw, rows, cols, y, c, taps, zone, edge_or);
+    if (edge_or) m = blur_item_generic(pw, rows, cols, y, c, taps, ksize);  // a bright pixel next to the border
+  } else {
     m = blur_item_generic(pw, rows, cols, y, c, taps, ksize);
+  }
   if (m) {
     const int xb0 = x0 - xw0 + 1, wi = xb0 >> 6, shb = xb0 & 63;
     atomicOr(&nzrow[wi], (u64)m << shb);
