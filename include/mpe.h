@@ -130,6 +130,13 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
                        const double* markers_xyz, int n_markers, const double K[9],
                        const double* D, int nD, const mpe_params* p, mpe_result* results);
 
+/* Page-locked host memory for frame buffers (what a camera driver / cv_bridge::toCvCopy target should write into,
+ * monocular_pose_estimator.cpp:147): with HOST frames in pinned memory mpe_estimate_batch ingests a large batch
+ * in chunks (option "ingest_chunk", default 2048 frames, 0 = one copy), the H2D copy of chunk c + 1 running
+ * beside the kernels of chunk c — the call is then bound by the PCIe link alone.  NULL on failure. */
+void* mpe_alloc_pinned(size_t bytes);
+void mpe_free_pinned(void* p);
+
 /* ---- the same entry point over SEVERAL GPUs of one node, from ONE host process ----
  * Frames are independent on this branch (pose_estimator.cpp:68-91 reads no estimator state when
  * it_since_initialized_ < 1), so the batch shards into contiguous chunks — shard d of n_dev gets frames
@@ -364,7 +371,8 @@ int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
  * scan of sub-batch s+1 rides inside the voting kernel of sub-batch s;  4 = as 3, with the validate /
  * refine kernels of sub-batch s on an internal side stream, beside the blob extraction of sub-batch
  * s+1 (joined back before the call returns its place on the stream)), "k1a_dummy_lds" (occupancy cap
- * of the stand-alone scan kernel in mode 0, per handle), "vote_arith" (arithmetic of the voting kernel: 1 (default)
+ * of the stand-alone scan kernel in mode 0, per handle), "ingest_chunk" (frames per chunk of the double-buffered
+ * host-frame ingest of mpe_estimate_batch, default 2048, 0 = one blocking copy per call), "vote_arith" (arithmetic of the voting kernel: 1 (default)
  * = fast — Newton-Raphson division / square root, Newton cube root, per-permutation tables, [R|C]-free
  * back-projection; 0 = strict — the validation kernel's P3P functions with IEEE operators in the reference's
  * statement order, so that voting and validation share one quartic solver; slower, never fused with the scan.

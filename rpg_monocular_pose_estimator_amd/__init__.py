@@ -8,11 +8,11 @@ from .binding import (MpeError, MpeParams, MpeResult, MpeDetections, RESULT_DTYP
                       MAX_DETECTIONS, MAX_MARKERS, Handle, build_library, library_path, load_library,
                       demo_params, exported_symbols, Tracker, determine_roi, distort_points, exponential_map, logarithm_map,
                       predict_pose, project_points, find_correspondences, shard_bounds, estimate_batch_multi,
-                      tracker_estimate_batch, tracker_run_sequences_batch)
+                      tracker_estimate_batch, tracker_run_sequences_batch, PinnedFrames)
 from .pose_estimator import PoseEstimator  # noqa: F401
 
 __all__ = ["MpeError", "MpeParams", "MpeResult", "MpeDetections", "RESULT_DTYPE", "DETECTIONS_DTYPE",
            "MAX_DETECTIONS", "MAX_MARKERS", "Handle", "build_library", "library_path", "load_library",
            "demo_params", "exported_symbols", "PoseEstimator", "Tracker", "determine_roi", "distort_points",
            "exponential_map", "logarithm_map", "predict_pose", "project_points", "find_correspondences",
-           "shard_bounds", "estimate_batch_multi", "tracker_estimate_batch", "tracker_run_sequences_batch"]
+           "shard_bounds", "estimate_batch_multi", "tracker_estimate_batch", "tracker_run_sequences_batch", "PinnedFrames"]

@@ -133,6 +133,10 @@ def load_library():
                                          C.POINTER(MpeResult), C.POINTER(C.c_int)]
     lib.mpe_tracker_run_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t,
                                              C.c_size_t, dp, C.c_void_p, C.c_void_p]
+    lib.mpe_alloc_pinned.restype = C.c_void_p
+    lib.mpe_alloc_pinned.argtypes = [C.c_size_t]
+    lib.mpe_free_pinned.restype = None
+    lib.mpe_free_pinned.argtypes = [C.c_void_p]
     hp = C.POINTER(C.c_void_p)
     lib.mpe_tracker_estimate_batch.argtypes = [hp, C.c_int, hp, C.c_int, C.c_int, C.c_size_t, dp, C.c_void_p, C.c_void_p,
                                                C.c_void_p]
@@ -191,6 +195,29 @@ def tracker_run_sequences_batch(trackers, frames, times):
         raise MpeError("mpe_tracker_run_sequences_batch failed (%d): %s"
                        % (rc, lib.mpe_last_error(trackers[0]._handle._h).decode()))
     return rec, info
+
+
+class PinnedFrames:
+    """(n, rows, cols) uint8 frame buffer in page-locked host memory (mpe_alloc_pinned): `.array` is a numpy view."""
+
+    def __init__(self, n, rows, cols):
+        self._lib = load_library()
+        self._p = self._lib.mpe_alloc_pinned(n * rows * cols)
+        if not self._p:
+            raise MpeError("mpe_alloc_pinned(%d) failed" % (n * rows * cols))
+        self.array = np.ctypeslib.as_array((C.c_uint8 * (n * rows * cols)).from_address(self._p)).reshape(n, rows, cols)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            self._lib.mpe_free_pinned(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_bounds(n_frames, shard, n_shards):

@@ -69,6 +69,9 @@ struct mpe_handle {
   hipEvent_t vote_done[kMaxSub] = {};
   hipEvent_t scan_done[kMaxSub] = {};
   hipEvent_t fork_ev = nullptr;
+  hipStream_t copy_stream = nullptr;  // host-frame ingest: the H2D copy of chunk c + 1 runs beside the kernels of chunk c
+  hipEvent_t copy_done[2] = {nullptr, nullptr};
+  int ingest_chunk = 2048;            // frames per ingest chunk (option "ingest_chunk"; 0 = one blocking copy per call)
   hipStream_t tail_stream = nullptr;  // fused schedule, mode 4: validate + refine of sub-batch s beside blobs(s + 1)
   hipEvent_t tail_done = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -677,6 +680,9 @@ void mpe_destroy(mpe_handle* h) {
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   if (h->tail_done) (void)hipEventDestroy(h->tail_done);
   if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
+  for (auto& e : h->copy_done)
+    if (e) (void)hipEventDestroy(e);
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   for (auto& st : h->sub_stream)
     if (st) (void)hipStreamDestroy(st);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -755,6 +761,7 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "lds_budget") *value = h->lds_budget;
   else if (n == "vote_splits") *value = h->vote_splits;
   else if (n == "vote_arith") *value = h->vote_arith;
+  else if (n == "ingest_chunk") *value = h->ingest_chunk;
   else if (n == "k1a_dummy_lds") *value = h->k1a_dummy_lds;
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
@@ -784,6 +791,11 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   }
   if (!std::strcmp(name, "vote_splits")) {
     h->vote_splits = value;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "ingest_chunk")) {
+    if (value < 0) return fail(h, MPE_ERR_ARG, "ingest_chunk must be >= 0");
+    h->ingest_chunk = value;
     return MPE_OK;
   }
   if (!std::strcmp(name, "vote_arith")) {
@@ -1147,20 +1159,62 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
   if (make_detect_params(p, K, D, nD, 0, 0, dp)) return fail(h, MPE_ERR_ARG, "gaussian_sigma must be in (0, 6]");
   SolveParams sp;
   if (make_solve_params(h, p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
-  const uint8_t* d_frames = nullptr;
-  int rc = stage_frames(h, frames, n_frames, rows, cols, stride_bytes, frame_stride_bytes, frames_on_device, 0, 0, cols,
-                        rows, g, &d_frames);
-  if (rc) return rc;
   HIP_TRY(h, h->dets.reserve((size_t)n_frames * sizeof(mpe_detections)));
   HIP_TRY(h, h->hist.reserve((size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t)));
   HIP_TRY(h, h->results.reserve((size_t)n_frames * sizeof(mpe_result)));
-  rc = run_pipeline(h, d_frames, n_frames, g, dp, &sp, static_cast<mpe_detections*>(h->dets.p),
-                    static_cast<uint32_t*>(h->hist.p), static_cast<mpe_result*>(h->results.p), nullptr);
-  if (rc) return rc;
+  mpe_detections* d_dets = static_cast<mpe_detections*>(h->dets.p);
+  uint32_t* d_hist = static_cast<uint32_t*>(h->hist.p);
+  mpe_result* d_res = static_cast<mpe_result*>(h->results.p);
+  const bool host_packed = !frames_on_device && stride_bytes == (size_t)cols && frame_stride_bytes == (size_t)rows * cols &&
+                           g.pitch == cols;
+  if (host_packed && h->ingest_chunk > 0 && n_frames > h->ingest_chunk) {
+    // Double-buffered ingest of HOST frames (sensor_msgs/Image payloads as monocular_pose_estimator.cpp:147 hands
+    // them over): the batch is cut into chunks; the H2D copy of chunk c + 1 runs on a copy stream beside the kernels
+    // of chunk c, each chunk in its own part of the device frame buffer.  With pinned host memory (hipHostMalloc /
+    // hipHostRegister, or mpe_alloc_pinned) the copies are asynchronous DMA and the call is PCIe bound with the
+    // compute hidden; with pageable memory the runtime stages the copy itself (same rate measured, host blocked).
+    const size_t frame_bytes = (size_t)rows * cols;
+    HIP_TRY(h, h->frames.reserve(frame_bytes * n_frames + 16));
+    uint8_t* d_all = static_cast<uint8_t*>(h->frames.p);
+    if (!h->copy_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (auto& e : h->copy_done)
+      if (!e) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // the copy stream starts after everything already queued on the caller's stream (the frame buffer may be in use)
+    HIP_TRY(h, hipEventRecord(h->copy_done[0], h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->copy_done[0], 0));
+    const int chunk = h->ingest_chunk;
+    int ci = 0;
+    for (int f0 = 0; f0 < n_frames; f0 += chunk, ++ci) {
+      const int nf = std::min(chunk, n_frames - f0);
+      HIP_TRY(h, hipMemcpyAsync(d_all + (size_t)f0 * frame_bytes, frames + (size_t)f0 * frame_bytes, frame_bytes * nf,
+                                hipMemcpyHostToDevice, h->copy_stream));
+      HIP_TRY(h, hipEventRecord(h->copy_done[ci & 1], h->copy_stream));
+      HIP_TRY(h, hipStreamWaitEvent(h->stream, h->copy_done[ci & 1], 0));
+      const int rc = run_pipeline(h, d_all + (size_t)f0 * frame_bytes, nf, g, dp, &sp, d_dets + f0,
+                                  d_hist + (size_t)f0 * MPE_HIST_STRIDE, d_res + f0, nullptr);
+      if (rc) return rc;
+    }
+  } else {
+    const uint8_t* d_frames = nullptr;
+    int rc = stage_frames(h, frames, n_frames, rows, cols, stride_bytes, frame_stride_bytes, frames_on_device, 0, 0, cols,
+                          rows, g, &d_frames);
+    if (rc) return rc;
+    rc = run_pipeline(h, d_frames, n_frames, g, dp, &sp, d_dets, d_hist, d_res, nullptr);
+    if (rc) return rc;
+  }
   HIP_TRY(h, hipMemcpyAsync(results, h->results.p, (size_t)n_frames * sizeof(mpe_result), hipMemcpyDeviceToHost,
                             h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPE_OK;
+}
+
+void* mpe_alloc_pinned(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void mpe_free_pinned(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 // ---- lock-step batches: frame k of N independent camera streams in ONE device submission ---------------

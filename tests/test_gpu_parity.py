@@ -1103,3 +1103,30 @@ def test_lockstep_tracker_batch_matches_oracle(orc):
     for t in trackers + t2 + solo + [other]:
         t.close()
     h.close()
+
+
+@pytest.mark.gpu
+def test_chunked_host_ingest_is_bit_identical(orc):
+    """mpe_estimate_batch on HOST frames: the double-buffered chunked ingest (copy of chunk c + 1 beside the kernels
+    of chunk c; option "ingest_chunk") gives byte-identical records to one blocking copy — from pageable memory and
+    from pinned memory obtained through the ABI (mpe_alloc_pinned)."""
+    d = synth.make_frames("C2", 37, seed=4321)
+    P = mpe.demo_params()
+    h = mpe.Handle(0)
+    try:
+        h.set_option("ingest_chunk", 0)
+        one = h.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], P)
+        ref = orc.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], orc.make_params(), n_threads=4)
+        assert np.array_equal(one["status"], ref["status"])
+        pin = mpe.PinnedFrames(*d["frames"].shape)
+        pin.array[...] = d["frames"]
+        for chunk in (8, 16, 36):
+            h.set_option("ingest_chunk", chunk)
+            assert h.get_option("ingest_chunk") == chunk
+            assert h.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], P).tobytes() == one.tobytes(), chunk
+            assert h.estimate_batch(pin.array, d["markers"], d["K"], d["D"], P).tobytes() == one.tobytes(), chunk
+        pin.close()
+        with pytest.raises(mpe.MpeError):
+            h.set_option("ingest_chunk", -1)
+    finally:
+        h.close()
