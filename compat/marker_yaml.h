@@ -8,13 +8,14 @@
 #ifndef MPE_COMPAT_MARKER_YAML_H_
 #define MPE_COMPAT_MARKER_YAML_H_
 
+#include "monocular_pose_estimator_lib/facade_namespace.h"
 #include <cstdlib>
 #include <fstream>
 #include <string>
 
 #include "monocular_pose_estimator_lib/datatypes.h"
 
-namespace monocular_pose_estimator {
+MPE_FACADE_BEGIN
 
 inline bool read_markers(const char* path, List4DPoints& out) {
   std::ifstream in(path);
@@ -46,5 +47,5 @@ inline bool read_markers(const char* path, List4DPoints& out) {
 }
 
 
-}  // namespace monocular_pose_estimator
+MPE_FACADE_END  // namespace monocular_pose_estimator
 #endif

@@ -6,9 +6,10 @@
 #ifndef MPE_COMPAT_COMBINATIONS_H_
 #define MPE_COMPAT_COMBINATIONS_H_
 
+#include "facade_namespace.h"
 #include "datatypes.h"
 
-namespace monocular_pose_estimator {
+MPE_FACADE_BEGIN
 
 class Combinations {
  public:
@@ -117,5 +118,5 @@ class Combinations {
   }
 };
 
-}  // namespace monocular_pose_estimator
+MPE_FACADE_END  // namespace monocular_pose_estimator
 #endif

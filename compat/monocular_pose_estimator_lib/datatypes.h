@@ -3,16 +3,18 @@
 // Mirrors the names of the reference's lib/include/monocular_pose_estimator_lib/datatypes.h:38-52
 // (List2DPoints, List4DPoints, VectorXuPairs, Matrix6d ...).  The reference builds them on Eigen,
 // which is not available in this toolchain, so they are plain fixed-size aggregates here (row-major
-// storage, operator()(r,c) access like Eigen).  When Eigen IS available, eigen_adapters.h converts.
+// storage, operator()(r,c) access like Eigen).  When Eigen IS available, compat/adapters/eigen_adapters.h converts
+// (and compat/adapters/reference_surface.h offers the reference's Eigen / cv::Mat class surface itself).
 #ifndef MPE_COMPAT_DATATYPES_H_
 #define MPE_COMPAT_DATATYPES_H_
 
+#include "facade_namespace.h"
 #include <array>
 #include <cstddef>
 #include <cstdint>
 #include <vector>
 
-namespace monocular_pose_estimator {
+MPE_FACADE_BEGIN
 
 template <int R, int C>
 struct Matrix {
@@ -88,5 +90,5 @@ struct Point2f {
   float x, y;
 };
 
-}  // namespace monocular_pose_estimator
+MPE_FACADE_END  // namespace monocular_pose_estimator
 #endif

@@ -5,11 +5,12 @@
 #ifndef MPE_COMPAT_LED_DETECTOR_H_
 #define MPE_COMPAT_LED_DETECTOR_H_
 
+#include "facade_namespace.h"
 #include <vector>
 
 #include "datatypes.h"
 
-namespace monocular_pose_estimator {
+MPE_FACADE_BEGIN
 
 class LEDDetector {
  public:
@@ -29,5 +30,5 @@ class LEDDetector {
                             const std::vector<double>& distortion_matrix);
 };
 
-}  // namespace monocular_pose_estimator
+MPE_FACADE_END  // namespace monocular_pose_estimator
 #endif

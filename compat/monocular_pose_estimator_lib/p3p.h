@@ -4,11 +4,12 @@
 #ifndef MPE_COMPAT_P3P_H_
 #define MPE_COMPAT_P3P_H_
 
+#include "facade_namespace.h"
 #include <array>
 
 #include "datatypes.h"
 
-namespace monocular_pose_estimator {
+MPE_FACADE_BEGIN
 
 typedef std::array<Matrix3x4d, 4> P3PSolutions;  //!< the reference's Matrix<Matrix<double,3,4>,4,1>
 
@@ -22,5 +23,5 @@ class P3P {
   static int solveQuartic(const Vector5d& factors, Vector4d& real_roots);
 };
 
-}  // namespace monocular_pose_estimator
+MPE_FACADE_END  // namespace monocular_pose_estimator
 #endif

@@ -1,9 +1,10 @@
 // pose_estimator.cpp — facade implementation: parameter marshalling + calls into the C ABI.
+#include "facade_namespace.h"
 #include "pose_estimator.h"
 
 #include <stdexcept>
 
-namespace monocular_pose_estimator {
+MPE_FACADE_BEGIN
 
 static void check(mpe_handle* h, int rc, const char* what) {
   if (rc != MPE_OK) throw std::runtime_error(std::string(what) + ": " + (h ? mpe_last_error(h) : "no handle"));
@@ -299,4 +300,4 @@ void PoseEstimator::estimateBodyPoseBatch(const uint8_t* frames, int n_frames, i
         "mpe_estimate_batch");
 }
 
-}  // namespace monocular_pose_estimator
+MPE_FACADE_END  // namespace monocular_pose_estimator

@@ -4,8 +4,9 @@
 //
 // Same class name, namespace, public data members and method names as the reference, so that the
 // only caller (MPENode, monocular_pose_estimator/src/monocular_pose_estimator.cpp) keeps compiling
-// after the type substitutions listed in INTEGRATION.md (cv::Mat -> ImageView or the OpenCV
-// adapter, Eigen types -> datatypes.h or the Eigen adapter).
+// after the type substitutions listed in INTEGRATION.md (cv::Mat -> ImageView, Eigen types -> datatypes.h) — or
+// WITHOUT any edit where Eigen and OpenCV exist: -DMPE_REFERENCE_SURFACE puts a PoseEstimator with the reference's
+// literal cv::Mat / Eigen surface on top of this class (compat/adapters/reference_surface.h).
 //
 // estimateBodyPose runs the reference's whole state machine (pose_estimator.cpp:62-147) through the
 // stateful mpe_tracker_* ABI: brute-force initialisation while not initialised, then constant-
@@ -15,6 +16,7 @@
 #ifndef MPE_COMPAT_POSE_ESTIMATOR_H_
 #define MPE_COMPAT_POSE_ESTIMATOR_H_
 
+#include "facade_namespace.h"
 #include <string>
 #include <vector>
 
@@ -23,7 +25,7 @@
 #include "mpe.h"
 #include "visualization.h"
 
-namespace monocular_pose_estimator {
+MPE_FACADE_BEGIN
 
 class PoseEstimator {
  public:
@@ -128,5 +130,10 @@ class PoseEstimator {
   bool pose_updated_;
 };
 
-}  // namespace monocular_pose_estimator
+MPE_FACADE_END  // namespace monocular_pose_estimator
+
+#ifdef MPE_REFERENCE_SURFACE
+// the reference's literal class surface (cv::Mat / Eigen types) on top of the facade above
+#include "../adapters/reference_surface.h"
+#endif
 #endif

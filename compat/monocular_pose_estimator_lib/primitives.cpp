@@ -1,5 +1,6 @@
 // primitives.cpp — the static classes P3P and LEDDetector on top of the C ABI.  The reference's static
 // functions carry no state; here they share one lazily created library handle per process.
+#include "facade_namespace.h"
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -8,7 +9,7 @@
 #include "mpe.h"
 #include "p3p.h"
 
-namespace monocular_pose_estimator {
+MPE_FACADE_BEGIN
 
 namespace {
 std::mutex g_lock;  // one handle = one caller at a time (include/mpe.h)
@@ -115,4 +116,4 @@ void LEDDetector::distortPoints(const std::vector<Point2f>& src, std::vector<Poi
   if (rc != MPE_OK) throw std::runtime_error("mpe_distort_points: bad argument");
 }
 
-}  // namespace monocular_pose_estimator
+MPE_FACADE_END  // namespace monocular_pose_estimator

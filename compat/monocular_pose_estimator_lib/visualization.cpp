@@ -1,4 +1,5 @@
 // visualization.cpp — overlay rasteriser (see visualization.h).
+#include "facade_namespace.h"
 #include "visualization.h"
 
 #include <cmath>
@@ -7,7 +8,7 @@
 
 #include "mpe.h"
 
-namespace monocular_pose_estimator {
+MPE_FACADE_BEGIN
 
 namespace {
 
@@ -118,4 +119,4 @@ void Visualization::grayToColor(const ImageView& gray, ColorImageView& color) {
   }
 }
 
-}  // namespace monocular_pose_estimator
+MPE_FACADE_END  // namespace monocular_pose_estimator

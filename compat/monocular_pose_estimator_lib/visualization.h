@@ -7,11 +7,12 @@
 #ifndef MPE_COMPAT_VISUALIZATION_H_
 #define MPE_COMPAT_VISUALIZATION_H_
 
+#include "facade_namespace.h"
 #include <vector>
 
 #include "datatypes.h"
 
-namespace monocular_pose_estimator {
+MPE_FACADE_BEGIN
 
 //! Writable interleaved 3-channel 8-bit image in B,G,R memory order (the node publishes "bgr8").
 struct ColorImageView {
@@ -40,5 +41,5 @@ class Visualization {
   static void grayToColor(const ImageView& gray, ColorImageView& color);
 };
 
-}  // namespace monocular_pose_estimator
+MPE_FACADE_END  // namespace monocular_pose_estimator
 #endif

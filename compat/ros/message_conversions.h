@@ -8,12 +8,13 @@
 #ifndef MPE_COMPAT_ROS_MESSAGE_CONVERSIONS_H_
 #define MPE_COMPAT_ROS_MESSAGE_CONVERSIONS_H_
 
+#include "../monocular_pose_estimator_lib/facade_namespace.h"
 #include <cmath>
 #include <vector>
 
 #include "monocular_pose_estimator_lib/pose_estimator.h"
 
-namespace monocular_pose_estimator {
+MPE_FACADE_BEGIN
 
 struct PoseMessageFields {
   double position[3];
@@ -96,5 +97,5 @@ inline void applyReconfigure(PoseEstimator& pe, const ReconfigureValues& v) {
   pe.setValidCorrespondenceThreshold(v.valid_correspondence_threshold);
 }
 
-}  // namespace monocular_pose_estimator
+MPE_FACADE_END  // namespace monocular_pose_estimator
 #endif

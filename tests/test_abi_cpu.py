@@ -157,9 +157,10 @@ def test_cpp_facade_builds(lib):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "compat")])
     out = subprocess.check_output(["nm", "-DC", "--defined-only",
                                    os.path.join(ROOT, "compat", "libmonocular_pose_estimator_compat.so")], text=True)
-    for sym in ("monocular_pose_estimator::PoseEstimator::estimateBodyPose",
-                "monocular_pose_estimator::PoseEstimator::setMarkerPositions",
-                "monocular_pose_estimator::PoseEstimator::initialise"):
+    # (the facade's classes sit in the inline namespace monocular_pose_estimator::hip, see facade_namespace.h)
+    for sym in ("monocular_pose_estimator::hip::PoseEstimator::estimateBodyPose",
+                "monocular_pose_estimator::hip::PoseEstimator::setMarkerPositions",
+                "monocular_pose_estimator::hip::PoseEstimator::initialise"):
         assert sym in out, sym
 
 
@@ -373,3 +374,29 @@ def test_bench_entry_under_a_launcher_and_error_paths(lib):
     if lib.mpe_device_count() < 2:
         few = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
         assert few.returncode != 0 and "GPU(s) are visible" in few.stderr, (few.returncode, few.stderr[-400:])
+
+
+def test_reference_class_surface_compiles(lib):
+    """compat/adapters: with -DMPE_REFERENCE_SURFACE monocular_pose_estimator::PoseEstimator has the reference's
+    literal public surface (cv::Mat camera_matrix_K_, estimateBodyPose(cv::Mat, double), Eigen return types,
+    Eigen-based datatypes); a driver written like MPENode's call sites compiles and links against it.  (Against
+    tests/mock_deps — container-only spellings of the Eigen / OpenCV types involved; neither library is in this
+    image.)  The default build (no macro) keeps the plain-array facade names: both share ONE compiled library."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "compat")])
+    exe = os.path.join(ROOT, "compat", "reference_surface_check")
+    libdir = os.path.dirname(mpe.library_path())
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-O1", "-DMPE_REFERENCE_SURFACE",
+                           "-I", os.path.join(ROOT, "tests", "mock_deps"), "-I", os.path.join(ROOT, "compat"),
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "reference_surface_check.cpp"),
+                           "-o", exe, "-L", os.path.join(ROOT, "compat"), "-lmonocular_pose_estimator_compat", "-L", libdir,
+                           "-lmpe_hip", "-Wl,-rpath," + os.path.join(ROOT, "compat"), "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.check_output(["nm", "-DC", "--defined-only",
+                                   os.path.join(ROOT, "compat", "libmonocular_pose_estimator_compat.so")], text=True)
+    assert "monocular_pose_estimator::hip::PoseEstimator::estimateBodyPose" in out
+    launch = open(os.path.join(ROOT, "compat", "ros", "launch", "nodelet.launch")).read()
+    assert "monocular_pose_estimator/MPENodelet" in launch and "mpe_nodelet_manager" in launch
+    for name in ("threshold_value", "gaussian_sigma", "min_blob_area", "max_blob_area", "max_width_height_distortion",
+                 "max_circular_distortion", "back_projection_pixel_tolerance", "nearest_neighbour_pixel_tolerance",
+                 "certainty_threshold", "valid_correspondence_threshold", "roi_border_thickness"):
+        assert name in launch, name

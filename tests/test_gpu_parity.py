@@ -1130,3 +1130,26 @@ def test_chunked_host_ingest_is_bit_identical(orc):
             h.set_option("ingest_chunk", -1)
     finally:
         h.close()
+
+
+@pytest.mark.gpu
+def test_reference_class_surface_runs(tmp_path):
+    """The literal reference surface (estimateBodyPose(cv::Mat, double), cv::Mat camera_matrix_K_, Eigen getters —
+    compat/adapters/reference_surface.h) driven the way MPENode drives the class, on a tracked sequence: identical
+    poses / covariances to the plain facade underneath, overlay through augmentImage(cv::Mat&)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "compat")])
+    exe = str(tmp_path / "reference_surface_check")
+    libdir = os.path.dirname(mpe.library_path())
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-DMPE_REFERENCE_SURFACE", "-I", os.path.join(root, "tests", "mock_deps"),
+                           "-I", os.path.join(root, "compat"), "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "reference_surface_check.cpp"), "-o", exe, "-L",
+                           os.path.join(root, "compat"), "-lmonocular_pose_estimator_compat", "-L", libdir, "-lmpe_hip",
+                           "-Wl,-rpath," + os.path.join(root, "compat"), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    d = synth.make_sequence("C2", 20, seed=99)
+    raw = str(tmp_path / "seq.raw")
+    d["frames"].tofile(raw)
+    out = subprocess.run([exe, raw, "20", str(d["rows"]), str(d["cols"])], capture_output=True, text=True)
+    assert out.returncode == 0 and "surface ok" in out.stdout, (out.returncode, out.stdout, out.stderr[-500:])
