@@ -272,18 +272,22 @@ def main():
     # FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
     # coalesced reads on gfx950), scaled from bytes per frame to this launch
     traffic = None
+    traffic_source = None
+    pmc_all = {}
     try:
-        name = "round1_k2_vote_scan_pmc.json" if fused else "round1_k1a_scan_pmc.json"
-        with open(os.path.join(ROOT, "profiles", name)) as fh:
-            pmc = json.load(fh)
+        with open(os.path.join(ROOT, "profiles", "round2_pmc.json")) as fh:
+            pmc_all = json.load(fh)
+        pmc = pmc_all["k2_vote_scan" if fused else "k1a_scan"]
         if pmc.get("rows") == rows and pmc.get("cols") == cols:
             traffic = pmc["hbm_bytes_per_frame"] * min(fpl, B)
+            traffic_source = "profiles/round2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, " \
+                             "FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes; %s)" % pmc.get("from", "")
     except Exception:
         pass
     if fused:
         roofline = {"kernel": "k2_vote<scan>", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": traffic, "bytes_per_launch": bytes_per_launch,
-                    "avg_launch_ms": vote_scan_ms, "launches_per_step": launches - 1, "frames_per_launch": fpl,
+                    "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+                    "bytes_per_launch": bytes_per_launch, "avg_launch_ms": vote_scan_ms, "launches_per_step": launches - 1, "frames_per_launch": fpl,
                     "measured": "HIP events around every k2_vote<scan> launch on its stream in steps of the same "
                                 "mode as the timed region.  This kernel is the image pass AND the FP64 voting: each "
                                 "voting wave streams its share of the next sub-batch's pixels through LDS DMA "
@@ -293,7 +297,7 @@ def main():
                                 "kernel, which the first sub-batch of every step still uses."}
     else:
         roofline = {"kernel": "k1a_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": traffic,
+                    "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
                     "bytes_per_launch": bytes_per_launch, "avg_launch_ms": kavg["scan"],
                     "launches_per_step": launches, "frames_per_launch": fpl,
                     "measured": "HIP events around every k1a_scan launch on its stream, steps in the same mode as "
@@ -370,8 +374,18 @@ def main():
         out["k2_rates"] = {"p3p_solves_per_step": solves, "p3p_solves_per_s": solves / (vote_ms * 1e-3),
                            "hypotheses_per_s": 4 * solves / (vote_ms * 1e-3),
                            "vote_ms_per_step": vote_ms,
-                           "timing": "isolated launch" if kiso is not None else "launches inside the pipelined step",
-                           "valu_utilisation": "see profiles/round1_pmc_sq_k2_vote.csv and DESIGN.md section 5"}
+                           "timing": "isolated launch" if kiso is not None else "launches inside the pipelined step"}
+        # VALU utilisation of the voting kernel = wave-instructions x 4 clk / (1024 SIMDs x 2.4 GHz x time): the
+        # instruction count per frame comes from the committed SQ_INSTS_VALU pass of the same kernel and marker /
+        # detection shape (profiles/round2_pmc.json), the time is the one measured in this run
+        vp = pmc_all.get("k2_vote_valu", {}).get(args.config)
+        if vp:
+            t_s = vote_ms * 1e-3
+            n_fr = B
+            out["k2_rates"]["valu_util"] = vp["valu_insts_per_frame"] * n_fr * 4.0 / (1024 * 2.4e9 * t_s)
+            out["k2_rates"]["valu_insts_per_p3p_solve"] = vp["valu_insts_per_frame"] * 64.0 * n_fr / max(1, solves)
+            out["k2_rates"]["valu_source"] = "profiles/round2_pmc.json k2_vote_valu[%s] (%s), kernel %s" % (
+                args.config, vp.get("from", ""), vp.get("kernel", ""))
         if host_leg is not None:
             out["host_streamed_fps"] = host_leg["fps"]
             out["host_streamed"] = host_leg

@@ -1,6 +1,7 @@
 """End-to-end parity soak: N frames through the HIP path (default fused schedule) and through the oracle.
-usage (on an MI355X): python tests/soak_parity.py [frames [config [chunk]]]
-python tests/soak_parity.py 1048576   -> profiles/round1_parity_soak.json"""
+usage (on an MI355X): [MPE_VOTE_ARITH=0|1] python tests/soak_parity.py [frames [config [chunk]]]
+MPE_VOTE_ARITH: option "vote_arith" of the handle (1 = fast voting arithmetic, the default; 0 = strict).
+python tests/soak_parity.py 1048576   -> profiles/round2_parity_soak_*.json"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,6 +17,8 @@ cfg = synth.CONFIGS[CONFIG]; rows, cols = cfg["rows"], cfg["cols"]
 K, D = synth.camera_for(rows, cols); markers = np.asarray(cfg["markers"])
 dev = torch.device("cuda", 0)
 h = mpe.Handle(0); P = mpe.demo_params()
+ARITH = int(os.environ.get("MPE_VOTE_ARITH", "1"))
+h.set_option("vote_arith", ARITH)
 st = torch.cuda.Stream(device=dev); h.set_stream(st.cuda_stream)
 tot = st_mis = pose_mis = n_pose = 0
 worst = 0.0
@@ -39,4 +42,5 @@ for part in range(N // CH):
     worst = max(worst, float(d.max()) if len(d) else 0.0)
     print(part, tot, st_mis, pose_mis, worst, round(time.time() - t0), flush=True)
 print(json.dumps({"config": CONFIG, "frames": tot, "status_mismatches": st_mis, "poses_compared": n_pose, "pose_mismatches_gt_1e-4m": pose_mis,
-                  "worst_position_difference_m": worst, "schedule": h.get_option("last_schedule")}))
+                  "worst_position_difference_m": worst, "schedule": h.get_option("last_schedule"),
+                  "vote_arith": ARITH, "vote_arith_meaning": "1 = fast (Newton-Raphson div / sqrt, Newton cube root), 0 = strict (IEEE, validation kernel's P3P)"}))
