@@ -37,4 +37,5 @@ find $O -name "*counter_collection.csv" -delete; find $O -name "*kernel_trace.cs
 MPE_VOTE_ARITH=1 python $R/tests/soak_parity.py 1048576 C2 2>/dev/null | tail -1 > $O/soak_fast.json
 MPE_VOTE_ARITH=0 python $R/tests/soak_parity.py 262144 C2 2>/dev/null | tail -1 > $O/soak_strict.json
 MPE_VOTE_ARITH=1 python $R/tests/soak_parity.py 2048 C3 2048 2>/dev/null | tail -1 > $O/soak_fast_c3.json
+python $R/tests/soak_votes.py 131072 C2 2>/dev/null | tail -1 > $O/soak_votes.json
 ls $O

@@ -71,7 +71,7 @@ def main():
         },
     }
     json.dump(out, open(P + "pmc.json", "w"), indent=1)
-    for n in ("soak_fast", "soak_strict", "soak_fast_c3"):
+    for n in ("soak_fast", "soak_strict", "soak_fast_c3", "soak_votes"):
         json.dump(last_json(F + n + ".json"), open(P + "parity_%s.json" % n, "w"), indent=1)
 
 
