@@ -113,8 +113,7 @@ def main():
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive host-streamed leg")
     ap.add_argument("--k1a-lds", type=int, default=-1, help="tuning: dummy LDS per scan block (-1 = automatic)")
     ap.add_argument("--pipeline-mode", type=int, default=-1,
-                    help="-1 automatic, 0 two-stream pipeline, 3 fused, 4 fused + side-stream tail, 5 look-ahead")
-    ap.add_argument("--vote-blocks-per-cu", type=int, default=6, help="mode 5: resident voting blocks per CU")
+                    help="-1 automatic (fused single-stream schedule for <= 5 markers), 0 two-stream pipeline, 3 fused")
     ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
     ap.add_argument("--vote-arith", type=int, default=1, help="1 fast voting arithmetic (default), 0 strict (IEEE)")
     ap.add_argument("--plumbing-only", action="store_true",
@@ -186,7 +185,6 @@ def main():
     h.set_option("pipeline", args.pipeline)
     h.set_option("pipeline_mode", args.pipeline_mode)
     h.set_option("vote_arith", args.vote_arith)
-    h.set_option("vote_blocks_per_cu", args.vote_blocks_per_cu)
     if args.k1a_lds >= 0:
         h.set_option("k1a_dummy_lds", args.k1a_lds)
 
@@ -243,12 +241,11 @@ def main():
     launches, fpl = int(kms[0]["launches"]), int(kms[0]["frames_per_launch"])
     kavg["launches"], kavg["frames_per_launch"] = launches, fpl
     bytes_per_launch = min(fpl, B) * rows * cols  # algorithmic: every pixel read once
-    fused = schedule in (3, 4, 5) and launches > 1
+    fused = schedule in (3, 4) and launches > 1
     if fused:
         # fused schedule: the scan of sub-batch s+1 runs INSIDE the voting kernel of sub-batch s; only the first
         # sub-batch is scanned by a stand-alone k1a_scan launch.  Average the launches that do the same thing.
-        n_carry = launches - (2 if schedule == 5 else 1)  # look-ahead: vote(s) carries scan(s + 2)
-        vote_scan_ms = float(np.mean([sub[i]["vote"] for sub in subs for i in range(n_carry)]))
+        vote_scan_ms = float(np.mean([sub[i]["vote"] for sub in subs for i in range(launches - 1)]))
         vote_plain_ms = float(np.mean([sub[launches - 1]["vote"] for sub in subs]))
         scan_alone_ms = float(np.mean([sub[0]["scan"] for sub in subs]))
         kavg.update({"scan_standalone_first_sub_batch": scan_alone_ms, "vote_with_scan": vote_scan_ms,
@@ -290,7 +287,7 @@ def main():
     if fused:
         roofline = {"kernel": "k2_vote<scan>", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
-                    "bytes_per_launch": bytes_per_launch, "avg_launch_ms": vote_scan_ms, "launches_per_step": n_carry, "frames_per_launch": fpl,
+                    "bytes_per_launch": bytes_per_launch, "avg_launch_ms": vote_scan_ms, "launches_per_step": launches - 1, "frames_per_launch": fpl,
                     "measured": "HIP events around every k2_vote<scan> launch on its stream in steps of the same "
                                 "mode as the timed region.  This kernel is the image pass AND the FP64 voting: each "
                                 "voting wave streams its share of the next sub-batch's pixels through LDS DMA "
@@ -353,8 +350,7 @@ def main():
                                                                       cfg["n_distractors"]),
                        "frames_per_gpu_per_step": B, "frames_resident_in_hbm": True,
                        "streams_per_gpu": args.pipeline,
-                       "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel", 4: "fused + validate/refine on a side stream",
-                                    5: "look-ahead: persistent voting blocks carry scan(s+2); blobs(s+1) and tail(s-1) on side streams"}.get(schedule, schedule),
+                       "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel", 4: "fused + validate/refine on a side stream"}.get(schedule, schedule),
                        "side_streams_concurrent": h.get_option("streams_concurrent"),
                        "parallelism": "frames sharded over %d GPU(s), pose records gathered to rank 0 (async, double-buffered)" % world},
             "poses_found_frac": n_pose / B,

@@ -72,11 +72,6 @@ struct mpe_handle {
   hipStream_t copy_stream = nullptr;  // host-frame ingest: the H2D copy of chunk c + 1 runs beside the kernels of chunk c
   hipEvent_t copy_done[2] = {nullptr, nullptr};
   int ingest_chunk = 2048;            // frames per ingest chunk (option "ingest_chunk"; 0 = one blocking copy per call)
-  hipStream_t blob_stream = nullptr;  // look-ahead schedule (mode 5): blob extraction of sub-batch s + 1 beside vote(s)
-  hipEvent_t blobs_done[kMaxSub] = {};
-  hipEvent_t pre_done = nullptr;
-  DevBuf counters;                    // work counters of the persistent voting launches
-  int vote_blocks_per_cu = 6;         // mode 5: resident voting blocks per CU (option "vote_blocks_per_cu")
   hipStream_t tail_stream = nullptr;  // fused schedule, mode 4: validate + refine of sub-batch s beside blobs(s + 1)
   hipEvent_t tail_done = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -417,118 +412,6 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (h->streams_concurrent == 0) schedule = 4;
   }
   h->last_schedule = schedule;
-  if (schedule == 5 && sp && sp->n_markers <= 5 && nsub >= 3) {
-    // Look-ahead schedule: the voting kernel of sub-batch s carries the image scan of sub-batch s + 2 and runs as
-    // PERSISTENT blocks (vote_blocks_per_cu per CU, work units from an atomic counter), which leaves a wave slot
-    // per SIMD and ~50 KB of LDS per CU free for the whole launch; the blob extraction of sub-batch s + 1 (its scan
-    // came with vote(s - 1)) and the validate / refine of sub-batch s - 1 run beside it on two side streams.
-    //   main : scan(0) blobs(0) scan(1) | vote(0)+scan(2) | vote(1)+scan(3) | ...
-    //   blobs:                          | blobs(1)        | blobs(2)        | ...
-    //   tail :                          |                 | tail(0)         | tail(1) ...
-    hipStream_t st = h->stream;
-    if (!h->tail_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
-    if (!h->blob_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->blob_stream, hipStreamNonBlocking));
-    if (!h->tail_done) HIP_TRY(h, hipEventCreateWithFlags(&h->tail_done, hipEventDisableTiming));
-    if (!h->pre_done) HIP_TRY(h, hipEventCreateWithFlags(&h->pre_done, hipEventDisableTiming));
-    for (int i = 0; i < mpe_handle::kMaxSub; ++i) {
-      if (!h->vote_done[i]) HIP_TRY(h, hipEventCreateWithFlags(&h->vote_done[i], hipEventDisableTiming));
-      if (!h->blobs_done[i]) HIP_TRY(h, hipEventCreateWithFlags(&h->blobs_done[i], hipEventDisableTiming));
-    }
-    HIP_TRY(h, h->counters.reserve(mpe_handle::kMaxSub * sizeof(int)));
-    int* counters = static_cast<int*>(h->counters.p);
-    auto sub_ptrs = [&](int s, int& f0, int& nf, const uint8_t*& fr, unsigned long long*& fl) {
-      f0 = s * per;
-      nf = std::max(0, std::min(per, n_frames - f0));
-      fr = d_frames + (size_t)f0 * frame_bytes;
-      fl = static_cast<unsigned long long*>(h->flags.p) + fw_per * s;
-    };
-    auto blobs = [&](int s, hipStream_t q) -> int {
-      int f0, nf;
-      const uint8_t* fr;
-      unsigned long long* fl;
-      sub_ptrs(s, f0, nf, fr, fl);
-      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], q));
-      HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0, static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
-                                  static_cast<uint8_t*>(h->scratch.p), sp->n_markers, q));
-      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], q));
-      return MPE_OK;
-    };
-    int f0, nf;
-    const uint8_t* fr;
-    unsigned long long* fl;
-    HIP_TRY(h, hipMemsetAsync(counters, 0, mpe_handle::kMaxSub * sizeof(int), st));
-    sub_ptrs(0, f0, nf, fr, fl);
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][0], st));
-    HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, scan_lds(h, false), st));
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][1], st));
-    { const int rc = blobs(0, st); if (rc) return rc; }
-    sub_ptrs(1, f0, nf, fr, fl);
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[1][0], st));
-    HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, scan_lds(h, false), st));
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[1][1], st));
-    HIP_TRY(h, hipEventRecord(h->pre_done, st));
-    int used = 0;
-    for (int s = 0; s < nsub; ++s) {
-      sub_ptrs(s, f0, nf, fr, fl);
-      if (nf <= 0) break;
-      used = s + 1;
-      // side: blobs(s + 1) beside vote(s)
-      int nf_next = 0;
-      if (s + 1 < nsub) {
-        int q0;
-        const uint8_t* qfr;
-        unsigned long long* qfl;
-        sub_ptrs(s + 1, q0, nf_next, qfr, qfl);
-      }
-      if (nf_next > 0) {
-        HIP_TRY(h, hipStreamWaitEvent(h->blob_stream, s == 0 ? h->pre_done : h->vote_done[s - 1], 0));
-        const int rc = blobs(s + 1, h->blob_stream);
-        if (rc) return rc;
-        HIP_TRY(h, hipEventRecord(h->blobs_done[s + 1], h->blob_stream));
-      }
-      // main: vote(s) + scan(s + 2)
-      if (s > 0) HIP_TRY(h, hipStreamWaitEvent(st, h->blobs_done[s], 0));
-      uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
-      HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), st));
-      const uint8_t* nfr = nullptr;
-      unsigned long long* nfl = nullptr;
-      size_t nbytes = 0, scanned = 0;
-      if (s + 2 < nsub) {
-        int q0, qn;
-        sub_ptrs(s + 2, q0, qn, nfr, nfl);
-        nbytes = (size_t)qn * frame_bytes;
-      }
-      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], st));
-      HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, *sp, static_cast<const double*>(h->mtab.p), hs,
-                                auto_splits(h, nf, sp->n_markers), sp->n_markers, st, nbytes ? nfr : nullptr, nbytes, nfl,
-                                dp.thr, &scanned, 256 * h->vote_blocks_per_cu, counters + s));
-      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], st));
-      if (nbytes > 0) {
-        if (prof) HIP_TRY(h, hipEventRecord(h->pev[s + 2][0], st));
-        if (nbytes > scanned)
-          HIP_TRY(h, launch_k1a_scan(nfr + scanned, nbytes - scanned, nfl + scanned / 1024, dp.thr, scan_lds(h, false), st));
-        if (prof) HIP_TRY(h, hipEventRecord(h->pev[s + 2][1], st));
-      }
-      HIP_TRY(h, hipEventRecord(h->vote_done[s], st));
-      // tail(s) on its side stream
-      HIP_TRY(h, hipStreamWaitEvent(h->tail_stream, h->vote_done[s], 0));
-      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], h->tail_stream));
-      HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
-                                d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0,
-                                static_cast<uint8_t*>(h->mid.p) + k3_mid_bytes(1) * (size_t)f0, h->tail_stream));
-      if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], h->tail_stream));
-    }
-    HIP_TRY(h, hipEventRecord(h->tail_done, h->tail_stream));
-    HIP_TRY(h, hipStreamWaitEvent(st, h->tail_done, 0));
-    if (prof) {
-      h->prof_launches = used;
-      h->have_ms = true;
-      h->prof_pipelined = true;
-      h->prof_frames_per_launch = per;
-    }
-    return MPE_OK;
-  }
-  if (schedule == 5) schedule = h->last_schedule = 4;  // (too few sub-batches / more than 5 markers)
   if (schedule == 3 || schedule == 4) {
     const bool side_tail = schedule == 4;
     if (side_tail) {
@@ -797,11 +680,6 @@ void mpe_destroy(mpe_handle* h) {
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   if (h->tail_done) (void)hipEventDestroy(h->tail_done);
   if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
-  if (h->blob_stream) (void)hipStreamDestroy(h->blob_stream);
-  for (auto& e : h->blobs_done)
-    if (e) (void)hipEventDestroy(e);
-  if (h->pre_done) (void)hipEventDestroy(h->pre_done);
-  h->counters.release();
   for (auto& e : h->copy_done)
     if (e) (void)hipEventDestroy(e);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -884,7 +762,6 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "vote_splits") *value = h->vote_splits;
   else if (n == "vote_arith") *value = h->vote_arith;
   else if (n == "ingest_chunk") *value = h->ingest_chunk;
-  else if (n == "vote_blocks_per_cu") *value = h->vote_blocks_per_cu;
   else if (n == "k1a_dummy_lds") *value = h->k1a_dummy_lds;
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
@@ -914,11 +791,6 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   }
   if (!std::strcmp(name, "vote_splits")) {
     h->vote_splits = value;
-    return MPE_OK;
-  }
-  if (!std::strcmp(name, "vote_blocks_per_cu")) {
-    if (value < 1 || value > 16) return fail(h, MPE_ERR_ARG, "vote_blocks_per_cu out of range");
-    h->vote_blocks_per_cu = value;
     return MPE_OK;
   }
   if (!std::strcmp(name, "ingest_chunk")) {

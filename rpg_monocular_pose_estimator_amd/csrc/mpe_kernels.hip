@@ -1437,13 +1437,8 @@ struct NoRider {
 template <bool SCAN>
 __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_detections* __restrict__ dets, SolveParams sp,
                                                       const double* __restrict__ tab, uint32_t* __restrict__ hist,
-                                                      int splits, ScanArgs scan, int n_units,
-                                                      int* __restrict__ work_counter) {
-  // Work unit = (frame, part).  One block per unit (gridDim.x == n_units, work_counter == nullptr), or PERSISTENT
-  // blocks that pull units from an atomic counter: a grid of 256 CUs x k blocks then holds exactly k blocks per CU
-  // for the whole kernel, which leaves the rest of every CU to kernels on other streams (look-ahead schedule).
+                                                      int splits, ScanArgs scan) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int s_unit;
   __shared__ double s_px[MPE_MAX_DETECTIONS][2];
   __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
   // detection triples staged per pass: 64, or 16 in the scan-carrying variant (LDS goes to the scan staging
@@ -1454,26 +1449,16 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   __shared__ unsigned s_hist[MPE_HIST_STRIDE];
   __shared__ f32x2 s_pxf[MPE_MAX_DETECTIONS];  // the detections in single precision (nearest-neighbour prefilter)
 
+  const int f = blockIdx.x / splits, part = blockIdx.x - f * splits;
   const int tid = threadIdx.x;
   const int nthr = blockDim.x;
-  const int n_m = sp.n_markers;
+  const mpe_detections* d = dets + f;
+  const int n_d = d->n, n_m = sp.n_markers;
   typename std::conditional<SCAN, ScanRider, NoRider>::type rider;
   if constexpr (SCAN) rider.init(scan, smem);  // (this variant keeps the back-projections in registers)
-  bool table_loaded = false;
-  for (int unit = blockIdx.x;;) {
-  if (work_counter) {  // persistent block: next unit from the counter (block-uniform through LDS)
-    __syncthreads();
-    if (tid == 0) s_unit = atomicAdd(work_counter, 1);
-    __syncthreads();
-    unit = s_unit;
-  }
-  if (unit >= n_units) break;
-  const int f = unit / splits, part = unit - f * splits;
-  const mpe_detections* d = dets + f;
-  const int n_d = d->n;
   if (n_d < 4 || d->status != 0 || n_m < 4) {  // min_num_leds_detected_ (pose_estimator.h:78)
-    if (!work_counter) break;
-    continue;
+    rider.drain();
+    return;
   }
 
   for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) s_hist[i] = 0;
@@ -1512,15 +1497,12 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   double* s_tab = nullptr;
   if constexpr (SCAN) {
     s_tab = reinterpret_cast<double*>(smem + (size_t)(blockDim.x >> 6) * (K2_SCAN_R * 1024));
-    if (!table_loaded) {  // (frame independent: once per block)
-      for (int i = tid; i < n_perms * K2_LTAB; i += nthr) {
-        const int pe = i / K2_LTAB, fld = i - pe * K2_LTAB;
-        const int src = fld < 5 ? 12 + fld : 13 + fld;  // 12..16, 18..23
-        s_tab[i] = (fld < 5 + 3 * nuo) ? tab[(size_t)pe * esz + src] : 0.0;
-      }
-      table_loaded = true;
-      __syncthreads();
+    for (int i = tid; i < n_perms * K2_LTAB; i += nthr) {
+      const int pe = i / K2_LTAB, fld = i - pe * K2_LTAB;
+      const int src = fld < 5 ? 12 + fld : 13 + fld;  // 12..16, 18..23
+      s_tab[i] = (fld < 5 + 3 * nuo) ? tab[(size_t)pe * esz + src] : 0.0;
     }
+    __syncthreads();
   }
   for (int tc0 = 0; tc0 < n_combos; tc0 += TRI) {
     const int ntri = min(TRI, n_combos - tc0);
@@ -1763,15 +1745,13 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
       pj = pj_keep;
     }
   }
+  rider.drain();
   __syncthreads();
   uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
   for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) {
     const unsigned v = s_hist[i];
     if (v) atomicAdd(&gh[i], v);
   }
-  if (!work_counter) break;  // one unit per block
-  }  // units
-  rider.drain();
 }
 
 // Strict voting kernel (option "vote_arith" = 0): initialise()'s loop nest (pose_estimator.cpp:565-702) with the
@@ -1875,8 +1855,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detection
 
 hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
                           uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px,
-                          size_t scan_bytes, unsigned long long* scan_flags, int scan_thr, size_t* scanned_bytes,
-                          int persistent_blocks, int* work_counter) {
+                          size_t scan_bytes, unsigned long long* scan_flags, int scan_thr, size_t* scanned_bytes) {
   if (scanned_bytes) *scanned_bytes = 0;
   if (n_frames <= 0 || sp.n_markers < 4) return hipSuccess;
   if (splits < 1) splits = 1;
@@ -1916,13 +1895,11 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
     lds = (size_t)(threads / 64) * chunk_bytes +
           (size_t)sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2) * K2_LTAB * sizeof(double);
     if (scanned_bytes) *scanned_bytes = (size_t)sa.n_chunks * chunk_bytes;
-    const int n_units = n_frames * splits;
-    const bool persistent = persistent_blocks > 0 && work_counter && persistent_blocks < n_units;
-    hipLaunchKernelGGL(k2_vote<true>, dim3((unsigned)(persistent ? persistent_blocks : n_units)), dim3(threads), lds, s,
-                       dets, sp, tab, hist, splits, sa, n_units, persistent ? work_counter : (int*)nullptr);
+    hipLaunchKernelGGL(k2_vote<true>, dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
+                       splits, sa);
   } else {
     hipLaunchKernelGGL(k2_vote<false>, dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
-                       splits, sa, n_frames * splits, (int*)nullptr);
+                       splits, sa);
   }
   return hipGetLastError();
 }
