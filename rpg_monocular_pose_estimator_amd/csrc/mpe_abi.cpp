@@ -449,7 +449,9 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
                                   static_cast<uint8_t*>(h->scratch.p), sp->n_markers, st));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], st));
       uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
-      HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), st));
+      // (with one voting block per frame the kernel stores every histogram row the tail reads: no memset)
+      if (sp->vote_arith == 0 || auto_splits(h, nf, sp->n_markers) != 1)
+        HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), st));
       const uint8_t* nfr = nullptr;
       unsigned long long* nfl = nullptr;
       size_t nbytes = 0, scanned = 0;

@@ -1748,9 +1748,15 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   rider.drain();
   __syncthreads();
   uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
-  for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) {
-    const unsigned v = s_hist[i];
-    if (v) atomicAdd(&gh[i], v);
+  if (splits == 1) {
+    // this block owns the frame's histogram: plain stores of the rows the tail kernel reads (detections < n_d) —
+    // the caller then needs no memset of the histogram buffer
+    for (int i = tid; i < n_d * MPE_MAX_MARKERS; i += nthr) gh[i] = s_hist[i];
+  } else {
+    for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) {
+      const unsigned v = s_hist[i];
+      if (v) atomicAdd(&gh[i], v);
+    }
   }
 }
 
