@@ -6,7 +6,7 @@
 //   facade_selftest message < 16+36 doubles per line
 //       pose (row-major 4x4) + covariance (row-major 6x6) -> "px py pz qx qy qz qw c0 .. c35" per line, the
 //       PoseWithCovarianceStamped fields as compat/ros/message_conversions.h packs them (host only)
-//   facade_selftest steps --markers <yaml> --frames <file.raw> --rows R --cols C [--dt s]
+//   facade_selftest steps --markers <yaml> --frames <file.raw> --rows R --cols C [--dt s] [--overlay-out file.bgr]
 //       object A: estimateBodyPose per frame.  object B: the same state machine written out with the
 //       class's public step methods exactly as pose_estimator.cpp:62-147 strings them together
 //       (LEDDetector::findLeds, setImagePoints, initialise, optimiseAndUpdatePose, predictWithROI,
@@ -136,7 +136,7 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "usage: facade_selftest combos N K | steps --markers y --frames f --rows R --cols C\n");
     return 2;
   }
-  const char *markers = 0, *frames = 0;
+  const char *markers = 0, *frames = 0, *overlay_out = 0;
   int rows = 480, cols = 752;
   double dt = 0.02;
   for (int i = 2; i + 1 < argc; i += 2) {
@@ -145,6 +145,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--rows")) rows = std::atoi(argv[i + 1]);
     else if (!std::strcmp(argv[i], "--cols")) cols = std::atoi(argv[i + 1]);
     else if (!std::strcmp(argv[i], "--dt")) dt = std::atof(argv[i + 1]);
+    else if (!std::strcmp(argv[i], "--overlay-out")) overlay_out = argv[i + 1];
   }
   List4DPoints pts;
   if (!markers || !frames || !read_markers(markers, pts)) {
@@ -232,6 +233,18 @@ int main(int argc, char** argv) {
     }
     const std::vector<Point2f>& c = a.getDistortedDetectionCenters();
     std::printf("overlay: %d red %d green %d blue pixels, %d detection rings\n", red, green, blue, (int)c.size());
+    if (overlay_out) {  // the painted image + what it was painted from, for the independent geometric check
+      FILE* fo = std::fopen(overlay_out, "wb");
+      if (!fo || std::fwrite(rgb.data(), 1, rgb.size(), fo) != rgb.size()) return 4;
+      std::fclose(fo);
+      const Matrix4d Tp = a.getPredictedPose();
+      const Rect r = a.getRegionOfInterest();
+      std::printf("overlay_state");
+      for (int i = 0; i < 16; ++i) std::printf(" %.17g", Tp(i));
+      std::printf(" %d %d %d %d %d", r.x, r.y, r.width, r.height, (int)c.size());
+      for (size_t i = 0; i < c.size(); ++i) std::printf(" %.9g %.9g", (double)c[i].x, (double)c[i].y);
+      std::printf("\n");
+    }
     if (c.size() < 4 || red < (int)c.size() * 60 || blue < 100 || green < 4) return 1;
     const int cx = (int)std::lrint(c[0].x) + 10, cy = (int)std::lrint(c[0].y);  // a ring pixel right of LED 0
     const uint8_t* px = rgb.data() + ((size_t)cy * cols + cx) * 3;

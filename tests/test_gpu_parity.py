@@ -1153,3 +1153,80 @@ def test_reference_class_surface_runs(tmp_path):
     d["frames"].tofile(raw)
     out = subprocess.run([exe, raw, "20", str(d["rows"]), str(d["cols"])], capture_output=True, text=True)
     assert out.returncode == 0 and "surface ok" in out.stdout, (out.returncode, out.stdout, out.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_overlay_geometry_against_an_independent_projection(tmp_path):
+    """The debug overlay (Visualization::createVisualizationImage, visualization.cpp:58-99: body axes x red / y green
+    / z blue of length 0.075 m projected WITH lens distortion, a radius-10 ring around every detection, the ROI
+    rectangle, all 2 px thick) painted by the facade's rasteriser, checked against geometry computed independently in
+    numpy from the same pose / ROI / detections: every ring is complete and every coloured pixel lies where the
+    reference's primitives put ink (within the 2 px pen).  OpenCV is not available to compare pixel for pixel."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "compat")])
+    d = synth.make_sequence("C2", 12, seed=77)
+    raw, yaml, ov = str(tmp_path / "seq.raw"), str(tmp_path / "m.yaml"), str(tmp_path / "ov.bgr")
+    d["frames"].tofile(raw)
+    with open(yaml, "w") as fh:
+        fh.write("marker_positions:\n")
+        for m in d["markers"]:
+            fh.write("  - x: %.17g\n    y: %.17g\n    z: %.17g\n" % tuple(m))
+    out = subprocess.run([os.path.join(root, "compat", "facade_selftest"), "steps", "--markers", yaml, "--frames", raw,
+                          "--rows", str(d["rows"]), "--cols", str(d["cols"]), "--dt", "0.02", "--overlay-out", ov],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-500:])
+    st = [ln for ln in out.stdout.splitlines() if ln.startswith("overlay_state")][0].split()[1:]
+    T = np.array([float(x) for x in st[:16]]).reshape(4, 4)
+    rx, ry, rw, rh, nc = [int(x) for x in st[16:21]]
+    centres = np.array([float(x) for x in st[21:21 + 2 * nc]]).reshape(nc, 2)
+    rows, cols = d["rows"], d["cols"]
+    img = np.fromfile(ov, np.uint8).reshape(rows, cols, 3)  # B, G, R
+    red = (img[..., 0] == 0) & (img[..., 1] == 0) & (img[..., 2] == 255)
+    green = (img[..., 0] == 0) & (img[..., 1] == 255) & (img[..., 2] == 0)
+    blue = (img[..., 0] == 255) & (img[..., 1] == 0) & (img[..., 2] == 0)
+    # the selftest's camera (facade_selftest.cpp configure()): independent pinhole + plumb-bob projection
+    K = np.array([[307.8119, 0, 371.6954], [0, 307.5514, 243.5497], [0, 0, 1.0]])
+    D = np.array([-0.2819, 0.0675, 0.0004, -0.0003, -0.0063])
+    tips = np.array([[0, 0, 0], [0.075, 0, 0], [0, 0.075, 0], [0, 0, 0.075]])
+    pc = tips @ T[:3, :3].T + T[:3, 3]
+    px = synth.distort_px(np.stack([K[0, 0] * pc[:, 0] / pc[:, 2] + K[0, 2], K[1, 1] * pc[:, 1] / pc[:, 2] + K[1, 2]], -1), K, D)
+
+    def dist_to_segment(yy, xx, a, b):
+        p = np.stack([xx, yy], -1).astype(float)
+        ab = b - a
+        t = np.clip(((p - a) @ ab) / max(ab @ ab, 1e-12), 0, 1)
+        return np.linalg.norm(p - (a + t[:, None] * ab), axis=1)
+
+    def near_any(mask, tests, tol):
+        yy, xx = np.nonzero(mask)
+        ok = np.zeros(len(yy), bool)
+        for fn in tests:
+            ok |= fn(yy, xx) <= tol
+        return ok
+
+    ring_d = [lambda yy, xx, c=c: np.abs(np.hypot(xx - np.rint(c[0]), yy - np.rint(c[1])) - 10.0) for c in centres]
+    x0, y0, x1, y1 = rx, ry, rx + rw - 1, ry + rh - 1
+    corners = [np.array(p, float) for p in ((x0, y0), (x1, y0), (x1, y1), (x0, y1))]
+    rect_d = [lambda yy, xx, a=corners[i], b=corners[(i + 1) % 4]: dist_to_segment(yy, xx, a, b) for i in range(4)]
+    axis_d = [lambda yy, xx, k=k: dist_to_segment(yy, xx, px[0], px[k]) for k in (1, 2, 3)]
+    tol = 2.6  # 2 px pen (2x2 brush) + rounding of the end points
+    assert near_any(red, ring_d + [axis_d[0]], tol).all()
+    assert near_any(green, [axis_d[1]], tol).all() and green.sum() >= 4
+    assert near_any(blue, rect_d + [axis_d[2]], tol).all()
+    # completeness: every ring closed (sampled every 5 degrees), the rectangle outline fully inked, the axes inked
+    inked = red | green | blue
+    for c in centres:
+        for ang in np.deg2rad(np.arange(0, 360, 5)):
+            x, y = int(np.rint(np.rint(c[0]) + 10 * np.cos(ang))), int(np.rint(np.rint(c[1]) + 10 * np.sin(ang)))
+            if 1 <= x < cols - 1 and 1 <= y < rows - 1:
+                assert inked[y - 1:y + 2, x - 1:x + 2].any(), (c, ang)
+    if rw < cols or rh < rows:  # (a whole-image ROI lies on the frame border)
+        assert blue[y0, x0:x1 + 1].all() and blue[y1, x0:x1 + 1].all() and blue[y0:y1 + 1, x0].all() and blue[y0:y1 + 1, x1].all()
+    for k, col in ((1, red), (2, green), (3, blue)):
+        for t in np.linspace(0, 1, 20):
+            q = px[0] + t * (px[k] - px[0])
+            x, y = int(np.rint(q[0])), int(np.rint(q[1]))
+            if 2 <= x < cols - 2 and 2 <= y < rows - 2:
+                assert inked[y - 2:y + 3, x - 2:x + 3].any(), (k, t)
