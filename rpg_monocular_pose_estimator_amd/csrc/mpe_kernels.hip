@@ -1189,7 +1189,7 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
   if (e != hipSuccess) return e;
   e = hipMemsetAsync(list_b, 0, sizeof(int), s);
   if (e != hipSuccess) return e;
-  if (blob_hint > 0 && blob_hint <= 6) {
+  if (blob_hint > 0 && blob_hint <= 8) {  // (the small tier is cheap to try: frames that overflow it go on to the large one)
     const int blocks = (n_frames + K1bSmall::FRAMES - 1) / K1bSmall::FRAMES;
     hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
                        list_a, n_frames, wins);
