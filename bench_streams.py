@@ -30,8 +30,9 @@ sys.path.insert(0, ROOT)
 def lockstep(args, mpe, seqs, mine, rank, world, local_rank):
     """All streams of this rank in lock step on one handle: every time step is one batched submission."""
     import torch
-    h = mpe.Handle(local_rank)
-    trackers = [mpe.Tracker(h, seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], mpe.demo_params()) for _ in mine]
+    hs = [mpe.Handle(local_rank) for _ in range(max(1, args.groups))]
+    trackers = [mpe.Tracker(hs[i % len(hs)], seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], mpe.demo_params())
+                for i in range(len(mine))]
     frames = [q["frames"] for q in seqs]
     mpe.tracker_run_sequences_batch(trackers, [f[:8] for f in frames], seqs[0]["times"][:8])  # warm-up
     for t in trackers:
@@ -57,7 +58,8 @@ def lockstep(args, mpe, seqs, mine, rank, world, local_rank):
                           "value": n_frames / dt, "unit": "frames/s", "n_gpus": world, "streams": args.streams,
                           "streams_per_gpu": len(mine), "frames_per_stream": args.frames, "higher_is_better": True,
                           "data": "synthetic", "dtype": "f64", "frames_in": "pageable host memory",
-                          "mode": "lock step: one device submission per time step for all streams of a GPU",
+                          "mode": "lock step: one device submission per time step and group of streams",
+                          "groups_per_gpu": len(hs),
                           "ms_per_time_step": dt / args.frames * 1e3,
                           "poses_found_frac": n_pose / max(1, n_frames), "bruteforce_frac": n_brute / max(1, n_frames),
                           "config": {"workload": "%s sequences (constant twist + jitter, 50 Hz), demo.launch parameters"
@@ -66,7 +68,8 @@ def lockstep(args, mpe, seqs, mine, rank, world, local_rank):
         dist.destroy_process_group()
     for t in trackers:
         t.close()
-    h.close()
+    for h in hs:
+        h.close()
 
 
 def main():
@@ -76,6 +79,9 @@ def main():
     ap.add_argument("--frames", type=int, default=400, help="frames per stream")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--no-cpu", action="store_true", help="(kept for compatibility; this script never runs CPU code)")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="--lockstep: spread the streams over this many handles; the groups are pipelined against each "
+                         "other (host work of one group beside the device work of another)")
     ap.add_argument("--lockstep", action="store_true",
                     help="all streams of a rank on ONE handle, driven in lock step: one device submission per time "
                          "step for all of them (mpe_tracker_run_sequences_batch) instead of one host thread per stream")

@@ -246,6 +246,13 @@ int mpe_track_step_batch(mpe_handle* h, const mpe_track_item* items, int n, int 
                          const mpe_params* p, const double K[9], const double* D, int nD,
                          const double* markers_xyz, int n_markers, mpe_detections* dets_out, uint32_t* corr_out,
                          mpe_result* out);
+/* The same in two halves, for callers that overlap the host work of one group of streams with the device work of
+ * another: _submit packs the ROIs and enqueues copy-in, kernels and copy-out on the handle's stream WITHOUT waiting;
+ * _collect waits and hands out the records of that submission (one outstanding submission per handle). */
+int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int n, int rows, int cols,
+                                size_t stride_bytes, const mpe_params* p, const double K[9], const double* D, int nD,
+                                const double* markers_xyz, int n_markers);
+int mpe_track_step_batch_collect(mpe_handle* h, mpe_detections* dets_out, uint32_t* corr_out, mpe_result* out);
 /* mpe_solve_bruteforce for N detection sets in one submission (the re-initialisations of a lock-step batch):
  * det_xy n x MPE_MAX_DETECTIONS x 2 (n_det[i] valid rows); hist (optional) n x MPE_MAX_DETECTIONS x
  * MPE_MAX_MARKERS, corr (optional) n x 2*MPE_MAX_MARKERS. */
@@ -286,7 +293,11 @@ int mpe_tracker_estimate_batch(mpe_tracker* const* trackers, int n, const uint8_
 
 /* The image-callback loops of N streams in lock step over recorded sequences: frames[i] = stream i's sequence
  * (frame f at frames[i] + f*frame_stride_bytes), times[f] the common time stamps; out / info (optional):
- * n x n_frames records / n x n_frames x 8 ints, stream-major.  Returns the number of pose updates or <0. */
+ * n x n_frames records / n x n_frames x 8 ints, stream-major.  Returns the number of pose updates or <0.
+ * The trackers may live on SEVERAL handles (same device or not): each handle's trackers form one lock-step group
+ * (same camera / markers / parameters within a group), and the groups are pipelined against each other — while
+ * the device works on step k of one group the host collects, advances and packs another — which hides the host
+ * work of a time step behind the device latency.  Results do not depend on the grouping. */
 int mpe_tracker_run_sequences_batch(mpe_tracker* const* trackers, int n, const uint8_t* const* frames, int n_frames,
                                     int rows, int cols, size_t stride_bytes, size_t frame_stride_bytes,
                                     const double* times, mpe_result* out, int* info);

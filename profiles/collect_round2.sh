@@ -12,6 +12,8 @@ python $R/bench.py --no-cpu --no-host-leg --steps 10 --pipeline-mode 3 2>/dev/nu
 python $R/bench_streams.py --streams 1 --frames 400 2>/dev/null | tail -1 > $O/streams1.json
 python $R/bench_streams.py --streams 8 --frames 400 2>/dev/null | tail -1 > $O/streams8.json
 for n in 8 64 128 256; do python $R/bench_streams.py --streams $n --frames 300 --lockstep 2>/dev/null | tail -1 > $O/lockstep$n.json; done
+python $R/bench_streams.py --streams 64 --frames 300 --lockstep --groups 2 2>/dev/null | tail -1 > $O/lockstep64g2.json
+python $R/bench_streams.py --streams 256 --frames 300 --lockstep --groups 4 2>/dev/null | tail -1 > $O/lockstep256g4.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python $R/bench.py --no-cpu --no-host-leg > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_seq -o s -- python $R/bench.py --no-cpu --no-host-leg --pipeline 1 --frames 16384 --steps 20 --warmup 3 > $O/stats_seq.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -o s -- python $R/bench.py --no-cpu --no-host-leg --config C3 --pipeline 1 --frames 16384 --steps 3 --warmup 1 > $O/stats_c3.log 2>&1

@@ -44,7 +44,7 @@ def main():
     json.dump(last_json(F + "bench.json"), open(P + "bench.json", "w"), indent=1)
     for c in ("C1", "C3", "C4", "mode3"):
         json.dump(last_json(F + "bench_%s.json" % c), open(P + "bench_%s.json" % c, "w"), indent=1)
-    for n in ("streams1", "streams8", "lockstep8", "lockstep64", "lockstep128", "lockstep256"):
+    for n in ("streams1", "streams8", "lockstep8", "lockstep64", "lockstep128", "lockstep256", "lockstep64g2", "lockstep256g4"):
         json.dump(last_json(F + n + ".json"), open(P + "bench_%s.json" % n, "w"), indent=1)
     keep_mpe(F + "stats/s_kernel_stats.csv", P + "bench_kernel_stats.csv")
     keep_mpe(F + "stats_seq/s_kernel_stats.csv", P + "bench_sequential_kernel_stats.csv")

@@ -49,6 +49,8 @@ struct mpe_handle {
   DevBuf frames, flags, dets, hist, results, corr, mtab, work, scratch, track, mid;
   void* mailbox = nullptr;  // pinned host memory for the single-frame tracking step (ROI in, record out)
   size_t mailbox_cap = 0;
+  int pending_track_n = 0;            // mpe_track_step_batch_submit without its _collect yet: streams in flight
+  const uint8_t* pending_track_rec = nullptr;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
   int vote_splits = 0;         // 0 = auto
   int vote_arith = 1;          // 1 = fast voting arithmetic (default), 0 = strict: IEEE operators, the validation
@@ -1226,11 +1228,11 @@ void mpe_free_pinned(void* p) {
 // of the stand-alone cv::Mat clone of led_detector.cpp:44 — then ONE k1a_scan + ONE blob extraction over the N
 // slots and ONE validate / refine over the N detection sets (nearest-neighbour correspondences from the stream's
 // predicted pixels) run, and one copy brings the N records back.
-int mpe_track_step_batch(mpe_handle* h, const mpe_track_item* items, int n, int rows, int cols, size_t stride_bytes,
-                         const mpe_params* p, const double K[9], const double* D, int nD, const double* markers_xyz,
-                         int n_markers, mpe_detections* dets_out, uint32_t* corr_out, mpe_result* out) {
-  if (!h || !items || n < 0 || !p || !K || !markers_xyz || !dets_out || !corr_out || !out)
-    return fail(h, MPE_ERR_ARG, "bad argument");
+int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int n, int rows, int cols,
+                                size_t stride_bytes, const mpe_params* p, const double K[9], const double* D, int nD,
+                                const double* markers_xyz, int n_markers) {
+  if (!h || !items || n < 0 || !p || !K || !markers_xyz) return fail(h, MPE_ERR_ARG, "bad argument");
+  if (h->pending_track_n) return fail(h, MPE_ERR_ARG, "a submitted batch has not been collected yet");
   if (n == 0) return MPE_OK;
   int rmax = 0, wmax = 0;
   for (int i = 0; i < n; ++i) {
@@ -1310,6 +1312,19 @@ int mpe_track_step_batch(mpe_handle* h, const mpe_track_item* items, int n, int 
   HIP_TRY(h, launch_k3_tail(d_dets, static_cast<uint32_t*>(h->hist.p), n, sp, d_res, d_corr, nullptr, d_pred,
                             p->nearest_neighbour_pixel_tolerance, h->mid.p, h->stream));
   HIP_TRY(h, hipMemcpyAsync(host_rec, d_dets, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+  h->pending_track_n = n;
+  h->pending_track_rec = host_rec;
+  return MPE_OK;
+}
+
+int mpe_track_step_batch_collect(mpe_handle* h, mpe_detections* dets_out, uint32_t* corr_out, mpe_result* out) {
+  if (!h || !dets_out || !corr_out || !out) return fail(h, MPE_ERR_ARG, "bad argument");
+  const int n = h->pending_track_n;
+  if (n == 0) return MPE_OK;
+  const uint8_t* host_rec = h->pending_track_rec;
+  h->pending_track_n = 0;
+  h->pending_track_rec = nullptr;
+  HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   const mpe_detections* hd = reinterpret_cast<const mpe_detections*>(host_rec);
   const uint32_t* hc = reinterpret_cast<const uint32_t*>(hd + n);
@@ -1318,6 +1333,15 @@ int mpe_track_step_batch(mpe_handle* h, const mpe_track_item* items, int n, int 
   std::memcpy(corr_out, hc, (size_t)n * 2 * MPE_MAX_MARKERS * sizeof(uint32_t));
   std::memcpy(out, hr, (size_t)n * sizeof(mpe_result));
   return MPE_OK;
+}
+
+int mpe_track_step_batch(mpe_handle* h, const mpe_track_item* items, int n, int rows, int cols, size_t stride_bytes,
+                         const mpe_params* p, const double K[9], const double* D, int nD, const double* markers_xyz,
+                         int n_markers, mpe_detections* dets_out, uint32_t* corr_out, mpe_result* out) {
+  if (!dets_out || !corr_out || !out) return fail(h, MPE_ERR_ARG, "bad argument");
+  const int rc = mpe_track_step_batch_submit(h, items, n, rows, cols, stride_bytes, p, K, D, nD, markers_xyz, n_markers);
+  if (rc != MPE_OK) return rc;
+  return mpe_track_step_batch_collect(h, dets_out, corr_out, out);
 }
 
 // setImagePoints + initialise + optimiseAndUpdatePose for N detection sets in one submission (the brute-force

@@ -596,6 +596,12 @@ int mpe_tracker_estimate(mpe_tracker* t, const uint8_t* img, int rows, int cols,
 // The state machine of mpe_tracker_estimate per stream, with the device steps of all streams that are at the same
 // point batched into one submission: DETECT = findLeds in the stream's ROI (+ nearest-neighbour correspondences,
 // validation and refinement when tracking), BRUTE = initialise() + optimisePose on the stream's detections.
+// A frame is processed in three parts so that a caller can overlap the host work of one group of streams with the
+// device work of another: begin (per-stream prediction / ROI), the first DETECT submission (asynchronous), and
+// finish (collect it, then whatever else the streams need — second size class, whole-image retries,
+// re-initialisations — synchronously, until every stream is done).
+}  // extern "C"
+
 namespace {
 enum BatchOp { OP_DETECT, OP_BRUTE, OP_DONE };
 struct BatchLane {
@@ -609,226 +615,342 @@ bool same_setup(const mpe_tracker* a, const mpe_tracker* b) {
   return a->h == b->h && a->markers == b->markers && a->D == b->D && !std::memcmp(a->K, b->K, sizeof(a->K)) &&
          !std::memcmp(&a->p, &b->p, sizeof(mpe_params));
 }
+
+struct BatchCtx {
+  mpe_tracker* const* ts = nullptr;
+  int n = 0;
+  const uint8_t* const* imgs = nullptr;
+  int rows = 0, cols = 0;
+  size_t stride = 0;
+  mpe_handle* h = nullptr;
+  int nm = 0, nD = 0;
+  const double* Dp = nullptr;
+  std::vector<BatchLane> L;
+  std::vector<int> pend;  // lanes of the submitted, not yet collected DETECT batch
+  std::vector<mpe_track_item> items;
+  std::vector<mpe_detections> dets;
+  std::vector<uint32_t> corr;
+  std::vector<mpe_result> res;
+
+  int validate(mpe_tracker* const* ts_, int n_) {
+    ts = ts_;
+    n = n_;
+    for (int i = 0; i < n; ++i) {
+      if (!ts[i]) return MPE_ERR_ARG;
+      if (!same_setup(ts[0], ts[i])) return MPE_ERR_ARG;  // one handle, camera model, marker set, parameter set
+      for (int j = 0; j < i; ++j)
+        if (ts[j] == ts[i]) return MPE_ERR_ARG;
+    }
+    h = ts[0]->h;
+    nm = n_markers(ts[0]);
+    Dp = ts[0]->D.empty() ? nullptr : ts[0]->D.data();
+    nD = (int)ts[0]->D.size();
+    L.assign((size_t)n, BatchLane());
+    return MPE_OK;
+  }
+
+  // begin of frame: pose_estimator.cpp:62-72 / 98-103 (predictWithROI)
+  void begin(const uint8_t* const* imgs_, int rows_, int cols_, size_t stride_, const double* times) {
+    imgs = imgs_;
+    rows = rows_;
+    cols = cols_;
+    stride = stride_;
+    for (int i = 0; i < n; ++i) {
+      mpe_tracker* t = ts[i];
+      L[(size_t)i] = BatchLane();
+      t->pose_updated = false;
+      t->used_bruteforce = false;
+      t->det.clear();
+      t->fused_valid = false;
+      t->t_predicted = times[i];
+      if (t->it_since_initialized < 1) {
+        t->roi[0] = t->roi[1] = 0;
+        t->roi[2] = cols;
+        t->roi[3] = rows;
+        L[(size_t)i].tracking = false;
+      } else {
+        if (t->it_since_initialized >= 2)
+          t->predicted = predict_pose(t->current, t->previous, t->t_current, t->t_previous, t->t_predicted);
+        for (int k = 0; k < nm; ++k)
+          project(t, t->predicted, &t->markers[3 * k], t->predicted_px[2 * k], t->predicted_px[2 * k + 1]);
+        determine_roi(t, rows, cols);
+        L[(size_t)i].tracking = true;
+      }
+      L[(size_t)i].op = OP_DETECT;
+    }
+  }
+
+  bool is_big(int i) const { return (long long)ts[i]->roi[2] * ts[i]->roi[3] * 4 > (long long)rows * cols; }
+
+  // submit the DETECT lanes of one size class (two classes, so that a few whole-image retries do not inflate every
+  // ROI slot of the batch); returns the number of lanes submitted or < 0
+  int submit_detect(int big) {
+    items.clear();
+    pend.clear();
+    for (int i = 0; i < n; ++i) {
+      if (L[(size_t)i].op != OP_DETECT || (int)is_big(i) != big) continue;
+      const mpe_tracker* t = ts[i];
+      mpe_track_item it;
+      it.img = imgs[i];
+      it.roi_x = t->roi[0];
+      it.roi_y = t->roi[1];
+      it.roi_w = t->roi[2];
+      it.roi_h = t->roi[3];
+      it.predicted_px = L[(size_t)i].tracking ? t->predicted_px.data() : nullptr;
+      items.push_back(it);
+      pend.push_back(i);
+    }
+    if (items.empty()) return 0;
+    const int rc = mpe_track_step_batch_submit(h, items.data(), (int)items.size(), rows, cols, stride, &ts[0]->p, ts[0]->K,
+                                               Dp, nD, ts[0]->markers.data(), nm);
+    if (rc != MPE_OK) {
+      pend.clear();
+      return rc;
+    }
+    return (int)items.size();
+  }
+
+  // collect the submitted DETECT batch and advance its lanes
+  int collect_detect() {
+    if (pend.empty()) return MPE_OK;
+    const int m = (int)pend.size();
+    dets.resize((size_t)m);
+    corr.resize((size_t)m * 2 * MPE_MAX_MARKERS);
+    res.resize((size_t)m);
+    const int rc = mpe_track_step_batch_collect(h, dets.data(), corr.data(), res.data());
+    if (rc != MPE_OK) return rc;
+    for (int k = 0; k < m; ++k) {
+      const int i = pend[(size_t)k];
+      mpe_tracker* t = ts[i];
+      BatchLane& ln = L[(size_t)i];
+      const mpe_detections& d = dets[(size_t)k];
+      if (d.status != 0) {  // device capacity exceeded on this stream's frame
+        ln.error = d.status;
+        ln.op = OP_DONE;
+        continue;
+      }
+      t->det_dist.assign(d.dist_xy, d.dist_xy + 2 * d.n);
+      if (d.n > 0) t->det.assign(d.undist_xy, d.undist_xy + 2 * d.n);  // kept when nothing was found
+      if (!ln.tracking) {  // pose_estimator.cpp:80-91
+        ln.op = (t->det.size() / 2 >= 4) ? OP_BRUTE : OP_DONE;
+        continue;
+      }
+      ln.num_loops++;  // pose_estimator.cpp:105-144
+      if (t->det.size() / 2 >= 4) {
+        // (>= 4 detections can only come from this very detection: the device already ran findCorrespondences +
+        //  checkCorrespondences + optimisePose on them)
+        const mpe_result& r = res[(size_t)k];
+        if (r.status < 0) {
+          ln.error = r.status;
+          ln.op = OP_DONE;
+          continue;
+        }
+        t->n_corr = r.n_corr;
+        t->corr.assign(corr.begin() + (size_t)k * 2 * MPE_MAX_MARKERS,
+                       corr.begin() + (size_t)k * 2 * MPE_MAX_MARKERS + 2 * r.n_corr);
+        if (r.status == MPE_FRAME_POSE) {
+          take_result(t, r);
+          ln.op = OP_DONE;
+        } else {
+          ln.op = OP_BRUTE;  // reinitialise if the correspondences were not valid
+        }
+      } else if (ln.num_loops < 2) {  // too few LEDs in the ROI: search the whole image once
+        t->roi[0] = t->roi[1] = 0;
+        t->roi[2] = cols;
+        t->roi[3] = rows;
+        ln.op = OP_DETECT;
+      } else {
+        ln.op = OP_DONE;
+      }
+    }
+    pend.clear();
+    return MPE_OK;
+  }
+
+  // brute-force (re-)initialisations requested so far, one submission
+  int brute() {
+    std::vector<int> idx;
+    for (int i = 0; i < n; ++i)
+      if (L[(size_t)i].op == OP_BRUTE) idx.push_back(i);
+    if (idx.empty()) return MPE_OK;
+    const int m = (int)idx.size();
+    std::vector<double> det_xy((size_t)m * 2 * MPE_MAX_DETECTIONS, 0.0);
+    std::vector<int> nd((size_t)m);
+    for (int k = 0; k < m; ++k) {
+      const mpe_tracker* t = ts[idx[(size_t)k]];
+      nd[(size_t)k] = (int)t->det.size() / 2;
+      std::memcpy(&det_xy[(size_t)k * 2 * MPE_MAX_DETECTIONS], t->det.data(), t->det.size() * sizeof(double));
+    }
+    res.resize((size_t)m);
+    std::vector<uint32_t> hist((size_t)m * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS), bc((size_t)m * 2 * MPE_MAX_MARKERS);
+    const int rc = mpe_solve_bruteforce_batch(h, det_xy.data(), nd.data(), m, ts[0]->markers.data(), nm, ts[0]->K, &ts[0]->p,
+                                              res.data(), hist.data(), bc.data());
+    if (rc != MPE_OK) return rc;
+    for (int k = 0; k < m; ++k) {
+      const int i = idx[(size_t)k];
+      mpe_tracker* t = ts[i];
+      const mpe_result& r = res[(size_t)k];
+      t->used_bruteforce = true;
+      L[(size_t)i].op = OP_DONE;
+      if (r.status < 0) {
+        L[(size_t)i].error = r.status;
+        continue;
+      }
+      bool any_vote = false;  // initialise() keeps correspondences_ when the histogram is empty (:704-719)
+      for (size_t q = 0; q < (size_t)MPE_MAX_DETECTIONS * MPE_MAX_MARKERS; ++q)
+        any_vote |= hist[(size_t)k * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS + q] != 0;
+      if (any_vote) {
+        t->n_corr = r.n_corr;
+        t->corr.assign(bc.begin() + (size_t)k * 2 * MPE_MAX_MARKERS, bc.begin() + (size_t)k * 2 * MPE_MAX_MARKERS + 2 * r.n_corr);
+      }
+      if (r.status == MPE_FRAME_POSE) take_result(t, r);
+    }
+    return MPE_OK;
+  }
+
+  // first asynchronous submission of a frame: the size class that has lanes (the small one first)
+  int submit_first() {
+    const int rc = submit_detect(0);
+    if (rc != 0) return rc < 0 ? rc : MPE_OK;
+    const int rc2 = submit_detect(1);
+    return rc2 < 0 ? rc2 : MPE_OK;
+  }
+
+  // everything else of the frame, synchronously, until every stream is done
+  int finish() {
+    int rc = collect_detect();
+    if (rc != MPE_OK) return rc;
+    for (;;) {
+      bool any_detect = false, any_brute = false;
+      for (int i = 0; i < n; ++i) {
+        any_detect |= L[(size_t)i].op == OP_DETECT;
+        any_brute |= L[(size_t)i].op == OP_BRUTE;
+      }
+      if (!any_detect && !any_brute) break;
+      if (any_detect)
+        for (int big = 0; big < 2; ++big) {
+          const int m = submit_detect(big);
+          if (m < 0) return m;
+          if (m > 0 && (rc = collect_detect()) != MPE_OK) return rc;
+        }
+      if ((rc = brute()) != MPE_OK) return rc;
+    }
+    return MPE_OK;
+  }
+
+  int outputs(mpe_result* out, size_t out_stride, int* info, size_t info_stride, int* updated) const {
+    int n_updated = 0;
+    for (int i = 0; i < n; ++i) {
+      const mpe_tracker* t = ts[i];
+      if (out) {
+        mpe_result& o = out[(size_t)i * out_stride];
+        std::memcpy(o.T, t->predicted.a, sizeof(o.T));
+        std::memcpy(o.cov, t->cov, sizeof(o.cov));
+        o.status = L[(size_t)i].error ? L[(size_t)i].error : (t->pose_updated ? MPE_FRAME_POSE : MPE_FRAME_NO_POSE);
+        o.n_det = (int)t->det.size() / 2;
+        o.n_corr = t->n_corr;
+        o.gn_iterations = t->gn_iterations;
+      }
+      if (info) {
+        int* q = info + (size_t)i * info_stride;
+        for (int k = 0; k < 4; ++k) q[k] = t->roi[k];
+        q[4] = (int)t->it_since_initialized;
+        q[5] = (int)t->det.size() / 2;
+        q[6] = t->n_corr;
+        q[7] = t->used_bruteforce ? 1 : 0;
+      }
+      if (updated) updated[i] = t->pose_updated ? 1 : 0;
+      n_updated += t->pose_updated ? 1 : 0;
+    }
+    return n_updated;
+  }
+};
 }  // namespace
+
+extern "C" {
 
 int mpe_tracker_estimate_batch(mpe_tracker* const* ts, int n, const uint8_t* const* imgs, int rows, int cols,
                                size_t stride_bytes, const double* times, mpe_result* out, int* info, int* updated) {
   if (!ts || n < 0 || !imgs || !times) return MPE_ERR_ARG;
   if (n == 0) return 0;
-  for (int i = 0; i < n; ++i) {
-    if (!ts[i] || !imgs[i]) return MPE_ERR_ARG;
-    if (!same_setup(ts[0], ts[i])) return MPE_ERR_ARG;  // one handle, one camera model, one marker set, one parameter set
-    for (int j = 0; j < i; ++j)
-      if (ts[j] == ts[i]) return MPE_ERR_ARG;
-  }
-  mpe_handle* h = ts[0]->h;
-  const int nm = n_markers(ts[0]);
-  const double* Dp = ts[0]->D.empty() ? nullptr : ts[0]->D.data();
-  const int nD = (int)ts[0]->D.size();
-  std::vector<BatchLane> L((size_t)n);
-  // ---- begin of frame: pose_estimator.cpp:62-72 / 98-103 (predictWithROI)
-  for (int i = 0; i < n; ++i) {
-    mpe_tracker* t = ts[i];
-    t->pose_updated = false;
-    t->used_bruteforce = false;
-    t->det.clear();
-    t->fused_valid = false;
-    t->t_predicted = times[i];
-    if (t->it_since_initialized < 1) {
-      t->roi[0] = t->roi[1] = 0;
-      t->roi[2] = cols;
-      t->roi[3] = rows;
-      L[i].tracking = false;
-    } else {
-      if (t->it_since_initialized >= 2)
-        t->predicted = predict_pose(t->current, t->previous, t->t_current, t->t_previous, t->t_predicted);
-      for (int k = 0; k < nm; ++k)
-        project(t, t->predicted, &t->markers[3 * k], t->predicted_px[2 * k], t->predicted_px[2 * k + 1]);
-      determine_roi(t, rows, cols);
-      L[i].tracking = true;
-    }
-    L[i].op = OP_DETECT;
-  }
-  std::vector<mpe_track_item> items;
-  std::vector<int> idx;
-  std::vector<mpe_detections> dets;
-  std::vector<uint32_t> corr;
-  std::vector<mpe_result> res;
-  for (;;) {
-    bool any_detect = false, any_brute = false;
-    for (int i = 0; i < n; ++i) {
-      any_detect |= L[i].op == OP_DETECT;
-      any_brute |= L[i].op == OP_BRUTE;
-    }
-    if (!any_detect && !any_brute) break;
-    if (any_detect) {
-      // two size classes, so that a few whole-image retries do not inflate every ROI slot of the batch
-      for (int big = 0; big < 2; ++big) {
-        items.clear();
-        idx.clear();
-        for (int i = 0; i < n; ++i) {
-          if (L[i].op != OP_DETECT) continue;
-          const mpe_tracker* t = ts[i];
-          const bool is_big = (long long)t->roi[2] * t->roi[3] * 4 > (long long)rows * cols;
-          if ((int)is_big != big) continue;
-          mpe_track_item it;
-          it.img = imgs[i];
-          it.roi_x = t->roi[0];
-          it.roi_y = t->roi[1];
-          it.roi_w = t->roi[2];
-          it.roi_h = t->roi[3];
-          it.predicted_px = L[i].tracking ? t->predicted_px.data() : nullptr;
-          items.push_back(it);
-          idx.push_back(i);
-        }
-        if (items.empty()) continue;
-        const int m = (int)items.size();
-        dets.resize((size_t)m);
-        corr.resize((size_t)m * 2 * MPE_MAX_MARKERS);
-        res.resize((size_t)m);
-        const int rc = mpe_track_step_batch(h, items.data(), m, rows, cols, stride_bytes, &ts[0]->p, ts[0]->K, Dp, nD,
-                                            ts[0]->markers.data(), nm, dets.data(), corr.data(), res.data());
-        if (rc != MPE_OK) return rc;
-        for (int k = 0; k < m; ++k) {
-          const int i = idx[(size_t)k];
-          mpe_tracker* t = ts[i];
-          const mpe_detections& d = dets[(size_t)k];
-          if (d.status != 0) {  // device capacity exceeded on this stream's frame
-            L[i].error = d.status;
-            L[i].op = OP_DONE;
-            continue;
-          }
-          t->det_dist.assign(d.dist_xy, d.dist_xy + 2 * d.n);
-          if (d.n > 0) t->det.assign(d.undist_xy, d.undist_xy + 2 * d.n);  // kept when nothing was found
-          if (!L[i].tracking) {  // pose_estimator.cpp:80-91
-            L[i].op = (t->det.size() / 2 >= 4) ? OP_BRUTE : OP_DONE;
-            continue;
-          }
-          L[i].num_loops++;  // pose_estimator.cpp:105-144
-          if (t->det.size() / 2 >= 4) {
-            if (d.n >= 4) {  // the device ran findCorrespondences + checkCorrespondences + optimisePose on them
-              const mpe_result& r = res[(size_t)k];
-              if (r.status < 0) {
-                L[i].error = r.status;
-                L[i].op = OP_DONE;
-                continue;
-              }
-              t->n_corr = r.n_corr;
-              t->corr.assign(corr.begin() + (size_t)k * 2 * MPE_MAX_MARKERS,
-                             corr.begin() + (size_t)k * 2 * MPE_MAX_MARKERS + 2 * r.n_corr);
-              if (r.status == MPE_FRAME_POSE) {
-                take_result(t, r);
-                L[i].op = OP_DONE;
-              } else {
-                L[i].op = OP_BRUTE;  // reinitialise if the correspondences were not valid
-              }
-            } else {
-              // stale detections of an earlier call with a fresh empty one (pixel_positions is not cleared,
-              // led_detector.cpp:91-111): the single-stream path handles this corner on the host
-              const int rc1 = track(t);
-              if (rc1 != MPE_OK) {
-                if (rc1 > MPE_FRAME_TOO_MANY_DETECTIONS) return rc1;
-                L[i].error = rc1;
-              }
-              L[i].op = OP_DONE;
-            }
-          } else if (L[i].num_loops < 2) {  // too few LEDs in the ROI: search the whole image once
-            t->roi[0] = t->roi[1] = 0;
-            t->roi[2] = cols;
-            t->roi[3] = rows;
-            L[i].op = OP_DETECT;
-          } else {
-            L[i].op = OP_DONE;
-          }
-        }
-      }
-    }
-    // brute-force (re-)initialisations requested so far, one submission
-    idx.clear();
-    for (int i = 0; i < n; ++i)
-      if (L[i].op == OP_BRUTE) idx.push_back(i);
-    if (!idx.empty()) {
-      const int m = (int)idx.size();
-      std::vector<double> det_xy((size_t)m * 2 * MPE_MAX_DETECTIONS, 0.0);
-      std::vector<int> nd((size_t)m);
-      for (int k = 0; k < m; ++k) {
-        const mpe_tracker* t = ts[idx[(size_t)k]];
-        nd[(size_t)k] = (int)t->det.size() / 2;
-        std::memcpy(&det_xy[(size_t)k * 2 * MPE_MAX_DETECTIONS], t->det.data(), t->det.size() * sizeof(double));
-      }
-      res.resize((size_t)m);
-      std::vector<uint32_t> hist((size_t)m * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS), bc((size_t)m * 2 * MPE_MAX_MARKERS);
-      const int rc = mpe_solve_bruteforce_batch(h, det_xy.data(), nd.data(), m, ts[0]->markers.data(), nm, ts[0]->K,
-                                                &ts[0]->p, res.data(), hist.data(), bc.data());
-      if (rc != MPE_OK) return rc;
-      for (int k = 0; k < m; ++k) {
-        const int i = idx[(size_t)k];
-        mpe_tracker* t = ts[i];
-        const mpe_result& r = res[(size_t)k];
-        t->used_bruteforce = true;
-        L[i].op = OP_DONE;
-        if (r.status < 0) {
-          L[i].error = r.status;
-          continue;
-        }
-        bool any_vote = false;  // initialise() keeps correspondences_ when the histogram is empty (:704-719)
-        for (size_t q = 0; q < (size_t)MPE_MAX_DETECTIONS * MPE_MAX_MARKERS; ++q)
-          any_vote |= hist[(size_t)k * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS + q] != 0;
-        if (any_vote) {
-          t->n_corr = r.n_corr;
-          t->corr.assign(bc.begin() + (size_t)k * 2 * MPE_MAX_MARKERS, bc.begin() + (size_t)k * 2 * MPE_MAX_MARKERS + 2 * r.n_corr);
-        }
-        if (r.status == MPE_FRAME_POSE) take_result(t, r);
-      }
-    }
-  }
-  int n_updated = 0;
-  for (int i = 0; i < n; ++i) {
-    mpe_tracker* t = ts[i];
-    if (out) {
-      mpe_result& o = out[i];
-      std::memcpy(o.T, t->predicted.a, sizeof(o.T));
-      std::memcpy(o.cov, t->cov, sizeof(o.cov));
-      o.status = L[i].error ? L[i].error : (t->pose_updated ? MPE_FRAME_POSE : MPE_FRAME_NO_POSE);
-      o.n_det = (int)t->det.size() / 2;
-      o.n_corr = t->n_corr;
-      o.gn_iterations = t->gn_iterations;
-    }
-    if (info) {
-      for (int k = 0; k < 4; ++k) info[8 * i + k] = t->roi[k];
-      info[8 * i + 4] = (int)t->it_since_initialized;
-      info[8 * i + 5] = (int)t->det.size() / 2;
-      info[8 * i + 6] = t->n_corr;
-      info[8 * i + 7] = t->used_bruteforce ? 1 : 0;
-    }
-    if (updated) updated[i] = t->pose_updated ? 1 : 0;
-    n_updated += t->pose_updated ? 1 : 0;
-  }
-  return n_updated;
+  for (int i = 0; i < n; ++i)
+    if (!imgs[i]) return MPE_ERR_ARG;
+  BatchCtx c;
+  int rc = c.validate(ts, n);
+  if (rc != MPE_OK) return rc;
+  c.begin(imgs, rows, cols, stride_bytes, times);
+  if ((rc = c.submit_first()) != MPE_OK) return rc;
+  if ((rc = c.finish()) != MPE_OK) return rc;
+  return c.outputs(out, 1, info, 8, updated);
 }
 
+// The lock-step loops of N streams over recorded sequences.  Trackers that live on DIFFERENT handles form groups
+// (one group per handle, each with the same camera / marker / parameter set inside the group); the groups are
+// pipelined against each other: while the device works on step k of one group, the host collects, advances and
+// packs another — the host work of a time step (~3 us per stream) hides behind the device latency (~0.2 ms).
 int mpe_tracker_run_sequences_batch(mpe_tracker* const* ts, int n, const uint8_t* const* frames, int n_frames, int rows,
                                     int cols, size_t stride_bytes, size_t frame_stride_bytes, const double* times,
                                     mpe_result* out, int* info) {
   if (!ts || n < 0 || !frames || !times || n_frames < 0) return MPE_ERR_ARG;
-  std::vector<const uint8_t*> imgs((size_t)n);
-  std::vector<double> tk((size_t)n);
+  if (n == 0 || n_frames == 0) return 0;
+  for (int i = 0; i < n; ++i)
+    if (!ts[i] || !frames[i]) return MPE_ERR_ARG;
+  // groups by handle, in order of first appearance
+  std::vector<mpe_handle*> hs;
+  std::vector<std::vector<int> > members;
+  for (int i = 0; i < n; ++i) {
+    size_t g = 0;
+    while (g < hs.size() && hs[g] != ts[i]->h) ++g;
+    if (g == hs.size()) {
+      hs.push_back(ts[i]->h);
+      members.push_back(std::vector<int>());
+    }
+    members[g].push_back(i);
+  }
+  const size_t G = hs.size();
+  std::vector<BatchCtx> ctx(G);
+  std::vector<std::vector<mpe_tracker*> > gts(G);
+  std::vector<std::vector<const uint8_t*> > gimgs(G);
+  std::vector<std::vector<double> > gtimes(G);
+  for (size_t g = 0; g < G; ++g) {
+    for (int i : members[g]) gts[g].push_back(ts[i]);
+    gimgs[g].resize(members[g].size());
+    gtimes[g].resize(members[g].size());
+    const int rc = ctx[g].validate(gts[g].data(), (int)gts[g].size());
+    if (rc != MPE_OK) return rc;
+  }
   std::vector<mpe_result> step_out((size_t)n);
   std::vector<int> step_info((size_t)n * 8);
   long long updated = 0;
-  for (int f = 0; f < n_frames; ++f) {
-    for (int i = 0; i < n; ++i) {
-      imgs[(size_t)i] = frames[i] + (size_t)f * frame_stride_bytes;
-      tk[(size_t)i] = times[f];
+  auto finish_group = [&](size_t g, int f) -> int {  // complete step f of group g and store its records
+    int rc = ctx[g].finish();
+    if (rc != MPE_OK) return rc;
+    const int m = (int)members[g].size();
+    updated += ctx[g].outputs(step_out.data(), 1, step_info.data(), 8, nullptr);
+    for (int k = 0; k < m; ++k) {
+      const int i = members[g][(size_t)k];
+      if (out) out[(size_t)i * n_frames + f] = step_out[(size_t)k];
+      if (info) std::memcpy(info + ((size_t)i * n_frames + f) * 8, &step_info[(size_t)k * 8], 8 * sizeof(int));
     }
-    const int rc = mpe_tracker_estimate_batch(ts, n, imgs.data(), rows, cols, stride_bytes, tk.data(), step_out.data(),
-                                              step_info.data(), nullptr);
-    if (rc < 0) return rc;
-    updated += rc;
-    for (int i = 0; i < n; ++i) {
-      if (out) out[(size_t)i * n_frames + f] = step_out[(size_t)i];
-      if (info) std::memcpy(info + ((size_t)i * n_frames + f) * 8, &step_info[(size_t)i * 8], 8 * sizeof(int));
+    return MPE_OK;
+  };
+  for (int f = 0; f < n_frames; ++f)
+    for (size_t g = 0; g < G; ++g) {
+      if (f > 0) {
+        const int rc = finish_group(g, f - 1);
+        if (rc != MPE_OK) return rc;
+      }
+      for (size_t k = 0; k < members[g].size(); ++k) {
+        gimgs[g][k] = frames[members[g][k]] + (size_t)f * frame_stride_bytes;
+        gtimes[g][k] = times[f];
+      }
+      ctx[g].begin(gimgs[g].data(), rows, cols, stride_bytes, gtimes[g].data());
+      const int rc = ctx[g].submit_first();
+      if (rc != MPE_OK) return rc;
     }
+  for (size_t g = 0; g < G; ++g) {
+    const int rc = finish_group(g, n_frames - 1);
+    if (rc != MPE_OK) return rc;
   }
   return (int)std::min<long long>(updated, 0x7fffffff);
 }

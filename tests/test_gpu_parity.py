@@ -1096,6 +1096,15 @@ def test_lockstep_tracker_batch_matches_oracle(orc):
         for s in range(n_streams):
             r1 = solo[s].estimate(seqs[s]["frames"][k], seqs[s]["times"][k])
             assert r1["updated"] == bool(upd[s]) and np.array_equal(r1["T"], r2["T"][s].reshape(4, 4)), (s, k)
+    # the same streams spread over three handles (pipelined groups): identical records
+    hg = [mpe.Handle(0) for _ in range(3)]
+    t3 = [mpe.Tracker(hg[s % 3], seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], P) for s in range(n_streams)]
+    rec3, info3 = mpe.tracker_run_sequences_batch(t3, [q["frames"] for q in seqs], seqs[0]["times"])
+    assert rec3.tobytes() == rec.tobytes() and np.array_equal(info3, info)
+    for t in t3:
+        t.close()
+    for hh in hg:
+        hh.close()
     # streams with different set-ups cannot share a lock-step batch
     other = mpe.Tracker(h, seqs[0]["markers"][:4], seqs[0]["K"], seqs[0]["D"], P)
     with pytest.raises(mpe.MpeError):
