@@ -1076,6 +1076,7 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
     return fail(h, MPE_ERR_ARG, "bad argument");
   if (roi_x < 0 || roi_y < 0 || roi_w <= 0 || roi_h <= 0 || roi_x + roi_w > cols || roi_y + roi_h > rows)
     return fail(h, MPE_ERR_ARG, "ROI outside the image");
+  if (h->pending_track_n) return fail(h, MPE_ERR_ARG, "a submitted batch has not been collected yet (shared staging memory)");
   HIP_TRY(h, hipSetDevice(h->device));
   FrameGeom g;
   if (make_geom(h, roi_h, roi_w, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
