@@ -113,7 +113,9 @@ def main():
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive host-streamed leg")
     ap.add_argument("--k1a-lds", type=int, default=-1, help="tuning: dummy LDS per scan block (-1 = automatic)")
     ap.add_argument("--pipeline-mode", type=int, default=-1,
-                    help="-1 automatic (fused single-stream schedule for <= 5 markers), 0 two-stream pipeline, 3 fused")
+                    help="-1 automatic, 0 two-stream pipeline, 3 fused, 4 fused + side-stream tail, 6 = 4 + split scan")
+    ap.add_argument("--side-scan-blocks", type=int, default=2, help="mode 6: resident blocks per CU of the side scan")
+    ap.add_argument("--scan-split-pct", type=int, default=20, help="mode 6: share of a sub-batch scanned on the side stream")
     ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
     ap.add_argument("--vote-arith", type=int, default=1, help="1 fast voting arithmetic (default), 0 strict (IEEE)")
     ap.add_argument("--plumbing-only", action="store_true",
@@ -185,6 +187,8 @@ def main():
     h.set_option("pipeline", args.pipeline)
     h.set_option("pipeline_mode", args.pipeline_mode)
     h.set_option("vote_arith", args.vote_arith)
+    h.set_option("scan_split_pct", args.scan_split_pct)
+    h.set_option("side_scan_blocks", args.side_scan_blocks)
     if args.k1a_lds >= 0:
         h.set_option("k1a_dummy_lds", args.k1a_lds)
 
@@ -241,7 +245,7 @@ def main():
     launches, fpl = int(kms[0]["launches"]), int(kms[0]["frames_per_launch"])
     kavg["launches"], kavg["frames_per_launch"] = launches, fpl
     bytes_per_launch = min(fpl, B) * rows * cols  # algorithmic: every pixel read once
-    fused = schedule in (3, 4) and launches > 1
+    fused = schedule in (3, 4, 6) and launches > 1
     if fused:
         # fused schedule: the scan of sub-batch s+1 runs INSIDE the voting kernel of sub-batch s; only the first
         # sub-batch is scanned by a stand-alone k1a_scan launch.  Average the launches that do the same thing.
@@ -251,6 +255,9 @@ def main():
         kavg.update({"scan_standalone_first_sub_batch": scan_alone_ms, "vote_with_scan": vote_scan_ms,
                      "vote_last_sub_batch_without_scan": vote_plain_ms})
         scan_s = vote_scan_ms * 1e-3
+        rider_kib = h.get_option("last_rider_kib")
+        if rider_kib > 0:  # what ONE fused launch actually scanned (mode 6 gives part of a sub-batch to a side scan)
+            bytes_per_launch = rider_kib * 1024
     else:
         scan_s = kavg["scan"] * 1e-3
     achieved = bytes_per_launch / scan_s / 1e9
@@ -350,10 +357,14 @@ def main():
                                                                       cfg["n_distractors"]),
                        "frames_per_gpu_per_step": B, "frames_resident_in_hbm": True,
                        "streams_per_gpu": args.pipeline,
-                       "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel", 4: "fused + validate/refine on a side stream"}.get(schedule, schedule),
+                       "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel", 4: "fused + validate/refine on a side stream",
+                                    6: "fused + side-stream tail + scan split between a side k1a_scan and the rider"}.get(schedule, schedule),
                        "side_streams_concurrent": h.get_option("streams_concurrent"),
                        "parallelism": "frames sharded over %d GPU(s), pose records gathered to rank 0 (async, double-buffered)" % world},
             "poses_found_frac": n_pose / B,
+            # every pixel of the batch is read once per step: the whole-step HBM rate against the 8 TB/s spec
+            "step_hbm": {"bytes_per_step": B * rows * cols, "achieved_GBps": world * B * rows * cols / (dt / args.steps) / 1e9,
+                         "frac_of_spec": B * rows * cols / (dt / args.steps) / 1e9 / 8000.0},
             "kernel_ms": kavg,
             "roofline": roofline,
         }

@@ -377,11 +377,14 @@ int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
  * for the blob bitmaps, 8192..163840), "vote_splits" (workgroups per frame in the voting kernel,
  * 0 = auto), "pipeline" (a large call is cut into up to this many sub-batches of about 16384 frames,
  * default 16, 1 = one chain of four kernels), "pipeline_mode" (how the sub-batches are scheduled:
- * -1 automatic (default) = 4;  0 = two-stream software
+ * -1 automatic (default) = 6;  0 = two-stream software
  * pipeline, the scan of sub-batch s+1 beside the voting of sub-batch s;  3 = fused, one stream: the
  * scan of sub-batch s+1 rides inside the voting kernel of sub-batch s;  4 = as 3, with the validate /
  * refine kernels of sub-batch s on an internal side stream, beside the blob extraction of sub-batch
- * s+1 (joined back before the call returns its place on the stream)), "k1a_dummy_lds" (occupancy cap
+ * s+1 (joined back before the call returns its place on the stream);  6 = as 4, and the image scan of a
+ * sub-batch is split: "scan_split_pct" % of it (default 20) is taken by a stand-alone scan kernel on a second
+ * side stream during the blob / tail window two sub-batches earlier ("side_scan_blocks" resident blocks per CU,
+ * default 2), the voting kernel's rider scans the rest), "k1a_dummy_lds" (occupancy cap
  * of the stand-alone scan kernel in mode 0, per handle), "ingest_chunk" (frames per chunk of the double-buffered
  * host-frame ingest of mpe_estimate_batch, default 2048, 0 = one blocking copy per call), "vote_arith" (arithmetic of the voting kernel: 1 (default)
  * = fast — Newton-Raphson division / square root, Newton cube root, per-permutation tables, [R|C]-free

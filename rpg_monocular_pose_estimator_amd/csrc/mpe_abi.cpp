@@ -58,8 +58,8 @@ struct mpe_handle {
   int k1a_dummy_lds = -1;      // tuning: dummy LDS per scan block in the two-stream schedule (-1 = automatic)
   int last_schedule = 0;       // schedule the last large batch actually ran with
   int pipeline_mode = -1;      // -1 automatic; 0 two-stream staggered pipeline, 3 fused single stream (scan rides in the voting
-                               // kernel), 4 fused + validate / refine on a side stream; 1 / 2 experiment variants of the
-                               // two-stream schedule
+                               // kernel), 4 fused + validate / refine on a side stream, 6 = 4 + the scan split between a
+                               // side k1a_scan and the rider (default); 1 / 2 experiment variants of the two-stream schedule
   bool profiling = false;
   int pipeline = 16;  // a large call is cut into up to this many sub-batches (about 16384 frames each, never
                       // below 8192) that the schedules pipeline against each other; 1 = one chain of kernels
@@ -74,6 +74,11 @@ struct mpe_handle {
   hipStream_t copy_stream = nullptr;  // host-frame ingest: the H2D copy of chunk c + 1 runs beside the kernels of chunk c
   hipEvent_t copy_done[2] = {nullptr, nullptr};
   int ingest_chunk = 2048;            // frames per ingest chunk (option "ingest_chunk"; 0 = one blocking copy per call)
+  hipStream_t scan_stream = nullptr;  // mode 6: part of the next-but-one sub-batch's scan beside blobs / tail
+  hipEvent_t scanpart_done[kMaxSub] = {};
+  int side_scan_blocks = 2;           // mode 6: resident blocks per CU of the side scan (4 waves each)
+  int scan_split_pct = 20;            // mode 6: share of a sub-batch scanned by the stand-alone kernel on the side stream
+  unsigned long long last_rider_bytes = 0;  // bytes one fused voting launch scanned in the last large call
   hipStream_t tail_stream = nullptr;  // fused schedule, mode 4: validate + refine of sub-batch s beside blobs(s + 1)
   hipEvent_t tail_done = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -407,15 +412,31 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   // automatic: the fused schedule for every marker count.  For more than 5 markers the voting kernel cannot carry
   // the scan (its LDS table would not fit) and launch_k2_vote falls back to the plain kernel + a stand-alone scan —
   // the voting then takes > 95 % of a sub-batch anyway (C(n_d,3) P(n_m,3) P3P solves), so nothing is lost.
-  if (schedule < 0) schedule = 4;
+  if (schedule < 0) schedule = 6;
   if (schedule == 0) {
     const int rc = pick_concurrent_streams(h);
     if (rc) return rc;
-    if (h->streams_concurrent == 0) schedule = 4;
+    if (h->streams_concurrent == 0) schedule = 6;
   }
   h->last_schedule = schedule;
-  if (schedule == 3 || schedule == 4) {
-    const bool side_tail = schedule == 4;
+  if (schedule == 3 || schedule == 4 || schedule == 6) {
+    const bool side_tail = schedule != 3;
+    // mode 6: the HBM stream is spread over the whole sub-batch period.  In modes 3 / 4 the voting kernel scans all
+    // of the next sub-batch and is HBM bound (0.95 ms for 5.9 GB) with 40 % of its issue slots idle, while the blob /
+    // tail window before it (0.4 ms) moves no image bytes.  Here a stand-alone k1a_scan on a side stream takes
+    // scan_split_pct % of sub-batch s + 2 DURING the blob / tail window of sub-batch s + 1 (its 48-VGPR waves fit
+    // beside four blob waves per SIMD, it needs no LDS), and the rider of vote(s + 1) scans only the rest.
+    const bool split_scan = schedule == 6 && h->scan_split_pct > 0;
+    if (split_scan) {
+      if (!h->scan_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking));
+      for (auto& e : h->scanpart_done)
+        if (!e) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+    }
+    auto split_bytes = [&](size_t nbytes) -> size_t {
+      return split_scan ? (nbytes * (size_t)h->scan_split_pct / 100) / 8192 * 8192 : 0;
+    };
+    h->last_rider_bytes = 0;
     if (side_tail) {
       if (!h->tail_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
       if (!h->tail_done) HIP_TRY(h, hipEventCreateWithFlags(&h->tail_done, hipEventDisableTiming));
@@ -440,11 +461,32 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][0], st));
     HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, scan_lds(h, false), st));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][1], st));
+    // side scan of the first part of sub-batch k (k >= 1), gated so that it runs in the blob / tail window that
+    // follows vote(k - 2) (k = 1: at the start of the call)
+    auto side_scan = [&](int k) -> int {
+      if (!split_scan || k >= nsub || k * per >= n_frames) return MPE_OK;
+      int q0, qn;
+      const uint8_t* qfr;
+      unsigned long long* qfl;
+      sub_ptrs(k, q0, qn, qfr, qfl);
+      const size_t P = split_bytes((size_t)qn * frame_bytes);
+      if (k == 1) {
+        HIP_TRY(h, hipEventRecord(h->fork_ev, st));
+        HIP_TRY(h, hipStreamWaitEvent(h->scan_stream, h->fork_ev, 0));
+      } else {
+        HIP_TRY(h, hipStreamWaitEvent(h->scan_stream, h->vote_done[k - 2], 0));
+      }
+      if (P) HIP_TRY(h, launch_k1a_scan(qfr, P, qfl, dp.thr, 0, h->scan_stream, h->side_scan_blocks));
+      HIP_TRY(h, hipEventRecord(h->scanpart_done[k], h->scan_stream));
+      return MPE_OK;
+    };
+    { const int rc = side_scan(1); if (rc) return rc; }
     int used = 0;
     for (int s = 0; s < nsub; ++s) {
       sub_ptrs(s, f0, nf, fr, fl);
       if (f0 >= n_frames) break;
       used = s + 1;
+      if (split_scan && s >= 1) HIP_TRY(h, hipStreamWaitEvent(st, h->scanpart_done[s], 0));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], st));
       HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
                                   static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
@@ -462,15 +504,18 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
         sub_ptrs(s + 1, nf0, nnf, nfr, nfl);
         nbytes = (size_t)nnf * frame_bytes;
       }
+      const size_t P = split_bytes(nbytes);  // (the first P bytes of sub-batch s + 1 come from the side scan)
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], st));
       HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, *sp, static_cast<const double*>(h->mtab.p), hs,
-                                auto_splits(h, nf, sp->n_markers), sp->n_markers, st, nfr, nbytes, nfl, dp.thr,
-                                &scanned));
+                                auto_splits(h, nf, sp->n_markers), sp->n_markers, st, nbytes ? nfr + P : nullptr,
+                                nbytes - P, nbytes ? nfl + P / 1024 : nullptr, dp.thr, &scanned));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], st));
+      if (scanned > h->last_rider_bytes) h->last_rider_bytes = scanned;
       if (nbytes > 0) {  // what the riders left over: less than one chunk, or everything if they could not run
         if (prof) HIP_TRY(h, hipEventRecord(h->pev[s + 1][0], st));
-        if (nbytes > scanned)
-          HIP_TRY(h, launch_k1a_scan(nfr + scanned, nbytes - scanned, nfl + scanned / 1024, dp.thr, scan_lds(h, false), st));
+        if (nbytes - P > scanned)
+          HIP_TRY(h, launch_k1a_scan(nfr + P + scanned, nbytes - P - scanned, nfl + (P + scanned) / 1024, dp.thr,
+                                     scan_lds(h, false), st));
         if (prof) HIP_TRY(h, hipEventRecord(h->pev[s + 1][1], st));
       }
       // validate + refine of this sub-batch: on the caller's stream, or (mode 4) on a side stream so that its
@@ -480,6 +525,8 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
         HIP_TRY(h, hipEventRecord(h->vote_done[s], st));
         HIP_TRY(h, hipStreamWaitEvent(h->tail_stream, h->vote_done[s], 0));
         tst = h->tail_stream;
+        const int rc = side_scan(s + 2);  // runs beside blobs(s + 1) / tail(s)
+        if (rc) return rc;
       }
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], tst));
       HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
@@ -491,6 +538,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       HIP_TRY(h, hipEventRecord(h->tail_done, h->tail_stream));
       HIP_TRY(h, hipStreamWaitEvent(st, h->tail_done, 0));
     }
+    // (every side scan was waited for by the blob extraction of its sub-batch)
     if (prof) {
       h->prof_launches = used;
       h->have_ms = true;
@@ -684,6 +732,9 @@ void mpe_destroy(mpe_handle* h) {
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   if (h->tail_done) (void)hipEventDestroy(h->tail_done);
   if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
+  if (h->scan_stream) (void)hipStreamDestroy(h->scan_stream);
+  for (auto& e : h->scanpart_done)
+    if (e) (void)hipEventDestroy(e);
   for (auto& e : h->copy_done)
     if (e) (void)hipEventDestroy(e);
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
@@ -766,6 +817,9 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "vote_splits") *value = h->vote_splits;
   else if (n == "vote_arith") *value = h->vote_arith;
   else if (n == "ingest_chunk") *value = h->ingest_chunk;
+  else if (n == "scan_split_pct") *value = h->scan_split_pct;
+  else if (n == "side_scan_blocks") *value = h->side_scan_blocks;
+  else if (n == "last_rider_kib") *value = (int)(h->last_rider_bytes >> 10);
   else if (n == "k1a_dummy_lds") *value = h->k1a_dummy_lds;
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
@@ -795,6 +849,16 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   }
   if (!std::strcmp(name, "vote_splits")) {
     h->vote_splits = value;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "side_scan_blocks")) {
+    if (value < 1 || value > 32) return fail(h, MPE_ERR_ARG, "side_scan_blocks out of range (1..32)");
+    h->side_scan_blocks = value;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "scan_split_pct")) {
+    if (value < 0 || value > 90) return fail(h, MPE_ERR_ARG, "scan_split_pct out of range (0..90)");
+    h->scan_split_pct = value;
     return MPE_OK;
   }
   if (!std::strcmp(name, "ingest_chunk")) {

@@ -50,7 +50,7 @@ struct SolveParams {
 // launchers (mpe_kernels.hip)
 size_t k1b_scratch_bytes(const FrameGeom& g);
 hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long long* flags, int thr,
-                           int dummy_lds_bytes, hipStream_t s);
+                           int dummy_lds_bytes, hipStream_t s, int blocks_per_cu = 0);
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
                             int blob_hint, hipStream_t s, const void* frame_windows = nullptr);

@@ -124,13 +124,15 @@ __global__ __launch_bounds__(256) void k1a_scan(const uint4* __restrict__ px, u6
 // 40 KB per block by default) so that its 44-VGPR waves leave room for the voting waves; HBM throughput is
 // unchanged at that occupancy (measured).  The value is a per-handle setting (option "k1a_dummy_lds").
 hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long long* flags, int thr,
-                           int dummy_lds_bytes, hipStream_t s) {
+                           int dummy_lds_bytes, hipStream_t s, int blocks_per_cu) {
   const size_t n_seg = n_bytes / 16;
   if (n_seg == 0) return hipSuccess;
   const ThrTest q = make_thr_test(thr);
   const size_t n_chunks = (n_seg + 64 * K1A_UNROLL - 1) / (64 * K1A_UNROLL);
   size_t blocks = (n_chunks + 3) / 4;  // 4 waves per block
-  const size_t max_blocks = 256 * K1A_BLOCKS_PER_CU;  // 256 CUs x blocks per CU, grid-stride beyond
+  // 256 CUs x blocks per CU, grid-stride beyond.  blocks_per_cu > 0: a deliberately small resident set (a side scan
+  // that must leave the wave slots to the kernel it runs beside)
+  const size_t max_blocks = 256 * (size_t)(blocks_per_cu > 0 ? blocks_per_cu : K1A_BLOCKS_PER_CU);
   if (blocks > max_blocks) blocks = max_blocks;
   const size_t dummy_lds = dummy_lds_bytes > 0 ? (size_t)dummy_lds_bytes : 0;
   if (dummy_lds > 65536) {  // tuning experiments only: more than the default dynamic-LDS limit

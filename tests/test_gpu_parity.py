@@ -723,9 +723,15 @@ def test_full_size_batch_properties(orc):
     h.set_option("pipeline_mode", 4)                       # fused + validate / refine on a side stream
     fused4 = run(frames, 8)
     assert h.get_option("last_schedule") == 4 and torch.equal(fused4, plain)
-    h.set_option("pipeline_mode", -1)                      # automatic = fused (4) for a 5-marker object
+    h.set_option("pipeline_mode", 6)                       # ... + the scan split between a side scan kernel and the rider
+    for pct in (20, 0, 55):
+        h.set_option("scan_split_pct", pct)
+        fused6 = run(frames, 8)
+        assert h.get_option("last_schedule") == 6 and torch.equal(fused6, plain), pct
+    h.set_option("scan_split_pct", 20)
+    h.set_option("pipeline_mode", -1)                      # automatic = 6
     piped = run(frames, 8)
-    assert h.get_option("last_schedule") == 4 and torch.equal(piped, plain)
+    assert h.get_option("last_schedule") == 6 and torch.equal(piped, plain)
     flipped = torch.flip(frames, dims=[0]).contiguous()
     torch.cuda.synchronize()
     rev = run(flipped, 8)
