@@ -286,7 +286,8 @@ def main():
             pmc_all = json.load(fh)
         pmc = pmc_all["k2_vote_scan" if fused else "k1a_scan"]
         if pmc.get("rows") == rows and pmc.get("cols") == cols:
-            traffic = pmc["hbm_bytes_per_frame"] * min(fpl, B)
+            # (scaled to the frames' worth of pixels this launch scans: bytes_per_launch / (rows * cols))
+            traffic = pmc["hbm_bytes_per_frame"] * (bytes_per_launch / float(rows * cols))
             traffic_source = "profiles/round2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, " \
                              "FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes; %s)" % pmc.get("from", "")
     except Exception:
