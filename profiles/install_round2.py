@@ -55,8 +55,10 @@ def main():
                  ("pmc1_sq", "sequential_sq"), ("pmc3_sq", "C3_sq")):
         shutil.copy(F + a + "_summary.csv", P + "pmc_" + b + ".csv")
     out = {
-        "k2_vote_scan": hbm("k2_vote<true>", "k2_vote<true> (voting kernel carrying the image scan of the next sub-batch)",
-                            F + "pmc_fetch_summary.csv", F + "pmc_write_summary.csv", 16384, "round2_pmc_fused_*.csv"),
+        # default schedule 6: 20 % of the next sub-batch is scanned by a side k1a_scan, the rider of this launch scans
+        # the other 80 % = 4 731 174 912 B = 13 107.2 frames' worth of pixels (what bench.py reports as bytes_per_launch)
+        "k2_vote_scan": hbm("k2_vote<true>", "k2_vote<true> (voting kernel carrying 80 % of the image scan of the next sub-batch)",
+                            F + "pmc_fetch_summary.csv", F + "pmc_write_summary.csv", 16384 * 0.8, "round2_pmc_fused_*.csv"),
         "k1a_scan": hbm("k1a_scan", "k1a_scan", F + "pmc1_fetch_summary.csv", F + "pmc1_write_summary.csv", 16384,
                         "round2_pmc_sequential_*.csv"),
         "k2_vote_valu": {
