@@ -245,7 +245,10 @@ def main():
     launches, fpl = int(kms[0]["launches"]), int(kms[0]["frames_per_launch"])
     kavg["launches"], kavg["frames_per_launch"] = launches, fpl
     bytes_per_launch = min(fpl, B) * rows * cols  # algorithmic: every pixel read once
-    fused = schedule in (3, 4, 6) and launches > 1
+    rider_kib = h.get_option("last_rider_kib")
+    # (more than 5 markers: the voting kernel cannot carry the scan -- its LDS table would not fit -- and every
+    #  sub-batch is scanned by a stand-alone k1a_scan although the schedule is nominally fused: rider bytes 0)
+    fused = schedule in (3, 4, 6) and launches > 1 and rider_kib > 0
     if fused:
         # fused schedule: the scan of sub-batch s+1 runs INSIDE the voting kernel of sub-batch s; only the first
         # sub-batch is scanned by a stand-alone k1a_scan launch.  Average the launches that do the same thing.
@@ -255,9 +258,7 @@ def main():
         kavg.update({"scan_standalone_first_sub_batch": scan_alone_ms, "vote_with_scan": vote_scan_ms,
                      "vote_last_sub_batch_without_scan": vote_plain_ms})
         scan_s = vote_scan_ms * 1e-3
-        rider_kib = h.get_option("last_rider_kib")
-        if rider_kib > 0:  # what ONE fused launch actually scanned (mode 6 gives part of a sub-batch to a side scan)
-            bytes_per_launch = rider_kib * 1024
+        bytes_per_launch = rider_kib * 1024  # what ONE fused launch actually scanned (mode 6 gives part of a sub-batch to a side scan)
     else:
         scan_s = kavg["scan"] * 1e-3
     achieved = bytes_per_launch / scan_s / 1e9
@@ -311,6 +312,9 @@ def main():
                     "measured": "HIP events around every k1a_scan launch on its stream, steps in the same mode as "
                                 "the timed region (with >1 launches per step the scan of sub-batch i+1 runs beside "
                                 "the FP64 voting of sub-batch i and shares the chip with it)"}
+        if kavg.get("vote", 0.0) > 5.0 * kavg["scan"]:
+            roofline["note"] = ("this is the kernel that moves the bytes; the step itself is dominated by k2_vote "
+                                "(FP64 VALU bound, no HBM traffic to speak of): see k2_rates.valu_util")
 
     # ---- PCIe-inclusive leg (SURVEY 8d "report both"): the same frames streamed from PINNED HOST memory through
     #      mpe_estimate_batch every call (double-buffered chunked ingest: the copy of chunk c + 1 beside the kernels of
