@@ -230,8 +230,11 @@ struct PixWin {
 // inside the frame / the tracking ROI (20 px border), so the mirrored zone is almost always dark.
 template <int KS, bool EDGE>
 __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, int cols, int y, int c,
-                                                   const int* __restrict__ taps, unsigned zone, unsigned& edge_or) {
+                                                   const DetectParams& dp, unsigned zone, unsigned& edge_or) {
   constexpr int R = KS / 2;
+  int taps[KS];  // constant indices into the by-value kernel argument: scalar registers, no LDS traffic
+#pragma unroll
+  for (int j = 0; j < KS; ++j) taps[j] = dp.taps[j];
   int acc[16];
 #pragma unroll
   for (int x = 0; x < 16; ++x) acc[x] = 0;
@@ -299,22 +302,10 @@ __device__ __noinline__ unsigned blur_item_generic(const PixWin& w, int rows, in
   return m;
 }
 
-// three bits (x-1, x, x+1) of a bitmap row at bit index xb (>= 1)
-__device__ __forceinline__ unsigned bits3(const u64* row, int xb) {
-  const int lo = xb - 1, wi = lo >> 6, sh = lo & 63;
-  u64 v = row[wi] >> sh;
-  if (sh >= 62) v |= row[wi + 1] << (64 - sh);  // the three bits straddle a word boundary (rare)
-  return (unsigned)(v & 7);
-}
-// 8-neighbourhood occupancy, bit d = direction d non-zero; directions as OpenCV's chain codes:
+// 8-neighbourhood occupancy codes, bit d = direction d non-zero; directions as OpenCV's chain codes:
 // 0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE (y grows downwards)
-__device__ __forceinline__ unsigned neighbours(const u64* nz, int wb, int slot, int xb) {
-  const unsigned u = bits3(nz + (size_t)(slot - 1) * wb, xb);
-  const unsigned m = bits3(nz + (size_t)slot * wb, xb);
-  const unsigned d = bits3(nz + (size_t)(slot + 1) * wb, xb);
-  return ((m >> 2) & 1) | (((u >> 2) & 1) << 1) | (((u >> 1) & 1) << 2) | ((u & 1) << 3) | ((m & 1) << 4) |
-         ((d & 1) << 5) | (((d >> 1) & 1) << 6) | (((d >> 2) & 1) << 7);
-}
+// (image coordinates are < 2^15 and steps are -1 / 0 / 1: the 24-bit multiplier is exact and full rate)
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 // chain-code steps, packed 2 bits per direction (value + 1)
 __device__ __forceinline__ int dir_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }
 __device__ __forceinline__ int dir_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }
@@ -362,21 +353,27 @@ __device__ __forceinline__ void set_bit(u64* bm, int wb, int slot, int xb) {
 // visited pixels are marked "positive" (pm) or, when the east neighbour was examined and is 0,
 // "negative" (ng, takes precedence).  (xoff, yoff) turn window coordinates into image
 // coordinates.  Returns false if the step bound was hit.
-__device__ __forceinline__ unsigned bits3_at(const u64* rowp, int xb) {  // branch-free bits3: always two words
-  const int lo = xb - 1, wi = lo >> 6, sh = lo & 63;
-  const u64 v = (rowp[wi] >> sh) | ((rowp[wi + 1] << 1) << (63 - sh));  // (the pools end in a pad word)
-  return (unsigned)v & 7u;
+// The bitmaps as 32-bit words (a row = 2 * wb of them): the three bits x-1, x, x+1 of a row come out of two
+// consecutive words and one funnel shift, for any x >= 1 (the pools end in a pad word).
+__device__ __forceinline__ unsigned bits3_at(const unsigned* row32, int i, int sh) {
+  const u64 v = ((u64)row32[i + 1] << 32) | row32[i];
+  return (unsigned)(v >> sh);  // (callers mask)
 }
-__device__ __forceinline__ unsigned neighbours_at(const u64* nz, int ro, int wb, int xb) {  // ro = slot * wb
-  const unsigned u3 = bits3_at(nz + ro - wb, xb), m3 = bits3_at(nz + ro, xb), d3 = bits3_at(nz + ro + wb, xb);
-  const unsigned urev = ((u3 & 1u) << 2) | (u3 & 2u) | (u3 >> 2);
-  return (m3 >> 2) | (urev << 1) | ((m3 & 1u) << 4) | (d3 << 5);  // 0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE
+__device__ __forceinline__ unsigned neighbours_at(const unsigned* nz32, int rd, int stride, int xb) {  // rd = slot * stride
+  const int i = rd + ((xb - 1) >> 5), sh = (xb - 1) & 31;
+  const unsigned u3 = bits3_at(nz32, i - stride, sh), m3 = bits3_at(nz32, i, sh), d3 = bits3_at(nz32, i + stride, sh);
+  const unsigned urev = (__builtin_bitreverse32(u3) >> 28) & 0xEu;  // NE, N, NW at bits 1, 2, 3
+  return ((m3 >> 2) & 1u) | urev | ((m3 & 1u) << 4) | ((d3 & 7u) << 5);  // 0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE
 }
 __device__ __forceinline__ bool trace_outer_border(const u64* nz, u64* pm, u64* ng, int wb, int slot0, int xb0, int xoff, int yoff,
                                    PolyAcc& acc) {
   acc.init();
-  int ro = slot0 * wb;  // word offset of the current row, advanced by +-wb (no multiplication per step)
-  unsigned nb = neighbours_at(nz, ro, wb, xb0);
+  const unsigned* nz32 = reinterpret_cast<const unsigned*>(nz);
+  unsigned* pm32 = reinterpret_cast<unsigned*>(pm);
+  unsigned* ng32 = reinterpret_cast<unsigned*>(ng);
+  const int stride = 2 * wb;
+  int rd = slot0 * stride;  // 32-bit word offset of the current row, advanced by +-stride (no multiplication per step)
+  unsigned nb = neighbours_at(nz32, rd, stride, xb0);
   int s = 4;
   const int s_end0 = 4;
   bool hit;
@@ -390,52 +387,53 @@ __device__ __forceinline__ bool trace_outer_border(const u64* nz, u64* pm, u64* 
     acc.close();
     return true;
   }
-  const int x1b = xb0 + dir_dx(s), s1 = slot0 + dir_dy(s);
-  int xb = xb0, slot = slot0;
+  // positions packed as slot << 16 | x (both < 2^15): one comparison each for "back at the start" and "about to repeat
+  // the first step"
+  const int pos0 = (slot0 << 16) | xb0;
+  const int pos1 = pos0 + (dir_dy(s) << 16) + dir_dx(s);
+  int pos = pos0;
+  int X = xb0 + xoff, Y = slot0 + yoff;  // image coordinates of the current border pixel
   long long a00 = 0, a10 = 0, a01 = 0;
-  int xmin = xb, xmax = xb, ymin = slot, ymax = slot;  // window coordinates, shifted at the end
+  int xmin = X, xmax = X, ymin = Y, ymax = Y;
   // Straight-line loop body (lanes of different blobs stay in lock step).  The polygon sums take the edge to the
   // NEXT border pixel every step: for b = a + (dx, dy), a_x b_y - b_x a_y = a_x dy - a_y dx; at the last step the
   // next pixel is the start pixel, i.e. that edge closes the polygon.
-  for (int step = 0; step < (1 << 20); ++step) {
+  bool done;
+  int step = 0;
+  do {  // (everything after the test of `done` is harmless on the last step: the next pixel is the start pixel)
     const int s_end = s;
     const unsigned m16 = nb | (nb << 8);
     const int k = __builtin_ctz(m16 >> (s + 1));
     const int sn = (s + 1 + k) & 7;
     const bool negative = (unsigned)(sn - 1) < (unsigned)s_end;
-    const u64 bit = 1ull << (xb & 63);
-    const int wi = ro + (xb >> 6);
-    atomicOr(&ng[wi], negative ? bit : 0ull);
-    atomicOr(&pm[wi], negative ? 0ull : bit);
+    const int xb = pos & 0xFFFF;
+    atomicOr((negative ? ng32 : pm32) + rd + (xb >> 5), 1u << (xb & 31));
     const int dx = dir_dx(sn), dy = dir_dy(sn);
-    const int nxb = xb + dx, nslot = slot + dy;
-    const bool done = (nxb == xb0) & (nslot == slot0) & (xb == x1b) & (slot == s1);
-    const int X = xb + xoff, Y = slot + yoff;
-    const int dxy = X * dy - Y * dx;
+    const int npos = pos + (dy << 16) + dx;
+    done = (npos == pos0) & (pos == pos1);
+    const int dxy = mul24(X, dy) - mul24(Y, dx);
     a00 += dxy;
     a10 += (long long)dxy * (2 * X + dx);
     a01 += (long long)dxy * (2 * Y + dy);
-    xmin = min(xmin, xb);
-    xmax = max(xmax, xb);
-    ymin = min(ymin, slot);
-    ymax = max(ymax, slot);
-    if (done) {
-      acc.a00 = a00;
-      acc.a10 = a10;
-      acc.a01 = a01;
-      acc.xmin = xmin + xoff;
-      acc.xmax = xmax + xoff;
-      acc.ymin = ymin + yoff;
-      acc.ymax = ymax + yoff;
-      return true;
-    }
-    slot = nslot;
-    xb = nxb;
-    ro += dy * wb;
+    xmin = min(xmin, X);
+    xmax = max(xmax, X);
+    ymin = min(ymin, Y);
+    ymax = max(ymax, Y);
+    pos = npos;
+    X += dx;
+    Y += dy;
+    rd += dy * stride;
     s = (sn + 4) & 7;
-    nb = neighbours_at(nz, ro, wb, xb);
-  }
-  return false;
+    nb = neighbours_at(nz32, rd, stride, xb + dx);
+  } while (!done && ++step < (1 << 20));
+  acc.a00 = a00;
+  acc.a10 = a10;
+  acc.a01 = a01;
+  acc.xmin = xmin;
+  acc.xmax = xmax;
+  acc.ymin = ymin;
+  acc.ymax = ymax;
+  return done;
 }
 
 // cv::undistortPoints(src, dst, K, D, noArray(), K) for one float point  (led_detector.cpp:97-98)
@@ -489,23 +487,39 @@ __device__ __forceinline__ bool blob_filter(const BlobRec& b, const DetectParams
 // mode.  Window rows are bitmap slots 1..H (slot 0 and H+1 are zero separators), bit index
 // xb = x - xw0 + 1.  For every traced outer border the polygon sums go through the shape filter;
 // blobs that pass are handed to emit(mcx, mcy, key) with key = raster position of the start pixel.
+// Raster scan of one island window for outer-border start points (one LANE per island).  Written as a per-lane
+// state machine (slot, w, done, last_sign) so that the wave alternates between two converged phases: every lane
+// advances its scan to its next start point (cheap, divergent trip counts), then ALL lanes that found one follow
+// their borders in the same loop.  With the border following nested inside the scan loops the lanes reached it in
+// different iterations and the wave executed the traces one after the other (the sum of the perimeters instead
+// of the longest one).
 template <class Emit>
 __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, int H, int ylo, int xw0,
                                             const DetectParams& dp, int roi_x, int roi_y, int* over, Emit emit) {
-  for (int slot = 1; slot <= H; ++slot) {
-    u64* nzrow = nz + (size_t)slot * W;
-    u64* pmrow = pm + (size_t)slot * W;
-    u64* ngrow = ng + (size_t)slot * W;
-    int last_sign = 0;  // sign of the nearest marked pixel to the left (lnbd), 0 = none yet
-    for (int w = 0; w < W; ++w) {
-      const u64 nzw = nzrow[w];
-      if (!nzw) continue;
-      const u64 leftnz = (nzw << 1) | (w ? (nzrow[w - 1] >> 63) : 0);
-      u64 done = 0;
-      for (;;) {
-        const u64 pw_ = pmrow[w], gw = ngrow[w];
-        const u64 cand = nzw & ~(pw_ | gw) & ~leftnz & ~done;  // unmarked 1 with a 0 on its left
-        if (!cand) break;
+  int slot = 1, w = 0;
+  int last_sign = 0;  // sign of the nearest marked pixel to the left (lnbd), 0 = none yet
+  u64 done = 0;
+  bool fin = H < 1;
+  for (;;) {
+    // ---- find: the next unmarked 1 with a 0 on its left that is not inside an already traced outer border
+    bool have = false;
+    int xb = 0;
+    while (!have && !fin) {
+      // (empty words — most of a window — only move the cursor: done is 0 on arrival, no mark can sit on them)
+      while (!fin && nz[slot * W + w] == 0) {
+        if (++w == W) {
+          w = 0;
+          last_sign = 0;
+          fin = ++slot > H;
+        }
+      }
+      if (fin) break;
+      const int ro = slot * W + w;
+      const u64 nzw = nz[ro];
+      const u64 pw_ = pm[ro], gw = ng[ro];
+      const u64 leftnz = (nzw << 1) | (w ? (nz[ro - 1] >> 63) : 0);
+      const u64 cand = nzw & ~(pw_ | gw) & ~leftnz & ~done;
+      if (cand) {
         const int bb = __builtin_ctzll(cand);
         done |= (bb == 63) ? ~0ull : ((2ull << bb) - 1);
         const u64 below = (pw_ | gw) & ((1ull << bb) - 1);
@@ -514,33 +528,49 @@ __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, in
           const int hb = 63 - __builtin_clzll(below);
           sign = ((gw >> hb) & 1) ? -1 : 1;
         }
-        if (sign > 0) continue;  // inside an already traced outer border: not external
-        PolyAcc acc;
-        const int xb = w * 64 + bb;
-        if (!trace_outer_border(nz, pm, ng, W, slot, xb, xw0 - 1, ylo - 1, acc)) *over = 1;
-        BlobRec br;
-        br.a00 = acc.a00;
-        br.a10 = acc.a10;
-        br.a01 = acc.a01;
-        br.xmin = acc.xmin;
-        br.xmax = acc.xmax;
-        br.ymin = acc.ymin;
-        br.ymax = acc.ymax;
-        float mcx, mcy;
-        if (blob_filter(br, dp, roi_x, roi_y, mcx, mcy)) emit(mcx, mcy, ((unsigned)(ylo + slot - 1) << 12) | (unsigned)(xb + xw0 - 1));
+        if (sign <= 0) {  // (sign > 0: inside an already traced outer border, not external)
+          have = true;
+          xb = w * 64 + bb;
+        }
+      } else {  // this word is finished
+        const u64 mk = pw_ | gw;
+        if (mk) {
+          const int hb = 63 - __builtin_clzll(mk);
+          last_sign = ((gw >> hb) & 1) ? -1 : 1;
+        }
+        done = 0;
+        if (++w == W) {
+          w = 0;
+          last_sign = 0;
+          fin = ++slot > H;
+        }
       }
-      const u64 mk = pmrow[w] | ngrow[w];
-      if (mk) {
-        const int hb = 63 - __builtin_clzll(mk);
-        last_sign = ((ngrow[w] >> hb) & 1) ? -1 : 1;
-      }
+    }
+    // (a wave-uniform exit test: the compiler must finish the find loop of every lane before the border following
+    //  starts instead of merging the two loops into one, which would serialise the lanes again)
+    if (__builtin_amdgcn_ballot_w64(have) == 0) break;  // every lane of this call has scanned its whole window
+    // ---- follow: all lanes that hold a start point, in lock step
+    if (have) {
+      PolyAcc acc;
+      if (!trace_outer_border(nz, pm, ng, W, slot, xb, xw0 - 1, ylo - 1, acc)) *over = 1;
+      BlobRec br;
+      br.a00 = acc.a00;
+      br.a10 = acc.a10;
+      br.a01 = acc.a01;
+      br.xmin = acc.xmin;
+      br.xmax = acc.xmax;
+      br.ymin = acc.ymin;
+      br.ymax = acc.ymax;
+      float mcx, mcy;
+      if (blob_filter(br, dp, roi_x, roi_y, mcx, mcy)) emit(mcx, mcy, ((unsigned)(ylo + slot - 1) << 12) | (unsigned)(xb + xw0 - 1));
     }
   }
 }
 
 // blurred-mask bits of the 16 outputs of segment column c in image row y -> OR into the bitmap
-__device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int cols, const int* taps, int ksize, int y,
-                                               int c, u64* nzrow, int xw0) {
+__device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int cols, const DetectParams& dp,
+                                               const int* taps, int y, int c, u64* nzrow, int xw0) {
+  const int ksize = dp.ksize;
   const int r = ksize / 2;
   const int x0 = 16 * c;
   if (x0 >= cols) return;
@@ -548,9 +578,9 @@ __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int c
   const bool interior = (x0 - r >= 0) && (x0 + 15 + r < cols);
   unsigned edge_or = 0;
   if (interior && ksize == 5) {
-    m = blur_item_fast<5, false>(pw, rows, cols, y, c, taps, 0u, edge_or);
+    m = blur_item_fast<5, false>(pw, rows, cols, y, c, dp, 0u, edge_or);
   } else if (interior && ksize == 3) {
-    m = blur_item_fast<3, false>(pw, rows, cols, y, c, taps, 0u, edge_or);
+    m = blur_item_fast<3, false>(pw, rows, cols, y, c, dp, 0u, edge_or);
   } else if ((ksize == 5 || ksize == 3) && cols >= 2 * r + 2) {
     // border segment: mirrored input positions j (pixel x = x0 - r + j): left border x in [1, r], right border
     // x in [cols - 1 - r, cols - 2]
@@ -559,8 +589,8 @@ __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int c
       const int x = x0 - r + j;
       if ((x0 - r < 0 && x >= 1 && x <= r) || (x0 + 15 + r >= cols && x >= cols - 1 - r && x <= cols - 2)) zone |= 1u << j;
     }
-    m = ksize == 5 ? blur_item_fast<5, true>(pw, rows, cols, y, c, taps, zone, edge_or)
-                   : blur_item_fast<3, true>(pw, rows, cols, y, c, taps, zone, edge_or);
+    m = ksize == 5 ? blur_item_fast<5, true>(pw, rows, cols, y, c, dp, zone, edge_or)
+                   : blur_item_fast<3, true>(pw, rows, cols, y, c, dp, zone, edge_or);
     if (edge_or) m = blur_item_generic(pw, rows, cols, y, c, taps, ksize);  // a bright pixel next to the border
   } else {
     m = blur_item_generic(pw, rows, cols, y, c, taps, ksize);
@@ -602,16 +632,13 @@ __device__ __forceinline__ void write_detections(const float* kx, const float* k
 }
 
 // =============================================================================================
-// K1b fast path.  A wave works on C::FRAMES frames: the front phases (A-D: flag bits -> bands ->
-// islands -> thresholded pixels -> blurred mask bitmaps) run frame after frame with all 64 lanes and
-// share one pixel pool (which also hosts the front phases' scratch lists); the contour phase (E), where
-// one lane owns one island, runs over the islands of all the wave's frames at once.
+// K1b fast path.  One wave per frame: the front phases (A-D: flag bits -> bands -> islands -> thresholded
+// pixels -> blurred mask bitmaps) use all 64 lanes; in the contour phase (E) one lane owns one island, and the lanes
+// follow their borders in lock step (scan_window).
 // Two capacity tiers, tried in turn (device work-lists chain them): K1bSmall covers the 4-6 LED case in
 // 9.6 KB per wave (16 waves per CU), K1bLarge ~16 blobs per frame.
-// Measured on MI355X (16 384 C2 frames, kernel alone): 0.34 ms with the former 14.4 KB layout ->
-// 0.26 ms; FRAMES = 2 / 4 / 8 (busier lanes in phase E, but 10 / 18 / 34 KB per wave) 0.25 / 0.29 /
-// 0.47 ms alone and slower than FRAMES = 1 when the kernel shares the chip with the tail kernel, so
-// one frame per wave stays the default.
+// Measured on MI355X (16 384 C2 frames, kernel alone): 0.317 ms with the border following nested in the raster scan
+// (the lanes then follow their borders one after the other: phase E was 58 % of the kernel) -> 0.26 ms.
 // =============================================================================================
 // Per-frame window inside a uniform frame slot (batched ROI detection: every stream's ROI is cloned into a slot of
 // g.rows x g.pitch bytes, zero beyond its own rows x cols; borders — BORDER_REFLECT_101, clipping — follow the
@@ -643,9 +670,9 @@ struct Island {
 };
 
 // capacities: thresholded-pixel pool [bytes], bitmap pool [u64 words per bitmap], bright segments, bands,
-// islands, blobs kept per frame, frames per wave
-#ifndef K1B_SMALL_FRAMES
-#define K1B_SMALL_FRAMES 1
+// islands, blobs kept per frame; WAVES = frames (one wave each) per block, whose islands ONE wave traces together
+#ifndef K1B_SMALL_WAVES
+#define K1B_SMALL_WAVES 1
 #endif
 #ifndef K1B_SMALL_PIX
 #define K1B_SMALL_PIX 4096
@@ -654,14 +681,23 @@ struct Island {
 #define K1B_SMALL_BM 208
 #endif
 struct K1bSmall {
-  enum { PIX = K1B_SMALL_PIX, BM = K1B_SMALL_BM, SEG = 64, BAND = 8, ISL = 8, KEPT = 16, FRAMES = K1B_SMALL_FRAMES };
+  enum { PIX = K1B_SMALL_PIX, BM = K1B_SMALL_BM, SEG = 64, BAND = 8, ISL = 8, KEPT = 16, WAVES = K1B_SMALL_WAVES, MIN_WAVES = 4 };
 };
 struct K1bLarge {
-  enum { PIX = 12288, BM = 704, SEG = 512, BAND = 32, ISL = 32, KEPT = 64, FRAMES = 1 };
+  enum { PIX = 12288, BM = 704, SEG = 512, BAND = 32, ISL = 32, KEPT = 64, WAVES = 1, MIN_WAVES = 2 };
 };
 
+// Synchronisation among the 64 lanes of ONE wave that communicate through LDS (the front phases of a frame
+// belong to one wave; a block barrier there would couple the data-dependent control flow of the block's waves).
+// DS operations of a wave execute in program order, so all that is needed is that the compiler keeps that order.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <class C>
-struct K1bWaveLds {  // shared by the frames of a wave (front phases are sequential)
+struct K1bWaveLds {  // front-phase storage of one wave
   enum { SCRATCH = 4 * C::SEG + 512 + 32 * C::BAND + 4 * C::BAND, POOL = C::PIX > SCRATCH ? C::PIX : SCRATCH };
   __attribute__((aligned(16))) uint8_t pool[POOL];
   int taps[MPE_MAX_KSIZE];  // (taking the address of the by-value kernel argument would make the
@@ -675,6 +711,7 @@ struct K1bFrameLds {  // what the contour phase needs of one frame
   float kx[C::KEPT], ky[C::KEPT];
   unsigned kkey[C::KEPT];
   int nkept, over, nisl;
+  int ready, cols, roi_x, roi_y;  // for the wave that traces the block's islands
 };
 
 // Front phases of frame f.  Returns true when the island bitmaps in S are ready for the contour phase,
@@ -684,7 +721,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
                                           const u64* __restrict__ flags, const FrameGeom& g, const DetectParams& dp,
                                           mpe_detections* __restrict__ dets, int* __restrict__ worklist,
                                           K1bWaveLds<C>& W, K1bFrameLds<C>& S) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   // front-phase scratch lives in the pixel pool (dead before the pool is filled in phase C)
   unsigned* s_seg = reinterpret_cast<unsigned*>(W.pool);  // y << 16 | segment column
   u64* s_rowact = reinterpret_cast<u64*>(W.pool + 4 * C::SEG);
@@ -700,7 +737,6 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   int& s_nkept = S.nkept;
   int& s_over = S.over;
   int& s_nisl = S.nisl;
-  __syncthreads();  // the previous user of the pool (frame before this one) is completely done
   const uint8_t* frame = frames + (size_t)f * slot_bytes;  // (g = the frame's window geometry, see window_geom)
   mpe_detections* out = dets + f;
   const int r = dp.ksize / 2;
@@ -717,7 +753,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
     s_nband = 0;
     s_nisl = 0;
   }
-  __syncthreads();
+  wave_sync();
 
   // ---- A: bright segments of this frame -> LDS list; rows within +-r become active
   {
@@ -753,7 +789,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
       }
     }
   }
-  __syncthreads();
+  wave_sync();
   const int nseg = s_nseg;
   if (nseg == 0) {
     if (lane == 0) {
@@ -799,7 +835,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
     }
     if (lane == 63) s_nband = ps;
   }
-  __syncthreads();
+  wave_sync();
   const int nband = s_nband;
   fallback = fallback || nband > C::BAND;
 
@@ -813,7 +849,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
       atomicOr(&s_colocc[b][c >> 6], 1ull << (c & 63));
     }
   }
-  __syncthreads();
+  wave_sync();
 
   // ---- B3: islands = runs of occupied columns (dilated by dc) inside a band; lane b owns band b
   if (!fallback && lane < nband) {
@@ -855,7 +891,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
       }
     }
   }
-  __syncthreads();
+  wave_sync();
   const int nisl = s_nisl;
   fallback = fallback || nisl > C::ISL;
 
@@ -904,7 +940,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
     }
     return false;
   }
-  __syncthreads();
+  wave_sync();
 
   // ---- C: clear the bitmaps, stage the thresholded pixels of every island (16-byte loads)
   {
@@ -932,7 +968,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
       *reinterpret_cast<uint4*>(s_pix + is.pix_off + (size_t)yb * 16 * nbs + 16 * sc) = v;
     }
   }
-  __syncthreads();
+  wave_sync();
 
   // ---- D: blurred mask of every island
   {
@@ -948,11 +984,11 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
       const int xhi = min(g.cols - 1, 16 * is.chi + 15);
       const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
       const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1)};
-      blur_to_bitmap(pw, g.rows, g.cols, s_taps, dp.ksize, is.ylo + yb, c, s_nz + is.bm_off + (size_t)(yb + 1) * W,
+      blur_to_bitmap(pw, g.rows, g.cols, dp, s_taps, is.ylo + yb, c, s_nz + is.bm_off + (size_t)(yb + 1) * W,
                      16 * is.clo);
     }
   }
-  __syncthreads();
+  wave_sync();
   return true;
 }
 
@@ -966,90 +1002,96 @@ __device__ __forceinline__ void k1b_hand_over(int f, mpe_detections* __restrict_
   }
 }
 
-// The frames fr[0..nf) of one wave: front phases one after the other, contour phase together.
+// One block = C::WAVES frames.  Every wave runs the front phases of its own frame; the contour phase, in which one
+// LANE owns one island, is run by wave 0 over the islands of ALL the block's frames.  Measured on MI355X (16 384 C2
+// frames, 5 islands per frame): WAVES = 1 / 2 / 4 / 8 take 0.260 / 0.256 / 0.258 / 0.282 ms alone and 20.73 / 20.92 /
+// 20.99 / 21.97 ms per 262 144-frame step inside the pipeline (the other waves of a block wait at the barrier while
+// wave 0 follows the borders), so one frame per block stays the default.  `valid`: this wave has a frame.
 template <class C>
-__device__ __forceinline__ void k1b_wave(const int* fr, int nf, const uint8_t* __restrict__ frames,
+__device__ __forceinline__ void k1b_wave(const int f, const bool valid, const uint8_t* __restrict__ frames,
                                          const u64* __restrict__ flags, const FrameGeom& gslot, const DetectParams& dp,
                                          mpe_detections* __restrict__ dets, int* __restrict__ worklist,
                                          const FrameWin* __restrict__ wins) {
-  __shared__ K1bWaveLds<C> W;
-  __shared__ K1bFrameLds<C> S[C::FRAMES];
-  const int lane = threadIdx.x;
+  __shared__ K1bWaveLds<C> Wl[C::WAVES];
+  __shared__ K1bFrameLds<C> Sl[C::WAVES];
+  const int lane = threadIdx.x & 63;
+  const int wv = C::WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  K1bWaveLds<C>& W = Wl[wv];
+  K1bFrameLds<C>& S = Sl[wv];
   __syncthreads();  // (list mode: the previous group of this block is completely done)
   if (lane < MPE_MAX_KSIZE) W.taps[lane] = dp.taps[lane < dp.ksize ? lane : 0];
-  static_assert(C::FRAMES == 1, "per-frame windows assume one frame per wave");
   const size_t slot_bytes = (size_t)gslot.rows * gslot.pitch;
   int roi_x, roi_y;
-  const FrameGeom g = window_geom(gslot, wins, nf > 0 ? fr[0] : 0, dp, roi_x, roi_y);
-  bool ready[C::FRAMES];
-  int base[C::FRAMES + 1];
-  base[0] = 0;
-#pragma unroll
-  for (int i = 0; i < C::FRAMES; ++i) {
-    ready[i] = false;
-    if (i < nf) ready[i] = k1b_front<C>(fr[i], frames, slot_bytes, flags, g, dp, dets, worklist, W, S[i]);
-    base[i + 1] = base[i] + (ready[i] ? S[i].nisl : 0);
+  const FrameGeom g = window_geom(gslot, wins, valid ? f : 0, dp, roi_x, roi_y);
+  bool ready = false;
+  if (valid) ready = k1b_front<C>(f, frames, slot_bytes, flags, g, dp, dets, worklist, W, S);
+  if (lane == 0) {
+    S.ready = ready ? 1 : 0;
+    S.cols = g.cols;
+    S.roi_x = roi_x;
+    S.roi_y = roi_y;
   }
   __syncthreads();
 
-  // ---- E: one lane per island, over the islands of all frames of the wave (the islands are
+  // ---- E: one lane per island, over the islands of all frames of the block (the islands are
   //      independent, see the header comment)
-  for (int it = lane; it < base[C::FRAMES]; it += 64) {
-    int fi = 0;
+  if (wv == 0) {
+    int base[C::WAVES + 1];
+    base[0] = 0;
 #pragma unroll
-    for (int i = 1; i < C::FRAMES; ++i) fi += (it >= base[i]) ? 1 : 0;
-    K1bFrameLds<C>& F = S[fi];
-    const Island is = F.isl[it - base[fi]];
-    const int H = is.yhi - is.ylo + 1;
-    const int xhi = min(g.cols - 1, 16 * is.chi + 15);
-    const int Wd = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
-    scan_window(F.nz + is.bm_off, F.pm + is.bm_off, F.ng + is.bm_off, Wd, H, is.ylo, 16 * is.clo, dp, roi_x, roi_y,
-                &F.over,
-                [&](float mcx, float mcy, unsigned key) {
-                  const int k = atomicAdd(&F.nkept, 1);
-                  if (k < C::KEPT) {
-                    F.kx[k] = mcx;
-                    F.ky[k] = mcy;
-                    F.kkey[k] = key;
-                  }
-                });
+    for (int i = 0; i < C::WAVES; ++i) base[i + 1] = base[i] + (Sl[i].ready ? Sl[i].nisl : 0);
+    for (int it = lane; it < base[C::WAVES]; it += 64) {
+      int fi = 0;
+#pragma unroll
+      for (int i = 1; i < C::WAVES; ++i) fi += (it >= base[i]) ? 1 : 0;
+      K1bFrameLds<C>& F = Sl[fi];
+      const Island is = F.isl[it - base[fi]];
+      const int H = is.yhi - is.ylo + 1;
+      const int xhi = min(F.cols - 1, 16 * is.chi + 15);
+      const int Wd = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
+      scan_window(F.nz + is.bm_off, F.pm + is.bm_off, F.ng + is.bm_off, Wd, H, is.ylo, 16 * is.clo, dp, F.roi_x,
+                  F.roi_y, &F.over,
+                  [&](float mcx, float mcy, unsigned key) {
+                    const int k = atomicAdd(&F.nkept, 1);
+                    if (k < C::KEPT) {
+                      F.kx[k] = mcx;
+                      F.ky[k] = mcy;
+                      F.kkey[k] = key;
+                    }
+                  });
+    }
   }
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < C::FRAMES; ++i) {
-    if (!ready[i]) continue;
-    if (C::KEPT < 2 * MPE_MAX_DETECTIONS && S[i].nkept > C::KEPT) {  // more blobs than this tier records
-      if (lane == 0) k1b_hand_over(fr[i], dets, worklist);
-      continue;
-    }
-    write_detections(S[i].kx, S[i].ky, S[i].kkey, S[i].nkept, C::KEPT, S[i].over, dp, dets + fr[i], lane);
+  if (!ready) return;
+  if (C::KEPT < 2 * MPE_MAX_DETECTIONS && S.nkept > C::KEPT) {  // more blobs than this tier records
+    if (lane == 0) k1b_hand_over(f, dets, worklist);
+    return;
   }
+  write_detections(S.kx, S.ky, S.kkey, S.nkept, C::KEPT, S.over, dp, dets + f, lane);
 }
 
-// block b works on frames b * C::FRAMES ...
+// wave w of block b works on frame b * C::WAVES + w
 template <class C>
-__global__ __launch_bounds__(64) void k1b_blobs(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
-                                               FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
-                                               int* __restrict__ worklist, int n_frames,
-                                               const FrameWin* __restrict__ wins) {
-  int fr[C::FRAMES];
-  const int f0 = blockIdx.x * C::FRAMES;
-#pragma unroll
-  for (int i = 0; i < C::FRAMES; ++i) fr[i] = f0 + i;
-  k1b_wave<C>(fr, min((int)C::FRAMES, n_frames - f0), frames, flags, g, dp, dets, worklist, wins);
+__global__ __launch_bounds__(64 * C::WAVES, C::MIN_WAVES) void k1b_blobs(const uint8_t* __restrict__ frames,
+                                                           const u64* __restrict__ flags, FrameGeom g, DetectParams dp,
+                                                           mpe_detections* __restrict__ dets,
+                                                           int* __restrict__ worklist, int n_frames,
+                                                           const FrameWin* __restrict__ wins) {
+  const int f = blockIdx.x * C::WAVES + (int)(threadIdx.x >> 6);
+  k1b_wave<C>(f, f < n_frames, frames, flags, g, dp, dets, worklist, wins);
 }
 // frames taken from a device work-list (those the smaller tier handed over)
 template <class C>
-__global__ __launch_bounds__(64) void k1b_blobs_list(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
-                                                    FrameGeom g, DetectParams dp, mpe_detections* __restrict__ dets,
-                                                    const int* __restrict__ in_list, int* __restrict__ worklist,
-                                                    const FrameWin* __restrict__ wins) {
+__global__ __launch_bounds__(64 * C::WAVES, C::MIN_WAVES) void k1b_blobs_list(const uint8_t* __restrict__ frames,
+                                                                const u64* __restrict__ flags, FrameGeom g,
+                                                                DetectParams dp, mpe_detections* __restrict__ dets,
+                                                                const int* __restrict__ in_list,
+                                                                int* __restrict__ worklist,
+                                                                const FrameWin* __restrict__ wins) {
   const int count = in_list[0];
-  for (int w0 = blockIdx.x * C::FRAMES; w0 < count; w0 += gridDim.x * C::FRAMES) {
-    int fr[C::FRAMES];
-#pragma unroll
-    for (int i = 0; i < C::FRAMES; ++i) fr[i] = (w0 + i < count) ? in_list[1 + w0 + i] : 0;
-    k1b_wave<C>(fr, min((int)C::FRAMES, count - w0), frames, flags, g, dp, dets, worklist, wins);
+  for (int b0 = blockIdx.x * C::WAVES; b0 < count; b0 += gridDim.x * C::WAVES) {  // (uniform over the block)
+    const int w0 = b0 + (int)(threadIdx.x >> 6);
+    k1b_wave<C>(w0 < count ? in_list[1 + w0] : 0, w0 < count, frames, flags, g, dp, dets, worklist, wins);
   }
 }
 
@@ -1151,7 +1193,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
         while (tb) {
           const int c = tw * 64 + __builtin_ctzll(tb);
           tb &= tb - 1;
-          blur_to_bitmap(pw, gl.rows, gl.cols, s_taps, dp.ksize, y, c, nz + (size_t)(y + 1) * g.wb, 0);
+          blur_to_bitmap(pw, gl.rows, gl.cols, dp, s_taps, y, c, nz + (size_t)(y + 1) * g.wb, 0);
         }
       }
     __threadfence_block();
@@ -1192,8 +1234,8 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
   e = hipMemsetAsync(list_b, 0, sizeof(int), s);
   if (e != hipSuccess) return e;
   if (blob_hint > 0 && blob_hint <= 8) {  // (the small tier is cheap to try: frames that overflow it go on to the large one)
-    const int blocks = (n_frames + K1bSmall::FRAMES - 1) / K1bSmall::FRAMES;
-    hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
+    const int blocks = (n_frames + K1bSmall::WAVES - 1) / K1bSmall::WAVES;
+    hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64 * K1bSmall::WAVES), 0, s, frames, (const u64*)flags, g, dp, dets,
                        list_a, n_frames, wins);
     const int grid = n_frames < 2048 ? n_frames : 2048;
     hipLaunchKernelGGL((k1b_blobs_list<K1bLarge>), dim3(grid), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
