@@ -257,6 +257,8 @@ def main():
         scan_alone_ms = float(np.mean([sub[0]["scan"] for sub in subs]))
         kavg.update({"scan_standalone_first_sub_batch": scan_alone_ms, "vote_with_scan": vote_scan_ms,
                      "vote_last_sub_batch_without_scan": vote_plain_ms})
+        kavg["per_sub_batch"] = [{k: round(float(np.mean([sub[i][k] for sub in subs])), 4) for k in ("scan", "blobs", "vote", "tail")}
+                                 for i in range(launches)]
         scan_s = vote_scan_ms * 1e-3
         bytes_per_launch = rider_kib * 1024  # what ONE fused launch actually scanned (mode 6 gives part of a sub-batch to a side scan)
     else:
