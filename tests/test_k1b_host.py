@@ -1,0 +1,142 @@
+"""The DEVICE source of the blob extraction (threshold, fixed-point blur, Suzuki border following, polygon sums,
+shape filter, undistortion: everything of K1b that is not wave plumbing), compiled for the HOST and checked against
+the oracle's findLeds — the CPU tier has no GPU, but it can still run the very code the GPU runs.
+
+The region is cut out of rpg_monocular_pose_estimator_amd/csrc/mpe_kernels.hip at test time (tests/host/k1b_host.cpp
+holds the one-lane shims and the whole-frame flow of the device's general tier).  Reference being matched:
+led_detector.cpp:35-112 through oracle.find_leds."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rpg_monocular_pose_estimator_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rpg_monocular_pose_estimator_amd", "csrc")
+
+
+def _cut(text, begin, end):
+    i = text.index(begin)
+    return text[i:text.index(end, i)]
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    d = tmp_path_factory.mktemp("k1b_host")
+    hip = open(os.path.join(CSRC, "mpe_kernels.hip")).read()
+    internal = open(os.path.join(CSRC, "mpe_internal.h")).read()
+    inc = _cut(internal, "struct DetectParams {", "struct SolveParams {")
+    inc += _cut(hip, "struct BlobRec {", "// final stage: kept blobs")
+    with open(os.path.join(d, "k1b_extract.inc"), "w") as fh:
+        fh.write(inc)
+    so = os.path.join(d, "libk1b_host.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-I", str(d),
+                           os.path.join(ROOT, "tests", "host", "k1b_host.cpp"), "-o", so])
+    lib = C.CDLL(so)
+    lib.host_find_leds.restype = C.c_int
+    return lib
+
+
+def _host_find_leds(lib, orc, img, P, K, D, roi_xy=(0, 0)):
+    taps = np.ascontiguousarray(orc.gaussian_kernel_q8(P.gaussian_sigma), np.int32)
+    shape = np.array([P.min_blob_area, P.max_blob_area, P.max_width_height_distortion, P.max_circular_distortion])
+    Kf = np.ascontiguousarray(np.asarray(K, float).reshape(9))
+    Df = np.ascontiguousarray(np.asarray(D, float).reshape(-1))
+    cap = 4096
+    dist = np.zeros((cap, 2), np.float32)
+    und = np.zeros((cap, 2))
+    img = np.ascontiguousarray(img, np.uint8)
+    n = lib.host_find_leds(img.ctypes.data_as(C.c_void_p), img.shape[0], img.shape[1], int(P.threshold_value),
+                           taps.ctypes.data_as(C.c_void_p), len(taps), shape.ctypes.data_as(C.c_void_p),
+                           Kf.ctypes.data_as(C.c_void_p), Df.ctypes.data_as(C.c_void_p), len(Df), roi_xy[0], roi_xy[1],
+                           dist.ctypes.data_as(C.c_void_p), und.ctypes.data_as(C.c_void_p), cap)
+    assert n >= 0
+    return und[:n], dist[:n]
+
+
+@pytest.fixture(scope="module")
+def orc():
+    import oracle
+    oracle.build()
+    from oracle import binding
+    return binding
+
+
+def _random_image(rng, rows, cols, kind):
+    img = rng.integers(0, 60, (rows, cols)).astype(np.uint8)  # below the threshold
+    if kind == "spots":  # LED-like Gaussian spots, some on the border (mirrored blur taps)
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        for _ in range(rng.integers(1, 9)):
+            cx, cy = rng.uniform(-2, cols + 2), rng.uniform(-2, rows + 2)
+            s = rng.uniform(0.8, 4.0)
+            img = np.maximum(img, (255 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))).astype(np.uint8))
+    elif kind == "noise":  # salt: single pixels, thin lines, touching components, holes after the blur
+        m = rng.random((rows, cols)) < rng.uniform(0.01, 0.2)
+        img[m] = rng.integers(100, 256, m.sum())
+    else:  # rings and bars: nested components and holes (RETR_EXTERNAL must skip what lies inside)
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        for _ in range(rng.integers(1, 5)):
+            cx, cy, r = rng.uniform(0, cols), rng.uniform(0, rows), rng.uniform(5, 30)
+            d = np.hypot(xx - cx, yy - cy)
+            for rr in np.arange(r, 4, -rng.uniform(6, 9)):  # concentric rings ...
+                img[(d > rr - 1.5) & (d < rr + 1.0)] = 255
+            if rng.random() < 0.7:
+                img[(d < 1.8)] = 230                         # ... around a disc
+        if rng.random() < 0.5:
+            y0 = rng.integers(0, rows)
+            img[y0:y0 + 1, rng.integers(0, cols // 2):] = 200
+    return img
+
+
+@pytest.mark.parametrize("kind", ["spots", "noise", "rings"])
+def test_device_blob_source_on_the_host_equals_the_oracle(host, orc, kind):
+    rng = np.random.default_rng({"spots": 1, "noise": 2, "rings": 3}[kind])
+    n_blobs = 0
+    for it in range(400):
+        rows, cols = int(rng.integers(8, 90)), int(rng.integers(18, 150))
+        img = _random_image(rng, rows, cols, kind)
+        K, D = synth.camera_for(rows, cols)
+        if it % 3 == 0:  # wide-open shape filter: every traced contour with a non-degenerate box is reported
+            P = orc.make_params(min_blob_area=0.0, max_blob_area=1e9, max_width_height_distortion=1e9,
+                                max_circular_distortion=1e9, gaussian_sigma=[0.6, 0.5, 0.85][it % 9 // 3])
+        else:
+            P = orc.make_params(gaussian_sigma=0.6 if it % 2 else 0.4)
+        roi_xy = (int(rng.integers(0, 50)), int(rng.integers(0, 50))) if it % 4 == 1 else (0, 0)
+        # (the oracle adds the ROI origin of the window it is given; here the window is the whole small image and the
+        #  origin is only the float offset of led_detector.cpp:74)
+        ref_und, ref_dist = orc.find_leds(np.pad(img, ((roi_xy[1], 0), (roi_xy[0], 0))), P, K, D,
+                                          roi=(roi_xy[0], roi_xy[1], cols, rows))
+        und, dist = _host_find_leds(host, orc, img, P, K, D, roi_xy)
+        assert len(dist) == len(ref_dist), (kind, it, len(dist), len(ref_dist))
+        assert np.array_equal(dist, ref_dist), (kind, it)            # float32 centroids, bit for bit, same order
+        assert np.array_equal(und, ref_und), (kind, it)              # undistorted: float32 stored as double
+        n_blobs += len(dist)
+    assert n_blobs > 100, n_blobs
+
+
+def test_blurred_value_exactly_at_the_rounding_boundary(host, orc):
+    """GaussianBlur keeps a pixel iff (sum + 2^15) >> 16 != 0, i.e. sum >= 2^15.  With taps [1, 42, 170, 42, 1] three dim
+    pixels (1 at the output position, 2 one step diagonally, 2 two steps to the side) give exactly
+    170*170 + 2*42*42 + 2*170 = 32768; the mask pixel they switch on touches the halo of a bright block three pixels
+    away, so it changes that blob's contour and centroid: '>=' and '>' give different answers."""
+    img = np.zeros((40, 48), np.uint8)
+    img[10:20, 10:20] = 255              # its blurred mask reaches x = 21 (two pixels beyond the block)
+    y, x = 15, 22                        # diagonal neighbour of the halo: 8-connected to the blob
+    img[y, x] = 1
+    img[y + 1, x + 1] = 2
+    img[y, x + 2] = 2
+    K, D = synth.camera_for(40, 48)
+    P = orc.make_params(threshold_value=0, gaussian_sigma=0.6, min_blob_area=0.0, max_blob_area=1e9,
+                        max_width_height_distortion=1e9, max_circular_distortion=1e9)
+    assert list(orc.gaussian_kernel_q8(0.6)) == [1, 42, 170, 42, 1]
+    blurred, mask = orc.blur_mask(img, 0, 0.6)
+    assert mask[y, x] and not mask[y - 1, x] and not mask[y + 1, x]   # the bridge between the halo and (y, x + 1)
+    ref_und, ref_dist = orc.find_leds(img, P, K, D)
+    und, dist = _host_find_leds(host, orc, img, P, K, D)
+    assert len(ref_dist) == 1 and np.array_equal(dist, ref_dist) and np.array_equal(und, ref_und)
+    img[y, x] = 0                                      # below the boundary: the bridge is gone and the answer changes
+    _, dist2 = _host_find_leds(host, orc, img, P, K, D)
+    assert not np.array_equal(dist2, dist)
