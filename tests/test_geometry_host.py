@@ -1,0 +1,105 @@
+"""The DEVICE geometry source — mpe_p3p.h (Ferrari quartic in both arithmetics, Kneip P3P) and the tail helpers of
+mpe_kernels.hip (Hestenes-Jacobi Kabsch rotation, LDL^T solve, exponential-map update) — compiled for the HOST and
+checked against the oracle with the same criteria the `-m gpu` tests apply to the kernels.  The CPU tier has no GPU,
+but it can still run the source the GPU runs; only the hardware reciprocal / rsqrt seeds of the fast arithmetic are
+replaced (tests/host/stub/hip/hip_runtime.h).  Reference: p3p.cpp:65-286, pose_estimator.cpp:908-994."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rpg_monocular_pose_estimator_amd import synth
+from util import p3p_test_problems, check_p3p_solutions, quartic_test_problems, check_quartic_roots
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rpg_monocular_pose_estimator_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    d = tmp_path_factory.mktemp("geom_host")
+    hip = open(os.path.join(CSRC, "mpe_kernels.hip")).read()
+    i = hip.index("struct T34 {")
+    with open(os.path.join(d, "k3_extract.inc"), "w") as fh:
+        fh.write(hip[i:hip.index("#define K3_GROUP", i)])
+    so = os.path.join(d, "libgeom_host.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-I", str(d),
+                           "-I", os.path.join(ROOT, "tests", "host", "stub"), "-I", CSRC,
+                           os.path.join(ROOT, "tests", "host", "geom_host.cpp"), "-o", so])
+    return C.CDLL(so)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    import oracle
+    oracle.build()
+    from oracle import binding
+    return binding
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_device_quartic_on_the_host(host, orc, variant):
+    f, roots = quartic_test_problems(variant)
+    f = np.ascontiguousarray(f)
+    got = np.zeros((len(f), 4))
+    host.host_quartic(_ptr(f), len(f), variant, _ptr(got))
+    check_quartic_roots(got, f, roots, orc)
+
+
+def test_device_p3p_on_the_host(host, orc):
+    fv, wp = p3p_test_problems()
+    fv, wp = np.ascontiguousarray(fv), np.ascontiguousarray(wp)
+    sol = np.zeros((len(fv), 4, 3, 4))
+    st = np.zeros(len(fv), np.int32)
+    host.host_p3p(_ptr(fv), _ptr(wp), len(fv), _ptr(sol), _ptr(st))
+    check_p3p_solutions(st, sol, fv, wp, orc)
+
+
+def test_device_kabsch_on_the_host(host, orc):
+    """R = V U^T without reflection guard (pose_estimator.cpp:908-930), general and COPLANAR point sets (rank-2 H:
+    the sigma <= 1e-12 sigma_max column is completed by the cross product, as in the oracle)."""
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for it in range(400):
+        n = int(rng.integers(4, 9))
+        obj = rng.uniform(-0.3, 0.3, (n, 3))
+        if it % 2:
+            obj[:, 2] = 0.0                                  # planar rig
+        ax = rng.normal(size=3)
+        R0 = synth.rodrigues(ax / np.linalg.norm(ax), rng.uniform(0, 3.0))
+        rep = obj @ R0.T + rng.uniform(-1, 1, 3) + rng.normal(0, 1e-3, (n, 3))
+        T = orc.compute_transformation(obj, rep)
+        A, B = obj - obj.mean(axis=0), rep - rep.mean(axis=0)
+        H = np.ascontiguousarray(A.T @ B)
+        R = np.zeros((3, 3))
+        host.host_kabsch(_ptr(H), _ptr(R))
+        worst = max(worst, float(np.abs(R - T[:3, :3]).max()))
+    assert worst < 1e-9, worst
+
+
+def test_device_exponential_map_and_ldl_on_the_host(host, orc):
+    rng = np.random.default_rng(4)
+    for it in range(300):
+        tw = rng.normal(0, [0.1, 0.01, 1e-6][it % 3], 6)
+        if it == 7:
+            tw[3:] = 0.0                                     # theta == 0 branch
+        T0 = np.eye(4)
+        ax = rng.normal(size=3)
+        T0[:3, :3] = synth.rodrigues(ax / np.linalg.norm(ax), rng.uniform(0, 2.0))
+        T0[:3, 3] = rng.uniform(-1, 1, 3)
+        want = orc.exponential_map(tw) @ T0                  # T <- exp(dT) T, pose_estimator.cpp:781
+        got = np.ascontiguousarray(T0[:3, :])
+        host.host_apply_exp(_ptr(np.ascontiguousarray(tw)), _ptr(got))
+        assert np.abs(got - want[:3, :]).max() < 1e-14, it
+        J = rng.normal(size=(10, 6))
+        A = np.ascontiguousarray(J.T @ J)
+        b = rng.normal(size=6)
+        x = np.zeros(6)
+        host.host_ldl_solve(_ptr(A), _ptr(np.ascontiguousarray(b)), _ptr(x))
+        assert np.abs(x - np.linalg.solve(A, b)).max() < 1e-9 * max(1.0, np.abs(x).max()), it
