@@ -148,6 +148,7 @@ int make_detect_params(const mpe_params* p, const double K[9], const double* D, 
   dp.thr = p->threshold_value < -1 ? -1 : (p->threshold_value > 255 ? 255 : p->threshold_value);
   dp.ksize = gaussian_taps(p->gaussian_sigma, dp.taps);
   if (dp.ksize < 0) return -1;
+  pack_taps(dp);
   dp.min_area = p->min_blob_area;
   dp.max_area = p->max_blob_area;
   dp.max_wh = p->max_width_height_distortion;

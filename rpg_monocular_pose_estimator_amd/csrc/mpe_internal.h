@@ -32,7 +32,19 @@ struct DetectParams {
   double k[8];  // distortion coefficients k1 k2 p1 p2 k3 k4 k5 k6
   int undist_iters;
   int roi_x, roi_y;  // added to the centroid (float add), LED.cpp:74
+  // the taps as bytes for the packed dot product of the blur: [0] = taps 0..3, [1] = tap 4 in byte 0; taps_u8 = 0 when
+  // a tap does not fit a byte (a centre tap of 256 at sigma < 0.3: the byte-wise blur code then does the work)
+  unsigned taps_packed[2];
+  int taps_u8;
 };
+inline void pack_taps(DetectParams& dp) {
+  dp.taps_packed[0] = dp.taps_packed[1] = 0;
+  dp.taps_u8 = 1;
+  for (int i = 0; i < dp.ksize && i < MPE_MAX_KSIZE; ++i) {
+    if (dp.taps[i] < 0 || dp.taps[i] > 255) dp.taps_u8 = 0;
+    if (i < 8) dp.taps_packed[i >> 2] |= ((unsigned)dp.taps[i] & 0xFFu) << (8 * (i & 3));
+  }
+}
 
 struct SolveParams {
   int n_markers;

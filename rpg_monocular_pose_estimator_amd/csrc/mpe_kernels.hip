@@ -232,10 +232,11 @@ template <int KS, bool EDGE>
 __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, int cols, int y, int c,
                                                    const DetectParams& dp, unsigned zone, unsigned& edge_or) {
   constexpr int R = KS / 2;
-  int taps[KS];  // constant indices into the by-value kernel argument: scalar registers, no LDS traffic
-#pragma unroll
-  for (int j = 0; j < KS; ++j) taps[j] = dp.taps[j];
-  int acc[16];
+  // The horizontal pass as packed byte dot products: the four bytes from input position x .. x + 3 against taps 0..3
+  // (v_dot4_u32_u8), for five taps a second one for tap 4.  Integer arithmetic throughout: the same sums as tap by
+  // tap, in any order.  (Constant indices into the by-value kernel argument: scalar registers, no LDS traffic.)
+  const unsigned TA = dp.taps_packed[0], TB = dp.taps_packed[1];
+  unsigned acc[16];
 #pragma unroll
   for (int x = 0; x < 16; ++x) acc[x] = 0;
   unsigned eor = 0;
@@ -250,26 +251,32 @@ __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, in
     const uint4 q1 = ((unsigned)(sc + 1) < (unsigned)nsw) ? p[sc + 1] : z4;
     const uint4 q2 = ((unsigned)(sc + 2) < (unsigned)nsw) ? p[sc + 2] : z4;
     const unsigned q[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
-    int t[16 + 2 * R];
+    if (EDGE) {
 #pragma unroll
-    for (int j = 0; j < 16 + 2 * R; ++j) {
-      const int k = 16 - R + j;
-      t[j] = (int)((q[k >> 2] >> (8 * (k & 3))) & 0xFFu);
-      if (EDGE) eor |= ((zone >> j) & 1u) ? (unsigned)t[j] : 0u;
+      for (int j = 0; j < 16 + 2 * R; ++j) {
+        const int k = 16 - R + j;
+        eor |= ((zone >> j) & 1u) ? ((q[k >> 2] >> (8 * (k & 3))) & 0xFFu) : 0u;
+      }
     }
-    const int ky = taps[i];
+    constexpr int NW = 16 + (KS > 4 ? 4 : 0);
+    unsigned win[NW];  // win[x] = the bytes of input positions x .. x + 3 (position j = pixel x0 - R + j)
+#pragma unroll
+    for (int x = 0; x < NW; ++x) {
+      const int k = 16 - R + x;
+      win[x] = (k & 3) ? __builtin_amdgcn_alignbyte(q[(k >> 2) + 1], q[k >> 2], k & 3) : q[k >> 2];
+    }
+    const unsigned ky = (unsigned)dp.taps[i];
 #pragma unroll
     for (int x = 0; x < 16; ++x) {
-      int h = 0;
-#pragma unroll
-      for (int j = 0; j < KS; ++j) h += taps[j] * t[x + j];
+      unsigned h = __builtin_amdgcn_udot4(win[x], TA, 0u, false);
+      if (KS > 4) h = __builtin_amdgcn_udot4(win[x + 4], TB, h, false);
       acc[x] += ky * h;
     }
   }
   unsigned m = 0;
 #pragma unroll
   for (int x = 0; x < 16; ++x)
-    if (acc[x] >= (1 << 15)) m |= 1u << x;
+    if (acc[x] >= (1u << 15)) m |= 1u << x;
   if (EDGE) {
     edge_or = eor;
     const int valid = cols - 16 * c;  // outputs at x >= cols do not exist
@@ -577,11 +584,11 @@ __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int c
   unsigned m = 0;
   const bool interior = (x0 - r >= 0) && (x0 + 15 + r < cols);
   unsigned edge_or = 0;
-  if (interior && ksize == 5) {
+  if (interior && ksize == 5 && dp.taps_u8) {
     m = blur_item_fast<5, false>(pw, rows, cols, y, c, dp, 0u, edge_or);
-  } else if (interior && ksize == 3) {
+  } else if (interior && ksize == 3 && dp.taps_u8) {
     m = blur_item_fast<3, false>(pw, rows, cols, y, c, dp, 0u, edge_or);
-  } else if ((ksize == 5 || ksize == 3) && cols >= 2 * r + 2) {
+  } else if ((ksize == 5 || ksize == 3) && dp.taps_u8 && cols >= 2 * r + 2) {
     // border segment: mirrored input positions j (pixel x = x0 - r + j): left border x in [1, r], right border
     // x in [cols - 1 - r, cols - 2]
     unsigned zone = 0;

@@ -34,6 +34,13 @@ static inline unsigned __builtin_bitreverse32(unsigned v) {
     if ((v >> i) & 1) r |= 1u << (31 - i);
   return r;
 }
+static inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh) {
+  return (unsigned)(((((u64)hi) << 32) | lo) >> (8 * (sh & 3)));
+}
+static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool) {
+  for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
+  return c;
+}
 #include "k1b_extract.inc"
 
 extern "C" int host_find_leds(const uint8_t* img, int rows, int cols, int thr, const int* taps, int ksize,
@@ -45,6 +52,7 @@ extern "C" int host_find_leds(const uint8_t* img, int rows, int cols, int thr, c
   dp.thr = thr;
   dp.ksize = ksize;
   for (int i = 0; i < ksize; ++i) dp.taps[i] = taps[i];
+  pack_taps(dp);
   dp.min_area = shape[0];
   dp.max_area = shape[1];
   dp.max_wh = shape[2];

@@ -101,7 +101,7 @@ def test_device_blob_source_on_the_host_equals_the_oracle(host, orc, kind):
         K, D = synth.camera_for(rows, cols)
         if it % 3 == 0:  # wide-open shape filter: every traced contour with a non-degenerate box is reported
             P = orc.make_params(min_blob_area=0.0, max_blob_area=1e9, max_width_height_distortion=1e9,
-                                max_circular_distortion=1e9, gaussian_sigma=[0.6, 0.5, 0.85][it % 9 // 3])
+                                max_circular_distortion=1e9, gaussian_sigma=[0.6, 0.5, 0.85, 0.2][it % 12 // 3])  # 5, 3, 7 taps; [0, 256, 0]
         else:
             P = orc.make_params(gaussian_sigma=0.6 if it % 2 else 0.4)
         roi_xy = (int(rng.integers(0, 50)), int(rng.integers(0, 50))) if it % 4 == 1 else (0, 0)
@@ -111,8 +111,9 @@ def test_device_blob_source_on_the_host_equals_the_oracle(host, orc, kind):
                                           roi=(roi_xy[0], roi_xy[1], cols, rows))
         und, dist = _host_find_leds(host, orc, img, P, K, D, roi_xy)
         assert len(dist) == len(ref_dist), (kind, it, len(dist), len(ref_dist))
-        assert np.array_equal(dist, ref_dist), (kind, it)            # float32 centroids, bit for bit, same order
-        assert np.array_equal(und, ref_und), (kind, it)              # undistorted: float32 stored as double
+        assert np.array_equal(dist, ref_dist, equal_nan=True), (kind, it)   # float32 centroids, bit for bit, same order
+        # (a zero-area contour that the wide-open filter lets through has a 0 / 0 centroid on both sides)
+        assert np.array_equal(und, ref_und, equal_nan=True), (kind, it)     # undistorted: float32 stored as double
         n_blobs += len(dist)
     assert n_blobs > 100, n_blobs
 
