@@ -460,6 +460,8 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     unsigned long long* fl;
     sub_ptrs(0, f0, nf, fr, fl);
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][0], st));
+    // the work-lists of all sub-batches with one memset (instead of one per sub-batch in front of its blob kernels)
+    HIP_TRY(h, hipMemsetAsync(h->work.p, 0, (size_t)2 * (per + 1) * nsub * sizeof(int), st));
     HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, scan_lds(h, false), st));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][1], st));
     // side scan of the first part of sub-batch k (k >= 1), gated so that it runs in the blob / tail window that
@@ -491,7 +493,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], st));
       HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
                                   static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
-                                  static_cast<uint8_t*>(h->scratch.p), sp->n_markers, st));
+                                  static_cast<uint8_t*>(h->scratch.p), sp->n_markers, st, nullptr, true));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], st));
       uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
       // (with one voting block per frame the kernel stores every histogram row the tail reads: no memset)

@@ -1229,17 +1229,18 @@ size_t k1b_scratch_bytes(const FrameGeom& g) { return k1b_gen_scratch_bytes(g) *
 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
-                            int blob_hint, hipStream_t s, const void* frame_windows) {
+                            int blob_hint, hipStream_t s, const void* frame_windows, bool lists_zeroed) {
   const FrameWin* wins = static_cast<const FrameWin*>(frame_windows);
   // Three tiers, chained through device work-lists (no host round trip):
   //   small LDS pools (3 waves/SIMD) -> large LDS pools -> whole-frame window in global scratch
   if (n_frames <= 0) return hipSuccess;
   int* list_a = worklist;                   // small -> large
   int* list_b = worklist + (n_frames + 1);  // large -> general
-  hipError_t e = hipMemsetAsync(list_a, 0, sizeof(int), s);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(list_b, 0, sizeof(int), s);
-  if (e != hipSuccess) return e;
+  hipError_t e = hipSuccess;
+  if (!lists_zeroed) {  // both counters with ONE memset: list_b's counter sits right behind list_a's entries
+    e = hipMemsetAsync(list_a, 0, (size_t)(n_frames + 2) * sizeof(int), s);
+    if (e != hipSuccess) return e;
+  }
   if (blob_hint > 0 && blob_hint <= 8) {  // (the small tier is cheap to try: frames that overflow it go on to the large one)
     const int blocks = (n_frames + K1bSmall::WAVES - 1) / K1bSmall::WAVES;
     hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64 * K1bSmall::WAVES), 0, s, frames, (const u64*)flags, g, dp, dets,
