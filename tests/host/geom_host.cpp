@@ -6,6 +6,7 @@
 #include "mpe_p3p.h"
 namespace mpe {
 #include "k3_extract.inc"
+#include "k2_extract.inc"  // unrank_combo3, bearing, pick_root, perm_from_index
 }
 using namespace mpe;
 
@@ -68,4 +69,17 @@ extern "C" void host_ldl_solve(const double* A, const double* b, double* x) {
   std::memset(&F, 0, sizeof(F));
   ldl6_factor(a, F);
   ldl6_solve(F, b, x);
+}
+
+// the index arithmetic of the voting kernel: idx-th detection triple, pj-th marker permutation (0-based)
+extern "C" void host_unrank(int n, int n_combos, int n_perms, int* combos, int* perms) {
+  for (int i = 0; i < n_combos; ++i) unrank_combo3(i, n, combos[3 * i], combos[3 * i + 1], combos[3 * i + 2]);
+  for (int i = 0; i < n_perms; ++i) perm_from_index(i, n, perms[3 * i], perms[3 * i + 1], perms[3 * i + 2]);
+}
+
+extern "C" void host_bearing(double u, double v, const double* k4, double* out) {
+  const V3 b = bearing(u, v, k4[0], k4[1], k4[2], k4[3]);
+  out[0] = b.x;
+  out[1] = b.y;
+  out[2] = b.z;
 }

@@ -24,6 +24,11 @@ def host(tmp_path_factory):
     i = hip.index("struct T34 {")
     with open(os.path.join(d, "k3_extract.inc"), "w") as fh:
         fh.write(hip[i:hip.index("#define K3_GROUP", i)])
+    i = hip.index("// lexicographic unranking of the idx-th 3-combination")
+    with open(os.path.join(d, "k2_extract.inc"), "w") as fh:
+        fh.write(hip[i:hip.index("#define K2_THREADS", i)])
+        i = hip.index("__device__ __forceinline__ void perm_from_index(")
+        fh.write(hip[i:hip.index("__global__ void k2_prep_markers(", i)])
     so = os.path.join(d, "libgeom_host.so")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-I", str(d),
                            "-I", os.path.join(ROOT, "tests", "host", "stub"), "-I", CSRC,
@@ -103,3 +108,25 @@ def test_device_exponential_map_and_ldl_on_the_host(host, orc):
         x = np.zeros(6)
         host.host_ldl_solve(_ptr(A), _ptr(np.ascontiguousarray(b)), _ptr(x))
         assert np.abs(x - np.linalg.solve(A, b)).max() < 1e-9 * max(1.0, np.abs(x).max()), it
+
+
+def test_device_index_arithmetic_on_the_host(host, orc):
+    """The voting kernel enumerates (detection triple, marker permutation) by index instead of building the
+    reference's tables (combinations.cpp:52-244): its unranking must reproduce those tables row by row."""
+    for n in range(3, 33):
+        ref_c = orc.combinations3(n).astype(np.int64) - 1      # the reference's tables are 1-based
+        ref_p = orc.permutations3(n).astype(np.int64) - 1
+        combos = np.zeros((len(ref_c), 3), np.int32)
+        perms = np.zeros((len(ref_p), 3), np.int32)
+        host.host_unrank(n, len(ref_c), len(ref_p) if n <= 8 else 0, _ptr(combos), _ptr(perms))
+        assert np.array_equal(combos, ref_c), n
+        if n <= 8:                                              # marker sets hold at most 8 markers
+            assert np.array_equal(perms, ref_p), n
+    rng = np.random.default_rng(9)
+    K4 = np.array([430.0, 431.5, 376.2, 239.9])
+    for _ in range(200):
+        u, v = rng.uniform(0, 752), rng.uniform(0, 480)
+        out = np.zeros(3)
+        host.host_bearing(C.c_double(u), C.c_double(v), _ptr(K4), _ptr(out))
+        Km = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1]])
+        assert np.array_equal(out, orc.image_vectors(np.array([[u, v]]), Km)[0])
