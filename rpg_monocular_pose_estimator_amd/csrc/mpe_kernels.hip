@@ -1316,46 +1316,50 @@ __device__ __forceinline__ void perm_from_index(int pj, int n_m, int& p0, int& p
   }
 }
 
+// one entry of the table (layout above) -> e
+__device__ __forceinline__ void k2_marker_entry(const SolveParams& sp, int pj, double* __restrict__ e) {
+  const int n_m = sp.n_markers;
+  int p0, p1, p2;
+  perm_from_index(pj, n_m, p0, p1, p2);
+  const V3 P1 = {sp.markers[3 * p0], sp.markers[3 * p0 + 1], sp.markers[3 * p0 + 2]};
+  const V3 P2 = {sp.markers[3 * p1], sp.markers[3 * p1 + 1], sp.markers[3 * p1 + 2]};
+  const V3 P3 = {sp.markers[3 * p2], sp.markers[3 * p2 + 1], sp.markers[3 * p2 + 2]};
+  const bool valid = norm(cross(P2 - P1, P3 - P1)) != 0.0;  // p3p.cpp:77-80
+  V3 n1 = P2 - P1;
+  n1 = vdiv(n1, norm(n1));
+  V3 n3 = cross(n1, P3 - P1);
+  n3 = vdiv(n3, norm(n3));
+  const V3 n2 = cross(n3, n1);
+  const M3 N = {n1, n2, n3};
+  const V3 P3n = mul(N, P3 - P1);
+  e[0] = n1.x; e[1] = n1.y; e[2] = n1.z;
+  e[3] = n2.x; e[4] = n2.y; e[5] = n2.z;
+  e[6] = n3.x; e[7] = n3.y; e[8] = n3.z;
+  e[9] = P1.x; e[10] = P1.y; e[11] = P1.z;
+  e[12] = P3n.x;
+  e[13] = P3n.y;
+  e[14] = norm(P2 - P1);
+  e[15] = valid ? 1.0 : 0.0;
+  e[16] = (double)(p0 | (p1 << 8) | (p2 << 16));
+  e[17] = 0.0;
+  int u = 0;
+  for (int m = 0; m < n_m; ++m) {
+    if (m == p0 || m == p1 || m == p2) continue;
+    const V3 mm = {sp.markers[3 * m], sp.markers[3 * m + 1], sp.markers[3 * m + 2]};
+    const V3 me = mul(N, mm - P1);
+    e[18 + 3 * u] = me.x;
+    e[18 + 3 * u + 1] = me.y;
+    e[18 + 3 * u + 2] = me.z;
+    ++u;
+  }
+}
+
 __global__ void k2_prep_markers(SolveParams sp, double* __restrict__ tab) {
   const int n_m = sp.n_markers;
   const int n_perms = n_m * (n_m - 1) * (n_m - 2);
   const int esz = k2_entry_doubles(n_m);
-  for (int pj = blockIdx.x * blockDim.x + threadIdx.x; pj < n_perms; pj += gridDim.x * blockDim.x) {
-    int p0, p1, p2;
-    perm_from_index(pj, n_m, p0, p1, p2);
-    const V3 P1 = {sp.markers[3 * p0], sp.markers[3 * p0 + 1], sp.markers[3 * p0 + 2]};
-    const V3 P2 = {sp.markers[3 * p1], sp.markers[3 * p1 + 1], sp.markers[3 * p1 + 2]};
-    const V3 P3 = {sp.markers[3 * p2], sp.markers[3 * p2 + 1], sp.markers[3 * p2 + 2]};
-    double* e = tab + (size_t)pj * esz;
-    const bool valid = norm(cross(P2 - P1, P3 - P1)) != 0.0;  // p3p.cpp:77-80
-    V3 n1 = P2 - P1;
-    n1 = vdiv(n1, norm(n1));
-    V3 n3 = cross(n1, P3 - P1);
-    n3 = vdiv(n3, norm(n3));
-    const V3 n2 = cross(n3, n1);
-    const M3 N = {n1, n2, n3};
-    const V3 P3n = mul(N, P3 - P1);
-    e[0] = n1.x; e[1] = n1.y; e[2] = n1.z;
-    e[3] = n2.x; e[4] = n2.y; e[5] = n2.z;
-    e[6] = n3.x; e[7] = n3.y; e[8] = n3.z;
-    e[9] = P1.x; e[10] = P1.y; e[11] = P1.z;
-    e[12] = P3n.x;
-    e[13] = P3n.y;
-    e[14] = norm(P2 - P1);
-    e[15] = valid ? 1.0 : 0.0;
-    e[16] = (double)(p0 | (p1 << 8) | (p2 << 16));
-    e[17] = 0.0;
-    int u = 0;
-    for (int m = 0; m < n_m; ++m) {
-      if (m == p0 || m == p1 || m == p2) continue;
-      const V3 mm = {sp.markers[3 * m], sp.markers[3 * m + 1], sp.markers[3 * m + 2]};
-      const V3 me = mul(N, mm - P1);
-      e[18 + 3 * u] = me.x;
-      e[18 + 3 * u + 1] = me.y;
-      e[18 + 3 * u + 2] = me.z;
-      ++u;
-    }
-  }
+  for (int pj = blockIdx.x * blockDim.x + threadIdx.x; pj < n_perms; pj += gridDim.x * blockDim.x)
+    k2_marker_entry(sp, pj, tab + (size_t)pj * esz);
 }
 
 hipError_t launch_k2_prep(const SolveParams& sp, double* tab, hipStream_t s) {
@@ -1476,6 +1480,249 @@ struct NoRider {
   __device__ __forceinline__ void drain() {}
 };
 
+// Everything of computePoses that depends on the detection triple only (p3p.cpp:82-121, 143-154): the tau frame T
+// (rows, t[0..8]), f_1, f_2, b, f_1 / f_2 (t[9..12]) and the triple's indices + the swap flag (packed).
+__device__ __forceinline__ void k2_triple_entry(const double (*iv)[3], int n_d, int idx, double* __restrict__ t,
+                                                unsigned& packed) {
+  int c0, c1, c2;
+  unrank_combo3(idx, n_d, c0, c1, c2);
+  const V3 fa = {iv[c0][0], iv[c0][1], iv[c0][2]}, fb = {iv[c1][0], iv[c1][1], iv[c1][2]},
+           fc = {iv[c2][0], iv[c2][1], iv[c2][2]};
+  V3 f1 = fa, f2 = fb;
+  V3 e1 = f1;
+  V3 e3 = cross(f1, f2);
+  e3 = vdiv(e3, norm(e3));
+  V3 e2 = cross(e3, e1);
+  M3 T = {e1, e2, e3};
+  V3 f3 = mul(T, fc);
+  unsigned swap = 0;
+  if (f3.z > 0.0) {
+    swap = 1;
+    f1 = fb;
+    f2 = fa;
+    e1 = f1;
+    e3 = cross(f1, f2);
+    e3 = vdiv(e3, norm(e3));
+    e2 = cross(e3, e1);
+    T = {e1, e2, e3};
+    f3 = mul(T, fc);
+  }
+  const double cos_beta = dot(f1, f2);
+  double b = 1 / (1 - cos_beta * cos_beta) - 1;
+  b = (cos_beta < 0) ? -sqrt(b) : sqrt(b);
+  t[0] = T.r0.x; t[1] = T.r0.y; t[2] = T.r0.z;
+  t[3] = T.r1.x; t[4] = T.r1.y; t[5] = T.r1.z;
+  t[6] = T.r2.x; t[7] = T.r2.y; t[8] = T.r2.z;
+  t[9] = f3.x / f3.z;
+  t[10] = f3.y / f3.z;
+  t[11] = b;
+  t[12] = t[9] / t[10];
+  packed = (unsigned)c0 | ((unsigned)c1 << 8) | ((unsigned)c2 << 16) | (swap << 24);
+}
+
+// What a voting work item reads of its frame and block (LDS in the kernels; plain arrays when the host-tier test runs
+// this source, tests/test_vote_host.py).
+struct K2Frame {
+  const unsigned* trii;      // per staged triple: c0 | c1 << 8 | c2 << 16 | swap << 24
+  const double (*tri)[13];   // per staged triple: T rows, f_1, f_2, b, f_1 / f_2
+  const double (*px)[2];     // undistorted detections
+  const f32x2* pxf;          // the same in single precision (nearest-neighbour prefilter)
+  double* q;                 // back-projections [2 * j + {0, 1}][lane] (plain variant)
+  f32x2* qf;                 // their single-precision copies [j][lane]
+  unsigned* hist;            // vote histogram of the frame
+  const double* tab;         // marker-permutation table (global memory; plain variant)
+  const double* ltab;        // its LDS copy, K2_LTAB doubles per permutation (scan-carrying variant)
+  int n_d, nuo, nthr, tid, esz;
+  double fx, fy, cx, cy, back_tol;
+  float thr_pre;
+};
+
+// Nearest-neighbour prefilter: a detection can only vote if its exact distance to some back-projection is below
+// tol; single precision places both points within 1e-3 px for any point that close to a detection (pixel
+// coordinates < 4096), so "minimum single-precision distance <= tol (1 + 1e-4) + 0.05" is a safe necessary
+// condition, and the exact double-precision search only runs for the few detections that pass it.
+__device__ __forceinline__ float k2_prefilter_threshold(double back_tol) {
+  const double tol_pre = back_tol * (1.0 + 1e-4) + 0.05;
+  return (float)(tol_pre * tol_pre * (1.0 + 1e-5));
+}
+
+// One work item = (staged detection triple ti, marker permutation pj): quartic coefficients (p3p.cpp:171-185),
+// Ferrari, and for each root the back-projection of the unused markers and the nearest-neighbour votes
+// (pose_estimator.cpp:596-702).  `live` = false: compute on, never vote (wave-uniform loop of the rider variant).
+template <bool SCAN, class Rider>
+__device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, bool live, Rider& rider) {
+  const double fx = F.fx, fy = F.fy, cx = F.cx, cy = F.cy;
+  const unsigned ii = F.trii[ti];
+  const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
+  const bool swap = (ii >> 24) & 1;
+  const int packed = SCAN ? (int)F.ltab[pj * K2_LTAB + 4]
+                          : (int)F.tab[(size_t)pj * F.esz + 16];  // marker indices of this permutation
+  const int p0 = packed & 0xFF, p1 = (packed >> 8) & 0xFF, p2 = (packed >> 16) & 0xFF;
+  const int r6 = pj % 6;
+  const int pjs = swap ? (pj - r6 + (int)((0x134052u >> (4 * r6)) & 7u)) : pj;  // kSwapRow packed
+  // e[12..] of the global table entry; in the scan-carrying variant e points into the LDS copy, shifted so
+  // that the SAME indices work for p_1 p_2 d_12 valid (12..15), and the markers are read through lt below
+  const double* lt = SCAN ? F.ltab + pjs * K2_LTAB : nullptr;
+  const double* e = SCAN ? lt - 12 : F.tab + (size_t)pjs * F.esz;
+  if (e[15] == 0.0) {  // collinear world points: computePoses returns -1
+    if constexpr (SCAN)
+      live = false;
+    else
+      return;
+  }
+  const double p_1 = e[12], p_2 = e[13], d_12 = e[14];
+  const double* tr = F.tri[ti];
+  const double f_1 = tr[9], f_2 = tr[10], b = tr[11], f12 = tr[12];
+
+  const double f_1_pw2 = f_1 * f_1, f_2_pw2 = f_2 * f_2;
+  const double p_1_pw2 = p_1 * p_1, p_1_pw3 = p_1_pw2 * p_1, p_1_pw4 = p_1_pw3 * p_1;
+  const double p_2_pw2 = p_2 * p_2, p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2;
+  const double d_12_pw2 = d_12 * d_12, b_pw2 = b * b;
+  const double F0 = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
+  const double F1 = 2 * p_2_pw3 * d_12 * b + 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * f_2 * p_2_pw3 * f_1 * d_12;
+  const double F2 = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 -
+                    f_2_pw2 * p_2_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw4 + p_2_pw4 * f_1_pw2 +
+                    2 * p_1 * p_2_pw2 * d_12 + 2 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b -
+                    p_2_pw2 * p_1_pw2 * f_1_pw2 + 2 * p_1 * p_2_pw2 * f_2_pw2 * d_12 -
+                    p_2_pw2 * d_12_pw2 * b_pw2 - 2 * p_1_pw2 * p_2_pw2;
+  const double F3 = 2 * p_1_pw2 * p_2 * d_12 * b + 2 * f_2 * p_2_pw3 * f_1 * d_12 -
+                    2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * p_1 * p_2 * d_12_pw2 * b;
+  const double F4 = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 +
+                    2 * p_1_pw3 * d_12 - p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 -
+                    2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 + p_2_pw2 * f_1_pw2 * p_1_pw2 +
+                    f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
+  rider.issue();  // P0: first scan round of the item (nothing is staged here: P6 consumed the last one)
+  double root[4];
+  solve_quartic_lit2(F0, F1, F2, F3, F4, root, [&]() {
+    rider.consume();
+    rider.issue();
+  });
+  rider.consume();  // P1
+  rider.issue();
+  // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
+  const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
+  const double tol2 = F.back_tol * F.back_tol;
+
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    rider.consume();  // P2..P5 (no-op when nothing is staged)
+    // next scan round: nothing of the voting loop waits on vmcnt (table and triples are in LDS)
+    rider.issue();
+    const double rt = k == 0 ? root[0] : (k == 1 ? root[1] : (k == 2 ? root[2] : root[3]));
+    // back-substitution, p3p.cpp:193-213
+    // cot_alpha = cn / cd;  sin_alpha = sqrt(1 / (cot^2 + 1)) = |cd| / hypot(cn, cd),
+    // cos_alpha = sign(cot) sqrt(1 - sin^2) = cn sign(cd) / hypot(cn, cd)
+    const double cn = g1 - rt * p_2, cd = g2 * rt + g3;
+    const double ih = rsqrt_nr(cn * cn + cd * cd);
+    const double cos_theta = rt;
+    const double sin_theta = sqrt_nr(1 - rt * rt);
+    const double sin_alpha = fabs(cd) * ih;
+    const double cos_alpha = (cd < 0 ? -cn : cn) * ih;
+    const double kk = sin_alpha * b + cos_alpha;
+    const double Cx = d_12 * cos_alpha * kk, Cy = cos_theta * d_12 * sin_alpha * kk,
+                 Cz = sin_theta * d_12 * sin_alpha * kk;
+    // isFinite([R C]) (pose_estimator.cpp:653): R and C are finite iff these are
+    const double z = (cos_alpha - cos_alpha) + (sin_alpha - sin_alpha) + (sin_theta - sin_theta) +
+                     (cos_theta - cos_theta) + (Cx - Cx) + (Cy - Cy) + (Cz - Cz);
+    bool finite_pose = true;
+    if (!(z == 0.0)) {
+      if constexpr (SCAN)
+        finite_pose = false;
+      else
+        continue;
+    }
+    const bool may_vote = live && finite_pose;
+    const double T00 = tr[0], T01 = tr[1], T02 = tr[2], T10 = tr[3], T11 = tr[4], T12 = tr[5], T20 = tr[6],
+                 T21 = tr[7], T22 = tr[8];
+    double q0u = 0, q0v = 0, q1u = 0, q1v = 0;
+    f32x2 q0f = {0.f, 0.f}, q1f = {0.f, 0.f};
+    for (int j = 0; j < F.nuo; ++j) {
+      const double* mk = SCAN ? lt + 5 + 3 * j : e + 18 + 3 * j;
+      const double v0 = mk[0] - Cx, v1 = mk[1] - Cy, v2 = mk[2] - Cz;
+      const double g = cos_theta * v1 + sin_theta * v2;
+      const double w0 = -cos_alpha * v0 - sin_alpha * g;
+      const double w1 = sin_alpha * v0 - cos_alpha * g;
+      const double w2 = -sin_theta * v1 + cos_theta * v2;
+      const double X = T00 * w0 + T10 * w1 + T20 * w2;  // T^T w
+      const double Y = T01 * w0 + T11 * w1 + T21 * w2;
+      const double Z = T02 * w0 + T12 * w1 + T22 * w2;
+      const double iZ = rcp_nr(Z);
+      const double qu = (fx * X + cx * Z) * iZ, qv = (fy * Y + cy * Z) * iZ;
+      if constexpr (SCAN) {  // <= 2 unused markers in this variant: registers instead of the LDS columns
+        if (j == 0) {
+          q0u = qu;
+          q0v = qv;
+          q0f = f32x2{(float)qu, (float)qv};
+        } else {
+          q1u = qu;
+          q1v = qv;
+          q1f = f32x2{(float)qu, (float)qv};
+        }
+      } else {
+        F.q[(2 * j) * F.nthr + F.tid] = qu;
+        F.q[(2 * j + 1) * F.nthr + F.tid] = qv;
+        F.qf[j * F.nthr + F.tid] = f32x2{(float)qu, (float)qv};
+      }
+    }
+    // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
+    bool any = false;
+    // the detections that are not part of the triple, ascending (c0 < c1 < c2): the u-th one is found by
+    // skipping over the three used indices — a uniform trip count for the frame and no lane sits out
+    for (int u = 0; u < F.n_d - 3; ++u) {
+      int a = u;
+      a += (a >= c0);
+      a += (a >= c1);
+      a += (a >= c2);
+      {  // single-precision prefilter (packed arithmetic: both coordinates per instruction)
+        const f32x2 af = F.pxf[a];
+        float mn = INFINITY;
+#pragma unroll 4
+        for (int jj = 0; jj < F.nuo; ++jj) {
+          const f32x2 qf = SCAN ? (jj == 0 ? q0f : q1f) : F.qf[jj * F.nthr + F.tid];
+          f32x2 df = af - qf;
+          df = df * df;
+          const float d2f = df.x + df.y;
+          mn = d2f < mn ? d2f : mn;  // (a NaN distance never wins, as in the exact search)
+        }
+        if (!(mn <= F.thr_pre)) continue;
+      }
+      const double au = F.px[a][0], av = F.px[a][1];
+      double best = INFINITY;
+      int bj = 0;
+      for (int jj = 0; jj < F.nuo; ++jj) {
+        const double bu = SCAN ? (jj == 0 ? q0u : q1u) : F.q[(2 * jj) * F.nthr + F.tid];
+        const double bv = SCAN ? (jj == 0 ? q0v : q1v) : F.q[(2 * jj + 1) * F.nthr + F.tid];
+        const double du = au - bu, dv = av - bv;
+        const double d2 = du * du + dv * dv;
+        if (d2 < best) {
+          best = d2;
+          bj = jj;
+        }
+      }
+      // sqrt(best) < tol (strict, pose_estimator.cpp:689) decided on the squares; the square
+      // root is only taken inside the rounding band around tol^2
+      bool within = best < tol2 * (1.0 - 1e-14);
+      if (!within && best < tol2 * (1.0 + 1e-14)) within = sqrt(best) < F.back_tol;
+      if (within && may_vote) {
+        // bj-th unused marker (ascending) -> marker index: skip over the sorted used indices
+        const int lo = min(p0, min(p1, p2)), hi = max(p0, max(p1, p2)), mid = p0 + p1 + p2 - lo - hi;
+        int mi = bj;
+        mi += (mi >= lo);
+        mi += (mi >= mid);
+        mi += (mi >= hi);
+        atomicAdd(&F.hist[a * MPE_MAX_MARKERS + mi], 1u);
+        any = true;
+      }
+    }
+    if (any) {  // pose_estimator.cpp:676-685
+      atomicAdd(&F.hist[c0 * MPE_MAX_MARKERS + p0], 1u);
+      atomicAdd(&F.hist[c1 * MPE_MAX_MARKERS + p1], 1u);
+      atomicAdd(&F.hist[c2 * MPE_MAX_MARKERS + p2], 1u);
+    }
+  }
+  rider.consume();  // P6: nothing of the scan is in flight while the next item fetches its table values
+}
+
 // Voting kernel.  Work item = (detection triple, marker permutation).  Everything that depends
 // only on the detection triple (tau frame T, f_1, f_2, b and the swap of p3p.cpp:100-121) is
 // computed once per triple into LDS; everything that depends only on the marker permutation comes
@@ -1532,12 +1779,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   const int nuo = n_m - 3;
   // single-precision copies of the back-projections behind the double ones: [j][tid] (plain variant)
   f32x2* s_qf = reinterpret_cast<f32x2*>(s_q + (size_t)2 * nuo * nthr);
-  // Nearest-neighbour prefilter: a detection can only vote if its exact distance to some back-projection is below
-  // tol; single precision places both points within 1e-3 px for any point that close to a detection (pixel
-  // coordinates < 4096), so "minimum single-precision distance <= tol (1 + 1e-4) + 0.05" is a safe necessary
-  // condition, and the exact double-precision search below only runs for the few detections that pass it.
-  const double tol_pre = sp.back_tol * (1.0 + 1e-4) + 0.05;
-  const float thr_pre = (float)(tol_pre * tol_pre * (1.0 + 1e-5));
+  const float thr_pre = k2_prefilter_threshold(sp.back_tol);
   const int esz = k2_entry_doubles(n_m);
   const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
   // block row with P1 <-> P2 exchanged: {2, 5, 0, 4, 3, 1}, packed 4 bits per row as 0x134052
@@ -1556,46 +1798,14 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
     }
     __syncthreads();
   }
+  const K2Frame F = {s_trii, s_tri, s_px, s_pxf, s_q,  s_qf, s_hist, tab, s_tab, n_d,
+                     nuo,    nthr,  tid,  esz,   fx,   fy,   cx,     cy,  sp.back_tol, thr_pre};
   for (int tc0 = 0; tc0 < n_combos; tc0 += TRI) {
     const int ntri = min(TRI, n_combos - tc0);
     if (tc0) __syncthreads();
     // ---- per-triple part of computePoses (p3p.cpp:82-121, 143-154)
     if (tid < ntri) {
-      int c0, c1, c2;
-      unrank_combo3(tc0 + tid, n_d, c0, c1, c2);
-      const V3 fa = {s_iv[c0][0], s_iv[c0][1], s_iv[c0][2]}, fb = {s_iv[c1][0], s_iv[c1][1], s_iv[c1][2]},
-               fc = {s_iv[c2][0], s_iv[c2][1], s_iv[c2][2]};
-      V3 f1 = fa, f2 = fb;
-      V3 e1 = f1;
-      V3 e3 = cross(f1, f2);
-      e3 = vdiv(e3, norm(e3));
-      V3 e2 = cross(e3, e1);
-      M3 T = {e1, e2, e3};
-      V3 f3 = mul(T, fc);
-      unsigned swap = 0;
-      if (f3.z > 0.0) {
-        swap = 1;
-        f1 = fb;
-        f2 = fa;
-        e1 = f1;
-        e3 = cross(f1, f2);
-        e3 = vdiv(e3, norm(e3));
-        e2 = cross(e3, e1);
-        T = {e1, e2, e3};
-        f3 = mul(T, fc);
-      }
-      const double cos_beta = dot(f1, f2);
-      double b = 1 / (1 - cos_beta * cos_beta) - 1;
-      b = (cos_beta < 0) ? -sqrt(b) : sqrt(b);
-      double* t = s_tri[tid];
-      t[0] = T.r0.x; t[1] = T.r0.y; t[2] = T.r0.z;
-      t[3] = T.r1.x; t[4] = T.r1.y; t[5] = T.r1.z;
-      t[6] = T.r2.x; t[7] = T.r2.y; t[8] = T.r2.z;
-      t[9] = f3.x / f3.z;
-      t[10] = f3.y / f3.z;
-      t[11] = b;
-      t[12] = t[9] / t[10];
-      s_trii[tid] = (unsigned)c0 | ((unsigned)c1 << 8) | ((unsigned)c2 << 16) | (swap << 24);
+      k2_triple_entry(s_iv, n_d, tc0 + tid, s_tri[tid], s_trii[tid]);
     }
     __syncthreads();
 
@@ -1624,175 +1834,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           pj = 0;
         }
       }
-      const unsigned ii = s_trii[ti];
-      const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
-      const bool swap = (ii >> 24) & 1;
-      const int packed = SCAN ? (int)s_tab[pj * K2_LTAB + 4]
-                              : (int)tab[(size_t)pj * esz + 16];  // marker indices of this permutation
-      const int p0 = packed & 0xFF, p1 = (packed >> 8) & 0xFF, p2 = (packed >> 16) & 0xFF;
-      const int r6 = pj % 6;
-      const int pjs = swap ? (pj - r6 + (int)((0x134052u >> (4 * r6)) & 7u)) : pj;  // kSwapRow packed
-      // e[12..] of the global table entry; in the scan-carrying variant e points into the LDS copy, shifted so
-      // that the SAME indices work for p_1 p_2 d_12 valid (12..15), and the markers are read through lt below
-      const double* lt = SCAN ? s_tab + pjs * K2_LTAB : nullptr;
-      const double* e = SCAN ? lt - 12 : tab + (size_t)pjs * esz;
-      if (e[15] == 0.0) {  // collinear world points: computePoses returns -1
-        if constexpr (SCAN)
-          live = false;
-        else
-          continue;
-      }
-      const double p_1 = e[12], p_2 = e[13], d_12 = e[14];
-      const double* tr = s_tri[ti];
-      const double f_1 = tr[9], f_2 = tr[10], b = tr[11], f12 = tr[12];
-
-      const double f_1_pw2 = f_1 * f_1, f_2_pw2 = f_2 * f_2;
-      const double p_1_pw2 = p_1 * p_1, p_1_pw3 = p_1_pw2 * p_1, p_1_pw4 = p_1_pw3 * p_1;
-      const double p_2_pw2 = p_2 * p_2, p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2;
-      const double d_12_pw2 = d_12 * d_12, b_pw2 = b * b;
-      const double F0 = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
-      const double F1 = 2 * p_2_pw3 * d_12 * b + 2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * f_2 * p_2_pw3 * f_1 * d_12;
-      const double F2 = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 -
-                        f_2_pw2 * p_2_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw4 + p_2_pw4 * f_1_pw2 +
-                        2 * p_1 * p_2_pw2 * d_12 + 2 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b -
-                        p_2_pw2 * p_1_pw2 * f_1_pw2 + 2 * p_1 * p_2_pw2 * f_2_pw2 * d_12 -
-                        p_2_pw2 * d_12_pw2 * b_pw2 - 2 * p_1_pw2 * p_2_pw2;
-      const double F3 = 2 * p_1_pw2 * p_2 * d_12 * b + 2 * f_2 * p_2_pw3 * f_1 * d_12 -
-                        2 * f_2_pw2 * p_2_pw3 * d_12 * b - 2 * p_1 * p_2 * d_12_pw2 * b;
-      const double F4 = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 +
-                        2 * p_1_pw3 * d_12 - p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 -
-                        2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 + p_2_pw2 * f_1_pw2 * p_1_pw2 +
-                        f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
-      rider.issue();  // P0: first scan round of the item (nothing is staged here: P6 consumed the last one)
-      double root[4];
-      solve_quartic_lit2(F0, F1, F2, F3, F4, root, [&]() {
-        rider.consume();
-        rider.issue();
-      });
-      rider.consume();  // P1
-      rider.issue();
-      // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
-      const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
-      const double tol2 = sp.back_tol * sp.back_tol;
-
-#pragma unroll 1
-      for (int k = 0; k < 4; ++k) {
-        rider.consume();  // P2..P5 (no-op when nothing is staged)
-        // next scan round: nothing of the voting loop waits on vmcnt (table and triples are in LDS)
-        rider.issue();
-        const double rt = k == 0 ? root[0] : (k == 1 ? root[1] : (k == 2 ? root[2] : root[3]));
-        // back-substitution, p3p.cpp:193-213
-        // cot_alpha = cn / cd;  sin_alpha = sqrt(1 / (cot^2 + 1)) = |cd| / hypot(cn, cd),
-        // cos_alpha = sign(cot) sqrt(1 - sin^2) = cn sign(cd) / hypot(cn, cd)
-        const double cn = g1 - rt * p_2, cd = g2 * rt + g3;
-        const double ih = rsqrt_nr(cn * cn + cd * cd);
-        const double cos_theta = rt;
-        const double sin_theta = sqrt_nr(1 - rt * rt);
-        const double sin_alpha = fabs(cd) * ih;
-        const double cos_alpha = (cd < 0 ? -cn : cn) * ih;
-        const double kk = sin_alpha * b + cos_alpha;
-        const double Cx = d_12 * cos_alpha * kk, Cy = cos_theta * d_12 * sin_alpha * kk,
-                     Cz = sin_theta * d_12 * sin_alpha * kk;
-        // isFinite([R C]) (pose_estimator.cpp:653): R and C are finite iff these are
-        const double z = (cos_alpha - cos_alpha) + (sin_alpha - sin_alpha) + (sin_theta - sin_theta) +
-                         (cos_theta - cos_theta) + (Cx - Cx) + (Cy - Cy) + (Cz - Cz);
-        bool finite_pose = true;
-        if (!(z == 0.0)) {
-          if constexpr (SCAN)
-            finite_pose = false;
-          else
-            continue;
-        }
-        const bool may_vote = live && finite_pose;
-        const double T00 = tr[0], T01 = tr[1], T02 = tr[2], T10 = tr[3], T11 = tr[4], T12 = tr[5], T20 = tr[6],
-                     T21 = tr[7], T22 = tr[8];
-        double q0u = 0, q0v = 0, q1u = 0, q1v = 0;
-        f32x2 q0f = {0.f, 0.f}, q1f = {0.f, 0.f};
-        for (int j = 0; j < nuo; ++j) {
-          const double* mk = SCAN ? lt + 5 + 3 * j : e + 18 + 3 * j;
-          const double v0 = mk[0] - Cx, v1 = mk[1] - Cy, v2 = mk[2] - Cz;
-          const double g = cos_theta * v1 + sin_theta * v2;
-          const double w0 = -cos_alpha * v0 - sin_alpha * g;
-          const double w1 = sin_alpha * v0 - cos_alpha * g;
-          const double w2 = -sin_theta * v1 + cos_theta * v2;
-          const double X = T00 * w0 + T10 * w1 + T20 * w2;  // T^T w
-          const double Y = T01 * w0 + T11 * w1 + T21 * w2;
-          const double Z = T02 * w0 + T12 * w1 + T22 * w2;
-          const double iZ = rcp_nr(Z);
-          const double qu = (fx * X + cx * Z) * iZ, qv = (fy * Y + cy * Z) * iZ;
-          if constexpr (SCAN) {  // <= 2 unused markers in this variant: registers instead of the LDS columns
-            if (j == 0) {
-              q0u = qu;
-              q0v = qv;
-              q0f = f32x2{(float)qu, (float)qv};
-            } else {
-              q1u = qu;
-              q1v = qv;
-              q1f = f32x2{(float)qu, (float)qv};
-            }
-          } else {
-            s_q[(2 * j) * nthr + tid] = qu;
-            s_q[(2 * j + 1) * nthr + tid] = qv;
-            s_qf[j * nthr + tid] = f32x2{(float)qu, (float)qv};
-          }
-        }
-        // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
-        bool any = false;
-        // the detections that are not part of the triple, ascending (c0 < c1 < c2): the u-th one is found by
-        // skipping over the three used indices — a uniform trip count for the frame and no lane sits out
-        for (int u = 0; u < n_d - 3; ++u) {
-          int a = u;
-          a += (a >= c0);
-          a += (a >= c1);
-          a += (a >= c2);
-          {  // single-precision prefilter (packed arithmetic: both coordinates per instruction)
-            const f32x2 af = s_pxf[a];
-            float mn = INFINITY;
-#pragma unroll 4
-            for (int jj = 0; jj < nuo; ++jj) {
-              const f32x2 qf = SCAN ? (jj == 0 ? q0f : q1f) : s_qf[jj * nthr + tid];
-              f32x2 df = af - qf;
-              df = df * df;
-              const float d2f = df.x + df.y;
-              mn = d2f < mn ? d2f : mn;  // (a NaN distance never wins, as in the exact search)
-            }
-            if (!(mn <= thr_pre)) continue;
-          }
-          const double au = s_px[a][0], av = s_px[a][1];
-          double best = INFINITY;
-          int bj = 0;
-          for (int jj = 0; jj < nuo; ++jj) {
-            const double bu = SCAN ? (jj == 0 ? q0u : q1u) : s_q[(2 * jj) * nthr + tid];
-            const double bv = SCAN ? (jj == 0 ? q0v : q1v) : s_q[(2 * jj + 1) * nthr + tid];
-            const double du = au - bu, dv = av - bv;
-            const double d2 = du * du + dv * dv;
-            if (d2 < best) {
-              best = d2;
-              bj = jj;
-            }
-          }
-          // sqrt(best) < tol (strict, pose_estimator.cpp:689) decided on the squares; the square
-          // root is only taken inside the rounding band around tol^2
-          bool within = best < tol2 * (1.0 - 1e-14);
-          if (!within && best < tol2 * (1.0 + 1e-14)) within = sqrt(best) < sp.back_tol;
-          if (within && may_vote) {
-            // bj-th unused marker (ascending) -> marker index: skip over the sorted used indices
-            const int lo = min(p0, min(p1, p2)), hi = max(p0, max(p1, p2)), mid = p0 + p1 + p2 - lo - hi;
-            int mi = bj;
-            mi += (mi >= lo);
-            mi += (mi >= mid);
-            mi += (mi >= hi);
-            atomicAdd(&s_hist[a * MPE_MAX_MARKERS + mi], 1u);
-            any = true;
-          }
-        }
-        if (any) {  // pose_estimator.cpp:676-685
-          atomicAdd(&s_hist[c0 * MPE_MAX_MARKERS + p0], 1u);
-          atomicAdd(&s_hist[c1 * MPE_MAX_MARKERS + p1], 1u);
-          atomicAdd(&s_hist[c2 * MPE_MAX_MARKERS + p2], 1u);
-        }
-      }
-      rider.consume();  // P6: nothing of the scan is in flight while the next item fetches its table values
+      k2_vote_item<SCAN>(F, ti, pj, live, rider);
       ti = ti_keep;
       pj = pj_keep;
     }

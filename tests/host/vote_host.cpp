@@ -1,0 +1,71 @@
+// Host build of the DEVICE voting source (test scaffolding, CPU tier): mpe_p3p.h as it is and, cut out of
+// mpe_kernels.hip at test time (vote_extract.inc), the index arithmetic, the marker-permutation table entry, the
+// per-triple part of computePoses and the voting work item (quartic coefficients, Ferrari in the fast arithmetic,
+// back-projection without forming [R|C], single-precision prefilter, exact nearest-neighbour votes) — i.e. what
+// k2_vote<false> runs per lane, driven here by one "lane" over all (triple, permutation) items of a frame.
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+#include <vector>
+#include "mpe.h"
+#include "mpe_p3p.h"
+using std::max;
+using std::min;
+struct f32x2 {  // clang's ext_vector_type(2) float, as far as the voting item uses it
+  float x, y;
+};
+static inline f32x2 operator-(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y - b.y}; }
+static inline f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) {
+  const unsigned o = *p;
+  *p += v;
+  return o;
+}
+namespace mpe {
+#include "vote_extract.inc"
+}
+using namespace mpe;
+
+extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers, int n_m, const double* k4,
+                         double back_tol, unsigned* hist /* MPE_MAX_DETECTIONS x MPE_MAX_MARKERS */) {
+  if (n_d < 4 || n_m < 4 || n_d > MPE_MAX_DETECTIONS || n_m > MPE_MAX_MARKERS) return -1;
+  SolveParams sp;
+  std::memset(&sp, 0, sizeof(sp));
+  sp.n_markers = n_m;
+  for (int i = 0; i < 3 * n_m; ++i) sp.markers[i] = markers[i];
+  sp.fx = k4[0];
+  sp.fy = k4[1];
+  sp.cx = k4[2];
+  sp.cy = k4[3];
+  sp.back_tol = back_tol;
+  const int n_perms = n_m * (n_m - 1) * (n_m - 2), n_combos = n_d * (n_d - 1) * (n_d - 2) / 6, nuo = n_m - 3;
+  const int esz = k2_entry_doubles(n_m);
+  std::vector<double> tab((size_t)n_perms * esz);
+  for (int pj = 0; pj < n_perms; ++pj) k2_marker_entry(sp, pj, tab.data() + (size_t)pj * esz);
+  double px[MPE_MAX_DETECTIONS][2], iv[MPE_MAX_DETECTIONS][3];
+  f32x2 pxf[MPE_MAX_DETECTIONS];
+  for (int i = 0; i < n_d; ++i) {
+    const double u = undist_xy[2 * i], v = undist_xy[2 * i + 1];
+    px[i][0] = u;
+    px[i][1] = v;
+    pxf[i] = f32x2{(float)u, (float)v};
+    const V3 b = bearing(u, v, sp.fx, sp.fy, sp.cx, sp.cy);
+    iv[i][0] = b.x;
+    iv[i][1] = b.y;
+    iv[i][2] = b.z;
+  }
+  std::vector<double> tri((size_t)n_combos * 13);
+  std::vector<unsigned> trii(n_combos);
+  for (int i = 0; i < n_combos; ++i) k2_triple_entry(iv, n_d, i, tri.data() + (size_t)i * 13, trii[i]);
+  std::vector<double> q(2 * nuo);
+  std::vector<f32x2> qf(nuo);
+  std::memset(hist, 0, sizeof(unsigned) * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS);
+  const K2Frame F = {trii.data(), reinterpret_cast<const double(*)[13]>(tri.data()), px, pxf, q.data(), qf.data(),
+                     hist, tab.data(), nullptr, n_d, nuo, 1, 0, esz, sp.fx, sp.fy, sp.cx, sp.cy, sp.back_tol,
+                     k2_prefilter_threshold(sp.back_tol)};
+  NoRider rider;
+  for (int ti = 0; ti < n_combos; ++ti)
+    for (int pj = 0; pj < n_perms; ++pj) k2_vote_item<false>(F, ti, pj, true, rider);
+  return 0;
+}

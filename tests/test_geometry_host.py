@@ -28,7 +28,7 @@ def host(tmp_path_factory):
     with open(os.path.join(d, "k2_extract.inc"), "w") as fh:
         fh.write(hip[i:hip.index("#define K2_THREADS", i)])
         i = hip.index("__device__ __forceinline__ void perm_from_index(")
-        fh.write(hip[i:hip.index("__global__ void k2_prep_markers(", i)])
+        fh.write(hip[i:hip.index("// one entry of the table (layout above) -> e", i)])
     so = os.path.join(d, "libgeom_host.so")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-I", str(d),
                            "-I", os.path.join(ROOT, "tests", "host", "stub"), "-I", CSRC,

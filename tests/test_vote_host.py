@@ -1,0 +1,99 @@
+"""The DEVICE voting source — what one lane of k2_vote runs for a (detection triple, marker permutation) item, plus the
+marker-permutation table and the per-triple part of computePoses — compiled for the HOST and driven over all items of
+a frame: the vote histogram must equal the oracle's `initialise()` loop (pose_estimator.cpp:544-702) cell by cell.
+Only the hardware reciprocal / rsqrt seeds of the fast arithmetic are replaced (tests/host/stub/hip/hip_runtime.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rpg_monocular_pose_estimator_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rpg_monocular_pose_estimator_amd", "csrc")
+MAX_DET, MAX_MARK = 32, 16
+
+
+def _cut(text, begin, end):
+    i = text.index(begin)
+    return text[i:text.index(end, i)]
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    d = tmp_path_factory.mktemp("vote_host")
+    hip = open(os.path.join(CSRC, "mpe_kernels.hip")).read()
+    internal = open(os.path.join(CSRC, "mpe_internal.h")).read()
+    inc = _cut(internal, "struct SolveParams {", "#define MPE_HIST_STRIDE")
+    inc += _cut(hip, "// lexicographic unranking of the idx-th 3-combination", "#define K2_THREADS")
+    inc += _cut(hip, "#define K2_LTAB", "__global__ void k2_prep_markers(")
+    inc += _cut(hip, "struct NoRider {", "// Voting kernel.  Work item =")
+    with open(os.path.join(d, "vote_extract.inc"), "w") as fh:
+        fh.write(inc)
+    so = os.path.join(d, "libvote_host.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-I", str(d),
+                           "-I", os.path.join(ROOT, "tests", "host", "stub"), "-I", CSRC,
+                           "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "host", "vote_host.cpp"), "-o", so])
+    lib = C.CDLL(so)
+    lib.host_vote.restype = C.c_int
+    return lib
+
+
+@pytest.fixture(scope="module")
+def orc():
+    import oracle
+    oracle.build()
+    from oracle import binding
+    return binding
+
+
+def _host_hist(lib, det, markers, K, tol):
+    det = np.ascontiguousarray(det, float)
+    markers = np.ascontiguousarray(markers, float)
+    k4 = np.array([K[0][0], K[1][1], K[0][2], K[1][2]], float)
+    hist = np.zeros((MAX_DET, MAX_MARK), np.uint32)
+    rc = lib.host_vote(det.ctypes.data_as(C.c_void_p), len(det), markers.ctypes.data_as(C.c_void_p), len(markers),
+                       k4.ctypes.data_as(C.c_void_p), C.c_double(tol), hist.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return hist[:len(det), :len(markers)]
+
+
+@pytest.mark.parametrize("config,n_frames", [("C1", 40), ("C2", 60), ("C3", 2)])
+def test_device_voting_source_on_the_host(host, orc, config, n_frames):
+    """Synthetic frames of the BASELINE configs: detections from the oracle's findLeds, votes from the device source."""
+    d = synth.make_frames(config, n_frames, seed=2024)
+    P = orc.make_params()
+    n_votes = 0
+    n_done = 0
+    for i in range(n_frames):
+        und, _ = orc.find_leds(d["frames"][i], P, d["K"], d["D"])
+        if len(und) < 4 or len(und) > MAX_DET:
+            continue
+        ref = orc.vote_histogram(und, d["markers"], d["K"], P.back_projection_pixel_tolerance)
+        got = _host_hist(host, und, d["markers"], d["K"], P.back_projection_pixel_tolerance)
+        assert np.array_equal(got, ref), (config, i, np.argwhere(got != ref)[:5])
+        n_votes += int(ref.sum())
+        n_done += 1
+    assert n_done >= n_frames // 2 and n_votes > 0, (n_done, n_votes)
+
+
+def test_device_voting_source_random_detections(host, orc):
+    """Detections that do NOT come from the marker set (most hypotheses vote for nothing, some by accident), planar and
+    general rigs, tolerances 1 / 3 / 5 px."""
+    rng = np.random.default_rng(77)
+    cfg = synth.CONFIGS["C2"]
+    K, _ = synth.camera_for(cfg["rows"], cfg["cols"])
+    for it in range(60):
+        n_m = int(rng.integers(4, 7))
+        markers = rng.uniform(-0.15, 0.15, (n_m, 3))
+        if it % 3 == 0:
+            markers[:, 2] = 0.0
+        n_d = int(rng.integers(4, 9))
+        det = np.column_stack([rng.uniform(250, 500, n_d), rng.uniform(150, 330, n_d)])
+        tol = [1.0, 3.0, 5.0][it % 3]
+        ref = orc.vote_histogram(det, markers, K, tol)
+        got = _host_hist(host, det, markers, K, tol)
+        assert np.array_equal(got, ref), (it, np.argwhere(got != ref)[:5])
