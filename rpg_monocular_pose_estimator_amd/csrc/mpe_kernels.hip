@@ -2188,6 +2188,82 @@ __device__ __forceinline__ void apply_exp(const double tw[6], T34& T) {
   T = N;
 }
 
+// optimisePose (pose_estimator.cpp:733-792): Gauss-Newton on SE(3) over the n_c correspondence rows
+// row(j, 0..2) = marker xyz, row(j, 3..4) = detection uv; T is updated in place, cov = A^-1 of the last iteration
+// (row-major 6x6), returns the number of iterations.
+template <class Row>
+__device__ __forceinline__ int k3_gauss_newton(int n_c, Row row, double fx, double fy, double cx, double cy, T34& T,
+                                               double* __restrict__ cov) {
+  double A[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) A[r][c] = 0;
+  int iters = 0;
+  for (int it = 0; it < 500; ++it) {
+    double b[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) A[r][c] = 0;
+    for (int j = 0; j < n_c; ++j) {
+      const double mk[3] = {row(j, 0), row(j, 1), row(j, 2)};
+      double u, v, x, y, z;
+      project_T(T, mk, fx, fy, cx, cy, u, v, x, y, z);
+      const double e0 = row(j, 3) - u, e1 = row(j, 4) - v;
+      const double z_2 = z * z;
+      // computeJacobian, pose_estimator.cpp:945-957
+      double J0[6] = {0, 0, 0, 0, 0, 0}, J1[6] = {0, 0, 0, 0, 0, 0};
+      J0[0] = 1 / z * fx;
+      J0[2] = -x / z_2 * fx;
+      J0[3] = -x * y / z_2 * fx;
+      J0[4] = (1 + (x * x / z_2)) * fx;
+      J0[5] = -y / z * fx;
+      J1[1] = 1 / z * fy;
+      J1[2] = -y / z_2 * fy;
+      J1[3] = -(1 + y * y / z_2) * fy;
+      J1[4] = x * y / z_2 * fy;
+      J1[5] = x / z * fy;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = r; c < 6; ++c) A[r][c] += J0[r] * J0[c] + J1[r] * J1[c];  // A += J^T J (upper triangle)
+        b[r] += J0[r] * e0 + J1[r] * e1;                                       // b += J^T e
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < r; ++c) A[r][c] = A[c][r];
+    LDL6 F;
+    ldl6_factor(A, F);
+    double dT[6];
+    ldl6_solve(F, b, dT);
+    apply_exp(dT, T);
+    iters = it + 1;
+    double mx = -1;  // norm_max, pose_estimator.cpp:1073-1085
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double av = fabs(dT[r]);
+      if (av > mx) mx = av;
+    }
+    if (mx <= 1e-13) break;
+  }
+  // pose_covariance_ = A.inverse() with the A of the last iteration (pose_estimator.cpp:790)
+  LDL6 F;
+  ldl6_factor(A, F);
+#pragma unroll 1
+  for (int c = 0; c < 6; ++c) {
+    double e[6], x[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) e[r] = (r == c) ? 1.0 : 0.0;
+    ldl6_solve(F, e, x);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) cov[r * 6 + c] = x[r];
+  }
+  return iters;
+}
+
 #define K3_GROUP 16                 // lanes cooperating on one frame in the validation kernel
 #define K3_FRAMES_PER_BLOCK 4       // one wave = 4 frames
 #define K3B_THREADS 64              // refinement kernel: one lane per frame
@@ -2562,75 +2638,9 @@ __global__ __launch_bounds__(K3B_THREADS) void k3b_refine(const mpe_detections* 
   }
 
   // ---- optimisePose (pose_estimator.cpp:733-792)
-  double A[6][6];
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int c = 0; c < 6; ++c) A[r][c] = 0;
   int iters = 0;
-  if (MODE != 1) {
-    for (int it = 0; it < 500; ++it) {
-      double b[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) A[r][c] = 0;
-      for (int j = 0; j < n_c; ++j) {
-        const double mk[3] = {ROW(j, 0), ROW(j, 1), ROW(j, 2)};
-        double u, v, x, y, z;
-        project_T(T, mk, fx, fy, cx, cy, u, v, x, y, z);
-        const double e0 = ROW(j, 3) - u, e1 = ROW(j, 4) - v;
-        const double z_2 = z * z;
-        // computeJacobian, pose_estimator.cpp:945-957
-        double J0[6] = {0, 0, 0, 0, 0, 0}, J1[6] = {0, 0, 0, 0, 0, 0};
-        J0[0] = 1 / z * fx;
-        J0[2] = -x / z_2 * fx;
-        J0[3] = -x * y / z_2 * fx;
-        J0[4] = (1 + (x * x / z_2)) * fx;
-        J0[5] = -y / z * fx;
-        J1[1] = 1 / z * fy;
-        J1[2] = -y / z_2 * fy;
-        J1[3] = -(1 + y * y / z_2) * fy;
-        J1[4] = x * y / z_2 * fy;
-        J1[5] = x / z * fy;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-#pragma unroll
-          for (int c = r; c < 6; ++c) A[r][c] += J0[r] * J0[c] + J1[r] * J1[c];  // A += J^T J (upper triangle)
-          b[r] += J0[r] * e0 + J1[r] * e1;                                       // b += J^T e
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < r; ++c) A[r][c] = A[c][r];
-      LDL6 F;
-      ldl6_factor(A, F);
-      double dT[6];
-      ldl6_solve(F, b, dT);
-      apply_exp(dT, T);
-      iters = it + 1;
-      double mx = -1;  // norm_max, pose_estimator.cpp:1073-1085
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const double av = fabs(dT[r]);
-        if (av > mx) mx = av;
-      }
-      if (mx <= 1e-13) break;
-    }
-    // pose_covariance_ = A.inverse() with the A of the last iteration (pose_estimator.cpp:790)
-    LDL6 F;
-    ldl6_factor(A, F);
-#pragma unroll 1
-    for (int c = 0; c < 6; ++c) {
-      double e[6], x[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) e[r] = (r == c) ? 1.0 : 0.0;
-      ldl6_solve(F, e, x);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) res->cov[r * 6 + c] = x[r];
-    }
-  }
+  if (MODE != 1)
+    iters = k3_gauss_newton(n_c, [&](int j, int k) -> double { return ROW(j, k); }, fx, fy, cx, cy, T, res->cov);
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 4; ++c) res->T[r * 4 + c] = T.m[r][c];
   res->T[12] = 0.0;

@@ -83,3 +83,13 @@ extern "C" void host_bearing(double u, double v, const double* k4, double* out) 
   out[1] = b.y;
   out[2] = b.z;
 }
+
+// optimisePose as k3b_refine runs it: rows = n_c x (marker xyz, detection uv)
+extern "C" int host_gauss_newton(const double* rows, int n_c, const double* k4, double* T34_rows, double* cov) {
+  T34 T;
+  std::memcpy(T.m, T34_rows, sizeof(T.m));
+  const int it = k3_gauss_newton(n_c, [&](int j, int k) -> double { return rows[5 * j + k]; }, k4[0], k4[1], k4[2],
+                                 k4[3], T, cov);
+  std::memcpy(T34_rows, T.m, sizeof(T.m));
+  return it;
+}

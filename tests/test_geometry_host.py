@@ -130,3 +130,42 @@ def test_device_index_arithmetic_on_the_host(host, orc):
         host.host_bearing(C.c_double(u), C.c_double(v), _ptr(K4), _ptr(out))
         Km = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1]])
         assert np.array_equal(out, orc.image_vectors(np.array([[u, v]]), Km)[0])
+
+
+def test_device_gauss_newton_on_the_host(host, orc):
+    """optimisePose (pose_estimator.cpp:733-792) as the refinement kernel runs it: same iteration count as the oracle,
+    pose and covariance to rounding level — started near the solution and from a poor initial pose."""
+    rng = np.random.default_rng(12)
+    cfg = synth.CONFIGS["C2"]
+    K, _ = synth.camera_for(cfg["rows"], cfg["cols"])
+    k4 = np.array([K[0][0], K[1][1], K[0][2], K[1][2]], float)
+    markers = np.asarray(cfg["markers"], float)
+    host.host_gauss_newton.restype = C.c_int
+    n_run = n_off = 0
+    for it in range(200):
+        ax = rng.normal(size=3)
+        T_true = np.eye(4)
+        T_true[:3, :3] = synth.rodrigues(ax / np.linalg.norm(ax), rng.uniform(0, 0.8))
+        T_true[:3, 3] = [rng.uniform(-0.3, 0.3), rng.uniform(-0.2, 0.2), rng.uniform(0.8, 2.5)]
+        det = synth.project(T_true, markers, K) + rng.normal(0, 0.3, (len(markers), 2))
+        n_c = int(rng.integers(4, len(markers) + 1))
+        corr = np.column_stack([np.arange(1, n_c + 1), np.arange(1, n_c + 1)]).astype(np.uint32)
+        T0 = T_true.copy()
+        bx = rng.normal(size=3)
+        T0[:3, :3] = synth.rodrigues(bx / np.linalg.norm(bx), [0.02, 0.3][it % 2]) @ T0[:3, :3]
+        T0[:3, 3] += rng.normal(0, [0.005, 0.1][it % 2], 3)
+        T_ref, cov_ref, it_ref = orc.optimise_pose(det, markers, K, corr, T0)
+        if not np.isfinite(T_ref).all() or it_ref > 25:
+            continue                                  # diverging start: chaotic, not comparable at rounding level
+        rows = np.ascontiguousarray(np.column_stack([markers[:n_c], det[:n_c]]))
+        T = np.ascontiguousarray(T0[:3, :])
+        cov = np.zeros((6, 6))
+        it_got = host.host_gauss_newton(_ptr(rows), n_c, _ptr(k4), _ptr(T), _ptr(cov))
+        # (the stopping test max|dT| <= 1e-13 sits at rounding level: a last step of 1.0e-13 on one side and 0.99e-13 on
+        #  the other moves the count by one; counted and bounded)
+        assert abs(it_got - it_ref) <= 1, (it, it_got, it_ref)
+        n_off += it_got != it_ref
+        assert np.abs(T - T_ref[:3, :]).max() < 1e-11, it
+        assert np.allclose(cov, cov_ref, rtol=1e-7, atol=1e-14), it
+        n_run += 1
+    assert n_run > 150 and n_off <= n_run // 20, (n_run, n_off)
