@@ -34,7 +34,7 @@ def lockstep(args, mpe, seqs, mine, rank, world, local_rank):
     trackers = [mpe.Tracker(hs[i % len(hs)], seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], mpe.demo_params())
                 for i in range(len(mine))]
     frames = [q["frames"] for q in seqs]
-    mpe.tracker_run_sequences_batch(trackers, [f[:8] for f in frames], seqs[0]["times"][:8])  # warm-up
+    mpe.tracker_run_sequences_batch(trackers, [f[:8] for f in frames], seqs[0]["times"][:8], args.group_threads)  # warm-up
     for t in trackers:
         t.reset()
     if world > 1:
@@ -42,7 +42,7 @@ def lockstep(args, mpe, seqs, mine, rank, world, local_rank):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rec, info = mpe.tracker_run_sequences_batch(trackers, frames, seqs[0]["times"])
+    rec, info = mpe.tracker_run_sequences_batch(trackers, frames, seqs[0]["times"], args.group_threads)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n_frames = len(mine) * args.frames
@@ -59,7 +59,7 @@ def lockstep(args, mpe, seqs, mine, rank, world, local_rank):
                           "streams_per_gpu": len(mine), "frames_per_stream": args.frames, "higher_is_better": True,
                           "data": "synthetic", "dtype": "f64", "frames_in": "pageable host memory",
                           "mode": "lock step: one device submission per time step and group of streams",
-                          "groups_per_gpu": len(hs),
+                          "groups_per_gpu": len(hs), "host_threads_per_gpu": min(len(hs), max(1, args.group_threads)),
                           "ms_per_time_step": dt / args.frames * 1e3,
                           "poses_found_frac": n_pose / max(1, n_frames), "bruteforce_frac": n_brute / max(1, n_frames),
                           "config": {"workload": "%s sequences (constant twist + jitter, 50 Hz), demo.launch parameters"
@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--groups", type=int, default=1,
                     help="--lockstep: spread the streams over this many handles; the groups are pipelined against each "
                          "other (host work of one group beside the device work of another)")
+    ap.add_argument("--group-threads", type=int, default=1,
+                    help="--lockstep --groups G: drive the groups from this many host threads "
+                         "(mpe_tracker_run_sequences_batch_threads)")
     ap.add_argument("--lockstep", action="store_true",
                     help="all streams of a rank on ONE handle, driven in lock step: one device submission per time "
                          "step for all of them (mpe_tracker_run_sequences_batch) instead of one host thread per stream")

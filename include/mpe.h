@@ -301,6 +301,14 @@ int mpe_tracker_estimate_batch(mpe_tracker* const* trackers, int n, const uint8_
 int mpe_tracker_run_sequences_batch(mpe_tracker* const* trackers, int n, const uint8_t* const* frames, int n_frames,
                                     int rows, int cols, size_t stride_bytes, size_t frame_stride_bytes,
                                     const double* times, mpe_result* out, int* info);
+/* The same with the groups spread over up to n_threads host threads (group g on thread g % n_threads; the groups of
+ * one thread are pipelined against each other as above).  Groups share nothing — own handle and stream, own trackers,
+ * own rows of out / info — so the records are those of the single-threaded call; with 64 streams in 4-8 groups the
+ * host work of a time step no longer bounds the rate.  n_threads = 1: the call above. */
+int mpe_tracker_run_sequences_batch_threads(mpe_tracker* const* trackers, int n, const uint8_t* const* frames,
+                                            int n_frames, int rows, int cols, size_t stride_bytes,
+                                            size_t frame_stride_bytes, const double* times, mpe_result* out, int* info,
+                                            int n_threads);
 
 /* The estimator's private state (pose_estimator.h:56-62, 74-79), for callers that drive the public
  * step methods of the class (predictPose, findCorrespondences, ... — see compat/) between calls of

@@ -142,6 +142,8 @@ def load_library():
                                                C.c_void_p]
     lib.mpe_tracker_run_sequences_batch.argtypes = [hp, C.c_int, hp, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                                     dp, C.c_void_p, C.c_void_p]
+    lib.mpe_tracker_run_sequences_batch_threads.argtypes = [hp, C.c_int, hp, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                                            C.c_size_t, dp, C.c_void_p, C.c_void_p, C.c_int]
     lib.mpe_shard_bounds.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.mpe_shard_bounds.restype = None
     lib.mpe_estimate_batch_multi.argtypes = [hp, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
@@ -176,9 +178,10 @@ def tracker_estimate_batch(trackers, imgs, times):
     return rec, info, upd.astype(bool)
 
 
-def tracker_run_sequences_batch(trackers, frames, times):
-    """mpe_tracker_run_sequences_batch: the lock-step loop in C.  frames: list of (n,rows,cols) uint8 arrays (one
-    sequence per tracker), times: n floats.  -> (records (N,n), info (N,n,8))."""
+def tracker_run_sequences_batch(trackers, frames, times, threads=1):
+    """mpe_tracker_run_sequences_batch[_threads]: the lock-step loop in C.  frames: list of (n,rows,cols) uint8 arrays
+    (one sequence per tracker), times: n floats; threads > 1: the handle groups on that many host threads.
+    -> (records (N,n), info (N,n,8))."""
     lib = load_library()
     N = len(trackers)
     frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
@@ -189,8 +192,9 @@ def tracker_run_sequences_batch(trackers, frames, times):
     times = _f64(times).reshape(-1)
     rec = np.zeros((N, n), RESULT_DTYPE)
     info = np.zeros((N, n, 8), np.int32)
-    rc = lib.mpe_tracker_run_sequences_batch(ts, N, ptrs, n, rows, cols, frames[0].strides[1], frames[0].strides[0],
-                                             _dp(times), rec.ctypes.data, info.ctypes.data)
+    rc = lib.mpe_tracker_run_sequences_batch_threads(ts, N, ptrs, n, rows, cols, frames[0].strides[1],
+                                                     frames[0].strides[0], _dp(times), rec.ctypes.data,
+                                                     info.ctypes.data, int(threads))
     if rc < 0:
         raise MpeError("mpe_tracker_run_sequences_batch failed (%d): %s"
                        % (rc, lib.mpe_last_error(trackers[0]._handle._h).decode()))

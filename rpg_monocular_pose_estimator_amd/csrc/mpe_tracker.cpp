@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "../../include/mpe.h"
@@ -888,10 +889,10 @@ int mpe_tracker_estimate_batch(mpe_tracker* const* ts, int n, const uint8_t* con
 // (one group per handle, each with the same camera / marker / parameter set inside the group); the groups are
 // pipelined against each other: while the device works on step k of one group, the host collects, advances and
 // packs another — the host work of a time step (~3 us per stream) hides behind the device latency (~0.2 ms).
-int mpe_tracker_run_sequences_batch(mpe_tracker* const* ts, int n, const uint8_t* const* frames, int n_frames, int rows,
-                                    int cols, size_t stride_bytes, size_t frame_stride_bytes, const double* times,
-                                    mpe_result* out, int* info) {
-  if (!ts || n < 0 || !frames || !times || n_frames < 0) return MPE_ERR_ARG;
+int mpe_tracker_run_sequences_batch_threads(mpe_tracker* const* ts, int n, const uint8_t* const* frames, int n_frames,
+                                            int rows, int cols, size_t stride_bytes, size_t frame_stride_bytes,
+                                            const double* times, mpe_result* out, int* info, int n_threads) {
+  if (!ts || n < 0 || !frames || !times || n_frames < 0 || n_threads < 1) return MPE_ERR_ARG;
   if (n == 0 || n_frames == 0) return 0;
   for (int i = 0; i < n; ++i)
     if (!ts[i] || !frames[i]) return MPE_ERR_ARG;
@@ -919,40 +920,69 @@ int mpe_tracker_run_sequences_batch(mpe_tracker* const* ts, int n, const uint8_t
     const int rc = ctx[g].validate(gts[g].data(), (int)gts[g].size());
     if (rc != MPE_OK) return rc;
   }
-  std::vector<mpe_result> step_out((size_t)n);
-  std::vector<int> step_info((size_t)n * 8);
-  long long updated = 0;
-  auto finish_group = [&](size_t g, int f) -> int {  // complete step f of group g and store its records
-    int rc = ctx[g].finish();
-    if (rc != MPE_OK) return rc;
-    const int m = (int)members[g].size();
-    updated += ctx[g].outputs(step_out.data(), 1, step_info.data(), 8, nullptr);
-    for (int k = 0; k < m; ++k) {
-      const int i = members[g][(size_t)k];
-      if (out) out[(size_t)i * n_frames + f] = step_out[(size_t)k];
-      if (info) std::memcpy(info + ((size_t)i * n_frames + f) * 8, &step_info[(size_t)k * 8], 8 * sizeof(int));
+  // The groups gs[0..) on the calling thread, pipelined against each other: while the device works on step k of one
+  // group, the host collects, advances and packs another.  Groups share nothing (own handle, own trackers, own rows
+  // of out / info), so disjoint sets of groups can also run on different host threads.
+  auto run_groups = [&](const std::vector<size_t>& gs, long long& updated) -> int {
+    std::vector<mpe_result> step_out((size_t)n);
+    std::vector<int> step_info((size_t)n * 8);
+    auto finish_group = [&](size_t g, int f) -> int {  // complete step f of group g and store its records
+      int rc = ctx[g].finish();
+      if (rc != MPE_OK) return rc;
+      const int m = (int)members[g].size();
+      updated += ctx[g].outputs(step_out.data(), 1, step_info.data(), 8, nullptr);
+      for (int k = 0; k < m; ++k) {
+        const int i = members[g][(size_t)k];
+        if (out) out[(size_t)i * n_frames + f] = step_out[(size_t)k];
+        if (info) std::memcpy(info + ((size_t)i * n_frames + f) * 8, &step_info[(size_t)k * 8], 8 * sizeof(int));
+      }
+      return MPE_OK;
+    };
+    for (int f = 0; f < n_frames; ++f)
+      for (size_t g : gs) {
+        if (f > 0) {
+          const int rc = finish_group(g, f - 1);
+          if (rc != MPE_OK) return rc;
+        }
+        for (size_t k = 0; k < members[g].size(); ++k) {
+          gimgs[g][k] = frames[members[g][k]] + (size_t)f * frame_stride_bytes;
+          gtimes[g][k] = times[f];
+        }
+        ctx[g].begin(gimgs[g].data(), rows, cols, stride_bytes, gtimes[g].data());
+        const int rc = ctx[g].submit_first();
+        if (rc != MPE_OK) return rc;
+      }
+    for (size_t g : gs) {
+      const int rc = finish_group(g, n_frames - 1);
+      if (rc != MPE_OK) return rc;
     }
     return MPE_OK;
   };
-  for (int f = 0; f < n_frames; ++f)
-    for (size_t g = 0; g < G; ++g) {
-      if (f > 0) {
-        const int rc = finish_group(g, f - 1);
-        if (rc != MPE_OK) return rc;
-      }
-      for (size_t k = 0; k < members[g].size(); ++k) {
-        gimgs[g][k] = frames[members[g][k]] + (size_t)f * frame_stride_bytes;
-        gtimes[g][k] = times[f];
-      }
-      ctx[g].begin(gimgs[g].data(), rows, cols, stride_bytes, gtimes[g].data());
-      const int rc = ctx[g].submit_first();
-      if (rc != MPE_OK) return rc;
-    }
-  for (size_t g = 0; g < G; ++g) {
-    const int rc = finish_group(g, n_frames - 1);
-    if (rc != MPE_OK) return rc;
+  const size_t T = std::min<size_t>((size_t)n_threads, G);
+  std::vector<std::vector<size_t> > sets(T);
+  for (size_t g = 0; g < G; ++g) sets[g % T].push_back(g);
+  std::vector<long long> upd(T, 0);
+  std::vector<int> rcs(T, MPE_OK);
+  if (T <= 1) {
+    rcs[0] = run_groups(sets[0], upd[0]);
+  } else {
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; ++t) th.emplace_back([&, t]() { rcs[t] = run_groups(sets[t], upd[t]); });
+    for (auto& x : th) x.join();
+  }
+  long long updated = 0;
+  for (size_t t = 0; t < T; ++t) {
+    if (rcs[t] != MPE_OK) return rcs[t];
+    updated += upd[t];
   }
   return (int)std::min<long long>(updated, 0x7fffffff);
+}
+
+int mpe_tracker_run_sequences_batch(mpe_tracker* const* ts, int n, const uint8_t* const* frames, int n_frames, int rows,
+                                    int cols, size_t stride_bytes, size_t frame_stride_bytes, const double* times,
+                                    mpe_result* out, int* info) {
+  return mpe_tracker_run_sequences_batch_threads(ts, n, frames, n_frames, rows, cols, stride_bytes, frame_stride_bytes,
+                                                 times, out, info, 1);
 }
 
 int mpe_tracker_run_sequence(mpe_tracker* t, const uint8_t* frames, int n_frames, int rows, int cols,

@@ -1031,6 +1031,12 @@ def test_lockstep_tracker_batch_matches_oracle(orc):
     t3 = [mpe.Tracker(hg[s % 3], seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], P) for s in range(n_streams)]
     rec3, info3 = mpe.tracker_run_sequences_batch(t3, [q["frames"] for q in seqs], seqs[0]["times"])
     assert rec3.tobytes() == rec.tobytes() and np.array_equal(info3, info)
+    # ... and the three groups on two / three host threads
+    for threads in (2, 3):
+        for t in t3:
+            t.reset()
+        rec4, info4 = mpe.tracker_run_sequences_batch(t3, [q["frames"] for q in seqs], seqs[0]["times"], threads)
+        assert rec4.tobytes() == rec.tobytes() and np.array_equal(info4, info), threads
     for t in t3:
         t.close()
     for hh in hg:
