@@ -329,6 +329,21 @@ def test_multi_entry_rejects_bad_usage_without_a_device(lib):
     assert rc == -1
 
 
+def test_threaded_lockstep_entry_rejects_bad_usage_without_a_device(lib):
+    """mpe_tracker_run_sequences_batch_threads validates its arguments before touching a device."""
+    hp = ctypes.POINTER(ctypes.c_void_p)
+    ts = (ctypes.c_void_p * 1)(None)
+    fr = np.zeros((2, 16, 16), np.uint8)
+    ptrs = (ctypes.c_void_p * 1)(fr.ctypes.data)
+    times = np.zeros(2)
+    dp = times.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    call = lib.mpe_tracker_run_sequences_batch_threads
+    assert call(None, 1, ptrs, 2, 16, 16, 16, 256, dp, None, None, 2) == -1      # no trackers
+    assert call(ts, 1, ptrs, 2, 16, 16, 16, 256, dp, None, None, 2) == -1        # null tracker
+    assert call(ts, 1, ptrs, 2, 16, 16, 16, 256, dp, None, None, 0) == -1        # n_threads < 1
+    assert call(ts, 0, ptrs, 2, 16, 16, 16, 256, dp, None, None, 1) == 0         # nothing to do
+
+
 def _run_bench(args, env_extra=None, timeout=240):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
