@@ -1535,7 +1535,18 @@ struct K2Frame {
   int n_d, nuo, nthr, tid, esz;
   double fx, fy, cx, cy, back_tol;
   float thr_pre;
+  u64* vq;        // this wave's queue of deferred exact votes, K2_VQ_CAP entries of K2_VQ_WORDS u64 (scan variant;
+                  // its fill count is a wave-uniform register of the caller)
+  int vq_lanes;   // lanes that work the queue off together: 64 (1 when the host-tier test runs this source)
 };
+
+// i-th double of the LDS copy of the marker-permutation table (scan-carrying variant), K2_LTAB per permutation:
+//   [0] p_1 [1] p_2 [2] d_12 [3] valid [4] packed marker indices [5..10] eta-frame unused markers (<= 2)
+__device__ __forceinline__ double k2_ltab_value(const double* __restrict__ tab, int esz, int nuo, int i) {
+  const int pe = i / K2_LTAB, fld = i - pe * K2_LTAB;
+  const int src = fld < 5 ? 12 + fld : 13 + fld;  // 12..16, 18..23
+  return (fld < 5 + 3 * nuo) ? tab[(size_t)pe * esz + src] : 0.0;
+}
 
 // Nearest-neighbour prefilter: a detection can only vote if its exact distance to some back-projection is below
 // tol; single precision places both points within 1e-3 px for any point that close to a detection (pixel
@@ -1546,11 +1557,86 @@ __device__ __forceinline__ float k2_prefilter_threshold(double back_tol) {
   return (float)(tol_pre * tol_pre * (1.0 + 1e-5));
 }
 
+// The exact half of the nearest-neighbour vote of ONE hypothesis (pose_estimator.cpp:663-702) for the unused
+// detections whose bit is set in `pass` (those that got through the single-precision prefilter), with the (<= 2)
+// back-projections passed by value: exact double-precision search, strict `< tol` decided on the squares (the square
+// root is only taken inside the rounding band around tol^2), votes, and the triple's own three votes if any
+// detection voted.  The lane must be allowed to vote.
+__device__ __forceinline__ void k2_vote_exact(const K2Frame& F, int c0, int c1, int c2, int p0, int p1, int p2,
+                                              unsigned pass, double q0u, double q0v, double q1u, double q1v) {
+  const double tol2 = F.back_tol * F.back_tol;
+  // bj-th unused marker (ascending) -> marker index: skip over the sorted used indices
+  const int lo = min(p0, min(p1, p2)), hi = max(p0, max(p1, p2)), mid = p0 + p1 + p2 - lo - hi;
+  bool any = false;
+  while (pass) {
+    const int u = __builtin_ctz(pass);
+    pass &= pass - 1;
+    int a = u;
+    a += (a >= c0);
+    a += (a >= c1);
+    a += (a >= c2);
+    const double au = F.px[a][0], av = F.px[a][1];
+    double best = INFINITY;
+    int bj = 0;
+    for (int jj = 0; jj < F.nuo; ++jj) {
+      const double du = au - (jj == 0 ? q0u : q1u), dv = av - (jj == 0 ? q0v : q1v);
+      const double d2 = du * du + dv * dv;
+      if (d2 < best) {
+        best = d2;
+        bj = jj;
+      }
+    }
+    bool within = best < tol2 * (1.0 - 1e-14);
+    if (!within && best < tol2 * (1.0 + 1e-14)) within = sqrt(best) < F.back_tol;
+    if (within) {
+      int mi = bj;
+      mi += (mi >= lo);
+      mi += (mi >= mid);
+      mi += (mi >= hi);
+      atomicAdd(&F.hist[a * MPE_MAX_MARKERS + mi], 1u);
+      any = true;
+    }
+  }
+  if (any) {  // pose_estimator.cpp:676-685
+    atomicAdd(&F.hist[c0 * MPE_MAX_MARKERS + p0], 1u);
+    atomicAdd(&F.hist[c1 * MPE_MAX_MARKERS + p1], 1u);
+    atomicAdd(&F.hist[c2 * MPE_MAX_MARKERS + p2], 1u);
+  }
+}
+
+// Deferred exact votes (scan-carrying variant).  About 1 % of the (hypothesis, detection) pairs pass the prefilter,
+// but in a wave of 64 independent hypotheses SOME lane does in every other iteration, and the whole wave then walks
+// through the exact search and the vote with one or two lanes alive: that was 21 % of the voting kernel's time
+// (0.68 -> 0.54 ms per 16 384 frames with everything behind the prefilter compiled out).  Instead a lane that has a
+// candidate appends {back-projections, indices, prefilter mask} to its wave's small LDS queue (one entry per
+// hypothesis; slots come from a ballot, the fill count is a wave-uniform register) and the wave works the queue off
+// with one entry per LANE whenever it is nearly full: the same exact test, the same votes (integer adds: any order).
+// A lane that finds the queue full votes on the spot.  Measured: 0.855 -> 0.833 ms per fused launch.
+#define K2_VQ_CAP 12
+#define K2_VQ_WORDS 5
+__device__ __forceinline__ u64 k2_vq_meta(int c0, int c1, int c2, int p0, int p1, int p2, unsigned pass) {
+  return (u64)pass | ((u64)(unsigned)(c0 | (c1 << 5) | (c2 << 10) | (p0 << 15) | (p1 << 19) | (p2 << 23)) << 32);
+}
+__device__ __forceinline__ void k2_vote_flush(const K2Frame& F, int count) {
+  wave_sync();
+  const unsigned n = min((unsigned)count, (unsigned)K2_VQ_CAP);
+  const unsigned lane = (unsigned)F.tid & 63u;
+  for (unsigned i = lane; i < n; i += (unsigned)F.vq_lanes) {  // (one trip at most on the device: n <= 12 < 64)
+    const u64* e = F.vq + (size_t)i * K2_VQ_WORDS;
+    const u64 meta = e[4];
+    const unsigned ix = (unsigned)(meta >> 32);
+    k2_vote_exact(F, ix & 31, (ix >> 5) & 31, (ix >> 10) & 31, (ix >> 15) & 15, (ix >> 19) & 15, (ix >> 23) & 15,
+                  (unsigned)meta, __longlong_as_double((long long)e[0]), __longlong_as_double((long long)e[1]),
+                  __longlong_as_double((long long)e[2]), __longlong_as_double((long long)e[3]));
+  }
+  wave_sync();  // (the entries are read before the next ones overwrite them)
+}
+
 // One work item = (staged detection triple ti, marker permutation pj): quartic coefficients (p3p.cpp:171-185),
 // Ferrari, and for each root the back-projection of the unused markers and the nearest-neighbour votes
 // (pose_estimator.cpp:596-702).  `live` = false: compute on, never vote (wave-uniform loop of the rider variant).
 template <bool SCAN, class Rider>
-__device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, bool live, Rider& rider) {
+__device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, bool live, Rider& rider, int& vq_count) {
   const double fx = F.fx, fy = F.fy, cx = F.cx, cy = F.cy;
   const unsigned ii = F.trii[ti];
   const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
@@ -1665,6 +1751,47 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
       }
     }
     // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
+    if constexpr (SCAN) {
+      // prefilter over all unused detections -> mask; the exact half is deferred (k2_vote_flush)
+      unsigned pass = 0;
+      for (int u = 0; u < F.n_d - 3; ++u) {
+        int a = u;
+        a += (a >= c0);
+        a += (a >= c1);
+        a += (a >= c2);
+        const f32x2 af = F.pxf[a];
+        float mn = INFINITY;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          if (jj < F.nuo) {
+            f32x2 df = af - (jj == 0 ? q0f : q1f);
+            df = df * df;
+            const float d2f = df.x + df.y;
+            mn = d2f < mn ? d2f : mn;  // (a NaN distance never wins, as in the exact search)
+          }
+        }
+        pass |= (mn <= F.thr_pre) ? (1u << u) : 0u;
+      }
+      // slots by ballot: the queue's fill count is wave-uniform (a scalar register), no LDS atomic
+      const bool want = pass != 0u && may_vote;
+      const u64 bal = __ballot(want);
+      if (bal != 0) {
+        const unsigned slot = (unsigned)vq_count + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        vq_count += (int)__builtin_popcountll(bal);
+        if (!want) {
+        } else if (slot < (unsigned)K2_VQ_CAP) {
+          u64* e = F.vq + (size_t)slot * K2_VQ_WORDS;
+          e[0] = (u64)__double_as_longlong(q0u);
+          e[1] = (u64)__double_as_longlong(q0v);
+          e[2] = (u64)__double_as_longlong(q1u);
+          e[3] = (u64)__double_as_longlong(q1v);
+          e[4] = k2_vq_meta(c0, c1, c2, p0, p1, p2, pass);
+        } else {
+          k2_vote_exact(F, c0, c1, c2, p0, p1, p2, pass, q0u, q0v, q1u, q1v);
+        }
+      }
+      continue;
+    }
     bool any = false;
     // the detections that are not part of the triple, ascending (c0 < c1 < c2): the u-th one is found by
     // skipping over the three used indices — a uniform trip count for the frame and no lane sits out
@@ -1721,6 +1848,12 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     }
   }
   rider.consume();  // P6: nothing of the scan is in flight while the next item fetches its table values
+  if constexpr (SCAN) {
+    if (vq_count >= K2_VQ_CAP - 4) {  // wave-uniform
+      k2_vote_flush(F, vq_count);
+      vq_count = 0;
+    }
+  }
 }
 
 // Voting kernel.  Work item = (detection triple, marker permutation).  Everything that depends
@@ -1789,17 +1922,16 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   // table values the loop needs are copied to LDS once per block:
   //   [0] p_1 [1] p_2 [2] d_12 [3] valid [4] packed marker indices [5..10] eta-frame unused markers (<= 2)
   double* s_tab = nullptr;
+  u64* s_vq = nullptr;  // per-wave queue of deferred exact votes, behind the table copy
   if constexpr (SCAN) {
     s_tab = reinterpret_cast<double*>(smem + (size_t)(blockDim.x >> 6) * (K2_SCAN_R * 1024));
-    for (int i = tid; i < n_perms * K2_LTAB; i += nthr) {
-      const int pe = i / K2_LTAB, fld = i - pe * K2_LTAB;
-      const int src = fld < 5 ? 12 + fld : 13 + fld;  // 12..16, 18..23
-      s_tab[i] = (fld < 5 + 3 * nuo) ? tab[(size_t)pe * esz + src] : 0.0;
-    }
+    s_vq = reinterpret_cast<u64*>(s_tab + (size_t)n_perms * K2_LTAB) + (size_t)(tid >> 6) * (K2_VQ_CAP * K2_VQ_WORDS);
+    for (int i = tid; i < n_perms * K2_LTAB; i += nthr) s_tab[i] = k2_ltab_value(tab, esz, nuo, i);
     __syncthreads();
   }
-  const K2Frame F = {s_trii, s_tri, s_px, s_pxf, s_q,  s_qf, s_hist, tab, s_tab, n_d,
-                     nuo,    nthr,  tid,  esz,   fx,   fy,   cx,     cy,  sp.back_tol, thr_pre};
+  const K2Frame F = {s_trii, s_tri, s_px, s_pxf, s_q,  s_qf, s_hist, tab,         s_tab,   n_d,  nuo,
+                     nthr,   tid,   esz,  fx,    fy,   cx,   cy,     sp.back_tol, thr_pre, s_vq, 64};
+  int vq_count = 0;  // entries in this wave's queue (wave-uniform)
   for (int tc0 = 0; tc0 < n_combos; tc0 += TRI) {
     const int ntri = min(TRI, n_combos - tc0);
     if (tc0) __syncthreads();
@@ -1834,11 +1966,12 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           pj = 0;
         }
       }
-      k2_vote_item<SCAN>(F, ti, pj, live, rider);
+      k2_vote_item<SCAN>(F, ti, pj, live, rider, vq_count);
       ti = ti_keep;
       pj = pj_keep;
     }
   }
+  if constexpr (SCAN) k2_vote_flush(F, vq_count);  // what is left in this wave's queue of deferred votes
   rider.drain();
   __syncthreads();
   uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
@@ -1993,7 +2126,8 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
     sa.n_chunks = (int)(scan_bytes / chunk_bytes);
     sa.thr = make_thr_test(scan_thr);
     lds = (size_t)(threads / 64) * chunk_bytes +
-          (size_t)sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2) * K2_LTAB * sizeof(double);
+          (size_t)sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2) * K2_LTAB * sizeof(double) +
+          (size_t)(threads / 64) * K2_VQ_CAP * K2_VQ_WORDS * sizeof(u64);
     if (scanned_bytes) *scanned_bytes = (size_t)sa.n_chunks * chunk_bytes;
     hipLaunchKernelGGL(k2_vote<true>, dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
                        splits, sa);

@@ -22,13 +22,31 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
   *p += v;
   return o;
 }
+typedef unsigned long long u64;
+static inline void wave_sync() {}
+static inline double __longlong_as_double(long long v) {
+  double d;
+  std::memcpy(&d, &v, 8);
+  return d;
+}
+static inline long long __double_as_longlong(double d) {
+  long long v;
+  std::memcpy(&v, &d, 8);
+  return v;
+}
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+static inline u64 __ballot(bool b) { return b ? 1ull : 0ull; }                       // a wave of one lane
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned, unsigned base) { return base; }  // no lower lanes
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned, unsigned base) { return base; }
 namespace mpe {
 #include "vote_extract.inc"
 }
 using namespace mpe;
 
+// variant 0: k2_vote<false> (back-projections in the LDS columns, votes on the spot); variant 1: k2_vote<true> as far as
+// one lane can run it (LDS copy of the table, back-projections by value, exact votes deferred through the queue)
 extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers, int n_m, const double* k4,
-                         double back_tol, unsigned* hist /* MPE_MAX_DETECTIONS x MPE_MAX_MARKERS */) {
+                         double back_tol, unsigned* hist /* MPE_MAX_DETECTIONS x MPE_MAX_MARKERS */, int variant) {
   if (n_d < 4 || n_m < 4 || n_d > MPE_MAX_DETECTIONS || n_m > MPE_MAX_MARKERS) return -1;
   SolveParams sp;
   std::memset(&sp, 0, sizeof(sp));
@@ -61,11 +79,23 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   std::vector<double> q(2 * nuo);
   std::vector<f32x2> qf(nuo);
   std::memset(hist, 0, sizeof(unsigned) * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS);
+  std::vector<double> ltab((size_t)n_perms * K2_LTAB);
+  for (size_t i = 0; i < ltab.size(); ++i) ltab[i] = k2_ltab_value(tab.data(), esz, nuo, (int)i);
+  std::vector<u64> vq((size_t)K2_VQ_CAP * K2_VQ_WORDS, 0);
   const K2Frame F = {trii.data(), reinterpret_cast<const double(*)[13]>(tri.data()), px, pxf, q.data(), qf.data(),
-                     hist, tab.data(), nullptr, n_d, nuo, 1, 0, esz, sp.fx, sp.fy, sp.cx, sp.cy, sp.back_tol,
-                     k2_prefilter_threshold(sp.back_tol)};
+                     hist, tab.data(), ltab.data(), n_d, nuo, 1, 0, esz, sp.fx, sp.fy, sp.cx, sp.cy, sp.back_tol,
+                     k2_prefilter_threshold(sp.back_tol), vq.data(), 1};
   NoRider rider;
-  for (int ti = 0; ti < n_combos; ++ti)
-    for (int pj = 0; pj < n_perms; ++pj) k2_vote_item<false>(F, ti, pj, true, rider);
+  if (variant == 1) {
+    if (nuo > 2) return -2;  // the scan-carrying variant keeps at most two back-projections (in registers)
+    int vq_count = 0;
+    for (int ti = 0; ti < n_combos; ++ti)
+      for (int pj = 0; pj < n_perms; ++pj) k2_vote_item<true>(F, ti, pj, true, rider, vq_count);
+    k2_vote_flush(F, vq_count);
+  } else {
+    int unused = 0;
+    for (int ti = 0; ti < n_combos; ++ti)
+      for (int pj = 0; pj < n_perms; ++pj) k2_vote_item<false>(F, ti, pj, true, rider, unused);
+  }
   return 0;
 }

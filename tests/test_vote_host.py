@@ -29,7 +29,7 @@ def host(tmp_path_factory):
     inc = _cut(internal, "struct SolveParams {", "#define MPE_HIST_STRIDE")
     inc += _cut(hip, "// lexicographic unranking of the idx-th 3-combination", "#define K2_THREADS")
     inc += _cut(hip, "#define K2_LTAB", "__global__ void k2_prep_markers(")
-    inc += _cut(hip, "struct NoRider {", "// Voting kernel.  Work item =")
+    inc += _cut(hip, "struct NoRider {", "// Voting kernel.  Work item =")   # incl. the deferred-vote queue
     with open(os.path.join(d, "vote_extract.inc"), "w") as fh:
         fh.write(inc)
     so = os.path.join(d, "libvote_host.so")
@@ -50,13 +50,13 @@ def orc():
     return binding
 
 
-def _host_hist(lib, det, markers, K, tol):
+def _host_hist(lib, det, markers, K, tol, variant=0):
     det = np.ascontiguousarray(det, float)
     markers = np.ascontiguousarray(markers, float)
     k4 = np.array([K[0][0], K[1][1], K[0][2], K[1][2]], float)
     hist = np.zeros((MAX_DET, MAX_MARK), np.uint32)
     rc = lib.host_vote(det.ctypes.data_as(C.c_void_p), len(det), markers.ctypes.data_as(C.c_void_p), len(markers),
-                       k4.ctypes.data_as(C.c_void_p), C.c_double(tol), hist.ctypes.data_as(C.c_void_p))
+                       k4.ctypes.data_as(C.c_void_p), C.c_double(tol), hist.ctypes.data_as(C.c_void_p), variant)
     assert rc == 0
     return hist[:len(det), :len(markers)]
 
@@ -75,6 +75,9 @@ def test_device_voting_source_on_the_host(host, orc, config, n_frames):
         ref = orc.vote_histogram(und, d["markers"], d["K"], P.back_projection_pixel_tolerance)
         got = _host_hist(host, und, d["markers"], d["K"], P.back_projection_pixel_tolerance)
         assert np.array_equal(got, ref), (config, i, np.argwhere(got != ref)[:5])
+        if len(d["markers"]) <= 5:   # the scan-carrying variant: prefilter mask, deferred exact votes, queue + flush
+            got1 = _host_hist(host, und, d["markers"], d["K"], P.back_projection_pixel_tolerance, 1)
+            assert np.array_equal(got1, ref), (config, i, "scan variant", np.argwhere(got1 != ref)[:5])
         n_votes += int(ref.sum())
         n_done += 1
     assert n_done >= n_frames // 2 and n_votes > 0, (n_done, n_votes)
@@ -97,3 +100,6 @@ def test_device_voting_source_random_detections(host, orc):
         ref = orc.vote_histogram(det, markers, K, tol)
         got = _host_hist(host, det, markers, K, tol)
         assert np.array_equal(got, ref), (it, np.argwhere(got != ref)[:5])
+        if n_m <= 5:
+            got1 = _host_hist(host, det, markers, K, tol, 1)
+            assert np.array_equal(got1, ref), (it, "scan variant", np.argwhere(got1 != ref)[:5])
