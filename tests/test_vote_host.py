@@ -21,15 +21,16 @@ def _cut(text, begin, end):
     return text[i:text.index(end, i)]
 
 
-@pytest.fixture(scope="module")
-def host(tmp_path_factory):
-    d = tmp_path_factory.mktemp("vote_host")
+def _build(d, tiny_queues=False):
     hip = open(os.path.join(CSRC, "mpe_kernels.hip")).read()
     internal = open(os.path.join(CSRC, "mpe_internal.h")).read()
     inc = _cut(internal, "struct SolveParams {", "#define MPE_HIST_STRIDE")
     inc += _cut(hip, "// lexicographic unranking of the idx-th 3-combination", "#define K2_THREADS")
     inc += _cut(hip, "#define K2_LTAB", "__global__ void k2_prep_markers(")
     inc += _cut(hip, "struct NoRider {", "// Voting kernel.  Work item =")   # incl. the deferred-vote queue
+    if tiny_queues:  # capacities at which the "no room: vote on the spot" paths run all the time
+        assert "#define K2_VQ_CAP 12" in inc
+        inc = inc.replace("#define K2_VQ_CAP 12", "#define K2_VQ_CAP 5")
     with open(os.path.join(d, "vote_extract.inc"), "w") as fh:
         fh.write(inc)
     so = os.path.join(d, "libvote_host.so")
@@ -40,6 +41,16 @@ def host(tmp_path_factory):
     lib = C.CDLL(so)
     lib.host_vote.restype = C.c_int
     return lib
+
+
+@pytest.fixture(scope="module")
+def host(tmp_path_factory):
+    return _build(tmp_path_factory.mktemp("vote_host"))
+
+
+@pytest.fixture(scope="module")
+def host_tiny(tmp_path_factory):
+    return _build(tmp_path_factory.mktemp("vote_host_tiny"), tiny_queues=True)
 
 
 @pytest.fixture(scope="module")
@@ -103,3 +114,19 @@ def test_device_voting_source_random_detections(host, orc):
         if n_m <= 5:
             got1 = _host_hist(host, det, markers, K, tol, 1)
             assert np.array_equal(got1, ref), (it, "scan variant", np.argwhere(got1 != ref)[:5])
+
+
+def test_device_voting_source_with_full_queues(host_tiny, orc):
+    """The same source built with a 5-entry vote queue (flush threshold 1): the queue is worked off after nearly every
+    push and lanes that find no room vote on the spot — histograms unchanged."""
+    for config, n_frames in (("C2", 12), ("C3", 1)):
+        d = synth.make_frames(config, n_frames, seed=31)
+        P = orc.make_params()
+        for i in range(n_frames):
+            und, _ = orc.find_leds(d["frames"][i], P, d["K"], d["D"])
+            if len(und) < 4:
+                continue
+            ref = orc.vote_histogram(und, d["markers"], d["K"], P.back_projection_pixel_tolerance)
+            for variant in ((0, 1) if len(d["markers"]) <= 5 else (0,)):
+                got = _host_hist(host_tiny, und, d["markers"], d["K"], P.back_projection_pixel_tolerance, variant)
+                assert np.array_equal(got, ref), (config, i, variant)
