@@ -41,6 +41,8 @@ static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c
   for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
   return c;
 }
+#define __host__
+#include "k1a_extract.inc"  // ThrTest, make_thr_test, gt_word, maybe_gt16, any_gt16 (`struct ThrTest {` .. `#ifndef K1A_UNROLL`)
 #include "k1b_extract.inc"
 
 extern "C" int host_find_leds(const uint8_t* img, int rows, int cols, int thr, const int* taps, int ksize,
@@ -100,4 +102,12 @@ extern "C" int host_find_leds(const uint8_t* img, int rows, int cols, int thr, c
     undist_xy[2 * i + 1] = (double)uy;
   }
   return n;
+}
+
+// The image scan's per-segment tests (k1a_scan and the voting kernel's scan rider): bit 0 = any_gt16, bit 1 = maybe_gt16
+extern "C" int host_scan_tests(const uint8_t* seg16, int thr) {
+  uint4 v;
+  std::memcpy(&v, seg16, 16);
+  const ThrTest q = make_thr_test(thr);
+  return (any_gt16(v, q) ? 1 : 0) | (maybe_gt16(v, q) ? 2 : 0);
 }

@@ -28,6 +28,8 @@ def host(tmp_path_factory):
     d = tmp_path_factory.mktemp("k1b_host")
     hip = open(os.path.join(CSRC, "mpe_kernels.hip")).read()
     internal = open(os.path.join(CSRC, "mpe_internal.h")).read()
+    with open(os.path.join(d, "k1a_extract.inc"), "w") as fh:
+        fh.write(_cut(hip, "struct ThrTest {", "#ifndef K1A_UNROLL"))
     inc = _cut(internal, "struct DetectParams {", "struct SolveParams {")
     inc += _cut(hip, "struct BlobRec {", "// final stage: kept blobs")
     with open(os.path.join(d, "k1b_extract.inc"), "w") as fh:
@@ -141,3 +143,28 @@ def test_blurred_value_exactly_at_the_rounding_boundary(host, orc):
     img[y, x] = 0                                      # below the boundary: the bridge is gone and the answer changes
     _, dist2 = _host_find_leds(host, orc, img, P, K, D)
     assert not np.array_equal(dist2, dist)
+
+
+def test_scan_threshold_arithmetic_exhaustively(host):
+    """The image scan flags a 16-byte segment iff one of its bytes exceeds the threshold (strictly, THRESH_TOZERO,
+    led_detector.cpp:44) — computed with three SWAR operations per word on the device.  Every threshold from -1 to 255
+    (and the clamps beyond) against the byte-wise definition, on segments with one byte at every value around the
+    threshold, random segments, all-equal segments; the cheap OR test must never miss a hit."""
+    rng = np.random.default_rng(8)
+    host.host_scan_tests.restype = C.c_int
+    for thr in list(range(-1, 256)) + [-5, 300]:
+        t = min(255, max(-1, thr))
+        segs = []
+        for v in {max(0, t - 1), max(0, t), min(255, t + 1), 0, 127, 128, 255}:
+            for pos in (0, 5, 15):
+                s = np.full(16, rng.integers(0, max(1, t + 1)) if t >= 0 else 0, np.uint8)  # background <= thr
+                s[pos] = v
+                segs.append(s)
+            segs.append(np.full(16, v, np.uint8))
+        segs += [rng.integers(0, 256, 16).astype(np.uint8) for _ in range(20)]
+        for s in segs:
+            s = np.ascontiguousarray(s)
+            want = bool((s.astype(int) > t).any())
+            r = host.host_scan_tests(s.ctypes.data_as(C.c_void_p), thr)
+            assert bool(r & 1) == want, (thr, s)
+            assert (r & 2) or not want, (thr, s)        # maybe_gt16 is a necessary condition
