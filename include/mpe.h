@@ -366,6 +366,16 @@ int mpe_vote_batch(mpe_handle* h, const double* det_xy, const int* n_det, int n_
                    const double* markers_xyz, int n_markers, const double K[9],
                    double back_projection_pixel_tolerance, uint32_t* hist);
 
+/* Forensics for the parity soaks (tests/forensics.py): the voting of mpe_vote_batch restricted, per detection set, to
+ * the hypotheses [item_lo[f], item_hi[f]) of initialise()'s loop nest — flattened index = detection-triple index x
+ * P(n_markers,3) + marker-permutation index, both in the reference's table order (combinations.cpp:52-203,
+ * pose_estimator.cpp:565-600).  With n copies of one detection set and ranges [i, i+1) it returns every hypothesis'
+ * own votes, which is how a HIP-vs-oracle histogram difference is traced to the hypotheses that cast it.  Same
+ * kernels and arithmetic as mpe_vote_batch (option "vote_arith" applies). */
+int mpe_vote_items(mpe_handle* h, const double* det_xy, const int* n_det, int n_frames, const double* markers_xyz,
+                   int n_markers, const double K[9], double back_projection_pixel_tolerance, const int* item_lo,
+                   const int* item_hi, uint32_t* hist);
+
 /* Time (ms) of the kernels of the last mpe_estimate_batch* call, measured with HIP events on the
  * handle's stream: [0] image scan, [1] blob extraction, [2] voting, [3] validate+refine, [4] total.
  * Only valid after mpe_set_profiling(h, 1); profiling adds event records to the stream. */

@@ -256,6 +256,17 @@ def vote_histogram(det, markers, K, tol):
     return h
 
 
+def vote_items(det, markers, K, tol, lo, hi):
+    """Votes of the hypotheses [lo, hi) of initialise()'s loop nest only (forensics)."""
+    det = _f64(det).reshape(-1, 2)
+    markers = _f64(markers).reshape(-1, 3)
+    K = _f64(K).reshape(9)
+    h = np.zeros((len(det), len(markers)), np.uint32)
+    lib().orc_vote_items(_p(det, C.c_double), len(det), _p(markers, C.c_double), len(markers), _p(K, C.c_double),
+                         C.c_double(tol), C.c_longlong(lo), C.c_longlong(hi), _p(h, C.c_uint32))
+    return h
+
+
 def correspondences_from_histogram(hist, threshold):
     h = np.ascontiguousarray(hist, np.uint32).copy()
     n_det, n_m = h.shape

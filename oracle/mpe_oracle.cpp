@@ -1047,7 +1047,9 @@ class Estimator {
   }
 
   // the voting part of initialise(), PE.cpp:544-702
-  void voteHistogram(std::vector<unsigned>& hist) const {
+  // (item_lo, item_hi: forensics only — the hypotheses [lo, hi) of the loop nest, flattened as triple * n_perms +
+  //  permutation; the default is the whole nest)
+  void voteHistogram(std::vector<unsigned>& hist, long long item_lo = 0, long long item_hi = -1) const {
     const int n_d = (int)image_points_.size(), n_m = (int)object_points_.size();
     hist.assign((size_t)n_d * n_m, 0u);
     std::vector<unsigned> combos((size_t)orc_combinations3(n_d, nullptr) * 3);
@@ -1076,6 +1078,10 @@ class Estimator {
         }
       }
       for (unsigned j = 0; j < n_perms; ++j) {
+        if (item_hi >= 0) {
+          const long long g = (long long)i * n_perms + j;
+          if (g < item_lo || g >= item_hi) continue;
+        }
         V3 wp[3];
         for (int k = 0; k < 3; ++k) {
           const V4& mp = object_points_[perms[j * 3 + k] - 1];
@@ -1688,6 +1694,20 @@ void orc_compute_transformation(const double* obj, const double* rep, int n, dou
   }
   M4 M = Estimator::computeTransformation(a, b);
   std::memcpy(T, M.m, sizeof(M.m));
+}
+
+// forensics (tests/forensics.py): the votes of the hypotheses [item_lo, item_hi) of initialise()'s loop nest only
+int orc_vote_items(const double* det, int n_det, const double* markers, int n_markers, const double K[9], double tol,
+                   long long item_lo, long long item_hi, uint32_t* hist) {
+  Estimator e;
+  e.setCamera(K);
+  e.setMarkerPositions(markers, n_markers);
+  e.back_projection_pixel_tolerance_ = tol;
+  e.setImagePoints(det, n_det);
+  std::vector<unsigned> h;
+  e.voteHistogram(h, item_lo, item_hi < 0 ? 0 : item_hi);
+  std::memcpy(hist, h.data(), h.size() * sizeof(unsigned));
+  return 0;
 }
 
 int orc_vote_histogram(const double* det, int n_det, const double* markers, int n_markers,

@@ -106,6 +106,10 @@ void orc_compute_transformation(const double* obj, const double* rep, int n, dou
 /* voting only: PE.cpp:544-702.  returns 0 */
 int orc_vote_histogram(const double* det, int n_det, const double* markers, int n_markers,
                        const double K[9], double back_projection_pixel_tolerance, uint32_t* hist);
+/* forensics: the votes of the hypotheses [item_lo, item_hi) of that loop nest only (flattened index = detection-triple
+ * index * P(n_markers,3) + marker-permutation index, COMB.cpp table order) */
+int orc_vote_items(const double* det, int n_det, const double* markers, int n_markers, const double K[9],
+                   double back_projection_pixel_tolerance, long long item_lo, long long item_hi, uint32_t* hist);
 /* PE.cpp:344-370 — consumes (zeroes columns of) hist; returns number of rows written to corr */
 int orc_correspondences_from_histogram(uint32_t* hist, int n_det, int n_markers,
                                        unsigned histogram_threshold, uint32_t* corr);

@@ -120,6 +120,8 @@ def load_library():
                                      dp, dp, C.c_int, C.POINTER(MpeParams), C.c_void_p]
     lib.mpe_vote_batch.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int), C.c_int, dp, C.c_int, dp, C.c_double,
                                    C.POINTER(C.c_uint32)]
+    lib.mpe_vote_items.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int), C.c_int, dp, C.c_int, dp, C.c_double,
+                                   C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
     lib.mpe_check_and_refine.argtypes = [C.c_void_p, dp, C.c_int, dp, C.c_int, dp, C.POINTER(MpeParams),
                                          C.POINTER(C.c_uint32), C.c_int, C.POINTER(MpeResult)]
     lib.mpe_tracker_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -589,6 +591,27 @@ class Handle:
                                       len(markers), _dp(K), float(tol), hist.ctypes.data_as(C.POINTER(C.c_uint32)))
         self._check(rc, "mpe_vote_batch")
         return [hist[i, :nd[i], :len(markers)].copy() for i in range(n)]
+
+
+    def vote_items(self, det, markers, K, tol, lo, hi):
+        """Forensics: the detection set `det` voted len(lo) times, copy i with the hypotheses [lo[i], hi[i]) only
+        (flattened index = triple index * P(n_markers,3) + permutation index).  -> (len(lo), n_det, n_markers)."""
+        markers = _f64(markers).reshape(-1, 3)
+        K = _f64(K).reshape(9)
+        det = _f64(det).reshape(-1, 2)
+        lo = np.ascontiguousarray(lo, np.int32)
+        hi = np.ascontiguousarray(hi, np.int32)
+        n = len(lo)
+        buf = np.zeros((n, MAX_DETECTIONS, 2))
+        buf[:, :len(det)] = det
+        nd = np.full(n, len(det), np.int32)
+        hist = np.zeros((n, MAX_DETECTIONS, MAX_MARKERS), np.uint32)
+        ip = C.POINTER(C.c_int)
+        rc = self._lib.mpe_vote_items(self._h, _dp(buf), nd.ctypes.data_as(ip), n, _dp(markers), len(markers), _dp(K),
+                                      float(tol), lo.ctypes.data_as(ip), hi.ctypes.data_as(ip),
+                                      hist.ctypes.data_as(C.POINTER(C.c_uint32)))
+        self._check(rc, "mpe_vote_items")
+        return hist[:, :len(det), :len(markers)].copy()
 
 
 class Tracker:

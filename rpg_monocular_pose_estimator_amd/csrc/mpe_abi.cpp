@@ -940,8 +940,27 @@ int mpe_find_leds(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t 
   return MPE_OK;
 }
 
+namespace {
+int vote_batch_impl(mpe_handle* h, const double* det_xy, const int* n_det, int n_frames, const double* markers_xyz,
+                    int n_markers, const double K[9], double back_projection_pixel_tolerance, const int* item_lo,
+                    const int* item_hi, uint32_t* hist);
+}
 int mpe_vote_batch(mpe_handle* h, const double* det_xy, const int* n_det, int n_frames, const double* markers_xyz,
                    int n_markers, const double K[9], double back_projection_pixel_tolerance, uint32_t* hist) {
+  return vote_batch_impl(h, det_xy, n_det, n_frames, markers_xyz, n_markers, K, back_projection_pixel_tolerance, nullptr,
+                         nullptr, hist);
+}
+int mpe_vote_items(mpe_handle* h, const double* det_xy, const int* n_det, int n_frames, const double* markers_xyz,
+                   int n_markers, const double K[9], double back_projection_pixel_tolerance, const int* item_lo,
+                   const int* item_hi, uint32_t* hist) {
+  if (!item_lo || !item_hi) return fail(h, MPE_ERR_ARG, "bad argument");
+  return vote_batch_impl(h, det_xy, n_det, n_frames, markers_xyz, n_markers, K, back_projection_pixel_tolerance, item_lo,
+                         item_hi, hist);
+}
+namespace {
+int vote_batch_impl(mpe_handle* h, const double* det_xy, const int* n_det, int n_frames, const double* markers_xyz,
+                    int n_markers, const double K[9], double back_projection_pixel_tolerance, const int* item_lo,
+                    const int* item_hi, uint32_t* hist) {
   if (!h || !det_xy || !n_det || !markers_xyz || !K || !hist || n_frames < 0) return fail(h, MPE_ERR_ARG, "bad argument");
   if (n_frames == 0) return MPE_OK;
   HIP_TRY(h, hipSetDevice(h->device));
@@ -964,14 +983,27 @@ int mpe_vote_batch(mpe_handle* h, const double* det_xy, const int* n_det, int n_
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
   HIP_TRY(h, h->mtab.reserve(k2_table_bytes(n_markers)));
   HIP_TRY(h, launch_k2_prep(sp, static_cast<double*>(h->mtab.p), h->stream));
+  const int* d_range = nullptr;
+  if (item_lo) {  // forensics: per-frame hypothesis ranges, interleaved {lo, hi}
+    std::vector<int> rg((size_t)2 * n_frames);
+    for (int f = 0; f < n_frames; ++f) {
+      rg[(size_t)2 * f] = item_lo[f];
+      rg[(size_t)2 * f + 1] = item_hi[f];
+    }
+    HIP_TRY(h, h->work.reserve(rg.size() * sizeof(int)));
+    HIP_TRY(h, hipMemcpyAsync(h->work.p, rg.data(), rg.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));  // (rg goes out of scope)
+    d_range = static_cast<const int*>(h->work.p);
+  }
   HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), n_frames, sp, static_cast<const double*>(h->mtab.p),
                             static_cast<uint32_t*>(h->hist.p), auto_splits(h, n_frames, n_markers), n_markers,
-                            h->stream));
+                            h->stream, nullptr, 0, nullptr, 0, nullptr, d_range));
   HIP_TRY(h, hipMemcpyAsync(hist, h->hist.p, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPE_OK;
 }
+}  // namespace
 
 namespace {
 int solve_bruteforce_impl(mpe_handle* h, const double* det_xy, int n_det, const double* markers_xyz, int n_markers,

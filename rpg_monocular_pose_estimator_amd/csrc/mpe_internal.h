@@ -81,7 +81,8 @@ hipError_t launch_k2_prep(const SolveParams& sp, double* tab, hipStream_t s);
 hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
                           uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px = nullptr,
                           size_t scan_bytes = 0, unsigned long long* scan_flags = nullptr, int scan_thr = 0,
-                          size_t* scanned_bytes = nullptr);
+                          size_t* scanned_bytes = nullptr, const int* item_range = nullptr);
+// item_range (device, 2 ints per frame, forensics only): frame f votes with hypotheses [lo, hi) only, see mpe_vote_items
 // the tail = k3a_validate + k3b_refine; mid_buf: k3_mid_bytes(n_frames) of device memory handed from one to the other
 size_t k3_mid_bytes(int n_frames);
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,

@@ -1474,6 +1474,10 @@ struct ScanRider {
     }
   }
 };
+// small helpers of the voting item; the host-tier build (tests/host/vote_host.cpp) brings its own one-lane versions
+__device__ __forceinline__ bool k2_isfinite(double x) { return __builtin_isfinite(x); }
+__device__ __forceinline__ f32x2 k2_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float k2_fminf(float a, float b) { return __builtin_fminf(a, b); }
 struct NoRider {
   __device__ __forceinline__ void consume() {}
   __device__ __forceinline__ void issue() {}
@@ -1481,9 +1485,9 @@ struct NoRider {
 };
 
 // Everything of computePoses that depends on the detection triple only (p3p.cpp:82-121, 143-154): the tau frame T
-// (rows, t[0..8]), f_1, f_2, b, f_1 / f_2 (t[9..12]) and the triple's indices + the swap flag (packed).
-__device__ __forceinline__ void k2_triple_entry(const double (*iv)[3], int n_d, int idx, double* __restrict__ t,
-                                                unsigned& packed) {
+// (as K T^T, t[0..8]), f_1, f_2, b, f_1 / f_2 (t[9..12]) and the triple's indices + the swap flag (packed).
+__device__ __forceinline__ void k2_triple_entry(const double (*iv)[3], int n_d, int idx, double fx, double fy, double cx,
+                                                double cy, double* __restrict__ t, unsigned& packed) {
   int c0, c1, c2;
   unrank_combo3(idx, n_d, c0, c1, c2);
   const V3 fa = {iv[c0][0], iv[c0][1], iv[c0][2]}, fb = {iv[c1][0], iv[c1][1], iv[c1][2]},
@@ -1510,9 +1514,11 @@ __device__ __forceinline__ void k2_triple_entry(const double (*iv)[3], int n_d, 
   const double cos_beta = dot(f1, f2);
   double b = 1 / (1 - cos_beta * cos_beta) - 1;
   b = (cos_beta < 0) ? -sqrt(b) : sqrt(b);
-  t[0] = T.r0.x; t[1] = T.r0.y; t[2] = T.r0.z;
-  t[3] = T.r1.x; t[4] = T.r1.y; t[5] = T.r1.z;
-  t[6] = T.r2.x; t[7] = T.r2.y; t[8] = T.r2.z;
+  // K T^T, row by row: a point w of the tau frame projects to (t[0..2].w, t[3..5].w) / (t[6..8].w) — the camera
+  // matrix folded into the frame change once per triple instead of once per back-projection
+  t[0] = fx * T.r0.x + cx * T.r0.z; t[1] = fx * T.r1.x + cx * T.r1.z; t[2] = fx * T.r2.x + cx * T.r2.z;
+  t[3] = fy * T.r0.y + cy * T.r0.z; t[4] = fy * T.r1.y + cy * T.r1.z; t[5] = fy * T.r2.y + cy * T.r2.z;
+  t[6] = T.r0.z; t[7] = T.r1.z; t[8] = T.r2.z;
   t[9] = f3.x / f3.z;
   t[10] = f3.y / f3.z;
   t[11] = b;
@@ -1524,7 +1530,7 @@ __device__ __forceinline__ void k2_triple_entry(const double (*iv)[3], int n_d, 
 // this source, tests/test_vote_host.py).
 struct K2Frame {
   const unsigned* trii;      // per staged triple: c0 | c1 << 8 | c2 << 16 | swap << 24
-  const double (*tri)[13];   // per staged triple: T rows, f_1, f_2, b, f_1 / f_2
+  const double (*tri)[13];   // per staged triple: K T^T rows, f_1, f_2, b, f_1 / f_2
   const double (*px)[2];     // undistorted detections
   const f32x2* pxf;          // the same in single precision (nearest-neighbour prefilter)
   double* q;                 // back-projections [2 * j + {0, 1}][lane] (plain variant)
@@ -1558,9 +1564,9 @@ __device__ __forceinline__ float k2_prefilter_threshold(double back_tol) {
 }
 
 // The exact half of the nearest-neighbour vote of ONE hypothesis (pose_estimator.cpp:663-702) for the unused
-// detections whose bit is set in `pass` (those that got through the single-precision prefilter), with the (<= 2)
-// back-projections passed by value: exact double-precision search, strict `< tol` decided on the squares (the square
-// root is only taken inside the rounding band around tol^2), votes, and the triple's own three votes if any
+// detections whose bit is set in `pass` (bit a = detection a got through the single-precision prefilter), with the
+// (<= 2) back-projections passed by value: exact double-precision search, strict `< tol` decided on the squares (the
+// square root is only taken inside the rounding band around tol^2), votes, and the triple's own three votes if any
 // detection voted.  The lane must be allowed to vote.
 __device__ __forceinline__ void k2_vote_exact(const K2Frame& F, int c0, int c1, int c2, int p0, int p1, int p2,
                                               unsigned pass, double q0u, double q0v, double q1u, double q1v) {
@@ -1569,12 +1575,8 @@ __device__ __forceinline__ void k2_vote_exact(const K2Frame& F, int c0, int c1, 
   const int lo = min(p0, min(p1, p2)), hi = max(p0, max(p1, p2)), mid = p0 + p1 + p2 - lo - hi;
   bool any = false;
   while (pass) {
-    const int u = __builtin_ctz(pass);
+    const int a = __builtin_ctz(pass);
     pass &= pass - 1;
-    int a = u;
-    a += (a >= c0);
-    a += (a >= c1);
-    a += (a >= c2);
     const double au = F.px[a][0], av = F.px[a][1];
     double best = INFINITY;
     int bj = 0;
@@ -1637,7 +1639,6 @@ __device__ __forceinline__ void k2_vote_flush(const K2Frame& F, int count) {
 // (pose_estimator.cpp:596-702).  `live` = false: compute on, never vote (wave-uniform loop of the rider variant).
 template <bool SCAN, class Rider>
 __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, bool live, Rider& rider, int& vq_count) {
-  const double fx = F.fx, fy = F.fy, cx = F.cx, cy = F.cy;
   const unsigned ii = F.trii[ti];
   const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
   const bool swap = (ii >> 24) & 1;
@@ -1688,6 +1689,24 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
   // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
   const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
   const double tol2 = F.back_tol * F.back_tol;
+  // the detections outside the triple, as a bit mask (n_d <= 32)
+  const unsigned unused = (0xFFFFFFFFu >> (32 - F.n_d)) & ~((1u << c0) | (1u << c1) | (1u << c2));
+  // scan-carrying variant: the first two of them (all of them in a 5-detection frame) stay in registers for the four
+  // roots' prefilters; a missing second one sits at infinity and passes no test
+  unsigned rest = unused, lsb0 = 0, lsb1 = 0;
+  f32x2 af0 = {INFINITY, INFINITY}, af1 = {INFINITY, INFINITY};
+  if constexpr (SCAN) {
+    lsb0 = rest & (0u - rest);
+    rest ^= lsb0;
+    lsb1 = rest & (0u - rest);
+    rest ^= lsb1;
+    af0 = F.pxf[__builtin_ctz(lsb0 | 0x80000000u)];
+    const f32x2 t1 = F.pxf[__builtin_ctz(lsb1 | 0x80000000u)];
+    af1 = lsb1 ? t1 : af1;
+  }
+  // Everything behind the roots is evaluated with fused multiply-adds: this part never was in the reference's
+  // operation order ([R|C]-free back-projection), its results feed only the `< tol` test, and a vote can only change
+  // when a distance sits within ~1e-13 px of the tolerance.  (The quartic above keeps the literal order.)
 
 #pragma unroll 1
   for (int k = 0; k < 4; ++k) {
@@ -1699,50 +1718,51 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     // cot_alpha = cn / cd;  sin_alpha = sqrt(1 / (cot^2 + 1)) = |cd| / hypot(cn, cd),
     // cos_alpha = sign(cot) sqrt(1 - sin^2) = cn sign(cd) / hypot(cn, cd)
     const double cn = g1 - rt * p_2, cd = g2 * rt + g3;
-    const double ih = rsqrt_nr(cn * cn + cd * cd);
+    const double ih = rsqrt_nr(__builtin_fma(cn, cn, cd * cd));
     const double cos_theta = rt;
     const double sin_theta = sqrt_nr(1 - rt * rt);
     const double sin_alpha = fabs(cd) * ih;
     const double cos_alpha = (cd < 0 ? -cn : cn) * ih;
-    const double kk = sin_alpha * b + cos_alpha;
-    const double Cx = d_12 * cos_alpha * kk, Cy = cos_theta * d_12 * sin_alpha * kk,
-                 Cz = sin_theta * d_12 * sin_alpha * kk;
-    // isFinite([R C]) (pose_estimator.cpp:653): R and C are finite iff these are
-    const double z = (cos_alpha - cos_alpha) + (sin_alpha - sin_alpha) + (sin_theta - sin_theta) +
-                     (cos_theta - cos_theta) + (Cx - Cx) + (Cy - Cy) + (Cz - Cz);
+    const double dk = d_12 * __builtin_fma(sin_alpha, b, cos_alpha);
+    const double sdk = sin_alpha * dk;
+    const double Cx = cos_alpha * dk, Cy = cos_theta * sdk, Cz = sin_theta * sdk;
+    // isFinite([R C]) (pose_estimator.cpp:653): a product is finite only if every factor is (0 * inf = NaN), so
+    // R (products of the four sines / cosines with the finite frames) and C are finite iff C_eta is
     bool finite_pose = true;
-    if (!(z == 0.0)) {
+    if (!(k2_isfinite(Cx) && k2_isfinite(Cy) && k2_isfinite(Cz))) {
       if constexpr (SCAN)
         finite_pose = false;
       else
         continue;
     }
     const bool may_vote = live && finite_pose;
-    const double T00 = tr[0], T01 = tr[1], T02 = tr[2], T10 = tr[3], T11 = tr[4], T12 = tr[5], T20 = tr[6],
-                 T21 = tr[7], T22 = tr[8];
     double q0u = 0, q0v = 0, q1u = 0, q1v = 0;
-    f32x2 q0f = {0.f, 0.f}, q1f = {0.f, 0.f};
+    // the prefilter's operands, transposed: (u of marker 0, u of marker 1) and (v, v); a missing second marker sits
+    // at infinity and never is the nearest
+    f32x2 qfu = {0.f, INFINITY}, qfv = {0.f, INFINITY};
     for (int j = 0; j < F.nuo; ++j) {
       const double* mk = SCAN ? lt + 5 + 3 * j : e + 18 + 3 * j;
       const double v0 = mk[0] - Cx, v1 = mk[1] - Cy, v2 = mk[2] - Cz;
-      const double g = cos_theta * v1 + sin_theta * v2;
-      const double w0 = -cos_alpha * v0 - sin_alpha * g;
-      const double w1 = sin_alpha * v0 - cos_alpha * g;
-      const double w2 = -sin_theta * v1 + cos_theta * v2;
-      const double X = T00 * w0 + T10 * w1 + T20 * w2;  // T^T w
-      const double Y = T01 * w0 + T11 * w1 + T21 * w2;
-      const double Z = T02 * w0 + T12 * w1 + T22 * w2;
+      const double g = __builtin_fma(cos_theta, v1, sin_theta * v2);
+      const double w0 = -__builtin_fma(cos_alpha, v0, sin_alpha * g);
+      const double w1 = __builtin_fma(sin_alpha, v0, -(cos_alpha * g));
+      const double w2 = __builtin_fma(cos_theta, v2, -(sin_theta * v1));
+      const double U = __builtin_fma(tr[0], w0, __builtin_fma(tr[1], w1, tr[2] * w2));  // K T^T w
+      const double V = __builtin_fma(tr[3], w0, __builtin_fma(tr[4], w1, tr[5] * w2));
+      const double Z = __builtin_fma(tr[6], w0, __builtin_fma(tr[7], w1, tr[8] * w2));
       const double iZ = rcp_nr(Z);
-      const double qu = (fx * X + cx * Z) * iZ, qv = (fy * Y + cy * Z) * iZ;
+      const double qu = U * iZ, qv = V * iZ;
       if constexpr (SCAN) {  // <= 2 unused markers in this variant: registers instead of the LDS columns
         if (j == 0) {
           q0u = qu;
           q0v = qv;
-          q0f = f32x2{(float)qu, (float)qv};
+          qfu.x = (float)qu;
+          qfv.x = (float)qv;
         } else {
           q1u = qu;
           q1v = qv;
-          q1f = f32x2{(float)qu, (float)qv};
+          qfu.y = (float)qu;
+          qfv.y = (float)qv;
         }
       } else {
         F.q[(2 * j) * F.nthr + F.tid] = qu;
@@ -1752,25 +1772,20 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     }
     // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
     if constexpr (SCAN) {
-      // prefilter over all unused detections -> mask; the exact half is deferred (k2_vote_flush)
-      unsigned pass = 0;
-      for (int u = 0; u < F.n_d - 3; ++u) {
-        int a = u;
-        a += (a >= c0);
-        a += (a >= c1);
-        a += (a >= c2);
-        const f32x2 af = F.pxf[a];
-        float mn = INFINITY;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          if (jj < F.nuo) {
-            f32x2 df = af - (jj == 0 ? q0f : q1f);
-            df = df * df;
-            const float d2f = df.x + df.y;
-            mn = d2f < mn ? d2f : mn;  // (a NaN distance never wins, as in the exact search)
-          }
-        }
-        pass |= (mn <= F.thr_pre) ? (1u << u) : 0u;
+      // prefilter over all unused detections -> mask over the detections; the exact half is deferred (k2_vote_flush)
+      // squared single-precision distances of one detection to marker 0 / marker 1, the smaller one against the
+      // threshold (a NaN distance never wins, as in the exact search)
+      auto near = [&](const f32x2 af) -> bool {
+        const f32x2 du = f32x2{af.x, af.x} - qfu, dv = f32x2{af.y, af.y} - qfv;
+        const f32x2 d2 = k2_pk_fma(dv, dv, du * du);
+        return k2_fminf(d2.x, d2.y) <= F.thr_pre;
+      };
+      unsigned pass = (near(af0) ? lsb0 : 0u) | (near(af1) ? lsb1 : 0u);
+      for (unsigned m = rest; m;) {  // (more than five detections)
+        const unsigned lsb = m & (0u - m);
+        const int a = __builtin_ctz(m);
+        m ^= lsb;
+        pass |= near(F.pxf[a]) ? lsb : 0u;
       }
       // slots by ballot: the queue's fill count is wave-uniform (a scalar register), no LDS atomic
       const bool want = pass != 0u && may_vote;
@@ -1793,19 +1808,15 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
       continue;
     }
     bool any = false;
-    // the detections that are not part of the triple, ascending (c0 < c1 < c2): the u-th one is found by
-    // skipping over the three used indices — a uniform trip count for the frame and no lane sits out
-    for (int u = 0; u < F.n_d - 3; ++u) {
-      int a = u;
-      a += (a >= c0);
-      a += (a >= c1);
-      a += (a >= c2);
+    // the detections that are not part of the triple, ascending: a uniform trip count for the frame
+    for (unsigned m = unused; m; m &= m - 1) {
+      const int a = __builtin_ctz(m);
       {  // single-precision prefilter (packed arithmetic: both coordinates per instruction)
         const f32x2 af = F.pxf[a];
         float mn = INFINITY;
 #pragma unroll 4
         for (int jj = 0; jj < F.nuo; ++jj) {
-          const f32x2 qf = SCAN ? (jj == 0 ? q0f : q1f) : F.qf[jj * F.nthr + F.tid];
+          const f32x2 qf = F.qf[jj * F.nthr + F.tid];
           f32x2 df = af - qf;
           df = df * df;
           const float d2f = df.x + df.y;
@@ -1817,8 +1828,8 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
       double best = INFINITY;
       int bj = 0;
       for (int jj = 0; jj < F.nuo; ++jj) {
-        const double bu = SCAN ? (jj == 0 ? q0u : q1u) : F.q[(2 * jj) * F.nthr + F.tid];
-        const double bv = SCAN ? (jj == 0 ? q0v : q1v) : F.q[(2 * jj + 1) * F.nthr + F.tid];
+        const double bu = F.q[(2 * jj) * F.nthr + F.tid];
+        const double bv = F.q[(2 * jj + 1) * F.nthr + F.tid];
         const double du = au - bu, dv = av - bv;
         const double d2 = du * du + dv * dv;
         if (d2 < best) {
@@ -1866,10 +1877,13 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
 #ifndef K2_MIN_WAVES
 #define K2_MIN_WAVES 3
 #endif
-template <bool SCAN>
+// RANGE (forensics only, mpe_vote_items): frame f votes with the hypotheses whose flattened index — detection triple
+// x P(n_m,3) + marker permutation, the reference's loop order — lies in [item_range[2f], item_range[2f+1]); the
+// arithmetic of an item is the hot kernel's (same k2_vote_item).
+template <bool SCAN, bool RANGE = false>
 __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_detections* __restrict__ dets, SolveParams sp,
                                                       const double* __restrict__ tab, uint32_t* __restrict__ hist,
-                                                      int splits, ScanArgs scan) {
+                                                      int splits, ScanArgs scan, const int* __restrict__ item_range) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double s_px[MPE_MAX_DETECTIONS][2];
   __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
@@ -1937,7 +1951,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
     if (tc0) __syncthreads();
     // ---- per-triple part of computePoses (p3p.cpp:82-121, 143-154)
     if (tid < ntri) {
-      k2_triple_entry(s_iv, n_d, tc0 + tid, s_tri[tid], s_trii[tid]);
+      k2_triple_entry(s_iv, n_d, tc0 + tid, fx, fy, cx, cy, s_tri[tid], s_trii[tid]);
     }
     __syncthreads();
 
@@ -1959,6 +1973,10 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
       }
       bool live = true;
       const int ti_keep = ti, pj_keep = pj;
+      if constexpr (RANGE) {
+        const int g = (tc0 + ti) * n_perms + pj;
+        if (g < item_range[2 * f] || g >= item_range[2 * f + 1]) continue;
+      }
       if constexpr (SCAN) {
         if (t >= total) {
           live = false;
@@ -1993,7 +2011,8 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
 // No tables, no scan rider, about 2.5x the instructions of k2_vote: the reference point for the fast kernel's
 // divergence rate, selectable at run time.
 __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detections* __restrict__ dets, SolveParams sp,
-                                                             uint32_t* __restrict__ hist, int splits) {
+                                                             uint32_t* __restrict__ hist, int splits,
+                                                             const int* __restrict__ item_range) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double s_px[MPE_MAX_DETECTIONS][2];
   __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
@@ -2020,6 +2039,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detection
   const int nuo = n_m - 3;
   const long long total = (long long)n_combos * n_perms;
   for (long long t = (long long)part * nthr + tid; t < total; t += (long long)splits * nthr) {
+    if (item_range && (t < item_range[2 * f] || t >= item_range[2 * f + 1])) continue;  // (forensics only)
     const int ti = (int)(t / n_perms), pj = (int)(t - (long long)ti * n_perms);
     int c0, c1, c2, p0, p1, p2;
     unrank_combo3(ti, n_d, c0, c1, c2);
@@ -2088,7 +2108,8 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detection
 
 hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
                           uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px,
-                          size_t scan_bytes, unsigned long long* scan_flags, int scan_thr, size_t* scanned_bytes) {
+                          size_t scan_bytes, unsigned long long* scan_flags, int scan_thr, size_t* scanned_bytes,
+                          const int* item_range) {
   if (scanned_bytes) *scanned_bytes = 0;
   if (n_frames <= 0 || sp.n_markers < 4) return hipSuccess;
   if (splits < 1) splits = 1;
@@ -2096,7 +2117,7 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
   if (sp.vote_arith == 0) {  // strict arithmetic: the validation kernel's P3P, no tables, no scan rider
     const size_t lds_strict = (size_t)nuo * 2 * K2_THREADS * sizeof(double);
     hipLaunchKernelGGL(k2_vote_strict, dim3((unsigned)(n_frames * splits)), dim3(K2_THREADS), lds_strict, s, dets, sp,
-                       hist, splits);
+                       hist, splits, item_range);
     return hipGetLastError();
   }
   // block size: the multiple of 64 (<= 256) that wastes the fewest lanes on the expected item count
@@ -2117,6 +2138,10 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
       }
     }
   }
+  // plain kernel: 24 bytes of dynamic LDS per thread and unused marker (double + single precision back-projections) on
+  // top of ~10.5 KB static; the block shrinks until both fit the 64 KB a block may have without an opt-in (14 - 16
+  // markers: 192 / 128 threads)
+  while (threads > 64 && (size_t)nuo * 24 * threads + 11 * 1024 > 64 * 1024) threads -= 64;
   size_t lds = (size_t)nuo * 2 * threads * sizeof(double) + (size_t)nuo * threads * sizeof(f32x2);
   ScanArgs sa = {nullptr, nullptr, 0, {0u, 0u}};
   const size_t chunk_bytes = (size_t)K2_SCAN_R * 1024;
@@ -2129,11 +2154,14 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
           (size_t)sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2) * K2_LTAB * sizeof(double) +
           (size_t)(threads / 64) * K2_VQ_CAP * K2_VQ_WORDS * sizeof(u64);
     if (scanned_bytes) *scanned_bytes = (size_t)sa.n_chunks * chunk_bytes;
-    hipLaunchKernelGGL(k2_vote<true>, dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
-                       splits, sa);
+    hipLaunchKernelGGL((k2_vote<true, false>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
+                       splits, sa, (const int*)nullptr);
+  } else if (item_range) {
+    hipLaunchKernelGGL((k2_vote<false, true>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab,
+                       hist, splits, sa, item_range);
   } else {
-    hipLaunchKernelGGL(k2_vote<false>, dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
-                       splits, sa);
+    hipLaunchKernelGGL((k2_vote<false, false>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab,
+                       hist, splits, sa, (const int*)nullptr);
   }
   return hipGetLastError();
 }

@@ -142,6 +142,13 @@ __device__ __forceinline__ void solve_quartic(double A, double B, double C, doub
   rr[3] = off + 0.5 * (-w.re - s2.re);
 }
 
+// single-precision hardware units used by the cube-root seed (the host-tier build maps the builtins to libm)
+__device__ __forceinline__ float p3p_exp2f(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+__device__ __forceinline__ float p3p_log2f(float x) { return __builtin_amdgcn_logf(x); }    // v_log_f32 (base 2)
+__device__ __forceinline__ float p3p_rcpf(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32
+__device__ __forceinline__ float p3p_sin_rev(float x) { return __builtin_amdgcn_sinf(x); }  // sin(2 pi x)
+__device__ __forceinline__ float p3p_cos_rev(float x) { return __builtin_amdgcn_cosf(x); }  // cos(2 pi x)
+
 // ---- fast arithmetic of the voting kernel (option "vote_arith" = 1, the default) -----------------
 // Newton-Raphson reciprocal / division / square root on top of v_rcp_f64 / v_rsq_f64, without the
 // range scaling and fix-up of the IEEE expansions (12 / 22 VALU ops each): ~7 / 9 ops, <= 1 ulp for
@@ -161,7 +168,9 @@ __device__ __forceinline__ double div_nr(double a, double b) {
   const double r = __builtin_fma(-b, q, a);
   return __builtin_fma(r, x, q);
 }
-__device__ __forceinline__ double sqrt_nr(double a) {
+// sqrt(a) and, as a by-product of the same Newton-Raphson sequence, hh = 1 / (2 sqrt(a)) (relative error ~1e-16):
+// a ready reciprocal for a division by the root that follows (a == 0: the root is 0, hh is not usable)
+__device__ __forceinline__ double sqrt_nr_h(double a, double& hh) {
   const double y = __builtin_amdgcn_rsq(a);
   double g = a * y, h = 0.5 * y;
   double r = __builtin_fma(-h, g, 0.5);
@@ -172,7 +181,12 @@ __device__ __forceinline__ double sqrt_nr(double a) {
   h = __builtin_fma(h, r, h);
   const double d = __builtin_fma(-g, g, a);
   g = __builtin_fma(d, h, g);
+  hh = h;
   return a == 0.0 ? 0.0 : g;
+}
+__device__ __forceinline__ double sqrt_nr(double a) {
+  double hh;
+  return sqrt_nr_h(a, hh);
 }
 // 1/sqrt(a)
 __device__ __forceinline__ double rsqrt_nr(double a) {
@@ -198,8 +212,9 @@ __device__ __forceinline__ double hypot_acc(double x, double y) {
   const double sum = s + t;
   const double bb = sum - s;
   const double err = ((s - (sum - bb)) + (t - bb)) + (es + et);  // two-sum residue + product residues
-  const double r = sqrt_nr(sum);
-  return r + 0.5 * err * rcp_nr(r);  // first-order correction of sqrt(sum + err)
+  double h;
+  const double r = sqrt_nr_h(sum, h);
+  return r + err * h;  // first-order correction of sqrt(sum + err): err / (2 r), the reciprocal from the root itself
 }
 // ---- cheaper forms of the same operations ------------------------------------------------------------
 // x / c for a compile-time constant c: reciprocal constant + one residual correction (3 ops, <= 1 ulp)
@@ -227,42 +242,61 @@ __device__ __forceinline__ C2 cdiv_lit2(C2 n, C2 d) {
   return {div_with_rcp(p * ratio + q, denom, x), div_with_rcp(swap ? t : -t, denom, x)};
 }
 // csqrt_ with its two half-planes folded the same way: t = sqrt((|z| + |re|) / 2), u = im / (2 t);
-// re > 0: (t, u), else (|u|, copysign(t, im)).
+// re > 0: (t, u), else (|u|, copysign(t, im)).  The real-axis case of csqrt_ (im == 0: sqrt(|re|) on the real or the
+// imaginary axis, im keeps its signed zero) goes through the SAME instructions — its radicand |re| is selected in
+// front of the one square root, its u is im itself — because in a wave of 64 hypotheses some lane nearly always has a
+// real operand (a real discriminant, a real resolvent root) and a branch would make the whole wave walk both sides.
+// The division by t takes its reciprocal from the square root's own Newton sequence (2h = 1/t).
 __device__ __forceinline__ C2 csqrt_lit2(C2 z) {
-  if (z.im == 0.0) {
-    if (z.re < 0.0) return {0.0, copysign(sqrt_nr(-z.re), z.im)};
-    return {fabs(sqrt_nr(z.re)), z.im};
-  }
+  const bool real = z.im == 0.0;
+  const double are = fabs(z.re);
   const double d = hypot_acc(z.re, z.im);
-  const double t = sqrt_nr(0.5 * (d + fabs(z.re)));
-  const double u = 0.5 * div_nr(z.im, t);
-  const bool right = z.re > 0.0;
+  double h;
+  const double t = sqrt_nr_h(real ? are : 0.5 * (d + are), h);
+  double u = 0.5 * div_with_rcp(z.im, t, 2.0 * h);
+  u = real ? z.im : u;  // (+-0; also when t == 0)
+  const bool right = !(z.re <= 0.0);  // re > 0, or NaN (which then stays in the real part, as in csqrt_)
   return {right ? t : fabs(u), right ? copysign(u, z.im) : copysign(t, z.im)};
 }
 // Principal complex cube root (= std::pow(z, 1/3.) of p3p.cpp:262,266 through its polar form) without the
-// double-precision atan2 / sincos / cbrt (~330 VALU ops): a single-precision polar seed (relative error
-// ~1e-6) refined by two Newton steps w <- (2w + z / w^2) / 3 in double (quadratic: 1e-6 -> 1e-12 -> rounding).
+// double-precision atan2 / sincos / cbrt (~330 VALU ops): a single-precision polar seed (relative error < 5e-6)
+// refined by two Newton steps w <- (2w + z / w^2) / 3 in double (quadratic: 5e-6 -> 2.5e-11 -> rounding level).
 // z is first scaled by a power of 8 into [1/8, 8) so that the float seed cannot overflow or flush.
+// The seed costs ~25 instructions: |z|^(1/3) = exp2(log2(|z|^2) / 6) on the hardware log / exp units, the angle by
+// a 5-term odd polynomial for atan on [0, 1] (|error| <= 1e-5 rad, Abramowitz & Stegun 4.4.47) with the usual octant
+// fix-ups, sine / cosine on the hardware units (argument in revolutions).  A positive real z (std::pow's real branch:
+// cbrt) takes the same path — seed angle 0, imaginary part 0 throughout — instead of a branch that a wave of 64
+// hypotheses would nearly always have to walk as well; its imaginary part is returned as +0.
 __device__ __forceinline__ C2 cpow_third_newton(C2 z) {
-  if (z.im == 0.0 && z.re > 0.0) return {cbrt(z.re), 0.0};
+  const bool posreal = z.im == 0.0 && z.re > 0.0;
   const double m = fmax(fabs(z.re), fabs(z.im));
   if (m == 0.0) return {0.0, 0.0};  // pow(0, 1/3): rho = 0
   const int e = ilogb(m);                       // NaN / inf propagate through the arithmetic below
   const int k = (e >= 0 ? e : e - 2) / 3;       // floor(e / 3)
   const double a = ldexp(z.re, -3 * k), b = ldexp(z.im, -3 * k);
   const float af = (float)a, bf = (float)b;
-  const float rho = cbrtf(sqrtf(af * af + bf * bf));
-  const float phi = atan2f(bf, af) * (1.0f / 3.0f);
-  double wr = (double)(rho * __cosf(phi)), wi = (double)(rho * __sinf(phi));
+  const float rho = p3p_exp2f(p3p_log2f(af * af + bf * bf) * (1.0f / 6.0f));
+  const float ax = fabsf(af), ay = fabsf(bf);
+  const float tq = fminf(ax, ay) * p3p_rcpf(fmaxf(ax, ay));
+  const float t2 = tq * tq;
+  float phi = fmaf(fmaf(fmaf(fmaf(0.0208351f, t2, -0.0851330f), t2, 0.1801410f), t2, -0.3302995f), t2, 0.9998660f) * tq;
+  phi = ay > ax ? 1.57079632679f - phi : phi;
+  phi = af < 0.0f ? 3.14159265359f - phi : phi;
+  phi = copysignf(phi, bf);
+  const float rev = phi * (float)(1.0 / (6.0 * 3.14159265358979323846));  // phi / 3 in revolutions
+  double wr = (double)(rho * p3p_cos_rev(rev)), wi = (double)(rho * p3p_sin_rev(rev));
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
-    const double sr = wr * wr - wi * wi, si = 2.0 * wr * wi;  // w^2
-    const double in = rcp_nr(sr * sr + si * si);
-    const double tr = (a * sr + b * si) * in, ti = (b * sr - a * si) * in;  // z / w^2
-    wr = (2.0 * wr + tr) * (1.0 / 3.0);
-    wi = (2.0 * wi + ti) * (1.0 / 3.0);
+    const double sr = __builtin_fma(wr, wr, -(wi * wi)), si = (wr + wr) * wi;  // w^2
+    const double n2 = __builtin_fma(sr, sr, si * si);
+    double in = __builtin_amdgcn_rcp(n2);
+    in = __builtin_fma(in, __builtin_fma(-n2, in, 1.0), in);
+    if (it == 1) in = __builtin_fma(in, __builtin_fma(-n2, in, 1.0), in);  // (the first step only needs ~1e-11)
+    const double tr = __builtin_fma(a, sr, b * si) * in, ti = __builtin_fma(b, sr, -(a * si)) * in;  // z / w^2
+    wr = __builtin_fma(wr, 2.0 / 3.0, tr * (1.0 / 3.0));
+    wi = __builtin_fma(wi, 2.0 / 3.0, ti * (1.0 / 3.0));
   }
-  return {ldexp(wr, k), ldexp(wi, k)};
+  return {ldexp(wr, k), posreal ? 0.0 : ldexp(wi, k)};
 }
 struct NoService {
   __device__ __forceinline__ void operator()() const {}

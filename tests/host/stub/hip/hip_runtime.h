@@ -14,3 +14,10 @@
 // (glibc declares __sinf / __cosf itself but does not export them: route the names to the public functions)
 #define __sinf(x) sinf(x)
 #define __cosf(x) cosf(x)
+// single-precision hardware units of the cube-root seed (v_exp_f32 / v_log_f32 are base 2, v_sin_f32 / v_cos_f32
+// take revolutions)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_amdgcn_logf(x) log2f(x)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_sinf(x) sinf(6.28318530717958647692f * (x))
+#define __builtin_amdgcn_cosf(x) cosf(6.28318530717958647692f * (x))

@@ -17,6 +17,9 @@ struct f32x2 {  // clang's ext_vector_type(2) float, as far as the voting item u
 };
 static inline f32x2 operator-(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y - b.y}; }
 static inline f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
+static inline f32x2 k2_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{std::fmaf(a.x, b.x, c.x), std::fmaf(a.y, b.y, c.y)}; }
+static inline float k2_fminf(float a, float b) { return std::fminf(a, b); }
+static inline bool k2_isfinite(double x) { return std::isfinite(x); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) {
   const unsigned o = *p;
   *p += v;
@@ -75,7 +78,7 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   }
   std::vector<double> tri((size_t)n_combos * 13);
   std::vector<unsigned> trii(n_combos);
-  for (int i = 0; i < n_combos; ++i) k2_triple_entry(iv, n_d, i, tri.data() + (size_t)i * 13, trii[i]);
+  for (int i = 0; i < n_combos; ++i) k2_triple_entry(iv, n_d, i, sp.fx, sp.fy, sp.cx, sp.cy, tri.data() + (size_t)i * 13, trii[i]);
   std::vector<double> q(2 * nuo);
   std::vector<f32x2> qf(nuo);
   std::memset(hist, 0, sizeof(unsigned) * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS);
@@ -96,6 +99,22 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
     int unused = 0;
     for (int ti = 0; ti < n_combos; ++ti)
       for (int pj = 0; pj < n_perms; ++pj) k2_vote_item<false>(F, ti, pj, true, rider, unused);
+  }
+  return 0;
+}
+
+// n detection sets in one call (tests/soak_votes_host.py): det n x MPE_MAX_DETECTIONS x 2, hist n x MPE_MAX_DETECTIONS
+// x MPE_MAX_MARKERS
+extern "C" int host_vote_batch(const double* det, const int* n_det, int n, const double* markers, int n_m, const double* k4,
+                               double back_tol, unsigned* hist, int variant) {
+  for (int i = 0; i < n; ++i) {
+    unsigned* h = hist + (size_t)i * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS;
+    if (n_det[i] < 4) {
+      std::memset(h, 0, sizeof(unsigned) * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS);
+      continue;
+    }
+    const int rc = host_vote(det + (size_t)i * 2 * MPE_MAX_DETECTIONS, n_det[i], markers, n_m, k4, back_tol, h, variant);
+    if (rc) return rc;
   }
   return 0;
 }

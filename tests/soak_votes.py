@@ -1,25 +1,32 @@
-"""Vote-histogram parity soak: detection sets of N synthetic frames (HIP detection, bit-exact vs the oracle) through
-the HIP voting kernel in BOTH arithmetics (option "vote_arith": 1 fast, 0 strict) and through the oracle's
-voting (frame-parallel on the host cores); counts the frames whose histogram differs anywhere.
-usage (on an MI355X): python tests/soak_votes.py [frames [config]]      -> one JSON line"""
+"""Vote-histogram parity soak with forensics: detection sets of N synthetic frames (HIP detection, bit-exact vs the
+oracle) through the HIP voting kernel in BOTH arithmetics (option "vote_arith": 1 fast, 0 strict) and through the
+oracle's voting (frame-parallel on the host cores).  Every frame whose histogram differs anywhere is SAVED
+(detections + both histograms -> <out>.npz) and CLASSIFIED (tests/forensics.py): both paths are asked for every
+hypothesis' own votes, the difference is traced to the hypotheses that cast it, and each of those must sit in the
+unstable corner of the reference's Ferrari solver (cancellation < 1e-12) or be one on which the oracle's own P3P
+answer moves under a 1-ulp change of an input.  Exit code 1 if a mismatch stays unexplained.
+usage (on an MI355X): python tests/soak_votes.py [frames [config [out_prefix]]]      -> one JSON line"""
 import json
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import rpg_monocular_pose_estimator_amd as mpe  # noqa: E402
 from rpg_monocular_pose_estimator_amd import synth  # noqa: E402
 import oracle  # noqa: E402
+import forensics  # noqa: E402
 
 oracle.build()
 from oracle import binding as orc  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 CONFIG = sys.argv[2] if len(sys.argv) > 2 else "C2"
-CH = min(N, 32768)
+OUT = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/soak_votes_%s" % CONFIG
+CH = min(N, 32768 if CONFIG != "C3" else 2048)
 cfg = synth.CONFIGS[CONFIG]
 rows, cols = cfg["rows"], cfg["cols"]
 K, D = synth.camera_for(rows, cols)
@@ -27,29 +34,50 @@ markers = np.asarray(cfg["markers"])
 dev = torch.device("cuda", 0)
 h = mpe.Handle(0)
 P = mpe.demo_params()
+TOL = 5.0
+cores = len(os.sched_getaffinity(0))
 diff = {0: 0, 1: 0}
 cells = {0: 0, 1: 0}
+saved = []
 tot = 0
 t0 = time.time()
-for part in range(N // CH):
+for part in range(max(1, N // CH)):
     _, spots = synth.make_scenes_batch(cfg, CH, seed=7100 + part)
     frames = synth.render_frames_torch(spots, rows, cols, cfg["spot_sigma"], dev, seed=8100 + part)
     torch.cuda.synchronize()
     det = h.detect_batch(frames, K, D, P)
     nd = det["n"].astype(np.int32)
     dets = det["undist_xy"].reshape(CH, mpe.MAX_DETECTIONS, 2)
-    ref = orc.vote_batch(dets, nd, markers, K, 5.0, n_threads=16)
+    ref = orc.vote_batch(dets, nd, markers, K, TOL, n_threads=cores)
     for arith in (1, 0):
+        if arith == 0 and CONFIG == "C3":
+            continue  # (the strict kernel takes 2.5x the time; C3 is soaked in the product arithmetic)
         h.set_option("vote_arith", arith)
-        got = h.vote_batch([dets[i, :nd[i]] for i in range(CH)], markers, K, 5.0)
+        got = h.vote_batch([dets[i, :nd[i]] for i in range(CH)], markers, K, TOL)
         for i in range(CH):
             r = ref[i, :nd[i], :len(markers)] if nd[i] >= 4 else np.zeros((nd[i], len(markers)), np.uint32)
             g = got[i] if nd[i] >= 4 else np.zeros_like(r)
             if not np.array_equal(g, r):
                 diff[arith] += 1
                 cells[arith] += int((g != r).sum())
+                c = forensics.classify_mismatch(dets[i, :nd[i]], markers, K, TOL, orc, h)
+                saved.append({"part": part, "frame": i, "vote_arith": arith, "det": dets[i, :nd[i]].copy(),
+                              "hip": g.copy(), "oracle": r.copy(), "verdict": c})
+    h.set_option("vote_arith", 1)
     tot += CH
     print(part, tot, diff, round(time.time() - t0), flush=True)
+unexplained = [s for s in saved if not s["verdict"]["unstable"]]
+if saved:
+    os.makedirs(os.path.dirname(OUT) or ".", exist_ok=True)
+    np.savez(OUT + ".npz", **{"det_%d" % k: s["det"] for k, s in enumerate(saved)},
+             **{"hip_%d" % k: s["hip"] for k, s in enumerate(saved)},
+             **{"oracle_%d" % k: s["oracle"] for k, s in enumerate(saved)},
+             meta=json.dumps([{k: v for k, v in s.items() if k not in ("det", "hip", "oracle")} for s in saved]))
 print(json.dumps({"config": CONFIG, "frames": tot, "p3p_solves_per_frame": "C(n_det,3) x P(n_markers,3)",
                   "frames_with_a_different_histogram": {"fast (vote_arith 1)": diff[1], "strict (vote_arith 0)": diff[0]},
-                  "differing_cells": {"fast": cells[1], "strict": cells[0]}}))
+                  "differing_cells": {"fast": cells[1], "strict": cells[0]},
+                  "mismatches_classified_unstable": len(saved) - len(unexplained),
+                  "mismatches_unexplained": len(unexplained),
+                  "mismatching_frames_saved_to": (OUT + ".npz") if saved else None,
+                  "verdicts": [{k: v for k, v in s.items() if k not in ("det", "hip", "oracle")} for s in saved]}))
+sys.exit(1 if unexplained else 0)

@@ -1,0 +1,233 @@
+"""GPU parity tests at the sizes VERDICT round 2 asked for: C3 (8 LEDs / 12 detections) and C4 (1920 x 1200) on 256
+frames each against the oracle, a full-size C4 batch through size-independent properties, marker sets up to the
+documented capacity (12 and 16 markers) in both voting arithmetics, and the frames on which the HIP path is KNOWN to
+differ from this CPU build of the oracle — each of those must be traced, hypothesis by hypothesis, to an instability of
+the reference algorithm itself (tests/forensics.py), or the test fails."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from rpg_monocular_pose_estimator_amd import synth
+import rpg_monocular_pose_estimator_amd as mpe
+from util import pose_diff, POS_TOL_M, ROT_TOL_RAD
+import forensics
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _frames_on_device(config, n, seed):
+    import torch
+    cfg = synth.CONFIGS[config]
+    T_true, spots = synth.make_scenes_batch(cfg, n, seed=seed)
+    dev = torch.device("cuda", 0)
+    frames = synth.render_frames_torch(spots, cfg["rows"], cfg["cols"], cfg["spot_sigma"], dev, seed=seed + 1)
+    torch.cuda.synchronize()
+    return cfg, T_true, frames
+
+
+def _compare_with_oracle(hip, orc, config, n, seed, tol, min_pose_frac):
+    """n frames end to end; every disagreement must be explained by the forensics; returns the number of poses."""
+    cfg, _, frames = _frames_on_device(config, n, seed)
+    K, D = synth.camera_for(cfg["rows"], cfg["cols"])
+    markers = np.asarray(cfg["markers"])
+    Ph = mpe.demo_params(back_projection_pixel_tolerance=tol)
+    Po = orc.make_params(back_projection_pixel_tolerance=tol)
+    host = frames.cpu().numpy()
+    got = hip.estimate_batch(frames, markers, K, D, Ph)
+    ref = orc.estimate_batch(host, markers, K, D, Po, n_threads=len(os.sched_getaffinity(0)))
+    assert np.array_equal(got["n_det"], ref["n_det"])
+    # detections bit-equal on a sub-sample (the oracle's findLeds alone, frame by frame)
+    det = hip.detect_batch(frames[:32], K, D, Ph)
+    for i in range(32):
+        und, dist = orc.find_leds(host[i], Po, K, D)
+        k = len(und)
+        assert det["n"][i] == k and np.array_equal(det["undist_xy"][i][:2 * k].reshape(-1, 2), und), i
+        assert np.array_equal(det["dist_xy"][i][:2 * k].reshape(-1, 2), dist), i
+    n_pose = n_bad = 0
+    for i in range(n):
+        same = got["status"][i] == ref["status"][i] and got["n_corr"][i] == ref["n_corr"][i]
+        if same and ref["status"][i] == 0:
+            dp, dr = pose_diff(got["T"][i], ref["T"][i])
+            same = dp <= POS_TOL_M and dr <= ROT_TOL_RAD
+            n_pose += 1
+        if not same:
+            n_bad += 1
+            und, _ = orc.find_leds(host[i], Po, K, D)
+            v = forensics.classify_end_to_end(hip, orc, und, markers, K, Ph, Po)
+            assert v["unstable"], ("unexplained HIP-vs-oracle mismatch", config, i, v)
+    assert n_bad <= max(1, n // 128), n_bad
+    assert n_pose >= min_pose_frac * n, (n_pose, n)
+    return n_pose
+
+
+@pytest.mark.parametrize("tol,min_pose_frac", [(2.0, 0.5), (5.0, 0.0)])
+def test_c3_256_frames_against_the_oracle(hip, orc, tol, min_pose_frac):
+    """BASELINE configs[2]: 8 LEDs + 4 distractors, 73 920 P3P solves per frame, 56 validation solves.  With the demo
+    tolerance (5 px) the reference algorithm itself mostly fails to initialise (12 detections x 8 markers pollute the
+    vote table) — parity of the verdicts is what is checked there; at 2 px most frames yield a pose."""
+    _compare_with_oracle(hip, orc, "C3", 256, 5150 + int(tol), tol, min_pose_frac)
+
+
+def test_c4_256_frames_against_the_oracle(hip, orc):
+    """BASELINE configs[3]: 1920 x 1200 frames, 5 LEDs."""
+    _compare_with_oracle(hip, orc, "C4", 256, 6160, 5.0, 0.85)
+
+
+def test_c4_full_size_batch_properties(orc):
+    """16 384 device-resident 1920 x 1200 frames (37.7 GB; 2 sub-batches of 8192): every schedule bit-identical to the
+    plain chain of kernels, frames independent (reversed batch -> reversed records), a random sample equal to the
+    oracle, poses close to the ground truth of the synthetic scenes."""
+    import torch
+    B = 16384
+    cfg, T_true, frames = _frames_on_device("C4", B, 7170)
+    rows, cols = cfg["rows"], cfg["cols"]
+    K, D = synth.camera_for(rows, cols)
+    markers = np.asarray(cfg["markers"])
+    dev = frames.device
+    P = mpe.demo_params()
+    h = mpe.Handle(0)
+    stream = torch.cuda.Stream(device=dev)
+    h.set_stream(stream.cuda_stream)
+    nb = B * mpe.RESULT_DTYPE.itemsize
+
+    def run(fr, pipeline, mode):
+        with torch.cuda.stream(stream):
+            out = torch.zeros(nb, dtype=torch.uint8, device=dev)
+            h.set_option("pipeline", pipeline)
+            h.set_option("pipeline_mode", mode)
+            h.estimate_batch_device(fr.data_ptr(), B, rows, cols, markers, K, D, P, out.data_ptr())
+        stream.synchronize()
+        return out
+
+    plain = run(frames, 1, -1)
+    for mode in (3, 4, 6, -1):
+        piped = run(frames, 16, mode)
+        assert torch.equal(piped, plain), mode
+    assert h.get_option("last_schedule") == 6
+    rec = np.frombuffer(plain.cpu().numpy().tobytes(), mpe.RESULT_DTYPE)
+    # (reversing 37.7 GB in place would need a second copy of the batch: reverse the first quarter instead)
+    q = B // 4
+    flipped = torch.flip(frames[:q], dims=[0]).contiguous()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        out = torch.zeros(q * mpe.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        h.estimate_batch_device(flipped.data_ptr(), q, rows, cols, markers, K, D, P, out.data_ptr())
+    stream.synchronize()
+    assert torch.equal(out.view(q, -1).flip(0), plain.view(B, -1)[:q])
+    del flipped
+    found = rec["status"] == 0
+    assert 0.88 < found.mean() <= 1.0 and (rec["status"] >= 0).all(), found.mean()
+    T = rec["T"].reshape(B, 4, 4)
+    dpos = np.linalg.norm(T[found][:, :3, 3] - T_true[found][:, :3, 3], axis=1)
+    assert np.median(dpos) < 5e-3 and np.mean(dpos < 0.05) > 0.97, (np.median(dpos), np.mean(dpos < 0.05))
+    idx = np.random.default_rng(1).choice(B, 64, replace=False)
+    sample = frames[torch.as_tensor(idx, device=dev)].cpu().numpy()
+    ref = orc.estimate_batch(sample, markers, K, D, orc.make_params(), n_threads=len(os.sched_getaffinity(0)))
+    for j, i in enumerate(idx):
+        assert rec["status"][i] == ref["status"][j] and rec["n_det"][i] == ref["n_det"][j], i
+        if ref["status"][j] == 0:
+            dp, dr = pose_diff(T[i], ref["T"][j].reshape(4, 4))
+            assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (i, dp, dr)
+    h.close()
+
+
+@pytest.mark.parametrize("n_markers", [9, 12, 14, 16])
+def test_many_markers_both_voting_kernels(orc, n_markers):
+    """Marker sets up to MPE_MAX_MARKERS: P(16,3) = 3360 permutations, 13 unused markers per hypothesis — the plain
+    voting kernel's per-thread LDS columns (24 bytes per unused marker) decide its block size there — in the fast and
+    in the strict arithmetic, histograms integer-equal to the oracle, and the whole brute-force solve."""
+    rng = np.random.default_rng(900 + n_markers)
+    K, _ = synth.camera_for(480, 752)
+    markers = rng.uniform(-0.12, 0.12, (n_markers, 3))
+    T = np.eye(4)
+    T[:3, :3] = synth.rodrigues(np.array([0.3, -0.5, 0.8]) / np.linalg.norm([0.3, -0.5, 0.8]), 0.4)
+    T[:3, 3] = [0.03, -0.02, 1.1]
+    px = synth.project(T, markers, K)
+    sets = []
+    for n_d in (5, 6):
+        pick = rng.choice(n_markers, n_d, replace=False)
+        sets.append(np.asarray(px[pick] + rng.normal(0, 0.05, (n_d, 2)), np.float32).astype(float))
+    h = mpe.Handle()
+    try:
+        for arith in (1, 0):
+            h.set_option("vote_arith", arith)
+            got = h.vote_batch(sets, markers, K, 3.0)
+            for i, det in enumerate(sets):
+                ref = orc.vote_histogram(det, markers, K, 3.0)
+                if not np.array_equal(got[i], ref):
+                    v = forensics.classify_mismatch(det, markers, K, 3.0, orc, h)
+                    assert v["unstable"], (n_markers, arith, i, v)
+                assert ref.sum() > 0
+        h.set_option("vote_arith", 1)
+        Po, Ph = orc.make_params(back_projection_pixel_tolerance=3.0), mpe.demo_params(back_projection_pixel_tolerance=3.0)
+        for det in sets:
+            ro = orc.solve_bruteforce(det, markers, K, Po)
+            rh = h.solve_bruteforce(det, markers, K, Ph)
+            assert rh["status"] == ro["status"] and np.array_equal(rh["corr"], ro["corr"])
+    finally:
+        h.close()
+
+
+def _known_sets():
+    files = sorted(glob.glob(os.path.join(HERE, "data", "unstable_det_*.npy")))
+    return [os.path.join(HERE, "data", "vote_regression_det_0.npy")] + files
+
+
+@pytest.mark.parametrize("path", _known_sets(), ids=lambda p: os.path.basename(p))
+def test_known_mismatching_frames_are_explained(hip, orc, path):
+    """Detection sets on which a build of the HIP path differed from this CPU build of the oracle (found by the parity
+    soaks, committed under tests/data).  Whatever the current build does on them — agree or differ — a difference must
+    be traced to hypotheses on which the reference algorithm disagrees with itself, and the oracle's own histogram must
+    move under a 1-ulp change of a detection coordinate (that is what made the frame a mismatch in the first place)."""
+    det = np.load(path)
+    K, _ = synth.camera_for(480, 752)
+    for arith in (1, 0):
+        h = mpe.Handle()
+        try:
+            h.set_option("vote_arith", arith)
+            got = h.vote_batch([det], synth.M5, K, 5.0)[0].astype(int)
+            ref = orc.vote_histogram(det, synth.M5, K, 5.0).astype(int)
+            v = forensics.classify_mismatch(det, synth.M5, K, 5.0, orc, h)
+            assert v["oracle_flips_under_1ulp"] or v["min_w"] < forensics.W_UNSTABLE, v
+            a = v["attribution"]
+            assert a["consistent"]
+            if not np.array_equal(got, ref):
+                assert a["differing_hypotheses"] and a["explained"], a
+                assert np.abs(got - ref).max() <= 2
+        finally:
+            h.close()
+
+
+def test_forensics_reject_an_injected_error(hip, orc):
+    """The classifier must not explain everything: a histogram difference that does NOT come from an unstable hypothesis
+    (here: the HIP histogram of a slightly different tolerance, compared with the oracle at the nominal one) is
+    reported as unexplained."""
+    d = synth.make_frames("C2", 12, seed=77)
+    n_checked = 0
+    for i in range(12):
+        und, _ = orc.find_leds(d["frames"][i], orc.make_params(), d["K"], d["D"])
+        if len(und) < 5:
+            continue
+        got = hip.vote_batch([und], d["markers"], d["K"], 9.0)[0]
+        ref = orc.vote_histogram(und, d["markers"], d["K"], 5.0)
+        if np.array_equal(got, ref):
+            continue
+        # per-hypothesis comparison of the HIP path at 9 px against the oracle at 5 px
+        n = forensics.n_hypotheses(len(und), len(d["markers"]))
+        lo = np.arange(n)
+        g = hip.vote_items(und, d["markers"], d["K"], 9.0, lo, lo + 1).astype(int)
+        r = np.stack([orc.vote_items(und, d["markers"], d["K"], 5.0, k, k + 1) for k in range(n)]).astype(int)
+        bad = np.nonzero((g != r).reshape(n, -1).any(1))[0]
+        assert len(bad) > 0
+        F, ok = forensics.hypothesis_quartics(und, d["markers"], d["K"])
+        w = forensics.ferrari_cancellation(F)
+        stable_bad = [k for k in bad if w[k] >= forensics.W_UNSTABLE and
+                      not forensics._oracle_p3p_moves(und, d["markers"], d["K"], k, orc)]
+        assert stable_bad, "an injected tolerance error was explained away"
+        n_checked += 1
+        if n_checked >= 2:
+            break
+    assert n_checked >= 1
