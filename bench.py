@@ -118,6 +118,10 @@ def main():
     ap.add_argument("--scan-split-pct", type=int, default=20, help="mode 6: share of a sub-batch scanned on the side stream")
     ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
     ap.add_argument("--vote-arith", type=int, default=1, help="1 fast voting arithmetic (default), 0 strict (IEEE)")
+    ap.add_argument("--no-streaming", action="store_true",
+                    help="one joined mpe_estimate_batch_device call per step instead of the submit / collect stream of batches")
+    ap.add_argument("--no-records-to-host", dest="records_to_host", action="store_false",
+                    help="leave the pose records on the device (no D2H copy inside the step)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no GPU work: the launch / shard / pose-gather / timing plumbing of the N-rank bench on CPU "
                          "(gloo), with synthetic records instead of kernels; used by the CPU test-suite")
@@ -193,17 +197,42 @@ def main():
         h.set_option("k1a_dummy_lds", args.k1a_lds)
 
     step_no = [0]
+    # The steps form a STREAM of batches (mpe_estimate_batch_device_submit / _collect): a submission does not join the
+    # library's side streams back, its completion is an event that the CONSUMER stream waits for — here the stream
+    # that delivers the pose records: an asynchronous, double-buffered D2H copy of the 432-byte records into pinned
+    # host memory on every rank (what a caller of estimateBodyPose ends up holding), and for N > 1 the RCCL gather of
+    # the records to rank 0.  Every submission announces the next one's frames, so its last voting launch carries the
+    # image scan of the next batch's first sub-batch.
+    out_stream = torch.cuda.Stream(device=dev)
+    rec_bytes = B * mpe.RESULT_DTYPE.itemsize
+    host_rec = [torch.empty(rec_bytes, dtype=torch.uint8).pin_memory() for _ in range(2)] if args.records_to_host else None
+    out_done = [None, None]
+    streaming = not args.no_streaming
 
     def step():
         k = step_no[0]
         step_no[0] += 1
         with torch.cuda.stream(work_stream):
             buf = pipe.local(k)             # (waits until this buffer's previous transfer has left)
-            h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, buf.data_ptr())
+            if out_done[k & 1] is not None:
+                work_stream.wait_event(out_done[k & 1])   # ... and until its previous D2H copy has read it
+            if streaming:
+                h.estimate_batch_device_submit(frames.data_ptr(), B, rows, cols, markers, K, D, P, buf.data_ptr(),
+                                               frames.data_ptr(), B)
+                h.estimate_batch_device_collect(out_stream.cuda_stream)
+            else:
+                h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, buf.data_ptr())
+                out_stream.wait_stream(work_stream)
+        with torch.cuda.stream(out_stream):
+            if host_rec is not None:
+                host_rec[k & 1].copy_(buf, non_blocking=True)
             pipe.submit(k)                  # the only collective: pose records -> rank 0, asynchronous
+            ev = torch.cuda.Event()
+            ev.record(out_stream)
+            out_done[k & 1] = ev
 
     def barrier():
-        with torch.cuda.stream(work_stream):
+        with torch.cuda.stream(out_stream):
             pipe.finish()
         if world > 1:
             dist.barrier()
@@ -234,8 +263,17 @@ def main():
     #      once per sub-batch; the numbers are AVERAGES PER LAUNCH, like rocprofv3 --stats reports them)
     h.set_profiling(True)
     kms, subs = [], []
+
+    def one_call():
+        if streaming:  # the same entry, hint included, as the timed region
+            h.estimate_batch_device_submit(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr(),
+                                           frames.data_ptr(), B)
+            h.estimate_batch_device_collect(0)
+        else:
+            h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
+
     for _ in range(min(5, max(3, args.steps))):
-        h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
+        one_call()
         kms.append(h.last_kernel_ms())
         if int(kms[-1]["launches"]) > 1:
             subs.append([h.last_kernel_ms_sub(i) for i in range(int(kms[-1]["launches"]))])
@@ -252,11 +290,13 @@ def main():
     if fused:
         # fused schedule: the scan of sub-batch s+1 runs INSIDE the voting kernel of sub-batch s; only the first
         # sub-batch is scanned by a stand-alone k1a_scan launch.  Average the launches that do the same thing.
-        vote_scan_ms = float(np.mean([sub[i]["vote"] for sub in subs for i in range(launches - 1)]))
-        vote_plain_ms = float(np.mean([sub[launches - 1]["vote"] for sub in subs]))
+        # (streaming: the last launch carries the scan of the NEXT batch's first sub-batch, like all the others)
+        n_fused = launches if streaming else launches - 1
+        vote_scan_ms = float(np.mean([sub[i]["vote"] for sub in subs for i in range(n_fused)]))
         scan_alone_ms = float(np.mean([sub[0]["scan"] for sub in subs]))
-        kavg.update({"scan_standalone_first_sub_batch": scan_alone_ms, "vote_with_scan": vote_scan_ms,
-                     "vote_last_sub_batch_without_scan": vote_plain_ms})
+        kavg.update({"scan_standalone_first_sub_batch": scan_alone_ms, "vote_with_scan": vote_scan_ms})
+        if not streaming:
+            kavg["vote_last_sub_batch_without_scan"] = float(np.mean([sub[launches - 1]["vote"] for sub in subs]))
         kavg["per_sub_batch"] = [{k: round(float(np.mean([sub[i][k] for sub in subs])), 4) for k in ("scan", "blobs", "vote", "tail")}
                                  for i in range(launches)]
         scan_s = vote_scan_ms * 1e-3
@@ -298,14 +338,13 @@ def main():
     if fused:
         roofline = {"kernel": "k2_vote<scan>", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
-                    "bytes_per_launch": bytes_per_launch, "avg_launch_ms": vote_scan_ms, "launches_per_step": launches - 1, "frames_per_launch": fpl,
+                    "bytes_per_launch": bytes_per_launch, "avg_launch_ms": vote_scan_ms, "launches_per_step": n_fused, "frames_per_launch": fpl,
                     "measured": "HIP events around every k2_vote<scan> launch on its stream in steps of the same "
                                 "mode as the timed region.  This kernel is the image pass AND the FP64 voting: each "
                                 "voting wave streams its share of the next sub-batch's pixels through LDS DMA "
                                 "(global_load_lds) between pieces of P3P arithmetic; bytes = the pixels it scans, "
-                                "time = the whole fused launch (the voting alone takes kernel_ms."
-                                "vote_last_sub_batch_without_scan).  roofline_isolated = the stand-alone scan "
-                                "kernel, which the first sub-batch of every step still uses."}
+                                "time = the whole fused launch (the voting alone: kernel_ms_isolated.vote / "
+                                "launches).  roofline_isolated = the stand-alone scan kernel."}
     else:
         roofline = {"kernel": "k1a_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
@@ -368,6 +407,9 @@ def main():
                        "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel", 4: "fused + validate/refine on a side stream",
                                     6: "fused + side-stream tail + scan split between a side k1a_scan and the rider"}.get(schedule, schedule),
                        "side_streams_concurrent": h.get_option("streams_concurrent"),
+                       "entry": ("mpe_estimate_batch_device_submit / _collect: a stream of batches, each announcing the "
+                                 "next one's frames" if streaming else "mpe_estimate_batch_device, one joined call per step"),
+                       "records_to_host": bool(args.records_to_host),
                        "parallelism": "frames sharded over %d GPU(s), pose records gathered to rank 0 (async, double-buffered)" % world},
             "poses_found_frac": n_pose / B,
             # every pixel of the batch is read once per step: the whole-step HBM rate against the 8 TB/s spec

@@ -174,6 +174,25 @@ int mpe_estimate_batch_device(mpe_handle* h, const uint8_t* d_frames, int n_fram
                               const double K[9], const double* D, int nD, const mpe_params* p,
                               mpe_result* d_results);
 
+/* The same for a STREAM of device-resident batches (a camera pipeline that keeps frames coming): _submit only enqueues,
+ * and it does not join the library's internal side streams back into the handle's stream — the records of the
+ * submission are complete when the event behind _collect says so, not at a point of the handle's stream.  _collect
+ * makes `hip_stream` (NULL = the handle's stream) wait for the records of the OLDEST un-collected submission; use the
+ * stream that consumes them (a D2H copy, a pose gather) so that the next batch's kernels need not wait for it.
+ * Up to two submissions may be in flight (submit k, submit k+1, collect k, ...); d_results must stay valid and
+ * untouched until its submission has been collected and the consumer stream has passed that point.
+ * d_next_frames / n_next_frames (optional): the frames of the NEXT submission (same geometry, camera, parameters).
+ * The last voting launch of this submission then also scans the next one's first sub-batch, and the next _submit with
+ * exactly those frames skips that scan — in steady state no kernel of a batch runs without an image scan beside it
+ * (pose_estimator.cpp:62-96 has no counterpart: the reference handles one frame at a time).  A hint that does not come
+ * true only costs the wasted scan.  mpe_estimate_batch_device = _submit without a hint + _collect on the handle's
+ * stream; it refuses to run while a submission is un-collected. */
+int mpe_estimate_batch_device_submit(mpe_handle* h, const uint8_t* d_frames, int n_frames, int rows, int cols,
+                                     const double* markers_xyz, int n_markers, const double K[9], const double* D,
+                                     int nD, const mpe_params* p, mpe_result* d_results,
+                                     const uint8_t* d_next_frames, int n_next_frames);
+int mpe_estimate_batch_device_collect(mpe_handle* h, void* hip_stream);
+
 /* ≙ PoseEstimator::setCorrespondences + checkCorrespondences + optimiseAndUpdatePose
  * (pose_estimator.h:463,724,773; pose_estimator.cpp:394-542,733-812) — the tracking path's
  * validate-and-refine step for correspondences found by nearest neighbour.  corr: n_corr rows
@@ -253,6 +272,10 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
                                 size_t stride_bytes, const mpe_params* p, const double K[9], const double* D, int nD,
                                 const double* markers_xyz, int n_markers);
 int mpe_track_step_batch_collect(mpe_handle* h, mpe_detections* dets_out, uint32_t* corr_out, mpe_result* out);
+/* _collect without a submission in flight is an error (MPE_ERR_ARG: a caller that missed a failed _submit must not read
+ * records that were never written).  _cancel abandons the submission in flight, if any: it waits for the device and
+ * frees the handle for the next _submit / mpe_track_step (used on error paths that drive several handles). */
+int mpe_track_step_batch_cancel(mpe_handle* h);
 /* mpe_solve_bruteforce for N detection sets in one submission (the re-initialisations of a lock-step batch):
  * det_xy n x MPE_MAX_DETECTIONS x 2 (n_det[i] valid rows); hist (optional) n x MPE_MAX_DETECTIONS x
  * MPE_MAX_MARKERS, corr (optional) n x 2*MPE_MAX_MARKERS. */

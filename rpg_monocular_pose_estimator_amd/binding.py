@@ -116,6 +116,11 @@ def load_library():
                                        C.c_int, dp, C.c_int, dp, dp, C.c_int, C.POINTER(MpeParams), C.c_void_p]
     lib.mpe_estimate_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, dp,
                                               C.c_int, C.POINTER(MpeParams), C.c_void_p]
+    lib.mpe_estimate_batch_device_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, dp, C.c_int, dp,
+                                                     dp, C.c_int, C.POINTER(MpeParams), C.c_void_p, C.c_void_p, C.c_int]
+    lib.mpe_estimate_batch_device_collect.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mpe_track_step_batch_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mpe_track_step_batch_cancel.argtypes = [C.c_void_p]
     lib.mpe_detect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int,
                                      dp, dp, C.c_int, C.POINTER(MpeParams), C.c_void_p]
     lib.mpe_vote_batch.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int), C.c_int, dp, C.c_int, dp, C.c_double,
@@ -557,6 +562,24 @@ class Handle:
                                                  len(markers), _dp(K), _dp(D), len(D), C.byref(params),
                                                  C.c_void_p(d_results_ptr))
         self._check(rc, "mpe_estimate_batch_device")
+
+    def estimate_batch_device_submit(self, d_frames_ptr, n, rows, cols, markers, K, D, params, d_results_ptr,
+                                     d_next_frames_ptr=0, n_next=0):
+        """Streaming variant: enqueue only, no join of the internal side streams; `d_next_frames_ptr` announces the
+        frames of the next submission (its first sub-batch is then scanned by this one's last voting launch)."""
+        markers = _f64(markers).reshape(-1, 3)
+        K = _f64(K).reshape(9)
+        D = _f64(D).reshape(-1)
+        rc = self._lib.mpe_estimate_batch_device_submit(self._h, C.c_void_p(d_frames_ptr), n, rows, cols, _dp(markers),
+                                                        len(markers), _dp(K), _dp(D), len(D), C.byref(params),
+                                                        C.c_void_p(d_results_ptr), C.c_void_p(d_next_frames_ptr or None),
+                                                        int(n_next))
+        self._check(rc, "mpe_estimate_batch_device_submit")
+
+    def estimate_batch_device_collect(self, stream_ptr=0):
+        """Make `stream_ptr` (0 = the handle's stream) wait for the records of the oldest un-collected submission."""
+        self._check(self._lib.mpe_estimate_batch_device_collect(self._h, C.c_void_p(stream_ptr or None)),
+                    "mpe_estimate_batch_device_collect")
 
     # ---- stage level ---------------------------------------------------------------------------
     def detect_batch(self, frames, K, D, params):

@@ -81,6 +81,29 @@ struct mpe_handle {
   unsigned long long last_rider_bytes = 0;  // bytes one fused voting launch scanned in the last large call
   hipStream_t tail_stream = nullptr;  // fused schedule, mode 4: validate + refine of sub-batch s beside blobs(s + 1)
   hipEvent_t tail_done = nullptr;
+  // ---- streaming submissions (mpe_estimate_batch_device_submit / _collect): up to two batches in flight
+  hipEvent_t batch_done[2] = {nullptr, nullptr};  // records of submission q complete: batch_done[q & 1]
+  unsigned submit_seq = 0, collect_seq = 0;       // submissions made / collected
+  hipEvent_t tail_sub_done[kMaxSub] = {};         // tail(s) of the previous submission has read dets / hist of region s
+  bool tail_sub_pending = false;
+  int tail_last = 0;                              // index of the last event recorded there
+  // image scan of the NEXT submission's first sub-batch, carried by the last voting launch of this one
+  struct Prefetch {
+    bool valid = false;
+    const uint8_t* frames = nullptr;
+    int per = 0;              // frames of that sub-batch
+    size_t frame_bytes = 0;
+    int thr = 0;
+    void* flags_base = nullptr;  // flags buffer the prefetched words live in (a re-allocation loses them)
+    size_t fw_per = 0;
+    bool side_part = false;      // part of it came from the side scan: wait for prefetch_side_done
+  } prefetch;
+  hipEvent_t prefetch_side_done = nullptr;
+  bool done_recorded = false;  // run_pipeline has recorded batch_done[submit_seq & 1] itself (fused schedules)
+  // side streams of schedules 4 / 6 verified (spin probe) to execute beside the caller's stream
+  int side_streams_ok = -1;           // 1 yes, 0 no concurrent set found (-> schedule 3), -1 not probed
+  hipStream_t probed_for = nullptr;   // the caller's stream the verdict holds for
+  bool probed_scan = false;           // ... including the scan stream
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   // per-sub-batch kernel brackets for the pipelined mode: [s][0..1] scan, [2..3] blobs (all tiers),
   // [4..5] vote, [6..7] tail
@@ -108,6 +131,26 @@ int fail(mpe_handle* h, int code, const char* what, hipError_t e = hipSuccess) {
   do {                                                           \
     hipError_t e__ = (call);                                     \
     if (e__ != hipSuccess) return fail(h, MPE_ERR_HIP, #call, e__); \
+  } while (0)
+
+// Every entry point that re-uses the handle's device buffers on its stream: select the device and, if a streaming
+// submission (mpe_estimate_batch_device_submit) still has validate / refine kernels on the internal tail stream, make
+// the handle's stream wait for them first (they read the detection / histogram buffers).  The streaming entry itself
+// orders those buffers region by region instead (run_pipeline).
+int enter(mpe_handle* h) {
+  hipError_t e = hipSetDevice(h->device);
+  if (e != hipSuccess) return fail(h, MPE_ERR_HIP, "hipSetDevice", e);
+  if (h->tail_sub_pending) {
+    e = hipStreamWaitEvent(h->stream, h->tail_sub_done[h->tail_last], 0);
+    if (e != hipSuccess) return fail(h, MPE_ERR_HIP, "hipStreamWaitEvent", e);
+    h->tail_sub_pending = false;
+  }
+  return MPE_OK;
+}
+#define ENTER(h)                  \
+  do {                            \
+    const int rc__ = enter(h);    \
+    if (rc__ != MPE_OK) return rc__; \
   } while (0)
 
 unsigned factorial_u32(int n) {  // combinations.cpp:34-40: 32-bit wrap-around kept on purpose
@@ -361,26 +404,136 @@ int pick_concurrent_streams(mpe_handle* h) {
   return MPE_OK;
 }
 
+// how a large batch is cut into sub-batches (shared by a call and by the previous call that prefetches for it)
+void sub_batch_shape(const mpe_handle* h, int n_frames, bool have_sp, int vote_arith, int& nsub, int& per) {
+  // sub-batches of about 16384 frames (measured sweet spot at 752x480: 8192 and 32768 are 3-5 % slower), never
+  // below 8192 (tail effects then cost more than the overlap gains)
+  nsub = n_frames / 16384;
+  if (nsub < 2) nsub = n_frames / 8192;
+  if (nsub > h->pipeline) nsub = h->pipeline;
+  if (nsub > mpe_handle::kMaxSub) nsub = mpe_handle::kMaxSub;
+  if (nsub < 1 || !have_sp) nsub = 1;
+  if (have_sp && vote_arith == 0) nsub = 1;  // strict voting arithmetic: one plain chain of kernels (no scan rider)
+  // frames per sub-batch: multiple of 64 so every sub-batch starts on a 16-byte / flag-word boundary
+  per = nsub > 1 ? (((n_frames + nsub - 1) / nsub + 63) & ~63) : n_frames;
+}
+
+// streaming: what the caller knows about the submission that follows this one
+struct StreamHint {
+  const uint8_t* next_frames = nullptr;  // device frames of the next submission (same geometry / parameters), or null
+  int n_next = 0;
+  bool no_join = false;  // do not join the side streams back into the caller's stream: completion = batch_done event
+};
+
+// Device time (ms) for one 1 ms spin kernel on each of two streams started together: ~1 when they execute
+// concurrently, ~2 when the runtime put them on one hardware queue.
+hipError_t spin_pair_ms(hipStream_t a, hipStream_t b, double& ms) {
+  const unsigned long long ticks = 100000;  // 1 ms at 100 MHz
+  hipEvent_t t0 = nullptr, t1 = nullptr, eb = nullptr;
+  hipError_t e = hipEventCreate(&t0);
+  if (e == hipSuccess) e = hipEventCreate(&t1);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&eb, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipStreamSynchronize(a);
+  if (e == hipSuccess) e = hipStreamSynchronize(b);
+  if (e == hipSuccess) e = hipEventRecord(t0, a);
+  if (e == hipSuccess) e = hipStreamWaitEvent(b, t0, 0);
+  if (e == hipSuccess) e = launch_spin(ticks, a);
+  if (e == hipSuccess) e = launch_spin(ticks, b);
+  if (e == hipSuccess) e = hipEventRecord(eb, b);
+  if (e == hipSuccess) e = hipStreamWaitEvent(a, eb, 0);
+  if (e == hipSuccess) e = hipEventRecord(t1, a);
+  if (e == hipSuccess) e = hipEventSynchronize(t1);
+  float fms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&fms, t0, t1);
+  ms = fms;
+  if (t0) (void)hipEventDestroy(t0);
+  if (t1) (void)hipEventDestroy(t1);
+  if (eb) (void)hipEventDestroy(eb);
+  return e;
+}
+
+// Schedules 4 / 6 put the validate / refine kernels (and, in 6, a share of the image scan) on internal side streams;
+// that only pays when those streams execute BESIDE the caller's stream.  The runtime multiplexes streams onto a few
+// hardware queues (GPU_MAX_HW_QUEUES) in an order that depends on the process's other streams, so the overlap can
+// silently vanish (Schedules).  Verified here once per (handle, caller stream): every pair of {caller's
+// stream, tail stream, scan stream} must run two 1 ms spin kernels in ~1 ms; a side stream that shares a queue is
+// replaced (the rejected ones stay alive until the end so that the runtime hands out other queues).  No concurrent set
+// after 8 replacements -> side_streams_ok = 0 and the caller falls back to the one-stream schedule 3.
+int ensure_side_streams(mpe_handle* h, bool need_scan) {
+  if (h->side_streams_ok >= 0 && h->probed_for == h->stream && (!need_scan || h->probed_scan)) return MPE_OK;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (!h->tail_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
+  if (need_scan && !h->scan_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking));
+  HIP_TRY(h, hipStreamSynchronize(h->tail_stream));
+  if (h->scan_stream) HIP_TRY(h, hipStreamSynchronize(h->scan_stream));
+  double ms = 0;
+  HIP_TRY(h, spin_pair_ms(h->stream, h->stream, ms));  // first launch of the kernel (code object load) is not timed
+  std::vector<hipStream_t> rejected;
+  bool ok = false;
+  for (int attempt = 0; attempt <= 8 && !ok; ++attempt) {
+    bool tail_bad = false, scan_bad = false;
+    HIP_TRY(h, spin_pair_ms(h->stream, h->tail_stream, ms));
+    if (ms >= 1.6) tail_bad = true;
+    if (!tail_bad && need_scan) {
+      HIP_TRY(h, spin_pair_ms(h->stream, h->scan_stream, ms));
+      if (ms >= 1.6) scan_bad = true;
+      if (!scan_bad) {
+        HIP_TRY(h, spin_pair_ms(h->tail_stream, h->scan_stream, ms));
+        if (ms >= 1.6) scan_bad = true;
+      }
+    }
+    if (!tail_bad && !scan_bad) {
+      ok = true;
+      break;
+    }
+    if (attempt == 8) break;
+    hipStream_t fresh = nullptr;
+    HIP_TRY(h, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+    if (tail_bad) {
+      rejected.push_back(h->tail_stream);
+      h->tail_stream = fresh;
+    } else {
+      rejected.push_back(h->scan_stream);
+      h->scan_stream = fresh;
+    }
+  }
+  for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+  h->side_streams_ok = ok ? 1 : 0;
+  h->streams_concurrent = h->side_streams_ok;
+  h->probed_for = h->stream;
+  h->probed_scan = need_scan;
+  h->tail_sub_pending = false;  // (everything was synchronised above)
+  return MPE_OK;
+}
+
 int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const FrameGeom& g, const DetectParams& dp,
                  const SolveParams* sp, mpe_detections* d_dets, uint32_t* d_hist, mpe_result* d_results,
-                 uint32_t* d_corr) {
+                 uint32_t* d_corr, const StreamHint* hint = nullptr) {
+  h->done_recorded = false;
   const size_t frame_bytes = (size_t)g.rows * g.pitch;
+  const mpe_handle::Prefetch pf = h->prefetch;  // what the previous submission scanned for this one (if anything)
+  h->prefetch.valid = false;
   if (sp) {
     HIP_TRY(h, h->mtab.reserve(k2_table_bytes(sp->n_markers)));
     HIP_TRY(h, launch_k2_prep(*sp, static_cast<double*>(h->mtab.p), h->stream));
   }
-  // sub-batches of about 16384 frames (measured sweet spot at 752x480: 8192 and 32768 are 3-5 % slower), never
-  // below 8192 (tail effects then cost more than the overlap gains)
-  int nsub = n_frames / 16384;
-  if (nsub < 2) nsub = n_frames / 8192;
-  if (nsub > h->pipeline) nsub = h->pipeline;
-  if (nsub > mpe_handle::kMaxSub) nsub = mpe_handle::kMaxSub;
-  if (nsub < 1 || !sp) nsub = 1;
-  if (sp && sp->vote_arith == 0) nsub = 1;  // strict voting arithmetic: one plain chain of kernels (no scan rider)
+  int nsub, per;
+  sub_batch_shape(h, n_frames, sp != nullptr, sp ? sp->vote_arith : 1, nsub, per);
   h->have_ms = false;
+  // a streaming submission may still have validate / refine kernels on the tail stream that read the detection and
+  // histogram buffers this call is about to overwrite: the fused schedules order themselves region by region, every
+  // other path waits for all of them here
+  auto drain_tails = [&]() -> int {
+    if (h->tail_sub_pending) {
+      HIP_TRY(h, hipStreamWaitEvent(h->stream, h->tail_sub_done[h->tail_last], 0));
+      h->tail_sub_pending = false;
+    }
+    return MPE_OK;
+  };
   HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
   if (sp) HIP_TRY(h, h->mid.reserve(k3_mid_bytes(n_frames)));
   if (nsub <= 1) {
+    { const int rc = drain_tails(); if (rc) return rc; }
     HIP_TRY(h, h->flags.reserve(flag_words(frame_bytes * n_frames) * 8));
     HIP_TRY(h, h->work.reserve((size_t)2 * (n_frames + 1) * sizeof(int)));
     int rc = run_front(h, h->stream, h->profiling, 0, n_frames, d_frames, n_frames, g, dp, sp,
@@ -399,16 +552,15 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       for (int k = 0; k < 8; ++k)
         if (!h->pev[s][k]) HIP_TRY(h, hipEventCreate(&h->pev[s][k]));
   // Software pipeline over nsub sub-batches on two streams: A runs scan + blobs, B voting + tail.
-  // frames per sub-batch: multiple of 64 so every sub-batch starts on a 16-byte / flag-word boundary
-  const int per = ((n_frames + nsub - 1) / nsub + 63) & ~63;
   const size_t fw_per = flag_words(frame_bytes * per);
-  HIP_TRY(h, h->flags.reserve(fw_per * nsub * 8));
+  // (one region per sub-batch + one for the first sub-batch of the NEXT submission, see StreamHint)
+  HIP_TRY(h, h->flags.reserve(fw_per * (nsub + 1) * 8));
   HIP_TRY(h, h->work.reserve((size_t)2 * (per + 1) * nsub * sizeof(int)));
-  // schedule: 0 two-stream software pipeline (default); 3 fused single stream.  If the probe found no pair of
-  // concurrently executing side streams the two-stream pipeline cannot overlap anything -> fused schedule.
-  // pipeline_mode -1 (default) = automatic: the fused single-stream schedule whenever the voting kernel can carry
-  // the scan (its LDS copy of the marker table exists for <= 5 markers), else the two-stream pipeline — unless the
-  // probe finds no pair of concurrently executing side streams, in which case it could not overlap anything.
+  // schedule = option "pipeline_mode": -1 (default) = automatic = 6 (fused voting + scan, validate / refine on a side
+  // stream, the scan split between a side k1a_scan and the rider); 3 / 4 = its one-stream / no-split-scan variants;
+  // 0 (1, 2: experiment variants) = the older two-stream software pipeline.  Schedules with side streams verify once
+  // per caller stream that those streams really execute concurrently (ensure_side_streams / pick_concurrent_streams)
+  // and fall back to the one-stream schedule 3 when the runtime cannot give them separate hardware queues.
   int schedule = h->pipeline_mode;
   // automatic: the fused schedule for every marker count.  For more than 5 markers the voting kernel cannot carry
   // the scan (its LDS table would not fit) and launch_k2_vote falls back to the plain kernel + a stand-alone scan —
@@ -420,6 +572,14 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (h->streams_concurrent == 0) schedule = 6;
   }
   h->last_schedule = schedule;
+  if (schedule == 4 || schedule == 6) {
+    // the side streams of these schedules only pay when they really execute beside the caller's stream: verify it
+    // once per (handle, caller stream) with the spin probe; without a concurrent triple -> schedule 3 (one stream)
+    const int rc = ensure_side_streams(h, schedule == 6 && h->scan_split_pct > 0);
+    if (rc) return rc;
+    if (h->side_streams_ok == 0) schedule = 3;
+    h->last_schedule = schedule;
+  }
   if (schedule == 3 || schedule == 4 || schedule == 6) {
     const bool side_tail = schedule != 3;
     // mode 6: the HBM stream is spread over the whole sub-batch period.  In modes 3 / 4 the voting kernel scans all
@@ -429,32 +589,62 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     // beside four blob waves per SIMD, it needs no LDS), and the rider of vote(s + 1) scans only the rest.
     const bool split_scan = schedule == 6 && h->scan_split_pct > 0;
     if (split_scan) {
-      if (!h->scan_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking));
       for (auto& e : h->scanpart_done)
         if (!e) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
       if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+      if (!h->prefetch_side_done) HIP_TRY(h, hipEventCreateWithFlags(&h->prefetch_side_done, hipEventDisableTiming));
     }
     auto split_bytes = [&](size_t nbytes) -> size_t {
       return split_scan ? (nbytes * (size_t)h->scan_split_pct / 100) / 8192 * 8192 : 0;
     };
     h->last_rider_bytes = 0;
     if (side_tail) {
-      if (!h->tail_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
       if (!h->tail_done) HIP_TRY(h, hipEventCreateWithFlags(&h->tail_done, hipEventDisableTiming));
       if (!h->vote_done[0])
         for (int i = 0; i < mpe_handle::kMaxSub; ++i)
           HIP_TRY(h, hipEventCreateWithFlags(&h->vote_done[i], hipEventDisableTiming));
+      for (auto& e : h->tail_sub_done)
+        if (!e) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // Fused schedule, ONE stream: the voting kernel of sub-batch s carries the image scan of sub-batch
     // s + 1 on its idle memory pipeline (ScanRider in mpe_kernels.hip).
     //   scan(0) | blobs(0) vote(0)+scan(1) tail(0) | blobs(1) vote(1)+scan(2) tail(1) | ...
+    // Streaming (StreamHint): the LAST voting launch carries the scan of the first sub-batch of the NEXT submission
+    // (into the extra flag region behind the nsub regions of this one), whose stand-alone scan then disappears:
+    //   ... vote(n-1)+scan(next 0) tail(n-1) || blobs(next 0) vote(next 0)+scan(next 1) ...
     hipStream_t st = h->stream;
+    unsigned long long* flags_base = static_cast<unsigned long long*>(h->flags.p);
+    // was sub-batch 0 of THIS call scanned by the previous submission?
+    const bool prefetched = pf.valid && pf.frames == d_frames && pf.per == std::min(per, n_frames) &&
+                            pf.frame_bytes == frame_bytes && pf.thr == dp.thr && pf.flags_base == h->flags.p &&
+                            pf.fw_per == fw_per;
+    // the next submission's first sub-batch, if the caller announced it and it will run pipelined as well
+    int next_per = 0;
+    if (hint && hint->next_frames && hint->n_next > 0) {
+      int nn, np;
+      sub_batch_shape(h, hint->n_next, true, sp->vote_arith, nn, np);
+      if (nn > 1 && flag_words(frame_bytes * std::min(np, hint->n_next)) <= fw_per) next_per = std::min(np, hint->n_next);
+    }
+    // region index of a sub-batch's flag words: 0 .. nsub-1, nsub = the extra region (prefetch target / source)
     auto sub_ptrs = [&](int s, int& f0, int& nf, const uint8_t*& fr, unsigned long long*& fl) {
+      if (s >= nsub) {  // the virtual sub-batch behind the last one = the next submission's first
+        f0 = 0;
+        nf = next_per;
+        fr = hint->next_frames;
+        fl = flags_base + fw_per * nsub;
+        return;
+      }
       f0 = s * per;
       nf = std::min(per, n_frames - f0);
       fr = d_frames + (size_t)f0 * frame_bytes;
-      fl = static_cast<unsigned long long*>(h->flags.p) + fw_per * s;
+      fl = flags_base + fw_per * ((s == 0 && prefetched) ? nsub : s);
     };
+    // number of real sub-batches (the last ones may be empty when n_frames is not a multiple of `per`)
+    int n_real = 0;
+    while (n_real < nsub && n_real * per < n_frames) ++n_real;
+    const bool tail_was_pending = h->tail_sub_pending;  // (this call records the same events anew)
+    const int tail_was_last = h->tail_last;
+    auto has_sub = [&](int s) { return s < n_real || (s == n_real && next_per > 0); };
     int f0, nf;
     const uint8_t* fr;
     unsigned long long* fl;
@@ -462,16 +652,21 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][0], st));
     // the work-lists of all sub-batches with one memset (instead of one per sub-batch in front of its blob kernels)
     HIP_TRY(h, hipMemsetAsync(h->work.p, 0, (size_t)2 * (per + 1) * nsub * sizeof(int), st));
-    HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, scan_lds(h, false), st));
+    if (prefetched) {
+      if (pf.side_part) HIP_TRY(h, hipStreamWaitEvent(st, h->prefetch_side_done, 0));
+    } else {
+      HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, scan_lds(h, false), st));
+    }
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][1], st));
-    // side scan of the first part of sub-batch k (k >= 1), gated so that it runs in the blob / tail window that
-    // follows vote(k - 2) (k = 1: at the start of the call)
+    // side scan of the first part of sub-batch k (k >= 1; k == n_real: the next submission's first sub-batch), gated
+    // so that it runs in the blob / tail window that follows vote(k - 2) (k = 1: at the start of the call)
+    bool prefetch_side = false;
     auto side_scan = [&](int k) -> int {
-      if (!split_scan || k >= nsub || k * per >= n_frames) return MPE_OK;
+      if (!split_scan || !has_sub(k)) return MPE_OK;
       int q0, qn;
       const uint8_t* qfr;
       unsigned long long* qfl;
-      sub_ptrs(k, q0, qn, qfr, qfl);
+      sub_ptrs(k >= n_real ? nsub : k, q0, qn, qfr, qfl);
       const size_t P = split_bytes((size_t)qn * frame_bytes);
       if (k == 1) {
         HIP_TRY(h, hipEventRecord(h->fork_ev, st));
@@ -480,16 +675,22 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
         HIP_TRY(h, hipStreamWaitEvent(h->scan_stream, h->vote_done[k - 2], 0));
       }
       if (P) HIP_TRY(h, launch_k1a_scan(qfr, P, qfl, dp.thr, 0, h->scan_stream, h->side_scan_blocks));
-      HIP_TRY(h, hipEventRecord(h->scanpart_done[k], h->scan_stream));
+      if (k >= n_real) {
+        HIP_TRY(h, hipEventRecord(h->prefetch_side_done, h->scan_stream));
+        prefetch_side = true;
+      } else {
+        HIP_TRY(h, hipEventRecord(h->scanpart_done[k], h->scan_stream));
+      }
       return MPE_OK;
     };
     { const int rc = side_scan(1); if (rc) return rc; }
     int used = 0;
-    for (int s = 0; s < nsub; ++s) {
+    for (int s = 0; s < n_real; ++s) {
       sub_ptrs(s, f0, nf, fr, fl);
-      if (f0 >= n_frames) break;
       used = s + 1;
       if (split_scan && s >= 1) HIP_TRY(h, hipStreamWaitEvent(st, h->scanpart_done[s], 0));
+      // streaming: the tail of the PREVIOUS submission has read the detections / histograms of this region
+      if (tail_was_pending) HIP_TRY(h, hipStreamWaitEvent(st, h->tail_sub_done[std::min(s, tail_was_last)], 0));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], st));
       HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
                                   static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
@@ -502,9 +703,9 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       const uint8_t* nfr = nullptr;
       unsigned long long* nfl = nullptr;
       size_t nbytes = 0, scanned = 0;
-      if ((s + 1) * per < n_frames) {
+      if (has_sub(s + 1)) {
         int nf0, nnf;
-        sub_ptrs(s + 1, nf0, nnf, nfr, nfl);
+        sub_ptrs(s + 1 >= n_real ? nsub : s + 1, nf0, nnf, nfr, nfl);
         nbytes = (size_t)nnf * frame_bytes;
       }
       const size_t P = split_bytes(nbytes);  // (the first P bytes of sub-batch s + 1 come from the side scan)
@@ -515,11 +716,12 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], st));
       if (scanned > h->last_rider_bytes) h->last_rider_bytes = scanned;
       if (nbytes > 0) {  // what the riders left over: less than one chunk, or everything if they could not run
-        if (prof) HIP_TRY(h, hipEventRecord(h->pev[s + 1][0], st));
+        const bool real_next = s + 1 < n_real;
+        if (prof && real_next) HIP_TRY(h, hipEventRecord(h->pev[s + 1][0], st));
         if (nbytes - P > scanned)
           HIP_TRY(h, launch_k1a_scan(nfr + P + scanned, nbytes - P - scanned, nfl + (P + scanned) / 1024, dp.thr,
                                      scan_lds(h, false), st));
-        if (prof) HIP_TRY(h, hipEventRecord(h->pev[s + 1][1], st));
+        if (prof && real_next) HIP_TRY(h, hipEventRecord(h->pev[s + 1][1], st));
       }
       // validate + refine of this sub-batch: on the caller's stream, or (mode 4) on a side stream so that its
       // thin, latency-bound kernels run beside the blob extraction of the next sub-batch
@@ -536,12 +738,34 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
                                 d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0,
                                 static_cast<uint8_t*>(h->mid.p) + k3_mid_bytes(1) * (size_t)f0, tst));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], tst));
+      if (side_tail) {
+        HIP_TRY(h, hipEventRecord(h->tail_sub_done[s], tst));
+        h->tail_last = s;
+      }
     }
-    if (side_tail) {  // join: the call behaves like one operation on the caller's stream
-      HIP_TRY(h, hipEventRecord(h->tail_done, h->tail_stream));
-      HIP_TRY(h, hipStreamWaitEvent(st, h->tail_done, 0));
+    h->tail_sub_pending = side_tail;
+    if (next_per > 0) {  // sub-batch 0 of the next submission has been scanned into the extra region
+      h->prefetch.valid = true;
+      h->prefetch.frames = hint->next_frames;
+      h->prefetch.per = next_per;
+      h->prefetch.frame_bytes = frame_bytes;
+      h->prefetch.thr = dp.thr;
+      h->prefetch.flags_base = h->flags.p;
+      h->prefetch.fw_per = fw_per;
+      h->prefetch.side_part = prefetch_side;
     }
-    // (every side scan was waited for by the blob extraction of its sub-batch)
+    // completion: everything of this submission is done when its last tail is (side_tail: on the tail stream, which
+    // executes the tails in order; else on the caller's stream)
+    if (!h->batch_done[0])
+      for (auto& e : h->batch_done) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t done = h->batch_done[h->submit_seq & 1];
+    HIP_TRY(h, hipEventRecord(done, side_tail ? h->tail_stream : st));
+    h->done_recorded = true;
+    if (!(hint && hint->no_join) && side_tail) {  // join: the call behaves like one operation on the caller's stream
+      HIP_TRY(h, hipStreamWaitEvent(st, done, 0));
+      h->tail_sub_pending = false;  // (the next call's kernels are ordered behind every tail of this one anyway)
+    }
+    // (every side scan was waited for by the blob extraction of its sub-batch; a prefetch side scan by the next call)
     if (prof) {
       h->prof_launches = used;
       h->have_ms = true;
@@ -551,7 +775,9 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     return MPE_OK;
   }
   {
-    const int rc = pick_concurrent_streams(h);
+    int rc = drain_tails();
+    if (rc) return rc;
+    rc = pick_concurrent_streams(h);
     if (rc) return rc;
   }
   if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
@@ -709,6 +935,8 @@ void mpe_destroy(mpe_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->tail_stream) (void)hipStreamSynchronize(h->tail_stream);  // (an un-collected streaming submission)
+  if (h->scan_stream) (void)hipStreamSynchronize(h->scan_stream);
   h->frames.release();
   h->flags.release();
   h->dets.release();
@@ -734,6 +962,11 @@ void mpe_destroy(mpe_handle* h) {
       if (e) (void)hipEventDestroy(e);
   if (h->fork_ev) (void)hipEventDestroy(h->fork_ev);
   if (h->tail_done) (void)hipEventDestroy(h->tail_done);
+  for (auto& e : h->batch_done)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->tail_sub_done)
+    if (e) (void)hipEventDestroy(e);
+  if (h->prefetch_side_done) (void)hipEventDestroy(h->prefetch_side_done);
   if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
   if (h->scan_stream) (void)hipStreamDestroy(h->scan_stream);
   for (auto& e : h->scanpart_done)
@@ -842,6 +1075,8 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
     return MPE_OK;
   }
   if (!std::strcmp(name, "pipeline_mode")) {
+    if (value != -1 && value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 6)
+      return fail(h, MPE_ERR_ARG, "pipeline_mode must be -1 (automatic), 0, 1, 2, 3, 4 or 6");
     h->pipeline_mode = value;
     return MPE_OK;
   }
@@ -882,7 +1117,7 @@ int mpe_detect_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int row
                      const mpe_params* p, mpe_detections* dets) {
   if (!h || !frames || !p || !K || !dets || n_frames < 0) return fail(h, MPE_ERR_ARG, "bad argument");
   if (n_frames == 0) return MPE_OK;
-  HIP_TRY(h, hipSetDevice(h->device));
+  ENTER(h);
   FrameGeom g;
   if (make_geom(h, rows, cols, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
   DetectParams dp;
@@ -907,7 +1142,7 @@ int mpe_find_leds(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t 
   if (!h || !img || !p || !K) return fail(h, MPE_ERR_ARG, "bad argument");
   if (roi_x < 0 || roi_y < 0 || roi_w <= 0 || roi_h <= 0 || roi_x + roi_w > cols || roi_y + roi_h > rows)
     return fail(h, MPE_ERR_ARG, "ROI outside the image");  // cv::Mat::operator()(Rect) asserts the same
-  HIP_TRY(h, hipSetDevice(h->device));
+  ENTER(h);
   FrameGeom g;
   if (make_geom(h, roi_h, roi_w, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
   DetectParams dp;
@@ -963,7 +1198,7 @@ int vote_batch_impl(mpe_handle* h, const double* det_xy, const int* n_det, int n
                     const int* item_hi, uint32_t* hist) {
   if (!h || !det_xy || !n_det || !markers_xyz || !K || !hist || n_frames < 0) return fail(h, MPE_ERR_ARG, "bad argument");
   if (n_frames == 0) return MPE_OK;
-  HIP_TRY(h, hipSetDevice(h->device));
+  ENTER(h);
   mpe_params p;
   mpe_default_params(&p);
   p.back_projection_pixel_tolerance = back_projection_pixel_tolerance;
@@ -1012,7 +1247,7 @@ int solve_bruteforce_impl(mpe_handle* h, const double* det_xy, int n_det, const 
   if (!h || (!det_xy && n_det > 0) || !markers_xyz || !K || !p || !out || n_det < 0)
     return fail(h, MPE_ERR_ARG, "bad argument");
   if (n_det > MPE_MAX_DETECTIONS) return fail(h, MPE_ERR_UNSUPPORTED, "n_det > MPE_MAX_DETECTIONS");
-  HIP_TRY(h, hipSetDevice(h->device));
+  ENTER(h);
   SolveParams sp;
   if (make_solve_params(h, p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
   mpe_detections hd;
@@ -1065,7 +1300,7 @@ int run_tail_single(mpe_handle* h, const double* det_xy, int n_det, const double
   if (!h || (!det_xy && n_det > 0) || !markers_xyz || !K || !p || !out || n_det < 0 || n_corr < 0 || (!corr && n_corr > 0))
     return fail(h, MPE_ERR_ARG, "bad argument");
   if (n_det > MPE_MAX_DETECTIONS || n_corr > MPE_MAX_MARKERS) return fail(h, MPE_ERR_UNSUPPORTED, "too many points");
-  HIP_TRY(h, hipSetDevice(h->device));
+  ENTER(h);
   SolveParams sp;
   if (make_solve_params(h, p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
   for (int i = 0; i < n_corr; ++i)
@@ -1123,7 +1358,7 @@ int mpe_p3p_batch(mpe_handle* h, const double* feature_vectors, const double* wo
   if (!h || n < 0 || (n > 0 && (!feature_vectors || !world_points || !solutions || !status)))
     return fail(h, MPE_ERR_ARG, "bad argument");
   if (n == 0) return MPE_OK;
-  HIP_TRY(h, hipSetDevice(h->device));
+  ENTER(h);
   const size_t in = (size_t)n * 9 * sizeof(double), out = (size_t)n * 48 * sizeof(double);
   HIP_TRY(h, h->scratch.reserve(2 * in + out + (size_t)n * sizeof(int) + 64));
   uint8_t* base = static_cast<uint8_t*>(h->scratch.p);
@@ -1145,7 +1380,7 @@ int mpe_solve_quartic_batch(mpe_handle* h, const double* factors, int n, int var
   if (!h || n < 0 || (n > 0 && (!factors || !real_roots)) || (variant != 0 && variant != 1))
     return fail(h, MPE_ERR_ARG, "bad argument");
   if (n == 0) return MPE_OK;
-  HIP_TRY(h, hipSetDevice(h->device));
+  ENTER(h);
   const size_t in = (size_t)n * 5 * sizeof(double), out = (size_t)n * 4 * sizeof(double);
   HIP_TRY(h, h->scratch.reserve(in + out + 64));
   double* d_f = static_cast<double*>(h->scratch.p);
@@ -1176,7 +1411,7 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   if (roi_x < 0 || roi_y < 0 || roi_w <= 0 || roi_h <= 0 || roi_x + roi_w > cols || roi_y + roi_h > rows)
     return fail(h, MPE_ERR_ARG, "ROI outside the image");
   if (h->pending_track_n) return fail(h, MPE_ERR_ARG, "a submitted batch has not been collected yet (shared staging memory)");
-  HIP_TRY(h, hipSetDevice(h->device));
+  ENTER(h);
   FrameGeom g;
   if (make_geom(h, roi_h, roi_w, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
   DetectParams dp;
@@ -1230,12 +1465,12 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   return MPE_OK;
 }
 
-int mpe_estimate_batch_device(mpe_handle* h, const uint8_t* d_frames, int n_frames, int rows, int cols,
-                              const double* markers_xyz, int n_markers, const double K[9], const double* D, int nD,
-                              const mpe_params* p, mpe_result* d_results) {
+namespace {
+int estimate_device_impl(mpe_handle* h, const uint8_t* d_frames, int n_frames, int rows, int cols,
+                         const double* markers_xyz, int n_markers, const double K[9], const double* D, int nD,
+                         const mpe_params* p, mpe_result* d_results, const StreamHint* hint) {
   if (!h || !d_frames || !markers_xyz || !K || !p || !d_results || n_frames < 0)
     return fail(h, MPE_ERR_ARG, "bad argument");
-  if (n_frames == 0) return MPE_OK;
   if ((cols & 15) || (reinterpret_cast<uintptr_t>(d_frames) & 15))
     return fail(h, MPE_ERR_UNSUPPORTED, "device frames must be packed, 16-byte aligned, cols % 16 == 0");
   HIP_TRY(h, hipSetDevice(h->device));
@@ -1247,8 +1482,55 @@ int mpe_estimate_batch_device(mpe_handle* h, const uint8_t* d_frames, int n_fram
   if (make_solve_params(h, p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
   HIP_TRY(h, h->dets.reserve((size_t)n_frames * sizeof(mpe_detections)));
   HIP_TRY(h, h->hist.reserve((size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t)));
-  return run_pipeline(h, d_frames, n_frames, g, dp, &sp, static_cast<mpe_detections*>(h->dets.p),
-                      static_cast<uint32_t*>(h->hist.p), d_results, nullptr);
+  const int rc = run_pipeline(h, d_frames, n_frames, g, dp, &sp, static_cast<mpe_detections*>(h->dets.p),
+                              static_cast<uint32_t*>(h->hist.p), d_results, nullptr, hint);
+  if (rc) return rc;
+  if (!h->done_recorded) {  // schedules without side streams: the records are complete in the caller's stream order
+    if (!h->batch_done[0])
+      for (auto& e : h->batch_done) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(h, hipEventRecord(h->batch_done[h->submit_seq & 1], h->stream));
+  }
+  return MPE_OK;
+}
+}  // namespace
+
+int mpe_estimate_batch_device(mpe_handle* h, const uint8_t* d_frames, int n_frames, int rows, int cols,
+                              const double* markers_xyz, int n_markers, const double K[9], const double* D, int nD,
+                              const mpe_params* p, mpe_result* d_results) {
+  if (h && h->submit_seq != h->collect_seq)
+    return fail(h, MPE_ERR_ARG, "a submitted batch has not been collected yet (mpe_estimate_batch_device_collect)");
+  if (n_frames == 0 && h && d_frames && d_results) return MPE_OK;
+  const int rc = estimate_device_impl(h, d_frames, n_frames, rows, cols, markers_xyz, n_markers, K, D, nD, p, d_results,
+                                      nullptr);  // (no hint: the side streams are joined back, one operation on the stream)
+  return rc;
+}
+
+int mpe_estimate_batch_device_submit(mpe_handle* h, const uint8_t* d_frames, int n_frames, int rows, int cols,
+                                     const double* markers_xyz, int n_markers, const double K[9], const double* D, int nD,
+                                     const mpe_params* p, mpe_result* d_results, const uint8_t* d_next_frames,
+                                     int n_next_frames) {
+  if (!h || n_frames <= 0) return fail(h, MPE_ERR_ARG, "bad argument");
+  if (h->submit_seq - h->collect_seq >= 2)
+    return fail(h, MPE_ERR_ARG, "two submissions are in flight already: collect the older one first");
+  StreamHint hint;
+  hint.next_frames = d_next_frames;
+  hint.n_next = d_next_frames ? n_next_frames : 0;
+  hint.no_join = true;
+  const int rc = estimate_device_impl(h, d_frames, n_frames, rows, cols, markers_xyz, n_markers, K, D, nD, p, d_results,
+                                      &hint);
+  if (rc) return rc;
+  ++h->submit_seq;
+  return MPE_OK;
+}
+
+int mpe_estimate_batch_device_collect(mpe_handle* h, void* hip_stream) {
+  if (!h) return MPE_ERR_ARG;
+  if (h->submit_seq == h->collect_seq) return fail(h, MPE_ERR_ARG, "nothing has been submitted");
+  HIP_TRY(h, hipSetDevice(h->device));
+  hipStream_t consumer = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->stream;
+  HIP_TRY(h, hipStreamWaitEvent(consumer, h->batch_done[h->collect_seq & 1], 0));
+  ++h->collect_seq;
+  return MPE_OK;
 }
 
 int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int rows, int cols, size_t stride_bytes,
@@ -1256,7 +1538,7 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
                        const double K[9], const double* D, int nD, const mpe_params* p, mpe_result* results) {
   if (!h || !frames || !markers_xyz || !K || !p || !results || n_frames < 0) return fail(h, MPE_ERR_ARG, "bad argument");
   if (n_frames == 0) return MPE_OK;
-  HIP_TRY(h, hipSetDevice(h->device));
+  ENTER(h);
   FrameGeom g;
   if (make_geom(h, rows, cols, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
   DetectParams dp;
@@ -1296,7 +1578,11 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
       HIP_TRY(h, hipStreamWaitEvent(h->stream, h->copy_done[ci & 1], 0));
       const int rc = run_pipeline(h, d_all + (size_t)f0 * frame_bytes, nf, g, dp, &sp, d_dets + f0,
                                   d_hist + (size_t)f0 * MPE_HIST_STRIDE, d_res + f0, nullptr);
-      if (rc) return rc;
+      if (rc) {  // no copy may still be reading the caller's buffer when the call returns
+        (void)hipStreamSynchronize(h->copy_stream);
+        (void)hipStreamSynchronize(h->stream);
+        return rc;
+      }
     }
   } else {
     const uint8_t* d_frames = nullptr;
@@ -1343,7 +1629,7 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
     rmax = std::max(rmax, it.roi_h);
     wmax = std::max(wmax, it.roi_w);
   }
-  HIP_TRY(h, hipSetDevice(h->device));
+  ENTER(h);
   FrameGeom g;
   if (make_geom(h, rmax, wmax, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
   DetectParams dp;
@@ -1417,14 +1703,24 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
   return MPE_OK;
 }
 
-int mpe_track_step_batch_collect(mpe_handle* h, mpe_detections* dets_out, uint32_t* corr_out, mpe_result* out) {
-  if (!h || !dets_out || !corr_out || !out) return fail(h, MPE_ERR_ARG, "bad argument");
-  const int n = h->pending_track_n;
-  if (n == 0) return MPE_OK;
-  const uint8_t* host_rec = h->pending_track_rec;
+int mpe_track_step_batch_cancel(mpe_handle* h) {
+  if (!h) return MPE_ERR_ARG;
+  if (h->pending_track_n == 0) return MPE_OK;
   h->pending_track_n = 0;
   h->pending_track_rec = nullptr;
   HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // the copy-out of the abandoned submission has left the staging memory
+  return MPE_OK;
+}
+
+int mpe_track_step_batch_collect(mpe_handle* h, mpe_detections* dets_out, uint32_t* corr_out, mpe_result* out) {
+  if (!h || !dets_out || !corr_out || !out) return fail(h, MPE_ERR_ARG, "bad argument");
+  const int n = h->pending_track_n;
+  if (n == 0) return fail(h, MPE_ERR_ARG, "no submitted batch to collect (did mpe_track_step_batch_submit fail?)");
+  const uint8_t* host_rec = h->pending_track_rec;
+  h->pending_track_n = 0;
+  h->pending_track_rec = nullptr;
+  ENTER(h);
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   const mpe_detections* hd = reinterpret_cast<const mpe_detections*>(host_rec);
   const uint32_t* hc = reinterpret_cast<const uint32_t*>(hd + n);
@@ -1441,6 +1737,7 @@ int mpe_track_step_batch(mpe_handle* h, const mpe_track_item* items, int n, int 
   if (!dets_out || !corr_out || !out) return fail(h, MPE_ERR_ARG, "bad argument");
   const int rc = mpe_track_step_batch_submit(h, items, n, rows, cols, stride_bytes, p, K, D, nD, markers_xyz, n_markers);
   if (rc != MPE_OK) return rc;
+  if (n == 0) return MPE_OK;  // (nothing was submitted)
   return mpe_track_step_batch_collect(h, dets_out, corr_out, out);
 }
 
@@ -1452,7 +1749,7 @@ int mpe_solve_bruteforce_batch(mpe_handle* h, const double* det_xy, const int* n
                                uint32_t* corr) {
   if (!h || !det_xy || !n_det || n < 0 || !markers_xyz || !K || !p || !out) return fail(h, MPE_ERR_ARG, "bad argument");
   if (n == 0) return MPE_OK;
-  HIP_TRY(h, hipSetDevice(h->device));
+  ENTER(h);
   SolveParams sp;
   if (make_solve_params(h, p, markers_xyz, n_markers, K, sp)) return fail(h, MPE_ERR_UNSUPPORTED, "n_markers > MPE_MAX_MARKERS");
   std::vector<mpe_detections> hd((size_t)n);

@@ -504,6 +504,7 @@ int mpe_tracker_set_params(mpe_tracker* t, const mpe_params* p) {
 int mpe_tracker_reset(mpe_tracker* t) {
   if (!t) return MPE_ERR_ARG;
   t->it_since_initialized = 0;
+  if (t->h) (void)mpe_track_step_batch_cancel(t->h);  // (a submission abandoned by a failed batch call)
   return MPE_OK;
 }
 
@@ -809,6 +810,12 @@ struct BatchCtx {
     return MPE_OK;
   }
 
+  // error path: abandon whatever this group has in flight, so that its handle accepts the next submission
+  void cancel() {
+    pend.clear();
+    if (h) (void)mpe_track_step_batch_cancel(h);
+  }
+
   // first asynchronous submission of a frame: the size class that has lanes (the small one first)
   int submit_first() {
     const int rc = submit_detect(0);
@@ -843,22 +850,32 @@ struct BatchCtx {
     int n_updated = 0;
     for (int i = 0; i < n; ++i) {
       const mpe_tracker* t = ts[i];
+      const int err = L[(size_t)i].error;
       if (out) {
         mpe_result& o = out[(size_t)i * out_stride];
-        std::memcpy(o.T, t->predicted.a, sizeof(o.T));
-        std::memcpy(o.cov, t->cov, sizeof(o.cov));
-        o.status = L[(size_t)i].error ? L[(size_t)i].error : (t->pose_updated ? MPE_FRAME_POSE : MPE_FRAME_NO_POSE);
-        o.n_det = (int)t->det.size() / 2;
-        o.n_corr = t->n_corr;
-        o.gn_iterations = t->gn_iterations;
+        if (err) {  // a device capacity was exceeded on this stream's frame: as mpe_tracker_run_sequence reports it —
+          std::memset(&o, 0, sizeof(o));  // a zeroed record that carries the code
+          o.status = err;
+        } else {
+          std::memcpy(o.T, t->predicted.a, sizeof(o.T));
+          std::memcpy(o.cov, t->cov, sizeof(o.cov));
+          o.status = t->pose_updated ? MPE_FRAME_POSE : MPE_FRAME_NO_POSE;
+          o.n_det = (int)t->det.size() / 2;
+          o.n_corr = t->n_corr;
+          o.gn_iterations = t->gn_iterations;
+        }
       }
       if (info) {
         int* q = info + (size_t)i * info_stride;
-        for (int k = 0; k < 4; ++k) q[k] = t->roi[k];
-        q[4] = (int)t->it_since_initialized;
-        q[5] = (int)t->det.size() / 2;
-        q[6] = t->n_corr;
-        q[7] = t->used_bruteforce ? 1 : 0;
+        if (err) {
+          std::memset(q, 0, 8 * sizeof(int));
+        } else {
+          for (int k = 0; k < 4; ++k) q[k] = t->roi[k];
+          q[4] = (int)t->it_since_initialized;
+          q[5] = (int)t->det.size() / 2;
+          q[6] = t->n_corr;
+          q[7] = t->used_bruteforce ? 1 : 0;
+        }
       }
       if (updated) updated[i] = t->pose_updated ? 1 : 0;
       n_updated += t->pose_updated ? 1 : 0;
@@ -880,8 +897,10 @@ int mpe_tracker_estimate_batch(mpe_tracker* const* ts, int n, const uint8_t* con
   int rc = c.validate(ts, n);
   if (rc != MPE_OK) return rc;
   c.begin(imgs, rows, cols, stride_bytes, times);
-  if ((rc = c.submit_first()) != MPE_OK) return rc;
-  if ((rc = c.finish()) != MPE_OK) return rc;
+  if ((rc = c.submit_first()) != MPE_OK || (rc = c.finish()) != MPE_OK) {
+    c.cancel();  // (a submission may still be in flight: leave the handle usable)
+    return rc;
+  }
   return c.outputs(out, 1, info, 8, updated);
 }
 
@@ -923,7 +942,7 @@ int mpe_tracker_run_sequences_batch_threads(mpe_tracker* const* ts, int n, const
   // The groups gs[0..) on the calling thread, pipelined against each other: while the device works on step k of one
   // group, the host collects, advances and packs another.  Groups share nothing (own handle, own trackers, own rows
   // of out / info), so disjoint sets of groups can also run on different host threads.
-  auto run_groups = [&](const std::vector<size_t>& gs, long long& updated) -> int {
+  auto run_groups_impl = [&](const std::vector<size_t>& gs, long long& updated) -> int {
     std::vector<mpe_result> step_out((size_t)n);
     std::vector<int> step_info((size_t)n * 8);
     auto finish_group = [&](size_t g, int f) -> int {  // complete step f of group g and store its records
@@ -957,6 +976,14 @@ int mpe_tracker_run_sequences_batch_threads(mpe_tracker* const* ts, int n, const
       if (rc != MPE_OK) return rc;
     }
     return MPE_OK;
+  };
+  // on any error every group of the set is drained: the other groups' submissions would otherwise stay un-collected
+  // and their handles would refuse every later mpe_track_step / _submit
+  auto run_groups = [&](const std::vector<size_t>& gs, long long& updated) -> int {
+    const int rc = run_groups_impl(gs, updated);
+    if (rc != MPE_OK)
+      for (size_t g : gs) ctx[g].cancel();
+    return rc;
   };
   const size_t T = std::min<size_t>((size_t)n_threads, G);
   std::vector<std::vector<size_t> > sets(T);

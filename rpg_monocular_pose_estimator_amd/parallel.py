@@ -56,7 +56,7 @@ class RootGatherPipeline:
     def __init__(self, rank, world, nbytes, device, dst=0):
         import torch
         self.rank, self.world, self.dst = rank, world, dst
-        n = 2 if world > 1 else 1
+        n = 2  # (also at world == 1: two submissions may be in flight, each with its own record buffer)
         self._local = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(n)]
         self._out = [torch.zeros(world * nbytes, dtype=torch.uint8, device=device) if (world > 1 and rank == dst)
                      else None for _ in range(n)]
@@ -88,7 +88,7 @@ class RootGatherPipeline:
             self.wait(b)
 
     def gathered(self, step):
-        return self._local[0] if self.world == 1 else self._out[self._slot(step)]
+        return self._local[self._slot(step)] if self.world == 1 else self._out[self._slot(step)]
 
 
 def records_from_bytes(t):

@@ -231,3 +231,124 @@ def test_forensics_reject_an_injected_error(hip, orc):
         if n_checked >= 2:
             break
     assert n_checked >= 1
+
+
+def test_streaming_submissions_are_bit_identical():
+    """mpe_estimate_batch_device_submit / _collect: a stream of batches whose last voting launch scans the first
+    sub-batch of the NEXT submission.  Records byte-identical to the joined one-call entry — with a hint that comes
+    true, with one that does not, without one —, the announced batch's own stand-alone scan disappears, and the
+    misuse paths are loud."""
+    import torch
+    B = 32768
+    cfg, _, fa = _frames_on_device("C2", B, 8180)
+    _, _, fb = _frames_on_device("C2", B, 8190)
+    rows, cols = cfg["rows"], cfg["cols"]
+    K, D = synth.camera_for(rows, cols)
+    markers = np.asarray(cfg["markers"])
+    dev = fa.device
+    P = mpe.demo_params()
+    h = mpe.Handle(0)
+    stream = torch.cuda.Stream(device=dev)
+    consumer = torch.cuda.Stream(device=dev)
+    h.set_stream(stream.cuda_stream)
+    nb = B * mpe.RESULT_DTYPE.itemsize
+
+    def plain(fr):
+        with torch.cuda.stream(stream):
+            out = torch.zeros(nb, dtype=torch.uint8, device=dev)
+            h.estimate_batch_device(fr.data_ptr(), B, rows, cols, markers, K, D, P, out.data_ptr())
+        stream.synchronize()
+        return out
+
+    ref_a, ref_b = plain(fa), plain(fb)
+    assert not torch.equal(ref_a, ref_b)
+    h.set_profiling(True)
+    outs = [torch.zeros(nb, dtype=torch.uint8, device=dev) for _ in range(4)]
+    torch.cuda.synchronize()
+    seq = [(fa, fb), (fb, fa), (fa, fa), (fa, None), (fb, fa)]   # (batch, announced next): 3rd hint is true, 4th has none
+    refs = [ref_a, ref_b, ref_a, ref_a, ref_b]
+    prefetched_expected = [False, True, True, True, False]
+    for i, (fr, nxt) in enumerate(seq):
+        o = outs[i % 4]
+        with torch.cuda.stream(stream):
+            h.estimate_batch_device_submit(fr.data_ptr(), B, rows, cols, markers, K, D, P, o.data_ptr(),
+                                           nxt.data_ptr() if nxt is not None else 0, B)
+            h.estimate_batch_device_collect(consumer.cuda_stream)
+        consumer.synchronize()
+        assert torch.equal(o, refs[i]), i
+        stream.synchronize()
+        scan0 = h.last_kernel_ms_sub(0)["scan"]
+        if prefetched_expected[i]:
+            assert scan0 < 0.05, (i, scan0)      # no stand-alone scan of the first sub-batch: it was prefetched
+        else:
+            assert scan0 > 0.3, (i, scan0)
+    h.set_profiling(False)
+    # two in flight, collected in order on the handle's own stream
+    with torch.cuda.stream(stream):
+        h.estimate_batch_device_submit(fa.data_ptr(), B, rows, cols, markers, K, D, P, outs[0].data_ptr(), fb.data_ptr(), B)
+        h.estimate_batch_device_submit(fb.data_ptr(), B, rows, cols, markers, K, D, P, outs[1].data_ptr(), 0, 0)
+        with pytest.raises(mpe.MpeError):
+            h.estimate_batch_device_submit(fa.data_ptr(), B, rows, cols, markers, K, D, P, outs[2].data_ptr(), 0, 0)
+        with pytest.raises(mpe.MpeError):
+            h.estimate_batch_device(fa.data_ptr(), B, rows, cols, markers, K, D, P, outs[2].data_ptr())
+        h.estimate_batch_device_collect(0)
+        h.estimate_batch_device_collect(0)
+        with pytest.raises(mpe.MpeError):
+            h.estimate_batch_device_collect(0)
+    stream.synchronize()
+    assert torch.equal(outs[0], ref_a) and torch.equal(outs[1], ref_b)
+    # other schedules stream as well (no side streams: the completion event is recorded on the caller's stream)
+    for mode in (3, 4, 0):
+        h.set_option("pipeline_mode", mode)
+        with torch.cuda.stream(stream):
+            h.estimate_batch_device_submit(fa.data_ptr(), B, rows, cols, markers, K, D, P, outs[0].data_ptr(), fb.data_ptr(), B)
+            h.estimate_batch_device_collect(consumer.cuda_stream)
+            h.estimate_batch_device_submit(fb.data_ptr(), B, rows, cols, markers, K, D, P, outs[1].data_ptr(), 0, 0)
+            h.estimate_batch_device_collect(consumer.cuda_stream)
+        consumer.synchronize()
+        assert torch.equal(outs[0], ref_a) and torch.equal(outs[1], ref_b), mode
+    assert h.get_option("streams_concurrent") in (0, 1)
+    h.close()
+
+
+def test_capacity_overrun_is_reported_alike_by_single_and_batch_replays(orc):
+    """A frame with more blobs than MPE_MAX_DETECTIONS in the middle of a sequence: mpe_tracker_run_sequence and the
+    lock-step batch replay both hand out a ZEROED record that carries the status code for that frame (and a zeroed
+    info row), and both carry on with the sequence; a collect without a submission and a failed batch leave the
+    handle usable."""
+    seq = synth.make_sequence("C2", 8, seed=61)
+    frames = seq["frames"].copy()
+    rng = np.random.default_rng(8)
+    spots = np.stack([rng.uniform(20, 730, 60), rng.uniform(20, 460, 60)], 1)
+    frames[4] = synth.render_frame(rng, spots, 480, 752)
+    times = seq["times"]
+    P = mpe.demo_params()
+    h1, h2 = mpe.Handle(), mpe.Handle()
+    try:
+        t1 = mpe.Tracker(h1, seq["markers"], seq["K"], seq["D"], P)
+        rec1, info1 = t1.run_sequence(frames, times)
+        t2 = mpe.Tracker(h2, seq["markers"], seq["K"], seq["D"], P)
+        rec2, info2 = mpe.tracker_run_sequences_batch([t2], [frames], times)
+        rec2, info2 = rec2[0], info2[0]
+        assert rec1["status"][4] == -10 and rec2["status"][4] == -10
+        assert np.array_equal(rec1.view(np.uint8), rec2.view(np.uint8))
+        assert np.array_equal(info1, info2)
+        assert not rec1["T"][4].any() and not info1[4].any()
+        assert (rec1["status"][5:] >= 0).all()
+        # collect with nothing in flight is an error, cancel is harmless, and the handle still works afterwards
+        lib = mpe.load_library()
+        dets = np.zeros(1, mpe.DETECTIONS_DTYPE)
+        corr = np.zeros(2 * 16, np.uint32)
+        res = np.zeros(1, mpe.RESULT_DTYPE)
+        import ctypes as C
+        assert lib.mpe_track_step_batch_collect(h2._h, C.c_void_p(dets.ctypes.data), C.c_void_p(corr.ctypes.data),
+                                                C.c_void_p(res.ctypes.data)) < 0
+        assert lib.mpe_track_step_batch_cancel(h2._h) == 0
+        t2.reset()
+        rec3, _ = mpe.tracker_run_sequences_batch([t2], [frames[:3]], times[:3])
+        assert np.array_equal(rec3[0].view(np.uint8), rec1[:3].view(np.uint8))
+        t1.close()
+        t2.close()
+    finally:
+        h1.close()
+        h2.close()

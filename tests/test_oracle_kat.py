@@ -418,3 +418,49 @@ def test_reference_ferrari_is_unstable_when_w_vanishes(orc):
             G[k] = np.nextafter(G[k], sgn * np.inf)
             moved = max(moved, np.abs(np.sort(orc.solve_quartic(G)) - got).max())
     assert moved > 1e-4                                     # 1 ulp in -> 1e-4 .. 1e-2 out
+
+
+def test_blur_formulations_across_opencv_generations(orc):
+    """Which OpenCV the blur semantics restate, and where it matters.  The oracle / witness /
+    kernels restate generation A (OpenCV <= 3.4.1: getGaussianKernel(CV_32F) -> 8-bit integer taps, 8u32s filter
+    engine).  Against the two later data paths of cv::GaussianBlur for CV_8U (tests/witness.py):
+      * B (3.4.2 .. 4.1.1, ufixedpoint16, taps rounded from the CV_64F kernel): the SAME taps for every sigma on a 0.01
+        grid over (0, 6] (the dynamic-reconfigure range, cfg:13), and the same non-zero mask on images that drive the
+        16-bit horizontal accumulator into saturation;
+      * C (>= 4.1.2, error-diffused taps that sum to exactly 256): the same taps at the demo / default sigma 0.6 — the
+        only value the launch files and the cfg default use — but different taps at most other sigmas, i.e. there a
+        build of the reference against OpenCV 4 produces another mask than one against OpenCV 3.3, and this restatement
+        follows the latter."""
+    rng = np.random.default_rng(12)
+    sig = np.round(np.arange(1, 601) * 0.01, 2)
+    differs_c = []
+    for s in sig:
+        a = witness.gaussian_taps_q8(float(s))
+        assert np.array_equal(a, witness.gaussian_taps_ufixedpoint16(float(s))), s
+        assert np.array_equal(a, np.asarray(orc.gaussian_kernel_q8(float(s)))), s
+        if not np.array_equal(a, witness.gaussian_taps_bitexact_ed(float(s))):
+            differs_c.append(float(s))
+    assert 0.6 not in differs_c and 1.0 not in differs_c
+    assert 450 <= len(differs_c) <= 560, len(differs_c)   # most of the grid
+    # generation B's saturating 8.8 accumulator does not change the MASK (only plateau values of the blurred image)
+    for s in (0.3, 0.6, 0.77, 1.5, 3.1, 6.0):
+        img = rng.integers(0, 31, (64, 96)).astype(np.uint8)
+        img[20:40, 30:70] = 255                      # a plateau that saturates 255 * sum(taps) when sum(taps) > 257
+        img[5, 5] = 200
+        img[50:52, 80:83] = 180
+        taps = witness.gaussian_taps_q8(s)
+        m_a = witness.blur_mask_generation(img, 140, taps, False)
+        m_b = witness.blur_mask_generation(img, 140, taps, True)
+        assert np.array_equal(m_a, m_b), s
+        assert np.array_equal(m_a, witness.blur_fixed_point(img, 140, s) != 0), s
+        _, m_orc = orc.blur_mask(img, 140, s)
+        assert np.array_equal(m_a, np.asarray(m_orc) != 0), s
+    # ... and generation C really is another function where its taps differ: a sigma with a visible difference
+    n_diff_px = 0
+    for s in differs_c[:60]:
+        img = np.zeros((40, 40), np.uint8)
+        img[18:22, 18:22] = rng.integers(141, 256, (4, 4))
+        m_a = witness.blur_mask_generation(img, 140, witness.gaussian_taps_q8(s), False)
+        m_c = witness.blur_mask_generation(img, 140, witness.gaussian_taps_bitexact_ed(s), True)
+        n_diff_px += int((m_a != m_c).sum())
+    assert n_diff_px > 0
