@@ -77,7 +77,7 @@ struct mpe_handle {
   hipStream_t scan_stream = nullptr;  // mode 6: part of the next-but-one sub-batch's scan beside blobs / tail
   hipEvent_t scanpart_done[kMaxSub] = {};
   int side_scan_blocks = 2;           // mode 6: resident blocks per CU of the side scan (4 waves each)
-  int scan_split_pct = 20;            // mode 6: share of a sub-batch scanned by the stand-alone kernel on the side stream
+  int scan_split_pct = 30;            // mode 6: share of a sub-batch scanned by the stand-alone kernel on the side stream
   unsigned long long last_rider_bytes = 0;  // bytes one fused voting launch scanned in the last large call
   hipStream_t tail_stream = nullptr;  // fused schedule, mode 4: validate + refine of sub-batch s beside blobs(s + 1)
   hipEvent_t tail_done = nullptr;

@@ -1637,7 +1637,10 @@ __device__ __forceinline__ void k2_vote_flush(const K2Frame& F, int count) {
 // One work item = (staged detection triple ti, marker permutation pj): quartic coefficients (p3p.cpp:171-185),
 // Ferrari, and for each root the back-projection of the unused markers and the nearest-neighbour votes
 // (pose_estimator.cpp:596-702).  `live` = false: compute on, never vote (wave-uniform loop of the rider variant).
-template <bool SCAN, class Rider>
+// NP (plain variant): the single-precision copies of the back-projections stay in REGISTERS as NP packed marker pairs
+// (2 NP >= the number of unused markers) instead of LDS columns that every (detection, marker) pair of the prefilter
+// would read again; 0 = the LDS columns (more than 8 unused markers).
+template <bool SCAN, int NP = 0, class Rider>
 __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, bool live, Rider& rider, int& vq_count) {
   const unsigned ii = F.trii[ti];
   const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
@@ -1740,7 +1743,11 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     // the prefilter's operands, transposed: (u of marker 0, u of marker 1) and (v, v); a missing second marker sits
     // at infinity and never is the nearest
     f32x2 qfu = {0.f, INFINITY}, qfv = {0.f, INFINITY};
-    for (int j = 0; j < F.nuo; ++j) {
+    constexpr int NPA = NP > 0 ? NP : 1;
+    f32x2 pfu[NPA], pfv[NPA];  // plain variant, NP > 0: (u, u) and (v, v) of marker pair p; missing markers at infinity
+#pragma unroll
+    for (int pp = 0; pp < NPA; ++pp) pfu[pp] = pfv[pp] = f32x2{INFINITY, INFINITY};
+    auto back_project = [&](const int j) {
       const double* mk = SCAN ? lt + 5 + 3 * j : e + 18 + 3 * j;
       const double v0 = mk[0] - Cx, v1 = mk[1] - Cy, v2 = mk[2] - Cz;
       const double g = __builtin_fma(cos_theta, v1, sin_theta * v2);
@@ -1767,8 +1774,25 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
       } else {
         F.q[(2 * j) * F.nthr + F.tid] = qu;
         F.q[(2 * j + 1) * F.nthr + F.tid] = qv;
-        F.qf[j * F.nthr + F.tid] = f32x2{(float)qu, (float)qv};
+        if constexpr (NP > 0) {
+          if (j & 1) {
+            pfu[j >> 1].y = (float)qu;
+            pfv[j >> 1].y = (float)qv;
+          } else {
+            pfu[j >> 1].x = (float)qu;
+            pfv[j >> 1].x = (float)qv;
+          }
+        } else {
+          F.qf[j * F.nthr + F.tid] = f32x2{(float)qu, (float)qv};
+        }
       }
+    };
+    if constexpr (!SCAN && NP > 0) {
+#pragma unroll
+      for (int j = 0; j < 2 * NP; ++j)
+        if (j < F.nuo) back_project(j);  // (nuo is uniform over the block)
+    } else {
+      for (int j = 0; j < F.nuo; ++j) back_project(j);
     }
     // nearest back-projection for every unused detection (pose_estimator.cpp:862-906)
     if constexpr (SCAN) {
@@ -1811,16 +1835,25 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     // the detections that are not part of the triple, ascending: a uniform trip count for the frame
     for (unsigned m = unused; m; m &= m - 1) {
       const int a = __builtin_ctz(m);
-      {  // single-precision prefilter (packed arithmetic: both coordinates per instruction)
+      {  // single-precision prefilter
         const f32x2 af = F.pxf[a];
         float mn = INFINITY;
+        if constexpr (NP > 0) {  // two markers per packed instruction, the back-projections from registers
+#pragma unroll
+          for (int pp = 0; pp < NP; ++pp) {
+            const f32x2 du = f32x2{af.x, af.x} - pfu[pp], dv = f32x2{af.y, af.y} - pfv[pp];
+            const f32x2 d2 = k2_pk_fma(dv, dv, du * du);
+            mn = k2_fminf(mn, k2_fminf(d2.x, d2.y));  // (a NaN distance never wins, as in the exact search)
+          }
+        } else {  // (both coordinates per instruction, the back-projections from their LDS columns)
 #pragma unroll 4
-        for (int jj = 0; jj < F.nuo; ++jj) {
-          const f32x2 qf = F.qf[jj * F.nthr + F.tid];
-          f32x2 df = af - qf;
-          df = df * df;
-          const float d2f = df.x + df.y;
-          mn = d2f < mn ? d2f : mn;  // (a NaN distance never wins, as in the exact search)
+          for (int jj = 0; jj < F.nuo; ++jj) {
+            const f32x2 qf = F.qf[jj * F.nthr + F.tid];
+            f32x2 df = af - qf;
+            df = df * df;
+            const float d2f = df.x + df.y;
+            mn = d2f < mn ? d2f : mn;  // (a NaN distance never wins, as in the exact search)
+          }
         }
         if (!(mn <= F.thr_pre)) continue;
       }
@@ -1880,7 +1913,7 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
 // RANGE (forensics only, mpe_vote_items): frame f votes with the hypotheses whose flattened index — detection triple
 // x P(n_m,3) + marker permutation, the reference's loop order — lies in [item_range[2f], item_range[2f+1]); the
 // arithmetic of an item is the hot kernel's (same k2_vote_item).
-template <bool SCAN, bool RANGE = false>
+template <bool SCAN, bool RANGE = false, int NP = 0>
 __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_detections* __restrict__ dets, SolveParams sp,
                                                       const double* __restrict__ tab, uint32_t* __restrict__ hist,
                                                       int splits, ScanArgs scan, const int* __restrict__ item_range) {
@@ -1984,7 +2017,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           pj = 0;
         }
       }
-      k2_vote_item<SCAN>(F, ti, pj, live, rider, vq_count);
+      k2_vote_item<SCAN, NP>(F, ti, pj, live, rider, vq_count);
       ti = ti_keep;
       pj = pj_keep;
     }
@@ -2156,12 +2189,27 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
     if (scanned_bytes) *scanned_bytes = (size_t)sa.n_chunks * chunk_bytes;
     hipLaunchKernelGGL((k2_vote<true, false>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
                        splits, sa, (const int*)nullptr);
-  } else if (item_range) {
-    hipLaunchKernelGGL((k2_vote<false, true>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab,
-                       hist, splits, sa, item_range);
   } else {
-    hipLaunchKernelGGL((k2_vote<false, false>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab,
-                       hist, splits, sa, (const int*)nullptr);
+    // plain kernel: the prefilter's single-precision back-projections in registers as (nuo + 1) / 2 packed marker pairs
+    // (up to 8 unused markers), else in LDS columns; the forensics instantiation (item_range) the same way
+    const int np = nuo <= 8 ? (nuo + 1) / 2 : 0;
+    const dim3 grid((unsigned)(n_frames * splits)), block(threads);
+#define MPE_K2_PLAIN(NPV)                                                                                            \
+  do {                                                                                                               \
+    if (item_range)                                                                                                  \
+      hipLaunchKernelGGL((k2_vote<false, true, NPV>), grid, block, lds, s, dets, sp, tab, hist, splits, sa, item_range); \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k2_vote<false, false, NPV>), grid, block, lds, s, dets, sp, tab, hist, splits, sa,         \
+                         (const int*)nullptr);                                                                       \
+  } while (0)
+    switch (np) {
+      case 1: MPE_K2_PLAIN(1); break;
+      case 2: MPE_K2_PLAIN(2); break;
+      case 3: MPE_K2_PLAIN(3); break;
+      case 4: MPE_K2_PLAIN(4); break;
+      default: MPE_K2_PLAIN(0); break;
+    }
+#undef MPE_K2_PLAIN
   }
   return hipGetLastError();
 }

@@ -97,8 +97,18 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
     k2_vote_flush(F, vq_count);
   } else {
     int unused = 0;
+    // the instantiation the launcher would pick: (nuo + 1) / 2 marker pairs in registers up to 8 unused markers
+    const int np = nuo <= 8 ? (nuo + 1) / 2 : 0;
     for (int ti = 0; ti < n_combos; ++ti)
-      for (int pj = 0; pj < n_perms; ++pj) k2_vote_item<false>(F, ti, pj, true, rider, unused);
+      for (int pj = 0; pj < n_perms; ++pj) {
+        switch (variant == 2 ? 0 : np) {   // variant 2: force the LDS-column prefilter
+          case 1: k2_vote_item<false, 1>(F, ti, pj, true, rider, unused); break;
+          case 2: k2_vote_item<false, 2>(F, ti, pj, true, rider, unused); break;
+          case 3: k2_vote_item<false, 3>(F, ti, pj, true, rider, unused); break;
+          case 4: k2_vote_item<false, 4>(F, ti, pj, true, rider, unused); break;
+          default: k2_vote_item<false, 0>(F, ti, pj, true, rider, unused); break;
+        }
+      }
   }
   return 0;
 }

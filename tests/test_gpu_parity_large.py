@@ -320,7 +320,9 @@ def test_capacity_overrun_is_reported_alike_by_single_and_batch_replays(orc):
     frames = seq["frames"].copy()
     rng = np.random.default_rng(8)
     spots = np.stack([rng.uniform(20, 730, 60), rng.uniform(20, 460, 60)], 1)
-    frames[4] = synth.render_frame(rng, spots, 480, 752)
+    # the FIRST frame (whole-image detection: the estimator is not initialised yet) shows 60 blobs, more than
+    # MPE_MAX_DETECTIONS; the ordinary sequence follows
+    frames[0] = synth.render_frame(rng, spots, 480, 752)
     times = seq["times"]
     P = mpe.demo_params()
     h1, h2 = mpe.Handle(), mpe.Handle()
@@ -330,11 +332,11 @@ def test_capacity_overrun_is_reported_alike_by_single_and_batch_replays(orc):
         t2 = mpe.Tracker(h2, seq["markers"], seq["K"], seq["D"], P)
         rec2, info2 = mpe.tracker_run_sequences_batch([t2], [frames], times)
         rec2, info2 = rec2[0], info2[0]
-        assert rec1["status"][4] == -10 and rec2["status"][4] == -10
+        assert rec1["status"][0] == -10 and rec2["status"][0] == -10
         assert np.array_equal(rec1.view(np.uint8), rec2.view(np.uint8))
         assert np.array_equal(info1, info2)
-        assert not rec1["T"][4].any() and not info1[4].any()
-        assert (rec1["status"][5:] >= 0).all()
+        assert not rec1["T"][0].any() and not info1[0].any()
+        assert (rec1["status"][1:] >= 0).all() and (rec1["status"][1:] == 0).sum() >= 5
         # collect with nothing in flight is an error, cancel is harmless, and the handle still works afterwards
         lib = mpe.load_library()
         dets = np.zeros(1, mpe.DETECTIONS_DTYPE)
