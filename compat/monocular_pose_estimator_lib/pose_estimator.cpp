@@ -300,4 +300,11 @@ void PoseEstimator::estimateBodyPoseBatch(const uint8_t* frames, int n_frames, i
         "mpe_estimate_batch");
 }
 
+void PoseEstimator::decodeToMono8(const void* data, int mpe_encoding, bool is_bigendian, int rows, int cols, size_t step,
+                                  uint8_t* mono8_out) {
+  check(handle_, mpe_convert_to_mono8(handle_, data, 0, mpe_encoding, is_bigendian ? 1 : 0, 1, rows, cols, step,
+                                      step * (size_t)rows, mono8_out, 0),
+        "mpe_convert_to_mono8");
+}
+
 MPE_FACADE_END  // namespace monocular_pose_estimator

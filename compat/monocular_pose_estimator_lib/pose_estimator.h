@@ -106,6 +106,11 @@ class PoseEstimator {
   //! (host or device memory); results[i].status == 0 <=> estimateBodyPose returned true.
   void estimateBodyPoseBatch(const uint8_t* frames, int n_frames, int rows, int cols, bool frames_on_device,
                              mpe_result* results);
+  //! The node's cv_bridge::toCvCopy(image_msg, MONO8) (monocular_pose_estimator.cpp:147) on the device for the
+  //! encodings MPE_ENC_* (bgr8, rgb8, bgra8, rgba8, mono16, mono8): `data` / `step` as in sensor_msgs/Image,
+  //! mono8_out = rows x cols bytes (packed).  Throws on an unsupported encoding.
+  void decodeToMono8(const void* data, int mpe_encoding, bool is_bigendian, int rows, int cols, size_t step,
+                     uint8_t* mono8_out);
 
  private:
   void syncParams();

@@ -10,6 +10,7 @@
 
 #include "../monocular_pose_estimator_lib/facade_namespace.h"
 #include <cmath>
+#include <string>
 #include <vector>
 
 #include "monocular_pose_estimator_lib/pose_estimator.h"
@@ -64,6 +65,18 @@ inline void applyCameraInfo(PoseEstimator& pe, const double K9[9], const std::ve
 }
 
 //! The dynamic-reconfigure contract (cfg/MonocularPoseEstimator.cfg: names, defaults, ranges)
+// sensor_msgs/Image.encoding -> MPE_ENC_* for the encodings the back-end decodes itself (the node's
+// cv_bridge::toCvCopy(image_msg, MONO8), monocular_pose_estimator.cpp:147); -1: leave it to cv_bridge (Bayer etc.)
+inline int mpeEncodingFromString(const std::string& encoding) {
+  if (encoding == "mono8" || encoding == "8UC1") return MPE_ENC_MONO8;
+  if (encoding == "bgr8") return MPE_ENC_BGR8;
+  if (encoding == "rgb8") return MPE_ENC_RGB8;
+  if (encoding == "bgra8") return MPE_ENC_BGRA8;
+  if (encoding == "rgba8") return MPE_ENC_RGBA8;
+  if (encoding == "mono16") return MPE_ENC_MONO16;   // (16UC1 carries no [0, 65535] convention: cv_bridge refuses it too)
+  return -1;
+}
+
 struct ReconfigureValues {
   int threshold_value;                       // 180  [0, 255]
   double gaussian_sigma;                     // 0.6  [0, 6]

@@ -93,15 +93,38 @@ class MPENode {
       ROS_WARN("no camera info yet");
       return;
     }
+    // monocular_pose_estimator.cpp:147 converts every frame to MONO8 through cv_bridge.  mono8 is used in place; bgr8 /
+    // rgb8 / bgra8 / rgba8 / mono16 are decoded by the back-end itself (mpe_convert_to_mono8: the same integer /
+    // single-precision rules as cv::cvtColor / convertTo); anything else (Bayer patterns, ...) still goes through cv_bridge
     cv_bridge::CvImageConstPtr mono;
-    try {
-      mono = cv_bridge::toCvShare(msg, sensor_msgs::image_encodings::MONO8);  // the back-end never writes the frame
-    } catch (const cv_bridge::Exception& e) {
-      ROS_ERROR("cv_bridge: %s", e.what());
-      return;
+    const int enc = mpeEncodingFromString(msg->encoding);
+    const uint8_t* pixels = nullptr;
+    size_t step = 0;
+    if (enc == MPE_ENC_MONO8) {
+      pixels = msg->data.data();
+      step = msg->step;
+    } else if (enc > 0) {
+      decoded_.resize((size_t)msg->height * msg->width);
+      try {
+        estimator_.decodeToMono8(msg->data.data(), enc, msg->is_bigendian != 0, (int)msg->height, (int)msg->width, msg->step,
+                                 decoded_.data());
+      } catch (const std::exception& e) {
+        ROS_ERROR("decodeToMono8: %s", e.what());
+        return;
+      }
+      pixels = decoded_.data();
+      step = msg->width;
+    } else {
+      try {
+        mono = cv_bridge::toCvShare(msg, sensor_msgs::image_encodings::MONO8);  // the back-end never writes the frame
+      } catch (const cv_bridge::Exception& e) {
+        ROS_ERROR("cv_bridge: %s", e.what());
+        return;
+      }
+      pixels = mono->image.data;
+      step = mono->image.step;
     }
-    const cv::Mat& frame = mono->image;
-    const ImageView view(frame.data, frame.rows, frame.cols, frame.step);
+    const ImageView view(pixels, (int)msg->height, (int)msg->width, step);
     bool found = false;
     try {
       found = estimator_.estimateBodyPose(view, msg->header.stamp.toSec());
@@ -142,6 +165,7 @@ class MPENode {
   ros::Subscriber image_sub_, info_sub_;
   dynamic_reconfigure::Server<MonocularPoseEstimatorConfig> reconfigure_;
   PoseEstimator estimator_;
+  std::vector<uint8_t> decoded_;  // mono8 frame decoded from a colour / 16-bit message
   bool calibrated_;
 };
 

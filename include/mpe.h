@@ -130,6 +130,27 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
                        const double* markers_xyz, int n_markers, const double K[9],
                        const double* D, int nD, const mpe_params* p, mpe_result* results);
 
+/* ---- frame decode (SURVEY 8f "input side") -------------------------------------------------------------
+ * ≙ cv_bridge::toCvCopy(image_msg, sensor_msgs::image_encodings::MONO8) (monocular_pose_estimator.cpp:147) for the
+ * encodings a camera driver publishes: the payload of n_frames sensor_msgs/Image messages (rows x cols pixels, rows of
+ * src_stride_bytes = Image.step, frame f at src + f * src_frame_stride_bytes) -> packed mono8 frames (rows x cols bytes
+ * each, stride = cols), which is what every other entry point takes.  src / dst may each be a host or a device pointer.
+ *   MPE_ENC_BGR8 / RGB8 / BGRA8 / RGBA8: cv::cvtColor(..., COLOR_{BGR,RGB,BGRA,RGBA}2GRAY) on CV_8U:
+ *       Y = (B * 1868 + G * 9617 + R * 4899 + 2^13) >> 14   (integer, bit-exact)
+ *   MPE_ENC_MONO16: cv::Mat::convertTo(CV_8U, 255. / 65535.) = saturate_cast<uchar>((float)v * (float)(255. / 65535.)),
+ *       after cv_bridge's byte swap when Image.is_bigendian differs from the host (src_big_endian)
+ *   MPE_ENC_MONO8: a (strided) copy.
+ * Bayer encodings (cv_bridge demosaics them through COLOR_Bayer*2GRAY) are not covered: MPE_ERR_UNSUPPORTED. */
+#define MPE_ENC_MONO8 0
+#define MPE_ENC_BGR8 1
+#define MPE_ENC_RGB8 2
+#define MPE_ENC_BGRA8 3
+#define MPE_ENC_RGBA8 4
+#define MPE_ENC_MONO16 5
+int mpe_convert_to_mono8(mpe_handle* h, const void* src, int src_on_device, int encoding, int src_big_endian, int n_frames,
+                         int rows, int cols, size_t src_stride_bytes, size_t src_frame_stride_bytes, uint8_t* dst,
+                         int dst_on_device);
+
 /* Page-locked host memory for frame buffers (what a camera driver / cv_bridge::toCvCopy target should write into,
  * monocular_pose_estimator.cpp:147): with HOST frames in pinned memory mpe_estimate_batch ingests a large batch
  * in chunks (option "ingest_chunk", default 2048 frames, 0 = one copy), the H2D copy of chunk c + 1 running

@@ -256,6 +256,24 @@ def vote_histogram(det, markers, K, tol):
     return h
 
 
+ENCODINGS = {"mono8": 0, "bgr8": 1, "rgb8": 2, "bgra8": 3, "rgba8": 4, "mono16": 5}
+
+
+def convert_to_mono8(src, encoding, big_endian=False):
+    """cv_bridge::toCvCopy(msg, MONO8) for one image: src (rows, cols[, channels]) uint8, or (rows, cols) uint16 for
+    mono16 (given in the byte order the message declares: pass big_endian accordingly)."""
+    enc = ENCODINGS[encoding]
+    src = np.ascontiguousarray(src)
+    rows, cols = src.shape[:2]
+    raw = src.view(np.uint8).reshape(rows, -1)
+    dst = np.zeros((rows, cols), np.uint8)
+    rc = lib().orc_convert_to_mono8(raw.ctypes.data_as(C.c_void_p), enc, int(bool(big_endian)), rows, cols,
+                                    C.c_size_t(raw.strides[0]), dst.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError("orc_convert_to_mono8 failed")
+    return dst
+
+
 def vote_items(det, markers, K, tol, lo, hi):
     """Votes of the hypotheses [lo, hi) of initialise()'s loop nest only (forensics)."""
     det = _f64(det).reshape(-1, 2)

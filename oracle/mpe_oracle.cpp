@@ -1696,6 +1696,40 @@ void orc_compute_transformation(const double* obj, const double* rep, int n, dou
   std::memcpy(T, M.m, sizeof(M.m));
 }
 
+// ---- frame decode: cv_bridge::toCvCopy(image_msg, MONO8), monocular_pose_estimator.cpp:147 -------------------
+// What cv_bridge does for the encodings a camera driver publishes (cv_bridge/src/cv_bridge.cpp, toCvCopyImpl):
+//   bgr8 / rgb8 / bgra8 / rgba8 -> mono8: cv::cvtColor(COLOR_{BGR,RGB,BGRA,RGBA}2GRAY), for CV_8U the integer form
+//       Y = (B * B2Y + G * G2Y + R * R2Y + (1 << (yuv_shift - 1))) >> yuv_shift, B2Y 1868, G2Y 9617, R2Y 4899, yuv_shift 14
+//   mono16 -> mono8: a byte swap when Image.is_bigendian differs from the host, then
+//       Mat::convertTo(CV_8U, 255. / 65535.): saturate_cast<uchar>(src * (float)alpha) = round-half-even, clamped
+//   mono8: a copy.
+// encoding: 0 mono8, 1 bgr8, 2 rgb8, 3 bgra8, 4 rgba8, 5 mono16 (the MPE_ENC_* values).  dst: packed rows x cols.
+int orc_convert_to_mono8(const uint8_t* src, int encoding, int big_endian, int rows, int cols, size_t src_stride,
+                         uint8_t* dst) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || encoding < 0 || encoding > 5) return -1;
+  const float alpha = (float)(255. / 65535.);
+  for (int y = 0; y < rows; ++y) {
+    const uint8_t* s = src + (size_t)y * src_stride;
+    uint8_t* d = dst + (size_t)y * cols;
+    for (int x = 0; x < cols; ++x) {
+      if (encoding == 0) {
+        d[x] = s[x];
+      } else if (encoding == 5) {
+        const unsigned v = big_endian ? ((unsigned)s[2 * x] << 8 | s[2 * x + 1]) : ((unsigned)s[2 * x + 1] << 8 | s[2 * x]);
+        const float r = std::nearbyintf((float)v * alpha);  // cvRound: round half to even (default rounding mode)
+        d[x] = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+      } else {
+        const int bpp = (encoding == 3 || encoding == 4) ? 4 : 3;
+        const bool rgb = encoding == 2 || encoding == 4;
+        const unsigned c0 = s[bpp * x], c1 = s[bpp * x + 1], c2 = s[bpp * x + 2];
+        const unsigned b = rgb ? c2 : c0, r = rgb ? c0 : c2;
+        d[x] = (uint8_t)((b * 1868u + c1 * 9617u + r * 4899u + (1u << 13)) >> 14);
+      }
+    }
+  }
+  return 0;
+}
+
 // forensics (tests/forensics.py): the votes of the hypotheses [item_lo, item_hi) of initialise()'s loop nest only
 int orc_vote_items(const double* det, int n_det, const double* markers, int n_markers, const double K[9], double tol,
                    long long item_lo, long long item_hi, uint32_t* hist) {

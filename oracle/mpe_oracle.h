@@ -106,6 +106,10 @@ void orc_compute_transformation(const double* obj, const double* rep, int n, dou
 /* voting only: PE.cpp:544-702.  returns 0 */
 int orc_vote_histogram(const double* det, int n_det, const double* markers, int n_markers,
                        const double K[9], double back_projection_pixel_tolerance, uint32_t* hist);
+/* cv_bridge::toCvCopy(image_msg, MONO8) (monocular_pose_estimator.cpp:147) for encoding 0 mono8, 1 bgr8, 2 rgb8,
+ * 3 bgra8, 4 rgba8, 5 mono16 (big_endian: Image.is_bigendian); dst packed rows x cols.  returns 0 */
+int orc_convert_to_mono8(const uint8_t* src, int encoding, int big_endian, int rows, int cols, size_t src_stride,
+                         uint8_t* dst);
 /* forensics: the votes of the hypotheses [item_lo, item_hi) of that loop nest only (flattened index = detection-triple
  * index * P(n_markers,3) + marker-permutation index, COMB.cpp table order) */
 int orc_vote_items(const double* det, int n_det, const double* markers, int n_markers, const double K[9],

@@ -121,6 +121,8 @@ def load_library():
     lib.mpe_estimate_batch_device_collect.argtypes = [C.c_void_p, C.c_void_p]
     lib.mpe_track_step_batch_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mpe_track_step_batch_cancel.argtypes = [C.c_void_p]
+    lib.mpe_convert_to_mono8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
     lib.mpe_detect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int,
                                      dp, dp, C.c_int, C.POINTER(MpeParams), C.c_void_p]
     lib.mpe_vote_batch.argtypes = [C.c_void_p, dp, C.POINTER(C.c_int), C.c_int, dp, C.c_int, dp, C.c_double,
@@ -337,6 +339,9 @@ def find_correspondences(pred_px, det, tol):
     if n < 0:
         raise MpeError("mpe_find_correspondences failed (%d)" % n)
     return corr[:n].copy()
+
+
+ENCODINGS = {"mono8": 0, "bgr8": 1, "rgb8": 2, "bgra8": 3, "rgba8": 4, "mono16": 5}  # MPE_ENC_*
 
 
 def demo_params(**kw):
@@ -562,6 +567,33 @@ class Handle:
                                                  len(markers), _dp(K), _dp(D), len(D), C.byref(params),
                                                  C.c_void_p(d_results_ptr))
         self._check(rc, "mpe_estimate_batch_device")
+
+    def convert_to_mono8(self, src, encoding, big_endian=False):
+        """mpe_convert_to_mono8 for a batch: src (n, rows, cols[, channels]) uint8 / (n, rows, cols) uint16 numpy array
+        (host) or torch CUDA tensor; encoding "mono8" | "bgr8" | "rgb8" | "bgra8" | "rgba8" | "mono16".
+        -> (n, rows, cols) uint8, numpy for a host source, a torch CUDA tensor for a device source."""
+        enc = ENCODINGS[encoding]
+        if _is_torch(src):
+            import torch
+            src = src.contiguous()
+            n, rows, cols = src.shape[:3]
+            bpp = src.element_size() * (src.shape[3] if src.dim() == 4 else 1)
+            dst = torch.empty((n, rows, cols), dtype=torch.uint8, device=src.device)
+            rc = self._lib.mpe_convert_to_mono8(self._h, C.c_void_p(src.data_ptr()), 1, enc, int(bool(big_endian)), n, rows,
+                                                cols, C.c_size_t(cols * bpp), C.c_size_t(rows * cols * bpp),
+                                                C.c_void_p(dst.data_ptr()), 1)
+            self._check(rc, "mpe_convert_to_mono8")
+            self.synchronize()
+            return dst
+        src = np.ascontiguousarray(src)
+        n, rows, cols = src.shape[:3]
+        raw = src.view(np.uint8).reshape(n, rows, -1)
+        dst = np.zeros((n, rows, cols), np.uint8)
+        rc = self._lib.mpe_convert_to_mono8(self._h, C.c_void_p(raw.ctypes.data), 0, enc, int(bool(big_endian)), n, rows, cols,
+                                            C.c_size_t(raw.strides[1]), C.c_size_t(raw.strides[0]),
+                                            C.c_void_p(dst.ctypes.data), 0)
+        self._check(rc, "mpe_convert_to_mono8")
+        return dst
 
     def estimate_batch_device_submit(self, d_frames_ptr, n, rows, cols, markers, K, D, params, d_results_ptr,
                                      d_next_frames_ptr=0, n_next=0):

@@ -58,6 +58,8 @@ struct SolveParams {
 };
 
 #define MPE_HIST_STRIDE (MPE_MAX_DETECTIONS * MPE_MAX_MARKERS)
+// mpe_detections.n while a frame waits for a follow-up tier of the blob extraction (device-internal, never handed out)
+#define MPE_DETS_PENDING (-1)
 
 // launchers (mpe_kernels.hip)
 size_t k1b_scratch_bytes(const FrameGeom& g);
@@ -66,7 +68,8 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
                             int blob_hint, hipStream_t s, const void* frame_windows = nullptr,
-                            bool lists_zeroed = false);
+                            bool lists_zeroed = false, hipStream_t follow = nullptr, hipEvent_t first_done = nullptr,
+                            hipEvent_t follow_done = nullptr);
 // worklist: 2 * (n_frames + 1) ints (two device work-lists that chain the capacity tiers); lists_zeroed = the caller
 // has zeroed it in stream order already (one memset for all the sub-batches of a call) and no memset is issued here.
 // frame_windows: optional device array of n_frames x {rows, cols, roi_x, roi_y} ints — every frame then is a window
@@ -91,6 +94,9 @@ hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int 
 hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int n_frames, int roi_x,
                          int roi_y, int roi_w, int roi_h, uint8_t* dst, int dst_pitch, hipStream_t s);
 
+// sensor_msgs/Image payload (bgr8 / rgb8 / bgra8 / rgba8 / mono16 / mono8, MPE_ENC_*) -> packed mono8 frames
+hipError_t launch_to_mono8(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int encoding, int big_endian,
+                           int n_frames, int rows, int cols, uint8_t* dst, hipStream_t s);
 hipError_t launch_spin(unsigned long long ticks_100mhz, hipStream_t s);
 hipError_t launch_p3p_batch(const double* fv, const double* wp, int n, double* sol, int* status, hipStream_t s);
 hipError_t launch_quartic_batch(const double* factors, int n, int variant, double* roots, hipStream_t s);

@@ -629,13 +629,17 @@ __device__ __forceinline__ void write_detections(const float* kx, const float* k
       out->undist_xy[2 * pos + 1] = (double)uy;
     }
   }
+  // The count is the record's "ready" flag for a voting block that may already be waiting for this frame (the
+  // follow-up tiers run beside the voting kernel in the fused schedule): everything else first, made visible at
+  // agent scope by the whole wave, then the count.
   if (lane == 0) {
-    out->n = min(nk_all, MPE_MAX_DETECTIONS);
     int st = 0;
     if (nk_all > MPE_MAX_DETECTIONS) st = MPE_FRAME_TOO_MANY_DETECTIONS;
     if (over) st = MPE_FRAME_TOO_MANY_ROWS;
     out->status = st;
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  if (lane == 0) __hip_atomic_store(&out->n, min(nk_all, MPE_MAX_DETECTIONS), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // =============================================================================================
@@ -938,7 +942,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   }
   if (fallback) {  // hand the frame to the general kernel
     if (lane == 0) {
-      out->n = 0;
+      out->n = worklist ? MPE_DETS_PENDING : 0;  // (pending: a later tier writes the record, see k2_wait_detections)
       out->status = MPE_FRAME_TOO_MANY_ROWS;  // overwritten by the general kernel
       if (worklist) {
         const int k = atomicAdd(&worklist[0], 1);
@@ -1001,7 +1005,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
 
 // hand a frame to the next tier
 __device__ __forceinline__ void k1b_hand_over(int f, mpe_detections* __restrict__ dets, int* __restrict__ worklist) {
-  dets[f].n = 0;
+  dets[f].n = worklist ? MPE_DETS_PENDING : 0;
   dets[f].status = MPE_FRAME_TOO_MANY_ROWS;  // overwritten by the next tier
   if (worklist) {
     const int k = atomicAdd(&worklist[0], 1);
@@ -1227,12 +1231,17 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
 #define K1B_GEN_BLOCKS 32
 size_t k1b_scratch_bytes(const FrameGeom& g) { return k1b_gen_scratch_bytes(g) * K1B_GEN_BLOCKS; }
 
+// Three tiers, chained through device work-lists (no host round trip):
+//   small LDS pools (4 waves / SIMD) -> large LDS pools -> whole-frame window in global scratch.
+// The FIRST tier sees every frame; the follow-up tiers only the frames it handed over (normally none or a handful,
+// their records marked MPE_DETS_PENDING meanwhile).  `follow` != nullptr: the follow-up tiers go to that stream, after
+// `first_done` (recorded here on `s`), so that a consumer on `s` which knows how to wait for pending records — the
+// voting kernel — need not sit behind their one-wave-per-frame latency; `follow_done` is recorded behind them.
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
-                            int blob_hint, hipStream_t s, const void* frame_windows, bool lists_zeroed) {
+                            int blob_hint, hipStream_t s, const void* frame_windows, bool lists_zeroed,
+                            hipStream_t follow, hipEvent_t first_done, hipEvent_t follow_done) {
   const FrameWin* wins = static_cast<const FrameWin*>(frame_windows);
-  // Three tiers, chained through device work-lists (no host round trip):
-  //   small LDS pools (3 waves/SIMD) -> large LDS pools -> whole-frame window in global scratch
   if (n_frames <= 0) return hipSuccess;
   int* list_a = worklist;                   // small -> large
   int* list_b = worklist + (n_frames + 1);  // large -> general
@@ -1241,22 +1250,34 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
     e = hipMemsetAsync(list_a, 0, (size_t)(n_frames + 2) * sizeof(int), s);
     if (e != hipSuccess) return e;
   }
-  if (blob_hint > 0 && blob_hint <= 8) {  // (the small tier is cheap to try: frames that overflow it go on to the large one)
+  const bool small_first = blob_hint > 0 && blob_hint <= 8;
+  if (small_first) {  // (the small tier is cheap to try: frames that overflow it go on to the large one)
     const int blocks = (n_frames + K1bSmall::WAVES - 1) / K1bSmall::WAVES;
     hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64 * K1bSmall::WAVES), 0, s, frames, (const u64*)flags, g, dp, dets,
                        list_a, n_frames, wins);
-    const int grid = n_frames < 2048 ? n_frames : 2048;
-    hipLaunchKernelGGL((k1b_blobs_list<K1bLarge>), dim3(grid), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
-                       dets, (const int*)list_a, list_b, wins);
   } else {
     hipLaunchKernelGGL((k1b_blobs<K1bLarge>), dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
                        dets, list_b, n_frames, wins);
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k1b_general, dim3(K1B_GEN_BLOCKS), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
+  hipStream_t fs = s;
+  if (follow) {
+    if ((e = hipEventRecord(first_done, s)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(follow, first_done, 0)) != hipSuccess) return e;
+    fs = follow;
+  }
+  if (small_first) {
+    const int grid = n_frames < 2048 ? n_frames : 2048;
+    hipLaunchKernelGGL((k1b_blobs_list<K1bLarge>), dim3(grid), dim3(64), 0, fs, frames, (const u64*)flags, g, dp,
+                       dets, (const int*)list_a, list_b, wins);
+  }
+  hipLaunchKernelGGL(k1b_general, dim3(K1B_GEN_BLOCKS), dim3(64), 0, fs, frames, (const u64*)flags, g, dp, dets,
                      (const int*)list_b, scratch, wins);
-  return hipGetLastError();
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (follow) e = hipEventRecord(follow_done, follow);
+  return e;
 }
 
 // =============================================================================================
@@ -1900,6 +1921,24 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
   }
 }
 
+// A frame that overflowed the small tier of the blob extraction is finished by the follow-up tiers; in the fused
+// schedule those run on a side stream BESIDE the voting kernel (a handful of frames: one wave each, 60 us of latency
+// that used to sit on the critical path of every sub-batch), and the voting block of such a frame waits here until the
+// record is there: the count is the flag (MPE_DETS_PENDING until write_detections' release store).  Bounded: a
+// follow-up kernel that never comes leaves the frame without detections instead of hanging the GPU (its record then
+// keeps the pending count, which the tail kernel reports as MPE_FRAME_TOO_MANY_ROWS).
+__device__ __forceinline__ void k2_wait_detections(const mpe_detections* d, unsigned* lds_flag) {
+  if (threadIdx.x == 0) {
+    int n = __hip_atomic_load(&d->n, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    for (int it = 0; n == MPE_DETS_PENDING && it < (1 << 21); ++it) {  // (~2 us per probe: seconds in all)
+      __builtin_amdgcn_s_sleep(64);
+      n = __hip_atomic_load(&d->n, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    lds_flag[0] = 0;  // (any LDS word: the barrier below is what the other lanes wait at)
+  }
+  __syncthreads();
+}
+
 // Voting kernel.  Work item = (detection triple, marker permutation).  Everything that depends
 // only on the detection triple (tau frame T, f_1, f_2, b and the swap of p3p.cpp:100-121) is
 // computed once per triple into LDS; everything that depends only on the marker permutation comes
@@ -1932,7 +1971,8 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   const int tid = threadIdx.x;
   const int nthr = blockDim.x;
   const mpe_detections* d = dets + f;
-  const int n_d = d->n, n_m = sp.n_markers;
+  k2_wait_detections(d, s_hist);
+  const int n_d = max(d->n, 0), n_m = sp.n_markers;
   typename std::conditional<SCAN, ScanRider, NoRider>::type rider;
   if constexpr (SCAN) rider.init(scan, smem);  // (this variant keeps the back-projections in registers)
   if (n_d < 4 || d->status != 0 || n_m < 4) {  // min_num_leds_detected_ (pose_estimator.h:78)
@@ -2523,7 +2563,7 @@ __global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restr
   const bool live = f < n_frames;
   const mpe_detections* d = dets + (live ? f : 0);
   mpe_result* res = results + (live ? f : 0);
-  const int n_d = live ? d->n : 0, n_m = sp.n_markers;
+  const int n_d = live ? max(d->n, 0) : 0, n_m = sp.n_markers;  // (a count still pending = a follow-up tier never ran)
   const int dstatus = live ? d->status : 0;
   const uint32_t* H = hist + (size_t)(live ? f : 0) * MPE_HIST_STRIDE;
   const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
@@ -2934,6 +2974,81 @@ __global__ __launch_bounds__(64) void k_quartic_batch(const double* __restrict__
   else
     solve_quartic(a[0], a[1], a[2], a[3], a[4], r);  // IEEE operators (validation kernel)
   for (int k = 0; k < 4; ++k) roots[(size_t)i * 4 + k] = r[k];
+}
+
+// =============================================================================================
+// frame decode: sensor_msgs/Image payloads -> mono8 (what cv_bridge::toCvCopy(msg, MONO8) does for the node,
+// monocular_pose_estimator.cpp:147).  HBM bound, one pass: 4 output pixels per lane and step.
+//   bgr8 / rgb8 / bgra8 / rgba8: cv::cvtColor(..., COLOR_*2GRAY) for CV_8U — integer, 14 fractional bits,
+//       Y = (B * 1868 + G * 9617 + R * 4899 + 2^13) >> 14
+//   mono16 (host byte order after cv_bridge's endianness fix): Mat::convertTo(CV_8U, 255. / 65535.) —
+//       saturate_cast<uchar>((float)v * (float)(255. / 65535.)), i.e. round-half-even of the single-precision product
+// =============================================================================================
+__device__ __forceinline__ unsigned gray_px(unsigned c0, unsigned c1, unsigned c2, bool rgb) {
+  const unsigned b = rgb ? c2 : c0, r = rgb ? c0 : c2;
+  return (b * 1868u + c1 * 9617u + r * 4899u + (1u << 13)) >> 14;
+}
+__global__ __launch_bounds__(256) void k_to_mono8(const uint8_t* __restrict__ src, size_t src_stride, size_t src_frame_stride,
+                                                  int encoding, int big_endian, int rows, int cols, long long n_rows_total,
+                                                  uint8_t* __restrict__ dst) {
+  const int quads = (cols + 3) >> 2;  // 4 output pixels per work item
+  const long long total = n_rows_total * quads;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / quads;
+    const int x0 = (int)(i - row * quads) * 4;
+    const long long f = row / rows;
+    const int y = (int)(row - f * rows);
+    const uint8_t* s = src + (size_t)f * src_frame_stride + (size_t)y * src_stride;
+    uint8_t* d = dst + ((size_t)f * rows + y) * cols + x0;
+    const int n = min(4, cols - x0);
+    unsigned out[4] = {0, 0, 0, 0};
+    if (encoding == MPE_ENC_MONO16) {
+      for (int k = 0; k < n; ++k) {
+        const uint8_t* p = s + 2 * (size_t)(x0 + k);
+        const unsigned v = big_endian ? ((unsigned)p[0] << 8 | p[1]) : ((unsigned)p[1] << 8 | p[0]);
+        float r = rintf((float)v * (float)(255.0 / 65535.0));
+        r = fminf(fmaxf(r, 0.f), 255.f);
+        out[k] = (unsigned)r;
+      }
+    } else if (encoding == MPE_ENC_MONO8) {
+      for (int k = 0; k < n; ++k) out[k] = s[x0 + k];
+    } else {
+      const int bpp = (encoding == MPE_ENC_BGRA8 || encoding == MPE_ENC_RGBA8) ? 4 : 3;
+      const bool rgb = encoding == MPE_ENC_RGB8 || encoding == MPE_ENC_RGBA8;
+      const uint8_t* p = s + (size_t)bpp * x0;
+      if (n == 4 && ((reinterpret_cast<uintptr_t>(p) & 3) == 0)) {  // three or four aligned 32-bit loads
+        const unsigned* w = reinterpret_cast<const unsigned*>(p);
+        if (bpp == 3) {
+          const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
+          out[0] = gray_px(w0 & 0xFF, (w0 >> 8) & 0xFF, (w0 >> 16) & 0xFF, rgb);
+          out[1] = gray_px(w0 >> 24, w1 & 0xFF, (w1 >> 8) & 0xFF, rgb);
+          out[2] = gray_px((w1 >> 16) & 0xFF, w1 >> 24, w2 & 0xFF, rgb);
+          out[3] = gray_px((w2 >> 8) & 0xFF, (w2 >> 16) & 0xFF, w2 >> 24, rgb);
+        } else {
+          for (int k = 0; k < 4; ++k) out[k] = gray_px(w[k] & 0xFF, (w[k] >> 8) & 0xFF, (w[k] >> 16) & 0xFF, rgb);
+        }
+      } else {
+        for (int k = 0; k < n; ++k) out[k] = gray_px(p[bpp * k], p[bpp * k + 1], p[bpp * k + 2], rgb);
+      }
+    }
+    if (n == 4 && ((reinterpret_cast<uintptr_t>(d) & 3) == 0)) {
+      *reinterpret_cast<unsigned*>(d) = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+    } else {
+      for (int k = 0; k < n; ++k) d[k] = (uint8_t)out[k];
+    }
+  }
+}
+
+hipError_t launch_to_mono8(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int encoding, int big_endian,
+                           int n_frames, int rows, int cols, uint8_t* dst, hipStream_t s) {
+  if (n_frames <= 0 || rows <= 0 || cols <= 0) return hipSuccess;
+  const long long n_rows = (long long)n_frames * rows;
+  const long long items = n_rows * ((cols + 3) / 4);
+  long long blocks = (items + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond 64 blocks per CU
+  hipLaunchKernelGGL(k_to_mono8, dim3((unsigned)blocks), dim3(256), 0, s, src, src_stride, src_frame_stride, encoding,
+                     big_endian, rows, cols, n_rows, dst);
+  return hipGetLastError();
 }
 
 // one wave that keeps a CU slot busy for `ticks` of the constant-rate counter (100 MHz): used once per

@@ -354,3 +354,44 @@ def test_capacity_overrun_is_reported_alike_by_single_and_batch_replays(orc):
     finally:
         h1.close()
         h2.close()
+
+
+@pytest.mark.parametrize("encoding", ["bgr8", "rgb8", "bgra8", "rgba8", "mono16", "mono8"])
+def test_convert_to_mono8_bit_exact(hip, orc, encoding):
+    """mpe_convert_to_mono8 (= cv_bridge::toCvCopy(msg, MONO8), monocular_pose_estimator.cpp:147) against the oracle's
+    restatement: every byte equal — host and device sources, odd widths (unaligned rows), both byte orders for
+    mono16 — and the decoded frames give the same detections as the mono8 original."""
+    import torch
+    rng = np.random.default_rng(41)
+    for rows, cols in ((48, 64), (37, 53), (5, 3)):
+        n = 3
+        if encoding == "mono16":
+            src = rng.integers(0, 65536, (n, rows, cols)).astype(np.uint16)
+        elif encoding == "mono8":
+            src = rng.integers(0, 256, (n, rows, cols)).astype(np.uint8)
+        else:
+            src = rng.integers(0, 256, (n, rows, cols, 4 if encoding.endswith("a8") else 3)).astype(np.uint8)
+        ref = np.stack([orc.convert_to_mono8(src[i], encoding) for i in range(n)])
+        assert np.array_equal(hip.convert_to_mono8(src, encoding), ref), (encoding, rows, cols)
+        raw = src.view(np.uint8).reshape(n, rows, cols, 2) if encoding == "mono16" else src   # bytes per pixel last
+        dev = hip.convert_to_mono8(torch.from_numpy(raw).cuda(), encoding)
+        assert np.array_equal(dev.cpu().numpy(), ref), (encoding, rows, cols, "device source")
+        if encoding == "mono16":
+            assert np.array_equal(hip.convert_to_mono8(src.byteswap(), encoding, big_endian=True), ref)
+    # a colour / 16-bit rendering of a synthetic frame decodes to the frame the detector was tested on
+    d = synth.make_frames("C2", 2, seed=7)
+    f = d["frames"]
+    if encoding == "mono16":
+        enc_img = (f.astype(np.uint16) * 257)           # 8-bit value v as 16-bit v * 65535 / 255
+    elif encoding == "mono8":
+        enc_img = f
+    else:
+        ch = 4 if encoding.endswith("a8") else 3
+        enc_img = np.repeat(f[..., None], ch, axis=3)   # gray in every channel: Y = v exactly (the weights sum to 2^14)
+    got = hip.convert_to_mono8(np.ascontiguousarray(enc_img), encoding)
+    assert np.array_equal(got, f)
+    with pytest.raises(mpe.MpeError):
+        lib = mpe.load_library()
+        import ctypes as C
+        rc = lib.mpe_convert_to_mono8(hip._h, C.c_void_p(f.ctypes.data), 0, 9, 0, 1, 4, 4, 4, 16, C.c_void_p(f.ctypes.data), 0)
+        hip._check(rc, "mpe_convert_to_mono8")

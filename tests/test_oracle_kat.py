@@ -464,3 +464,27 @@ def test_blur_formulations_across_opencv_generations(orc):
         m_c = witness.blur_mask_generation(img, 140, witness.gaussian_taps_bitexact_ed(s), True)
         n_diff_px += int((m_a != m_c).sum())
     assert n_diff_px > 0
+
+
+def test_convert_to_mono8_restates_cv_bridge(orc):
+    """cv_bridge::toCvCopy(msg, MONO8) (monocular_pose_estimator.cpp:147): BGR / RGB(A) -> gray with OpenCV's 14-bit
+    integer coefficients, mono16 -> mono8 by convertTo(CV_8U, 255 / 65535.) in single precision, round half to even —
+    against independent numpy forms, incl. the known values 255/255/255 -> 255, pure channels, 65535 -> 255."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (9, 13, 3)).astype(np.uint8)
+    y = (img[..., 0].astype(np.int64) * 1868 + img[..., 1].astype(np.int64) * 9617 + img[..., 2].astype(np.int64) * 4899
+         + (1 << 13)) >> 14
+    assert np.array_equal(orc.convert_to_mono8(img, "bgr8"), y.astype(np.uint8))
+    assert np.array_equal(orc.convert_to_mono8(img[..., ::-1], "rgb8"), y.astype(np.uint8))
+    img4 = np.concatenate([img, rng.integers(0, 256, (9, 13, 1)).astype(np.uint8)], axis=2)
+    assert np.array_equal(orc.convert_to_mono8(img4, "bgra8"), y.astype(np.uint8))
+    assert np.array_equal(orc.convert_to_mono8(np.ascontiguousarray(img4[..., [2, 1, 0, 3]]), "rgba8"), y.astype(np.uint8))
+    px = np.array([[[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [0, 0, 0]]], np.uint8)
+    assert orc.convert_to_mono8(px, "bgr8").tolist() == [[255, 29, 150, 76, 0]]   # 0.114 / 0.587 / 0.299 of 255
+    m = rng.integers(0, 65536, (6, 7)).astype(np.uint16)
+    ref = np.clip(np.rint(m.astype(np.float32) * np.float32(255. / 65535.)), 0, 255).astype(np.uint8)
+    assert np.array_equal(orc.convert_to_mono8(m, "mono16"), ref)
+    assert np.array_equal(orc.convert_to_mono8(m.byteswap(), "mono16", big_endian=True), ref)
+    assert orc.convert_to_mono8(np.array([[65535, 0, 257, 128, 129]], np.uint16), "mono16").tolist() == [[255, 0, 1, 0, 1]]
+    g = rng.integers(0, 256, (4, 5)).astype(np.uint8)
+    assert np.array_equal(orc.convert_to_mono8(g, "mono8"), g)
