@@ -100,10 +100,6 @@ struct mpe_handle {
   } prefetch;
   hipEvent_t prefetch_side_done = nullptr;
   bool done_recorded = false;  // run_pipeline has recorded batch_done[submit_seq & 1] itself (fused schedules)
-  // follow-up tiers of the blob extraction beside the voting kernel (fused schedules with side streams)
-  hipStream_t tier_stream = nullptr;
-  hipEvent_t tier_first[kMaxSub] = {}, tier_done[kMaxSub] = {};
-  bool probed_tier = false;
   // side streams of schedules 4 / 6 verified (spin probe) to execute beside the caller's stream
   int side_streams_ok = -1;           // 1 yes, 0 no concurrent set found (-> schedule 3), -1 not probed
   hipStream_t probed_for = nullptr;   // the caller's stream the verdict holds for
@@ -468,10 +464,8 @@ int ensure_side_streams(mpe_handle* h, bool need_scan) {
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (!h->tail_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
   if (need_scan && !h->scan_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking));
-  if (!h->tier_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->tier_stream, hipStreamNonBlocking));
   HIP_TRY(h, hipStreamSynchronize(h->tail_stream));
   if (h->scan_stream) HIP_TRY(h, hipStreamSynchronize(h->scan_stream));
-  HIP_TRY(h, hipStreamSynchronize(h->tier_stream));
   double ms = 0;
   HIP_TRY(h, spin_pair_ms(h->stream, h->stream, ms));  // first launch of the kernel (code object load) is not timed
   std::vector<hipStream_t> rejected;
@@ -501,23 +495,6 @@ int ensure_side_streams(mpe_handle* h, bool need_scan) {
     } else {
       rejected.push_back(h->scan_stream);
       h->scan_stream = fresh;
-    }
-  }
-  // the stream of the blob extraction's follow-up tiers must run beside the CALLER's stream (voting blocks wait on it
-  // for the few frames those tiers finish); it may share a queue with the other side streams.  A few replacements; if
-  // none is concurrent the follow-up tiers simply stay on the caller's stream, in front of the voting kernel.
-  h->probed_tier = false;
-  if (ok) {
-    for (int attempt = 0; attempt <= 4; ++attempt) {
-      HIP_TRY(h, spin_pair_ms(h->stream, h->tier_stream, ms));
-      if (ms < 1.6) {
-        h->probed_tier = true;
-        break;
-      }
-      if (attempt == 4) break;
-      rejected.push_back(h->tier_stream);
-      h->tier_stream = nullptr;
-      HIP_TRY(h, hipStreamCreateWithFlags(&h->tier_stream, hipStreamNonBlocking));
     }
   }
   for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
@@ -715,17 +692,9 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       // streaming: the tail of the PREVIOUS submission has read the detections / histograms of this region
       if (tail_was_pending) HIP_TRY(h, hipStreamWaitEvent(st, h->tail_sub_done[std::min(s, tail_was_last)], 0));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], st));
-      // the follow-up tiers of the blob extraction (frames that overflow the first tier: none, or a handful) on their
-      // own stream beside the voting kernel, whose blocks wait for such a frame's record (k2_wait_detections)
-      const bool tiers_aside = side_tail && h->probed_tier && sp->vote_arith != 0;
-      if (tiers_aside && !h->tier_first[s]) {
-        HIP_TRY(h, hipEventCreateWithFlags(&h->tier_first[s], hipEventDisableTiming));
-        HIP_TRY(h, hipEventCreateWithFlags(&h->tier_done[s], hipEventDisableTiming));
-      }
       HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
                                   static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
-                                  static_cast<uint8_t*>(h->scratch.p), sp->n_markers, st, nullptr, true,
-                                  tiers_aside ? h->tier_stream : nullptr, h->tier_first[s], h->tier_done[s]));
+                                  static_cast<uint8_t*>(h->scratch.p), sp->n_markers, st, nullptr, true));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], st));
       uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
       // (with one voting block per frame the kernel stores every histogram row the tail reads: no memset)
@@ -745,7 +714,6 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
                                 auto_splits(h, nf, sp->n_markers), sp->n_markers, st, nbytes ? nfr + P : nullptr,
                                 nbytes - P, nbytes ? nfl + P / 1024 : nullptr, dp.thr, &scanned));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], st));
-      if (tiers_aside) HIP_TRY(h, hipStreamWaitEvent(st, h->tier_done[s], 0));  // (long finished: they ran beside the vote)
       if (scanned > h->last_rider_bytes) h->last_rider_bytes = scanned;
       if (nbytes > 0) {  // what the riders left over: less than one chunk, or everything if they could not run
         const bool real_next = s + 1 < n_real;
@@ -999,14 +967,7 @@ void mpe_destroy(mpe_handle* h) {
   for (auto& e : h->tail_sub_done)
     if (e) (void)hipEventDestroy(e);
   if (h->prefetch_side_done) (void)hipEventDestroy(h->prefetch_side_done);
-  for (auto& e : h->tier_first)
-    if (e) (void)hipEventDestroy(e);
-  for (auto& e : h->tier_done)
-    if (e) (void)hipEventDestroy(e);
-  if (h->tier_stream) {
-    (void)hipStreamSynchronize(h->tier_stream);
-    (void)hipStreamDestroy(h->tier_stream);
-  }
+
   if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
   if (h->scan_stream) (void)hipStreamDestroy(h->scan_stream);
   for (auto& e : h->scanpart_done)

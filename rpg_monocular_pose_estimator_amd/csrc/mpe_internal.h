@@ -58,8 +58,6 @@ struct SolveParams {
 };
 
 #define MPE_HIST_STRIDE (MPE_MAX_DETECTIONS * MPE_MAX_MARKERS)
-// mpe_detections.n while a frame waits for a follow-up tier of the blob extraction (device-internal, never handed out)
-#define MPE_DETS_PENDING (-1)
 
 // launchers (mpe_kernels.hip)
 size_t k1b_scratch_bytes(const FrameGeom& g);
@@ -68,8 +66,7 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
                             int blob_hint, hipStream_t s, const void* frame_windows = nullptr,
-                            bool lists_zeroed = false, hipStream_t follow = nullptr, hipEvent_t first_done = nullptr,
-                            hipEvent_t follow_done = nullptr);
+                            bool lists_zeroed = false);
 // worklist: 2 * (n_frames + 1) ints (two device work-lists that chain the capacity tiers); lists_zeroed = the caller
 // has zeroed it in stream order already (one memset for all the sub-batches of a call) and no memset is issued here.
 // frame_windows: optional device array of n_frames x {rows, cols, roi_x, roi_y} ints — every frame then is a window

@@ -629,17 +629,13 @@ __device__ __forceinline__ void write_detections(const float* kx, const float* k
       out->undist_xy[2 * pos + 1] = (double)uy;
     }
   }
-  // The count is the record's "ready" flag for a voting block that may already be waiting for this frame (the
-  // follow-up tiers run beside the voting kernel in the fused schedule): everything else first, made visible at
-  // agent scope by the whole wave, then the count.
   if (lane == 0) {
+    out->n = min(nk_all, MPE_MAX_DETECTIONS);
     int st = 0;
     if (nk_all > MPE_MAX_DETECTIONS) st = MPE_FRAME_TOO_MANY_DETECTIONS;
     if (over) st = MPE_FRAME_TOO_MANY_ROWS;
     out->status = st;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  if (lane == 0) __hip_atomic_store(&out->n, min(nk_all, MPE_MAX_DETECTIONS), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // =============================================================================================
@@ -942,7 +938,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   }
   if (fallback) {  // hand the frame to the general kernel
     if (lane == 0) {
-      out->n = worklist ? MPE_DETS_PENDING : 0;  // (pending: a later tier writes the record, see k2_wait_detections)
+      out->n = 0;
       out->status = MPE_FRAME_TOO_MANY_ROWS;  // overwritten by the general kernel
       if (worklist) {
         const int k = atomicAdd(&worklist[0], 1);
@@ -1005,7 +1001,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
 
 // hand a frame to the next tier
 __device__ __forceinline__ void k1b_hand_over(int f, mpe_detections* __restrict__ dets, int* __restrict__ worklist) {
-  dets[f].n = worklist ? MPE_DETS_PENDING : 0;
+  dets[f].n = 0;
   dets[f].status = MPE_FRAME_TOO_MANY_ROWS;  // overwritten by the next tier
   if (worklist) {
     const int k = atomicAdd(&worklist[0], 1);
@@ -1231,17 +1227,15 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
 #define K1B_GEN_BLOCKS 32
 size_t k1b_scratch_bytes(const FrameGeom& g) { return k1b_gen_scratch_bytes(g) * K1B_GEN_BLOCKS; }
 
-// Three tiers, chained through device work-lists (no host round trip):
-//   small LDS pools (4 waves / SIMD) -> large LDS pools -> whole-frame window in global scratch.
-// The FIRST tier sees every frame; the follow-up tiers only the frames it handed over (normally none or a handful,
-// their records marked MPE_DETS_PENDING meanwhile).  `follow` != nullptr: the follow-up tiers go to that stream, after
-// `first_done` (recorded here on `s`), so that a consumer on `s` which knows how to wait for pending records — the
-// voting kernel — need not sit behind their one-wave-per-frame latency; `follow_done` is recorded behind them.
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
-                            int blob_hint, hipStream_t s, const void* frame_windows, bool lists_zeroed,
-                            hipStream_t follow, hipEvent_t first_done, hipEvent_t follow_done) {
+                            int blob_hint, hipStream_t s, const void* frame_windows, bool lists_zeroed) {
   const FrameWin* wins = static_cast<const FrameWin*>(frame_windows);
+  // Three tiers, chained through device work-lists (no host round trip):
+  //   small LDS pools (4 waves/SIMD) -> large LDS pools -> whole-frame window in global scratch
+  // (Running the follow-up tiers on a side stream beside the voting kernel, whose blocks then waited for the few
+  //  frames those tiers finish, was built and measured in round 3: the agent-scope release every blob wave needs for
+  //  that hand-over — an L2 write-back — took the blob kernel from 0.34 to 2.0 ms per sub-batch.  Removed.)
   if (n_frames <= 0) return hipSuccess;
   int* list_a = worklist;                   // small -> large
   int* list_b = worklist + (n_frames + 1);  // large -> general
@@ -1250,34 +1244,22 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
     e = hipMemsetAsync(list_a, 0, (size_t)(n_frames + 2) * sizeof(int), s);
     if (e != hipSuccess) return e;
   }
-  const bool small_first = blob_hint > 0 && blob_hint <= 8;
-  if (small_first) {  // (the small tier is cheap to try: frames that overflow it go on to the large one)
+  if (blob_hint > 0 && blob_hint <= 8) {  // (the small tier is cheap to try: frames that overflow it go on to the large one)
     const int blocks = (n_frames + K1bSmall::WAVES - 1) / K1bSmall::WAVES;
     hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64 * K1bSmall::WAVES), 0, s, frames, (const u64*)flags, g, dp, dets,
                        list_a, n_frames, wins);
+    const int grid = n_frames < 2048 ? n_frames : 2048;
+    hipLaunchKernelGGL((k1b_blobs_list<K1bLarge>), dim3(grid), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
+                       dets, (const int*)list_a, list_b, wins);
   } else {
     hipLaunchKernelGGL((k1b_blobs<K1bLarge>), dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
                        dets, list_b, n_frames, wins);
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipStream_t fs = s;
-  if (follow) {
-    if ((e = hipEventRecord(first_done, s)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(follow, first_done, 0)) != hipSuccess) return e;
-    fs = follow;
-  }
-  if (small_first) {
-    const int grid = n_frames < 2048 ? n_frames : 2048;
-    hipLaunchKernelGGL((k1b_blobs_list<K1bLarge>), dim3(grid), dim3(64), 0, fs, frames, (const u64*)flags, g, dp,
-                       dets, (const int*)list_a, list_b, wins);
-  }
-  hipLaunchKernelGGL(k1b_general, dim3(K1B_GEN_BLOCKS), dim3(64), 0, fs, frames, (const u64*)flags, g, dp, dets,
+  hipLaunchKernelGGL(k1b_general, dim3(K1B_GEN_BLOCKS), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
                      (const int*)list_b, scratch, wins);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  if (follow) e = hipEventRecord(follow_done, follow);
-  return e;
+  return hipGetLastError();
 }
 
 // =============================================================================================
@@ -1921,24 +1903,6 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
   }
 }
 
-// A frame that overflowed the small tier of the blob extraction is finished by the follow-up tiers; in the fused
-// schedule those run on a side stream BESIDE the voting kernel (a handful of frames: one wave each, 60 us of latency
-// that used to sit on the critical path of every sub-batch), and the voting block of such a frame waits here until the
-// record is there: the count is the flag (MPE_DETS_PENDING until write_detections' release store).  Bounded: a
-// follow-up kernel that never comes leaves the frame without detections instead of hanging the GPU (its record then
-// keeps the pending count, which the tail kernel reports as MPE_FRAME_TOO_MANY_ROWS).
-__device__ __forceinline__ void k2_wait_detections(const mpe_detections* d, unsigned* lds_flag) {
-  if (threadIdx.x == 0) {
-    int n = __hip_atomic_load(&d->n, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    for (int it = 0; n == MPE_DETS_PENDING && it < (1 << 21); ++it) {  // (~2 us per probe: seconds in all)
-      __builtin_amdgcn_s_sleep(64);
-      n = __hip_atomic_load(&d->n, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    lds_flag[0] = 0;  // (any LDS word: the barrier below is what the other lanes wait at)
-  }
-  __syncthreads();
-}
-
 // Voting kernel.  Work item = (detection triple, marker permutation).  Everything that depends
 // only on the detection triple (tau frame T, f_1, f_2, b and the swap of p3p.cpp:100-121) is
 // computed once per triple into LDS; everything that depends only on the marker permutation comes
@@ -1971,8 +1935,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   const int tid = threadIdx.x;
   const int nthr = blockDim.x;
   const mpe_detections* d = dets + f;
-  k2_wait_detections(d, s_hist);
-  const int n_d = max(d->n, 0), n_m = sp.n_markers;
+  const int n_d = d->n, n_m = sp.n_markers;
   typename std::conditional<SCAN, ScanRider, NoRider>::type rider;
   if constexpr (SCAN) rider.init(scan, smem);  // (this variant keeps the back-projections in registers)
   if (n_d < 4 || d->status != 0 || n_m < 4) {  // min_num_leds_detected_ (pose_estimator.h:78)
@@ -2563,7 +2526,7 @@ __global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restr
   const bool live = f < n_frames;
   const mpe_detections* d = dets + (live ? f : 0);
   mpe_result* res = results + (live ? f : 0);
-  const int n_d = live ? max(d->n, 0) : 0, n_m = sp.n_markers;  // (a count still pending = a follow-up tier never ran)
+  const int n_d = live ? d->n : 0, n_m = sp.n_markers;
   const int dstatus = live ? d->status : 0;
   const uint32_t* H = hist + (size_t)(live ? f : 0) * MPE_HIST_STRIDE;
   const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
