@@ -278,6 +278,12 @@ def main():
         if int(kms[-1]["launches"]) > 1:
             subs.append([h.last_kernel_ms_sub(i) for i in range(int(kms[-1]["launches"]))])
     h.set_profiling(False)
+    # frames of one step that the first tier of the blob extraction handed on, by the capacity they exceeded
+    overflow = None
+    if int(kms[0]["launches"]) > 1:
+        overflow = {k: h.get_option("overflow_" + k) for k in ("frames", "general", "why_1", "why_2", "why_3", "why_4",
+                                                               "why_5", "why_6")}
+        overflow["why"] = "1 bright segments, 2 bands, 3 islands, 4 pixel pool, 5 bitmap pool, 6 blobs kept"
     schedule = h.get_option("last_schedule") if int(kms[0]["launches"]) > 1 else 0
     kavg = {k: float(np.mean([m[k] for m in kms])) for k in kms[0]}
     launches, fpl = int(kms[0]["launches"]), int(kms[0]["frames_per_launch"])
@@ -410,6 +416,7 @@ def main():
                        "entry": ("mpe_estimate_batch_device_submit / _collect: a stream of batches, each announcing the "
                                  "next one's frames" if streaming else "mpe_estimate_batch_device, one joined call per step"),
                        "records_to_host": bool(args.records_to_host),
+                       "blob_tier_overflow": overflow,
                        "parallelism": "frames sharded over %d GPU(s), pose records gathered to rank 0 (async, double-buffered)" % world},
             "poses_found_frac": n_pose / B,
             # every pixel of the batch is read once per step: the whole-step HBM rate against the 8 TB/s spec

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -100,6 +101,7 @@ struct mpe_handle {
   } prefetch;
   hipEvent_t prefetch_side_done = nullptr;
   bool done_recorded = false;  // run_pipeline has recorded batch_done[submit_seq & 1] itself (fused schedules)
+  int last_nsub = 0, last_per = 0;  // work-list layout of the last pipelined batch (option "overflow_*")
   // side streams of schedules 4 / 6 verified (spin probe) to execute beside the caller's stream
   int side_streams_ok = -1;           // 1 yes, 0 no concurrent set found (-> schedule 3), -1 not probed
   hipStream_t probed_for = nullptr;   // the caller's stream the verdict holds for
@@ -598,6 +600,8 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       return split_scan ? (nbytes * (size_t)h->scan_split_pct / 100) / 8192 * 8192 : 0;
     };
     h->last_rider_bytes = 0;
+    h->last_nsub = nsub;
+    h->last_per = per;
     if (side_tail) {
       if (!h->tail_done) HIP_TRY(h, hipEventCreateWithFlags(&h->tail_done, hipEventDisableTiming));
       if (!h->vote_done[0])
@@ -1060,6 +1064,31 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "k1a_dummy_lds") *value = h->k1a_dummy_lds;
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
+  else if (n.rfind("overflow_", 0) == 0) {
+    // statistics of the last large batch (synchronises): frames the first blob tier handed on, in all
+    // ("overflow_frames") or by the capacity that was exceeded ("overflow_why_1" .. 6: bright segments, bands,
+    // islands, pixel pool, bitmap pool, blobs kept); "overflow_general": frames that went on to the general tier
+    if (h->last_nsub <= 0 || !h->work.p) return fail(h, MPE_ERR_ARG, "no pipelined batch has run");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t region = (size_t)2 * (h->last_per + 1);
+    std::vector<int> w(region * (size_t)h->last_nsub);
+    HIP_TRY(h, hipMemcpy(w.data(), h->work.p, w.size() * sizeof(int), hipMemcpyDeviceToHost));
+    const int why = n.rfind("overflow_why_", 0) == 0 ? std::atoi(n.c_str() + 13) : 0;
+    long long cnt = 0;
+    for (int s = 0; s < h->last_nsub; ++s) {
+      const int* la = w.data() + region * (size_t)s;
+      const int* lb = la + (h->last_per + 1);
+      if (n == "overflow_general") {
+        cnt += lb[0];
+      } else if (why == 0) {
+        cnt += la[0];
+      } else {
+        for (int k = 0; k < la[0] && k < h->last_per; ++k) cnt += ((la[1 + k] >> 24) & 0xFF) == why;
+      }
+    }
+    *value = (int)std::min<long long>(cnt, 0x7fffffff);
+  }
   else return fail(h, MPE_ERR_ARG, "unknown option");
   return MPE_OK;
 }

@@ -806,6 +806,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
     return false;
   }
   bool fallback = nseg > C::SEG;
+  int why = fallback ? 1 : 0;  // which capacity sent the frame on (kept in the top byte of its work-list entry: statistics)
 
   // ---- B1: bands = maximal runs of active rows.  Lane w owns word w of the row bitset: band starts
   //      / ends are bit tricks, their ranks a wave prefix sum (starts and ends pair up in order).
@@ -845,6 +846,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   wave_sync();
   const int nband = s_nband;
   fallback = fallback || nband > C::BAND;
+  if (fallback && !why) why = 2;
 
   // ---- B2: segment-column occupancy per band
   if (!fallback) {
@@ -901,6 +903,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   wave_sync();
   const int nisl = s_nisl;
   fallback = fallback || nisl > C::ISL;
+  if (fallback && !why) why = 3;
 
   // ---- B4: pool offsets and work-item prefix sums (lane i owns island i; nisl <= 32)
   if (!fallback) {
@@ -935,6 +938,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
     }
     const int tot_pix = __shfl(ip, nisl - 1), tot_bm = __shfl(ib, nisl - 1);
     fallback = tot_pix > C::PIX || tot_bm > C::BM;
+    if (fallback) why = tot_pix > C::PIX ? 4 : 5;
   }
   if (fallback) {  // hand the frame to the general kernel
     if (lane == 0) {
@@ -942,7 +946,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
       out->status = MPE_FRAME_TOO_MANY_ROWS;  // overwritten by the general kernel
       if (worklist) {
         const int k = atomicAdd(&worklist[0], 1);
-        worklist[1 + k] = f;
+        worklist[1 + k] = f | (why << 24);
       }
     }
     return false;
@@ -1005,7 +1009,7 @@ __device__ __forceinline__ void k1b_hand_over(int f, mpe_detections* __restrict_
   dets[f].status = MPE_FRAME_TOO_MANY_ROWS;  // overwritten by the next tier
   if (worklist) {
     const int k = atomicAdd(&worklist[0], 1);
-    worklist[1 + k] = f;
+    worklist[1 + k] = f | (6 << 24);  // (more blobs kept than the tier records)
   }
 }
 
@@ -1098,7 +1102,7 @@ __global__ __launch_bounds__(64 * C::WAVES, C::MIN_WAVES) void k1b_blobs_list(co
   const int count = in_list[0];
   for (int b0 = blockIdx.x * C::WAVES; b0 < count; b0 += gridDim.x * C::WAVES) {  // (uniform over the block)
     const int w0 = b0 + (int)(threadIdx.x >> 6);
-    k1b_wave<C>(w0 < count ? in_list[1 + w0] : 0, w0 < count, frames, flags, g, dp, dets, worklist, wins);
+    k1b_wave<C>(w0 < count ? (in_list[1 + w0] & 0xFFFFFF) : 0, w0 < count, frames, flags, g, dp, dets, worklist, wins);
   }
 }
 
@@ -1145,7 +1149,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
   const unsigned add = (unsigned)(255 - dp.thr) * 0x00010001u;
 
   for (int wi = blockIdx.x; wi < count; wi += gridDim.x) {
-    const int f = worklist[1 + wi];
+    const int f = worklist[1 + wi] & 0xFFFFFF;
     const uint8_t* frame = frames + (size_t)f * g.rows * g.pitch;
     int roi_x, roi_y;
     const FrameGeom gl = window_geom(gslot, wins, f, dp, roi_x, roi_y);
