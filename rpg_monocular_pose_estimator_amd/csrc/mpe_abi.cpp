@@ -56,6 +56,8 @@ struct mpe_handle {
   int vote_splits = 0;         // 0 = auto
   int vote_arith = 1;          // 1 = fast voting arithmetic (default), 0 = strict: IEEE operators, the validation
                                //     kernel's P3P (same quartic in K2 and K3)
+  int refine_variant = 0;      // refinement kernel: 0 automatic (16 lanes per frame up to 2048 frames per launch, else one
+                               // lane per frame), 1 / 2 force one of them; bit-identical results
   int k1a_dummy_lds = -1;      // tuning: dummy LDS per scan block in the two-stream schedule (-1 = automatic)
   int last_schedule = 0;       // schedule the last large batch actually ran with
   int pipeline_mode = -1;      // -1 automatic; 0 two-stream staggered pipeline, 3 fused single stream (scan rides in the voting
@@ -78,7 +80,7 @@ struct mpe_handle {
   hipStream_t scan_stream = nullptr;  // mode 6: part of the next-but-one sub-batch's scan beside blobs / tail
   hipEvent_t scanpart_done[kMaxSub] = {};
   int side_scan_blocks = 2;           // mode 6: resident blocks per CU of the side scan (4 waves each)
-  int scan_split_pct = 30;            // mode 6: share of a sub-batch scanned by the stand-alone kernel on the side stream
+  int scan_split_pct = 25;            // mode 6: share of a sub-batch scanned by the stand-alone kernel on the side stream
   unsigned long long last_rider_bytes = 0;  // bytes one fused voting launch scanned in the last large call
   hipStream_t tail_stream = nullptr;  // fused schedule, mode 4: validate + refine of sub-batch s beside blobs(s + 1)
   hipEvent_t tail_done = nullptr;
@@ -223,6 +225,7 @@ int make_solve_params(const mpe_handle* h, const mpe_params* p, const double* ma
   sp.valid_corr_thr = p->valid_correspondence_threshold;
   sp.hist_thr = p->histogram_threshold ? p->histogram_threshold : num_combinations_u32((unsigned)n_markers, 3);
   sp.vote_arith = h->vote_arith;
+  sp.refine_variant = h->refine_variant;
   return 0;
 }
 
@@ -407,10 +410,14 @@ int pick_concurrent_streams(mpe_handle* h) {
 }
 
 // how a large batch is cut into sub-batches (shared by a call and by the previous call that prefetches for it)
-void sub_batch_shape(const mpe_handle* h, int n_frames, bool have_sp, int vote_arith, int& nsub, int& per) {
+void sub_batch_shape(const mpe_handle* h, int n_frames, size_t frame_bytes, bool have_sp, int vote_arith, int& nsub,
+                     int& per) {
   // sub-batches of about 16384 frames (measured sweet spot at 752x480: 8192 and 32768 are 3-5 % slower), never
   // below 8192 (tail effects then cost more than the overlap gains)
-  nsub = n_frames / 16384;
+  // (with the streaming entry, whose calls have no un-overlapped ends, 32768 frames per sub-batch measured 3 % faster
+  //  than 16384 at 752x480 — half as many kernel boundaries; 65536: 1 % slower again)
+  nsub = frame_bytes <= (size_t)512 * 1024 ? n_frames / 32768 : 0;
+  if (nsub < 2) nsub = n_frames / 16384;
   if (nsub < 2) nsub = n_frames / 8192;
   if (nsub > h->pipeline) nsub = h->pipeline;
   if (nsub > mpe_handle::kMaxSub) nsub = mpe_handle::kMaxSub;
@@ -520,7 +527,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     HIP_TRY(h, launch_k2_prep(*sp, static_cast<double*>(h->mtab.p), h->stream));
   }
   int nsub, per;
-  sub_batch_shape(h, n_frames, sp != nullptr, sp ? sp->vote_arith : 1, nsub, per);
+  sub_batch_shape(h, n_frames, frame_bytes, sp != nullptr, sp ? sp->vote_arith : 1, nsub, per);
   h->have_ms = false;
   // a streaming submission may still have validate / refine kernels on the tail stream that read the detection and
   // histogram buffers this call is about to overwrite: the fused schedules order themselves region by region, every
@@ -626,7 +633,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     int next_per = 0;
     if (hint && hint->next_frames && hint->n_next > 0) {
       int nn, np;
-      sub_batch_shape(h, hint->n_next, true, sp->vote_arith, nn, np);
+      sub_batch_shape(h, hint->n_next, frame_bytes, true, sp->vote_arith, nn, np);
       if (nn > 1 && flag_words(frame_bytes * std::min(np, hint->n_next)) <= fw_per) next_per = std::min(np, hint->n_next);
     }
     // region index of a sub-batch's flag words: 0 .. nsub-1, nsub = the extra region (prefetch target / source)
@@ -1057,6 +1064,7 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "lds_budget") *value = h->lds_budget;
   else if (n == "vote_splits") *value = h->vote_splits;
   else if (n == "vote_arith") *value = h->vote_arith;
+  else if (n == "refine_variant") *value = h->refine_variant;
   else if (n == "ingest_chunk") *value = h->ingest_chunk;
   else if (n == "scan_split_pct") *value = h->scan_split_pct;
   else if (n == "side_scan_blocks") *value = h->side_scan_blocks;
@@ -1132,6 +1140,11 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   if (!std::strcmp(name, "ingest_chunk")) {
     if (value < 0) return fail(h, MPE_ERR_ARG, "ingest_chunk must be >= 0");
     h->ingest_chunk = value;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "refine_variant")) {
+    if (value < 0 || value > 2) return fail(h, MPE_ERR_ARG, "refine_variant must be 0 (automatic), 1 (lane) or 2 (group)");
+    h->refine_variant = value;
     return MPE_OK;
   }
   if (!std::strcmp(name, "vote_arith")) {

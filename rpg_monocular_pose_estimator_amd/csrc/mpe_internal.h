@@ -55,6 +55,7 @@ struct SolveParams {
   double valid_corr_thr;  // valid_correspondence_threshold_
   unsigned hist_thr;      // histogram_threshold_
   int vote_arith;         // option "vote_arith": 1 fast voting arithmetic (default), 0 strict (IEEE, literal order)
+  int refine_variant;     // option "refine_variant": 0 automatic, 1 one lane per frame, 2 sixteen lanes per frame
 };
 
 #define MPE_HIST_STRIDE (MPE_MAX_DETECTIONS * MPE_MAX_MARKERS)

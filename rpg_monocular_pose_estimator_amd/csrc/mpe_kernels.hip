@@ -2869,10 +2869,284 @@ __global__ __launch_bounds__(K3B_THREADS) void k3b_refine(const mpe_detections* 
 #undef ROW
 }
 
+// ---------------------------------------------------------------------------------------------
+// K3b for SMALL launches (tracked frames, a handful of streams in lock step): the same computeTransformation +
+// optimisePose with 16 LANES PER FRAME.  One lane per frame (k3b_refine) is the right shape for 16 384 frames, but a
+// single tracked frame then waits for ~18 000 dependent FP64 instructions of one lane (54 us).  Here a Gauss-Newton
+// iteration is spread over the group: lane j computes the Jacobian rows of correspondence j, 27 lanes-slots sum the
+// 21 + 6 entries of A = sum J^T J and b = sum J^T e over the correspondences IN ROW ORDER (the reference's summation
+// order, as in the one-lane kernel), the LDL^T factorisation runs column by column with the five divisions of a column
+// on five lanes, the 3x3 matrices of the exponential map one entry per lane.  Every scalar is computed by the same
+// sequence of operations as in k3b_refine, so the two kernels return bit-identical poses, covariances and iteration
+// counts (tested).  Groups of a wave converge at different iterations; a finished group idles through the others'
+// synchronisation points.
+// ---------------------------------------------------------------------------------------------
+#define K3G_LANES 16
+#define K3G_FRAMES 4
+struct GnGroupLds {
+  double J[MPE_MAX_MARKERS][14];  // per correspondence row: J0[6], J1[6], e0, e1
+  double Ab[27];                  // upper triangle of A (21, row-major) then b (6)
+  double L[6][6];
+  double D[6];
+  double O[9], O2[9], Rm[9], Vm[9];
+  double T[12];
+};
+// index of A[r][c], r <= c, in the packed upper triangle
+__device__ __forceinline__ int k3g_tri(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k3b_refine_group(const mpe_detections* __restrict__ dets, int n_frames, SolveParams sp,
+                                                       mpe_result* __restrict__ results, const TailMid* __restrict__ mid,
+                                                       int row_cap) {
+  __shared__ GnGroupLds s_g[K3G_FRAMES];
+  const int tid = threadIdx.x;
+  const int grp = tid >> 4, l = tid & 15;
+  GnGroupLds& G = s_g[grp];
+  const int f = blockIdx.x * K3G_FRAMES + grp;
+  const bool in_range = f < n_frames;
+  const TailMid* m = mid + (in_range ? f : 0);
+  const bool live = in_range && m->active;
+  const mpe_detections* d = dets + (in_range ? f : 0);
+  mpe_result* res = results + (in_range ? f : 0);
+  const int n_m = sp.n_markers;
+  const int n_c = live ? min(m->n_c, row_cap) : 0;
+  const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
+  // this lane's correspondence row
+  double mk[3] = {0, 0, 0}, du = 0, dv = 0;
+  if (l < n_c) {
+    const int mi = m->cm[l] - 1, di = m->cd[l] - 1;
+    mk[0] = sp.markers[3 * mi];
+    mk[1] = sp.markers[3 * mi + 1];
+    mk[2] = sp.markers[3 * mi + 2];
+    du = d->undist_xy[2 * di];
+    dv = d->undist_xy[2 * di + 1];
+  }
+  // ---- start pose: computeTransformation (pose_estimator.cpp:908-930) by lane 0, or the given pose (MODE 2)
+  if (live && l == 0) {
+    T34 T0;
+    if (MODE == 2) {
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) T0.m[r][c] = res->T[r * 4 + c];
+    } else {
+      const double nv = (double)m->num_valid;
+      double mo[3] = {0, 0, 0}, mr[3] = {0, 0, 0};
+      for (int i = 0; i < n_m; ++i)
+        for (int k = 0; k < 3; ++k) {
+          mo[k] += sp.markers[3 * i + k];
+          mr[k] += m->mean[3 * i + k] / nv;
+        }
+      for (int k = 0; k < 3; ++k) {
+        mo[k] /= (double)n_m;
+        mr[k] /= (double)n_m;
+      }
+      double Hm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      for (int i = 0; i < n_m; ++i) {
+        const double a[3] = {sp.markers[3 * i] - mo[0], sp.markers[3 * i + 1] - mo[1], sp.markers[3 * i + 2] - mo[2]};
+        const double b[3] = {m->mean[3 * i] / nv - mr[0], m->mean[3 * i + 1] / nv - mr[1], m->mean[3 * i + 2] / nv - mr[2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Hm[r][c] += a[r] * b[c];
+      }
+      double X[3][3];
+      kabsch_rotation(Hm, X);  // R = V U^T
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) T0.m[r][c] = X[r][c];
+        T0.m[r][3] = mr[r] - (X[r][0] * mo[0] + X[r][1] * mo[1] + X[r][2] * mo[2]);
+      }
+    }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) G.T[r * 4 + c] = T0.m[r][c];
+  }
+  wave_sync();
+  T34 T;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) T.m[r][c] = live ? G.T[r * 4 + c] : ((r == c) ? 1.0 : 0.0);
+
+  // ---- optimisePose (pose_estimator.cpp:733-792)
+  bool done = !live || MODE == 1;
+  int iters = 0;
+  for (int it = 0; it < 500; ++it) {
+    if (__builtin_amdgcn_ballot_w64(!done) == 0) break;  // every group of the wave has converged
+    // (a) Jacobian rows, computeJacobian (pose_estimator.cpp:945-957): lane j <- correspondence j
+    if (!done && l < n_c) {
+      double u, v, x, y, z;
+      project_T(T, mk, fx, fy, cx, cy, u, v, x, y, z);
+      const double e0 = du - u, e1 = dv - v;
+      const double z_2 = z * z;
+      double* Jr = G.J[l];
+      Jr[0] = 1 / z * fx;
+      Jr[1] = 0;
+      Jr[2] = -x / z_2 * fx;
+      Jr[3] = -x * y / z_2 * fx;
+      Jr[4] = (1 + (x * x / z_2)) * fx;
+      Jr[5] = -y / z * fx;
+      Jr[6] = 0;
+      Jr[7] = 1 / z * fy;
+      Jr[8] = -y / z_2 * fy;
+      Jr[9] = -(1 + y * y / z_2) * fy;
+      Jr[10] = x * y / z_2 * fy;
+      Jr[11] = x / z * fy;
+      Jr[12] = e0;
+      Jr[13] = e1;
+    }
+    wave_sync();
+    // (b) A = sum J^T J (upper triangle), b = sum J^T e, each entry summed over the rows in row order
+    if (!done) {
+      for (int q = l; q < 27; q += K3G_LANES) {
+        double acc = 0;
+        if (q < 21) {
+          int r = 0, base = 0;
+          while (q >= base + (6 - r)) {
+            base += 6 - r;
+            ++r;
+          }
+          const int c = r + (q - base);
+          for (int j = 0; j < n_c; ++j) acc += G.J[j][r] * G.J[j][c] + G.J[j][6 + r] * G.J[j][6 + c];
+        } else {
+          const int r = q - 21;
+          for (int j = 0; j < n_c; ++j) acc += G.J[j][r] * G.J[j][12] + G.J[j][6 + r] * G.J[j][13];
+        }
+        G.Ab[q] = acc;
+      }
+    }
+    wave_sync();
+    // (c) unpivoted LDL^T (ldl6_factor), column by column: lane j the pivot, lanes j+1..5 the column's divisions
+    double Lrow[6] = {0, 0, 0, 0, 0, 0};  // row l of L (lanes 0..5)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if (!done && l == j) {
+        double dd = G.Ab[k3g_tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; ++k) dd -= Lrow[k] * Lrow[k] * G.D[k];
+        G.D[j] = dd;
+      }
+      wave_sync();
+      if (!done && l > j && l < 6) {
+        double sacc = G.Ab[k3g_tri(j, l)];  // A[l][j] = A[j][l]
+#pragma unroll
+        for (int k = 0; k < j; ++k) sacc -= Lrow[k] * G.L[j][k] * G.D[k];
+        Lrow[j] = sacc / G.D[j];
+        G.L[l][j] = Lrow[j];
+      }
+      wave_sync();
+    }
+    // (d) ldl6_solve, every lane for itself (a chain of 36 dependent operations: nothing to spread)
+    double dT[6] = {0, 0, 0, 0, 0, 0};
+    if (!done) {
+      double yv[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        double sacc = G.Ab[21 + i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) sacc -= G.L[i][k] * yv[k];
+        yv[i] = sacc;
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) yv[i] /= G.D[i];
+#pragma unroll
+      for (int i = 5; i >= 0; --i) {
+        double sacc = yv[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) sacc -= G.L[k][i] * dT[k];
+        dT[i] = sacc;
+      }
+    }
+    // (e) exponentialMap(dT) * T (apply_exp), the 3x3 matrices one entry per lane
+    const double ux = dT[0], uy = dT[1], uz = dT[2], wx = dT[3], wy = dT[4], wz = dT[5];
+    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+    const double th2 = theta * theta;
+    if (!done && l < 9) {
+      const double Ov[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+      double o = Ov[0];
+#pragma unroll
+      for (int q = 1; q < 9; ++q) o = (l == q) ? Ov[q] : o;
+      G.O[l] = o;
+    }
+    wave_sync();
+    if (!done && l < 9) {
+      const int i = l / 3, j = l - 3 * i;
+      const double o2 = G.O[3 * i] * G.O[j] + G.O[3 * i + 1] * G.O[3 + j] + G.O[3 * i + 2] * G.O[6 + j];
+      const double o = G.O[l];
+      const double I = (i == j) ? 1.0 : 0.0;
+      double rm = I, vm = I;
+      if (theta != 0) {
+        double st, ct;
+        sincos(theta, &st, &ct);
+        rm = I + o / theta * st + o2 / th2 * (1 - ct);
+        vm = I + (1 - ct) / th2 * o + (theta - st) / (th2 * theta) * o2;
+      }
+      G.Rm[l] = rm;
+      G.Vm[l] = vm;
+    }
+    wave_sync();
+    double nvv = 0;
+    if (!done && l < 12) {
+      const int i = l >> 2, j = l & 3;
+      double sacc = G.Rm[3 * i] * G.T[j] + G.Rm[3 * i + 1] * G.T[4 + j] + G.Rm[3 * i + 2] * G.T[8 + j];
+      if (j == 3) sacc += G.Vm[3 * i] * ux + G.Vm[3 * i + 1] * uy + G.Vm[3 * i + 2] * uz;
+      nvv = sacc;
+    }
+    wave_sync();  // (every read of the old pose is done)
+    if (!done && l < 12) G.T[l] = nvv;
+    wave_sync();
+    if (!done) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) T.m[r][c] = G.T[r * 4 + c];
+      iters = it + 1;
+      double mx = -1;  // norm_max, pose_estimator.cpp:1073-1085
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double av = fabs(dT[r]);
+        if (av > mx) mx = av;
+      }
+      if (mx <= 1e-13) done = true;
+    }
+  }
+  if (!live) return;
+  // pose_covariance_ = A.inverse() with the A of the last iteration (pose_estimator.cpp:790): its factors are still in
+  // G.L / G.D; column c of the inverse on lane c
+  if (MODE != 1 && l < 6) {
+    double yv[6], xv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double sacc = (i == l) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) sacc -= G.L[i][k] * yv[k];
+      yv[i] = sacc;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) yv[i] /= G.D[i];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+      double sacc = yv[i];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) sacc -= G.L[k][i] * xv[k];
+      xv[i] = sacc;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) res->cov[r * 6 + l] = xv[r];
+  }
+  if (l < 12) res->T[l] = G.T[l];  // (the group's latest pose)
+  if (l == 0) {
+    res->T[12] = 0.0;
+    res->T[13] = 0.0;
+    res->T[14] = 0.0;
+    res->T[15] = 1.0;
+    res->gn_iterations = iters;
+    res->status = MPE_FRAME_POSE;
+  }
+}
+
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
                           mpe_result* results, uint32_t* corr_out, const uint32_t* corr_in, const double* nn_pred,
                           double nn_tol, void* mid_buf, hipStream_t s, int mode) {
   if (n_frames <= 0) return hipSuccess;
+  const int refine_variant = sp.refine_variant;
   TailMid* mid = static_cast<TailMid*>(mid_buf);
   // explicit correspondences (corr_in) may hold up to MPE_MAX_MARKERS rows, also more than n_markers (repeated
   // markers are defined input for checkCorrespondences): size the row buffers for the row capacity
@@ -2882,12 +3156,21 @@ hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int 
   const size_t lds_b = (size_t)rows * 5 * K3B_THREADS * sizeof(double);
   const dim3 grid_a((n_frames + K3_FRAMES_PER_BLOCK - 1) / K3_FRAMES_PER_BLOCK);
   const dim3 grid_b((n_frames + K3B_THREADS - 1) / K3B_THREADS);
+  const dim3 grid_g((n_frames + K3G_FRAMES - 1) / K3G_FRAMES);
+  // refinement: 16 lanes per frame while the launch is too small to fill the chip with one lane per frame (a tracked
+  // frame, a few hundred streams in lock step), else one lane per frame; bit-identical results (refine_variant forces
+  // one of them: 1 = lane, 2 = group)
+  const bool group = refine_variant == 2 || (refine_variant == 0 && n_frames <= 2048);
 #define K3_LAUNCH(M_)                                                                                              \
   do {                                                                                                             \
     hipLaunchKernelGGL(k3a_validate<M_>, grid_a, dim3(64), lds_a, s, dets, hist, n_frames, sp, results, corr_out,  \
                        corr_in, nn_pred, nn_tol, mid);                                                             \
-    hipLaunchKernelGGL(k3b_refine<M_>, grid_b, dim3(K3B_THREADS), lds_b, s, dets, n_frames, sp, results,           \
-                       (const TailMid*)mid, rows);                                                                 \
+    if (group)                                                                                                     \
+      hipLaunchKernelGGL(k3b_refine_group<M_>, grid_g, dim3(64), 0, s, dets, n_frames, sp, results,                \
+                         (const TailMid*)mid, rows);                                                               \
+    else                                                                                                           \
+      hipLaunchKernelGGL(k3b_refine<M_>, grid_b, dim3(K3B_THREADS), lds_b, s, dets, n_frames, sp, results,         \
+                         (const TailMid*)mid, rows);                                                               \
   } while (0)
   if (mode == 1)
     K3_LAUNCH(1);
