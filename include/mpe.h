@@ -181,6 +181,17 @@ int mpe_estimate_batch_multi_device(mpe_handle* const* handles, int n_dev, const
                                     int n_markers, const double K[9], const double* D, int nD,
                                     const mpe_params* p, mpe_result* results);
 
+/* The same with the gather ON THE DEVICES: every shard's pose records travel from its GPU into ONE device-resident
+ * array on handles[0]'s device (sum(n_frames) records, shard after shard) — over RCCL (ncclCommInitAll once per device
+ * list, one grouped ncclSend / ncclRecv exchange per call: point-to-point over xGMI, 432 bytes per frame, no host
+ * copy) when the handles sit on distinct devices, by plain device-to-device copies when several handles share a
+ * device.  *used_rccl (optional) tells which.  RCCL is loaded at first use (dlopen of librccl.so); MPE_ERR_UNSUPPORTED
+ * if it cannot be found.  Blocking: the records are complete when the call returns. */
+int mpe_estimate_batch_multi_device_gather(mpe_handle* const* handles, int n_dev, const uint8_t* const* d_frames,
+                                           const int* n_frames, int rows, int cols, const double* markers_xyz,
+                                           int n_markers, const double K[9], const double* D, int nD,
+                                           const mpe_params* p, mpe_result* d_results_dev0, int* used_rccl);
+
 /* Fully asynchronous variant for device-resident pipelines: frames AND results are device
  * pointers, nothing is copied, the call only enqueues kernels on the handle's stream.
  * frames must be 16-byte aligned with cols % 16 == 0, stride_bytes == cols and

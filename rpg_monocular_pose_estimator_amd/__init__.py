@@ -8,6 +8,7 @@ from .binding import (MpeError, MpeParams, MpeResult, MpeDetections, RESULT_DTYP
                       MAX_DETECTIONS, MAX_MARKERS, Handle, build_library, library_path, load_library,
                       demo_params, exported_symbols, Tracker, determine_roi, distort_points, exponential_map, logarithm_map,
                       predict_pose, project_points, find_correspondences, shard_bounds, estimate_batch_multi,
+                      estimate_batch_multi_device_gather, ENCODINGS,
                       tracker_estimate_batch, tracker_run_sequences_batch, PinnedFrames)
 from .pose_estimator import PoseEstimator  # noqa: F401
 
@@ -15,4 +16,4 @@ __all__ = ["MpeError", "MpeParams", "MpeResult", "MpeDetections", "RESULT_DTYPE"
            "MAX_DETECTIONS", "MAX_MARKERS", "Handle", "build_library", "library_path", "load_library",
            "demo_params", "exported_symbols", "PoseEstimator", "Tracker", "determine_roi", "distort_points",
            "exponential_map", "logarithm_map", "predict_pose", "project_points", "find_correspondences",
-           "shard_bounds", "estimate_batch_multi", "tracker_estimate_batch", "tracker_run_sequences_batch", "PinnedFrames"]
+           "shard_bounds", "estimate_batch_multi", "estimate_batch_multi_device_gather", "ENCODINGS", "tracker_estimate_batch", "tracker_run_sequences_batch", "PinnedFrames"]

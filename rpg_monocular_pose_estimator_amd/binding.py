@@ -121,6 +121,9 @@ def load_library():
     lib.mpe_estimate_batch_device_collect.argtypes = [C.c_void_p, C.c_void_p]
     lib.mpe_track_step_batch_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mpe_track_step_batch_cancel.argtypes = [C.c_void_p]
+    lib.mpe_estimate_batch_multi_device_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, dp,
+                                                           C.c_int, dp, dp, C.c_int, C.POINTER(MpeParams), C.c_void_p,
+                                                           C.POINTER(C.c_int)]
     lib.mpe_convert_to_mono8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
     lib.mpe_detect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_int,
@@ -268,6 +271,32 @@ def estimate_batch_multi(handles, frames, markers, K, D, params):
         msgs = [lib.mpe_last_error(h._h).decode() for h in handles]
         raise MpeError("mpe_estimate_batch_multi failed (%d): %s" % (rc, "; ".join(m for m in msgs if m)))
     return out
+
+
+def estimate_batch_multi_device_gather(handles, frames, markers, K, D, params):
+    """mpe_estimate_batch_multi_device_gather: device-resident shards (a LIST of torch uint8 CUDA tensors, one per
+    handle, each on its handle's device) -> ONE torch uint8 tensor of records on handles[0]'s device, gathered GPU to
+    GPU (RCCL over xGMI when the handles sit on distinct devices).  -> (records as numpy, used_rccl)."""
+    import torch
+    lib = load_library()
+    markers = _f64(markers).reshape(-1, 3)
+    K = _f64(K).reshape(9)
+    D = _f64(D).reshape(-1)
+    hs = (C.c_void_p * len(handles))(*[h._h for h in handles])
+    rows, cols = frames[0].shape[1:]
+    ptrs = (C.c_void_p * len(frames))(*[f.data_ptr() for f in frames])
+    counts = (C.c_int * len(frames))(*[f.shape[0] for f in frames])
+    n = sum(f.shape[0] for f in frames)
+    out = torch.zeros(n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=frames[0].device)
+    torch.cuda.synchronize()
+    used = C.c_int(0)
+    rc = lib.mpe_estimate_batch_multi_device_gather(hs, len(handles), ptrs, counts, rows, cols, _dp(markers), len(markers),
+                                                    _dp(K), _dp(D), len(D), C.byref(params), C.c_void_p(out.data_ptr()),
+                                                    C.byref(used))
+    if rc != 0:
+        msgs = [lib.mpe_last_error(h._h).decode() for h in handles]
+        raise MpeError("mpe_estimate_batch_multi_device_gather failed (%d): %s" % (rc, "; ".join(m for m in msgs if m)))
+    return np.frombuffer(out.cpu().numpy().tobytes(), RESULT_DTYPE), bool(used.value)
 
 
 def determine_roi(px, rows, cols, border, K, D):

@@ -3,12 +3,15 @@
 // K1a -> K1b -> K2 -> K3 per batch.  No torch, no CPU fallback: without a HIP device every entry
 // point fails with MPE_ERR_NO_DEVICE / MPE_ERR_HIP.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -50,6 +53,7 @@ struct mpe_handle {
   DevBuf frames, flags, dets, hist, results, corr, mtab, work, scratch, track, mid;
   void* mailbox = nullptr;  // pinned host memory for the single-frame tracking step (ROI in, record out)
   size_t mailbox_cap = 0;
+  uint8_t* mailbox_dev = nullptr;  // the same memory as the device sees it (hipHostGetDevicePointer)
   int pending_track_n = 0;            // mpe_track_step_batch_submit without its _collect yet: streams in flight
   const uint8_t* pending_track_rec = nullptr;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
@@ -1471,6 +1475,9 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
     const size_t want = std::max(need + need / 4, (size_t)1 << 16);
     HIP_TRY(h, hipHostMalloc(&h->mailbox, want, hipHostMallocDefault));
     h->mailbox_cap = want;
+    void* dv = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer(&dv, h->mailbox, 0));
+    h->mailbox_dev = static_cast<uint8_t*>(dv);
   }
   // pack [predicted pixels | ROI rows, zero padded to the pitch] into pinned memory -> one H2D copy
   uint8_t* mb = static_cast<uint8_t*>(h->mailbox);
@@ -1489,18 +1496,21 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   HIP_TRY(h, h->hist.reserve(MPE_HIST_STRIDE * sizeof(uint32_t)));
   HIP_TRY(h, h->track.reserve(sizeof(TrackRecord)));
   HIP_TRY(h, h->mid.reserve(k3_mid_bytes(1)));
-  uint8_t* d_in = static_cast<uint8_t*>(h->frames.p);
+  // Zero-copy I/O: the kernels read the ROI and the predicted pixels straight from the pinned mailbox (a few KB over
+  // PCIe, once each), and a last small kernel writes the record into it — two copy commands fewer on a path whose
+  // whole budget is ~100 us.
+  const uint8_t* d_in = h->mailbox_dev;
   TrackRecord* d_rec = static_cast<TrackRecord*>(h->track.p);
   h->have_ms = false;
-  HIP_TRY(h, hipMemcpyAsync(d_in, mb, in_bytes, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, launch_k1a_scan(d_in + kTrackHeader, roi_bytes, static_cast<unsigned long long*>(h->flags.p), dp.thr, 0,
                              h->stream));
   HIP_TRY(h, launch_k1b_blobs(d_in + kTrackHeader, static_cast<unsigned long long*>(h->flags.p), 1, g, dp, &d_rec->det,
-                              static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), 0, h->stream));
+                              static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), sp.n_markers, h->stream));
   HIP_TRY(h, launch_k3_tail(&d_rec->det, static_cast<uint32_t*>(h->hist.p), 1, sp, &d_rec->res, d_rec->corr, nullptr,
                             reinterpret_cast<const double*>(d_in), p->nearest_neighbour_pixel_tolerance, h->mid.p,
                             h->stream));
-  HIP_TRY(h, hipMemcpyAsync(host_rec, d_rec, sizeof(TrackRecord), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, launch_copy_words(h->mailbox_dev + (reinterpret_cast<uint8_t*>(host_rec) - mb), d_rec, sizeof(TrackRecord),
+                               h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   *dets_out = host_rec->det;
   std::memcpy(corr_out, host_rec->corr, sizeof(host_rec->corr));
@@ -1727,6 +1737,9 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
     const size_t want = std::max(need + need / 4, (size_t)1 << 16);
     HIP_TRY(h, hipHostMalloc(&h->mailbox, want, hipHostMallocDefault));
     h->mailbox_cap = want;
+    void* dv = nullptr;
+    HIP_TRY(h, hipHostGetDevicePointer(&dv, h->mailbox, 0));
+    h->mailbox_dev = static_cast<uint8_t*>(dv);
   }
   uint8_t* mb = static_cast<uint8_t*>(h->mailbox);
   double* pred = reinterpret_cast<double*>(mb);
@@ -1761,7 +1774,7 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
   HIP_TRY(h, h->hist.reserve((size_t)n * MPE_HIST_STRIDE * sizeof(uint32_t)));
   HIP_TRY(h, h->track.reserve(rec_bytes));
   HIP_TRY(h, h->mid.reserve(k3_mid_bytes(n)));
-  uint8_t* d_in = static_cast<uint8_t*>(h->frames.p);
+  const uint8_t* d_in = h->mailbox_dev;  // zero-copy: the kernels read the pinned mailbox (see mpe_track_step)
   const double* d_pred = reinterpret_cast<const double*>(d_in);
   const void* d_wins = d_in + pred_bytes;
   const uint8_t* d_pix = d_in + pred_bytes + win_bytes;
@@ -1769,13 +1782,12 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
   uint32_t* d_corr = reinterpret_cast<uint32_t*>(d_dets + n);
   mpe_result* d_res = reinterpret_cast<mpe_result*>(d_corr + (size_t)n * 2 * MPE_MAX_MARKERS);
   h->have_ms = false;
-  HIP_TRY(h, hipMemcpyAsync(d_in, mb, in_bytes, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, launch_k1a_scan(d_pix, (size_t)n * slot, static_cast<unsigned long long*>(h->flags.p), dp.thr, 0, h->stream));
   HIP_TRY(h, launch_k1b_blobs(d_pix, static_cast<unsigned long long*>(h->flags.p), n, g, dp, d_dets,
-                              static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), 0, h->stream, d_wins));
+                              static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), sp.n_markers, h->stream, d_wins));
   HIP_TRY(h, launch_k3_tail(d_dets, static_cast<uint32_t*>(h->hist.p), n, sp, d_res, d_corr, nullptr, d_pred,
                             p->nearest_neighbour_pixel_tolerance, h->mid.p, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(host_rec, d_dets, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, launch_copy_words(h->mailbox_dev + (host_rec - mb), d_dets, rec_bytes, h->stream));
   h->pending_track_n = n;
   h->pending_track_rec = host_rec;
   return MPE_OK;
@@ -1905,6 +1917,143 @@ int mpe_estimate_batch_multi_device(mpe_handle* const* handles, int n_dev, const
     return mpe_estimate_batch(handles[d], d_frames[d], n_frames[d], rows, cols, (size_t)cols, (size_t)rows * cols, 1,
                               markers_xyz, n_markers, K, D, nD, p, results + off[(size_t)d]);
   });
+}
+
+}  // extern "C"
+
+// ---- several GPUs from one process, records gathered ON THE DEVICE over RCCL -------------------------------
+// ("ncclCommInitAll, one host thread + stream per device"; the only exchange of the sharded path is the
+// gather of the 432-byte pose records.)  RCCL is loaded at first use (dlopen of librccl.so: no link-time dependency,
+// and no clash with the copy a host framework may have loaded); one communicator set per device list, kept for the
+// life of the process.
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+  bool load() {
+    if (lib) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) {
+      err = "librccl.so not found (dlopen)";
+      return false;
+    }
+    CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+    Send = reinterpret_cast<decltype(Send)>(dlsym(lib, "ncclSend"));
+    Recv = reinterpret_cast<decltype(Recv)>(dlsym(lib, "ncclRecv"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!CommInitAll || !GroupStart || !GroupEnd || !Send || !Recv) {
+      err = "librccl.so lacks ncclCommInitAll / ncclGroupStart / ncclSend / ncclRecv";
+      lib = nullptr;
+      return false;
+    }
+    return true;
+  }
+};
+struct RcclComms {
+  std::vector<int> devices;
+  std::vector<ncclComm_t> comms;
+};
+std::mutex g_rccl_mutex;
+RcclApi g_rccl;
+std::vector<RcclComms> g_rccl_comms;
+}  // namespace
+
+extern "C" {
+
+int mpe_estimate_batch_multi_device_gather(mpe_handle* const* handles, int n_dev, const uint8_t* const* d_frames,
+                                           const int* n_frames, int rows, int cols, const double* markers_xyz,
+                                           int n_markers, const double K[9], const double* D, int nD, const mpe_params* p,
+                                           mpe_result* d_results_dev0, int* used_rccl) {
+  if (used_rccl) *used_rccl = 0;
+  if (!handles || n_dev < 1 || !d_frames || !n_frames || !d_results_dev0) return MPE_ERR_ARG;
+  std::vector<size_t> off((size_t)n_dev + 1, 0);
+  for (int d = 0; d < n_dev; ++d) {
+    if (!handles[d] || n_frames[d] < 0 || (n_frames[d] > 0 && !d_frames[d])) return MPE_ERR_ARG;
+    off[(size_t)d + 1] = off[(size_t)d] + (size_t)n_frames[d];
+  }
+  // distinct devices -> RCCL; handles that share a device (a 1-GPU box) -> plain device-to-device copies
+  bool distinct = true;
+  for (int d = 0; d < n_dev; ++d)
+    for (int e = 0; e < d; ++e) distinct = distinct && handles[d]->device != handles[e]->device;
+  // every shard computes into its own device: shard 0 straight into the result array, the others into their handle's
+  // record buffer
+  std::vector<mpe_result*> d_part((size_t)n_dev, nullptr);
+  int rc = run_shards(handles, n_dev, [&](int d) -> int {
+    mpe_handle* h = handles[d];
+    if (n_frames[d] == 0) return MPE_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (d == 0) {
+      d_part[0] = d_results_dev0;
+    } else {
+      HIP_TRY(h, h->results.reserve((size_t)n_frames[d] * sizeof(mpe_result)));
+      d_part[(size_t)d] = static_cast<mpe_result*>(h->results.p);
+    }
+    return mpe_estimate_batch_device(h, d_frames[d], n_frames[d], rows, cols, markers_xyz, n_markers, K, D, nD, p,
+                                     d_part[(size_t)d]);
+  });
+  if (rc != MPE_OK) return rc;
+  mpe_handle* h0 = handles[0];
+  if (n_dev > 1 && distinct) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (!g_rccl.load()) return fail(h0, MPE_ERR_UNSUPPORTED, g_rccl.err.c_str());
+    std::vector<int> devs((size_t)n_dev);
+    for (int d = 0; d < n_dev; ++d) devs[(size_t)d] = handles[d]->device;
+    RcclComms* cs = nullptr;
+    for (auto& c : g_rccl_comms)
+      if (c.devices == devs) cs = &c;
+    if (!cs) {
+      RcclComms c;
+      c.devices = devs;
+      c.comms.resize((size_t)n_dev);
+      const ncclResult_t r = g_rccl.CommInitAll(c.comms.data(), n_dev, devs.data());
+      if (r != ncclSuccess) return fail(h0, MPE_ERR_HIP, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "ncclCommInitAll failed");
+      g_rccl_comms.push_back(c);
+      cs = &g_rccl_comms.back();
+    }
+    // one grouped exchange: rank d sends its records to rank 0 on its own stream (behind its kernels), rank 0 receives
+    // them into their place of the result array on its stream — point-to-point over xGMI, 432 B per frame
+    ncclResult_t r = g_rccl.GroupStart();
+    for (int d = 1; d < n_dev && r == ncclSuccess; ++d) {
+      if (n_frames[d] == 0) continue;
+      const size_t bytes = (size_t)n_frames[d] * sizeof(mpe_result);
+      (void)hipSetDevice(handles[d]->device);
+      r = g_rccl.Send(d_part[(size_t)d], bytes, ncclUint8, 0, cs->comms[(size_t)d], handles[d]->stream);
+      if (r != ncclSuccess) break;
+      (void)hipSetDevice(h0->device);
+      r = g_rccl.Recv(d_results_dev0 + off[(size_t)d], bytes, ncclUint8, d, cs->comms[0], h0->stream);
+    }
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess)
+      return fail(h0, MPE_ERR_HIP, g_rccl.GetErrorString ? g_rccl.GetErrorString(r != ncclSuccess ? r : r2) : "RCCL send / recv failed");
+    if (used_rccl) *used_rccl = 1;
+    for (int d = 1; d < n_dev; ++d) {  // the senders' buffers are free again once their streams are through
+      (void)hipSetDevice(handles[d]->device);
+      HIP_TRY(handles[d], hipStreamSynchronize(handles[d]->stream));
+    }
+  } else {
+    for (int d = 1; d < n_dev; ++d) {
+      if (n_frames[d] == 0) continue;
+      mpe_handle* h = handles[d];
+      HIP_TRY(h, hipSetDevice(h->device));
+      HIP_TRY(h, hipMemcpyAsync(d_results_dev0 + off[(size_t)d], d_part[(size_t)d], (size_t)n_frames[d] * sizeof(mpe_result),
+                                hipMemcpyDeviceToDevice, h->stream));
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+  }
+  HIP_TRY(h0, hipSetDevice(h0->device));
+  HIP_TRY(h0, hipStreamSynchronize(h0->stream));
+  return MPE_OK;
 }
 
 }  // extern "C"

@@ -95,6 +95,8 @@ hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame
 // sensor_msgs/Image payload (bgr8 / rgb8 / bgra8 / rgba8 / mono16 / mono8, MPE_ENC_*) -> packed mono8 frames
 hipError_t launch_to_mono8(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int encoding, int big_endian,
                            int n_frames, int rows, int cols, uint8_t* dst, hipStream_t s);
+// device -> (mapped host) memory copy of a small record block by a kernel (bytes % 4 == 0)
+hipError_t launch_copy_words(void* dst, const void* src, size_t bytes, hipStream_t s);
 hipError_t launch_spin(unsigned long long ticks_100mhz, hipStream_t s);
 hipError_t launch_p3p_batch(const double* fv, const double* wp, int n, double* sol, int* status, hipStream_t s);
 hipError_t launch_quartic_batch(const double* factors, int n, int variant, double* roots, hipStream_t s);

@@ -73,6 +73,22 @@ __device__ __forceinline__ unsigned any_gt16(const uint4& v, ThrTest q) {
   return r & 0x80808080u;
 }
 
+// The threshold test with the AND / OR form fixed at compile time (3 VALU ops per word instead of the 5 of the
+// run-time select): the kernels branch ONCE, wave-uniformly, on thr.sel.
+template <bool HI>
+__device__ __forceinline__ unsigned gt_word_c(unsigned w, unsigned kk) {
+  const unsigned t = (w & 0x7F7F7F7Fu) + kk;
+  return HI ? (t & w) : (t | w);
+}
+template <bool HI>
+__device__ __forceinline__ unsigned maybe_gt16_c(const uint4& v, unsigned kk) {
+  return gt_word_c<HI>(v.x | v.y | v.z | v.w, kk) & 0x80808080u;
+}
+template <bool HI>
+__device__ __forceinline__ unsigned any_gt16_c(const uint4& v, unsigned kk) {
+  return (gt_word_c<HI>(v.x, kk) | gt_word_c<HI>(v.y, kk) | gt_word_c<HI>(v.z, kk) | gt_word_c<HI>(v.w, kk)) & 0x80808080u;
+}
+
 #ifndef K1A_UNROLL
 #define K1A_UNROLL 8  // 8 KiB per wave in flight: measured best on MI355X (6.5 TB/s)
 #endif
@@ -82,41 +98,61 @@ __device__ __forceinline__ unsigned any_gt16(const uint4& v, ThrTest q) {
 #ifndef K1A_BLOCKS_PER_CU
 #define K1A_BLOCKS_PER_CU 32
 #endif
-__global__ __launch_bounds__(256) void k1a_scan(const uint4* __restrict__ px, u64* __restrict__ flags, size_t n_seg,
-                                                ThrTest thr) {
+// One chunk of 64 * K1A_UNROLL segments of a wave.  FULL: the whole chunk lies inside the data — no bounds checks, one
+// base address per chunk, the loads differ by their immediate offsets only (round 3: the per-load 64-bit bounds check,
+// zero fill and address arithmetic were 9 of the 18 VALU instructions per KiB; with the compile-time threshold form
+// the full-chunk path is down to ~8, which matters because the scan shares the chip's VALU with the blob extraction).
+template <bool HI, bool FULL>
+__device__ __forceinline__ void k1a_chunk(const uint4* __restrict__ px, u64* __restrict__ flags, size_t n_seg, size_t c,
+                                          int lane, unsigned kk) {
+  const size_t base = c * (64 * K1A_UNROLL) + lane;
+  uint4 v[K1A_UNROLL];
+  const u32x4* p = reinterpret_cast<const u32x4*>(px) + base;
+#pragma unroll
+  for (int k = 0; k < K1A_UNROLL; ++k) {
+    if (FULL || base + 64 * k < n_seg) {
+#if K1A_NT
+      const u32x4 t = __builtin_nontemporal_load(p + 64 * k);
+#else
+      const u32x4 t = p[64 * k];
+#endif
+      v[k] = make_uint4(t.x, t.y, t.z, t.w);
+    } else {
+      v[k] = make_uint4(0, 0, 0, 0);
+    }
+  }
+  u64 b[K1A_UNROLL];
+#pragma unroll
+  for (int k = 0; k < K1A_UNROLL; ++k) {
+    b[k] = __ballot(maybe_gt16_c<HI>(v[k], kk) != 0);
+    if (b[k]) b[k] = __ballot(any_gt16_c<HI>(v[k], kk) != 0);  // wave-uniform, rare on dark frames
+  }
+  if (lane == 0) {
+    ulonglong2* out = reinterpret_cast<ulonglong2*>(flags + c * K1A_UNROLL);
+#pragma unroll
+    for (int k = 0; k < K1A_UNROLL / 2; ++k) out[k] = make_ulonglong2(b[2 * k], b[2 * k + 1]);
+  }
+}
+template <bool HI>
+__device__ __forceinline__ void k1a_scan_body(const uint4* __restrict__ px, u64* __restrict__ flags, size_t n_seg, unsigned kk) {
   const int lane = threadIdx.x & 63;
   const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const size_t n_full = n_seg / (64 * K1A_UNROLL);
   const size_t n_chunks = (n_seg + 64 * K1A_UNROLL - 1) / (64 * K1A_UNROLL);
   for (size_t c = wave; c < n_chunks; c += n_waves) {
-    const size_t base = c * (64 * K1A_UNROLL) + lane;
-    uint4 v[K1A_UNROLL];
-#pragma unroll
-    for (int k = 0; k < K1A_UNROLL; ++k) {
-      const size_t idx = base + 64 * k;
-      if (idx < n_seg) {
-#if K1A_NT
-        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(px) + idx);
-#else
-        const u32x4 t = *(reinterpret_cast<const u32x4*>(px) + idx);
-#endif
-        v[k] = make_uint4(t.x, t.y, t.z, t.w);
-      } else {
-        v[k] = make_uint4(0, 0, 0, 0);
-      }
-    }
-    u64 b[K1A_UNROLL];
-#pragma unroll
-    for (int k = 0; k < K1A_UNROLL; ++k) {
-      b[k] = __ballot(maybe_gt16(v[k], thr) != 0);
-      if (b[k]) b[k] = __ballot(any_gt16(v[k], thr) != 0);  // wave-uniform, rare on dark frames
-    }
-    if (lane == 0) {
-      ulonglong2* out = reinterpret_cast<ulonglong2*>(flags + c * K1A_UNROLL);
-#pragma unroll
-      for (int k = 0; k < K1A_UNROLL / 2; ++k) out[k] = make_ulonglong2(b[2 * k], b[2 * k + 1]);
-    }
+    if (c < n_full)
+      k1a_chunk<HI, true>(px, flags, n_seg, c, lane, kk);
+    else
+      k1a_chunk<HI, false>(px, flags, n_seg, c, lane, kk);
   }
+}
+__global__ __launch_bounds__(256) void k1a_scan(const uint4* __restrict__ px, u64* __restrict__ flags, size_t n_seg,
+                                                ThrTest thr) {
+  if (thr.sel)  // (wave-uniform: a kernel argument)
+    k1a_scan_body<true>(px, flags, n_seg, thr.kk);
+  else
+    k1a_scan_body<false>(px, flags, n_seg, thr.kk);
 }
 
 // dummy_lds > 0: the scan is about to run beside the FP64 voting kernel of another sub-batch (two-stream
@@ -1457,7 +1493,8 @@ struct ScanRider {
       all |= v[k].x | v[k].y | v[k].z | v[k].w;
       b[k] = 0;
     }
-    if (__ballot((gt_word(all, thr.kk, thr.sel) & 0x80808080u) != 0)) {  // wave-uniform
+    const unsigned hit = thr.sel ? gt_word_c<true>(all, thr.kk) : gt_word_c<false>(all, thr.kk);  // (uniform select)
+    if (__ballot((hit & 0x80808080u) != 0)) {  // wave-uniform
 #pragma unroll
       for (int k = 0; k < K2_SCAN_R; ++k) {
         b[k] = __ballot(maybe_gt16(v[k], thr) != 0);
@@ -3298,6 +3335,21 @@ hipError_t launch_to_mono8(const uint8_t* src, size_t src_stride, size_t src_fra
   if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond 64 blocks per CU
   hipLaunchKernelGGL(k_to_mono8, dim3((unsigned)blocks), dim3(256), 0, s, src, src_stride, src_frame_stride, encoding,
                      big_endian, rows, cols, n_rows, dst);
+  return hipGetLastError();
+}
+
+// small record blocks device -> pinned host memory without a copy command (tracked frames)
+__global__ void k_copy_words(unsigned* __restrict__ dst, const unsigned* __restrict__ src, size_t n_words) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+hipError_t launch_copy_words(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  const size_t n = bytes / 4;
+  if (n == 0) return hipSuccess;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_copy_words, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<unsigned*>(dst),
+                     static_cast<const unsigned*>(src), n);
   return hipGetLastError();
 }
 

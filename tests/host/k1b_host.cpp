@@ -109,5 +109,8 @@ extern "C" int host_scan_tests(const uint8_t* seg16, int thr) {
   uint4 v;
   std::memcpy(&v, seg16, 16);
   const ThrTest q = make_thr_test(thr);
-  return (any_gt16(v, q) ? 1 : 0) | (maybe_gt16(v, q) ? 2 : 0);
+  // bits 2 / 3: the same through the compile-time forms the kernels branch to (k1a_scan, the rider's first level)
+  const unsigned a_c = q.sel ? any_gt16_c<true>(v, q.kk) : any_gt16_c<false>(v, q.kk);
+  const unsigned m_c = q.sel ? maybe_gt16_c<true>(v, q.kk) : maybe_gt16_c<false>(v, q.kk);
+  return (any_gt16(v, q) ? 1 : 0) | (maybe_gt16(v, q) ? 2 : 0) | (a_c ? 4 : 0) | (m_c ? 8 : 0);
 }

@@ -425,3 +425,31 @@ def test_refinement_kernels_agree_bit_for_bit(orc):
             h.set_option("refine_variant", 3)
     finally:
         h.close()
+
+
+def test_multi_device_gather_on_the_device(hip):
+    """mpe_estimate_batch_multi_device_gather: the shards' pose records end up in ONE device array on GPU 0.  With two
+    or more GPUs they travel over RCCL (grouped ncclSend / ncclRecv); this box has one, so several handles share
+    GPU 0 and the gather is a device-to-device copy — the RCCL leg is then SKIPPED, loudly.  Either way the records
+    equal those of a single-handle call."""
+    import torch
+    d = synth.make_frames("C2", 41, seed=4321)
+    P = mpe.demo_params()
+    one = hip.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], P)
+    n_gpu = torch.cuda.device_count()
+    for n_dev in (1, 2, 3):
+        hs = [mpe.Handle(i % n_gpu) for i in range(n_dev)]
+        try:
+            shards = []
+            for i in range(n_dev):
+                lo, hi = mpe.shard_bounds(len(d["frames"]), i, n_dev)
+                shards.append(torch.from_numpy(d["frames"][lo:hi].copy()).to("cuda:%d" % (i % n_gpu)))
+            got, used_rccl = mpe.estimate_batch_multi_device_gather(hs, shards, d["markers"], d["K"], d["D"], P)
+            assert got.tobytes() == one.tobytes(), n_dev
+            assert used_rccl == (n_dev > 1 and n_gpu >= n_dev)
+        finally:
+            for h in hs:
+                h.close()
+    if n_gpu < 2:
+        pytest.skip("ONE GPU visible: the RCCL (xGMI) leg of mpe_estimate_batch_multi_device_gather was NOT exercised — "
+                    "only the same-device copy path ran; it needs a box with >= 2 GPUs")

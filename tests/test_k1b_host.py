@@ -168,3 +168,5 @@ def test_scan_threshold_arithmetic_exhaustively(host):
             r = host.host_scan_tests(s.ctypes.data_as(C.c_void_p), thr)
             assert bool(r & 1) == want, (thr, s)
             assert (r & 2) or not want, (thr, s)        # maybe_gt16 is a necessary condition
+            assert bool(r & 4) == want, (thr, s)        # ... and the compile-time AND / OR forms agree
+            assert (r & 8) or not want, (thr, s)
