@@ -114,8 +114,8 @@ def main():
     ap.add_argument("--k1a-lds", type=int, default=-1, help="tuning: dummy LDS per scan block (-1 = automatic)")
     ap.add_argument("--pipeline-mode", type=int, default=-1,
                     help="-1 automatic, 0 two-stream pipeline, 3 fused, 4 fused + side-stream tail, 6 = 4 + split scan")
-    ap.add_argument("--side-scan-blocks", type=int, default=2, help="mode 6: resident blocks per CU of the side scan")
-    ap.add_argument("--scan-split-pct", type=int, default=25, help="mode 6: share of a sub-batch scanned on the side stream")
+    ap.add_argument("--side-scan-blocks", type=int, default=3, help="mode 6: resident blocks per CU of the side scan")
+    ap.add_argument("--scan-split-pct", type=int, default=30, help="mode 6: share of a sub-batch scanned on the side stream")
     ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
     ap.add_argument("--vote-arith", type=int, default=1, help="1 fast voting arithmetic (default), 0 strict (IEEE)")
     ap.add_argument("--no-streaming", action="store_true",

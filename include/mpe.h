@@ -455,9 +455,9 @@ int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
  * scan of sub-batch s+1 rides inside the voting kernel of sub-batch s;  4 = as 3, with the validate /
  * refine kernels of sub-batch s on an internal side stream, beside the blob extraction of sub-batch
  * s+1 (joined back before the call returns its place on the stream);  6 = as 4, and the image scan of a
- * sub-batch is split: "scan_split_pct" % of it (default 25) is taken by a stand-alone scan kernel on a second
+ * sub-batch is split: "scan_split_pct" % of it (default 30) is taken by a stand-alone scan kernel on a second
  * side stream during the blob / tail window two sub-batches earlier ("side_scan_blocks" resident blocks per CU,
- * default 2), the voting kernel's rider scans the rest), "k1a_dummy_lds" (occupancy cap
+ * default 3), the voting kernel's rider scans the rest), "k1a_dummy_lds" (occupancy cap
  * of the stand-alone scan kernel in mode 0, per handle), "ingest_chunk" (frames per chunk of the double-buffered
  * host-frame ingest of mpe_estimate_batch, default 2048, 0 = one blocking copy per call), "refine_variant" (the refinement kernel: 0 automatic = 16 lanes per frame for launches of up to 2048 frames, else one lane per frame; 1 / 2 force one of them; bit-identical results), "vote_arith" (arithmetic of the voting kernel: 1 (default)
  * = fast — Newton-Raphson division / square root, Newton cube root, per-permutation tables, [R|C]-free

@@ -53,7 +53,6 @@ struct mpe_handle {
   DevBuf frames, flags, dets, hist, results, corr, mtab, work, scratch, track, mid;
   void* mailbox = nullptr;  // pinned host memory for the single-frame tracking step (ROI in, record out)
   size_t mailbox_cap = 0;
-  uint8_t* mailbox_dev = nullptr;  // the same memory as the device sees it (hipHostGetDevicePointer)
   int pending_track_n = 0;            // mpe_track_step_batch_submit without its _collect yet: streams in flight
   const uint8_t* pending_track_rec = nullptr;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
@@ -83,8 +82,8 @@ struct mpe_handle {
   int ingest_chunk = 2048;            // frames per ingest chunk (option "ingest_chunk"; 0 = one blocking copy per call)
   hipStream_t scan_stream = nullptr;  // mode 6: part of the next-but-one sub-batch's scan beside blobs / tail
   hipEvent_t scanpart_done[kMaxSub] = {};
-  int side_scan_blocks = 2;           // mode 6: resident blocks per CU of the side scan (4 waves each)
-  int scan_split_pct = 25;            // mode 6: share of a sub-batch scanned by the stand-alone kernel on the side stream
+  int side_scan_blocks = 3;           // mode 6: resident blocks per CU of the side scan (4 waves each)
+  int scan_split_pct = 30;            // mode 6: share of a sub-batch scanned by the stand-alone kernel on the side stream
   unsigned long long last_rider_bytes = 0;  // bytes one fused voting launch scanned in the last large call
   hipStream_t tail_stream = nullptr;  // fused schedule, mode 4: validate + refine of sub-batch s beside blobs(s + 1)
   hipEvent_t tail_done = nullptr;
@@ -291,8 +290,14 @@ int stage_frames(mpe_handle* h, const uint8_t* frames, int n_frames, int rows, i
   return MPE_OK;
 }
 
+// > 0: blocks per frame, each block a share of the flattened (triple, permutation) items;  < 0: -(blocks per frame),
+// each block a share of the marker PERMUTATIONS whose table slice it keeps in LDS (6 .. 10 markers, fast arithmetic)
 int auto_splits(const mpe_handle* h, int n_frames, int n_markers) {
   if (h->vote_splits > 0) return h->vote_splits;
+  if (h->vote_arith != 0 && h->vote_splits == 0) {
+    const int slices = k2_table_slices(n_markers);
+    if (slices > 0) return -slices;
+  }
   // few frames with a large hypothesis space: spread one frame over several workgroups
   if (n_frames >= 1024 || n_markers <= 5) return 1;
   int s = 2048 / std::max(1, n_frames);
@@ -1475,9 +1480,7 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
     const size_t want = std::max(need + need / 4, (size_t)1 << 16);
     HIP_TRY(h, hipHostMalloc(&h->mailbox, want, hipHostMallocDefault));
     h->mailbox_cap = want;
-    void* dv = nullptr;
-    HIP_TRY(h, hipHostGetDevicePointer(&dv, h->mailbox, 0));
-    h->mailbox_dev = static_cast<uint8_t*>(dv);
+
   }
   // pack [predicted pixels | ROI rows, zero padded to the pitch] into pinned memory -> one H2D copy
   uint8_t* mb = static_cast<uint8_t*>(h->mailbox);
@@ -1496,12 +1499,13 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   HIP_TRY(h, h->hist.reserve(MPE_HIST_STRIDE * sizeof(uint32_t)));
   HIP_TRY(h, h->track.reserve(sizeof(TrackRecord)));
   HIP_TRY(h, h->mid.reserve(k3_mid_bytes(1)));
-  // Zero-copy I/O: the kernels read the ROI and the predicted pixels straight from the pinned mailbox (a few KB over
-  // PCIe, once each), and a last small kernel writes the record into it — two copy commands fewer on a path whose
-  // whole budget is ~100 us.
-  const uint8_t* d_in = h->mailbox_dev;
+  // (Zero-copy I/O — the kernels reading the pinned mailbox over PCIe, a copy kernel writing the record back — was
+  //  built and measured in round 3: the image scan then waits for PCIe reads (4 -> 46 us for 64 streams) and the step
+  //  is no faster, 0.135 vs 0.136 ms for one stream.  The two copy commands stay.)
+  uint8_t* d_in = static_cast<uint8_t*>(h->frames.p);
   TrackRecord* d_rec = static_cast<TrackRecord*>(h->track.p);
   h->have_ms = false;
+  HIP_TRY(h, hipMemcpyAsync(d_in, mb, in_bytes, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, launch_k1a_scan(d_in + kTrackHeader, roi_bytes, static_cast<unsigned long long*>(h->flags.p), dp.thr, 0,
                              h->stream));
   HIP_TRY(h, launch_k1b_blobs(d_in + kTrackHeader, static_cast<unsigned long long*>(h->flags.p), 1, g, dp, &d_rec->det,
@@ -1509,8 +1513,7 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   HIP_TRY(h, launch_k3_tail(&d_rec->det, static_cast<uint32_t*>(h->hist.p), 1, sp, &d_rec->res, d_rec->corr, nullptr,
                             reinterpret_cast<const double*>(d_in), p->nearest_neighbour_pixel_tolerance, h->mid.p,
                             h->stream));
-  HIP_TRY(h, launch_copy_words(h->mailbox_dev + (reinterpret_cast<uint8_t*>(host_rec) - mb), d_rec, sizeof(TrackRecord),
-                               h->stream));
+  HIP_TRY(h, hipMemcpyAsync(host_rec, d_rec, sizeof(TrackRecord), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   *dets_out = host_rec->det;
   std::memcpy(corr_out, host_rec->corr, sizeof(host_rec->corr));
@@ -1737,9 +1740,7 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
     const size_t want = std::max(need + need / 4, (size_t)1 << 16);
     HIP_TRY(h, hipHostMalloc(&h->mailbox, want, hipHostMallocDefault));
     h->mailbox_cap = want;
-    void* dv = nullptr;
-    HIP_TRY(h, hipHostGetDevicePointer(&dv, h->mailbox, 0));
-    h->mailbox_dev = static_cast<uint8_t*>(dv);
+
   }
   uint8_t* mb = static_cast<uint8_t*>(h->mailbox);
   double* pred = reinterpret_cast<double*>(mb);
@@ -1774,7 +1775,7 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
   HIP_TRY(h, h->hist.reserve((size_t)n * MPE_HIST_STRIDE * sizeof(uint32_t)));
   HIP_TRY(h, h->track.reserve(rec_bytes));
   HIP_TRY(h, h->mid.reserve(k3_mid_bytes(n)));
-  const uint8_t* d_in = h->mailbox_dev;  // zero-copy: the kernels read the pinned mailbox (see mpe_track_step)
+  uint8_t* d_in = static_cast<uint8_t*>(h->frames.p);
   const double* d_pred = reinterpret_cast<const double*>(d_in);
   const void* d_wins = d_in + pred_bytes;
   const uint8_t* d_pix = d_in + pred_bytes + win_bytes;
@@ -1782,12 +1783,13 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
   uint32_t* d_corr = reinterpret_cast<uint32_t*>(d_dets + n);
   mpe_result* d_res = reinterpret_cast<mpe_result*>(d_corr + (size_t)n * 2 * MPE_MAX_MARKERS);
   h->have_ms = false;
+  HIP_TRY(h, hipMemcpyAsync(d_in, mb, in_bytes, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, launch_k1a_scan(d_pix, (size_t)n * slot, static_cast<unsigned long long*>(h->flags.p), dp.thr, 0, h->stream));
   HIP_TRY(h, launch_k1b_blobs(d_pix, static_cast<unsigned long long*>(h->flags.p), n, g, dp, d_dets,
                               static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), sp.n_markers, h->stream, d_wins));
   HIP_TRY(h, launch_k3_tail(d_dets, static_cast<uint32_t*>(h->hist.p), n, sp, d_res, d_corr, nullptr, d_pred,
                             p->nearest_neighbour_pixel_tolerance, h->mid.p, h->stream));
-  HIP_TRY(h, launch_copy_words(h->mailbox_dev + (host_rec - mb), d_dets, rec_bytes, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(host_rec, d_dets, rec_bytes, hipMemcpyDeviceToHost, h->stream));
   h->pending_track_n = n;
   h->pending_track_rec = host_rec;
   return MPE_OK;

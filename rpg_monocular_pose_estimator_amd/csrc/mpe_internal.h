@@ -83,6 +83,9 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
                           uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px = nullptr,
                           size_t scan_bytes = 0, unsigned long long* scan_flags = nullptr, int scan_thr = 0,
                           size_t* scanned_bytes = nullptr, const int* item_range = nullptr);
+// splits < 0 (plain kernel): -splits blocks per frame that divide the marker PERMUTATIONS among themselves and keep
+// their slice of the per-permutation table in LDS (k2_table_slices says when and into how many)
+int k2_table_slices(int n_markers);
 // item_range (device, 2 ints per frame, forensics only): frame f votes with hypotheses [lo, hi) only, see mpe_vote_items
 // the tail = k3a_validate + k3b_refine; mid_buf: k3_mid_bytes(n_frames) of device memory handed from one to the other
 size_t k3_mid_bytes(int n_frames);
@@ -95,8 +98,6 @@ hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame
 // sensor_msgs/Image payload (bgr8 / rgb8 / bgra8 / rgba8 / mono16 / mono8, MPE_ENC_*) -> packed mono8 frames
 hipError_t launch_to_mono8(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int encoding, int big_endian,
                            int n_frames, int rows, int cols, uint8_t* dst, hipStream_t s);
-// device -> (mapped host) memory copy of a small record block by a kernel (bytes % 4 == 0)
-hipError_t launch_copy_words(void* dst, const void* src, size_t bytes, hipStream_t s);
 hipError_t launch_spin(unsigned long long ticks_100mhz, hipStream_t s);
 hipError_t launch_p3p_batch(const double* fv, const double* wp, int n, double* sol, int* status, hipStream_t s);
 hipError_t launch_quartic_batch(const double* factors, int n, int variant, double* roots, hipStream_t s);

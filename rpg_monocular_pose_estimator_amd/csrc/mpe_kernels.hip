@@ -1416,6 +1416,21 @@ size_t k2_table_bytes(int n_markers) {
   return (size_t)n_markers * (n_markers - 1) * (n_markers - 2) * k2_entry_doubles(n_markers) * sizeof(double);
 }
 
+// How many blocks of a frame share the marker permutations when each keeps its slice of the table in LDS (plain
+// kernel): slices of at most ~7 KB (so that four 256-thread blocks with their back-projection columns still fit a CU),
+// at most 16 of them, whole blocks of six permutations; 0 = no slicing (<= 5 markers: the whole table is 5 KB and the
+// scan-carrying variant copies it; >= 11 markers: a 16th of the table is larger than that).
+int k2_table_slices(int n_markers) {
+  if (n_markers < 6 || n_markers > 10) return 0;
+  const int n_perms = n_markers * (n_markers - 1) * (n_markers - 2);
+  const size_t bytes = (size_t)n_perms * (k2_entry_doubles(n_markers) - 12) * sizeof(double);
+  int n = (int)((bytes + 7167) / 7168);
+  if (n < 2) n = 2;
+  if (n > 16) n = 16;
+  if (n > n_perms / 6) n = n_perms / 6;
+  return n;
+}
+
 // ---- image scan riding inside the voting kernel ----------------------------------------------
 // The voting kernel is FP64-VALU bound and leaves the memory pipeline idle; the image scan is HBM
 // bound and needs almost no VALU.  Instead of running the two side by side as separate kernels
@@ -1960,7 +1975,8 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
 template <bool SCAN, bool RANGE = false, int NP = 0>
 __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_detections* __restrict__ dets, SolveParams sp,
                                                       const double* __restrict__ tab, uint32_t* __restrict__ hist,
-                                                      int splits, ScanArgs scan, const int* __restrict__ item_range) {
+                                                      int splits, ScanArgs scan, const int* __restrict__ item_range,
+                                                      int slice_tab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double s_px[MPE_MAX_DETECTIONS][2];
   __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
@@ -2020,8 +2036,35 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
     for (int i = tid; i < n_perms * K2_LTAB; i += nthr) s_tab[i] = k2_ltab_value(tab, esz, nuo, i);
     __syncthreads();
   }
-  const K2Frame F = {s_trii, s_tri, s_px, s_pxf, s_q,  s_qf, s_hist, tab,         s_tab,   n_d,  nuo,
-                     nthr,   tid,   esz,  fx,    fy,   cx,   cy,     sp.back_tol, thr_pre, s_vq, 64};
+  // Plain variant, 6 .. 10 markers: the per-permutation table (88 KB at 8 markers) does not fit the LDS of a block, and
+  // reading it from global memory left the voting waves waiting (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES 0.21 at C3).  With
+  // `slice_tab` the `splits` blocks of a frame divide the PERMUTATIONS among themselves (whole blocks of six rows, so
+  // the swapped row of p3p.cpp:100-121 stays inside the slice) and each copies the fields the loop reads of its
+  // slice — [12 .. esz) of every entry: p_1 p_2 d_12 valid indices pad, eta-frame markers — to LDS once.
+  int p_lo = 0, n_perms_loc = n_perms, part_loc = part, splits_loc = splits;
+  const double* tab_eff = tab;
+  int esz_eff = esz;
+  if constexpr (!SCAN) {
+    if (slice_tab) {
+      const int combos6 = n_perms / 6;
+      p_lo = 6 * (int)(((long long)part * combos6) / splits);
+      const int p_hi = 6 * (int)(((long long)(part + 1) * combos6) / splits);
+      n_perms_loc = p_hi - p_lo;
+      part_loc = 0;
+      splits_loc = 1;
+      const int LT = esz - 12;
+      double* s_slice = reinterpret_cast<double*>(s_qf);  // (NP > 0: the single-precision columns are not used)
+      for (int i = tid; i < n_perms_loc * LT; i += nthr) {
+        const int pe = i / LT, fld = i - pe * LT;
+        s_slice[i] = tab[(size_t)(p_lo + pe) * esz + 12 + fld];
+      }
+      __syncthreads();
+      tab_eff = s_slice - (size_t)p_lo * LT - 12;  // so that tab_eff + pj * LT + 12 is field 12 of permutation pj
+      esz_eff = LT;
+    }
+  }
+  const K2Frame F = {s_trii, s_tri, s_px, s_pxf, s_q,  s_qf, s_hist, tab_eff,     s_tab,   n_d,  nuo,
+                     nthr,   tid,   esz_eff, fx, fy,   cx,   cy,     sp.back_tol, thr_pre, s_vq, 64};
   int vq_count = 0;  // entries in this wave's queue (wave-uniform)
   for (int tc0 = 0; tc0 < n_combos; tc0 += TRI) {
     const int ntri = min(TRI, n_combos - tc0);
@@ -2033,25 +2076,25 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
     __syncthreads();
 
     // flattened (triple, permutation) index, advanced without divisions
-    const int total = ntri * n_perms;  // <= 64 * 3360
-    const int stride = splits * nthr;
-    int t = part * nthr + tid;
-    int ti = t / n_perms, pj = t - ti * n_perms;
-    const int dti = stride / n_perms, dpj = stride - dti * n_perms;
+    const int total = ntri * n_perms_loc;  // <= 64 * 3360
+    const int stride = splits_loc * nthr;
+    int t = part_loc * nthr + tid;
+    int ti = t / n_perms_loc, pj = t - ti * n_perms_loc;  // (pj: within this block's permutation range)
+    const int dti = stride / n_perms_loc, dpj = stride - dti * n_perms_loc;
     // With the scan rider on board the loop nest must stay wave-uniform (the rider's LDS-DMA rounds need all
     // 64 lanes at every call): every lane then runs the iteration count of the slowest one and lanes without
     // a valid item — past the end, collinear marker triple, non-finite root — compute on harmlessly and are
     // merely barred from voting (`live`).  Without a rider those lanes skip ahead as before.
-    const int n_iter = (total - part * nthr + stride - 1) / stride;
+    const int n_iter = (total - part_loc * nthr + stride - 1) / stride;
     for (int it = 0; SCAN ? (it < n_iter) : (t < total); ++it, t += stride, ti += dti, pj += dpj) {
-      if (pj >= n_perms) {
-        pj -= n_perms;
+      if (pj >= n_perms_loc) {
+        pj -= n_perms_loc;
         ++ti;
       }
       bool live = true;
       const int ti_keep = ti, pj_keep = pj;
       if constexpr (RANGE) {
-        const int g = (tc0 + ti) * n_perms + pj;
+        const int g = (tc0 + ti) * n_perms + p_lo + pj;
         if (g < item_range[2 * f] || g >= item_range[2 * f + 1]) continue;
       }
       if constexpr (SCAN) {
@@ -2061,7 +2104,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
           pj = 0;
         }
       }
-      k2_vote_item<SCAN, NP>(F, ti, pj, live, rider, vq_count);
+      k2_vote_item<SCAN, NP>(F, ti, p_lo + pj, live, rider, vq_count);
       ti = ti_keep;
       pj = pj_keep;
     }
@@ -2189,6 +2232,11 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
                           const int* item_range) {
   if (scanned_bytes) *scanned_bytes = 0;
   if (n_frames <= 0 || sp.n_markers < 4) return hipSuccess;
+  int slice_tab = 0;
+  if (splits < 0) {  // -(blocks per frame): the blocks share the marker permutations, table slices in LDS
+    splits = -splits;
+    slice_tab = 1;
+  }
   if (splits < 1) splits = 1;
   const int nuo = sp.n_markers - 3;
   if (sp.vote_arith == 0) {  // strict arithmetic: the validation kernel's P3P, no tables, no scan rider
@@ -2232,19 +2280,29 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
           (size_t)(threads / 64) * K2_VQ_CAP * K2_VQ_WORDS * sizeof(u64);
     if (scanned_bytes) *scanned_bytes = (size_t)sa.n_chunks * chunk_bytes;
     hipLaunchKernelGGL((k2_vote<true, false>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
-                       splits, sa, (const int*)nullptr);
+                       splits, sa, (const int*)nullptr, 0);
   } else {
     // plain kernel: the prefilter's single-precision back-projections in registers as (nuo + 1) / 2 packed marker pairs
     // (up to 8 unused markers), else in LDS columns; the forensics instantiation (item_range) the same way
     const int np = nuo <= 8 ? (nuo + 1) / 2 : 0;
     const dim3 grid((unsigned)(n_frames * splits)), block(threads);
+    // the table slice of a block lives where the (unused, NP > 0) single-precision columns would: make it fit
+    if (slice_tab && np > 0) {
+      const size_t slice = (size_t)6 * ((size_t)sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2) / 6 / splits + 1) *
+                           (k2_entry_doubles(sp.n_markers) - 12) * sizeof(double);
+      const size_t have = (size_t)nuo * threads * sizeof(f32x2);
+      if (slice > have) lds += slice - have;
+    } else {
+      slice_tab = 0;
+    }
 #define MPE_K2_PLAIN(NPV)                                                                                            \
   do {                                                                                                               \
     if (item_range)                                                                                                  \
-      hipLaunchKernelGGL((k2_vote<false, true, NPV>), grid, block, lds, s, dets, sp, tab, hist, splits, sa, item_range); \
+      hipLaunchKernelGGL((k2_vote<false, true, NPV>), grid, block, lds, s, dets, sp, tab, hist, splits, sa, item_range, \
+                         slice_tab);                                                                                 \
     else                                                                                                             \
       hipLaunchKernelGGL((k2_vote<false, false, NPV>), grid, block, lds, s, dets, sp, tab, hist, splits, sa,         \
-                         (const int*)nullptr);                                                                       \
+                         (const int*)nullptr, slice_tab);                                                            \
   } while (0)
     switch (np) {
       case 1: MPE_K2_PLAIN(1); break;
@@ -3335,21 +3393,6 @@ hipError_t launch_to_mono8(const uint8_t* src, size_t src_stride, size_t src_fra
   if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond 64 blocks per CU
   hipLaunchKernelGGL(k_to_mono8, dim3((unsigned)blocks), dim3(256), 0, s, src, src_stride, src_frame_stride, encoding,
                      big_endian, rows, cols, n_rows, dst);
-  return hipGetLastError();
-}
-
-// small record blocks device -> pinned host memory without a copy command (tracked frames)
-__global__ void k_copy_words(unsigned* __restrict__ dst, const unsigned* __restrict__ src, size_t n_words) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x)
-    dst[i] = src[i];
-}
-hipError_t launch_copy_words(void* dst, const void* src, size_t bytes, hipStream_t s) {
-  const size_t n = bytes / 4;
-  if (n == 0) return hipSuccess;
-  size_t blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(k_copy_words, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<unsigned*>(dst),
-                     static_cast<const unsigned*>(src), n);
   return hipGetLastError();
 }
 

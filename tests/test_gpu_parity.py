@@ -652,7 +652,7 @@ def test_full_size_batch_properties(orc):
         h.set_option("scan_split_pct", pct)
         fused6 = run(frames, 8)
         assert h.get_option("last_schedule") == 6 and torch.equal(fused6, plain), pct
-    h.set_option("scan_split_pct", 25)
+    h.set_option("scan_split_pct", 30)
     h.set_option("pipeline_mode", -1)                      # automatic = 6
     piped = run(frames, 8)
     assert h.get_option("last_schedule") == 6 and torch.equal(piped, plain)
