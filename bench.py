@@ -330,15 +330,19 @@ def main():
     traffic = None
     traffic_source = None
     pmc_all = {}
+    pmc_matches_binary = None
     try:
-        with open(os.path.join(ROOT, "profiles", "round2_pmc.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "round3_pmc.json")) as fh:
             pmc_all = json.load(fh)
+        # the counter passes were taken from a build of THESE kernel sources? (fingerprint of csrc/*.hip, *.h)
+        pmc_matches_binary = pmc_all.get("source_fingerprint") == mpe.source_fingerprint()
         pmc = pmc_all["k2_vote_scan" if fused else "k1a_scan"]
         if pmc.get("rows") == rows and pmc.get("cols") == cols:
             # (scaled to the frames' worth of pixels this launch scans: bytes_per_launch / (rows * cols))
             traffic = pmc["hbm_bytes_per_frame"] * (bytes_per_launch / float(rows * cols))
-            traffic_source = "profiles/round2_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, " \
-                             "FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes; %s)" % pmc.get("from", "")
+            traffic_source = "profiles/round3_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, " \
+                             "FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes; %s; taken from a build of the kernel " \
+                             "sources timed here: %s)" % (pmc.get("from", ""), pmc_matches_binary)
     except Exception:
         pass
     if fused:
@@ -450,10 +454,16 @@ def main():
         if vp:
             t_s = vote_ms * 1e-3
             n_fr = B
-            out["k2_rates"]["valu_util"] = vp["valu_insts_per_frame"] * n_fr * 4.0 / (1024 * 2.4e9 * t_s)
+            # against the clock the kernel actually ran at (GRBM_GUI_ACTIVE / duration of the same counter pass; dense
+            # FP64 bodies clock below the 2.4 GHz maximum), and against the nominal maximum for comparison
+            clk = float(vp.get("effective_clock_GHz") or 2.4)
+            out["k2_rates"]["valu_util"] = vp["valu_insts_per_frame"] * n_fr * 4.0 / (1024 * clk * 1e9 * t_s)
+            out["k2_rates"]["valu_util_at_nominal_2.4GHz"] = vp["valu_insts_per_frame"] * n_fr * 4.0 / (1024 * 2.4e9 * t_s)
+            out["k2_rates"]["effective_clock_GHz"] = clk
             out["k2_rates"]["valu_insts_per_p3p_solve"] = vp["valu_insts_per_frame"] * 64.0 * n_fr / max(1, solves)
-            out["k2_rates"]["valu_source"] = "profiles/round2_pmc.json k2_vote_valu[%s] (%s), kernel %s" % (
-                args.config, vp.get("from", ""), vp.get("kernel", ""))
+            out["k2_rates"]["valu_source"] = "profiles/round3_pmc.json k2_vote_valu[%s] (%s), kernel %s; counters from a " \
+                                             "build of the sources timed here: %s" % (
+                args.config, vp.get("from", ""), vp.get("kernel", ""), pmc_matches_binary)
         if host_leg is not None:
             out["host_streamed_fps"] = host_leg["fps"]
             out["host_streamed"] = host_leg

@@ -67,6 +67,17 @@ def build_library(force=False):
     return _LIB
 
 
+def source_fingerprint():
+    """sha256 (16 hex digits) over the kernel / ABI sources of libmpe_hip.so: ties committed profiler passes
+    (profiles/round3_pmc.json) to the code a bench run times."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for name in ("mpe_kernels.hip", "mpe_p3p.h", "mpe_internal.h", "mpe_abi.cpp"):
+        with open(os.path.join(_CSRC, name), "rb") as fh:
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:16]
+
+
 def exported_symbols():
     """Function names declared in include/mpe.h (used by the symbol-export test)."""
     txt = open(_HEADER).read()

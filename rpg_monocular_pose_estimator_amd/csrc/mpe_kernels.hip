@@ -1603,6 +1603,7 @@ struct K2Frame {
   u64* vq;        // this wave's queue of deferred exact votes, K2_VQ_CAP entries of K2_VQ_WORDS u64 (scan variant;
                   // its fill count is a wave-uniform register of the caller)
   int vq_lanes;   // lanes that work the queue off together: 64 (1 when the host-tier test runs this source)
+  int pj_base;    // first permutation of the table `tab` points at (0: the whole table; plain variant with LDS slices)
 };
 
 // i-th double of the LDS copy of the marker-permutation table (scan-carrying variant), K2_LTAB per permutation:
@@ -1705,14 +1706,14 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
   const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
   const bool swap = (ii >> 24) & 1;
   const int packed = SCAN ? (int)F.ltab[pj * K2_LTAB + 4]
-                          : (int)F.tab[(size_t)pj * F.esz + 16];  // marker indices of this permutation
+                          : (int)F.tab[(size_t)(pj - F.pj_base) * F.esz + 16];  // marker indices of this permutation
   const int p0 = packed & 0xFF, p1 = (packed >> 8) & 0xFF, p2 = (packed >> 16) & 0xFF;
   const int r6 = pj % 6;
   const int pjs = swap ? (pj - r6 + (int)((0x134052u >> (4 * r6)) & 7u)) : pj;  // kSwapRow packed
   // e[12..] of the global table entry; in the scan-carrying variant e points into the LDS copy, shifted so
   // that the SAME indices work for p_1 p_2 d_12 valid (12..15), and the markers are read through lt below
   const double* lt = SCAN ? F.ltab + pjs * K2_LTAB : nullptr;
-  const double* e = SCAN ? lt - 12 : F.tab + (size_t)pjs * F.esz;
+  const double* e = SCAN ? lt - 12 : F.tab + (size_t)(pjs - F.pj_base) * F.esz;
   if (e[15] == 0.0) {  // collinear world points: computePoses returns -1
     if constexpr (SCAN)
       live = false;
@@ -2059,12 +2060,14 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
         s_slice[i] = tab[(size_t)(p_lo + pe) * esz + 12 + fld];
       }
       __syncthreads();
-      tab_eff = s_slice - (size_t)p_lo * LT - 12;  // so that tab_eff + pj * LT + 12 is field 12 of permutation pj
+      // (the item indexes the table with pj - pj_base: no pointer ever leaves the LDS allocation — an LDS pointer is a
+      //  32-bit offset, and one that wraps below zero is not an address)
+      tab_eff = s_slice - 12;  // so that tab_eff + (pj - p_lo) * LT + 12 is field 12 of permutation pj
       esz_eff = LT;
     }
   }
   const K2Frame F = {s_trii, s_tri, s_px, s_pxf, s_q,  s_qf, s_hist, tab_eff,     s_tab,   n_d,  nuo,
-                     nthr,   tid,   esz_eff, fx, fy,   cx,   cy,     sp.back_tol, thr_pre, s_vq, 64};
+                     nthr,   tid,   esz_eff, fx, fy,   cx,   cy,     sp.back_tol, thr_pre, s_vq, 64, p_lo};
   int vq_count = 0;  // entries in this wave's queue (wave-uniform)
   for (int tc0 = 0; tc0 < n_combos; tc0 += TRI) {
     const int ntri = min(TRI, n_combos - tc0);

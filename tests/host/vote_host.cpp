@@ -87,7 +87,7 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   std::vector<u64> vq((size_t)K2_VQ_CAP * K2_VQ_WORDS, 0);
   const K2Frame F = {trii.data(), reinterpret_cast<const double(*)[13]>(tri.data()), px, pxf, q.data(), qf.data(),
                      hist, tab.data(), ltab.data(), n_d, nuo, 1, 0, esz, sp.fx, sp.fy, sp.cx, sp.cy, sp.back_tol,
-                     k2_prefilter_threshold(sp.back_tol), vq.data(), 1};
+                     k2_prefilter_threshold(sp.back_tol), vq.data(), 1, 0};
   NoRider rider;
   if (variant == 1) {
     if (nuo > 2) return -2;  // the scan-carrying variant keeps at most two back-projections (in registers)
