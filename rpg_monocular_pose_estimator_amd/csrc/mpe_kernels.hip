@@ -2266,6 +2266,9 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
       }
     }
   }
+  // table slices: a block's items are 64 staged triples x its share of the permutations — full-size blocks (a 64-thread
+  // block per slice measured 6 waves per CU and 170 instead of 118 ms per 16 384 C3 frames)
+  if (slice_tab) threads = K2_THREADS;
   // plain kernel: 24 bytes of dynamic LDS per thread and unused marker (double + single precision back-projections) on
   // top of ~10.5 KB static; the block shrinks until both fit the 64 KB a block may have without an opt-in (14 - 16
   // markers: 192 / 128 threads)
