@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--scan-split-pct", type=int, default=30, help="mode 6: share of a sub-batch scanned on the side stream")
     ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
     ap.add_argument("--vote-arith", type=int, default=1, help="1 fast voting arithmetic (default), 0 strict (IEEE)")
+    ap.add_argument("--vote-splits", type=int, default=0,
+                    help="tuning: 0 automatic, n > 0 blocks per frame over the flattened items (no table slices)")
     ap.add_argument("--no-streaming", action="store_true",
                     help="one joined mpe_estimate_batch_device call per step instead of the submit / collect stream of batches")
     ap.add_argument("--no-records-to-host", dest="records_to_host", action="store_false",
@@ -191,6 +193,7 @@ def main():
     h.set_option("pipeline", args.pipeline)
     h.set_option("pipeline_mode", args.pipeline_mode)
     h.set_option("vote_arith", args.vote_arith)
+    h.set_option("vote_splits", args.vote_splits)
     h.set_option("scan_split_pct", args.scan_split_pct)
     h.set_option("side_scan_blocks", args.side_scan_blocks)
     if args.k1a_lds >= 0:
@@ -292,7 +295,7 @@ def main():
     rider_kib = h.get_option("last_rider_kib")
     # (more than 5 markers: the voting kernel cannot carry the scan -- its LDS table would not fit -- and every
     #  sub-batch is scanned by a stand-alone k1a_scan although the schedule is nominally fused: rider bytes 0)
-    fused = schedule in (3, 4, 6) and launches > 1 and rider_kib > 0
+    fused = schedule in (3, 4, 6, 7) and launches > 1 and rider_kib > 0
     if fused:
         # fused schedule: the scan of sub-batch s+1 runs INSIDE the voting kernel of sub-batch s; only the first
         # sub-batch is scanned by a stand-alone k1a_scan launch.  Average the launches that do the same thing.
@@ -415,7 +418,8 @@ def main():
                        "frames_per_gpu_per_step": B, "frames_resident_in_hbm": True,
                        "streams_per_gpu": args.pipeline,
                        "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel", 4: "fused + validate/refine on a side stream",
-                                    6: "fused + side-stream tail + scan split between a side k1a_scan and the rider"}.get(schedule, schedule),
+                                    6: "fused + side-stream tail + scan split between a side k1a_scan and the rider",
+                                    7: "votes back to back carrying the scan of sub-batch s + 2, blobs and tail beside them"}.get(schedule, schedule),
                        "side_streams_concurrent": h.get_option("streams_concurrent"),
                        "entry": ("mpe_estimate_batch_device_submit / _collect: a stream of batches, each announcing the "
                                  "next one's frames" if streaming else "mpe_estimate_batch_device, one joined call per step"),

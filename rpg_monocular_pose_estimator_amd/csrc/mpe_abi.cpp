@@ -96,8 +96,13 @@ struct mpe_handle {
   // image scan of the NEXT submission's first sub-batch, carried by the last voting launch of this one
   struct Prefetch {
     bool valid = false;
+    int schedule = 0;         // schedule that produced it (the consumer must run the same one)
     const uint8_t* frames = nullptr;
-    int per = 0;              // frames of that sub-batch
+    int per = 0;              // frames of that sub-batch (the first one)
+    int count = 0;            // sub-batches scanned ahead: 1 (schedule 6) or up to 2 (schedule 7)
+    int n[2] = {0, 0};        // frames of each
+    int stride = 0;           // frames between their starts
+    unsigned long long* flags_ptr[2] = {nullptr, nullptr};  // where their flag words are
     size_t frame_bytes = 0;
     int thr = 0;
     void* flags_base = nullptr;  // flags buffer the prefetched words live in (a re-allocation loses them)
@@ -105,6 +110,7 @@ struct mpe_handle {
     bool side_part = false;      // part of it came from the side scan: wait for prefetch_side_done
   } prefetch;
   hipEvent_t prefetch_side_done = nullptr;
+  hipEvent_t prefetch_ev[2] = {nullptr, nullptr};  // schedule 7: the vote that carried prefetched sub-batch k has finished
   bool done_recorded = false;  // run_pipeline has recorded batch_done[submit_seq & 1] itself (fused schedules)
   int last_nsub = 0, last_per = 0;  // work-list layout of the last pipelined batch (option "overflow_*")
   // side streams of schedules 4 / 6 verified (spin probe) to execute beside the caller's stream
@@ -524,6 +530,191 @@ int ensure_side_streams(mpe_handle* h, bool need_scan) {
   return MPE_OK;
 }
 
+// Schedule 7, "deep" fused schedule.  The voting kernels run back to back on the caller's stream, vote(s) carrying the
+// WHOLE image scan of sub-batch s + 2 (ScanRider); the blob extraction of sub-batch s + 1 — whose scan finished with
+// vote(s - 1) — runs on a side stream beside vote(s), validate / refine of sub-batch s - 1 on the tail stream:
+//   caller's stream  vote(0)+scan(2) | vote(1)+scan(3) | vote(2)+scan(4) | ...
+//   blob stream      blobs(1)        | blobs(2)        | blobs(3)        | ...
+//   tail stream                      | tail(0)         | tail(1)         | ...
+// There is no window in which no image bytes move (schedule 6 has one per sub-batch: the blob extraction, during which
+// its side scan reaches 3.5 TB/s), and the only serial chain is vote -> vote.  Streaming (StreamHint): the last two
+// voting launches carry the scans of the first TWO sub-batches of the next submission, whose blob extraction of
+// sub-batch 0 then runs beside the last vote of this one — submissions join without a gap.
+int run_deep(mpe_handle* h, const uint8_t* d_frames, int n_frames, const FrameGeom& g, const DetectParams& dp,
+             const SolveParams& sp, mpe_detections* d_dets, uint32_t* d_hist, mpe_result* d_results, uint32_t* d_corr,
+             const StreamHint* hint, const mpe_handle::Prefetch& pf, int nsub, int per) {
+  const size_t frame_bytes = (size_t)g.rows * g.pitch;
+  const size_t fw_per = flag_words(frame_bytes * per);
+  const bool prof = h->profiling;
+  hipStream_t st = h->stream, bst = h->scan_stream, tst = h->tail_stream;
+  auto make = [&](hipEvent_t& e) -> hipError_t { return e ? hipSuccess : hipEventCreateWithFlags(&e, hipEventDisableTiming); };
+  for (int i = 0; i < mpe_handle::kMaxSub; ++i) {
+    HIP_TRY(h, make(h->vote_done[i]));
+    HIP_TRY(h, make(h->scanpart_done[i]));  // (here: blobs(i) done)
+    HIP_TRY(h, make(h->tail_sub_done[i]));
+    HIP_TRY(h, make(h->scan_done[i]));
+  }
+  HIP_TRY(h, make(h->fork_ev));
+  HIP_TRY(h, make(h->prefetch_ev[0]));
+  HIP_TRY(h, make(h->prefetch_ev[1]));
+  for (auto& e : h->batch_done) HIP_TRY(h, make(e));
+  h->last_rider_bytes = 0;
+  h->last_nsub = nsub;
+  h->last_per = per;
+  unsigned long long* flags_base = static_cast<unsigned long long*>(h->flags.p);
+  int n_real = 0;
+  while (n_real < nsub && n_real * per < n_frames) ++n_real;
+  auto real_n = [&](int v) { return std::min(per, n_frames - v * per); };
+  // how many of this call's first sub-batches the previous submission scanned
+  int pf_count = 0;
+  if (pf.valid && pf.schedule == 7 && pf.frames == d_frames && pf.frame_bytes == frame_bytes && pf.thr == dp.thr &&
+      pf.flags_base == h->flags.p && pf.fw_per == fw_per && pf.stride == per) {
+    while (pf_count < pf.count && pf_count < n_real && pf.n[pf_count] == real_n(pf_count)) ++pf_count;
+  }
+  // the next submission's first two sub-batches, if the caller announced it and it will run this schedule as well
+  int next_n[2] = {0, 0}, next_stride = 0;
+  if (hint && hint->next_frames && hint->n_next > 0) {
+    int nn, np;
+    sub_batch_shape(h, hint->n_next, frame_bytes, true, sp.vote_arith, nn, np);
+    if (nn >= 3 && hint->n_next > 2 * np && flag_words(frame_bytes * np) <= fw_per) {
+      next_n[0] = np;
+      next_n[1] = np;
+      next_stride = np;
+    }
+  }
+  // virtual sub-batch v: v < n_real = of this call; n_real, n_real + 1 = the next submission's first two
+  auto sub_ptrs = [&](int v, int& f0, int& nf, const uint8_t*& fr, unsigned long long*& fl) -> bool {
+    if (v < n_real) {
+      f0 = v * per;
+      nf = real_n(v);
+      fr = d_frames + (size_t)f0 * frame_bytes;
+      fl = v < pf_count ? pf.flags_ptr[v] : flags_base + fw_per * v;
+      return true;
+    }
+    const int k = v - n_real;
+    if (k > 1 || next_n[k] == 0) return false;
+    f0 = k * next_stride;
+    nf = next_n[k];
+    fr = hint->next_frames + (size_t)f0 * frame_bytes;
+    fl = flags_base + fw_per * (nsub + k);
+    return true;
+  };
+  const bool tail_was_pending = h->tail_sub_pending;
+  const int tail_was_last = h->tail_last;
+  int f0, nf;
+  const uint8_t* fr;
+  unsigned long long* fl;
+  // the blob stream joins this call: behind the caller's stream as of now, or — streaming — behind the vote that
+  // finished the scan of sub-batch 0 (so that blobs(0) run beside the LAST vote of the previous submission)
+  if (pf_count == 0) {
+    HIP_TRY(h, hipEventRecord(h->fork_ev, st));
+    HIP_TRY(h, hipStreamWaitEvent(bst, h->fork_ev, 0));
+  } else {
+    HIP_TRY(h, hipStreamWaitEvent(bst, h->prefetch_ev[0], 0));
+  }
+  HIP_TRY(h, hipMemsetAsync(h->work.p, 0, (size_t)2 * (per + 1) * nsub * sizeof(int), bst));
+  // sub-batches 0 / 1 that nobody scanned ahead: stand-alone scans on the caller's stream
+  for (int v = 0; v < 2 && v < n_real; ++v) {
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[v][0], st));
+    if (v >= pf_count) {
+      sub_ptrs(v, f0, nf, fr, fl);
+      HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, scan_lds(h, false), st));
+      HIP_TRY(h, hipEventRecord(h->scan_done[v], st));
+    }
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[v][1], st));
+  }
+  auto blobs = [&](int v) -> int {
+    if (v >= n_real) return MPE_OK;
+    sub_ptrs(v, f0, nf, fr, fl);
+    // what finished the scan of sub-batch v
+    if (v < pf_count) {
+      HIP_TRY(h, hipStreamWaitEvent(bst, h->prefetch_ev[v], 0));
+    } else if (v < 2) {
+      HIP_TRY(h, hipStreamWaitEvent(bst, h->scan_done[v], 0));
+    } else {
+      HIP_TRY(h, hipStreamWaitEvent(bst, h->vote_done[v - 2], 0));
+    }
+    // streaming: the tail of the PREVIOUS submission has read the detections / histograms of this region
+    if (tail_was_pending) HIP_TRY(h, hipStreamWaitEvent(bst, h->tail_sub_done[std::min(v, tail_was_last)], 0));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[v][2], bst));
+    HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0, static_cast<int*>(h->work.p) + (size_t)v * 2 * (per + 1),
+                                static_cast<uint8_t*>(h->scratch.p), sp.n_markers, bst, nullptr, true));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[v][3], bst));
+    HIP_TRY(h, hipEventRecord(h->scanpart_done[v], bst));
+    return MPE_OK;
+  };
+  { const int rc = blobs(0); if (rc) return rc; }
+  for (int s = 0; s < n_real; ++s) {
+    { const int rc = blobs(s + 1); if (rc) return rc; }  // (beside vote(s))
+    sub_ptrs(s, f0, nf, fr, fl);
+    HIP_TRY(h, hipStreamWaitEvent(st, h->scanpart_done[s], 0));
+    uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
+    const int splits = auto_splits(h, nf, sp.n_markers);
+    if (sp.vote_arith == 0 || splits != 1)
+      HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), st));
+    int nf0, nnf = 0;
+    const uint8_t* nfr = nullptr;
+    unsigned long long* nfl = nullptr;
+    const bool carries = sub_ptrs(s + 2, nf0, nnf, nfr, nfl);
+    const size_t nbytes = carries ? (size_t)nnf * frame_bytes : 0;
+    size_t scanned = 0;
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], st));
+    HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, sp, static_cast<const double*>(h->mtab.p), hs, splits, sp.n_markers, st,
+                              nbytes ? nfr : nullptr, nbytes, nfl, dp.thr, &scanned));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], st));
+    if (scanned > h->last_rider_bytes) h->last_rider_bytes = scanned;
+    const bool real_next = s + 2 < n_real;
+    if (prof && real_next) HIP_TRY(h, hipEventRecord(h->pev[s + 2][0], st));
+    if (nbytes > scanned)  // what the riders left over: less than one chunk, or everything if they could not run
+      HIP_TRY(h, launch_k1a_scan(nfr + scanned, nbytes - scanned, nfl + scanned / 1024, dp.thr, scan_lds(h, false), st));
+    if (prof && real_next) HIP_TRY(h, hipEventRecord(h->pev[s + 2][1], st));
+    HIP_TRY(h, hipEventRecord(h->vote_done[s], st));
+    if (carries && s + 2 >= n_real) HIP_TRY(h, hipEventRecord(h->prefetch_ev[s + 2 - n_real], st));
+    HIP_TRY(h, hipStreamWaitEvent(tst, h->vote_done[s], 0));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], tst));
+    HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, sp, d_results + f0,
+                              d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0,
+                              static_cast<uint8_t*>(h->mid.p) + k3_mid_bytes(1) * (size_t)f0, tst));
+    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], tst));
+    HIP_TRY(h, hipEventRecord(h->tail_sub_done[s], tst));
+    h->tail_last = s;
+  }
+  h->tail_sub_pending = true;
+  if (next_n[0] > 0) {
+    mpe_handle::Prefetch& q = h->prefetch;
+    q.valid = true;
+    q.schedule = 7;
+    q.frames = hint->next_frames;
+    q.per = next_n[0];
+    q.count = next_n[1] > 0 ? 2 : 1;
+    q.n[0] = next_n[0];
+    q.n[1] = next_n[1];
+    q.stride = next_stride;
+    q.flags_ptr[0] = flags_base + fw_per * nsub;
+    q.flags_ptr[1] = flags_base + fw_per * (nsub + 1);
+    q.frame_bytes = frame_bytes;
+    q.thr = dp.thr;
+    q.flags_base = h->flags.p;
+    q.fw_per = fw_per;
+    q.side_part = false;
+  }
+  hipEvent_t done = h->batch_done[h->submit_seq & 1];
+  HIP_TRY(h, hipEventRecord(done, tst));
+  h->done_recorded = true;
+  if (!(hint && hint->no_join)) {  // join: the call behaves like one operation on the caller's stream
+    HIP_TRY(h, hipStreamWaitEvent(st, done, 0));
+    HIP_TRY(h, hipStreamWaitEvent(st, h->scanpart_done[n_real - 1], 0));
+    h->tail_sub_pending = false;
+  }
+  if (prof) {
+    h->prof_launches = n_real;
+    h->have_ms = true;
+    h->prof_pipelined = true;
+    h->prof_frames_per_launch = per;
+  }
+  return MPE_OK;
+}
+
 int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const FrameGeom& g, const DetectParams& dp,
                  const SolveParams* sp, mpe_detections* d_dets, uint32_t* d_hist, mpe_result* d_results,
                  uint32_t* d_corr, const StreamHint* hint = nullptr) {
@@ -571,8 +762,8 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
         if (!h->pev[s][k]) HIP_TRY(h, hipEventCreate(&h->pev[s][k]));
   // Software pipeline over nsub sub-batches on two streams: A runs scan + blobs, B voting + tail.
   const size_t fw_per = flag_words(frame_bytes * per);
-  // (one region per sub-batch + one for the first sub-batch of the NEXT submission, see StreamHint)
-  HIP_TRY(h, h->flags.reserve(fw_per * (nsub + 1) * 8));
+  // (one region per sub-batch + two for the first sub-batches of the NEXT submission, see StreamHint)
+  HIP_TRY(h, h->flags.reserve(fw_per * (nsub + 2) * 8));
   HIP_TRY(h, h->work.reserve((size_t)2 * (per + 1) * nsub * sizeof(int)));
   // schedule = option "pipeline_mode": -1 (default) = automatic = 6 (fused voting + scan, validate / refine on a side
   // stream, the scan split between a side k1a_scan and the rider); 3 / 4 = its one-stream / no-split-scan variants;
@@ -590,14 +781,16 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (h->streams_concurrent == 0) schedule = 6;
   }
   h->last_schedule = schedule;
-  if (schedule == 4 || schedule == 6) {
+  if (schedule == 4 || schedule == 6 || schedule == 7) {
     // the side streams of these schedules only pay when they really execute beside the caller's stream: verify it
     // once per (handle, caller stream) with the spin probe; without a concurrent triple -> schedule 3 (one stream)
-    const int rc = ensure_side_streams(h, schedule == 6 && h->scan_split_pct > 0);
+    const int rc = ensure_side_streams(h, schedule == 7 || (schedule == 6 && h->scan_split_pct > 0));
     if (rc) return rc;
     if (h->side_streams_ok == 0) schedule = 3;
+    if (schedule == 7 && (nsub < 3 || n_frames <= 2 * per)) schedule = 6;
     h->last_schedule = schedule;
   }
+  if (schedule == 7) return run_deep(h, d_frames, n_frames, g, dp, *sp, d_dets, d_hist, d_results, d_corr, hint, pf, nsub, per);
   if (schedule == 3 || schedule == 4 || schedule == 6) {
     const bool side_tail = schedule != 3;
     // mode 6: the HBM stream is spread over the whole sub-batch period.  In modes 3 / 4 the voting kernel scans all
@@ -635,9 +828,9 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     hipStream_t st = h->stream;
     unsigned long long* flags_base = static_cast<unsigned long long*>(h->flags.p);
     // was sub-batch 0 of THIS call scanned by the previous submission?
-    const bool prefetched = pf.valid && pf.frames == d_frames && pf.per == std::min(per, n_frames) &&
-                            pf.frame_bytes == frame_bytes && pf.thr == dp.thr && pf.flags_base == h->flags.p &&
-                            pf.fw_per == fw_per;
+    const bool prefetched = pf.valid && pf.schedule != 7 && pf.frames == d_frames &&
+                            pf.per == std::min(per, n_frames) && pf.frame_bytes == frame_bytes && pf.thr == dp.thr &&
+                            pf.flags_base == h->flags.p && pf.fw_per == fw_per && pf.flags_ptr[0] != nullptr;
     // the next submission's first sub-batch, if the caller announced it and it will run pipelined as well
     int next_per = 0;
     if (hint && hint->next_frames && hint->n_next > 0) {
@@ -657,7 +850,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       f0 = s * per;
       nf = std::min(per, n_frames - f0);
       fr = d_frames + (size_t)f0 * frame_bytes;
-      fl = flags_base + fw_per * ((s == 0 && prefetched) ? nsub : s);
+      fl = (s == 0 && prefetched) ? pf.flags_ptr[0] : flags_base + fw_per * s;
     };
     // number of real sub-batches (the last ones may be empty when n_frames is not a multiple of `per`)
     int n_real = 0;
@@ -766,6 +959,9 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     h->tail_sub_pending = side_tail;
     if (next_per > 0) {  // sub-batch 0 of the next submission has been scanned into the extra region
       h->prefetch.valid = true;
+      h->prefetch.schedule = schedule;
+      h->prefetch.count = 1;
+      h->prefetch.flags_ptr[0] = flags_base + fw_per * nsub;
       h->prefetch.frames = hint->next_frames;
       h->prefetch.per = next_per;
       h->prefetch.frame_bytes = frame_bytes;
@@ -987,6 +1183,8 @@ void mpe_destroy(mpe_handle* h) {
   for (auto& e : h->tail_sub_done)
     if (e) (void)hipEventDestroy(e);
   if (h->prefetch_side_done) (void)hipEventDestroy(h->prefetch_side_done);
+  for (auto& e : h->prefetch_ev)
+    if (e) (void)hipEventDestroy(e);
 
   if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
   if (h->scan_stream) (void)hipStreamDestroy(h->scan_stream);
@@ -1122,9 +1320,10 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
     return MPE_OK;
   }
   if (!std::strcmp(name, "pipeline_mode")) {
-    if (value != -1 && value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 6)
-      return fail(h, MPE_ERR_ARG, "pipeline_mode must be -1 (automatic), 0, 1, 2, 3, 4 or 6");
+    if (value != -1 && value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 6 && value != 7)
+      return fail(h, MPE_ERR_ARG, "pipeline_mode must be -1 (automatic), 0, 1, 2, 3, 4, 6 or 7");
     h->pipeline_mode = value;
+    h->prefetch.valid = false;  // (words scanned ahead by another schedule are not picked up)
     return MPE_OK;
   }
   if (!std::strcmp(name, "pipeline")) {
