@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--group-threads", type=int, default=1,
                     help="--lockstep --groups G: drive the groups from this many host threads "
                          "(mpe_tracker_run_sequences_batch_threads)")
+    ap.add_argument("--wait-spin", type=int, default=-1, help="tuning: 1 = the tracked frame polls its stream, 0 = blocks")
     ap.add_argument("--lockstep", action="store_true",
                     help="all streams of a rank on ONE handle, driven in lock step: one device submission per time "
                          "step for all of them (mpe_tracker_run_sequences_batch) instead of one host thread per stream")
@@ -132,10 +133,18 @@ def main():
         trackers[i].reset()
     # one stream alone (latency), then all streams of this rank at once (throughput)
     solo = None
+    host_ns = None
+    if args.wait_spin >= 0:
+        for hd in handles:
+            hd.set_option("track_wait_spin", args.wait_spin)
     if mine:
+        handles[0].set_option("track_profile", 1)
         t0 = time.perf_counter()
         trackers[0].run_sequence(seqs[0]["frames"], seqs[0]["times"])
         solo = (time.perf_counter() - t0) / args.frames
+        host_ns = {k: handles[0].get_option("track_ns_" + k) for k in ("pack", "enqueue", "wait")}
+        host_ns["steps"] = handles[0].get_option("track_steps")
+        handles[0].set_option("track_profile", 0)
         trackers[0].reset()
     if world > 1:
         dist.barrier()
@@ -163,6 +172,7 @@ def main():
                "streams_per_gpu": len(mine), "frames_per_stream": args.frames, "higher_is_better": True,
                "data": "synthetic", "dtype": "f64", "frames_in": "pageable host memory",
                "latency_ms_per_frame_one_stream_alone": solo * 1e3 if solo else None,
+               "tracked_step_host_ns_one_stream_alone": host_ns,
                "latency_ms_per_frame_streams_concurrent": float(np.mean(lat)) * 1e3 if lat else None,
                "poses_found_frac": n_pose / max(1, n_frames), "bruteforce_frac": n_brute / max(1, n_frames),
                "config": {"workload": "%s sequences (constant twist + jitter, 50 Hz), demo.launch parameters" % args.config}}

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -53,6 +54,9 @@ struct mpe_handle {
   DevBuf frames, flags, dets, hist, results, corr, mtab, work, scratch, track, mid;
   void* mailbox = nullptr;  // pinned host memory for the single-frame tracking step (ROI in, record out)
   size_t mailbox_cap = 0;
+  // host-side time of the tracked frame (option "track_profile" = 1 starts / resets): sums in ns
+  int track_profile = 0, track_wait_spin = 0;
+  long long track_ns[3] = {0, 0, 0}, track_steps = 0;  // pack, enqueue, wait
   int pending_track_n = 0;            // mpe_track_step_batch_submit without its _collect yet: streams in flight
   const uint8_t* pending_track_rec = nullptr;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
@@ -1279,6 +1283,11 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "k1a_dummy_lds") *value = h->k1a_dummy_lds;
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
+  else if (n == "track_wait_spin") *value = h->track_wait_spin;
+  else if (n == "track_steps") *value = (int)h->track_steps;
+  else if (n == "track_ns_pack") *value = (int)(h->track_ns[0] / std::max(1LL, h->track_steps));
+  else if (n == "track_ns_enqueue") *value = (int)(h->track_ns[1] / std::max(1LL, h->track_steps));
+  else if (n == "track_ns_wait") *value = (int)(h->track_ns[2] / std::max(1LL, h->track_steps));
   else if (n.rfind("overflow_", 0) == 0) {
     // statistics of the last large batch (synchronises): frames the first blob tier handed on, in all
     // ("overflow_frames") or by the capacity that was exceeded ("overflow_why_1" .. 6: bright segments, bands,
@@ -1329,6 +1338,16 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   if (!std::strcmp(name, "pipeline")) {
     if (value < 1 || value > mpe_handle::kMaxSub) return fail(h, MPE_ERR_ARG, "pipeline out of range");
     h->pipeline = value;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "track_profile")) {  // 1: start / reset the host-side timers of mpe_track_step ("track_ns_*")
+    h->track_profile = value != 0;
+    h->track_ns[0] = h->track_ns[1] = h->track_ns[2] = 0;
+    h->track_steps = 0;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "track_wait_spin")) {  // 1: mpe_track_step polls the stream instead of blocking in the runtime
+    h->track_wait_spin = value != 0;
     return MPE_OK;
   }
   if (!std::strcmp(name, "vote_splits")) {
@@ -1663,6 +1682,9 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
     return fail(h, MPE_ERR_ARG, "ROI outside the image");
   if (h->pending_track_n) return fail(h, MPE_ERR_ARG, "a submitted batch has not been collected yet (shared staging memory)");
   ENTER(h);
+  using clk = std::chrono::steady_clock;
+  const clk::time_point t_in = h->track_profile ? clk::now() : clk::time_point();
+  clk::time_point t_packed, t_queued;
   FrameGeom g;
   if (make_geom(h, roi_h, roi_w, g)) return fail(h, MPE_ERR_UNSUPPORTED, "frame size unsupported");
   DetectParams dp;
@@ -1704,16 +1726,40 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   uint8_t* d_in = static_cast<uint8_t*>(h->frames.p);
   TrackRecord* d_rec = static_cast<TrackRecord*>(h->track.p);
   h->have_ms = false;
+  if (h->track_profile) t_packed = clk::now();
   HIP_TRY(h, hipMemcpyAsync(d_in, mb, in_bytes, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, launch_k1a_scan(d_in + kTrackHeader, roi_bytes, static_cast<unsigned long long*>(h->flags.p), dp.thr, 0,
                              h->stream));
-  HIP_TRY(h, launch_k1b_blobs(d_in + kTrackHeader, static_cast<unsigned long long*>(h->flags.p), 1, g, dp, &d_rec->det,
-                              static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), sp.n_markers, h->stream));
-  HIP_TRY(h, launch_k3_tail(&d_rec->det, static_cast<uint32_t*>(h->hist.p), 1, sp, &d_rec->res, d_rec->corr, nullptr,
-                            reinterpret_cast<const double*>(d_in), p->nearest_neighbour_pixel_tolerance, h->mid.p,
-                            h->stream));
-  HIP_TRY(h, hipMemcpyAsync(host_rec, d_rec, sizeof(TrackRecord), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  // the small blob tier alone first (a tracked ROI holds a handful of LEDs): three launches and a memset less per
+  // frame; a frame that overflows it comes back with MPE_FRAME_TOO_MANY_ROWS and is repeated through the whole chain
+  const bool optimistic = sp.n_markers >= 1 && sp.n_markers <= 8;
+  for (int pass = optimistic ? 0 : 1; pass < 2; ++pass) {
+    HIP_TRY(h, launch_k1b_blobs(d_in + kTrackHeader, static_cast<unsigned long long*>(h->flags.p), 1, g, dp, &d_rec->det,
+                                static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), sp.n_markers, h->stream,
+                                nullptr, false, pass == 0));
+    HIP_TRY(h, launch_k3_tail(&d_rec->det, static_cast<uint32_t*>(h->hist.p), 1, sp, &d_rec->res, d_rec->corr, nullptr,
+                              reinterpret_cast<const double*>(d_in), p->nearest_neighbour_pixel_tolerance, h->mid.p,
+                              h->stream));
+    HIP_TRY(h, hipMemcpyAsync(host_rec, d_rec, sizeof(TrackRecord), hipMemcpyDeviceToHost, h->stream));
+    if (h->track_profile) t_queued = clk::now();
+    if (h->track_wait_spin) {  // poll instead of blocking in the runtime's wait
+      hipError_t q;
+      while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) {
+      }
+      HIP_TRY(h, q);
+    } else {
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    if (host_rec->det.status != MPE_FRAME_TOO_MANY_ROWS) break;
+  }
+  if (h->track_profile) {
+    const clk::time_point t_done = clk::now();
+    auto ns = [](clk::time_point a, clk::time_point b) { return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
+    h->track_ns[0] += ns(t_in, t_packed);
+    h->track_ns[1] += ns(t_packed, t_queued);
+    h->track_ns[2] += ns(t_queued, t_done);
+    ++h->track_steps;
+  }
   *dets_out = host_rec->det;
   std::memcpy(corr_out, host_rec->corr, sizeof(host_rec->corr));
   *out = host_rec->res;

@@ -67,9 +67,11 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
                             int blob_hint, hipStream_t s, const void* frame_windows = nullptr,
-                            bool lists_zeroed = false);
+                            bool lists_zeroed = false, bool first_tier_only = false);
 // worklist: 2 * (n_frames + 1) ints (two device work-lists that chain the capacity tiers); lists_zeroed = the caller
 // has zeroed it in stream order already (one memset for all the sub-batches of a call) and no memset is issued here.
+// first_tier_only: launch the small-pool tier alone (blob_hint 1 .. 8); frames it cannot hold keep status
+// MPE_FRAME_TOO_MANY_ROWS and the caller repeats them through the whole chain.
 // frame_windows: optional device array of n_frames x {rows, cols, roi_x, roi_y} ints — every frame then is a window
 // of that size in the top-left corner of its g.rows x g.pitch slot (zero beyond), as when LEDDetector::findLeds clones
 // image(ROI) (led_detector.cpp:44): borders follow the window, centroids get its ROI origin added.

@@ -1269,8 +1269,20 @@ size_t k1b_scratch_bytes(const FrameGeom& g) { return k1b_gen_scratch_bytes(g) *
 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
-                            int blob_hint, hipStream_t s, const void* frame_windows, bool lists_zeroed) {
+                            int blob_hint, hipStream_t s, const void* frame_windows, bool lists_zeroed,
+                            bool first_tier_only) {
   const FrameWin* wins = static_cast<const FrameWin*>(frame_windows);
+  if (first_tier_only) {
+    // low-latency tracked frame: the small tier alone, nothing queued behind it.  A frame that overflows it is left
+    // with status MPE_FRAME_TOO_MANY_ROWS and no work-list entry; the caller sees that in the record it fetches
+    // anyway and repeats the frame through the whole chain (three launches and a memset less on every other frame)
+    if (n_frames <= 0) return hipSuccess;
+    if (blob_hint <= 0 || blob_hint > 8) return hipErrorInvalidValue;
+    const int blocks = (n_frames + K1bSmall::WAVES - 1) / K1bSmall::WAVES;
+    hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64 * K1bSmall::WAVES), 0, s, frames, (const u64*)flags, g,
+                       dp, dets, (int*)nullptr, n_frames, wins);
+    return hipGetLastError();
+  }
   // Three tiers, chained through device work-lists (no host round trip):
   //   small LDS pools (4 waves/SIMD) -> large LDS pools -> whole-frame window in global scratch
   // (Running the follow-up tiers on a side stream beside the voting kernel, whose blocks then waited for the few
@@ -2620,6 +2632,7 @@ __global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restr
 #define s_q(j_, t_) s_q_[(j_)*64 + (t_)]
   __shared__ double s_mean[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS * 3];
   __shared__ double s_det[K3_FRAMES_PER_BLOCK][MPE_MAX_DETECTIONS][2];
+  __shared__ double s_pred[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS][2];
   __shared__ double s_mk[MPE_MAX_MARKERS][3];
   __shared__ unsigned s_valid[K3_FRAMES_PER_BLOCK][K3_GROUP];
   __shared__ unsigned char s_cm[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS], s_cd[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS];
@@ -2646,6 +2659,12 @@ __global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restr
     s_det[grp][i][0] = d->undist_xy[2 * i];
     s_det[grp][i][1] = d->undist_xy[2 * i + 1];
   }
+  if (nn_pred && live)  // (tracking path: lane 0's nearest-neighbour search below reads LDS, not a chain of global loads)
+    for (int i = l; i < n_m; i += K3_GROUP) {
+      s_pred[grp][i][0] = nn_pred[(size_t)f * 2 * MPE_MAX_MARKERS + 2 * i];
+      s_pred[grp][i][1] = nn_pred[(size_t)f * 2 * MPE_MAX_MARKERS + 2 * i + 1];
+    }
+  wave_sync();  // (the block is one wave)
   if (live && MODE != 2) {  // (MODE 2: results[f].T holds the start pose for the refinement kernel)
     for (int i = l; i < 16; i += K3_GROUP) res->T[i] = (i % 5 == 0) ? 1.0 : 0.0;
   }
@@ -2676,13 +2695,12 @@ __global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restr
       // tracking path, correspondences found here: findCorrespondences (pose_estimator.cpp:372-392) —
       // nearest detection of every predicted marker pixel (first minimum wins), kept if within
       // nearest_neighbour_pixel_tolerance_
-      const double* pp = nn_pred + (size_t)f * 2 * MPE_MAX_MARKERS;
       for (int i = 0; i < n_m; ++i) {
         double best = __builtin_huge_val();
         int bj = 0;
-        const double pu = pp[2 * i], pv = pp[2 * i + 1];
+        const double pu = s_pred[grp][i][0], pv = s_pred[grp][i][1];
         for (int j = 0; j < n_d; ++j) {
-          const double du = pu - d->undist_xy[2 * j], dv = pv - d->undist_xy[2 * j + 1];
+          const double du = pu - s_det[grp][j][0], dv = pv - s_det[grp][j][1];
           const double d2 = du * du + dv * dv;
           if (d2 < best) {
             best = d2;

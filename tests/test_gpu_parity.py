@@ -538,6 +538,31 @@ def test_track_step_matches_oracle_pieces(hip, orc):
 
 
 @pytest.mark.gpu
+def test_track_step_repeats_a_frame_the_small_blob_tier_cannot_hold(hip, orc):
+    """The tracked frame tries the small blob tier alone (no follow-up tiers queued); a ROI with more blobs than that
+    tier records comes back through the whole tier chain, transparently: the detections are the oracle's."""
+    rng = np.random.default_rng(77)
+    d = synth.make_frames("C2", 1, seed=322)
+    gx, gy = np.meshgrid(np.arange(6) * 100 + 80.0, np.arange(4) * 100 + 70.0)
+    spots = np.stack([gx.ravel(), gy.ravel()], 1) + rng.uniform(-10, 10, (24, 2))
+    frame = synth.render_frame(rng, spots, d["rows"], d["cols"])
+    Po, Ph = orc.make_params(), mpe.demo_params()
+    roi = (0, 0, d["cols"], d["rows"])
+    und, _ = orc.find_leds(frame, Po, d["K"], d["D"], roi=roi)
+    assert len(und) > 16                       # more than K1bSmall::KEPT
+    pred = spots[:len(d["markers"])] + 0.3
+    r = hip.track_step(frame, roi, Ph, d["K"], d["D"], d["markers"], pred)
+    assert r["det_status"] == 0 and np.array_equal(r["undist"], und)
+    # and an ordinary frame right after it on the same handle
+    d2 = synth.make_frames("C2", 1, seed=323)
+    pred2 = synth.project(d2["T_true"][0], d2["markers"], d2["K"])
+    roi2 = orc.determine_roi(pred2, d2["rows"], d2["cols"], 20, d2["K"], d2["D"])
+    und2, _ = orc.find_leds(d2["frames"][0], Po, d2["K"], d2["D"], roi=roi2)
+    r2 = hip.track_step(d2["frames"][0], roi2, Ph, d2["K"], d2["D"], d2["markers"], pred2)
+    assert r2["det_status"] == 0 and np.array_equal(r2["undist"], und2)
+
+
+@pytest.mark.gpu
 def test_check_and_optimise_stage_entry_points(hip, orc):
     """checkCorrespondences and optimisePose as separate device calls against the oracle's functions:
     the unrefined pose of computeTransformation, then Gauss-Newton from that pose AND from perturbed
