@@ -85,7 +85,6 @@ def main():
     ap.add_argument("--group-threads", type=int, default=1,
                     help="--lockstep --groups G: drive the groups from this many host threads "
                          "(mpe_tracker_run_sequences_batch_threads)")
-    ap.add_argument("--wait-spin", type=int, default=-1, help="tuning: 1 = the tracked frame polls its stream, 0 = blocks")
     ap.add_argument("--lockstep", action="store_true",
                     help="all streams of a rank on ONE handle, driven in lock step: one device submission per time "
                          "step for all of them (mpe_tracker_run_sequences_batch) instead of one host thread per stream")
@@ -134,9 +133,6 @@ def main():
     # one stream alone (latency), then all streams of this rank at once (throughput)
     solo = None
     host_ns = None
-    if args.wait_spin >= 0:
-        for hd in handles:
-            hd.set_option("track_wait_spin", args.wait_spin)
     if mine:
         handles[0].set_option("track_profile", 1)
         t0 = time.perf_counter()
