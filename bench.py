@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--scan-split-pct", type=int, default=30, help="mode 6: share of a sub-batch scanned on the side stream")
     ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
     ap.add_argument("--vote-arith", type=int, default=1, help="1 fast voting arithmetic (default), 0 strict (IEEE)")
+    ap.add_argument("--early-blobs", type=int, default=0,
+                    help="mode 6: 1 = blob extraction of the side-scanned frames of sub-batch s + 1 beside vote(s)")
     ap.add_argument("--vote-splits", type=int, default=0,
                     help="tuning: 0 automatic, n > 0 blocks per frame over the flattened items (no table slices)")
     ap.add_argument("--no-streaming", action="store_true",
@@ -194,6 +196,7 @@ def main():
     h.set_option("pipeline_mode", args.pipeline_mode)
     h.set_option("vote_arith", args.vote_arith)
     h.set_option("vote_splits", args.vote_splits)
+    h.set_option("early_blobs", args.early_blobs)
     h.set_option("scan_split_pct", args.scan_split_pct)
     h.set_option("side_scan_blocks", args.side_scan_blocks)
     if args.k1a_lds >= 0:

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (first half; the counter passes of the fused launch shape crashed in this script — see collect_round3_final_b.sh)
 # Collects everything under profiles/round3_* in ONE gpurun call on a 1xMI355X box:
 #   gpurun --timeout 2400 -- 'bash profiles/collect_round3.sh'
 # Raw output goes to gpurun_out/final3/; profiles/install_round3.py condenses it into the committed files.

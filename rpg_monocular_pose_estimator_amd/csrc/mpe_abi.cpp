@@ -129,6 +129,13 @@ struct mpe_handle {
   hipEvent_t prefetch_ev[2] = {nullptr, nullptr};  // schedule 7: the vote that carried prefetched sub-batch k has finished
   bool done_recorded = false;  // run_pipeline has recorded batch_done[submit_seq & 1] itself (fused schedules)
   int last_nsub = 0, last_per = 0;  // work-list layout of the last pipelined batch (option "overflow_*")
+  std::vector<std::pair<size_t, int>> blob_launches;  // its blob launches: work-list offset (ints), frames
+  size_t work_ints = 0;
+  // schedule 6, option "early_blobs": blob extraction of the side-scanned frames of sub-batch s + 1 beside vote(s).
+  // Measured on one MI355X (262 144 C2 frames, 20 steps): 19.6 ms per step with it, 18.4-18.6 without — the voting
+  // kernel with its rider leaves no room beside it (the same finding as schedule 7).  Off by default.
+  int early_blobs = 0;
+  hipEvent_t early_done[kMaxSub] = {};
   // side streams of schedules 4 / 6 verified (spin probe) to execute beside the caller's stream
   int side_streams_ok = -1;           // 1 yes, 0 no concurrent set found (-> schedule 3), -1 not probed
   hipStream_t probed_for = nullptr;   // the caller's stream the verdict holds for
@@ -628,7 +635,7 @@ int run_deep(mpe_handle* h, const uint8_t* d_frames, int n_frames, const FrameGe
   } else {
     HIP_TRY(h, hipStreamWaitEvent(bst, h->prefetch_ev[0], 0));
   }
-  HIP_TRY(h, hipMemsetAsync(h->work.p, 0, (size_t)2 * (per + 1) * nsub * sizeof(int), bst));
+  HIP_TRY(h, hipMemsetAsync(h->work.p, 0, (size_t)4 * (per + 1) * nsub * sizeof(int), bst));
   // sub-batches 0 / 1 that nobody scanned ahead: stand-alone scans on the caller's stream
   for (int v = 0; v < 2 && v < n_real; ++v) {
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[v][0], st));
@@ -655,6 +662,7 @@ int run_deep(mpe_handle* h, const uint8_t* d_frames, int n_frames, const FrameGe
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[v][2], bst));
     HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0, static_cast<int*>(h->work.p) + (size_t)v * 2 * (per + 1),
                                 static_cast<uint8_t*>(h->scratch.p), sp.n_markers, bst, nullptr, true));
+    h->blob_launches.emplace_back((size_t)v * 2 * (per + 1), nf);
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[v][3], bst));
     HIP_TRY(h, hipEventRecord(h->scanpart_done[v], bst));
     return MPE_OK;
@@ -755,7 +763,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     }
     return MPE_OK;
   };
-  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
+  HIP_TRY(h, h->scratch.reserve(2 * k1b_scratch_bytes(g)));  // (second half: the early blob launches of schedule 6)
   if (sp) HIP_TRY(h, h->mid.reserve(k3_mid_bytes(n_frames)));
   if (nsub <= 1) {
     { const int rc = drain_tails(); if (rc) return rc; }
@@ -780,7 +788,10 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   const size_t fw_per = flag_words(frame_bytes * per);
   // (one region per sub-batch + two for the first sub-batches of the NEXT submission, see StreamHint)
   HIP_TRY(h, h->flags.reserve(fw_per * (nsub + 2) * 8));
-  HIP_TRY(h, h->work.reserve((size_t)2 * (per + 1) * nsub * sizeof(int)));
+  // (two work-list regions per sub-batch: its main blob launch and, schedule 6, the early one of its side-scanned frames)
+  HIP_TRY(h, h->work.reserve((size_t)4 * (per + 1) * nsub * sizeof(int)));
+  h->work_ints = (size_t)4 * (per + 1) * nsub;
+  h->blob_launches.clear();
   // schedule = option "pipeline_mode": -1 (default) = automatic = 6 (fused voting + scan, validate / refine on a side
   // stream, the scan split between a side k1a_scan and the rider); 3 / 4 = its one-stream / no-split-scan variants;
   // 0 (1, 2: experiment variants) = the older two-stream software pipeline.  Schedules with side streams verify once
@@ -874,13 +885,24 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     const bool tail_was_pending = h->tail_sub_pending;  // (this call records the same events anew)
     const int tail_was_last = h->tail_last;
     auto has_sub = [&](int s) { return s < n_real || (s == n_real && next_per > 0); };
+    // frames at the head of sub-batch k (1 <= k < n_real) that its side scan covers completely (multiple of 64: the
+    // rest starts on a flag-word boundary)
+    auto early_frames = [&](int k) -> int {
+      if (!split_scan || !h->early_blobs || k < 1 || k >= n_real) return 0;
+      const int knf = std::min(per, n_frames - k * per);
+      const size_t P = split_bytes((size_t)knf * frame_bytes);
+      return (int)(P / frame_bytes) & ~63;
+    };
+    if (split_scan)
+      for (auto& e : h->early_done)
+        if (!e) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     int f0, nf;
     const uint8_t* fr;
     unsigned long long* fl;
     sub_ptrs(0, f0, nf, fr, fl);
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][0], st));
     // the work-lists of all sub-batches with one memset (instead of one per sub-batch in front of its blob kernels)
-    HIP_TRY(h, hipMemsetAsync(h->work.p, 0, (size_t)2 * (per + 1) * nsub * sizeof(int), st));
+    HIP_TRY(h, hipMemsetAsync(h->work.p, 0, (size_t)4 * (per + 1) * nsub * sizeof(int), st));
     if (prefetched) {
       if (pf.side_part) HIP_TRY(h, hipStreamWaitEvent(st, h->prefetch_side_done, 0));
     } else {
@@ -909,6 +931,20 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
         prefetch_side = true;
       } else {
         HIP_TRY(h, hipEventRecord(h->scanpart_done[k], h->scan_stream));
+        // early blobs: the frames of sub-batch k that the side scan has covered completely go through the blob
+        // extraction right behind it on the side stream, i.e. beside vote(k - 1) — the serial blob window of
+        // sub-batch k on the caller's stream shrinks by that share
+        const int fe = early_frames(k);
+        if (fe > 0) {
+          if (tail_was_pending)
+            HIP_TRY(h, hipStreamWaitEvent(h->scan_stream, h->tail_sub_done[std::min(k, tail_was_last)], 0));
+          const size_t off = (size_t)2 * (per + 1) * (nsub + k);
+          HIP_TRY(h, launch_k1b_blobs(qfr, qfl, fe, g, dp, d_dets + q0, static_cast<int*>(h->work.p) + off,
+                                      static_cast<uint8_t*>(h->scratch.p) + k1b_scratch_bytes(g), sp->n_markers,
+                                      h->scan_stream, nullptr, true));
+          h->blob_launches.emplace_back(off, fe);
+          HIP_TRY(h, hipEventRecord(h->early_done[k], h->scan_stream));
+        }
       }
       return MPE_OK;
     };
@@ -921,9 +957,12 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       // streaming: the tail of the PREVIOUS submission has read the detections / histograms of this region
       if (tail_was_pending) HIP_TRY(h, hipStreamWaitEvent(st, h->tail_sub_done[std::min(s, tail_was_last)], 0));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], st));
-      HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
-                                  static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
+      const int fe = early_frames(s);  // (these frames' blobs ran on the side stream, beside vote(s - 1))
+      HIP_TRY(h, launch_k1b_blobs(fr + (size_t)fe * frame_bytes, fl + (size_t)fe / 64 * g.segs_per_frame, nf - fe, g, dp,
+                                  d_dets + f0 + fe, static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
                                   static_cast<uint8_t*>(h->scratch.p), sp->n_markers, st, nullptr, true));
+      h->blob_launches.emplace_back((size_t)s * 2 * (per + 1), nf - fe);
+      if (fe > 0) HIP_TRY(h, hipStreamWaitEvent(st, h->early_done[s], 0));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], st));
       uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
       // (with one voting block per frame the kernel stores every histogram row the tail reads: no memset)
@@ -1201,6 +1240,8 @@ void mpe_destroy(mpe_handle* h) {
   if (h->prefetch_side_done) (void)hipEventDestroy(h->prefetch_side_done);
   for (auto& e : h->prefetch_ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : h->early_done)
+    if (e) (void)hipEventDestroy(e);
 
   if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
   if (h->scan_stream) (void)hipStreamDestroy(h->scan_stream);
@@ -1295,6 +1336,7 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "k1a_dummy_lds") *value = h->k1a_dummy_lds;
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
+  else if (n == "early_blobs") *value = h->early_blobs;
   else if (n == "track_steps") *value = (int)h->track_steps;
   else if (n == "track_ns_pack") *value = (int)(h->track_ns[0] / std::max(1LL, h->track_steps));
   else if (n == "track_ns_enqueue") *value = (int)(h->track_ns[1] / std::max(1LL, h->track_steps));
@@ -1303,23 +1345,23 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
     // statistics of the last large batch (synchronises): frames the first blob tier handed on, in all
     // ("overflow_frames") or by the capacity that was exceeded ("overflow_why_1" .. 6: bright segments, bands,
     // islands, pixel pool, bitmap pool, blobs kept); "overflow_general": frames that went on to the general tier
-    if (h->last_nsub <= 0 || !h->work.p) return fail(h, MPE_ERR_ARG, "no pipelined batch has run");
+    if (h->last_nsub <= 0 || !h->work.p || h->blob_launches.empty() || h->work_ints == 0)
+      return fail(h, MPE_ERR_ARG, "no pipelined batch has run");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    const size_t region = (size_t)2 * (h->last_per + 1);
-    std::vector<int> w(region * (size_t)h->last_nsub);
+    std::vector<int> w(h->work_ints);
     HIP_TRY(h, hipMemcpy(w.data(), h->work.p, w.size() * sizeof(int), hipMemcpyDeviceToHost));
     const int why = n.rfind("overflow_why_", 0) == 0 ? std::atoi(n.c_str() + 13) : 0;
     long long cnt = 0;
-    for (int s = 0; s < h->last_nsub; ++s) {
-      const int* la = w.data() + region * (size_t)s;
-      const int* lb = la + (h->last_per + 1);
+    for (const auto& bl : h->blob_launches) {  // (offset of the launch's two lists, its frame count)
+      const int* la = w.data() + bl.first;
+      const int* lb = la + (bl.second + 1);
       if (n == "overflow_general") {
         cnt += lb[0];
       } else if (why == 0) {
         cnt += la[0];
       } else {
-        for (int k = 0; k < la[0] && k < h->last_per; ++k) cnt += ((la[1 + k] >> 24) & 0xFF) == why;
+        for (int k = 0; k < la[0] && k < bl.second; ++k) cnt += ((la[1 + k] >> 24) & 0xFF) == why;
       }
     }
     *value = (int)std::min<long long>(cnt, 0x7fffffff);
@@ -1355,6 +1397,10 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
     h->track_profile = value != 0;
     h->track_ns[0] = h->track_ns[1] = h->track_ns[2] = 0;
     h->track_steps = 0;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "early_blobs")) {  // schedule 6: 1 = blobs of the side-scanned frames beside the previous vote (default 0)
+    h->early_blobs = value != 0;
     return MPE_OK;
   }
   if (!std::strcmp(name, "vote_splits")) {
