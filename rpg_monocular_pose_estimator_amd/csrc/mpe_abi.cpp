@@ -129,6 +129,12 @@ struct mpe_handle {
   hipEvent_t prefetch_ev[2] = {nullptr, nullptr};  // schedule 7: the vote that carried prefetched sub-batch k has finished
   bool done_recorded = false;  // run_pipeline has recorded batch_done[submit_seq & 1] itself (fused schedules)
   int last_nsub = 0, last_per = 0;  // work-list layout of the last pipelined batch (option "overflow_*")
+  // the marker-permutation table in mtab is that of these markers, built in the order of this stream (a call with the
+  // same rig on the same stream does not rebuild it: one 25-85 us single-wave kernel less in front of every batch)
+  double mtab_markers[MPE_MAX_MARKERS * 3] = {};
+  int mtab_n = 0;
+  const void* mtab_ptr = nullptr;
+  hipStream_t mtab_stream = nullptr;
   std::vector<std::pair<size_t, int>> blob_launches;  // its blob launches: work-list offset (ints), frames
   size_t work_ints = 0;
   // schedule 6, option "early_blobs": blob extraction of the side-scanned frames of sub-batch s + 1 beside vote(s).
@@ -553,6 +559,21 @@ int ensure_side_streams(mpe_handle* h, bool need_scan) {
   return MPE_OK;
 }
 
+// the marker-permutation table of sp in h->mtab (rebuilt only when the rig, the buffer or the stream changed)
+int prep_marker_table(mpe_handle* h, const SolveParams& sp) {
+  HIP_TRY(h, h->mtab.reserve(k2_table_bytes(sp.n_markers)));
+  if (h->mtab_ptr == h->mtab.p && h->mtab_n == sp.n_markers && h->mtab_stream == h->stream &&
+      std::memcmp(h->mtab_markers, sp.markers, sizeof(double) * 3 * (size_t)sp.n_markers) == 0)
+    return MPE_OK;
+  h->mtab_ptr = nullptr;
+  HIP_TRY(h, launch_k2_prep(sp, static_cast<double*>(h->mtab.p), h->stream));
+  std::memcpy(h->mtab_markers, sp.markers, sizeof(double) * 3 * (size_t)sp.n_markers);
+  h->mtab_n = sp.n_markers;
+  h->mtab_ptr = h->mtab.p;
+  h->mtab_stream = h->stream;
+  return MPE_OK;
+}
+
 // Schedule 7, "deep" fused schedule.  The voting kernels run back to back on the caller's stream, vote(s) carrying the
 // WHOLE image scan of sub-batch s + 2 (ScanRider); the blob extraction of sub-batch s + 1 — whose scan finished with
 // vote(s - 1) — runs on a side stream beside vote(s), validate / refine of sub-batch s - 1 on the tail stream:
@@ -747,8 +768,8 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   const mpe_handle::Prefetch pf = h->prefetch;  // what the previous submission scanned for this one (if anything)
   h->prefetch.valid = false;
   if (sp) {
-    HIP_TRY(h, h->mtab.reserve(k2_table_bytes(sp->n_markers)));
-    HIP_TRY(h, launch_k2_prep(*sp, static_cast<double*>(h->mtab.p), h->stream));
+    const int rc = prep_marker_table(h, *sp);
+    if (rc) return rc;
   }
   int nsub, per;
   sub_batch_shape(h, n_frames, frame_bytes, sp != nullptr, sp ? sp->vote_arith : 1, nsub, per);
@@ -1539,8 +1560,7 @@ int vote_batch_impl(mpe_handle* h, const double* det_xy, const int* n_det, int n
   HIP_TRY(h, hipMemcpyAsync(h->dets.p, hd.data(), (size_t)n_frames * sizeof(mpe_detections), hipMemcpyHostToDevice,
                             h->stream));
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
-  HIP_TRY(h, h->mtab.reserve(k2_table_bytes(n_markers)));
-  HIP_TRY(h, launch_k2_prep(sp, static_cast<double*>(h->mtab.p), h->stream));
+  { const int rc = prep_marker_table(h, sp); if (rc) return rc; }
   const int* d_range = nullptr;
   if (item_lo) {  // forensics: per-frame hypothesis ranges, interleaved {lo, hi}
     std::vector<int> rg((size_t)2 * n_frames);
@@ -1584,8 +1604,7 @@ int solve_bruteforce_impl(mpe_handle* h, const double* det_xy, int n_det, const 
   HIP_TRY(h, h->mid.reserve(k3_mid_bytes(1)));
   HIP_TRY(h, hipMemcpyAsync(h->dets.p, &hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
-  HIP_TRY(h, h->mtab.reserve(k2_table_bytes(n_markers)));
-  HIP_TRY(h, launch_k2_prep(sp, static_cast<double*>(h->mtab.p), h->stream));
+  { const int rc = prep_marker_table(h, sp); if (rc) return rc; }
   HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), 1, sp, static_cast<const double*>(h->mtab.p),
                             static_cast<uint32_t*>(h->hist.p), auto_splits(h, 1, n_markers), n_det, h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
@@ -2182,10 +2201,9 @@ int mpe_solve_bruteforce_batch(mpe_handle* h, const double* det_xy, const int* n
   HIP_TRY(h, h->results.reserve((size_t)n * sizeof(mpe_result)));
   HIP_TRY(h, h->corr.reserve(corr_bytes));
   HIP_TRY(h, h->mid.reserve(k3_mid_bytes(n)));
-  HIP_TRY(h, h->mtab.reserve(k2_table_bytes(n_markers)));
   HIP_TRY(h, hipMemcpyAsync(h->dets.p, hd.data(), (size_t)n * sizeof(mpe_detections), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, hist_bytes, h->stream));
-  HIP_TRY(h, launch_k2_prep(sp, static_cast<double*>(h->mtab.p), h->stream));
+  { const int rc = prep_marker_table(h, sp); if (rc) return rc; }
   HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), n, sp, static_cast<const double*>(h->mtab.p),
                             static_cast<uint32_t*>(h->hist.p), auto_splits(h, n, n_markers), nd_max, h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), n, sp,

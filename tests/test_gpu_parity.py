@@ -563,6 +563,29 @@ def test_track_step_repeats_a_frame_the_small_blob_tier_cannot_hold(hip, orc):
 
 
 @pytest.mark.gpu
+def test_marker_table_is_rebuilt_when_the_rig_changes():
+    """The marker-permutation table is kept between calls with the same rig on the same stream; another rig (other
+    positions, same count; another count) in between must rebuild it: records equal those of fresh handles."""
+    d = synth.make_frames("C2", 24, seed=4711)
+    P = mpe.demo_params()
+    rig_a = np.asarray(d["markers"], float)
+    rig_b = rig_a * np.array([1.0, 0.9, 1.1]) + 0.003          # other positions, same count
+    rig_c = np.vstack([rig_a, [[0.05, -0.07, 0.02]]])           # one marker more
+    fresh = {}
+    for name, rig in (("a", rig_a), ("b", rig_b), ("c", rig_c)):
+        h = mpe.Handle()
+        fresh[name] = h.estimate_batch(d["frames"], rig, d["K"], d["D"], P)
+        h.close()
+    assert (fresh["a"]["status"] == 0).sum() >= 12
+    assert not np.array_equal(fresh["a"].view(np.uint8), fresh["b"].view(np.uint8))
+    h = mpe.Handle()
+    for name, rig in (("a", rig_a), ("a", rig_a), ("b", rig_b), ("a", rig_a), ("c", rig_c), ("a", rig_a)):
+        got = h.estimate_batch(d["frames"], rig, d["K"], d["D"], P)
+        assert np.array_equal(got.view(np.uint8), fresh[name].view(np.uint8)), name
+    h.close()
+
+
+@pytest.mark.gpu
 def test_check_and_optimise_stage_entry_points(hip, orc):
     """checkCorrespondences and optimisePose as separate device calls against the oracle's functions:
     the unrefined pose of computeTransformation, then Gauss-Newton from that pose AND from perturbed
