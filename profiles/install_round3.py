@@ -79,12 +79,20 @@ def main():
         print("no fused counter passes in this collection: round3_pmc.json left as it is")
         return soaks()
     # what ONE fused launch of the timed shape scans: frames_per_launch sub-batch, minus the side scan's share
-    fpl = int(bench["kernel_ms"]["frames_per_launch"])
-    rider_frames = bench["roofline"]["bytes_per_launch"] / float(ROWS * COLS)
+    # (under counter collection the profiler serialises kernels: the library's spin probe then finds no concurrent side
+    #  streams and falls back to schedule 3, whose rider scans the WHOLE next sub-batch — the counter pass's own bench
+    #  line says what one fused launch scanned there)
+    pmc_line = None
+    for ln in open(F + "pmc_fetch.log"):
+        if ln.startswith('{"metric"'):
+            pmc_line = json.loads(ln)
+    fpl = int(pmc_line["kernel_ms"]["frames_per_launch"])
+    rider_frames = pmc_line["roofline"]["bytes_per_launch"] / float(ROWS * COLS)
+    pmc_schedule = pmc_line["config"]["schedule"]
     out = {
         "source_fingerprint": open(F + "source_fingerprint.txt").read().strip(),
         "k2_vote_scan": hbm("k2_vote<true", "k2_vote<true> (voting kernel of a %d-frame sub-batch carrying %.0f frames' worth "
-                            "of the image scan of the next one)" % (fpl, rider_frames),
+                            "of the image scan of the next one; schedule in the counter pass: %s)" % (fpl, rider_frames, pmc_schedule),
                             F + "pmc_fetch_summary.csv", F + "pmc_write_summary.csv", rider_frames, "round3_pmc_fused_*.csv"),
         "k1a_scan": hbm("k1a_scan", "k1a_scan", F + "pmc1_fetch_summary.csv", F + "pmc1_write_summary.csv", 16384,
                         "round3_pmc_sequential_*.csv"),
@@ -92,7 +100,8 @@ def main():
             "C2": valu(F + "pmc1_sq_summary.csv", "k2_vote<false", "k2_vote<false, false, 1>", 16384, "round3_pmc_sequential_sq.csv"),
             "C3": valu(F + "pmc3_sq_summary.csv", "k2_vote<false", "k2_vote<false, false, 3> (table slices in LDS)", 16384,
                        "round3_pmc_C3_sq.csv"),
-            "fused_C2": valu(F + "pmc_sq_summary.csv", "k2_vote<true", "k2_vote<true>", fpl, "round3_pmc_fused_sq.csv"),
+            "fused_C2": dict(valu(F + "pmc_sq_summary.csv", "k2_vote<true", "k2_vote<true>", fpl, "round3_pmc_fused_sq.csv"),
+                             frames_scanned_per_launch=rider_frames, schedule_in_the_counter_pass=pmc_schedule),
         },
         "k1b_blobs": valu(F + "pmc1_sq_summary.csv", "k1b_blobs<mpe::K1bSmall>", "k1b_blobs<K1bSmall>", 16384,
                           "round3_pmc_sequential_sq.csv"),
