@@ -56,7 +56,7 @@ def main():
     bench = last_json(F + "bench.json")
     json.dump(bench, open(P + "bench.json", "w"), indent=1)
     json.dump(last_json(F + "bench_nostream.json"), open(P + "bench_nostream.json", "w"), indent=1)
-    for c in ("C1", "C3", "C4", "schedule7", "C3_unsliced"):
+    for c in ("C1", "C3", "C4", "schedule7", "C3_unsliced", "no_vote_events", "vote_events"):
         if os.path.exists(F + "bench_%s.json" % c) and os.path.getsize(F + "bench_%s.json" % c) > 2:
             json.dump(last_json(F + "bench_%s.json" % c), open(P + "bench_%s.json" % c, "w"), indent=1)
     if os.path.exists(F + "stats_streams1/s_kernel_stats.csv"):

@@ -135,6 +135,16 @@ struct mpe_handle {
   int mtab_n = 0;
   const void* mtab_ptr = nullptr;
   hipStream_t mtab_stream = nullptr;
+  // option "vote_events" = N > 0: a pair of timing events around every voting launch that carries a scan, for the
+  // launches of the last N pipelined calls (ring) — the duration of the dominant kernel INSIDE a timed region, with
+  // nothing else recorded; read back as "vote_launch_ns_mean" / "vote_launches" (synchronises the stream)
+  struct VotePair {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool used = false;
+  };
+  std::vector<VotePair> vote_ev;  // N x kMaxSub
+  int vote_ev_calls = 0;          // N
+  long long vote_ev_seq = 0;      // pipelined calls seen since the option was set
   std::vector<std::pair<size_t, int>> blob_launches;  // its blob launches: work-list offset (ints), frames
   size_t work_ints = 0;
   // schedule 6, option "early_blobs": blob extraction of the side-scanned frames of sub-batch s + 1 beside vote(s).
@@ -559,6 +569,27 @@ int ensure_side_streams(mpe_handle* h, bool need_scan) {
   return MPE_OK;
 }
 
+// timing events around one voting launch (option "vote_events"); slot = sub-batch index of the current call
+hipError_t vote_ev_begin(mpe_handle* h, int slot, hipStream_t st) {
+  if (h->vote_ev_calls <= 0) return hipSuccess;
+  mpe_handle::VotePair& p = h->vote_ev[(size_t)(h->vote_ev_seq % h->vote_ev_calls) * mpe_handle::kMaxSub + slot];
+  p.used = false;
+  if (!p.a) {
+    hipError_t e = hipEventCreate(&p.a);
+    if (e != hipSuccess) return e;
+    e = hipEventCreate(&p.b);
+    if (e != hipSuccess) return e;
+  }
+  return hipEventRecord(p.a, st);
+}
+hipError_t vote_ev_end(mpe_handle* h, int slot, hipStream_t st, bool carried_a_scan) {
+  if (h->vote_ev_calls <= 0) return hipSuccess;
+  mpe_handle::VotePair& p = h->vote_ev[(size_t)(h->vote_ev_seq % h->vote_ev_calls) * mpe_handle::kMaxSub + slot];
+  const hipError_t e = hipEventRecord(p.b, st);
+  p.used = e == hipSuccess && carried_a_scan;
+  return e;
+}
+
 // the marker-permutation table of sp in h->mtab (rebuilt only when the rig, the buffer or the stream changed)
 int prep_marker_table(mpe_handle* h, const SolveParams& sp) {
   HIP_TRY(h, h->mtab.reserve(k2_table_bytes(sp.n_markers)));
@@ -704,8 +735,10 @@ int run_deep(mpe_handle* h, const uint8_t* d_frames, int n_frames, const FrameGe
     const size_t nbytes = carries ? (size_t)nnf * frame_bytes : 0;
     size_t scanned = 0;
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], st));
+    HIP_TRY(h, vote_ev_begin(h, s, st));
     HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, sp, static_cast<const double*>(h->mtab.p), hs, splits, sp.n_markers, st,
                               nbytes ? nfr : nullptr, nbytes, nfl, dp.thr, &scanned));
+    HIP_TRY(h, vote_ev_end(h, s, st, scanned > 0));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], st));
     if (scanned > h->last_rider_bytes) h->last_rider_bytes = scanned;
     const bool real_next = s + 2 < n_real;
@@ -751,6 +784,7 @@ int run_deep(mpe_handle* h, const uint8_t* d_frames, int n_frames, const FrameGe
     HIP_TRY(h, hipStreamWaitEvent(st, h->scanpart_done[n_real - 1], 0));
     h->tail_sub_pending = false;
   }
+  ++h->vote_ev_seq;
   if (prof) {
     h->prof_launches = n_real;
     h->have_ms = true;
@@ -999,9 +1033,11 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       }
       const size_t P = split_bytes(nbytes);  // (the first P bytes of sub-batch s + 1 come from the side scan)
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], st));
+      HIP_TRY(h, vote_ev_begin(h, s, st));
       HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, *sp, static_cast<const double*>(h->mtab.p), hs,
                                 auto_splits(h, nf, sp->n_markers), sp->n_markers, st, nbytes ? nfr + P : nullptr,
                                 nbytes - P, nbytes ? nfl + P / 1024 : nullptr, dp.thr, &scanned));
+      HIP_TRY(h, vote_ev_end(h, s, st, scanned > 0));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], st));
       if (scanned > h->last_rider_bytes) h->last_rider_bytes = scanned;
       if (nbytes > 0) {  // what the riders left over: less than one chunk, or everything if they could not run
@@ -1058,6 +1094,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       h->tail_sub_pending = false;  // (the next call's kernels are ordered behind every tail of this one anyway)
     }
     // (every side scan was waited for by the blob extraction of its sub-batch; a prefetch side scan by the next call)
+    ++h->vote_ev_seq;
     if (prof) {
       h->prof_launches = used;
       h->have_ms = true;
@@ -1263,6 +1300,10 @@ void mpe_destroy(mpe_handle* h) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : h->early_done)
     if (e) (void)hipEventDestroy(e);
+  for (auto& p : h->vote_ev) {
+    if (p.a) (void)hipEventDestroy(p.a);
+    if (p.b) (void)hipEventDestroy(p.b);
+  }
 
   if (h->tail_stream) (void)hipStreamDestroy(h->tail_stream);
   if (h->scan_stream) (void)hipStreamDestroy(h->scan_stream);
@@ -1358,6 +1399,21 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
   else if (n == "early_blobs") *value = h->early_blobs;
+  else if (n == "vote_launch_ns_mean" || n == "vote_launches") {
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    double sum_ms = 0;
+    long long cnt = 0;
+    for (auto& p : h->vote_ev)
+      if (p.used) {
+        float ms = 0;
+        HIP_TRY(h, hipEventSynchronize(p.b));
+        HIP_TRY(h, hipEventElapsedTime(&ms, p.a, p.b));
+        sum_ms += ms;
+        ++cnt;
+      }
+    *value = n == "vote_launches" ? (int)cnt : (cnt ? (int)(sum_ms * 1e6 / (double)cnt + 0.5) : 0);
+  }
   else if (n == "track_steps") *value = (int)h->track_steps;
   else if (n == "track_ns_pack") *value = (int)(h->track_ns[0] / std::max(1LL, h->track_steps));
   else if (n == "track_ns_enqueue") *value = (int)(h->track_ns[1] / std::max(1LL, h->track_steps));
@@ -1418,6 +1474,17 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
     h->track_profile = value != 0;
     h->track_ns[0] = h->track_ns[1] = h->track_ns[2] = 0;
     h->track_steps = 0;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "vote_events")) {  // N > 0: time the scan-carrying voting launches of the last N pipelined calls
+    if (value < 0 || value > 4096) return fail(h, MPE_ERR_ARG, "vote_events out of range (0..4096)");
+    for (auto& p : h->vote_ev) {
+      if (p.a) (void)hipEventDestroy(p.a);
+      if (p.b) (void)hipEventDestroy(p.b);
+    }
+    h->vote_ev.assign((size_t)value * mpe_handle::kMaxSub, mpe_handle::VotePair());
+    h->vote_ev_calls = value;
+    h->vote_ev_seq = 0;
     return MPE_OK;
   }
   if (!std::strcmp(name, "early_blobs")) {  // schedule 6: 1 = blobs of the side-scanned frames beside the previous vote (default 0)
