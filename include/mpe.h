@@ -457,7 +457,11 @@ int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
  * s+1 (joined back before the call returns its place on the stream);  6 = as 4, and the image scan of a
  * sub-batch is split: "scan_split_pct" % of it (default 30) is taken by a stand-alone scan kernel on a second
  * side stream during the blob / tail window two sub-batches earlier ("side_scan_blocks" resident blocks per CU,
- * default 3), the voting kernel's rider scans the rest), "k1a_dummy_lds" (occupancy cap
+ * default 3), the voting kernel's rider scans the rest; option "early_blobs" = 1 additionally runs the blob extraction
+ * of the side-scanned frames beside the previous voting launch — measured slower, default 0;  7 = the voting launches
+ * back to back, each carrying the whole scan of sub-batch s+2, blob extraction and validate / refine on side streams
+ * beside them, two sub-batches scanned ahead for an announced next submission — measured slower than 6, not the
+ * default), "k1a_dummy_lds" (occupancy cap
  * of the stand-alone scan kernel in mode 0, per handle), "ingest_chunk" (frames per chunk of the double-buffered
  * host-frame ingest of mpe_estimate_batch, default 2048, 0 = one blocking copy per call), "refine_variant" (the refinement kernel: 0 automatic = 16 lanes per frame for launches of up to 2048 frames, else one lane per frame; 1 / 2 force one of them; bit-identical results), "vote_arith" (arithmetic of the voting kernel: 1 (default)
  * = fast — Newton-Raphson division / square root, Newton cube root, per-permutation tables, [R|C]-free
@@ -466,6 +470,15 @@ int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
  * The two differ only in the unstable corner of the reference's Ferrari solver).
  * Results are bit-identical in every pipeline mode (for a given vote_arith). */
 int mpe_set_option(mpe_handle* h, const char* name, int value);
+/* Measurement read-outs through the same pair of calls:
+ * set "vote_events" = N > 0: a pair of timing events is recorded around every voting launch that carries a scan, for
+ *   the launches of the last N pipelined calls — nothing else, so a timed region stays what it is; get
+ *   "vote_launch_ns_mean" / "vote_launches" (synchronises the handle's stream); set 0 to release the events.
+ * set "track_profile" = 1 starts / resets host-side timers inside mpe_track_step; get "track_ns_pack",
+ *   "track_ns_enqueue", "track_ns_wait" (mean ns per step), "track_steps".
+ * get "overflow_frames", "overflow_general", "overflow_why_1" .. "overflow_why_6": frames of the last pipelined batch
+ *   that the first blob tier handed on, in all / to the general tier / by the capacity exceeded (bright segments,
+ *   bands, islands, pixel pool, bitmap pool, blobs kept); synchronises. */
 /* Read an option back.  Also "streams_concurrent": 1 once the library has verified (spin-kernel probe at
  * the first large batch) that its two pipeline side streams execute concurrently, 0 if no concurrent
  * pair was found (the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues), -1 not probed yet;
