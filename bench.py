@@ -121,8 +121,6 @@ def main():
     ap.add_argument("--no-vote-events", dest="vote_events", action="store_false",
                     help="do not time the scan-carrying voting launches inside the timed region (A/B: what the two "
                          "events per launch cost)")
-    ap.add_argument("--early-blobs", type=int, default=0,
-                    help="mode 6: 1 = blob extraction of the side-scanned frames of sub-batch s + 1 beside vote(s)")
     ap.add_argument("--vote-splits", type=int, default=0,
                     help="tuning: 0 automatic, n > 0 blocks per frame over the flattened items (no table slices)")
     ap.add_argument("--no-streaming", action="store_true",
@@ -199,7 +197,6 @@ def main():
     h.set_option("pipeline_mode", args.pipeline_mode)
     h.set_option("vote_arith", args.vote_arith)
     h.set_option("vote_splits", args.vote_splits)
-    h.set_option("early_blobs", args.early_blobs)
     h.set_option("scan_split_pct", args.scan_split_pct)
     h.set_option("side_scan_blocks", args.side_scan_blocks)
     if args.k1a_lds >= 0:
@@ -311,7 +308,7 @@ def main():
     rider_kib = h.get_option("last_rider_kib")
     # (more than 5 markers: the voting kernel cannot carry the scan -- its LDS table would not fit -- and every
     #  sub-batch is scanned by a stand-alone k1a_scan although the schedule is nominally fused: rider bytes 0)
-    fused = schedule in (3, 4, 6, 7) and launches > 1 and rider_kib > 0
+    fused = schedule in (3, 4, 6) and launches > 1 and rider_kib > 0
     if fused:
         # fused schedule: the scan of sub-batch s+1 runs INSIDE the voting kernel of sub-batch s; only the first
         # sub-batch is scanned by a stand-alone k1a_scan launch.  Average the launches that do the same thing.
@@ -445,8 +442,7 @@ def main():
                        "frames_per_gpu_per_step": B, "frames_resident_in_hbm": True,
                        "streams_per_gpu": args.pipeline,
                        "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel", 4: "fused + validate/refine on a side stream",
-                                    6: "fused + side-stream tail + scan split between a side k1a_scan and the rider",
-                                    7: "votes back to back carrying the scan of sub-batch s + 2, blobs and tail beside them"}.get(schedule, schedule),
+                                    6: "fused + side-stream tail + scan split between a side k1a_scan and the rider"}.get(schedule, schedule),
                        "side_streams_concurrent": h.get_option("streams_concurrent"),
                        "entry": ("mpe_estimate_batch_device_submit / _collect: a stream of batches, each announcing the "
                                  "next one's frames" if streaming else "mpe_estimate_batch_device, one joined call per step"),

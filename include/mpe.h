@@ -457,11 +457,7 @@ int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
  * s+1 (joined back before the call returns its place on the stream);  6 = as 4, and the image scan of a
  * sub-batch is split: "scan_split_pct" % of it (default 30) is taken by a stand-alone scan kernel on a second
  * side stream during the blob / tail window two sub-batches earlier ("side_scan_blocks" resident blocks per CU,
- * default 3), the voting kernel's rider scans the rest; option "early_blobs" = 1 additionally runs the blob extraction
- * of the side-scanned frames beside the previous voting launch — measured slower, default 0;  7 = the voting launches
- * back to back, each carrying the whole scan of sub-batch s+2, blob extraction and validate / refine on side streams
- * beside them, two sub-batches scanned ahead for an announced next submission — measured slower than 6, not the
- * default), "k1a_dummy_lds" (occupancy cap
+ * default 3), the voting kernel's rider scans the rest), "k1a_dummy_lds" (occupancy cap
  * of the stand-alone scan kernel in mode 0, per handle), "ingest_chunk" (frames per chunk of the double-buffered
  * host-frame ingest of mpe_estimate_batch, default 2048, 0 = one blocking copy per call), "refine_variant" (the refinement kernel: 0 automatic = 16 lanes per frame for launches of up to 2048 frames, else one lane per frame; 1 / 2 force one of them; bit-identical results), "vote_arith" (arithmetic of the voting kernel: 1 (default)
  * = fast — Newton-Raphson division / square root, Newton cube root, per-permutation tables, [R|C]-free

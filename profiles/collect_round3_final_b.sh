@@ -16,7 +16,6 @@ timeout 300 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench
 timeout 300 python $R/bench.py --no-cpu --no-host-leg --steps 20 --warmup 5 --no-streaming 2>/dev/null > $O/bench_nostream.json
 timeout 300 python $R/bench.py --no-cpu --no-host-leg --steps 20 --warmup 5 --no-vote-events 2>/dev/null > $O/bench_no_vote_events.json
 timeout 300 python $R/bench.py --no-cpu --no-host-leg --steps 20 --warmup 5 2>/dev/null > $O/bench_vote_events.json
-timeout 300 python $R/bench.py --no-cpu --no-host-leg --steps 20 --warmup 5 --pipeline-mode 7 2>/dev/null > $O/bench_schedule7.json
 timeout 300 python $R/bench.py --no-cpu --no-host-leg --steps 5 --config C3 --frames 65536 --vote-splits 1 2>/dev/null > $O/bench_C3_unsliced.json
 timeout 300 python $R/bench_streams.py --streams 1 --frames 400 2>/dev/null | tail -1 > $O/streams1.json
 timeout 300 python $R/bench_streams.py --streams 8 --frames 400 2>/dev/null | tail -1 > $O/streams8.json

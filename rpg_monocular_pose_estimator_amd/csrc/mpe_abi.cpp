@@ -81,7 +81,7 @@ struct mpe_handle {
   int last_schedule = 0;       // schedule the last large batch actually ran with
   int pipeline_mode = -1;      // -1 automatic; 0 two-stream staggered pipeline, 3 fused single stream (scan rides in the voting
                                // kernel), 4 fused + validate / refine on a side stream, 6 = 4 + the scan split between a
-                               // side k1a_scan and the rider (default); 1 / 2 experiment variants of the two-stream schedule
+                               // side k1a_scan and the rider (default)
   bool profiling = false;
   int pipeline = 16;  // a large call is cut into up to this many sub-batches (about 16384 frames each, never
                       // below 8192) that the schedules pipeline against each other; 1 = one chain of kernels
@@ -91,7 +91,6 @@ struct mpe_handle {
   int streams_concurrent = -1;  // result of the probe: 1 yes, 0 no pair found, -1 not probed
   hipEvent_t sub_done[kMaxSub] = {};
   hipEvent_t vote_done[kMaxSub] = {};
-  hipEvent_t scan_done[kMaxSub] = {};
   hipEvent_t fork_ev = nullptr;
   hipStream_t copy_stream = nullptr;  // host-frame ingest: the H2D copy of chunk c + 1 runs beside the kernels of chunk c
   hipEvent_t copy_done[2] = {nullptr, nullptr};
@@ -112,13 +111,9 @@ struct mpe_handle {
   // image scan of the NEXT submission's first sub-batch, carried by the last voting launch of this one
   struct Prefetch {
     bool valid = false;
-    int schedule = 0;         // schedule that produced it (the consumer must run the same one)
     const uint8_t* frames = nullptr;
-    int per = 0;              // frames of that sub-batch (the first one)
-    int count = 0;            // sub-batches scanned ahead: 1 (schedule 6) or up to 2 (schedule 7)
-    int n[2] = {0, 0};        // frames of each
-    int stride = 0;           // frames between their starts
-    unsigned long long* flags_ptr[2] = {nullptr, nullptr};  // where their flag words are
+    int per = 0;              // frames of that sub-batch
+    unsigned long long* flags_ptr = nullptr;  // where its flag words are (the producer's layout, not the consumer's)
     size_t frame_bytes = 0;
     int thr = 0;
     void* flags_base = nullptr;  // flags buffer the prefetched words live in (a re-allocation loses them)
@@ -126,7 +121,6 @@ struct mpe_handle {
     bool side_part = false;      // part of it came from the side scan: wait for prefetch_side_done
   } prefetch;
   hipEvent_t prefetch_side_done = nullptr;
-  hipEvent_t prefetch_ev[2] = {nullptr, nullptr};  // schedule 7: the vote that carried prefetched sub-batch k has finished
   bool done_recorded = false;  // run_pipeline has recorded batch_done[submit_seq & 1] itself (fused schedules)
   int last_nsub = 0, last_per = 0;  // work-list layout of the last pipelined batch (option "overflow_*")
   // the marker-permutation table in mtab is that of these markers, built in the order of this stream (a call with the
@@ -147,11 +141,6 @@ struct mpe_handle {
   long long vote_ev_seq = 0;      // pipelined calls seen since the option was set
   std::vector<std::pair<size_t, int>> blob_launches;  // its blob launches: work-list offset (ints), frames
   size_t work_ints = 0;
-  // schedule 6, option "early_blobs": blob extraction of the side-scanned frames of sub-batch s + 1 beside vote(s).
-  // Measured on one MI355X (262 144 C2 frames, 20 steps): 19.6 ms per step with it, 18.4-18.6 without — the voting
-  // kernel with its rider leaves no room beside it (the same finding as schedule 7).  Off by default.
-  int early_blobs = 0;
-  hipEvent_t early_done[kMaxSub] = {};
   // side streams of schedules 4 / 6 verified (spin probe) to execute beside the caller's stream
   int side_streams_ok = -1;           // 1 yes, 0 no concurrent set found (-> schedule 3), -1 not probed
   hipStream_t probed_for = nullptr;   // the caller's stream the verdict holds for
@@ -605,194 +594,6 @@ int prep_marker_table(mpe_handle* h, const SolveParams& sp) {
   return MPE_OK;
 }
 
-// Schedule 7, "deep" fused schedule.  The voting kernels run back to back on the caller's stream, vote(s) carrying the
-// WHOLE image scan of sub-batch s + 2 (ScanRider); the blob extraction of sub-batch s + 1 — whose scan finished with
-// vote(s - 1) — runs on a side stream beside vote(s), validate / refine of sub-batch s - 1 on the tail stream:
-//   caller's stream  vote(0)+scan(2) | vote(1)+scan(3) | vote(2)+scan(4) | ...
-//   blob stream      blobs(1)        | blobs(2)        | blobs(3)        | ...
-//   tail stream                      | tail(0)         | tail(1)         | ...
-// There is no window in which no image bytes move (schedule 6 has one per sub-batch: the blob extraction, during which
-// its side scan reaches 3.5 TB/s), and the only serial chain is vote -> vote.  Streaming (StreamHint): the last two
-// voting launches carry the scans of the first TWO sub-batches of the next submission, whose blob extraction of
-// sub-batch 0 then runs beside the last vote of this one — submissions join without a gap.
-int run_deep(mpe_handle* h, const uint8_t* d_frames, int n_frames, const FrameGeom& g, const DetectParams& dp,
-             const SolveParams& sp, mpe_detections* d_dets, uint32_t* d_hist, mpe_result* d_results, uint32_t* d_corr,
-             const StreamHint* hint, const mpe_handle::Prefetch& pf, int nsub, int per) {
-  const size_t frame_bytes = (size_t)g.rows * g.pitch;
-  const size_t fw_per = flag_words(frame_bytes * per);
-  const bool prof = h->profiling;
-  hipStream_t st = h->stream, bst = h->scan_stream, tst = h->tail_stream;
-  auto make = [&](hipEvent_t& e) -> hipError_t { return e ? hipSuccess : hipEventCreateWithFlags(&e, hipEventDisableTiming); };
-  for (int i = 0; i < mpe_handle::kMaxSub; ++i) {
-    HIP_TRY(h, make(h->vote_done[i]));
-    HIP_TRY(h, make(h->scanpart_done[i]));  // (here: blobs(i) done)
-    HIP_TRY(h, make(h->tail_sub_done[i]));
-    HIP_TRY(h, make(h->scan_done[i]));
-  }
-  HIP_TRY(h, make(h->fork_ev));
-  HIP_TRY(h, make(h->prefetch_ev[0]));
-  HIP_TRY(h, make(h->prefetch_ev[1]));
-  for (auto& e : h->batch_done) HIP_TRY(h, make(e));
-  h->last_rider_bytes = 0;
-  h->last_nsub = nsub;
-  h->last_per = per;
-  unsigned long long* flags_base = static_cast<unsigned long long*>(h->flags.p);
-  int n_real = 0;
-  while (n_real < nsub && n_real * per < n_frames) ++n_real;
-  auto real_n = [&](int v) { return std::min(per, n_frames - v * per); };
-  // how many of this call's first sub-batches the previous submission scanned
-  int pf_count = 0;
-  if (pf.valid && pf.schedule == 7 && pf.frames == d_frames && pf.frame_bytes == frame_bytes && pf.thr == dp.thr &&
-      pf.flags_base == h->flags.p && pf.fw_per == fw_per && pf.stride == per) {
-    while (pf_count < pf.count && pf_count < n_real && pf.n[pf_count] == real_n(pf_count)) ++pf_count;
-  }
-  // the next submission's first two sub-batches, if the caller announced it and it will run this schedule as well
-  int next_n[2] = {0, 0}, next_stride = 0;
-  if (hint && hint->next_frames && hint->n_next > 0) {
-    int nn, np;
-    sub_batch_shape(h, hint->n_next, frame_bytes, true, sp.vote_arith, nn, np);
-    if (nn >= 3 && hint->n_next > 2 * np && flag_words(frame_bytes * np) <= fw_per) {
-      next_n[0] = np;
-      next_n[1] = np;
-      next_stride = np;
-    }
-  }
-  // virtual sub-batch v: v < n_real = of this call; n_real, n_real + 1 = the next submission's first two
-  auto sub_ptrs = [&](int v, int& f0, int& nf, const uint8_t*& fr, unsigned long long*& fl) -> bool {
-    if (v < n_real) {
-      f0 = v * per;
-      nf = real_n(v);
-      fr = d_frames + (size_t)f0 * frame_bytes;
-      fl = v < pf_count ? pf.flags_ptr[v] : flags_base + fw_per * v;
-      return true;
-    }
-    const int k = v - n_real;
-    if (k > 1 || next_n[k] == 0) return false;
-    f0 = k * next_stride;
-    nf = next_n[k];
-    fr = hint->next_frames + (size_t)f0 * frame_bytes;
-    fl = flags_base + fw_per * (nsub + k);
-    return true;
-  };
-  const bool tail_was_pending = h->tail_sub_pending;
-  const int tail_was_last = h->tail_last;
-  int f0, nf;
-  const uint8_t* fr;
-  unsigned long long* fl;
-  // the blob stream joins this call: behind the caller's stream as of now, or — streaming — behind the vote that
-  // finished the scan of sub-batch 0 (so that blobs(0) run beside the LAST vote of the previous submission)
-  if (pf_count == 0) {
-    HIP_TRY(h, hipEventRecord(h->fork_ev, st));
-    HIP_TRY(h, hipStreamWaitEvent(bst, h->fork_ev, 0));
-  } else {
-    HIP_TRY(h, hipStreamWaitEvent(bst, h->prefetch_ev[0], 0));
-  }
-  HIP_TRY(h, hipMemsetAsync(h->work.p, 0, (size_t)4 * (per + 1) * nsub * sizeof(int), bst));
-  // sub-batches 0 / 1 that nobody scanned ahead: stand-alone scans on the caller's stream
-  for (int v = 0; v < 2 && v < n_real; ++v) {
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[v][0], st));
-    if (v >= pf_count) {
-      sub_ptrs(v, f0, nf, fr, fl);
-      HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, scan_lds(h, false), st));
-      HIP_TRY(h, hipEventRecord(h->scan_done[v], st));
-    }
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[v][1], st));
-  }
-  auto blobs = [&](int v) -> int {
-    if (v >= n_real) return MPE_OK;
-    sub_ptrs(v, f0, nf, fr, fl);
-    // what finished the scan of sub-batch v
-    if (v < pf_count) {
-      HIP_TRY(h, hipStreamWaitEvent(bst, h->prefetch_ev[v], 0));
-    } else if (v < 2) {
-      HIP_TRY(h, hipStreamWaitEvent(bst, h->scan_done[v], 0));
-    } else {
-      HIP_TRY(h, hipStreamWaitEvent(bst, h->vote_done[v - 2], 0));
-    }
-    // streaming: the tail of the PREVIOUS submission has read the detections / histograms of this region
-    if (tail_was_pending) HIP_TRY(h, hipStreamWaitEvent(bst, h->tail_sub_done[std::min(v, tail_was_last)], 0));
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[v][2], bst));
-    HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0, static_cast<int*>(h->work.p) + (size_t)v * 2 * (per + 1),
-                                static_cast<uint8_t*>(h->scratch.p), sp.n_markers, bst, nullptr, true));
-    h->blob_launches.emplace_back((size_t)v * 2 * (per + 1), nf);
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[v][3], bst));
-    HIP_TRY(h, hipEventRecord(h->scanpart_done[v], bst));
-    return MPE_OK;
-  };
-  { const int rc = blobs(0); if (rc) return rc; }
-  for (int s = 0; s < n_real; ++s) {
-    { const int rc = blobs(s + 1); if (rc) return rc; }  // (beside vote(s))
-    sub_ptrs(s, f0, nf, fr, fl);
-    HIP_TRY(h, hipStreamWaitEvent(st, h->scanpart_done[s], 0));
-    uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
-    const int splits = auto_splits(h, nf, sp.n_markers);
-    if (sp.vote_arith == 0 || splits != 1)
-      HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), st));
-    int nf0, nnf = 0;
-    const uint8_t* nfr = nullptr;
-    unsigned long long* nfl = nullptr;
-    const bool carries = sub_ptrs(s + 2, nf0, nnf, nfr, nfl);
-    const size_t nbytes = carries ? (size_t)nnf * frame_bytes : 0;
-    size_t scanned = 0;
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], st));
-    HIP_TRY(h, vote_ev_begin(h, s, st));
-    HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, sp, static_cast<const double*>(h->mtab.p), hs, splits, sp.n_markers, st,
-                              nbytes ? nfr : nullptr, nbytes, nfl, dp.thr, &scanned));
-    HIP_TRY(h, vote_ev_end(h, s, st, scanned > 0));
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], st));
-    if (scanned > h->last_rider_bytes) h->last_rider_bytes = scanned;
-    const bool real_next = s + 2 < n_real;
-    if (prof && real_next) HIP_TRY(h, hipEventRecord(h->pev[s + 2][0], st));
-    if (nbytes > scanned)  // what the riders left over: less than one chunk, or everything if they could not run
-      HIP_TRY(h, launch_k1a_scan(nfr + scanned, nbytes - scanned, nfl + scanned / 1024, dp.thr, scan_lds(h, false), st));
-    if (prof && real_next) HIP_TRY(h, hipEventRecord(h->pev[s + 2][1], st));
-    HIP_TRY(h, hipEventRecord(h->vote_done[s], st));
-    if (carries && s + 2 >= n_real) HIP_TRY(h, hipEventRecord(h->prefetch_ev[s + 2 - n_real], st));
-    HIP_TRY(h, hipStreamWaitEvent(tst, h->vote_done[s], 0));
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], tst));
-    HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, sp, d_results + f0,
-                              d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0,
-                              static_cast<uint8_t*>(h->mid.p) + k3_mid_bytes(1) * (size_t)f0, tst));
-    if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][7], tst));
-    HIP_TRY(h, hipEventRecord(h->tail_sub_done[s], tst));
-    h->tail_last = s;
-  }
-  h->tail_sub_pending = true;
-  if (next_n[0] > 0) {
-    mpe_handle::Prefetch& q = h->prefetch;
-    q.valid = true;
-    q.schedule = 7;
-    q.frames = hint->next_frames;
-    q.per = next_n[0];
-    q.count = next_n[1] > 0 ? 2 : 1;
-    q.n[0] = next_n[0];
-    q.n[1] = next_n[1];
-    q.stride = next_stride;
-    q.flags_ptr[0] = flags_base + fw_per * nsub;
-    q.flags_ptr[1] = flags_base + fw_per * (nsub + 1);
-    q.frame_bytes = frame_bytes;
-    q.thr = dp.thr;
-    q.flags_base = h->flags.p;
-    q.fw_per = fw_per;
-    q.side_part = false;
-  }
-  hipEvent_t done = h->batch_done[h->submit_seq & 1];
-  HIP_TRY(h, hipEventRecord(done, tst));
-  h->done_recorded = true;
-  if (!(hint && hint->no_join)) {  // join: the call behaves like one operation on the caller's stream
-    HIP_TRY(h, hipStreamWaitEvent(st, done, 0));
-    HIP_TRY(h, hipStreamWaitEvent(st, h->scanpart_done[n_real - 1], 0));
-    h->tail_sub_pending = false;
-  }
-  ++h->vote_ev_seq;
-  if (prof) {
-    h->prof_launches = n_real;
-    h->have_ms = true;
-    h->prof_pipelined = true;
-    h->prof_frames_per_launch = per;
-  }
-  return MPE_OK;
-}
 
 int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const FrameGeom& g, const DetectParams& dp,
                  const SolveParams* sp, mpe_detections* d_dets, uint32_t* d_hist, mpe_result* d_results,
@@ -818,7 +619,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     }
     return MPE_OK;
   };
-  HIP_TRY(h, h->scratch.reserve(2 * k1b_scratch_bytes(g)));  // (second half: the early blob launches of schedule 6)
+  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
   if (sp) HIP_TRY(h, h->mid.reserve(k3_mid_bytes(n_frames)));
   if (nsub <= 1) {
     { const int rc = drain_tails(); if (rc) return rc; }
@@ -841,15 +642,14 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
         if (!h->pev[s][k]) HIP_TRY(h, hipEventCreate(&h->pev[s][k]));
   // Software pipeline over nsub sub-batches on two streams: A runs scan + blobs, B voting + tail.
   const size_t fw_per = flag_words(frame_bytes * per);
-  // (one region per sub-batch + two for the first sub-batches of the NEXT submission, see StreamHint)
-  HIP_TRY(h, h->flags.reserve(fw_per * (nsub + 2) * 8));
-  // (two work-list regions per sub-batch: its main blob launch and, schedule 6, the early one of its side-scanned frames)
-  HIP_TRY(h, h->work.reserve((size_t)4 * (per + 1) * nsub * sizeof(int)));
-  h->work_ints = (size_t)4 * (per + 1) * nsub;
+  // (one region per sub-batch + one for the first sub-batch of the NEXT submission, see StreamHint)
+  HIP_TRY(h, h->flags.reserve(fw_per * (nsub + 1) * 8));
+  HIP_TRY(h, h->work.reserve((size_t)2 * (per + 1) * nsub * sizeof(int)));
+  h->work_ints = (size_t)2 * (per + 1) * nsub;
   h->blob_launches.clear();
   // schedule = option "pipeline_mode": -1 (default) = automatic = 6 (fused voting + scan, validate / refine on a side
   // stream, the scan split between a side k1a_scan and the rider); 3 / 4 = its one-stream / no-split-scan variants;
-  // 0 (1, 2: experiment variants) = the older two-stream software pipeline.  Schedules with side streams verify once
+  // 0 = the older two-stream software pipeline.  Schedules with side streams verify once
   // per caller stream that those streams really execute concurrently (ensure_side_streams / pick_concurrent_streams)
   // and fall back to the one-stream schedule 3 when the runtime cannot give them separate hardware queues.
   int schedule = h->pipeline_mode;
@@ -863,16 +663,14 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (h->streams_concurrent == 0) schedule = 6;
   }
   h->last_schedule = schedule;
-  if (schedule == 4 || schedule == 6 || schedule == 7) {
+  if (schedule == 4 || schedule == 6) {
     // the side streams of these schedules only pay when they really execute beside the caller's stream: verify it
     // once per (handle, caller stream) with the spin probe; without a concurrent triple -> schedule 3 (one stream)
-    const int rc = ensure_side_streams(h, schedule == 7 || (schedule == 6 && h->scan_split_pct > 0));
+    const int rc = ensure_side_streams(h, schedule == 6 && h->scan_split_pct > 0);
     if (rc) return rc;
     if (h->side_streams_ok == 0) schedule = 3;
-    if (schedule == 7 && (nsub < 3 || n_frames <= 2 * per)) schedule = 6;
     h->last_schedule = schedule;
   }
-  if (schedule == 7) return run_deep(h, d_frames, n_frames, g, dp, *sp, d_dets, d_hist, d_results, d_corr, hint, pf, nsub, per);
   if (schedule == 3 || schedule == 4 || schedule == 6) {
     const bool side_tail = schedule != 3;
     // mode 6: the HBM stream is spread over the whole sub-batch period.  In modes 3 / 4 the voting kernel scans all
@@ -910,9 +708,9 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     hipStream_t st = h->stream;
     unsigned long long* flags_base = static_cast<unsigned long long*>(h->flags.p);
     // was sub-batch 0 of THIS call scanned by the previous submission?
-    const bool prefetched = pf.valid && pf.schedule != 7 && pf.frames == d_frames &&
-                            pf.per == std::min(per, n_frames) && pf.frame_bytes == frame_bytes && pf.thr == dp.thr &&
-                            pf.flags_base == h->flags.p && pf.fw_per == fw_per && pf.flags_ptr[0] != nullptr;
+    const bool prefetched = pf.valid && pf.frames == d_frames && pf.per == std::min(per, n_frames) &&
+                            pf.frame_bytes == frame_bytes && pf.thr == dp.thr && pf.flags_base == h->flags.p &&
+                            pf.fw_per == fw_per && pf.flags_ptr != nullptr;
     // the next submission's first sub-batch, if the caller announced it and it will run pipelined as well
     int next_per = 0;
     if (hint && hint->next_frames && hint->n_next > 0) {
@@ -932,7 +730,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       f0 = s * per;
       nf = std::min(per, n_frames - f0);
       fr = d_frames + (size_t)f0 * frame_bytes;
-      fl = (s == 0 && prefetched) ? pf.flags_ptr[0] : flags_base + fw_per * s;
+      fl = (s == 0 && prefetched) ? pf.flags_ptr : flags_base + fw_per * s;
     };
     // number of real sub-batches (the last ones may be empty when n_frames is not a multiple of `per`)
     int n_real = 0;
@@ -940,24 +738,13 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     const bool tail_was_pending = h->tail_sub_pending;  // (this call records the same events anew)
     const int tail_was_last = h->tail_last;
     auto has_sub = [&](int s) { return s < n_real || (s == n_real && next_per > 0); };
-    // frames at the head of sub-batch k (1 <= k < n_real) that its side scan covers completely (multiple of 64: the
-    // rest starts on a flag-word boundary)
-    auto early_frames = [&](int k) -> int {
-      if (!split_scan || !h->early_blobs || k < 1 || k >= n_real) return 0;
-      const int knf = std::min(per, n_frames - k * per);
-      const size_t P = split_bytes((size_t)knf * frame_bytes);
-      return (int)(P / frame_bytes) & ~63;
-    };
-    if (split_scan)
-      for (auto& e : h->early_done)
-        if (!e) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     int f0, nf;
     const uint8_t* fr;
     unsigned long long* fl;
     sub_ptrs(0, f0, nf, fr, fl);
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[0][0], st));
     // the work-lists of all sub-batches with one memset (instead of one per sub-batch in front of its blob kernels)
-    HIP_TRY(h, hipMemsetAsync(h->work.p, 0, (size_t)4 * (per + 1) * nsub * sizeof(int), st));
+    HIP_TRY(h, hipMemsetAsync(h->work.p, 0, (size_t)2 * (per + 1) * nsub * sizeof(int), st));
     if (prefetched) {
       if (pf.side_part) HIP_TRY(h, hipStreamWaitEvent(st, h->prefetch_side_done, 0));
     } else {
@@ -986,20 +773,6 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
         prefetch_side = true;
       } else {
         HIP_TRY(h, hipEventRecord(h->scanpart_done[k], h->scan_stream));
-        // early blobs: the frames of sub-batch k that the side scan has covered completely go through the blob
-        // extraction right behind it on the side stream, i.e. beside vote(k - 1) — the serial blob window of
-        // sub-batch k on the caller's stream shrinks by that share
-        const int fe = early_frames(k);
-        if (fe > 0) {
-          if (tail_was_pending)
-            HIP_TRY(h, hipStreamWaitEvent(h->scan_stream, h->tail_sub_done[std::min(k, tail_was_last)], 0));
-          const size_t off = (size_t)2 * (per + 1) * (nsub + k);
-          HIP_TRY(h, launch_k1b_blobs(qfr, qfl, fe, g, dp, d_dets + q0, static_cast<int*>(h->work.p) + off,
-                                      static_cast<uint8_t*>(h->scratch.p) + k1b_scratch_bytes(g), sp->n_markers,
-                                      h->scan_stream, nullptr, true));
-          h->blob_launches.emplace_back(off, fe);
-          HIP_TRY(h, hipEventRecord(h->early_done[k], h->scan_stream));
-        }
       }
       return MPE_OK;
     };
@@ -1012,12 +785,10 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       // streaming: the tail of the PREVIOUS submission has read the detections / histograms of this region
       if (tail_was_pending) HIP_TRY(h, hipStreamWaitEvent(st, h->tail_sub_done[std::min(s, tail_was_last)], 0));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], st));
-      const int fe = early_frames(s);  // (these frames' blobs ran on the side stream, beside vote(s - 1))
-      HIP_TRY(h, launch_k1b_blobs(fr + (size_t)fe * frame_bytes, fl + (size_t)fe / 64 * g.segs_per_frame, nf - fe, g, dp,
-                                  d_dets + f0 + fe, static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
+      HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
+                                  static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
                                   static_cast<uint8_t*>(h->scratch.p), sp->n_markers, st, nullptr, true));
-      h->blob_launches.emplace_back((size_t)s * 2 * (per + 1), nf - fe);
-      if (fe > 0) HIP_TRY(h, hipStreamWaitEvent(st, h->early_done[s], 0));
+      h->blob_launches.emplace_back((size_t)s * 2 * (per + 1), nf);
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], st));
       uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
       // (with one voting block per frame the kernel stores every histogram row the tail reads: no memset)
@@ -1071,9 +842,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     h->tail_sub_pending = side_tail;
     if (next_per > 0) {  // sub-batch 0 of the next submission has been scanned into the extra region
       h->prefetch.valid = true;
-      h->prefetch.schedule = schedule;
-      h->prefetch.count = 1;
-      h->prefetch.flags_ptr[0] = flags_base + fw_per * nsub;
+      h->prefetch.flags_ptr = flags_base + fw_per * nsub;
       h->prefetch.frames = hint->next_frames;
       h->prefetch.per = next_per;
       h->prefetch.frame_bytes = frame_bytes;
@@ -1110,15 +879,10 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (rc) return rc;
   }
   if (!h->fork_ev) HIP_TRY(h, hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
-  hipStream_t sa = h->sub_stream[0], sb = h->sub_stream[1], sc = h->sub_stream[2];
-  const int mode = schedule;
+  hipStream_t sa = h->sub_stream[0], sb = h->sub_stream[1];
   HIP_TRY(h, hipEventRecord(h->fork_ev, h->stream));
   HIP_TRY(h, hipStreamWaitEvent(sa, h->fork_ev, 0));
   HIP_TRY(h, hipStreamWaitEvent(sb, h->fork_ev, 0));
-  HIP_TRY(h, hipStreamWaitEvent(sc, h->fork_ev, 0));
-  if (!h->scan_done[0])
-    for (int i = 0; i < mpe_handle::kMaxSub; ++i)
-      HIP_TRY(h, hipEventCreateWithFlags(&h->scan_done[i], hipEventDisableTiming));
   // Staggered schedule: scan(i+1) runs beside vote(i) (HBM-bound beside FP64-bound), blobs(i+1)
   // beside tail(i) (two latency-bound kernels): blobs(i+1) is held back until vote(i) has finished.
   if (!h->vote_done[0])
@@ -1135,12 +899,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     HIP_TRY(h, launch_k1a_scan(fr, (size_t)nf * frame_bytes, fl, dp.thr, scan_lds(h, true), sa));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][1], sa));
     hipStream_t sblob = sa;
-    if (mode == 2) {  // blobs (and tail) on a third stream
-      HIP_TRY(h, hipEventRecord(h->scan_done[s], sa));
-      HIP_TRY(h, hipStreamWaitEvent(sc, h->scan_done[s], 0));
-      sblob = sc;
-    }
-    if (mode == 0 && s > 0) HIP_TRY(h, hipStreamWaitEvent(sblob, h->vote_done[s - 1], 0));
+    if (s > 0) HIP_TRY(h, hipStreamWaitEvent(sblob, h->vote_done[s - 1], 0));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], sblob));
     HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
                                 static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
@@ -1156,10 +915,6 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], sb));
     HIP_TRY(h, hipEventRecord(h->vote_done[s], sb));
     hipStream_t stail = sb;
-    if (mode == 2) {
-      HIP_TRY(h, hipStreamWaitEvent(sc, h->vote_done[s], 0));
-      stail = sc;
-    }
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], stail));
     HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
                               d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0,
@@ -1169,10 +924,6 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
   }
   HIP_TRY(h, hipEventRecord(h->fork_ev, sb));  // B waited for every front half
   HIP_TRY(h, hipStreamWaitEvent(h->stream, h->fork_ev, 0));
-  if (mode == 2) {
-    HIP_TRY(h, hipEventRecord(h->fork_ev, sc));
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->fork_ev, 0));
-  }
   if (prof) {
     h->have_ms = true;
     h->prof_pipelined = true;
@@ -1284,8 +1035,6 @@ void mpe_destroy(mpe_handle* h) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : h->vote_done)
     if (e) (void)hipEventDestroy(e);
-  for (auto& e : h->scan_done)
-    if (e) (void)hipEventDestroy(e);
   for (auto& row : h->pev)
     for (auto& e : row)
       if (e) (void)hipEventDestroy(e);
@@ -1296,10 +1045,6 @@ void mpe_destroy(mpe_handle* h) {
   for (auto& e : h->tail_sub_done)
     if (e) (void)hipEventDestroy(e);
   if (h->prefetch_side_done) (void)hipEventDestroy(h->prefetch_side_done);
-  for (auto& e : h->prefetch_ev)
-    if (e) (void)hipEventDestroy(e);
-  for (auto& e : h->early_done)
-    if (e) (void)hipEventDestroy(e);
   for (auto& p : h->vote_ev) {
     if (p.a) (void)hipEventDestroy(p.a);
     if (p.b) (void)hipEventDestroy(p.b);
@@ -1398,7 +1143,6 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "k1a_dummy_lds") *value = h->k1a_dummy_lds;
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
-  else if (n == "early_blobs") *value = h->early_blobs;
   else if (n == "vote_launch_ns_mean" || n == "vote_launches") {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1459,8 +1203,8 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
     return MPE_OK;
   }
   if (!std::strcmp(name, "pipeline_mode")) {
-    if (value != -1 && value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 6 && value != 7)
-      return fail(h, MPE_ERR_ARG, "pipeline_mode must be -1 (automatic), 0, 1, 2, 3, 4, 6 or 7");
+    if (value != -1 && value != 0 && value != 3 && value != 4 && value != 6)
+      return fail(h, MPE_ERR_ARG, "pipeline_mode must be -1 (automatic), 0, 3, 4 or 6");
     h->pipeline_mode = value;
     h->prefetch.valid = false;  // (words scanned ahead by another schedule are not picked up)
     return MPE_OK;
@@ -1485,10 +1229,6 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
     h->vote_ev.assign((size_t)value * mpe_handle::kMaxSub, mpe_handle::VotePair());
     h->vote_ev_calls = value;
     h->vote_ev_seq = 0;
-    return MPE_OK;
-  }
-  if (!std::strcmp(name, "early_blobs")) {  // schedule 6: 1 = blobs of the side-scanned frames beside the previous vote (default 0)
-    h->early_blobs = value != 0;
     return MPE_OK;
   }
   if (!std::strcmp(name, "vote_splits")) {

@@ -701,13 +701,6 @@ def test_full_size_batch_properties(orc):
         fused6 = run(frames, 8)
         assert h.get_option("last_schedule") == 6 and torch.equal(fused6, plain), pct
     h.set_option("scan_split_pct", 30)
-    h.set_option("early_blobs", 1)                         # with early blob launches beside the previous vote
-    fused6 = run(frames, 8)
-    assert h.get_option("last_schedule") == 6 and torch.equal(fused6, plain)
-    h.set_option("early_blobs", 0)
-    h.set_option("pipeline_mode", 7)                       # votes back to back, blobs and tail beside them
-    deep = run(frames, 8)
-    assert h.get_option("last_schedule") in (6, 7) and torch.equal(deep, plain)
     h.set_option("pipeline_mode", -1)                      # automatic = 6
     piped = run(frames, 8)
     assert h.get_option("last_schedule") == 6 and torch.equal(piped, plain)

@@ -311,70 +311,6 @@ def test_streaming_submissions_are_bit_identical():
     h.close()
 
 
-def test_deep_schedule_is_bit_identical_joined_and_streaming():
-    """Schedule 7 (votes back to back, each carrying the whole scan of sub-batch s + 2; blobs and validate / refine
-    on side streams): byte-identical to the default schedule as a joined call, as a stream of submissions whose last
-    two votes scan the first TWO sub-batches of the announced batch (their stand-alone scans disappear), with a hint
-    that does not come true and without one."""
-    import torch
-    B = 49152                                     # 3 sub-batches of 16 384 frames
-    cfg, _, fa = _frames_on_device("C2", B, 8280)
-    _, _, fb = _frames_on_device("C2", B, 8290)
-    rows, cols = cfg["rows"], cfg["cols"]
-    K, D = synth.camera_for(rows, cols)
-    markers = np.asarray(cfg["markers"])
-    dev = fa.device
-    P = mpe.demo_params()
-    h = mpe.Handle(0)
-    stream = torch.cuda.Stream(device=dev)
-    consumer = torch.cuda.Stream(device=dev)
-    h.set_stream(stream.cuda_stream)
-    nb = B * mpe.RESULT_DTYPE.itemsize
-
-    def joined(fr):
-        with torch.cuda.stream(stream):
-            out = torch.zeros(nb, dtype=torch.uint8, device=dev)
-            h.estimate_batch_device(fr.data_ptr(), B, rows, cols, markers, K, D, P, out.data_ptr())
-        stream.synchronize()
-        return out
-
-    ref_a, ref_b = joined(fa), joined(fb)
-    assert h.get_option("last_schedule") == 6 and not torch.equal(ref_a, ref_b)
-    h.set_option("pipeline_mode", 7)
-    assert torch.equal(joined(fa), ref_a) and h.get_option("last_schedule") == 7
-    assert torch.equal(joined(fb), ref_b)
-    h.set_profiling(True)
-    outs = [torch.zeros(nb, dtype=torch.uint8, device=dev) for _ in range(4)]
-    torch.cuda.synchronize()
-    # (batch, announced next, the batch was scanned ahead)
-    seq = [(fa, fb, False), (fb, fa, True), (fa, fb, True), (fa, None, False), (fb, fa, False), (fa, None, True)]
-    refs = {fa.data_ptr(): ref_a, fb.data_ptr(): ref_b}
-    for i, (fr, nxt, ahead) in enumerate(seq):
-        o = outs[i % 4]
-        with torch.cuda.stream(stream):
-            h.estimate_batch_device_submit(fr.data_ptr(), B, rows, cols, markers, K, D, P, o.data_ptr(),
-                                           nxt.data_ptr() if nxt is not None else 0, B)
-            h.estimate_batch_device_collect(consumer.cuda_stream)
-        consumer.synchronize()
-        assert torch.equal(o, refs[fr.data_ptr()]), i
-        stream.synchronize()
-        for sub in (0, 1):
-            scan = h.last_kernel_ms_sub(sub)["scan"]
-            assert (scan < 0.05) if ahead else (scan > 0.3), (i, sub, scan)
-    h.set_profiling(False)
-    # two in flight, then back to the default schedule on the same handle (the words scanned ahead are dropped)
-    with torch.cuda.stream(stream):
-        h.estimate_batch_device_submit(fa.data_ptr(), B, rows, cols, markers, K, D, P, outs[0].data_ptr(), fb.data_ptr(), B)
-        h.estimate_batch_device_submit(fb.data_ptr(), B, rows, cols, markers, K, D, P, outs[1].data_ptr(), fa.data_ptr(), B)
-        h.estimate_batch_device_collect(0)
-        h.estimate_batch_device_collect(0)
-    stream.synchronize()
-    assert torch.equal(outs[0], ref_a) and torch.equal(outs[1], ref_b)
-    h.set_option("pipeline_mode", -1)
-    assert torch.equal(joined(fa), ref_a) and h.get_option("last_schedule") == 6
-    h.close()
-
-
 def test_capacity_overrun_is_reported_alike_by_single_and_batch_replays(orc):
     """A frame with more blobs than MPE_MAX_DETECTIONS in the middle of a sequence: mpe_tracker_run_sequence and the
     lock-step batch replay both hand out a ZEROED record that carries the status code for that frame (and a zeroed
