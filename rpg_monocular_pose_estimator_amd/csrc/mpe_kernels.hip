@@ -2633,6 +2633,8 @@ __global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restr
   __shared__ double s_mean[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS * 3];
   __shared__ double s_det[K3_FRAMES_PER_BLOCK][MPE_MAX_DETECTIONS][2];
   __shared__ double s_pred[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS][2];
+  __shared__ unsigned s_colmax[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS];
+  __shared__ unsigned char s_colrow[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS];
   __shared__ double s_mk[MPE_MAX_MARKERS][3];
   __shared__ unsigned s_valid[K3_FRAMES_PER_BLOCK][K3_GROUP];
   __shared__ unsigned char s_cm[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS], s_cd[K3_FRAMES_PER_BLOCK][MPE_MAX_MARKERS];
@@ -2663,6 +2665,19 @@ __global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restr
     for (int i = l; i < n_m; i += K3_GROUP) {
       s_pred[grp][i][0] = nn_pred[(size_t)f * 2 * MPE_MAX_MARKERS + 2 * i];
       s_pred[grp][i][1] = nn_pred[(size_t)f * 2 * MPE_MAX_MARKERS + 2 * i + 1];
+    }
+  if (live && !corr_in && !nn_pred && MODE != 2)  // (the histogram path: see lane 0 below)
+    for (int c = l; c < n_m; c += K3_GROUP) {
+      unsigned mv = 0, mr = 0;
+      for (int r = 0; r < n_d; ++r) {
+        const unsigned v = H[r * MPE_MAX_MARKERS + c];
+        if (v > mv) {  // (first row of the column's maximum; an all-zero column keeps row 0)
+          mv = v;
+          mr = (unsigned)r;
+        }
+      }
+      s_colmax[grp][c] = mv;
+      s_colrow[grp][c] = (unsigned char)mr;
     }
   wave_sync();  // (the block is one wave)
   if (live && MODE != 2) {  // (MODE 2: results[f].T holds the start pose for the refinement kernel)
@@ -2716,9 +2731,14 @@ __global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restr
       go0 = false;
     }
     if (go0) {
+      // The reference scans the whole histogram n_m times, column-major, for the first position of the maximum and
+      // then zeroes that COLUMN (pose_estimator.cpp:349-368).  Only columns are ever removed, so a column's maximum
+      // and the first row that reaches it never change: the group's lanes found them above (one column per lane, n_d
+      // independent loads each instead of n_m * n_m * n_d dependent ones here), and a round is the first column, in
+      // ascending order, with the largest value still standing.  A removed column stands at 0 with row 0, as in
+      // the reference's scan, which matters when hist_thr is 0.
       bool any = false;
-      for (int r = 0; r < n_d; ++r)
-        for (int c = 0; c < n_m; ++c) any |= (H[r * MPE_MAX_MARKERS + c] != 0);
+      for (int c = 0; c < n_m; ++c) any |= (s_colmax[grp][c] != 0);
       go0 = any;
     }
     if (go0) {
@@ -2727,16 +2747,16 @@ __global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restr
         unsigned mv = 0;
         int ri = 0, ci = 0;
         bool first = true;
-        for (int c = 0; c < n_m; ++c)
-          for (int r = 0; r < n_d; ++r) {
-            const unsigned v = ((removed >> c) & 1) ? 0u : H[r * MPE_MAX_MARKERS + c];
-            if (first || v > mv) {
-              mv = v;
-              ri = r;
-              ci = c;
-              first = false;
-            }
+        for (int c = 0; c < n_m; ++c) {
+          const bool gone = (removed >> c) & 1;
+          const unsigned v = gone ? 0u : s_colmax[grp][c];
+          if (first || v > mv) {
+            mv = v;
+            ri = gone ? 0 : (int)s_colrow[grp][c];
+            ci = c;
+            first = false;
           }
+        }
         if (mv < sp.hist_thr) break;
         s_cm[grp][n_c] = (unsigned char)(ci + 1);
         s_cd[grp][n_c] = (unsigned char)(ri + 1);
