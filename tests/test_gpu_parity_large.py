@@ -311,6 +311,50 @@ def test_streaming_submissions_are_bit_identical():
     h.close()
 
 
+def test_vote_events_time_the_fused_launches_inside_a_region():
+    """Option "vote_events": one pair of timing events per voting launch that carries a scan, for the last N pipelined
+    calls, read back as a mean (bench.py's roofline duration comes from it).  Joined calls of two sub-batches carry one
+    scan each, streaming submissions with a hint that comes true carry two; records are unaffected."""
+    import torch
+    B = 32768
+    cfg, _, fa = _frames_on_device("C2", B, 8380)
+    rows, cols = cfg["rows"], cfg["cols"]
+    K, D = synth.camera_for(rows, cols)
+    markers = np.asarray(cfg["markers"])
+    dev = fa.device
+    P = mpe.demo_params()
+    h = mpe.Handle(0)
+    stream = torch.cuda.Stream(device=dev)
+    h.set_stream(stream.cuda_stream)
+    nb = B * mpe.RESULT_DTYPE.itemsize
+    out = [torch.zeros(nb, dtype=torch.uint8, device=dev) for _ in range(2)]
+    with torch.cuda.stream(stream):
+        h.estimate_batch_device(fa.data_ptr(), B, rows, cols, markers, K, D, P, out[0].data_ptr())
+    stream.synchronize()
+    ref = out[0].clone()
+    assert h.get_option("vote_launches") == 0              # (off by default)
+    h.set_option("vote_events", 3)
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            h.estimate_batch_device(fa.data_ptr(), B, rows, cols, markers, K, D, P, out[1].data_ptr())
+    assert h.get_option("vote_launches") == 3              # one scan-carrying launch per joined call
+    ns = h.get_option("vote_launch_ns_mean")
+    assert 2e5 < ns < 2e7, ns                              # 16 384 frames voted + 70 % of 16 384 scanned: ~0.7 ms
+    assert torch.equal(out[1], ref)
+    h.set_option("vote_events", 2)                         # (resets)
+    with torch.cuda.stream(stream):
+        for i in range(3):
+            h.estimate_batch_device_submit(fa.data_ptr(), B, rows, cols, markers, K, D, P, out[i & 1].data_ptr(),
+                                           fa.data_ptr(), B)
+            h.estimate_batch_device_collect(0)
+    assert h.get_option("vote_launches") == 4              # the ring keeps the last two submissions, two launches each
+    stream.synchronize()
+    assert torch.equal(out[0], ref) and torch.equal(out[1], ref)
+    h.set_option("vote_events", 0)
+    assert h.get_option("vote_launches") == 0
+    h.close()
+
+
 def test_capacity_overrun_is_reported_alike_by_single_and_batch_replays(orc):
     """A frame with more blobs than MPE_MAX_DETECTIONS in the middle of a sequence: mpe_tracker_run_sequence and the
     lock-step batch replay both hand out a ZEROED record that carries the status code for that frame (and a zeroed
