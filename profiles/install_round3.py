@@ -61,8 +61,7 @@ def main():
             json.dump(last_json(F + "bench_%s.json" % c), open(P + "bench_%s.json" % c, "w"), indent=1)
     if os.path.exists(F + "stats_streams1/s_kernel_stats.csv"):
         keep_mpe(F + "stats_streams1/s_kernel_stats.csv", P + "bench_streams1_kernel_stats.csv")
-    if os.path.exists(F + "pytest_gpu.log"):
-        open(P + "pytest_gpu.txt", "w").write("".join(open(F + "pytest_gpu.log").readlines()[-4:]))
+    # (round3_pytest_gpu.txt: written by hand from collect_round3_u.sh, the last run on the committed tree)
     for n in ("streams1", "streams8", "lockstep8", "lockstep64", "lockstep256", "lockstep256g4t4", "lockstep512g8t8"):
         if os.path.exists(F + n + ".json") and os.path.getsize(F + n + ".json") > 2:
             json.dump(last_json(F + n + ".json"), open(P + "bench_%s.json" % n, "w"), indent=1)
