@@ -586,6 +586,33 @@ def test_marker_table_is_rebuilt_when_the_rig_changes():
 
 
 @pytest.mark.gpu
+def test_histogram_threshold_values(orc):
+    """correspondencesFromHistogram stops at the first maximum below histogram_threshold_ (pose_estimator.cpp:362; the
+    launch files use 0, the cfg allows more): thresholds 0, 1, 40, 200 and 100 000 on C2 frames with and without
+    distractors — statuses, correspondence counts and poses equal to the oracle's (the device kernel finds the
+    column maxima once and replays the reference's n_m scans on them)."""
+    d = synth.make_frames("C2", 24, seed=811)
+    cfgn = dict(synth.CONFIGS["C2"], n_distractors=3)
+    dn = synth.make_frames(cfgn, 24, seed=812)
+    h = mpe.Handle()
+    n_pose = {}
+    for thr in (0, 1, 40, 200, 100000):
+        Ph, Po = mpe.demo_params(histogram_threshold=thr), orc.make_params(histogram_threshold=thr)
+        n_pose[thr] = 0
+        for dd in (d, dn):
+            got = h.estimate_batch(dd["frames"], dd["markers"], dd["K"], dd["D"], Ph)
+            ref = orc.estimate_batch(dd["frames"], dd["markers"], dd["K"], dd["D"], Po)
+            assert np.array_equal(got["status"], ref["status"]), thr
+            assert np.array_equal(got["n_corr"], ref["n_corr"]) and np.array_equal(got["n_det"], ref["n_det"]), thr
+            for i in np.nonzero(got["status"] == 0)[0]:
+                dp, dr = pose_diff(got["T"][i].reshape(4, 4), ref["T"][i].reshape(4, 4))
+                assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (thr, i)
+                n_pose[thr] += 1
+    assert n_pose[0] >= 30 and n_pose[100000] == 0 and n_pose[200] <= n_pose[1]
+    h.close()
+
+
+@pytest.mark.gpu
 def test_check_and_optimise_stage_entry_points(hip, orc):
     """checkCorrespondences and optimisePose as separate device calls against the oracle's functions:
     the unrefined pose of computeTransformation, then Gauss-Newton from that pose AND from perturbed
