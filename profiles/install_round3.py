@@ -112,7 +112,7 @@ def main():
 
 def soaks():
     for n in ("soak_votes", "soak_fast", "soak_strict", "soak_fast_c3", "soak_fast_c3_tol2", "soak_fast_c4", "soak_fast_c1",
-              "soak_tracking", "soak_fast_1m", "soak_fast_c3_tol2_16k"):
+              "soak_tracking", "soak_fast_1m", "soak_fast_c3_tol2_16k", "soak_votes_c3"):
         if os.path.exists(F + n + ".json") and os.path.getsize(F + n + ".json") > 2:
             json.dump(last_json(F + n + ".json"), open(P + "parity_%s.json" % n, "w"), indent=1)
     # mismatching frames found by the soaks: detection sets -> tests/data/unstable_det_*.npy (C2 sets only), see
