@@ -9,7 +9,10 @@ a stream is latency bound (each frame needs the previous pose), so the figure of
 per-frame latency and how many streams one GPU carries at once.  8 streams over N ranks: rank r
 takes streams r, r+N, ...; there is no exchange step, rank 0 only gathers the counts.
 
-  python bench_streams.py [--streams 8] [--frames 400] [--gpus N]   (torchrun for N > 1)
+  python bench_streams.py [--streams 8] [--frames 400] [--gpus N]
+(`--gpus N` starts its own N ranks when no launcher did, like bench.py; `--plumbing-only` runs the launch / stream -> rank
+assignment / barrier / max-and-sum reductions / one JSON line on CPU over gloo with synthetic per-stream counts, which is
+how the CPU test suite drives the N > 1 path: tests/test_abi_cpu.py::test_bench_streams_plumbing_two_ranks)
 
 Parity of the tracking path against the CPU oracle is covered by tests/test_gpu_parity.py; the oracle's own
 tracking speed (the CPU figure quoted in DESIGN.md) is measured by tests/cpu_tracking_baseline.py.
@@ -25,6 +28,62 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def streams_of_rank(n_streams, rank, world):
+    """Stream s lives on rank s mod world (round robin): every rank carries floor or ceil of n_streams / world."""
+    return list(range(rank, n_streams, world))
+
+
+def reduce_counts(dt, n_frames, n_pose, n_brute, world, device):
+    """Whole-job numbers from the per-rank ones: wall time = the slowest rank's (MAX), the counts add up (SUM)."""
+    if world == 1:
+        return dt, n_frames, n_pose, n_brute
+    import torch
+    import torch.distributed as dist
+    v = torch.tensor([dt, n_frames, n_pose, n_brute], dtype=torch.float64, device=device)
+    vmax = v.clone()
+    dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    return float(vmax[0]), int(v[1]), int(v[2]), int(v[3])
+
+
+def plumbing_only(args, rank, world):
+    """No GPU, no kernels: every rank 'tracks' its streams by writing down deterministic counts (stream s finds a pose
+    in all but s % 3 frames and re-initialises s % 2 + 1 times) and sleeping 1 ms per time step plus 5 ms per rank
+    index — so the MAX over ranks is the last rank's time — then the same barrier / reductions / JSON line as the
+    real run, over gloo."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = streams_of_rank(args.streams, rank, world)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(1e-3 * args.frames * (1 if mine else 0) + 5e-3 * rank)
+    n_frames = len(mine) * args.frames
+    n_pose = sum(args.frames - s % 3 for s in mine)
+    n_brute = sum(s % 2 + 1 for s in mine)
+    dt_local = time.perf_counter() - t0
+    dt, n_frames, n_pose, n_brute = reduce_counts(dt_local, n_frames, n_pose, n_brute, world, "cpu")
+    # every rank's own stream list, gathered so that the test can see the assignment (not part of the real run)
+    owners = [None] * world
+    if world > 1:
+        dist.all_gather_object(owners, mine)
+    else:
+        owners = [mine]
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec over independent 752x480 camera streams, stateful estimator (tracking path)",
+                          "value": n_frames / dt, "unit": "frames/s", "n_gpus": world, "streams": args.streams,
+                          "streams_per_gpu": len(mine), "frames_per_stream": args.frames, "higher_is_better": True,
+                          "data": "synthetic", "dtype": "f64", "plumbing_only": True, "backend": "gloo",
+                          "wall_s_max_over_ranks": dt, "wall_s_rank0": dt_local, "frames_total": n_frames,
+                          "poses_total": n_pose, "bruteforce_total": n_brute, "streams_by_rank": owners,
+                          "config": {"workload": "plumbing only: no kernels"}}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
 
 
 def lockstep(args, mpe, seqs, mine, rank, world, local_rank):
@@ -47,12 +106,7 @@ def lockstep(args, mpe, seqs, mine, rank, world, local_rank):
     dt = time.perf_counter() - t0
     n_frames = len(mine) * args.frames
     n_pose, n_brute = int((rec["status"] == 0).sum()), int(info[:, :, 7].sum())
-    if world > 1:
-        v = torch.tensor([dt, n_frames, n_pose, n_brute], dtype=torch.float64, device="cuda")
-        vmax = v.clone()
-        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        dt, n_frames, n_pose, n_brute = float(vmax[0]), int(v[1]), int(v[2]), int(v[3])
+    dt, n_frames, n_pose, n_brute = reduce_counts(dt, n_frames, n_pose, n_brute, world, "cuda")
     if rank == 0:
         print(json.dumps({"metric": "frames/sec over independent 752x480 camera streams, stateful estimator (tracking path)",
                           "value": n_frames / dt, "unit": "frames/s", "n_gpus": world, "streams": args.streams,
@@ -88,15 +142,42 @@ def main():
     ap.add_argument("--lockstep", action="store_true",
                     help="all streams of a rank on ONE handle, driven in lock step: one device submission per time "
                          "step for all of them (mpe_tracker_run_sequences_batch) instead of one host thread per stream")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="no GPU work: launch, stream -> rank assignment, barrier, reductions and the JSON line on CPU "
+                         "(gloo) with synthetic per-stream counts; used by the CPU test-suite")
     args = ap.parse_args()
 
     import torch
-    import rpg_monocular_pose_estimator_amd as mpe
-    from rpg_monocular_pose_estimator_amd import synth
 
+    if args.gpus < 1 or args.streams < 1:
+        sys.exit("bench_streams.py: --gpus and --streams must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
+        if not args.plumbing_only and torch.cuda.device_count() < args.gpus:
+            sys.exit("bench_streams.py: --gpus %d, but only %d GPU(s) are visible on this box"
+                     % (args.gpus, torch.cuda.device_count()))
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench_streams.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+    if args.plumbing_only:
+        return plumbing_only(args, rank, world)
+
+    import rpg_monocular_pose_estimator_amd as mpe
+    from rpg_monocular_pose_estimator_amd import synth
+
+    if torch.cuda.device_count() < max(1, min(world, local_rank + 1)):
+        sys.exit("bench_streams.py: rank %d needs GPU %d, but only %d GPU(s) are visible"
+                 % (rank, local_rank, torch.cuda.device_count()))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -105,7 +186,7 @@ def main():
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
 
-    mine = list(range(rank, args.streams, world))
+    mine = streams_of_rank(args.streams, rank, world)
     # a smooth 36-frame trajectory played forwards and backwards keeps the target inside the image for any length
     seqs = []
     for s in mine:
@@ -156,12 +237,7 @@ def main():
     n_frames = len(mine) * args.frames
     n_pose = sum(int((o[0]["status"] == 0).sum()) for o in out)
     n_brute = sum(int(o[1][:, 7].sum()) for o in out)
-    if world > 1:
-        v = torch.tensor([dt, n_frames, n_pose, n_brute], dtype=torch.float64, device="cuda")
-        vmax = v.clone()
-        dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        dt, n_frames, n_pose, n_brute = float(vmax[0]), int(v[1]), int(v[2]), int(v[3])
+    dt, n_frames, n_pose, n_brute = reduce_counts(dt, n_frames, n_pose, n_brute, world, "cuda")
     if rank == 0:
         res = {"metric": "frames/sec over independent 752x480 camera streams, stateful estimator (tracking path)",
                "value": n_frames / dt, "unit": "frames/s", "n_gpus": world, "streams": args.streams,
@@ -182,4 +258,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

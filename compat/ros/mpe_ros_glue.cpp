@@ -7,8 +7,10 @@
 //   parameters  ~marker_positions (list of {x, y, z}), the 11 dynamic-reconfigure values of
 //               cfg/MonocularPoseEstimator.cfg
 //
-// NOT COMPILED IN THIS REPOSITORY'S ENVIRONMENT: ROS (roscpp, cv_bridge, image_transport, nodelet,
-// dynamic_reconfigure) is not installed here, so this file is source only.  Everything it does beyond
+// NOT BUILT IN THIS REPOSITORY'S ENVIRONMENT: ROS (roscpp, cv_bridge, image_transport, nodelet,
+// dynamic_reconfigure) is not installed here, so this file is source only — but it does see a compiler: the CPU test
+// tier runs `g++ -fsyntax-only` over it, as node and as nodelet, against declaration-only stand-ins for the ROS headers
+// (tests/mock_deps/ros_stubs, tests/test_abi_cpu.py::test_ros_glue_syntax).  Everything it does beyond
 // calling ROS — message field packing, calibration and parameter transfer — lives in
 // message_conversions.h and IS built and tested (tests/test_abi_cpu.py::test_ros_message_conversions);
 // the per-frame logic is the PoseEstimator facade (compat/monocular_pose_estimator_lib), tested on the GPU.
@@ -36,12 +38,15 @@ class MPENode {
  public:
   MPENode(const ros::NodeHandle& nh = ros::NodeHandle(), const ros::NodeHandle& nh_private = ros::NodeHandle("~"))
       : nh_(nh), nh_private_(nh_private), transport_(nh_), calibrated_(false) {
-    loadMarkers();
+    // the reference's order (monocular_pose_estimator.cpp:39-86): the dynamic-reconfigure server first ("before
+    // reading parameter server values": its first callback installs the cfg defaults / launch-file values), then the
+    // subscribers, the publishers, and the marker positions last
     reconfigure_.setCallback([this](MonocularPoseEstimatorConfig& cfg, uint32_t) { onReconfigure(cfg); });
-    pose_pub_ = nh_.advertise<geometry_msgs::PoseWithCovarianceStamped>("estimated_pose", 1);
-    overlay_pub_ = transport_.advertise("image_with_detections", 1);
     image_sub_ = nh_.subscribe("/camera/image_raw", 1, &MPENode::onImage, this);
     info_sub_ = nh_.subscribe("/camera/camera_info", 1, &MPENode::onCameraInfo, this);
+    pose_pub_ = nh_.advertise<geometry_msgs::PoseWithCovarianceStamped>("estimated_pose", 1);
+    overlay_pub_ = transport_.advertise("image_with_detections", 1);
+    loadMarkers();
   }
 
  private:
@@ -93,11 +98,17 @@ class MPENode {
       ROS_WARN("no camera info yet");
       return;
     }
-    // monocular_pose_estimator.cpp:147 converts every frame to MONO8 through cv_bridge.  mono8 is used in place; bgr8 /
-    // rgb8 / bgra8 / rgba8 / mono16 are decoded by the back-end itself (mpe_convert_to_mono8: the same integer /
-    // single-precision rules as cv::cvtColor / convertTo); anything else (Bayer patterns, ...) still goes through cv_bridge
+    // monocular_pose_estimator.cpp:147 converts every frame to MONO8 through cv_bridge.  mono8 is used in place and
+    // mono16 is decoded by the back-end (mpe_convert_to_mono8: convertTo's single-precision rule, the same in every
+    // OpenCV).  The colour encodings go through cv_bridge like everything else (Bayer patterns, ...) UNLESS the build
+    // says that the linked OpenCV converts 8-bit RGB to gray with the 14-bit weights (OpenCV <= 3.4.1: 1868 / 9617 /
+    // 4899, >> 14 — the rule mpe_convert_to_mono8 restates, for the OpenCV 3.3 of the reference's platform); OpenCV
+    // >= 3.4.2 uses 15-bit weights and can differ by one gray level, which near threshold_value flips LED pixels.
     cv_bridge::CvImageConstPtr mono;
-    const int enc = mpeEncodingFromString(msg->encoding);
+    int enc = mpeEncodingFromString(msg->encoding);
+#ifndef MPE_OPENCV_GRAY_14BIT
+    if (enc != MPE_ENC_MONO8 && enc != MPE_ENC_MONO16) enc = 0;
+#endif
     const uint8_t* pixels = nullptr;
     size_t step = 0;
     if (enc == MPE_ENC_MONO8) {
@@ -150,8 +161,8 @@ class MPENode {
     }
     if (overlay_pub_.getNumSubscribers() > 0) {
       cv_bridge::CvImage overlay(msg->header, sensor_msgs::image_encodings::BGR8,
-                                 cv::Mat(frame.rows, frame.cols, CV_8UC3));
-      ColorImageView colour(overlay.image.data, frame.rows, frame.cols, overlay.image.step);
+                                 cv::Mat((int)msg->height, (int)msg->width, CV_8UC3));
+      ColorImageView colour(overlay.image.data, (int)msg->height, (int)msg->width, overlay.image.step);
       Visualization::grayToColor(view, colour);
       if (found) estimator_.augmentImage(colour);
       overlay_pub_.publish(overlay.toImageMsg());

@@ -192,6 +192,12 @@ int mpe_estimate_batch_multi_device_gather(mpe_handle* const* handles, int n_dev
                                            int n_markers, const double K[9], const double* D, int nD,
                                            const mpe_params* p, mpe_result* d_results_dev0, int* used_rccl);
 
+/* Streaming entry, see mpe_estimate_batch_device_submit below: `hip_event` (a hipEvent_t, or NULL) marks the point at
+ * which the frames the NEXT _submit call announces (d_next_frames) are final; one-shot, consumed by that _submit. */
+int mpe_stream_next_ready(mpe_handle* h, void* hip_event);
+/* ... and: forget what the last submission scanned ahead (the announced buffer has been rewritten since). */
+int mpe_stream_drop_prefetch(mpe_handle* h);
+
 /* Fully asynchronous variant for device-resident pipelines: frames AND results are device
  * pointers, nothing is copied, the call only enqueues kernels on the handle's stream.
  * frames must be 16-byte aligned with cols % 16 == 0, stride_bytes == cols and
@@ -218,7 +224,15 @@ int mpe_estimate_batch_device(mpe_handle* h, const uint8_t* d_frames, int n_fram
  * exactly those frames skips that scan — in steady state no kernel of a batch runs without an image scan beside it
  * (pose_estimator.cpp:62-96 has no counterpart: the reference handles one frame at a time).  A hint that does not come
  * true only costs the wasted scan.  mpe_estimate_batch_device = _submit without a hint + _collect on the handle's
- * stream; it refuses to run while a submission is un-collected. */
+ * stream; it refuses to run while a submission is un-collected.
+ * CONTRACT for an announced buffer: its pixels are READ by this submission's last launches (on the handle's stream and
+ * on an internal side stream), i.e. possibly long before the next _submit.  They must therefore (a) be final, in the
+ * order of the handle's stream, when this _submit is called — or, if they are still being written on another stream
+ * (the upload of batch k+1 while batch k runs), the caller passes the event that marks their completion through
+ * mpe_stream_next_ready(h, event) right BEFORE this _submit: the reading launches then wait for it — and (b) stay
+ * unmodified until the next _submit has been called.  A buffer that was rewritten in between (a double-buffered camera
+ * pipeline that re-uses it) must be withdrawn with mpe_stream_drop_prefetch(h) before the next _submit, which then
+ * scans it again; the library recognises a prefetched batch by POINTER and shape only and cannot see the rewrite. */
 int mpe_estimate_batch_device_submit(mpe_handle* h, const uint8_t* d_frames, int n_frames, int rows, int cols,
                                      const double* markers_xyz, int n_markers, const double K[9], const double* D,
                                      int nD, const mpe_params* p, mpe_result* d_results,

@@ -130,6 +130,8 @@ def load_library():
     lib.mpe_estimate_batch_device_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, dp, C.c_int, dp,
                                                      dp, C.c_int, C.POINTER(MpeParams), C.c_void_p, C.c_void_p, C.c_int]
     lib.mpe_estimate_batch_device_collect.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mpe_stream_next_ready.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mpe_stream_drop_prefetch.argtypes = [C.c_void_p]
     lib.mpe_track_step_batch_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mpe_track_step_batch_cancel.argtypes = [C.c_void_p]
     lib.mpe_estimate_batch_multi_device_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, dp,
@@ -647,6 +649,14 @@ class Handle:
                                                         C.c_void_p(d_results_ptr), C.c_void_p(d_next_frames_ptr or None),
                                                         int(n_next))
         self._check(rc, "mpe_estimate_batch_device_submit")
+
+    def stream_next_ready(self, event_ptr):
+        """The frames the NEXT _submit announces are final once this hipEvent_t has completed (one-shot)."""
+        self._check(self._lib.mpe_stream_next_ready(self._h, C.c_void_p(event_ptr or None)), "mpe_stream_next_ready")
+
+    def stream_drop_prefetch(self):
+        """Forget what the last submission scanned ahead: the announced buffer has been rewritten since."""
+        self._check(self._lib.mpe_stream_drop_prefetch(self._h), "mpe_stream_drop_prefetch")
 
     def estimate_batch_device_collect(self, stream_ptr=0):
         """Make `stream_ptr` (0 = the handle's stream) wait for the records of the oldest un-collected submission."""

@@ -4,7 +4,16 @@
 // point fails with MPE_ERR_NO_DEVICE / MPE_ERR_HIP.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+// RCCL is dlopen'ed at first use by the one optional entry that needs it (mpe_estimate_batch_multi_device_gather): its
+// header is used when it is there, else the handful of declarations that entry touches are spelled out — the library
+// builds, and everything else works, on a box without RCCL.
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -52,6 +61,12 @@ struct mpe_handle {
   hipStream_t stream = nullptr;
   std::string err;
   DevBuf frames, flags, dets, hist, results, corr, mtab, work, scratch, track, mid;
+  // hypotheses the fast voting kernel leaves to the strict arithmetic (VoteFixup, mpe_internal.h): a control block of
+  // kMaxSub x 4 counters, then one list region per voting launch that can be in flight (sub-batch slot)
+  DevBuf fix;
+  unsigned fix_cap = 0;                 // entries per slot of the current layout
+  bool fix_pending[16] = {};            // slot: a voting launch has appended, its fix-up has not been launched yet
+  unsigned long long fix_items_base = 0, fix_overflow_base = 0;  // cumulative counters of layouts that were replaced
   void* mailbox = nullptr;  // pinned host memory for the single-frame tracking step (ROI in, record out)
   size_t mailbox_cap = 0;
   // host-side time of the tracked frame (option "track_profile" = 1 starts / resets): sums in ns
@@ -73,8 +88,12 @@ struct mpe_handle {
   const uint8_t* pending_track_rec = nullptr;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
   int vote_splits = 0;         // 0 = auto
-  int vote_arith = 1;          // 1 = fast voting arithmetic (default), 0 = strict: IEEE operators, the validation
-                               //     kernel's P3P (same quartic in K2 and K3)
+  int vote_arith = 1;          // 1 = fast voting arithmetic + strict re-evaluation of the hypotheses it cannot decide
+                               //     (default), 0 = strict: IEEE operators, the validation kernel's P3P (same quartic
+                               //     in K2 and K3), 2 = the fast arithmetic alone (round-3 behaviour, A/B only)
+  int force_rccl_gather = 0;   // option: mpe_estimate_batch_multi_device_gather sends EVERY shard's records (shard 0's
+                               // too: a send to itself) through RCCL, also with one handle — the self-test of that leg
+                               // on a 1-GPU box (dlopen, ncclCommInitAll, grouped send / recv)
   int refine_variant = 0;      // refinement kernel: 0 automatic (16 lanes per frame up to 2048 frames per launch, else one
                                // lane per frame), 1 / 2 force one of them; bit-identical results
   int k1a_dummy_lds = -1;      // tuning: dummy LDS per scan block in the two-stream schedule (-1 = automatic)
@@ -108,6 +127,7 @@ struct mpe_handle {
   hipEvent_t tail_sub_done[kMaxSub] = {};         // tail(s) of the previous submission has read dets / hist of region s
   bool tail_sub_pending = false;
   int tail_last = 0;                              // index of the last event recorded there
+  int tail_per = 0;                               // frames per region of the submission those events belong to
   // image scan of the NEXT submission's first sub-batch, carried by the last voting launch of this one
   struct Prefetch {
     bool valid = false;
@@ -121,6 +141,7 @@ struct mpe_handle {
     bool side_part = false;      // part of it came from the side scan: wait for prefetch_side_done
   } prefetch;
   hipEvent_t prefetch_side_done = nullptr;
+  hipEvent_t next_ready = nullptr;  // one-shot, consumed by the next _submit (mpe_stream_next_ready)
   bool done_recorded = false;  // run_pipeline has recorded batch_done[submit_seq & 1] itself (fused schedules)
   int last_nsub = 0, last_per = 0;  // work-list layout of the last pipelined batch (option "overflow_*")
   // the marker-permutation table in mtab is that of these markers, built in the order of this stream (a call with the
@@ -153,6 +174,9 @@ struct mpe_handle {
   int prof_frames_per_launch = 0;
   bool prof_pipelined = false;
   bool have_ms = false;
+  // chunked host ingest with profiling on: the kernel times of ALL chunks summed (mpe_last_kernel_ms), not the last one's
+  bool ms_accum_valid = false;
+  float ms_accum[5] = {0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -338,6 +362,69 @@ int auto_splits(const mpe_handle* h, int n_frames, int n_markers) {
   return std::max(1, std::min(s, 64));
 }
 
+// ---- strict re-evaluation of the fast voting kernel's suspects (VoteFixup) ----------------------------------------
+constexpr size_t kFixCtlBytes = (size_t)mpe_handle::kMaxSub * 4 * sizeof(unsigned);
+constexpr size_t kFixEntryBytes = 2 * sizeof(unsigned long long);
+// sum of the per-slot cumulative counters (synchronises the device); which = 1 list-full events, 3 entries re-evaluated
+int fix_counter_sum(mpe_handle* h, int which, unsigned long long& out) {
+  out = which == 1 ? h->fix_overflow_base : h->fix_items_base;
+  if (!h->fix.p) return MPE_OK;
+  HIP_TRY(h, hipDeviceSynchronize());
+  unsigned ctl[mpe_handle::kMaxSub * 4];
+  HIP_TRY(h, hipMemcpy(ctl, h->fix.p, sizeof(ctl), hipMemcpyDeviceToHost));
+  for (int s = 0; s < mpe_handle::kMaxSub; ++s) out += ctl[4 * s + which];
+  return MPE_OK;
+}
+// The list of voting launch `slot` (sub-batch index; 0 for single launches) sized for n_frames frames: ~0.6 % of the
+// hypotheses go to the list, the region holds 1/32 of them (>= 64 per frame), within a total of
+// 16 GB for all slots — a full list is not an error: the fast verdict then stands and "vote_fixup_overflow" counts it.
+int vote_fixup_for(mpe_handle* h, int slot, int n_frames, int n_markers, int n_det_hint, hipStream_t st, VoteFixup& fx) {
+  fx = VoteFixup{nullptr, nullptr, 0u};
+  if (h->vote_arith != 1 || n_markers < 4 || slot < 0 || slot >= mpe_handle::kMaxSub) return MPE_OK;
+  const long long nd = std::min(32, std::max(n_det_hint, n_markers) + 4);
+  const long long items = nd * (nd - 1) * (nd - 2) / 6 * n_markers * (n_markers - 1) * (n_markers - 2);
+  unsigned long long want = (unsigned long long)n_frames * (unsigned long long)std::max(64ll, items / 32);
+  const unsigned long long most = ((16ull << 30) / kFixEntryBytes) / mpe_handle::kMaxSub;
+  want = std::min(want, most);
+  if (want > h->fix_cap || !h->fix.p) {
+    // a new layout: nothing may be in flight on the old one (hipFree inside reserve() waits for the device anyway)
+    if (h->fix.p) {
+      unsigned long long v = 0;
+      int rc = fix_counter_sum(h, 1, v);
+      if (rc) return rc;
+      h->fix_overflow_base = v;
+      rc = fix_counter_sum(h, 3, v);
+      if (rc) return rc;
+      h->fix_items_base = v;
+    }
+    HIP_TRY(h, hipDeviceSynchronize());
+    h->fix.release();
+    const unsigned cap = (unsigned)std::max<unsigned long long>(want, h->fix_cap);
+    HIP_TRY(h, h->fix.reserve(kFixCtlBytes + (size_t)mpe_handle::kMaxSub * cap * kFixEntryBytes));
+    h->fix_cap = cap;
+    HIP_TRY(h, hipMemsetAsync(h->fix.p, 0, kFixCtlBytes, st));
+    HIP_TRY(h, hipStreamSynchronize(st));  // (other streams may be the first to touch it)
+    for (auto& b : h->fix_pending) b = false;
+  }
+  fx.ctl = static_cast<unsigned*>(h->fix.p) + 4 * slot;
+  fx.list = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(h->fix.p) + kFixCtlBytes) +
+            (size_t)slot * h->fix_cap * 2;
+  fx.cap = h->fix_cap;
+  if (h->fix_pending[slot]) {  // an earlier call failed between a voting launch and its fix-up: drop those entries
+    HIP_TRY(h, hipMemsetAsync(fx.ctl, 0, sizeof(unsigned), st));
+    HIP_TRY(h, hipMemsetAsync(fx.ctl + 2, 0, sizeof(unsigned), st));
+  }
+  h->fix_pending[slot] = true;
+  return MPE_OK;
+}
+hipError_t fixup_launch(mpe_handle* h, int slot, const mpe_detections* dets, const SolveParams& sp, uint32_t* hist,
+                        const VoteFixup& fx, hipStream_t st) {
+  if (!fx.ctl) return hipSuccess;
+  const hipError_t e = launch_k2_fixup(dets, sp, hist, fx, st);
+  if (e == hipSuccess) h->fix_pending[slot] = false;
+  return e;
+}
+
 // dummy LDS per block of the stand-alone scan kernel: the handle's tuning override, else 40 KB when the scan is
 // about to share the chip with the voting kernel of another sub-batch (two-stream schedule), else none
 int scan_lds(const mpe_handle* h, bool co_resident) {
@@ -368,8 +455,12 @@ int run_back(mpe_handle* h, hipStream_t st, bool prof, int n_frames, const Solve
              uint32_t* d_hist, mpe_result* d_results, uint32_t* d_corr) {
   if (sp) {
     HIP_TRY(h, hipMemsetAsync(d_hist, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), st));
+    VoteFixup fx;
+    { const int rc = vote_fixup_for(h, 0, n_frames, sp->n_markers, sp->n_markers, st, fx); if (rc) return rc; }
     HIP_TRY(h, launch_k2_vote(d_dets, n_frames, *sp, static_cast<const double*>(h->mtab.p), d_hist,
-                              auto_splits(h, n_frames, sp->n_markers), sp->n_markers, st));
+                              auto_splits(h, n_frames, sp->n_markers), sp->n_markers, st, nullptr, 0, nullptr, 0,
+                              nullptr, nullptr, &fx));
+    HIP_TRY(h, fixup_launch(h, 0, d_dets, *sp, d_hist, fx, st));
     if (prof) rec(h, 3);
     HIP_TRY(h, launch_k3_tail(d_dets, d_hist, n_frames, *sp, d_results, d_corr, nullptr, nullptr, 0.0, h->mid.p, st));
   } else if (prof) {
@@ -475,6 +566,7 @@ struct StreamHint {
   const uint8_t* next_frames = nullptr;  // device frames of the next submission (same geometry / parameters), or null
   int n_next = 0;
   bool no_join = false;  // do not join the side streams back into the caller's stream: completion = batch_done event
+  hipEvent_t next_ready = nullptr;  // the announced frames are final once this event has completed (mpe_stream_next_ready)
 };
 
 // Device time (ms) for one 1 ms spin kernel on each of two streams started together: ~1 when they execute
@@ -599,6 +691,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
                  const SolveParams* sp, mpe_detections* d_dets, uint32_t* d_hist, mpe_result* d_results,
                  uint32_t* d_corr, const StreamHint* hint = nullptr) {
   h->done_recorded = false;
+  h->ms_accum_valid = false;
   const size_t frame_bytes = (size_t)g.rows * g.pitch;
   const mpe_handle::Prefetch pf = h->prefetch;  // what the previous submission scanned for this one (if anything)
   h->prefetch.valid = false;
@@ -737,6 +830,10 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     while (n_real < nsub && n_real * per < n_frames) ++n_real;
     const bool tail_was_pending = h->tail_sub_pending;  // (this call records the same events anew)
     const int tail_was_last = h->tail_last;
+    // region s of this call covers the same frames as region s of the previous submission only if both cut their
+    // batches alike; otherwise every region waits for the previous submission's LAST tail (the tail stream executes
+    // them in order)
+    const bool tail_same_shape = h->tail_per == per;
     auto has_sub = [&](int s) { return s < n_real || (s == n_real && next_per > 0); };
     int f0, nf;
     const uint8_t* fr;
@@ -767,6 +864,8 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       } else {
         HIP_TRY(h, hipStreamWaitEvent(h->scan_stream, h->vote_done[k - 2], 0));
       }
+      if (k >= n_real && hint && hint->next_ready)  // the announced frames may still be uploading
+        HIP_TRY(h, hipStreamWaitEvent(h->scan_stream, hint->next_ready, 0));
       if (P) HIP_TRY(h, launch_k1a_scan(qfr, P, qfl, dp.thr, 0, h->scan_stream, h->side_scan_blocks));
       if (k >= n_real) {
         HIP_TRY(h, hipEventRecord(h->prefetch_side_done, h->scan_stream));
@@ -783,7 +882,8 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       used = s + 1;
       if (split_scan && s >= 1) HIP_TRY(h, hipStreamWaitEvent(st, h->scanpart_done[s], 0));
       // streaming: the tail of the PREVIOUS submission has read the detections / histograms of this region
-      if (tail_was_pending) HIP_TRY(h, hipStreamWaitEvent(st, h->tail_sub_done[std::min(s, tail_was_last)], 0));
+      if (tail_was_pending)
+        HIP_TRY(h, hipStreamWaitEvent(st, h->tail_sub_done[tail_same_shape ? std::min(s, tail_was_last) : tail_was_last], 0));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], st));
       HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
                                   static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
@@ -803,11 +903,15 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
         nbytes = (size_t)nnf * frame_bytes;
       }
       const size_t P = split_bytes(nbytes);  // (the first P bytes of sub-batch s + 1 come from the side scan)
+      if (nbytes && s + 1 >= n_real && hint && hint->next_ready)  // this launch reads the NEXT submission's frames
+        HIP_TRY(h, hipStreamWaitEvent(st, hint->next_ready, 0));
+      VoteFixup fx;
+      { const int rc = vote_fixup_for(h, s, per, sp->n_markers, sp->n_markers, st, fx); if (rc) return rc; }
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], st));
       HIP_TRY(h, vote_ev_begin(h, s, st));
       HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, *sp, static_cast<const double*>(h->mtab.p), hs,
                                 auto_splits(h, nf, sp->n_markers), sp->n_markers, st, nbytes ? nfr + P : nullptr,
-                                nbytes - P, nbytes ? nfl + P / 1024 : nullptr, dp.thr, &scanned));
+                                nbytes - P, nbytes ? nfl + P / 1024 : nullptr, dp.thr, &scanned, nullptr, &fx));
       HIP_TRY(h, vote_ev_end(h, s, st, scanned > 0));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], st));
       if (scanned > h->last_rider_bytes) h->last_rider_bytes = scanned;
@@ -830,6 +934,8 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
         if (rc) return rc;
       }
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], tst));
+      // the strict verdicts on what vote(s) left undecided: in front of the tail, off the caller's stream with it
+      HIP_TRY(h, fixup_launch(h, s, d_dets + f0, *sp, hs, fx, tst));
       HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
                                 d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0,
                                 static_cast<uint8_t*>(h->mid.p) + k3_mid_bytes(1) * (size_t)f0, tst));
@@ -840,6 +946,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       }
     }
     h->tail_sub_pending = side_tail;
+    h->tail_per = per;
     if (next_per > 0) {  // sub-batch 0 of the next submission has been scanned into the extra region
       h->prefetch.valid = true;
       h->prefetch.flags_ptr = flags_base + fw_per * nsub;
@@ -909,9 +1016,13 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     HIP_TRY(h, hipStreamWaitEvent(sb, h->sub_done[s], 0));
     uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
     HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), sb));
+    VoteFixup fx;
+    { const int rc = vote_fixup_for(h, s, per, sp->n_markers, sp->n_markers, sb, fx); if (rc) return rc; }
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], sb));
     HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, *sp, static_cast<const double*>(h->mtab.p), hs,
-                              auto_splits(h, nf, sp->n_markers), sp->n_markers, sb));
+                              auto_splits(h, nf, sp->n_markers), sp->n_markers, sb, nullptr, 0, nullptr, 0, nullptr,
+                              nullptr, &fx));
+    HIP_TRY(h, fixup_launch(h, s, d_dets + f0, *sp, hs, fx, sb));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], sb));
     HIP_TRY(h, hipEventRecord(h->vote_done[s], sb));
     hipStream_t stail = sb;
@@ -1028,6 +1139,7 @@ void mpe_destroy(mpe_handle* h) {
   h->scratch.release();
   h->track.release();
   h->mid.release();
+  h->fix.release();
   if (h->mailbox) (void)hipHostFree(h->mailbox);
   for (auto& e : h->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1087,8 +1199,19 @@ int mpe_set_profiling(mpe_handle* h, int enable) {
   return MPE_OK;
 }
 
+namespace {
+int last_kernel_ms_of_call(mpe_handle* h, float ms[5]);
+}
 int mpe_last_kernel_ms(mpe_handle* h, float ms[5]) {
   if (!h || !ms) return MPE_ERR_ARG;
+  if (h->ms_accum_valid) {  // a chunked host ingest: sums over its chunks
+    for (int i = 0; i < 5; ++i) ms[i] = h->ms_accum[i];
+    return MPE_OK;
+  }
+  return last_kernel_ms_of_call(h, ms);
+}
+namespace {
+int last_kernel_ms_of_call(mpe_handle* h, float ms[5]) {
   if (!h->have_ms) return fail(h, MPE_ERR_ARG, "profiling not enabled for the last batch");
   if (!h->prof_pipelined) {
     HIP_TRY(h, hipEventSynchronize(h->ev[4]));
@@ -1108,6 +1231,7 @@ int mpe_last_kernel_ms(mpe_handle* h, float ms[5]) {
   ms[4] = ms[0] + ms[1] + ms[2] + ms[3];
   return MPE_OK;
 }
+}  // namespace
 
 /* launches per kernel and frames per launch of the last profiled batch (1 / n_frames when not pipelined) */
 int mpe_last_kernel_ms_sub(mpe_handle* h, int sub_batch, float ms[4]) {
@@ -1135,6 +1259,7 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "lds_budget") *value = h->lds_budget;
   else if (n == "vote_splits") *value = h->vote_splits;
   else if (n == "vote_arith") *value = h->vote_arith;
+  else if (n == "force_rccl_gather") *value = h->force_rccl_gather;
   else if (n == "refine_variant") *value = h->refine_variant;
   else if (n == "ingest_chunk") *value = h->ingest_chunk;
   else if (n == "scan_split_pct") *value = h->scan_split_pct;
@@ -1143,6 +1268,15 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "k1a_dummy_lds") *value = h->k1a_dummy_lds;
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
+  else if (n == "vote_fixup_items" || n == "vote_fixup_overflow") {
+    // hypotheses (roots, detections) the fast voting kernel handed to the strict arithmetic since the handle was made,
+    // and how many it could not hand over because a list was full (the fast verdict then stood); saturating at INT_MAX
+    HIP_TRY(h, hipSetDevice(h->device));
+    unsigned long long v = 0;
+    const int rc = fix_counter_sum(h, n == "vote_fixup_items" ? 3 : 1, v);
+    if (rc) return rc;
+    *value = v > 0x7fffffffull ? 0x7fffffff : (int)v;
+  }
   else if (n == "vote_launch_ns_mean" || n == "vote_launches") {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1255,8 +1389,13 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
     h->refine_variant = value;
     return MPE_OK;
   }
+  if (!std::strcmp(name, "force_rccl_gather")) {
+    h->force_rccl_gather = value ? 1 : 0;
+    return MPE_OK;
+  }
   if (!std::strcmp(name, "vote_arith")) {
-    if (value != 0 && value != 1) return fail(h, MPE_ERR_ARG, "vote_arith must be 0 (strict) or 1 (fast)");
+    if (value < 0 || value > 2)
+      return fail(h, MPE_ERR_ARG, "vote_arith must be 0 (strict), 1 (fast + strict re-evaluation of suspects) or 2 (fast alone)");
     h->vote_arith = value;
     return MPE_OK;
   }
@@ -1380,9 +1519,18 @@ int vote_batch_impl(mpe_handle* h, const double* det_xy, const int* n_det, int n
     HIP_TRY(h, hipStreamSynchronize(h->stream));  // (rg goes out of scope)
     d_range = static_cast<const int*>(h->work.p);
   }
+  VoteFixup fx;
+  {
+    int nd_max = n_markers;
+    for (int f = 0; f < n_frames; ++f) nd_max = std::max(nd_max, n_det[f]);
+    const int rc = vote_fixup_for(h, 0, n_frames, n_markers, nd_max, h->stream, fx);
+    if (rc) return rc;
+  }
   HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), n_frames, sp, static_cast<const double*>(h->mtab.p),
                             static_cast<uint32_t*>(h->hist.p), auto_splits(h, n_frames, n_markers), n_markers,
-                            h->stream, nullptr, 0, nullptr, 0, nullptr, d_range));
+                            h->stream, nullptr, 0, nullptr, 0, nullptr, d_range, &fx));
+  HIP_TRY(h, fixup_launch(h, 0, static_cast<mpe_detections*>(h->dets.p), sp, static_cast<uint32_t*>(h->hist.p), fx,
+                          h->stream));
   HIP_TRY(h, hipMemcpyAsync(hist, h->hist.p, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1412,8 +1560,13 @@ int solve_bruteforce_impl(mpe_handle* h, const double* det_xy, int n_det, const 
   HIP_TRY(h, hipMemcpyAsync(h->dets.p, &hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
   { const int rc = prep_marker_table(h, sp); if (rc) return rc; }
+  VoteFixup fx;
+  { const int rc = vote_fixup_for(h, 0, 1, n_markers, n_det, h->stream, fx); if (rc) return rc; }
   HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), 1, sp, static_cast<const double*>(h->mtab.p),
-                            static_cast<uint32_t*>(h->hist.p), auto_splits(h, 1, n_markers), n_det, h->stream));
+                            static_cast<uint32_t*>(h->hist.p), auto_splits(h, 1, n_markers), n_det, h->stream, nullptr,
+                            0, nullptr, 0, nullptr, nullptr, &fx));
+  HIP_TRY(h, fixup_launch(h, 0, static_cast<mpe_detections*>(h->dets.p), sp, static_cast<uint32_t*>(h->hist.p), fx,
+                          h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
                             static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), nullptr,
                             nullptr, 0.0, h->mid.p, h->stream, tail_mode));
@@ -1690,10 +1843,24 @@ int mpe_estimate_batch_device_submit(mpe_handle* h, const uint8_t* d_frames, int
   hint.next_frames = d_next_frames;
   hint.n_next = d_next_frames ? n_next_frames : 0;
   hint.no_join = true;
+  hint.next_ready = hint.next_frames ? h->next_ready : nullptr;
+  h->next_ready = nullptr;  // one-shot
   const int rc = estimate_device_impl(h, d_frames, n_frames, rows, cols, markers_xyz, n_markers, K, D, nD, p, d_results,
                                       &hint);
   if (rc) return rc;
   ++h->submit_seq;
+  return MPE_OK;
+}
+
+int mpe_stream_next_ready(mpe_handle* h, void* hip_event) {
+  if (!h) return MPE_ERR_ARG;
+  h->next_ready = static_cast<hipEvent_t>(hip_event);
+  return MPE_OK;
+}
+
+int mpe_stream_drop_prefetch(mpe_handle* h) {
+  if (!h) return MPE_ERR_ARG;
+  h->prefetch.valid = false;  // the next _submit scans its first sub-batch itself
   return MPE_OK;
 }
 
@@ -1744,19 +1911,39 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
     HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->copy_done[0], 0));
     const int chunk = h->ingest_chunk;
     int ci = 0;
+    float acc[5] = {0, 0, 0, 0, 0};
+    // every early return below first waits for the copy stream: no DMA may still be reading the caller's (pinned)
+    // buffer when the call hands it back
+    auto bail = [&](int rc) -> int {
+      (void)hipStreamSynchronize(h->copy_stream);
+      (void)hipStreamSynchronize(h->stream);
+      return rc;
+    };
+#define INGEST_TRY(call)                                                   \
+  do {                                                                     \
+    const hipError_t e__ = (call);                                         \
+    if (e__ != hipSuccess) return bail(fail(h, MPE_ERR_HIP, #call, e__)); \
+  } while (0)
     for (int f0 = 0; f0 < n_frames; f0 += chunk, ++ci) {
       const int nf = std::min(chunk, n_frames - f0);
-      HIP_TRY(h, hipMemcpyAsync(d_all + (size_t)f0 * frame_bytes, frames + (size_t)f0 * frame_bytes, frame_bytes * nf,
+      INGEST_TRY(hipMemcpyAsync(d_all + (size_t)f0 * frame_bytes, frames + (size_t)f0 * frame_bytes, frame_bytes * nf,
                                 hipMemcpyHostToDevice, h->copy_stream));
-      HIP_TRY(h, hipEventRecord(h->copy_done[ci & 1], h->copy_stream));
-      HIP_TRY(h, hipStreamWaitEvent(h->stream, h->copy_done[ci & 1], 0));
+      INGEST_TRY(hipEventRecord(h->copy_done[ci & 1], h->copy_stream));
+      INGEST_TRY(hipStreamWaitEvent(h->stream, h->copy_done[ci & 1], 0));
       const int rc = run_pipeline(h, d_all + (size_t)f0 * frame_bytes, nf, g, dp, &sp, d_dets + f0,
                                   d_hist + (size_t)f0 * MPE_HIST_STRIDE, d_res + f0, nullptr);
-      if (rc) {  // no copy may still be reading the caller's buffer when the call returns
-        (void)hipStreamSynchronize(h->copy_stream);
-        (void)hipStreamSynchronize(h->stream);
-        return rc;
+      if (rc) return bail(rc);
+      if (h->profiling && h->have_ms) {  // (profiling: the chunks' kernel times add up; this synchronises per chunk)
+        float ms[5];
+        const int rm = last_kernel_ms_of_call(h, ms);
+        if (rm) return bail(rm);
+        for (int i = 0; i < 5; ++i) acc[i] += ms[i];
       }
+    }
+#undef INGEST_TRY
+    if (h->profiling && h->have_ms) {
+      for (int i = 0; i < 5; ++i) h->ms_accum[i] = acc[i];
+      h->ms_accum_valid = true;
     }
   } else {
     const uint8_t* d_frames = nullptr;
@@ -2011,8 +2198,13 @@ int mpe_solve_bruteforce_batch(mpe_handle* h, const double* det_xy, const int* n
   HIP_TRY(h, hipMemcpyAsync(h->dets.p, hd.data(), (size_t)n * sizeof(mpe_detections), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, hist_bytes, h->stream));
   { const int rc = prep_marker_table(h, sp); if (rc) return rc; }
+  VoteFixup fx;
+  { const int rc = vote_fixup_for(h, 0, n, n_markers, nd_max, h->stream, fx); if (rc) return rc; }
   HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), n, sp, static_cast<const double*>(h->mtab.p),
-                            static_cast<uint32_t*>(h->hist.p), auto_splits(h, n, n_markers), nd_max, h->stream));
+                            static_cast<uint32_t*>(h->hist.p), auto_splits(h, n, n_markers), nd_max, h->stream, nullptr,
+                            0, nullptr, 0, nullptr, nullptr, &fx));
+  HIP_TRY(h, fixup_launch(h, 0, static_cast<mpe_detections*>(h->dets.p), sp, static_cast<uint32_t*>(h->hist.p), fx,
+                          h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), n, sp,
                             static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), nullptr, nullptr,
                             0.0, h->mid.p, h->stream));
@@ -2131,18 +2323,23 @@ int mpe_estimate_batch_multi_device_gather(mpe_handle* const* handles, int n_dev
     if (!handles[d] || n_frames[d] < 0 || (n_frames[d] > 0 && !d_frames[d])) return MPE_ERR_ARG;
     off[(size_t)d + 1] = off[(size_t)d] + (size_t)n_frames[d];
   }
-  // distinct devices -> RCCL; handles that share a device (a 1-GPU box) -> plain device-to-device copies
+  // distinct devices -> RCCL; handles that share a device (a 1-GPU box) -> plain device-to-device copies.
+  // Option "force_rccl_gather" on handles[0]: RCCL for every shard including shard 0 (which then sends to itself) —
+  // with ONE handle that exercises the whole leg (library load, communicator, grouped send / recv) on a 1-GPU box.
   bool distinct = true;
   for (int d = 0; d < n_dev; ++d)
     for (int e = 0; e < d; ++e) distinct = distinct && handles[d]->device != handles[e]->device;
-  // every shard computes into its own device: shard 0 straight into the result array, the others into their handle's
-  // record buffer
+  const bool self_send = handles[0]->force_rccl_gather != 0 && distinct;
+  const bool via_rccl = distinct && (n_dev > 1 || self_send);
+  const int first = self_send ? 0 : 1;  // first shard whose records travel
+  // every shard computes into its own device: shard 0 straight into the result array (unless it is to travel as
+  // well), the others into their handle's record buffer
   std::vector<mpe_result*> d_part((size_t)n_dev, nullptr);
   int rc = run_shards(handles, n_dev, [&](int d) -> int {
     mpe_handle* h = handles[d];
     if (n_frames[d] == 0) return MPE_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    if (d == 0) {
+    if (d < first) {
       d_part[0] = d_results_dev0;
     } else {
       HIP_TRY(h, h->results.reserve((size_t)n_frames[d] * sizeof(mpe_result)));
@@ -2153,7 +2350,7 @@ int mpe_estimate_batch_multi_device_gather(mpe_handle* const* handles, int n_dev
   });
   if (rc != MPE_OK) return rc;
   mpe_handle* h0 = handles[0];
-  if (n_dev > 1 && distinct) {
+  if (via_rccl) {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (!g_rccl.load()) return fail(h0, MPE_ERR_UNSUPPORTED, g_rccl.err.c_str());
     std::vector<int> devs((size_t)n_dev);
@@ -2173,7 +2370,7 @@ int mpe_estimate_batch_multi_device_gather(mpe_handle* const* handles, int n_dev
     // one grouped exchange: rank d sends its records to rank 0 on its own stream (behind its kernels), rank 0 receives
     // them into their place of the result array on its stream — point-to-point over xGMI, 432 B per frame
     ncclResult_t r = g_rccl.GroupStart();
-    for (int d = 1; d < n_dev && r == ncclSuccess; ++d) {
+    for (int d = first; d < n_dev && r == ncclSuccess; ++d) {
       if (n_frames[d] == 0) continue;
       const size_t bytes = (size_t)n_frames[d] * sizeof(mpe_result);
       (void)hipSetDevice(handles[d]->device);
@@ -2183,13 +2380,22 @@ int mpe_estimate_batch_multi_device_gather(mpe_handle* const* handles, int n_dev
       r = g_rccl.Recv(d_results_dev0 + off[(size_t)d], bytes, ncclUint8, d, cs->comms[0], h0->stream);
     }
     const ncclResult_t r2 = g_rccl.GroupEnd();
+    // the senders' buffers are free again once their streams are through — also when the exchange failed half way:
+    // whatever was enqueued must not still be reading a handle's record buffer when the caller retries
+    hipError_t sync_err = hipSuccess;
+    mpe_handle* sync_h = nullptr;
+    for (int d = 0; d < n_dev; ++d) {
+      (void)hipSetDevice(handles[d]->device);
+      const hipError_t e = hipStreamSynchronize(handles[d]->stream);
+      if (e != hipSuccess && sync_err == hipSuccess) {
+        sync_err = e;
+        sync_h = handles[d];
+      }
+    }
     if (r != ncclSuccess || r2 != ncclSuccess)
       return fail(h0, MPE_ERR_HIP, g_rccl.GetErrorString ? g_rccl.GetErrorString(r != ncclSuccess ? r : r2) : "RCCL send / recv failed");
+    if (sync_err != hipSuccess) return fail(sync_h, MPE_ERR_HIP, "hipStreamSynchronize after the RCCL gather", sync_err);
     if (used_rccl) *used_rccl = 1;
-    for (int d = 1; d < n_dev; ++d) {  // the senders' buffers are free again once their streams are through
-      (void)hipSetDevice(handles[d]->device);
-      HIP_TRY(handles[d], hipStreamSynchronize(handles[d]->stream));
-    }
   } else {
     for (int d = 1; d < n_dev; ++d) {
       if (n_frames[d] == 0) continue;

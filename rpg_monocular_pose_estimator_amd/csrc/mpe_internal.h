@@ -54,11 +54,21 @@ struct SolveParams {
   double certainty_thr;   // certainty_threshold_
   double valid_corr_thr;  // valid_correspondence_threshold_
   unsigned hist_thr;      // histogram_threshold_
-  int vote_arith;         // option "vote_arith": 1 fast voting arithmetic (default), 0 strict (IEEE, literal order)
+  int vote_arith;         // option "vote_arith": 1 fast voting arithmetic + strict re-evaluation of the hypotheses it
+                          // cannot decide (default), 0 strict (IEEE, literal order), 2 fast alone (round-3 behaviour)
   int refine_variant;     // option "refine_variant": 0 automatic, 1 one lane per frame, 2 sixteen lanes per frame
 };
 
 #define MPE_HIST_STRIDE (MPE_MAX_DETECTIONS * MPE_MAX_MARKERS)
+
+// Hypotheses a fast voting launch does not decide itself (mpe_kernels.hip, k2_sus_push): a list in device memory that
+// launch_k2_fixup works off with the strict arithmetic, behind the voting launch and in front of the tail.
+struct VoteFixup {
+  unsigned* ctl;             // [0] entries appended (reset by the fix-up kernel), [1] appends that found the list full
+                             // (cumulative), [2] blocks done (internal), [3] entries re-evaluated (cumulative)
+  unsigned long long* list;  // cap entries of 2 words
+  unsigned cap;
+};
 
 // launchers (mpe_kernels.hip)
 size_t k1b_scratch_bytes(const FrameGeom& g);
@@ -84,7 +94,12 @@ hipError_t launch_k2_prep(const SolveParams& sp, double* tab, hipStream_t s);
 hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
                           uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px = nullptr,
                           size_t scan_bytes = 0, unsigned long long* scan_flags = nullptr, int scan_thr = 0,
-                          size_t* scanned_bytes = nullptr, const int* item_range = nullptr);
+                          size_t* scanned_bytes = nullptr, const int* item_range = nullptr,
+                          const VoteFixup* fixup = nullptr);
+// the strict re-evaluation of what that launch appended to `fixup` (sp.vote_arith == 1): same dets / hist pointers,
+// on a stream ordered behind the voting launch; its votes must be in before the tail reads the histograms
+hipError_t launch_k2_fixup(const mpe_detections* dets, const SolveParams& sp, uint32_t* hist, const VoteFixup& fixup,
+                           hipStream_t s);
 // splits < 0 (plain kernel): -splits blocks per frame that divide the marker PERMUTATIONS among themselves and keep
 // their slice of the per-permutation table in LDS (k2_table_slices says when and into how many)
 int k2_table_slices(int n_markers);

@@ -1616,6 +1616,11 @@ struct K2Frame {
                   // its fill count is a wave-uniform register of the caller)
   int vq_lanes;   // lanes that work the queue off together: 64 (1 when the host-tier test runs this source)
   int pj_base;    // first permutation of the table `tab` points at (0: the whole table; plain variant with LDS slices)
+  // hypotheses this arithmetic does not decide itself (k2_sus_push): list in global memory, worked off by k2_vote_fixup
+  unsigned* sus_ctl;  // [0] entries appended by this launch, [1] appends that found the list full (cumulative)
+  u64* sus_list;      // K2_SUS_WORDS words per entry
+  unsigned sus_cap;   // entries the list holds; 0 = no strict re-evaluation (every hypothesis votes in this arithmetic)
+  int frame;          // index of the frame within the launch
 };
 
 // i-th double of the LDS copy of the marker-permutation table (scan-carrying variant), K2_LTAB per permutation:
@@ -1635,47 +1640,144 @@ __device__ __forceinline__ float k2_prefilter_threshold(double back_tol) {
   return (float)(tol_pre * tol_pre * (1.0 + 1e-5));
 }
 
-// The exact half of the nearest-neighbour vote of ONE hypothesis (pose_estimator.cpp:663-702) for the unused
-// detections whose bit is set in `pass` (bit a = detection a got through the single-precision prefilter), with the
-// (<= 2) back-projections passed by value: exact double-precision search, strict `< tol` decided on the squares (the
-// square root is only taken inside the rounding band around tol^2), votes, and the triple's own three votes if any
-// detection voted.  The lane must be allowed to vote.
-__device__ __forceinline__ void k2_vote_exact(const K2Frame& F, int c0, int c1, int c2, int p0, int p1, int p2,
-                                              unsigned pass, double q0u, double q0v, double q1u, double q1v) {
+// ---- hypotheses handed to the strict arithmetic ------------------------------------------------------------------
+// The fast arithmetic of this kernel (Newton-Raphson division / square root, Newton cube root, [R|C]-free
+// back-projection with FMAs) and the strict one (IEEE operators, libm, the reference's statement order — k2_vote_strict,
+// which shares its P3P with the validation kernel) differ by a few ulp per operation.  A vote can only come out
+// differently where that difference is AMPLIFIED past the distance of a back-projection from the vote tolerance, so a
+// hypothesis is not decided here but appended to a list, and re-evaluated by k2_vote_fixup with the strict functions,
+// when
+//   (a) a subtraction of Ferrari's method cancelled below MPE_FERRARI_SUSPECT_EPS (1e-8) of its operands
+//       (solve_quartic_lit2: whole hypothesis, all four roots; 0.2 % of the hypotheses), or, per root,
+//       sin^2(theta) = 1 - root^2 or the vector (cn, cd) behind cot(alpha) is small for how well the quartic was
+//       conditioned (K2_SUS_OM / K2_SUS_HS), or |cos(alpha)| < 1e-6 (the strict arithmetic takes it as
+//       sqrt(1 - sin^2), which then has few digits);
+//   (b) the squared distance of a detection to its nearest back-projection lies within K2_SUS_BAND (relative) of
+//       tolerance^2 — +-1e-2 of the tolerance, e.g. +-0.05 px at 5 px, ten times what (a) lets through — or the
+//       nearest and the second nearest back-projection are that close to each other while in reach: only those
+//       detections of that root go to the list; the other detections' votes (and whether any of them voted: the
+//       triple's own three votes, pose_estimator.cpp:676-685) are cast here.
+// Votes are integer adds, so the order in which the two kernels cast them does not matter.  The strict verdict
+// REPLACES the fast one: with the list in place the histograms are those of k2_vote_strict (tests/soak_votes.py,
+// test_fast_votes_equal_strict_votes), at ~0.3 % of the hypotheses re-evaluated.  A full list (sized at > 100 times the
+// expected rate by the host side) leaves the fast verdict in place and counts the event (option
+// "vote_fixup_overflow").
+#ifndef K2_SUS_BAND
+#define K2_SUS_BAND 2e-2
+#endif
+// per root, by how well the quartic was conditioned (MPE_QUARTIC_MID: roots good to ~2e-8, else to ~2e-11): the error
+// of cos(theta) is divided by sin(theta) in the angle, that of (cn, cd) by its length relative to its operands
+#ifndef K2_SUS_OM
+#define K2_SUS_OM 1e-4       // sin^2(theta) below which a root of a MID quartic is suspect ...
+#define K2_SUS_OM_GOOD 1e-9  // ... and of a well-conditioned one
+#define K2_SUS_HS 1e-4       // (|(cn, cd)| / |operands|)^2 likewise
+#define K2_SUS_HS_GOOD 1e-10
+#define K2_SUS_COSA 1e-6     // |cos(alpha)| below which a root is suspect
+#endif
+#define K2_SUS_WORDS 2
+// entry: word 0 = frame | code << 32, word 1 = mask of the detections to decide; code = the hypothesis' detection and
+// marker indices, the roots to evaluate (kmask) and whether the fast arithmetic already cast the triple's own votes
+// for that root (any_fast; only with a single root in kmask)
+__device__ __forceinline__ unsigned k2_sus_code(int c0, int c1, int c2, int p0, int p1, int p2, unsigned kmask, bool any_fast) {
+  return (unsigned)(c0 | (c1 << 5) | (c2 << 10) | (p0 << 15) | (p1 << 19) | (p2 << 23)) | (kmask << 27) |
+         ((unsigned)any_fast << 31);
+}
+// append an entry; false = the list is full (the caller then votes in its own arithmetic)
+__device__ __forceinline__ bool k2_sus_push(const K2Frame& F, unsigned code, unsigned detmask) {
+  const unsigned slot = atomicAdd(&F.sus_ctl[0], 1u);
+  if (slot < F.sus_cap) {
+    F.sus_list[(size_t)K2_SUS_WORDS * slot] = (u64)(unsigned)F.frame | ((u64)code << 32);
+    F.sus_list[(size_t)K2_SUS_WORDS * slot + 1] = (u64)detmask;
+    return true;
+  }
+  atomicAdd(&F.sus_ctl[1], 1u);
+  return false;
+}
+
+// The exact half of the nearest-neighbour vote of ONE root of ONE hypothesis (pose_estimator.cpp:663-702) for the
+// unused detections whose bit is set in `pass` (bit a = detection a got through the single-precision prefilter), the
+// back-projections of the unused markers read through `qat(jj, u, v)`: exact double-precision search (first minimum),
+// strict `< tol` decided on the squares (the square root is only taken inside the rounding band around tol^2), votes,
+// and the triple's own three votes if any detection voted.  Detections in the suspect band (b) go to the list instead.
+// The lane must be allowed to vote.
+// cw = c0 | c1 << 8 | c2 << 16, pw = p0 | p1 << 8 | p2 << 16: the indices are unpacked where they are needed (the
+// rare branches), so that they do not occupy six registers across the search
+template <class QAt>
+__device__ __forceinline__ void k2_vote_root_exact(const K2Frame& F, const unsigned cw, const unsigned pw,
+                                                   unsigned pass, int k, QAt qat) {
   const double tol2 = F.back_tol * F.back_tol;
-  // bj-th unused marker (ascending) -> marker index: skip over the sorted used indices
-  const int lo = min(p0, min(p1, p2)), hi = max(p0, max(p1, p2)), mid = p0 + p1 + p2 - lo - hi;
+  const double band = F.sus_cap ? tol2 * K2_SUS_BAND : -1.0;  // (< 0: no detection ever is suspect)
   bool any = false;
-  while (pass) {
-    const int a = __builtin_ctz(pass);
-    pass &= pass - 1;
-    const double au = F.px[a][0], av = F.px[a][1];
-    double best = INFINITY;
-    int bj = 0;
-    for (int jj = 0; jj < F.nuo; ++jj) {
-      const double du = au - (jj == 0 ? q0u : q1u), dv = av - (jj == 0 ? q0v : q1v);
-      const double d2 = du * du + dv * dv;
-      if (d2 < best) {
-        best = d2;
-        bj = jj;
+  unsigned sus = 0;
+  // (one copy of the search in the code: a full list sends the suspects through the same loop once more, unscreened)
+  unsigned todo = pass;
+  bool screen = band >= 0.0;
+  for (;;) {
+    for (; todo; todo &= todo - 1) {
+      const int a = __builtin_ctz(todo);
+      const double au = F.px[a][0], av = F.px[a][1];
+      double best = INFINITY;
+      int bj = 0;
+      for (int jj = 0; jj < F.nuo; ++jj) {
+        double bu, bv;
+        qat(jj, bu, bv);
+        const double du = au - bu, dv = av - bv;
+        const double d2 = du * du + dv * dv;
+        if (d2 < best) {
+          best = d2;
+          bj = jj;
+        }
+      }
+      if (screen) {
+        bool s = fabs(best - tol2) <= band;
+        if (!s && best < tol2) {  // about to vote: is the runner-up as near as the winner?
+          for (int jj = 0; jj < F.nuo; ++jj) {
+            double bu, bv;
+            qat(jj, bu, bv);
+            const double du = au - bu, dv = av - bv;
+            s |= jj != bj && (du * du + dv * dv) - best <= band;
+          }
+        }
+        if (s) {
+          sus |= 1u << a;
+          continue;
+        }
+      }
+      bool within = best < tol2 * (1.0 - 1e-14);
+      if (!within && best < tol2 * (1.0 + 1e-14)) within = sqrt(best) < F.back_tol;
+      if (within) {
+        // bj-th unused marker (ascending) -> marker index: skip over the sorted used indices
+        const int p0 = pw & 0xFF, p1 = (pw >> 8) & 0xFF, p2 = (pw >> 16) & 0xFF;
+        const int lo = min(p0, min(p1, p2)), hi = max(p0, max(p1, p2)), mid = p0 + p1 + p2 - lo - hi;
+        int mi = bj;
+        mi += (mi >= lo);
+        mi += (mi >= mid);
+        mi += (mi >= hi);
+        atomicAdd(&F.hist[a * MPE_MAX_MARKERS + mi], 1u);
+        any = true;
       }
     }
-    bool within = best < tol2 * (1.0 - 1e-14);
-    if (!within && best < tol2 * (1.0 + 1e-14)) within = sqrt(best) < F.back_tol;
-    if (within) {
-      int mi = bj;
-      mi += (mi >= lo);
-      mi += (mi >= mid);
-      mi += (mi >= hi);
-      atomicAdd(&F.hist[a * MPE_MAX_MARKERS + mi], 1u);
-      any = true;
-    }
+    if (!sus) break;
+    if (k2_sus_push(F, k2_sus_code(cw & 0xFF, (cw >> 8) & 0xFF, (cw >> 16) & 0xFF, pw & 0xFF, (pw >> 8) & 0xFF,
+                                   (pw >> 16) & 0xFF, 1u << k, any), sus))
+      break;
+    todo = sus;  // list full: this arithmetic's own verdict for them
+    sus = 0;
+    screen = false;
   }
   if (any) {  // pose_estimator.cpp:676-685
-    atomicAdd(&F.hist[c0 * MPE_MAX_MARKERS + p0], 1u);
-    atomicAdd(&F.hist[c1 * MPE_MAX_MARKERS + p1], 1u);
-    atomicAdd(&F.hist[c2 * MPE_MAX_MARKERS + p2], 1u);
+    atomicAdd(&F.hist[(cw & 0xFF) * MPE_MAX_MARKERS + (pw & 0xFF)], 1u);
+    atomicAdd(&F.hist[((cw >> 8) & 0xFF) * MPE_MAX_MARKERS + ((pw >> 8) & 0xFF)], 1u);
+    atomicAdd(&F.hist[((cw >> 16) & 0xFF) * MPE_MAX_MARKERS + ((pw >> 16) & 0xFF)], 1u);
   }
+}
+// ... with the (<= 2) back-projections passed by value (scan-carrying variant)
+__device__ __forceinline__ void k2_vote_exact(const K2Frame& F, const unsigned cw, const unsigned pw, unsigned pass,
+                                              double q0u, double q0v, double q1u, double q1v, int k) {
+  k2_vote_root_exact(F, cw, pw, pass, k, [&](const int jj, double& bu, double& bv) {
+    bu = jj == 0 ? q0u : q1u;
+    bv = jj == 0 ? q0v : q1v;
+  });
 }
 
 // Deferred exact votes (scan-carrying variant).  About 1 % of the (hypothesis, detection) pairs pass the prefilter,
@@ -1683,13 +1785,16 @@ __device__ __forceinline__ void k2_vote_exact(const K2Frame& F, int c0, int c1, 
 // through the exact search and the vote with one or two lanes alive: that was 21 % of the voting kernel's time
 // (0.68 -> 0.54 ms per 16 384 frames with everything behind the prefilter compiled out).  Instead a lane that has a
 // candidate appends {back-projections, indices, prefilter mask} to its wave's small LDS queue (one entry per
-// hypothesis; slots come from a ballot, the fill count is a wave-uniform register) and the wave works the queue off
-// with one entry per LANE whenever it is nearly full: the same exact test, the same votes (integer adds: any order).
-// A lane that finds the queue full votes on the spot.  Measured: 0.855 -> 0.833 ms per fused launch.
+// hypothesis root; slots come from a ballot, the fill count is a wave-uniform register) and the wave works the queue
+// off with one entry per LANE whenever it is nearly full: the same exact test, the same votes (integer adds: any
+// order).  A lane that finds the queue full votes on the spot.  Measured: 0.855 -> 0.833 ms per fused launch.
 #define K2_VQ_CAP 12
 #define K2_VQ_WORDS 5
-__device__ __forceinline__ u64 k2_vq_meta(int c0, int c1, int c2, int p0, int p1, int p2, unsigned pass) {
-  return (u64)pass | ((u64)(unsigned)(c0 | (c1 << 5) | (c2 << 10) | (p0 << 15) | (p1 << 19) | (p2 << 23)) << 32);
+__device__ __forceinline__ u64 k2_vq_meta(const unsigned cw, const unsigned pw, int k, unsigned pass) {
+  const unsigned c0 = cw & 0xFF, c1 = (cw >> 8) & 0xFF, c2 = (cw >> 16) & 0xFF;
+  const unsigned p0 = pw & 0xFF, p1 = (pw >> 8) & 0xFF, p2 = (pw >> 16) & 0xFF;
+  return (u64)pass |
+         ((u64)(c0 | (c1 << 5) | (c2 << 10) | (p0 << 15) | (p1 << 19) | (p2 << 23) | ((unsigned)k << 27)) << 32);
 }
 __device__ __forceinline__ void k2_vote_flush(const K2Frame& F, int count) {
   wave_sync();
@@ -1699,9 +1804,10 @@ __device__ __forceinline__ void k2_vote_flush(const K2Frame& F, int count) {
     const u64* e = F.vq + (size_t)i * K2_VQ_WORDS;
     const u64 meta = e[4];
     const unsigned ix = (unsigned)(meta >> 32);
-    k2_vote_exact(F, ix & 31, (ix >> 5) & 31, (ix >> 10) & 31, (ix >> 15) & 15, (ix >> 19) & 15, (ix >> 23) & 15,
+    k2_vote_exact(F, (ix & 31) | (((ix >> 5) & 31) << 8) | (((ix >> 10) & 31) << 16),
+                  ((ix >> 15) & 15) | (((ix >> 19) & 15) << 8) | (((ix >> 23) & 15) << 16),
                   (unsigned)meta, __longlong_as_double((long long)e[0]), __longlong_as_double((long long)e[1]),
-                  __longlong_as_double((long long)e[2]), __longlong_as_double((long long)e[3]));
+                  __longlong_as_double((long long)e[2]), __longlong_as_double((long long)e[3]), (int)((ix >> 27) & 3));
   }
   wave_sync();  // (the entries are read before the next ones overwrite them)
 }
@@ -1755,17 +1861,30 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
                     f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
   rider.issue();  // P0: first scan round of the item (nothing is staged here: P6 consumed the last one)
   double root[4];
+  unsigned sus_item;
   solve_quartic_lit2(F0, F1, F2, F3, F4, root, [&]() {
     rider.consume();
     rider.issue();
-  });
+  }, sus_item);
   rider.consume();  // P1
   rider.issue();
-  // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
-  const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
-  const double tol2 = F.back_tol * F.back_tol;
   // the detections outside the triple, as a bit mask (n_d <= 32)
   const unsigned unused = (0xFFFFFFFFu >> (32 - F.n_d)) & ~((1u << c0) | (1u << c1) | (1u << c2));
+  const bool fix = F.sus_cap != 0u;  // (uniform) suspect hypotheses are decided by the strict arithmetic
+  if (fix && (sus_item & MPE_QUARTIC_SUSPECT) && live) {  // (a): Ferrari cancelled — all four roots to the list
+    if (k2_sus_push(F, k2_sus_code(c0, c1, c2, p0, p1, p2, 0xFu, false), unused)) {
+      if constexpr (SCAN)
+        live = false;
+      else
+        return;
+    }
+  }
+  // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
+  const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
+  // (cn, cd) below is suspect when it keeps less than 1e-2 of its operands
+  const bool q_mid = (sus_item & MPE_QUARTIC_MID) != 0u;
+  const double hs = (q_mid ? K2_SUS_HS : K2_SUS_HS_GOOD) * (__builtin_fma(g1, g1, p_2 * p_2) + __builtin_fma(g2, g2, g3 * g3));
+  const double oms = q_mid ? K2_SUS_OM : K2_SUS_OM_GOOD;
   // scan-carrying variant: the first two of them (all of them in a 5-detection frame) stay in registers for the four
   // roots' prefilters; a missing second one sits at infinity and passes no test
   unsigned rest = unused, lsb0 = 0, lsb1 = 0;
@@ -1793,9 +1912,11 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     // cot_alpha = cn / cd;  sin_alpha = sqrt(1 / (cot^2 + 1)) = |cd| / hypot(cn, cd),
     // cos_alpha = sign(cot) sqrt(1 - sin^2) = cn sign(cd) / hypot(cn, cd)
     const double cn = g1 - rt * p_2, cd = g2 * rt + g3;
-    const double ih = rsqrt_nr(__builtin_fma(cn, cn, cd * cd));
+    const double h2 = __builtin_fma(cn, cn, cd * cd);
+    const double ih = rsqrt_nr(h2);
     const double cos_theta = rt;
-    const double sin_theta = sqrt_nr(1 - rt * rt);
+    const double om = 1 - rt * rt;
+    const double sin_theta = sqrt_nr(om);
     const double sin_alpha = fabs(cd) * ih;
     const double cos_alpha = (cd < 0 ? -cn : cn) * ih;
     const double dk = d_12 * __builtin_fma(sin_alpha, b, cos_alpha);
@@ -1810,7 +1931,17 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
       else
         continue;
     }
-    const bool may_vote = live && finite_pose;
+    bool may_vote = live && finite_pose;
+    // (a), per root: sin(theta) = sqrt(1 - root^2) at its branch point, (cn, cd) cancelled, or cos(alpha) so small
+    // that the strict arithmetic's sqrt(1 - sin(alpha)^2) has no digits — this root to the list, all unused detections
+    if (fix && may_vote && (fabs(om) < oms || h2 < hs || fabs(cos_alpha) < K2_SUS_COSA)) {
+      if (k2_sus_push(F, k2_sus_code(c0, c1, c2, p0, p1, p2, 1u << k, false), unused)) {
+        if constexpr (SCAN)
+          may_vote = false;
+        else
+          continue;
+      }
+    }
     double q0u = 0, q0v = 0, q1u = 0, q1v = 0;
     // the prefilter's operands, transposed: (u of marker 0, u of marker 1) and (v, v); a missing second marker sits
     // at infinity and never is the nearest
@@ -1896,72 +2027,44 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
           e[1] = (u64)__double_as_longlong(q0v);
           e[2] = (u64)__double_as_longlong(q1u);
           e[3] = (u64)__double_as_longlong(q1v);
-          e[4] = k2_vq_meta(c0, c1, c2, p0, p1, p2, pass);
+          e[4] = k2_vq_meta(ii, (unsigned)packed, k, pass);
         } else {
-          k2_vote_exact(F, c0, c1, c2, p0, p1, p2, pass, q0u, q0v, q1u, q1v);
+          k2_vote_exact(F, ii & 0xFFFFFFu, (unsigned)packed & 0xFFFFFFu, pass, q0u, q0v, q1u, q1v, k);
         }
       }
       continue;
     }
-    bool any = false;
-    // the detections that are not part of the triple, ascending: a uniform trip count for the frame
+    // the detections that are not part of the triple, ascending: a uniform trip count for the frame; the ones that get
+    // through the single-precision prefilter are collected and decided together (k2_vote_root_exact)
+    unsigned pass = 0;
     for (unsigned m = unused; m; m &= m - 1) {
       const int a = __builtin_ctz(m);
-      {  // single-precision prefilter
-        const f32x2 af = F.pxf[a];
-        float mn = INFINITY;
-        if constexpr (NP > 0) {  // two markers per packed instruction, the back-projections from registers
+      const f32x2 af = F.pxf[a];
+      float mn = INFINITY;
+      if constexpr (NP > 0) {  // two markers per packed instruction, the back-projections from registers
 #pragma unroll
-          for (int pp = 0; pp < NP; ++pp) {
-            const f32x2 du = f32x2{af.x, af.x} - pfu[pp], dv = f32x2{af.y, af.y} - pfv[pp];
-            const f32x2 d2 = k2_pk_fma(dv, dv, du * du);
-            mn = k2_fminf(mn, k2_fminf(d2.x, d2.y));  // (a NaN distance never wins, as in the exact search)
-          }
-        } else {  // (both coordinates per instruction, the back-projections from their LDS columns)
+        for (int pp = 0; pp < NP; ++pp) {
+          const f32x2 du = f32x2{af.x, af.x} - pfu[pp], dv = f32x2{af.y, af.y} - pfv[pp];
+          const f32x2 d2 = k2_pk_fma(dv, dv, du * du);
+          mn = k2_fminf(mn, k2_fminf(d2.x, d2.y));  // (a NaN distance never wins, as in the exact search)
+        }
+      } else {  // (both coordinates per instruction, the back-projections from their LDS columns)
 #pragma unroll 4
-          for (int jj = 0; jj < F.nuo; ++jj) {
-            const f32x2 qf = F.qf[jj * F.nthr + F.tid];
-            f32x2 df = af - qf;
-            df = df * df;
-            const float d2f = df.x + df.y;
-            mn = d2f < mn ? d2f : mn;  // (a NaN distance never wins, as in the exact search)
-          }
-        }
-        if (!(mn <= F.thr_pre)) continue;
-      }
-      const double au = F.px[a][0], av = F.px[a][1];
-      double best = INFINITY;
-      int bj = 0;
-      for (int jj = 0; jj < F.nuo; ++jj) {
-        const double bu = F.q[(2 * jj) * F.nthr + F.tid];
-        const double bv = F.q[(2 * jj + 1) * F.nthr + F.tid];
-        const double du = au - bu, dv = av - bv;
-        const double d2 = du * du + dv * dv;
-        if (d2 < best) {
-          best = d2;
-          bj = jj;
+        for (int jj = 0; jj < F.nuo; ++jj) {
+          const f32x2 qf = F.qf[jj * F.nthr + F.tid];
+          f32x2 df = af - qf;
+          df = df * df;
+          const float d2f = df.x + df.y;
+          mn = d2f < mn ? d2f : mn;  // (a NaN distance never wins, as in the exact search)
         }
       }
-      // sqrt(best) < tol (strict, pose_estimator.cpp:689) decided on the squares; the square
-      // root is only taken inside the rounding band around tol^2
-      bool within = best < tol2 * (1.0 - 1e-14);
-      if (!within && best < tol2 * (1.0 + 1e-14)) within = sqrt(best) < F.back_tol;
-      if (within && may_vote) {
-        // bj-th unused marker (ascending) -> marker index: skip over the sorted used indices
-        const int lo = min(p0, min(p1, p2)), hi = max(p0, max(p1, p2)), mid = p0 + p1 + p2 - lo - hi;
-        int mi = bj;
-        mi += (mi >= lo);
-        mi += (mi >= mid);
-        mi += (mi >= hi);
-        atomicAdd(&F.hist[a * MPE_MAX_MARKERS + mi], 1u);
-        any = true;
-      }
+      pass |= (mn <= F.thr_pre) ? (1u << a) : 0u;
     }
-    if (any) {  // pose_estimator.cpp:676-685
-      atomicAdd(&F.hist[c0 * MPE_MAX_MARKERS + p0], 1u);
-      atomicAdd(&F.hist[c1 * MPE_MAX_MARKERS + p1], 1u);
-      atomicAdd(&F.hist[c2 * MPE_MAX_MARKERS + p2], 1u);
-    }
+    if (pass && may_vote)
+      k2_vote_root_exact(F, ii & 0xFFFFFFu, (unsigned)packed & 0xFFFFFFu, pass, k, [&](const int jj, double& bu, double& bv) {
+        bu = F.q[(2 * jj) * F.nthr + F.tid];
+        bv = F.q[(2 * jj + 1) * F.nthr + F.tid];
+      });
   }
   rider.consume();  // P6: nothing of the scan is in flight while the next item fetches its table values
   if constexpr (SCAN) {
@@ -1979,17 +2082,21 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
 // root the back-projection of the unused markers WITHOUT forming [R|C]:
 //     X_cam = R^T (m - C) = T^T Rm (N (m - P1) - C_eta),   Rm = the matrix of p3p.cpp:215-224,
 // which is the same point as project2d(m, inverse(H)) of pose_estimator.cpp:660 up to rounding.
+// Four waves per SIMD (<= 128 VGPRs) is what the voting kernels run at; with the suspect screening the allocator wants
+// 130 - 138, and asked for four waves it keeps a handful of loop-invariant values (table pointers, parameters) in
+// scratch OUTSIDE the item loop instead (checked in the ISA: every scratch access sits at loop depth <= 1).  The
+// instantiation with four packed marker pairs (10 - 11 markers) never fitted and stays at three.
 #ifndef K2_MIN_WAVES
-#define K2_MIN_WAVES 3
+#define K2_MIN_WAVES(NP) ((NP) == 4 ? 3 : 4)
 #endif
 // RANGE (forensics only, mpe_vote_items): frame f votes with the hypotheses whose flattened index — detection triple
 // x P(n_m,3) + marker permutation, the reference's loop order — lies in [item_range[2f], item_range[2f+1]); the
 // arithmetic of an item is the hot kernel's (same k2_vote_item).
 template <bool SCAN, bool RANGE = false, int NP = 0>
-__global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_detections* __restrict__ dets, SolveParams sp,
+__global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(const mpe_detections* __restrict__ dets, SolveParams sp,
                                                       const double* __restrict__ tab, uint32_t* __restrict__ hist,
                                                       int splits, ScanArgs scan, const int* __restrict__ item_range,
-                                                      int slice_tab) {
+                                                      int slice_tab, VoteFixup fixup) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double s_px[MPE_MAX_DETECTIONS][2];
   __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
@@ -2079,7 +2186,8 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
     }
   }
   const K2Frame F = {s_trii, s_tri, s_px, s_pxf, s_q,  s_qf, s_hist, tab_eff,     s_tab,   n_d,  nuo,
-                     nthr,   tid,   esz_eff, fx, fy,   cx,   cy,     sp.back_tol, thr_pre, s_vq, 64, p_lo};
+                     nthr,   tid,   esz_eff, fx, fy,   cx,   cy,     sp.back_tol, thr_pre, s_vq, 64, p_lo,
+                     fixup.ctl, reinterpret_cast<u64*>(fixup.list), fixup.cap, f};
   int vq_count = 0;  // entries in this wave's queue (wave-uniform)
   for (int tc0 = 0; tc0 < n_combos; tc0 += TRI) {
     const int ntri = min(TRI, n_combos - tc0);
@@ -2140,11 +2248,76 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES) void k2_vote(const mpe_de
   }
 }
 
-// Strict voting kernel (option "vote_arith" = 0): initialise()'s loop nest (pose_estimator.cpp:565-702) with the
-// SAME device functions the validation kernel uses — p3p_prepare / solve_quartic / p3p_solution / make_projection
-// / project, IEEE division and square root, the reference's statement order, [R|C] formed for every solution.
-// No tables, no scan rider, about 2.5x the instructions of k2_vote: the reference point for the fast kernel's
-// divergence rate, selectable at run time.
+// One hypothesis in the STRICT arithmetic: initialise()'s loop body (pose_estimator.cpp:596-702) for detection triple
+// (c0, c1, c2) against marker permutation (p0, p1, p2) with the SAME device functions the validation kernel uses —
+// p3p_prepare / solve_quartic / p3p_solution / make_projection / project, IEEE division and square root, libm cube
+// root, the reference's statement order, [R|C] formed for every solution.  `kmask` selects the roots, `detmask` the
+// detections to decide (k2_vote_strict: all four, every detection outside the triple; k2_vote_fixup: what the fast
+// kernel left undecided), `triple_voted`: the triple's own three votes of that root have been cast already.
+// q: 2 * (n_m - 3) doubles of scratch per lane, element i at q[i * qs].  vote(detection, marker) casts one vote.
+template <class Vote>
+__device__ __forceinline__ void k2_strict_item(const V3& fa, const V3& fb, const V3& fc, const double (*px)[2],
+                                               const SolveParams& sp, int c0, int c1, int c2, int p0, int p1, int p2,
+                                               unsigned kmask, unsigned detmask, bool triple_voted, double* q, int qs,
+                                               Vote vote) {
+  const int n_m = sp.n_markers, nuo = n_m - 3;
+  const V3 wa = {sp.markers[3 * p0], sp.markers[3 * p0 + 1], sp.markers[3 * p0 + 2]},
+           wb = {sp.markers[3 * p1], sp.markers[3 * p1 + 1], sp.markers[3 * p1 + 2]},
+           wc = {sp.markers[3 * p2], sp.markers[3 * p2 + 1], sp.markers[3 * p2 + 2]};
+  P3PCtx ctx;
+  if (!p3p_prepare(fa, fb, fc, wa, wb, wc, ctx)) return;  // computePoses returned -1
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    if (!((kmask >> k) & 1u)) continue;
+    M3 R;
+    V3 C;
+    p3p_solution(ctx, pick_root(ctx, k), R, C);
+    if (!rc_finite(R, C)) continue;  // pose_estimator.cpp:653
+    const Proj P = make_projection(R, C, sp.fx, sp.fy, sp.cx, sp.cy);
+    int j = 0;
+    for (int m = 0; m < n_m; ++m) {  // unused markers, ascending (pose_estimator.cpp:621-661)
+      if (m == p0 || m == p1 || m == p2) continue;
+      double u, v;
+      project(P, V3{sp.markers[3 * m], sp.markers[3 * m + 1], sp.markers[3 * m + 2]}, u, v);
+      q[(2 * j) * qs] = u;
+      q[(2 * j + 1) * qs] = v;
+      ++j;
+    }
+    bool any = false;
+    for (unsigned dm = detmask; dm; dm &= dm - 1) {  // unused detections, ascending (pose_estimator.cpp:576-597, 862-906)
+      const int a = __builtin_ctz(dm);
+      double best = INFINITY;
+      int bj = 0;
+      for (int jj = 0; jj < nuo; ++jj) {
+        const double du = px[a][0] - q[(2 * jj) * qs], dv = px[a][1] - q[(2 * jj + 1) * qs];
+        const double d2 = du * du + dv * dv;
+        if (d2 < best) {
+          best = d2;
+          bj = jj;
+        }
+      }
+      if (sqrt(best) < sp.back_tol) {  // strict <, pose_estimator.cpp:671,689
+        int mi = -1, cnt = 0;
+        for (int m = 0; m < n_m; ++m) {
+          if (m == p0 || m == p1 || m == p2) continue;
+          if (cnt == bj) mi = m;
+          ++cnt;
+        }
+        vote(a, mi);
+        any = true;
+      }
+    }
+    if (any && !triple_voted) {  // pose_estimator.cpp:676-685
+      vote(c0, p0);
+      vote(c1, p1);
+      vote(c2, p2);
+    }
+  }
+}
+
+// Strict voting kernel (option "vote_arith" = 0): initialise()'s loop nest (pose_estimator.cpp:565-702), every
+// hypothesis through k2_strict_item.  No tables, no scan rider, about 2.5x the instructions of k2_vote: the reference
+// point the default arithmetic is held against, selectable at run time.
 __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detections* __restrict__ dets, SolveParams sp,
                                                              uint32_t* __restrict__ hist, int splits,
                                                              const int* __restrict__ item_range) {
@@ -2171,7 +2344,6 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detection
   double* s_q = reinterpret_cast<double*>(smem);  // back-projections: [2*j + {0,1}][tid]
   const int n_combos = n_d * (n_d - 1) * (n_d - 2) / 6;
   const int n_perms = n_m * (n_m - 1) * (n_m - 2);
-  const int nuo = n_m - 3;
   const long long total = (long long)n_combos * n_perms;
   for (long long t = (long long)part * nthr + tid; t < total; t += (long long)splits * nthr) {
     if (item_range && (t < item_range[2 * f] || t >= item_range[2 * f + 1])) continue;  // (forensics only)
@@ -2181,57 +2353,9 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detection
     perm_from_index(pj, n_m, p0, p1, p2);
     const V3 fa = {s_iv[c0][0], s_iv[c0][1], s_iv[c0][2]}, fb = {s_iv[c1][0], s_iv[c1][1], s_iv[c1][2]},
              fc = {s_iv[c2][0], s_iv[c2][1], s_iv[c2][2]};
-    const V3 wa = {sp.markers[3 * p0], sp.markers[3 * p0 + 1], sp.markers[3 * p0 + 2]},
-             wb = {sp.markers[3 * p1], sp.markers[3 * p1 + 1], sp.markers[3 * p1 + 2]},
-             wc = {sp.markers[3 * p2], sp.markers[3 * p2 + 1], sp.markers[3 * p2 + 2]};
-    P3PCtx ctx;
-    if (!p3p_prepare(fa, fb, fc, wa, wb, wc, ctx)) continue;  // computePoses returned -1
-#pragma unroll 1
-    for (int k = 0; k < 4; ++k) {
-      M3 R;
-      V3 C;
-      p3p_solution(ctx, pick_root(ctx, k), R, C);
-      if (!rc_finite(R, C)) continue;  // pose_estimator.cpp:653
-      const Proj P = make_projection(R, C, sp.fx, sp.fy, sp.cx, sp.cy);
-      int j = 0;
-      for (int m = 0; m < n_m; ++m) {  // unused markers, ascending (pose_estimator.cpp:621-661)
-        if (m == p0 || m == p1 || m == p2) continue;
-        double u, v;
-        project(P, V3{sp.markers[3 * m], sp.markers[3 * m + 1], sp.markers[3 * m + 2]}, u, v);
-        s_q[(2 * j) * nthr + tid] = u;
-        s_q[(2 * j + 1) * nthr + tid] = v;
-        ++j;
-      }
-      bool any = false;
-      for (int a = 0; a < n_d; ++a) {  // unused detections, ascending (pose_estimator.cpp:576-597, 862-906)
-        if (a == c0 || a == c1 || a == c2) continue;
-        double best = INFINITY;
-        int bj = 0;
-        for (int jj = 0; jj < nuo; ++jj) {
-          const double du = s_px[a][0] - s_q[(2 * jj) * nthr + tid], dv = s_px[a][1] - s_q[(2 * jj + 1) * nthr + tid];
-          const double d2 = du * du + dv * dv;
-          if (d2 < best) {
-            best = d2;
-            bj = jj;
-          }
-        }
-        if (sqrt(best) < sp.back_tol) {  // strict <, pose_estimator.cpp:671,689
-          int mi = -1, cnt = 0;
-          for (int m = 0; m < n_m; ++m) {
-            if (m == p0 || m == p1 || m == p2) continue;
-            if (cnt == bj) mi = m;
-            ++cnt;
-          }
-          atomicAdd(&s_hist[a * MPE_MAX_MARKERS + mi], 1u);
-          any = true;
-        }
-      }
-      if (any) {  // pose_estimator.cpp:676-685
-        atomicAdd(&s_hist[c0 * MPE_MAX_MARKERS + p0], 1u);
-        atomicAdd(&s_hist[c1 * MPE_MAX_MARKERS + p1], 1u);
-        atomicAdd(&s_hist[c2 * MPE_MAX_MARKERS + p2], 1u);
-      }
-    }
+    const unsigned unused = (0xFFFFFFFFu >> (32 - n_d)) & ~((1u << c0) | (1u << c1) | (1u << c2));
+    k2_strict_item(fa, fb, fc, s_px, sp, c0, c1, c2, p0, p1, p2, 0xFu, unused, false, s_q + tid, nthr,
+                   [&](const int a, const int m) { atomicAdd(&s_hist[a * MPE_MAX_MARKERS + m], 1u); });
   }
   __syncthreads();
   uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
@@ -2241,11 +2365,65 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detection
   }
 }
 
+// The hypotheses a fast voting launch left undecided (k2_sus_push), one per lane, through k2_strict_item; their votes
+// go straight into the frames' histograms in global memory (the voting launch has stored or added its own by then:
+// same stream, or an event in between).  The last block to finish resets the list's fill count for the next launch
+// and adds the number of entries to the cumulative counter (ctl[3]).
+#define K2_FIX_THREADS 64
+__global__ __launch_bounds__(K2_FIX_THREADS) void k2_vote_fixup(const mpe_detections* __restrict__ dets, SolveParams sp,
+                                                                uint32_t* __restrict__ hist, VoteFixup fx) {
+  __shared__ double s_q[2 * (MPE_MAX_MARKERS - 3) * K2_FIX_THREADS];
+  const unsigned n = min(fx.ctl[0], fx.cap);
+  const u64* list = reinterpret_cast<const u64*>(fx.list);
+  const int tid = threadIdx.x;
+  for (unsigned i = blockIdx.x * K2_FIX_THREADS + tid; i < n; i += gridDim.x * K2_FIX_THREADS) {
+    const u64 w0 = list[(size_t)K2_SUS_WORDS * i];
+    const unsigned detmask = (unsigned)list[(size_t)K2_SUS_WORDS * i + 1];
+    const int f = (int)(unsigned)w0;
+    const unsigned code = (unsigned)(w0 >> 32);
+    const int c0 = code & 31, c1 = (code >> 5) & 31, c2 = (code >> 10) & 31;
+    const int p0 = (code >> 15) & 15, p1 = (code >> 19) & 15, p2 = (code >> 23) & 15;
+    const unsigned kmask = (code >> 27) & 15u;
+    const bool triple_voted = (code >> 31) & 1u;
+    const mpe_detections* d = dets + f;
+    // the frame's detections, read straight from the record: k2_strict_item indexes px[a][0 / 1]
+    const double (*px)[2] = reinterpret_cast<const double (*)[2]>(d->undist_xy);
+    const V3 fa = bearing(px[c0][0], px[c0][1], sp.fx, sp.fy, sp.cx, sp.cy),
+             fb = bearing(px[c1][0], px[c1][1], sp.fx, sp.fy, sp.cx, sp.cy),
+             fc = bearing(px[c2][0], px[c2][1], sp.fx, sp.fy, sp.cx, sp.cy);
+    uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
+    k2_strict_item(fa, fb, fc, px, sp, c0, c1, c2, p0, p1, p2, kmask, detmask, triple_voted, s_q + tid, K2_FIX_THREADS,
+                   [&](const int a, const int m) { atomicAdd(&gh[a * MPE_MAX_MARKERS + m], 1u); });
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    if (atomicAdd(&fx.ctl[2], 1u) == gridDim.x - 1) {  // every other block has read ctl[0] and finished
+      fx.ctl[3] += n;
+      fx.ctl[0] = 0;
+      fx.ctl[2] = 0;
+      __threadfence();
+    }
+  }
+}
+
+hipError_t launch_k2_fixup(const mpe_detections* dets, const SolveParams& sp, uint32_t* hist, const VoteFixup& fx,
+                           hipStream_t s) {
+  if (!fx.ctl || fx.cap == 0 || sp.n_markers < 4) return hipSuccess;
+  // (the entry count lives on the device: a fixed grid strides over it; lists are short — ~5e-5 of the hypotheses)
+  hipLaunchKernelGGL(k2_vote_fixup, dim3(256), dim3(K2_FIX_THREADS), 0, s, dets, sp, hist, fx);
+  return hipGetLastError();
+}
+
 hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
                           uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px,
                           size_t scan_bytes, unsigned long long* scan_flags, int scan_thr, size_t* scanned_bytes,
-                          const int* item_range) {
+                          const int* item_range, const VoteFixup* fixup) {
   if (scanned_bytes) *scanned_bytes = 0;
+  // vote_arith 1: suspect hypotheses go to `fixup` (the caller launches launch_k2_fixup behind this kernel);
+  // 2: the fast arithmetic decides everything itself (round-3 behaviour, for A/B measurements); 0: strict kernel
+  VoteFixup fx = {nullptr, nullptr, 0u};
+  if (sp.vote_arith == 1 && fixup && fixup->ctl && fixup->list) fx = *fixup;
   if (n_frames <= 0 || sp.n_markers < 4) return hipSuccess;
   int slice_tab = 0;
   if (splits < 0) {  // -(blocks per frame): the blocks share the marker permutations, table slices in LDS
@@ -2298,7 +2476,7 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
           (size_t)(threads / 64) * K2_VQ_CAP * K2_VQ_WORDS * sizeof(u64);
     if (scanned_bytes) *scanned_bytes = (size_t)sa.n_chunks * chunk_bytes;
     hipLaunchKernelGGL((k2_vote<true, false>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
-                       splits, sa, (const int*)nullptr, 0);
+                       splits, sa, (const int*)nullptr, 0, fx);
   } else {
     // plain kernel: the prefilter's single-precision back-projections in registers as (nuo + 1) / 2 packed marker pairs
     // (up to 8 unused markers), else in LDS columns; the forensics instantiation (item_range) the same way
@@ -2317,10 +2495,10 @@ hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveP
   do {                                                                                                               \
     if (item_range)                                                                                                  \
       hipLaunchKernelGGL((k2_vote<false, true, NPV>), grid, block, lds, s, dets, sp, tab, hist, splits, sa, item_range, \
-                         slice_tab);                                                                                 \
+                         slice_tab, fx);                                                                             \
     else                                                                                                             \
       hipLaunchKernelGGL((k2_vote<false, false, NPV>), grid, block, lds, s, dets, sp, tab, hist, splits, sa,         \
-                         (const int*)nullptr, slice_tab);                                                            \
+                         (const int*)nullptr, slice_tab, fx);                                                        \
   } while (0)
     switch (np) {
       case 1: MPE_K2_PLAIN(1); break;

@@ -301,11 +301,40 @@ __device__ __forceinline__ C2 cpow_third_newton(C2 z) {
 struct NoService {
   __device__ __forceinline__ void operator()() const {}
 };
+// Cancellation below which a subtraction of Ferrari's method is reported as `suspect` by solve_quartic_lit2: the
+// result keeps less than EPS of its operands.  Measured on the quartics of 1.2 M C2 hypotheses (host build of this
+// header, fast against strict arithmetic): the real parts of the roots differ by at most ~2e-16 / c where c is the
+// smallest of the five ratios below — and small ratios are COMMON (c < 1e-6 for 1.9 % of the hypotheses, < 1e-8 for
+// 0.25 %, < 1e-10 for 0.04 %: the P3P quartic of a wrong correspondence often has nearly coinciding roots).  With
+// 1e-8 the two arithmetics agree to ~2e-8 in every root that is not reported, i.e. to < 5e-3 px in a back-projection
+// (<= 600 px / sin(theta) per unit of cos(theta), sin(theta) >= 1e-2 or the root is reported separately) — a tenth of
+// the band (b) of the voting kernel.  The voting kernel hands reported hypotheses to the strict functions
+// (k2_vote_fixup) instead of voting on them itself.
+// A second, wider level (1e-5: roots agree to ~2e-11 when it is not reported either) lets the caller choose how close
+// to a branch point of the back-substitution (sin(theta) -> 0, cot(alpha) -> 0/0) a root may come before IT is suspect.
+#ifndef MPE_FERRARI_SUSPECT_EPS
+#define MPE_FERRARI_SUSPECT_EPS 1e-8
+#endif
+#ifndef MPE_FERRARI_MID_EPS
+#define MPE_FERRARI_MID_EPS 1e-5
+#endif
+#define MPE_QUARTIC_SUSPECT 1u  // some ratio below MPE_FERRARI_SUSPECT_EPS
+#define MPE_QUARTIC_MID 2u      // some ratio below MPE_FERRARI_MID_EPS
+__device__ __forceinline__ double cabs1(C2 z) { return fabs(z.re) + fabs(z.im); }
 // `service` is called at two points inside (after the cube root, after w): the voting kernel's scan rider uses
 // them to retire / start LDS-DMA rounds behind the arithmetic; a no-op everywhere else.
-template <class Service = NoService>
+// `suspect` (out, MPE_QUARTIC_*): some subtraction of p3p.cpp:253-283 cancelled below the two levels above — the
+// discriminant Q^2/4 + P^3/27, R = -Q/2 + sqrt(disc), w^2 = alpha + 2y (y with the magnitudes of ITS operands, so a
+// cancellation inside y counts), the two outer radicands -(3 alpha + 2y +- 2 beta / w): the quantities
+// tests/forensics.py classifies mismatching frames by.  NaN operands never compare true (such roots vote nowhere).
+template <class Service>
 __device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C, double D, double E, double rr[4],
-                                                   Service service = Service()) {
+                                                   Service service, unsigned& suspect) {
+  bool sus = false, mid = false;
+  auto check = [&](const double result, const double operands) {  // (|result|, sum of |operands|)
+    sus |= result < MPE_FERRARI_SUSPECT_EPS * operands;
+    mid |= result < MPE_FERRARI_MID_EPS * operands;
+  };
   const double A_pw2 = A * A, B_pw2 = B * B;
   const double A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B;
   const double A_pw4 = A_pw3 * A, B_pw4 = B_pw3 * B;
@@ -323,30 +352,48 @@ __device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C,
                     (beta * beta) * 0.125;
   const C2 q2 = cpow2_real(Qr), p3 = cpow3_real(Pr);
   const C2 disc = {q2.re * 0.25 + div_const(p3.re, 27.0, 1.0 / 27.0), q2.im * 0.25 + div_const(p3.im, 27.0, 1.0 / 27.0)};
+  check(fabs(disc.re), q2.re * 0.25 + fabs(p3.re) * (1.0 / 27.0));
   const C2 sq = csqrt_lit2(disc);
   const C2 R = {-Qr * 0.5 + sq.re, sq.im};
+  check(cabs1(R), fabs(Qr) * 0.5 + cabs1(sq));
   const C2 U = cpow_third_newton(R);
   service();
   C2 y;
+  double ysc;  // sum of the magnitudes of y's operands
   const double a56 = div_const(-5.0 * alpha, 6.0, 1.0 / 6.0);
   if (U.re == 0.0) {
     const C2 qc = cpow_third_newton(C2{Qr, 0.0});
     y = {a56 - qc.re, -qc.im};
+    ysc = fabs(a56) + cabs1(qc);
   } else {
     const C2 t = cdiv_lit2(C2{Pr, 0.0}, cscale(U, 3.0));
     y = {a56 - t.re + U.re, -t.im + U.im};
+    ysc = fabs(a56) + cabs1(t) + cabs1(U);
   }
-  const C2 w = csqrt_lit2(C2{alpha + 2.0 * y.re, 2.0 * y.im});
+  const C2 w2 = {alpha + 2.0 * y.re, 2.0 * y.im};
+  check(cabs1(w2), fabs(alpha) + 2.0 * ysc);
+  const C2 w = csqrt_lit2(w2);
   const C2 bw = cdiv_lit2(C2{2.0 * beta, 0.0}, w);
   service();
   const C2 base = {3.0 * alpha + 2.0 * y.re, 2.0 * y.im};
-  const C2 s1 = csqrt_lit2(C2{-(base.re + bw.re), -(base.im + bw.im)});
-  const C2 s2 = csqrt_lit2(C2{-(base.re - bw.re), -(base.im - bw.im)});
+  const C2 rad1 = {-(base.re + bw.re), -(base.im + bw.im)}, rad2 = {-(base.re - bw.re), -(base.im - bw.im)};
+  const double rsc = 3.0 * fabs(alpha) + 2.0 * ysc + cabs1(bw);
+  check(cabs1(rad1), rsc);
+  check(cabs1(rad2), rsc);
+  suspect = (sus ? MPE_QUARTIC_SUSPECT : 0u) | (mid ? MPE_QUARTIC_MID : 0u);
+  const C2 s1 = csqrt_lit2(rad1);
+  const C2 s2 = csqrt_lit2(rad2);
   const double off = div_with_rcp(-B, 4.0 * A, 0.25 * r1);
   rr[0] = off + 0.5 * (w.re + s1.re);
   rr[1] = off + 0.5 * (w.re - s1.re);
   rr[2] = off + 0.5 * (-w.re + s2.re);
   rr[3] = off + 0.5 * (-w.re - s2.re);
+}
+template <class Service = NoService>
+__device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C, double D, double E, double rr[4],
+                                                   Service service = Service()) {
+  unsigned suspect;
+  solve_quartic_lit2(A, B, C, D, E, rr, service, suspect);
 }
 
 // Everything of computePoses that does not depend on the root index.  p3p.cpp:65-190

@@ -45,6 +45,13 @@ namespace mpe {
 #include "vote_extract.inc"
 }
 using namespace mpe;
+// [0] suspect-list entries of the last call, [1] of which whole hypotheses (Ferrari), [2] list-full events
+static unsigned g_stats[3];
+extern "C" void host_vote_stats(unsigned* out) {
+  out[0] = g_stats[0];
+  out[1] = g_stats[1];
+  out[2] = g_stats[2];
+}
 
 // variant 0: k2_vote<false> (back-projections in the LDS columns, votes on the spot); variant 1: k2_vote<true> as far as
 // one lane can run it (LDS copy of the table, back-projections by value, exact votes deferred through the queue)
@@ -85,9 +92,64 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   std::vector<double> ltab((size_t)n_perms * K2_LTAB);
   for (size_t i = 0; i < ltab.size(); ++i) ltab[i] = k2_ltab_value(tab.data(), esz, nuo, (int)i);
   std::vector<u64> vq((size_t)K2_VQ_CAP * K2_VQ_WORDS, 0);
+  // variants 10 / 11: as 0 / 1 with the suspect list in place, worked off by k2_strict_item afterwards (what
+  // k2_vote_fixup does on the device); variant 20: every hypothesis through k2_strict_item (= k2_vote_strict)
+  // variants 30 / 31: the same with a list of four entries — nearly every append finds it full and the fast verdict
+  // stands (counted in the statistics)
+  const bool tiny_list = variant == 30 || variant == 31;
+  if (tiny_list) variant -= 20;
+  const bool fixup = variant == 10 || variant == 11;
+  if (fixup) variant -= 10;
+  g_stats[0] = g_stats[1] = g_stats[2] = 0;
+  if (variant == 20) {
+    std::vector<double> qs(2 * nuo);
+    for (int ti = 0; ti < n_combos; ++ti)
+      for (int pj = 0; pj < n_perms; ++pj) {
+        int c0, c1, c2, p0, p1, p2;
+        unrank_combo3(ti, n_d, c0, c1, c2);
+        perm_from_index(pj, n_m, p0, p1, p2);
+        const V3 fa = {iv[c0][0], iv[c0][1], iv[c0][2]}, fb = {iv[c1][0], iv[c1][1], iv[c1][2]},
+                 fc = {iv[c2][0], iv[c2][1], iv[c2][2]};
+        const unsigned unused = (0xFFFFFFFFu >> (32 - n_d)) & ~((1u << c0) | (1u << c1) | (1u << c2));
+        k2_strict_item(fa, fb, fc, px, sp, c0, c1, c2, p0, p1, p2, 0xFu, unused, false, qs.data(), 1,
+                       [&](const int a, const int m) { hist[a * MPE_MAX_MARKERS + m] += 1u; });
+      }
+    return 0;
+  }
+  const unsigned sus_cap = fixup ? (tiny_list ? 4u : 1u << 16) : 0u;
+  std::vector<u64> sus_list((size_t)K2_SUS_WORDS * (sus_cap + 1), 0);
+  unsigned sus_ctl[4] = {0, 0, 0, 0};
   const K2Frame F = {trii.data(), reinterpret_cast<const double(*)[13]>(tri.data()), px, pxf, q.data(), qf.data(),
                      hist, tab.data(), ltab.data(), n_d, nuo, 1, 0, esz, sp.fx, sp.fy, sp.cx, sp.cy, sp.back_tol,
-                     k2_prefilter_threshold(sp.back_tol), vq.data(), 1, 0};
+                     k2_prefilter_threshold(sp.back_tol), vq.data(), 1, 0, sus_ctl, sus_list.data(), sus_cap, 0};
+  struct Fix {
+    const K2Frame& F;
+    const SolveParams& sp;
+    const double (*iv)[3];
+    const double (*px)[2];
+    unsigned* hist;
+    int nuo;
+    ~Fix() {  // the strict re-evaluation of what the fast pass appended (k2_vote_fixup)
+      std::vector<double> qs(2 * nuo);
+      const unsigned n = std::min(F.sus_ctl[0], F.sus_cap);
+      g_stats[0] += n;
+      g_stats[2] += F.sus_ctl[1];
+      for (unsigned i = 0; i < n; ++i) {
+        const u64 w0 = F.sus_list[(size_t)K2_SUS_WORDS * i];
+        const unsigned detmask = (unsigned)F.sus_list[(size_t)K2_SUS_WORDS * i + 1];
+        const unsigned code = (unsigned)(w0 >> 32);
+        const int c0 = code & 31, c1 = (code >> 5) & 31, c2 = (code >> 10) & 31;
+        const int p0 = (code >> 15) & 15, p1 = (code >> 19) & 15, p2 = (code >> 23) & 15;
+        const unsigned kmask = (code >> 27) & 15u;
+        if (kmask == 0xFu) g_stats[1] += 1;
+        const V3 fa = {iv[c0][0], iv[c0][1], iv[c0][2]}, fb = {iv[c1][0], iv[c1][1], iv[c1][2]},
+                 fc = {iv[c2][0], iv[c2][1], iv[c2][2]};
+        unsigned* h = hist;
+        k2_strict_item(fa, fb, fc, px, sp, c0, c1, c2, p0, p1, p2, kmask, detmask, (code >> 31) & 1u, qs.data(), 1,
+                       [&](const int a, const int m) { h[a * MPE_MAX_MARKERS + m] += 1u; });
+      }
+    }
+  } fix_at_exit = {F, sp, iv, px, hist, nuo};
   NoRider rider;
   if (variant == 1) {
     if (nuo > 2) return -2;  // the scan-carrying variant keeps at most two back-projections (in registers)
@@ -116,7 +178,8 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
 // n detection sets in one call (tests/soak_votes_host.py): det n x MPE_MAX_DETECTIONS x 2, hist n x MPE_MAX_DETECTIONS
 // x MPE_MAX_MARKERS
 extern "C" int host_vote_batch(const double* det, const int* n_det, int n, const double* markers, int n_m, const double* k4,
-                               double back_tol, unsigned* hist, int variant) {
+                               double back_tol, unsigned* hist, int variant, unsigned* stats_sum /* 3, optional */) {
+  if (stats_sum) stats_sum[0] = stats_sum[1] = stats_sum[2] = 0;
   for (int i = 0; i < n; ++i) {
     unsigned* h = hist + (size_t)i * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS;
     if (n_det[i] < 4) {
@@ -125,6 +188,8 @@ extern "C" int host_vote_batch(const double* det, const int* n_det, int n, const
     }
     const int rc = host_vote(det + (size_t)i * 2 * MPE_MAX_DETECTIONS, n_det[i], markers, n_m, k4, back_tol, h, variant);
     if (rc) return rc;
+    if (stats_sum)
+      for (int j = 0; j < 3; ++j) stats_sum[j] += g_stats[j];
   }
   return 0;
 }

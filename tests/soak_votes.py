@@ -1,11 +1,15 @@
 """Vote-histogram parity soak with forensics: detection sets of N synthetic frames (HIP detection, bit-exact vs the
-oracle) through the HIP voting kernel in BOTH arithmetics (option "vote_arith": 1 fast, 0 strict) and through the
-oracle's voting (frame-parallel on the host cores).  Every frame whose histogram differs anywhere is SAVED
-(detections + both histograms -> <out>.npz) and CLASSIFIED (tests/forensics.py): both paths are asked for every
-hypothesis' own votes, the difference is traced to the hypotheses that cast it, and each of those must sit in the
-unstable corner of the reference's Ferrari solver (cancellation < 1e-12) or be one on which the oracle's own P3P
-answer moves under a 1-ulp change of an input.  Exit code 1 if a mismatch stays unexplained.
-usage (on an MI355X): python tests/soak_votes.py [frames [config [out_prefix]]]      -> one JSON line"""
+oracle) through the HIP voting in THREE arithmetics (option "vote_arith": 1 = the default: the fast kernel with its
+suspects re-evaluated by the strict functions, k2_vote_fixup; 0 = the strict kernel; 2 = the fast kernel alone, round 3's
+default) and through the oracle's voting (frame-parallel on the host cores).  Counted: frames whose histogram differs
+from the oracle's, per arithmetic, and — the round-4 claim — frames on which the DEFAULT differs from STRICT (must be
+0: exit code 2 otherwise).  Every frame that differs from the oracle is SAVED (detections + both histograms ->
+<out>.npz) and CLASSIFIED (tests/forensics.py): both paths are asked for every hypothesis' own votes, the difference is
+traced to the hypotheses that cast it, and each of those must sit in the unstable corner of the reference's Ferrari
+solver (cancellation < 1e-12) or be one on which the oracle's own P3P answer moves under a 1-ulp change of an input.
+Exit code 1 if a mismatch stays unexplained.
+usage (on an MI355X): python tests/soak_votes.py [frames [config [out_prefix]]]      -> one JSON line
+MPE_SOAK_STRICT=0 skips the strict kernel (2.5x the time; at C3 it is run on the first MPE_SOAK_STRICT_FRAMES frames)"""
 import json
 import os
 import sys
@@ -36,11 +40,17 @@ h = mpe.Handle(0)
 P = mpe.demo_params()
 TOL = 5.0
 cores = len(os.sched_getaffinity(0))
-diff = {0: 0, 1: 0}
-cells = {0: 0, 1: 0}
+STRICT = os.environ.get("MPE_SOAK_STRICT", "1") != "0"
+STRICT_FRAMES = int(os.environ.get("MPE_SOAK_STRICT_FRAMES", str(N if CONFIG != "C3" else min(N, 4096))))
+diff = {0: 0, 1: 0, 2: 0}
+cells = {0: 0, 1: 0, 2: 0}
+default_vs_strict = 0
+default_vs_strict_frames = []
+strict_frames = 0
 saved = []
 tot = 0
 t0 = time.time()
+h.get_option("vote_fixup_items")
 for part in range(max(1, N // CH)):
     _, spots = synth.make_scenes_batch(cfg, CH, seed=7100 + part)
     frames = synth.render_frames_torch(spots, rows, cols, cfg["spot_sigma"], dev, seed=8100 + part)
@@ -49,14 +59,16 @@ for part in range(max(1, N // CH)):
     nd = det["n"].astype(np.int32)
     dets = det["undist_xy"].reshape(CH, mpe.MAX_DETECTIONS, 2)
     ref = orc.vote_batch(dets, nd, markers, K, TOL, n_threads=cores)
-    for arith in (1, 0):
-        if arith == 0 and CONFIG == "C3":
-            continue  # (the strict kernel takes 2.5x the time; C3 is soaked in the product arithmetic)
+    got = {}
+    do_strict = STRICT and tot < STRICT_FRAMES
+    for arith in (1, 2, 0):
+        if arith == 0 and not do_strict:
+            continue
         h.set_option("vote_arith", arith)
-        got = h.vote_batch([dets[i, :nd[i]] for i in range(CH)], markers, K, TOL)
+        got[arith] = h.vote_batch([dets[i, :nd[i]] for i in range(CH)], markers, K, TOL)
         for i in range(CH):
             r = ref[i, :nd[i], :len(markers)] if nd[i] >= 4 else np.zeros((nd[i], len(markers)), np.uint32)
-            g = got[i] if nd[i] >= 4 else np.zeros_like(r)
+            g = got[arith][i] if nd[i] >= 4 else np.zeros_like(r)
             if not np.array_equal(g, r):
                 diff[arith] += 1
                 cells[arith] += int((g != r).sum())
@@ -64,8 +76,14 @@ for part in range(max(1, N // CH)):
                 saved.append({"part": part, "frame": i, "vote_arith": arith, "det": dets[i, :nd[i]].copy(),
                               "hip": g.copy(), "oracle": r.copy(), "verdict": c})
     h.set_option("vote_arith", 1)
+    if do_strict:
+        strict_frames += CH
+        for i in range(CH):
+            if nd[i] >= 4 and not np.array_equal(got[1][i], got[0][i]):
+                default_vs_strict += 1
+                default_vs_strict_frames.append([part, i])
     tot += CH
-    print(part, tot, diff, round(time.time() - t0), flush=True)
+    print(part, tot, diff, default_vs_strict, round(time.time() - t0), flush=True)
 unexplained = [s for s in saved if not s["verdict"]["unstable"]]
 if saved:
     os.makedirs(os.path.dirname(OUT) or ".", exist_ok=True)
@@ -74,10 +92,18 @@ if saved:
              **{"oracle_%d" % k: s["oracle"] for k, s in enumerate(saved)},
              meta=json.dumps([{k: v for k, v in s.items() if k not in ("det", "hip", "oracle")} for s in saved]))
 print(json.dumps({"config": CONFIG, "frames": tot, "p3p_solves_per_frame": "C(n_det,3) x P(n_markers,3)",
-                  "frames_with_a_different_histogram": {"fast (vote_arith 1)": diff[1], "strict (vote_arith 0)": diff[0]},
-                  "differing_cells": {"fast": cells[1], "strict": cells[0]},
+                  "frames_with_a_different_histogram_vs_oracle": {
+                      "default (vote_arith 1: fast + strict re-evaluation of suspects)": diff[1],
+                      "strict (vote_arith 0)": diff[0] if strict_frames else None,
+                      "fast alone (vote_arith 2, round 3's default)": diff[2]},
+                  "differing_cells": {"default": cells[1], "strict": cells[0], "fast alone": cells[2]},
+                  "frames_compared_default_vs_strict": strict_frames,
+                  "frames_default_differs_from_strict": default_vs_strict,
+                  "frames_default_differs_from_strict_idx": default_vs_strict_frames[:20],
+                  "vote_fixup_items": h.get_option("vote_fixup_items"),
+                  "vote_fixup_overflow": h.get_option("vote_fixup_overflow"),
                   "mismatches_classified_unstable": len(saved) - len(unexplained),
                   "mismatches_unexplained": len(unexplained),
                   "mismatching_frames_saved_to": (OUT + ".npz") if saved else None,
                   "verdicts": [{k: v for k, v in s.items() if k not in ("det", "hip", "oracle")} for s in saved]}))
-sys.exit(1 if unexplained else 0)
+sys.exit(2 if default_vs_strict else (1 if unexplained else 0))

@@ -48,21 +48,43 @@ def main():
         ref = orc.vote_batch(det, n_det, markers, K, 5.0, n_threads=os.cpu_count() or 1)
         t1 = time.time()
         k4 = np.array([K[0][0], K[1][1], K[0][2], K[1][2]], float)
-        got = np.zeros((n, MAX_DET, MAX_MARK), np.uint32)
-        rc = lib.host_vote_batch(det.ctypes.data_as(C.c_void_p), n_det.ctypes.data_as(C.c_void_p), n,
-                                 markers.ctypes.data_as(C.c_void_p), len(markers), k4.ctypes.data_as(C.c_void_p),
-                                 C.c_double(5.0), got.ctypes.data_as(C.c_void_p), variant)
-        assert rc == 0, rc
+
+        def run(var):
+            out = np.zeros((n, MAX_DET, MAX_MARK), np.uint32)
+            stats = np.zeros(3, np.uint32)
+            rc = lib.host_vote_batch(det.ctypes.data_as(C.c_void_p), n_det.ctypes.data_as(C.c_void_p), n,
+                                     markers.ctypes.data_as(C.c_void_p), len(markers), k4.ctypes.data_as(C.c_void_p),
+                                     C.c_double(5.0), out.ctypes.data_as(C.c_void_p), var, stats.ctypes.data_as(C.c_void_p))
+            assert rc == 0, rc
+            return out, stats
+        got, _ = run(variant)               # the fast arithmetic deciding everything itself (round 3)
+        fixed, stats = run(variant + 10)    # ... with its suspects re-evaluated by the strict functions (default now)
+        strict, _ = run(20)                 # every hypothesis through the strict functions
         t2 = time.time()
-    bad = [i for i in range(n) if not np.array_equal(got[i, :nd, :len(markers)], ref[i, :nd])]
-    cls = [forensics.classify_frame(det[i, :nd], markers, K, 5.0, orc) for i in bad]
-    print(json.dumps({"config": config, "frames": n, "variant": variant,
-                      "frames_with_a_different_histogram": len(bad),
+    nm = len(markers)
+
+    def differing(a, b):
+        return [i for i in range(n) if not np.array_equal(a[i, :nd, :nm], b[i, :nd, :nm])]
+    bad = differing(got, ref)
+    bad_fixed_vs_strict = differing(fixed, strict)
+    bad_fast_vs_strict = differing(got, strict)
+    bad_strict = differing(strict, ref)
+    bad_fixed = differing(fixed, ref)
+    cls = [forensics.classify_frame(det[i, :nd], markers, K, 5.0, orc) for i in sorted(set(bad) | set(bad_fixed))]
+    n_comb = nd * (nd - 1) * (nd - 2) // 6
+    hyp = n * n_comb * nm * (nm - 1) * (nm - 2)
+    print(json.dumps({"config": config, "frames": n, "variant": variant, "hypotheses": hyp,
+                      "fast_alone_vs_oracle": len(bad), "fast_alone_vs_strict": len(bad_fast_vs_strict),
+                      "fast_with_fixup_vs_strict": len(bad_fixed_vs_strict),
+                      "fast_with_fixup_vs_oracle": len(bad_fixed), "strict_vs_oracle": len(bad_strict),
+                      "suspect_entries": int(stats[0]), "suspect_whole_hypotheses": int(stats[1]),
+                      "suspect_list_full": int(stats[2]), "suspect_rate_per_hypothesis": float(stats[0]) / hyp,
                       "mismatches_classified_unstable": sum(1 for c in cls if c["unstable"]),
                       "mismatches_unexplained": sum(1 for c in cls if not c["unstable"]),
-                      "frames_idx": bad[:20], "classification": cls[:20],
+                      "frames_idx": bad[:20], "frames_fixed_vs_strict": bad_fixed_vs_strict[:20],
+                      "classification": cls[:20],
                       "oracle_s": round(t1 - t0, 1), "host_s": round(t2 - t1, 1)}))
-    return 1 if any(not c["unstable"] for c in cls) else 0
+    return 1 if (bad_fixed_vs_strict or any(not c["unstable"] for c in cls)) else 0
 
 
 if __name__ == "__main__":

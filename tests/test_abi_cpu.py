@@ -415,3 +415,77 @@ def test_reference_class_surface_compiles(lib):
                  "max_circular_distortion", "back_projection_pixel_tolerance", "nearest_neighbour_pixel_tolerance",
                  "certainty_threshold", "valid_correspondence_threshold", "roi_border_thickness"):
         assert name in launch, name
+
+
+def test_ros_glue_syntax(tmp_path):
+    """compat/ros/mpe_ros_glue.cpp cannot be BUILT here (no ROS in the image), but it must not rot: `g++ -fsyntax-only`
+    over it — as the node, as the nodelet, and with the build switch that lets the back-end decode colour encodings —
+    against declaration-only stand-ins for the ROS headers it includes (tests/mock_deps/ros_stubs: names and
+    signatures only, nothing links).  Round 3 shipped it with an undeclared identifier in the overlay branch; the
+    second half of the test plants exactly such an error and expects the check to catch it."""
+    src = os.path.join(ROOT, "compat", "ros", "mpe_ros_glue.cpp")
+    inc = ["-I", os.path.join(ROOT, "tests", "mock_deps", "ros_stubs"), "-I", os.path.join(ROOT, "tests", "mock_deps"),
+           "-I", os.path.join(ROOT, "compat"), "-I", os.path.join(ROOT, "compat", "ros"), "-I", os.path.join(ROOT, "include")]
+    for defs in ([], ["-DMPE_BUILD_NODELET"], ["-DMPE_OPENCV_GRAY_14BIT"]):
+        r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Werror", *defs, *inc, src],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (defs, r.stderr[-2000:])
+    text = open(src).read()
+    assert "cv::Mat((int)msg->height, (int)msg->width, CV_8UC3)" in text
+    broken = tmp_path / "broken_glue.cpp"
+    broken.write_text(text.replace("cv::Mat((int)msg->height, (int)msg->width, CV_8UC3)",
+                                   "cv::Mat(frame.rows, frame.cols, CV_8UC3)"))
+    r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", *inc, str(broken)], capture_output=True, text=True)
+    assert r.returncode != 0 and "frame" in r.stderr
+    # constructor order of the reference (monocular_pose_estimator.cpp:39-86): reconfigure server -> subscribers ->
+    # publishers -> marker positions
+    ctor = text[text.index("MPENode(const ros::NodeHandle& nh"):text.index(" private:")]
+    order = [ctor.index(k) for k in ("reconfigure_.setCallback", "image_sub_ =", "info_sub_ =", "pose_pub_ =",
+                                     "overlay_pub_ =", "loadMarkers();")]
+    assert order == sorted(order)
+
+
+def test_bench_streams_plumbing_two_ranks():
+    """BASELINE configs[4] shards STREAMS, not frames: `bench_streams.py --gpus N` had no CPU coverage of its N > 1
+    path.  --plumbing-only runs the launcher, the stream -> rank round robin, the barrier and the MAX (wall time) /
+    SUM (counts) reductions over gloo with deterministic synthetic counts, started (a) by the script itself and (b)
+    under torch.distributed.run as the driver would; a WORLD_SIZE that disagrees with --gpus is a hard error."""
+    import json
+    import socket
+    script = os.path.join(ROOT, "bench_streams.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    frames, streams = 30, 7
+
+    def check(rec, world):
+        assert rec["plumbing_only"] is True and rec["n_gpus"] == world and rec["streams"] == streams
+        owners = rec["streams_by_rank"]
+        assert owners == [list(range(r, streams, world)) for r in range(world)]
+        assert sorted(s for o in owners for s in o) == list(range(streams))      # every stream exactly once
+        assert rec["frames_total"] == streams * frames
+        assert rec["poses_total"] == sum(frames - s % 3 for s in range(streams))
+        assert rec["bruteforce_total"] == sum(s % 2 + 1 for s in range(streams))
+        # MAX over ranks: the last rank sleeps 5 ms per rank index longer than rank 0
+        assert rec["wall_s_max_over_ranks"] >= rec["wall_s_rank0"]
+        if world > 1:
+            assert rec["wall_s_max_over_ranks"] >= 1e-3 * frames + 5e-3 * (world - 1) - 1e-4
+        assert abs(rec["value"] - rec["frames_total"] / rec["wall_s_max_over_ranks"]) < 1e-6 * rec["value"]
+
+    for world in (1, 2, 3):
+        out = subprocess.run([sys.executable, script, "--gpus", str(world), "--plumbing-only", "--streams", str(streams),
+                              "--frames", str(frames)], capture_output=True, text=True, env=env, timeout=240)
+        assert out.returncode == 0, out.stderr[-1500:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        check(json.loads(lines[0]), world)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), script, "--gpus", "2", "--plumbing-only", "--streams", str(streams),
+           "--frames", str(frames)]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=240)
+    assert out.returncode == 0, out.stderr[-1500:]
+    check(json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0]), 2)
+    bad = subprocess.run([sys.executable, script, "--gpus", "2", "--plumbing-only"], capture_output=True, text=True,
+                         env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr

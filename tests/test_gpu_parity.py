@@ -943,7 +943,67 @@ def test_strict_vote_arithmetic(orc):
         assert np.abs(strict["T"][ok] - ref["T"][ok]).max() < 1e-9
         assert np.abs(fast["T"][ok] - ref["T"][ok]).max() < 1e-9
         with pytest.raises(mpe.MpeError):
-            h.set_option("vote_arith", 2)
+            h.set_option("vote_arith", 3)
+    finally:
+        h.close()
+
+
+@pytest.mark.gpu
+def test_default_votes_equal_strict_votes(orc):
+    """Round 4: the DEFAULT voting arithmetic (vote_arith 1 = the fast kernel + k2_vote_fixup, the strict re-evaluation
+    of the hypotheses it appends to its suspect list) must produce the STRICT kernel's histograms (vote_arith 0), cell
+    by cell — on ordinary frames of every config, on random detection sets (planar rigs, several tolerances), and on
+    the saved frames on which round 3's fast arithmetic differed from the oracle (tests/data/unstable_det_r3_*.npy,
+    vote_regression_det_0.npy: one hypothesis each in the corner of Ferrari's method) — through the plain kernel
+    (vote_batch) for every marker count incl. the table-slice variant (8 markers).  The list is used, never full."""
+    import os
+    h = mpe.Handle()
+    try:
+        cases = []
+        for config, n in (("C2", 256), ("C1", 64), ("C3", 6)):
+            d = synth.make_frames(config, n, seed=414)
+            dets = [orc.find_leds(f, orc.make_params(), d["K"], d["D"])[0] for f in d["frames"]]
+            dets = [x for x in dets if 4 <= len(x) <= mpe.MAX_DETECTIONS]
+            cases.append((config, dets, d["markers"], d["K"], 5.0))
+        K, _ = synth.camera_for(480, 752)
+        data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+        saved = [np.load(os.path.join(data, f)) for f in sorted(os.listdir(data))
+                 if f.startswith("unstable_det_r3_") or f.startswith("vote_regression_det")]
+        assert len(saved) >= 4
+        cases.append(("saved", saved, synth.M5, K, 5.0))
+        rng = np.random.default_rng(12)
+        for it in range(12):
+            n_m = int(rng.integers(4, 8))
+            markers = rng.uniform(-0.15, 0.15, (n_m, 3))
+            if it % 3 == 0:
+                markers[:, 2] = 0.0
+            dets = [np.column_stack([rng.uniform(250, 500, k), rng.uniform(150, 330, k)])
+                    for k in rng.integers(4, 10, 16)]
+            cases.append(("random%d" % it, dets, markers, K, [1.0, 3.0, 5.0][it % 3]))
+        items0 = h.get_option("vote_fixup_items")
+        for name, dets, markers, Kc, tol in cases:
+            h.set_option("vote_arith", 0)
+            strict = h.vote_batch(dets, markers, Kc, tol)
+            h.set_option("vote_arith", 1)
+            got = h.vote_batch(dets, markers, Kc, tol)
+            for i in range(len(dets)):
+                assert np.array_equal(got[i], strict[i]), (name, i, np.argwhere(got[i] != strict[i])[:5])
+        assert h.get_option("vote_fixup_items") > items0
+        assert h.get_option("vote_fixup_overflow") == 0
+        # the whole path (fused scan-carrying kernel, fix-up on the tail stream of the pipelined schedule, streaming
+        # submissions): records byte-identical to the strict arithmetic's wherever the votes are (same tail kernels)
+        import torch
+        d = synth.make_frames("C2", 96, seed=77)
+        big = torch.from_numpy(d["frames"]).cuda().repeat(342, 1, 1)[:32768 + 64].contiguous()  # 2 sub-batches
+        h.set_option("vote_arith", 0)
+        rs = h.estimate_batch(big, d["markers"], d["K"], d["D"], mpe.demo_params())
+        h.set_option("vote_arith", 1)
+        rf = h.estimate_batch(big, d["markers"], d["K"], d["D"], mpe.demo_params())
+        assert h.get_option("last_schedule") in (3, 6)
+        for k in ("status", "n_corr", "n_det"):
+            assert np.array_equal(rs[k], rf[k]), k
+        assert np.array_equal(rs["T"], rf["T"], equal_nan=True) and np.array_equal(rs["cov"], rf["cov"], equal_nan=True)
+        assert h.get_option("vote_fixup_overflow") == 0
     finally:
         h.close()
 
@@ -1123,6 +1183,70 @@ def test_lockstep_tracker_batch_matches_oracle(orc):
     for t in trackers + t2 + solo + [other]:
         t.close()
     h.close()
+
+
+@pytest.mark.gpu
+def test_c5_eight_streams_three_ways(orc):
+    """BASELINE configs[4] at its stated size — EIGHT independent 752x480 camera streams — on one GPU, in the three
+    arrangements the host side offers, every stream against the oracle's estimateBodyPose state machine
+    (pose_estimator.cpp:62-147) frame by frame, with LED drop-outs on five of the streams (whole-image retries,
+    brute-force re-initialisations while the other streams keep tracking):
+      (a) lock step on ONE handle: one device submission per time step for all eight;
+      (b) eight handles, eight host threads, one tracker each (mpe_tracker_run_sequence) — all on the device at once;
+      (c) two groups of four in lock step on two handles, each group on its own host thread
+          (mpe_tracker_run_sequences_batch_threads).
+    The three give byte-identical records and step information."""
+    import threading
+    n_streams, n = 8, 30
+    drop = {0: (12,), 2: (7, 8), 3: (20,), 5: (15, 16, 17), 6: (25,)}
+    seqs = [synth.make_sequence("C2", n, seed=500 + s, dropout=drop.get(s, ())) for s in range(n_streams)]
+    frames = [q["frames"] for q in seqs]
+    times = seqs[0]["times"]
+    P = mpe.demo_params()
+    mk, K, D = seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"]
+    # (a)
+    h = mpe.Handle(0)
+    ta = [mpe.Tracker(h, mk, K, D, P) for _ in range(n_streams)]
+    rec, info = mpe.tracker_run_sequences_batch(ta, frames, times)
+    n_brute = n_retry = n_pose = 0
+    for s in range(n_streams):
+        to = orc.Tracker(mk, K, D, orc.make_params())
+        for k in range(n):
+            ro = to.estimate(frames[s][k], times[k])
+            assert (rec["status"][s, k] == 0) == ro["updated"], (s, k)
+            assert tuple(info[s, k, 0:4]) == ro["roi"] and info[s, k, 4] == ro["it_since_initialized"], (s, k)
+            assert info[s, k, 5] == ro["n_det"] and info[s, k, 6] == ro["n_corr"], (s, k)
+            assert bool(info[s, k, 7]) == ro["used_bruteforce"], (s, k)
+            n_brute += int(info[s, k, 7])
+            if ro["updated"]:
+                n_pose += 1
+                dp, dr = pose_diff(rec["T"][s, k].reshape(4, 4), ro["T"])
+                assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (s, k, dp, dr)
+    n_retry = int(((info[:, 1:, 2] == seqs[0]["cols"]) & (info[:, 1:, 4] >= 1)).sum())
+    assert n_brute >= n_streams and n_retry >= 5 and n_pose >= n_streams * (n - 8), (n_brute, n_retry, n_pose)
+    # (b)
+    hb = [mpe.Handle(0) for _ in range(n_streams)]
+    tb = [mpe.Tracker(hb[s], mk, K, D, P) for s in range(n_streams)]
+    got = [None] * n_streams
+
+    def work(s):
+        got[s] = tb[s].run_sequence(frames[s], times)
+
+    th = [threading.Thread(target=work, args=(s,)) for s in range(n_streams)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for s in range(n_streams):
+        assert got[s] is not None, s
+        assert got[s][0].tobytes() == rec[s].tobytes() and np.array_equal(got[s][1], info[s]), s
+    # (c)
+    hc = [mpe.Handle(0) for _ in range(2)]
+    tc = [mpe.Tracker(hc[s // 4], mk, K, D, P) for s in range(n_streams)]
+    rec_c, info_c = mpe.tracker_run_sequences_batch(tc, frames, times, 2)
+    assert rec_c.tobytes() == rec.tobytes() and np.array_equal(info_c, info)
+    for t in ta + tb + tc:
+        t.close()
+    for hh in [h] + hb + hc:
+        hh.close()
 
 
 @pytest.mark.gpu

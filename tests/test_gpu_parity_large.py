@@ -236,8 +236,8 @@ def test_forensics_reject_an_injected_error(hip, orc):
 def test_streaming_submissions_are_bit_identical():
     """mpe_estimate_batch_device_submit / _collect: a stream of batches whose last voting launch scans the first
     sub-batch of the NEXT submission.  Records byte-identical to the joined one-call entry — with a hint that comes
-    true, with one that does not, without one —, the announced batch's own stand-alone scan disappears, and the
-    misuse paths are loud."""
+    true and without one (hints that do not come true: test_streaming_false_hints_rewrites_and_changing_shapes) —,
+    the announced batch's own stand-alone scan disappears, and the misuse paths are loud."""
     import torch
     B = 32768
     cfg, _, fa = _frames_on_device("C2", B, 8180)
@@ -308,6 +308,100 @@ def test_streaming_submissions_are_bit_identical():
         consumer.synchronize()
         assert torch.equal(outs[0], ref_a) and torch.equal(outs[1], ref_b), mode
     assert h.get_option("streams_concurrent") in (0, 1)
+    h.close()
+
+
+def test_streaming_false_hints_rewrites_and_changing_shapes():
+    """The streaming entry where round 3's test did not look:
+      * a hint that does NOT come true — another buffer of the same size, then another size — leaves a scanned-ahead
+        flag region behind that nobody must mistake for its own;
+      * an announced buffer that is still being WRITTEN when the submission is made, with the event of that write
+        handed over (mpe_stream_next_ready): the launches that read it wait;
+      * an announced buffer that is REWRITTEN before its own submission, withdrawn with mpe_stream_drop_prefetch;
+      * submissions of different sizes in flight (large - small - large): the regions of the detection / histogram
+        buffers a submission overwrites are ordered behind the previous one's tails even though the two cut their
+        batches differently.
+    Records byte-identical to the joined one-call entry every time."""
+    import torch
+    B, Bs = 32768, 16384
+    cfg, _, fa = _frames_on_device("C2", B, 9180)
+    _, _, fb = _frames_on_device("C2", B, 9190)
+    rows, cols = cfg["rows"], cfg["cols"]
+    K, D = synth.camera_for(rows, cols)
+    markers = np.asarray(cfg["markers"])
+    dev = fa.device
+    P = mpe.demo_params()
+    h = mpe.Handle(0)
+    stream = torch.cuda.Stream(device=dev)
+    consumer = torch.cuda.Stream(device=dev)
+    upload = torch.cuda.Stream(device=dev)
+    h.set_stream(stream.cuda_stream)
+    item = mpe.RESULT_DTYPE.itemsize
+
+    def plain(fr, n):
+        with torch.cuda.stream(stream):
+            out = torch.zeros(n * item, dtype=torch.uint8, device=dev)
+            h.estimate_batch_device(fr.data_ptr(), n, rows, cols, markers, K, D, P, out.data_ptr())
+        stream.synchronize()
+        return out
+
+    ref_a, ref_b, ref_as, ref_bs = plain(fa, B), plain(fb, B), plain(fa, Bs), plain(fb, Bs)
+
+    def run(seq):
+        """seq of (frames, n, announced frames or None, announced n, reference)"""
+        outs = []
+        for fr, n, nxt, nn, ref in seq:
+            o = torch.zeros(n * item, dtype=torch.uint8, device=dev)
+            with torch.cuda.stream(stream):
+                h.estimate_batch_device_submit(fr.data_ptr(), n, rows, cols, markers, K, D, P, o.data_ptr(),
+                                               nxt.data_ptr() if nxt is not None else 0, nn)
+                h.estimate_batch_device_collect(consumer.cuda_stream)
+            outs.append((o, ref))
+        consumer.synchronize()
+        stream.synchronize()
+        for i, (o, ref) in enumerate(outs):
+            assert torch.equal(o, ref), i
+
+    # false hints: fb announced, fa comes (same size); fa announced at full size, the small fb comes; then back
+    run([(fa, B, fb, B, ref_a), (fa, B, fa, B, ref_a), (fb, Bs, fa, B, ref_bs), (fb, B, None, 0, ref_b),
+         (fa, Bs, fb, Bs, ref_as), (fb, Bs, None, 0, ref_bs)])
+    # large - small - large, two in flight each time (no consumer wait in between)
+    run([(fa, B, None, 0, ref_a), (fb, Bs, None, 0, ref_bs), (fb, B, None, 0, ref_b), (fa, Bs, None, 0, ref_as),
+         (fa, B, None, 0, ref_a)])
+    # the announced buffer is still being written: a copy into `nxt` on another stream, its event handed over
+    nxt = torch.zeros_like(fb)
+    spin = torch.zeros(64 << 20, dtype=torch.float32, device=dev)
+    for rep in range(2):
+        nxt.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(upload):
+            for _ in range(20):
+                spin.mul_(1.0001)            # keeps the upload stream busy: the copy below lands late
+            nxt.copy_(fb, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(upload)
+        h.stream_next_ready(ev.cuda_event)
+        run([(fa, B, nxt, B, ref_a), (nxt, B, None, 0, ref_b)])
+    # the announced buffer is rewritten between the two submissions: withdrawn, scanned again
+    buf = fb.clone()
+    torch.cuda.synchronize()
+    o1 = torch.zeros(B * item, dtype=torch.uint8, device=dev)
+    o2 = torch.zeros(B * item, dtype=torch.uint8, device=dev)
+    with torch.cuda.stream(stream):
+        h.estimate_batch_device_submit(fa.data_ptr(), B, rows, cols, markers, K, D, P, o1.data_ptr(), buf.data_ptr(), B)
+        h.estimate_batch_device_collect(consumer.cuda_stream)
+    consumer.synchronize()
+    stream.synchronize()
+    buf.copy_(fa)                        # (the prefetched flag words now describe pixels that are gone)
+    torch.cuda.synchronize()
+    h.stream_drop_prefetch()
+    with torch.cuda.stream(stream):
+        h.estimate_batch_device_submit(buf.data_ptr(), B, rows, cols, markers, K, D, P, o2.data_ptr(), 0, 0)
+        h.estimate_batch_device_collect(consumer.cuda_stream)
+    consumer.synchronize()
+    stream.synchronize()
+    assert torch.equal(o1, ref_a) and torch.equal(o2, ref_a)
+    assert h.get_option("vote_fixup_overflow") == 0
     h.close()
 
 
@@ -495,5 +589,30 @@ def test_multi_device_gather_on_the_device(hip):
             for h in hs:
                 h.close()
     if n_gpu < 2:
-        pytest.skip("ONE GPU visible: the RCCL (xGMI) leg of mpe_estimate_batch_multi_device_gather was NOT exercised — "
-                    "only the same-device copy path ran; it needs a box with >= 2 GPUs")
+        pytest.skip("ONE GPU visible: the multi-rank RCCL (xGMI) leg of mpe_estimate_batch_multi_device_gather was NOT "
+                    "exercised here (its one-rank self-test is test_rccl_gather_self_test_on_one_device); it needs a box "
+                    "with >= 2 GPUs")
+
+
+def test_rccl_gather_self_test_on_one_device(hip):
+    """Option "force_rccl_gather": the RCCL leg of mpe_estimate_batch_multi_device_gather with ONE handle — librccl is
+    dlopen'ed and its symbols resolved, ncclCommInitAll makes a one-rank communicator, the handle's records go through
+    a grouped ncclSend / ncclRecv to itself into the caller's device array — so that the code an 8-GPU node would run
+    first has executed on hardware.  Records byte-identical to the plain call, twice (the communicator is re-used)."""
+    import torch
+    d = synth.make_frames("C2", 37, seed=808)
+    P = mpe.demo_params()
+    one = hip.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], P)
+    h = mpe.Handle(0)
+    try:
+        fr = [torch.from_numpy(d["frames"].copy()).to("cuda:0")]
+        got, used = mpe.estimate_batch_multi_device_gather([h], fr, d["markers"], d["K"], d["D"], P)
+        assert got.tobytes() == one.tobytes() and used is False          # one handle, not forced: no exchange at all
+        h.set_option("force_rccl_gather", 1)
+        assert h.get_option("force_rccl_gather") == 1
+        for _ in range(2):
+            got, used = mpe.estimate_batch_multi_device_gather([h], fr, d["markers"], d["K"], d["D"], P)
+            assert used is True, "the RCCL path was not taken"
+            assert got.tobytes() == one.tobytes()
+    finally:
+        h.close()

@@ -28,13 +28,15 @@ def _build(d, tiny_queues=False):
     inc += _cut(hip, "// lexicographic unranking of the idx-th 3-combination", "#define K2_THREADS")
     inc += _cut(hip, "#define K2_LTAB", "__global__ void k2_prep_markers(")
     inc += _cut(hip, "struct NoRider {", "// Voting kernel.  Work item =")   # incl. the deferred-vote queue
+    inc += _cut(hip, "// One hypothesis in the STRICT arithmetic", "// Strict voting kernel (option")
     if tiny_queues:  # capacities at which the "no room: vote on the spot" paths run all the time
         assert "#define K2_VQ_CAP 12" in inc
         inc = inc.replace("#define K2_VQ_CAP 12", "#define K2_VQ_CAP 5")
     with open(os.path.join(d, "vote_extract.inc"), "w") as fh:
         fh.write(inc)
     so = os.path.join(d, "libvote_host.so")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-I", str(d),
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
+                           *os.environ.get("MPE_HOST_CXXFLAGS", "").split(), "-I", str(d),
                            "-I", os.path.join(ROOT, "tests", "host", "stub"), "-I", CSRC,
                            "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "host", "vote_host.cpp"), "-o", so])
@@ -130,3 +132,71 @@ def test_device_voting_source_with_full_queues(host_tiny, orc):
             for variant in ((0, 1) if len(d["markers"]) <= 5 else (0,)):
                 got = _host_hist(host_tiny, und, d["markers"], d["K"], P.back_projection_pixel_tolerance, variant)
                 assert np.array_equal(got, ref), (config, i, variant)
+
+
+def _stats(lib):
+    st = np.zeros(3, np.uint32)
+    lib.host_vote_stats(st.ctypes.data_as(C.c_void_p))
+    return int(st[0]), int(st[1]), int(st[2])
+
+
+@pytest.mark.parametrize("config,n_frames", [("C1", 30), ("C2", 60), ("C3", 2)])
+def test_fast_votes_with_strict_fixup_equal_strict_votes(host, orc, config, n_frames):
+    """The default voting arithmetic = the fast work item + the strict re-evaluation of the hypotheses it appends to its
+    suspect list (k2_sus_push / k2_strict_item, what k2_vote_fixup runs on the device): the histogram must be the one
+    the strict functions produce for EVERY hypothesis (variant 20 = k2_vote_strict's loop), cell by cell — and the
+    oracle's.  Both kernel variants; the list must have been used (some entries) and never full."""
+    d = synth.make_frames(config, n_frames, seed=99)
+    P = orc.make_params()
+    tol = P.back_projection_pixel_tolerance
+    entries = 0
+    for i in range(n_frames):
+        und, _ = orc.find_leds(d["frames"][i], P, d["K"], d["D"])
+        if len(und) < 4 or len(und) > MAX_DET:
+            continue
+        strict = _host_hist(host, und, d["markers"], d["K"], tol, 20)
+        assert np.array_equal(strict, orc.vote_histogram(und, d["markers"], d["K"], tol)), (config, i, "strict vs oracle")
+        for variant in ((10, 11) if len(d["markers"]) <= 5 else (10,)):
+            got = _host_hist(host, und, d["markers"], d["K"], tol, variant)
+            n, whole, full = _stats(host)
+            assert np.array_equal(got, strict), (config, i, variant, np.argwhere(got != strict)[:5])
+            assert full == 0
+            entries += n
+    assert entries > 0
+
+
+def test_fixup_on_the_saved_unstable_frames(host, orc):
+    """The frames on which round 3's fast arithmetic and the oracle disagreed (tests/data/unstable_det_r3_*.npy, one
+    hypothesis each in the corner of Ferrari's method): with the suspect list the fast path hands exactly those
+    hypotheses to the strict functions and ends up with the strict histogram."""
+    cfg = synth.CONFIGS["C2"]
+    K, _ = synth.camera_for(cfg["rows"], cfg["cols"])
+    markers = np.ascontiguousarray(cfg["markers"], float)
+    data = os.path.join(ROOT, "tests", "data")
+    files = sorted(f for f in os.listdir(data) if f.startswith("unstable_det_r3_") or f.startswith("vote_regression_det"))
+    assert files
+    for f in files:
+        det = np.load(os.path.join(data, f))
+        strict = _host_hist(host, det, markers, K, 5.0, 20)
+        for variant in (10, 11):
+            got = _host_hist(host, det, markers, K, 5.0, variant)
+            assert np.array_equal(got, strict), (f, variant, np.argwhere(got != strict)[:5])
+            assert _stats(host)[1] >= 1, f   # at least one whole hypothesis went to the strict functions
+
+
+def test_fixup_list_full_leaves_the_fast_verdict(host, orc):
+    """A list of four entries: appends fail all the time, are counted, and the histogram is the fast arithmetic's own
+    (which on ordinary frames is the oracle's as well) — votes are neither lost nor cast twice."""
+    d = synth.make_frames("C2", 12, seed=5)
+    P = orc.make_params()
+    seen_full = 0
+    for i in range(12):
+        und, _ = orc.find_leds(d["frames"][i], P, d["K"], d["D"])
+        if len(und) < 4:
+            continue
+        ref = orc.vote_histogram(und, d["markers"], d["K"], P.back_projection_pixel_tolerance)
+        for variant in (30, 31):
+            got = _host_hist(host, und, d["markers"], d["K"], P.back_projection_pixel_tolerance, variant)
+            assert np.array_equal(got, ref), (i, variant)
+            seen_full += _stats(host)[2]
+    assert seen_full > 0
