@@ -117,7 +117,11 @@ def main():
     ap.add_argument("--side-scan-blocks", type=int, default=3, help="mode 6: resident blocks per CU of the side scan")
     ap.add_argument("--scan-split-pct", type=int, default=30, help="mode 6: share of a sub-batch scanned on the side stream")
     ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
-    ap.add_argument("--vote-arith", type=int, default=1, help="1 fast voting arithmetic (default), 0 strict (IEEE)")
+    ap.add_argument("--vote-arith", type=int, default=1,
+                    help="1 fast voting arithmetic with its suspects re-evaluated by the strict functions (default), "
+                         "0 strict (IEEE), 2 fast alone (round 3's default; A/B only)")
+    ap.add_argument("--no-false-hint-leg", dest="false_hint_leg", action="store_false",
+                    help="skip the extra steps whose next-batch announcement does not come true")
     ap.add_argument("--no-vote-events", dest="vote_events", action="store_false",
                     help="do not time the scan-carrying voting launches inside the timed region (A/B: what the two "
                          "events per launch cost)")
@@ -273,6 +277,50 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     fps = world * B * args.steps / dt
+    fix_items = h.get_option("vote_fixup_items")
+    fix_overflow = h.get_option("vote_fixup_overflow")
+
+    # ---- the same steps with a next-batch announcement that does NOT come true (the timed region above is the best
+    #      case: every hint is right).  The announced pointer is another view of the same frames, so the submission
+    #      that follows finds no scan of its own first sub-batch and runs it stand-alone: what a wrong hint costs.
+    false_hint = None
+    if streaming and args.false_hint_leg and B >= 2 * 32768 and len(markers) <= 5:
+        shift = 32768
+        wrong = frames[shift:]
+
+        def step_wrong():
+            k = step_no[0]
+            step_no[0] += 1
+            with torch.cuda.stream(work_stream):
+                buf = pipe.local(k)
+                if out_done[k & 1] is not None:
+                    work_stream.wait_event(out_done[k & 1])
+                h.estimate_batch_device_submit(frames.data_ptr(), B, rows, cols, markers, K, D, P, buf.data_ptr(),
+                                               wrong.data_ptr(), B - shift)
+                h.estimate_batch_device_collect(out_stream.cuda_stream)
+            with torch.cuda.stream(out_stream):
+                if host_rec is not None:
+                    host_rec[k & 1].copy_(buf, non_blocking=True)
+                pipe.submit(k)
+                ev = torch.cuda.Event()
+                ev.record(out_stream)
+                out_done[k & 1] = ev
+
+        nfh = max(3, min(10, args.steps))
+        step_wrong()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(nfh):
+            step_wrong()
+        barrier()
+        dt_fh = time.perf_counter() - t1
+        if world > 1:
+            tmax = torch.tensor([dt_fh], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_fh = float(tmax.item())
+        false_hint = {"ms_per_step": dt_fh / nfh * 1e3, "steps": nfh, "value": world * B * nfh / dt_fh,
+                      "note": "every submission announces a batch that does not come: one sub-batch scanned for nothing "
+                              "inside its last voting launch, and the next submission scans its first sub-batch itself"}
 
     # ---- per-kernel time with HIP events on the launch streams: extra steps in exactly the same mode
     #      and launch shape as the timed region (a big batch runs as sub-batches, every kernel is launched
@@ -328,6 +376,10 @@ def main():
         bytes_per_launch = rider_kib * 1024  # what ONE fused launch actually scanned (mode 6 gives part of a sub-batch to a side scan)
     else:
         scan_s = kavg["scan"] * 1e-3
+    # a pipelined step whose voting kernel does not carry the scan (> 5 markers): the per-sub-batch scan events bracket
+    # only the part of a sub-batch the side scan left over, and the step is the FP64 voting anyway — the dominant
+    # kernel is k2_vote<plain>, bound by FP64 VALU issue (roofline below), not k1a_scan
+    vote_bound = (not fused) and launches > 1
     achieved = bytes_per_launch / scan_s / 1e9
     # the same kernels one launch per step and back to back (no sub-batch pipelining): what each kernel
     # does when it has the chip to itself
@@ -351,7 +403,8 @@ def main():
     pmc_all = {}
     pmc_matches_binary = None
     try:
-        with open(os.path.join(ROOT, "profiles", "round3_pmc.json")) as fh:
+        pmc_file = "round4_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "round4_pmc.json")) else "round3_pmc.json"
+        with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
             pmc_all = json.load(fh)
         # the counter passes were taken from a build of THESE kernel sources? (fingerprint of csrc/*.hip, *.h)
         pmc_matches_binary = pmc_all.get("source_fingerprint") == mpe.source_fingerprint()
@@ -359,14 +412,25 @@ def main():
         if pmc.get("rows") == rows and pmc.get("cols") == cols:
             # (scaled to the frames' worth of pixels this launch scans: bytes_per_launch / (rows * cols))
             traffic = pmc["hbm_bytes_per_frame"] * (bytes_per_launch / float(rows * cols))
-            traffic_source = "profiles/round3_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, " \
+            traffic_source = "profiles/" + pmc_file + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, " \
                              "FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes; %s; taken from a build of the kernel " \
                              "sources timed here: %s)" % (pmc.get("from", ""), pmc_matches_binary)
     except Exception:
         pass
     if fused:
+        # the rocprofv3 average of the same kernel in the same command, from the committed kernel-trace pass that traces
+        # ONLY this kernel (profiles/: `--kernel-include-regex k2_vote<true`); `frac` is the LOWER of the two clocks
+        rp = pmc_all.get("k2_vote_scan", {}).get("rocprof_avg_launch_ms") if pmc_all.get("k2_vote_scan", {}).get(
+            "rocprof_bytes_per_launch") == bytes_per_launch else None
+        frac_events = achieved / 8000.0
+        frac_rocprof = (bytes_per_launch / (rp * 1e-3) / 1e9 / 8000.0) if rp else None
         roofline = {"kernel": "k2_vote<scan>", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+                    "frac": min(frac_events, frac_rocprof) if frac_rocprof else frac_events,
+                    "frac_hip_events": frac_events, "frac_rocprofv3": frac_rocprof,
+                    "rocprofv3_avg_launch_ms": rp,
+                    "rocprofv3_source": ("profiles/" + pmc_file + " k2_vote_scan.rocprof_avg_launch_ms: rocprofv3 "
+                                         "--kernel-trace --stats of this command with only this kernel traced") if rp else None,
+                    "traffic": traffic, "traffic_source": traffic_source,
                     "bytes_per_launch": bytes_per_launch, "avg_launch_ms": vote_scan_ms, "launches_per_step": n_fused, "frames_per_launch": fpl,
                     "avg_launch_ms_source": ("HIP events around all %d k2_vote<scan> launches of the timed region, on the "
                                              "stream they are launched on (the only events recorded in that region)"
@@ -382,6 +446,31 @@ def main():
                                 "(global_load_lds) between pieces of P3P arithmetic; bytes = the pixels it scans, "
                                 "time = the whole fused launch (the voting alone: kernel_ms_isolated.vote / "
                                 "launches).  roofline_isolated = the stand-alone scan kernel."}
+    elif vote_bound:
+        # FP64 VALU issue: a wave64 FP64 instruction occupies a SIMD for 4 cycles -> 1024 SIMDs x clock / 4 wave-
+        # instructions per second; the instruction count per frame is the committed SQ_INSTS_VALU pass of this kernel
+        # at this marker / detection shape, the clock the one that pass measured, the time is measured here
+        vp_ = pmc_all.get("k2_vote_valu", {}).get(args.config)
+        vote_launch_s = kavg["vote"] * 1e-3
+        roofline = {"kernel": "k2_vote<plain>", "bound": "fp64_valu", "unit": "G wave-instructions/s",
+                    "avg_launch_ms": kavg["vote"], "launches_per_step": launches, "frames_per_launch": fpl,
+                    "traffic": None,
+                    "measured": "HIP events around every voting launch on its stream, steps in the same mode as the timed "
+                                "region.  With more than 5 markers the voting kernel cannot carry the image scan (its "
+                                "LDS table would not fit) and takes > 95 % of a sub-batch; its bound is FP64 VALU issue "
+                                "(no MFMA: there is no dense contraction), so the figure is wave-instructions issued / "
+                                "what 1024 SIMDs can issue at the measured clock.  The image pass: roofline_isolated."}
+        if vp_:
+            clk_ = float(vp_.get("effective_clock_GHz") or 2.4)
+            insts = vp_["valu_insts_per_frame"] * min(fpl, B)
+            roofline.update({"achieved": insts / vote_launch_s / 1e9, "peak": 1024 * clk_ / 4.0,
+                             "frac": insts * 4.0 / (1024 * clk_ * 1e9 * vote_launch_s),
+                             "valu_wave_insts_per_launch": insts, "effective_clock_GHz": clk_,
+                             "counters": "profiles/%s k2_vote_valu[%s] (%s); from a build of the sources timed here: %s"
+                                         % (pmc_file, args.config, vp_.get("from", ""), pmc_matches_binary)})
+        else:
+            roofline.update({"achieved": None, "peak": 1024 * 2.4 / 4.0, "frac": None,
+                             "note": "no SQ_INSTS_VALU pass of this config under profiles/"})
     else:
         roofline = {"kernel": "k1a_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
@@ -426,11 +515,15 @@ def main():
 
     out = None
     parity_failed = False
+    impossible = False
     if rank == 0:
         res_host = parallel.records_from_bytes(results)
         n_pose = int((res_host["status"] == 0).sum())
         out = {
-            "metric": "frames/sec at 752x480, 5 LEDs, brute-force init; pose RMSE vs CPU ref",
+            # BASELINE.json's metric string for the configuration it is quoted on (C2); the other configs say what they are
+            "metric": ("frames/sec at 752x480, 5 LEDs, brute-force init; pose RMSE vs CPU ref" if args.config == "C2" else
+                       "frames/sec at %dx%d, %d LEDs / %d detections, brute-force init (BASELINE config %s, not the headline)"
+                       % (cols, rows, len(markers), len(markers) + cfg["n_distractors"], args.config)),
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": float(np.median(step_ms)),
             "value_at_median_step": world * B / (float(np.median(step_ms)) * 1e-3),
@@ -450,6 +543,12 @@ def main():
                        "blob_tier_overflow": overflow,
                        "parallelism": "frames sharded over %d GPU(s), pose records gathered to rank 0 (async, double-buffered)" % world},
             "poses_found_frac": n_pose / B,
+            "vote_arith": {"option": args.vote_arith,
+                           "meaning": {0: "strict kernel", 1: "fast kernel + strict re-evaluation of its suspects (k2_vote_fixup)",
+                                       2: "fast kernel alone"}.get(args.vote_arith),
+                           "hypotheses_re_evaluated_strictly_per_step": fix_items / max(1, args.steps + args.warmup),
+                           "suspect_list_full_events": fix_overflow},
+            "false_hint_leg": false_hint,
             # every pixel of the batch is read once per step: the whole-step HBM rate against the 8 TB/s spec
             "step_hbm": {"bytes_per_step": B * rows * cols, "achieved_GBps": world * B * rows * cols / (dt / args.steps) / 1e9,
                          "frac_of_spec": B * rows * cols / (dt / args.steps) / 1e9 / 8000.0},
@@ -544,10 +643,18 @@ def main():
                                      "change of an input (DESIGN.md section 8; ~1 frame in 1e5)"}
             parity_failed = n_unexplained > 0
         print(json.dumps(out))
+        bad_frac = [k for k in ("roofline", "roofline_isolated") if out.get(k) and (out[k].get("frac") or 0) > 1.0]
+        if out["step_hbm"]["frac_of_spec"] > 1.0:
+            bad_frac.append("step_hbm")
+        if bad_frac:
+            sys.stderr.write("bench.py: %s reports more than its peak — the measurement is broken\n" % ", ".join(bad_frac))
+            impossible = True
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     h.close()
+    if impossible:
+        sys.exit(4)
     if parity_failed:
         sys.stderr.write("bench.py: a HIP-vs-oracle mismatch of the parity sample is NOT explained by an instability of "
                          "the reference algorithm (see parity.verdicts)\n")

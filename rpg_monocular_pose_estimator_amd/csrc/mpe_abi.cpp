@@ -379,8 +379,8 @@ int fix_counter_sum(mpe_handle* h, int which, unsigned long long& out) {
 // hypotheses go to the list, the region holds 1/32 of them (>= 64 per frame), within a total of
 // 16 GB for all slots — a full list is not an error: the fast verdict then stands and "vote_fixup_overflow" counts it.
 int vote_fixup_for(mpe_handle* h, int slot, int n_frames, int n_markers, int n_det_hint, hipStream_t st, VoteFixup& fx) {
-  fx = VoteFixup{nullptr, nullptr, 0u};
-  if (h->vote_arith != 1 || n_markers < 4 || slot < 0 || slot >= mpe_handle::kMaxSub) return MPE_OK;
+  fx = VoteFixup{nullptr, nullptr, 0u, 0u};
+  if (h->vote_arith == 0 || n_markers < 4 || slot < 0 || slot >= mpe_handle::kMaxSub) return MPE_OK;
   const long long nd = std::min(32, std::max(n_det_hint, n_markers) + 4);
   const long long items = nd * (nd - 1) * (nd - 2) / 6 * n_markers * (n_markers - 1) * (n_markers - 2);
   unsigned long long want = (unsigned long long)n_frames * (unsigned long long)std::max(64ll, items / 32);
@@ -410,6 +410,7 @@ int vote_fixup_for(mpe_handle* h, int slot, int n_frames, int n_markers, int n_d
   fx.list = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(h->fix.p) + kFixCtlBytes) +
             (size_t)slot * h->fix_cap * 2;
   fx.cap = h->fix_cap;
+  fx.screen = h->vote_arith == 1 ? 1u : 0u;
   if (h->fix_pending[slot]) {  // an earlier call failed between a voting launch and its fix-up: drop those entries
     HIP_TRY(h, hipMemsetAsync(fx.ctl, 0, sizeof(unsigned), st));
     HIP_TRY(h, hipMemsetAsync(fx.ctl + 2, 0, sizeof(unsigned), st));

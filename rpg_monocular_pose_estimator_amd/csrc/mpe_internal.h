@@ -68,6 +68,8 @@ struct VoteFixup {
                              // (cumulative), [2] blocks done (internal), [3] entries re-evaluated (cumulative)
   unsigned long long* list;  // cap entries of 2 words
   unsigned cap;
+  unsigned screen;           // 1: the voting kernel screens its hypotheses (vote_arith 1); 0: it only sends what its
+                             // per-wave vote queue cannot hold (vote_arith 2: the fast arithmetic decides the rest)
 };
 
 // launchers (mpe_kernels.hip)
@@ -91,7 +93,7 @@ hipError_t launch_k2_prep(const SolveParams& sp, double* tab, hipStream_t s);
 // 0 = the strict kernel (the validation kernel's P3P with IEEE operators; never carries a scan: *scanned_bytes = 0).
 // scan_px != nullptr: the voting waves also scan scan_bytes of pixels (the next sub-batch) into scan_flags;
 // *scanned_bytes = the prefix they cover (whole chunks), the caller scans the rest with launch_k1a_scan
-hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
+hipError_t launch_k2_vote(mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
                           uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px = nullptr,
                           size_t scan_bytes = 0, unsigned long long* scan_flags = nullptr, int scan_thr = 0,
                           size_t* scanned_bytes = nullptr, const int* item_range = nullptr,

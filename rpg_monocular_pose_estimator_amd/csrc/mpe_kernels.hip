@@ -221,6 +221,9 @@ struct BlobRec {
   long long a00, a10, a01;  // polygon sums: sum dxy, sum dxy*(x_{i-1}+x_i), sum dxy*(y_{i-1}+y_i)
   int xmin, xmax, ymin, ymax;
 };
+#ifndef K1B_ON_BLOBREC
+#define K1B_ON_BLOBREC(rec, key)  // (the CPU tier records the raw contour sums here, from both contour phases)
+#endif
 
 __device__ __forceinline__ int reflect101(int p, int len) {  // cv::borderInterpolate(BORDER_REFLECT_101)
   if ((unsigned)p < (unsigned)len) return p;
@@ -605,9 +608,261 @@ __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, in
       br.ymin = acc.ymin;
       br.ymax = acc.ymax;
       float mcx, mcy;
+      K1B_ON_BLOBREC(br, ((unsigned)(ylo + slot - 1) << 12) | (unsigned)(xb + xw0 - 1));
       if (blob_filter(br, dp, roi_x, roi_y, mcx, mcy)) emit(mcx, mcy, ((unsigned)(ylo + slot - 1) << 12) | (unsigned)(xb + xw0 - 1));
     }
   }
+}
+
+// ---- contour phase WITHOUT border following ------------------------------------------------------------------
+// What the reference needs of an external contour is its polygon area, its first moments (cv::moments of the point
+// list) and its bounding box.  For a component without holes the polygon OpenCV's border following visits (8-connected
+// foreground, CHAIN_APPROX_NONE) is the boundary of a cell complex: one unit square for every 2 x 2 block of pixels that
+// is full, one half-square triangle for every block with exactly three pixels (the trace cuts the concave corner
+// diagonally), edges walked out and back for everything thinner.  By Green's theorem the contour sums are then sums over
+// cells — a00 = sum 2 |cell|, a10 = sum 6 int x dA, a01 = sum 6 int y dA, integers, any order — so they come from bit
+// operations on pairs of bitmap rows, all rows at once, instead of ~30 dependent steps per LED with one lane alive
+// (that phase was 20 of the 35 us of a frame's wave).  Holes are detected, not assumed away: 4 x the Euler number of the
+// complex is Q1 - Q3 - 2 QD over the same blocks (Gray's bit-quad count, 8-connectivity) and must be 4 for one component
+// without a hole; anything else — a hole, hence possibly components nested inside it which RETR_EXTERNAL must not report,
+// an island too large for the cap, more blobs than the island record holds, a flood that does not settle — sends the
+// WHOLE island to scan_window, the literal Suzuki-Abe trace.  Components are separated by flooding from the
+// raster-first remaining pixel (= the pixel the trace starts from: same key) with 3 x 3 dilations under the mask, the
+// rows of all islands of the frame at once.  (Checked against the trace on random masks in the CPU tier,
+// tests/test_k1b_host.py::test_cell_sums_equal_the_border_trace, and by every detection parity test on the GPU.)
+__device__ __forceinline__ void wave_sync();  // (defined with the fast path's wave plumbing below)
+#define K1B_CELL_BLOBS 4     // blobs an island may yield in this phase
+#define K1B_CELL_ITEMS 160   // (row, word) items an island may have
+#define K1B_CELL_ITERS 96    // flood rounds before giving up
+struct CellIsl {
+  int bm_off, W, H, ylo, xw0;  // the island's bitmap window (scan_window's arguments)
+  int lo, hi;                  // first / last slot with a pixel
+  int item_end;                // inclusive prefix sum of the islands' item counts (hi - lo + 3) * W
+  int seed;                    // slot << 16 | xb of the raster-first remaining pixel, INT_MAX: none
+  int a00, a10, a01, chi, xmin, xmax, ymin, ymax;
+  int nblob, state;            // state: 0 in progress, 1 finished, 2 handed to the border trace
+  float bx[K1B_CELL_BLOBS], by[K1B_CELL_BLOBS];
+  unsigned bkey[K1B_CELL_BLOBS];
+};
+__device__ __forceinline__ int bitpos_sum(u64 m) {  // sum of the positions of the set bits
+  return __builtin_popcountll(m & 0xAAAAAAAAAAAAAAAAull) + 2 * __builtin_popcountll(m & 0xCCCCCCCCCCCCCCCCull) +
+         4 * __builtin_popcountll(m & 0xF0F0F0F0F0F0F0F0ull) + 8 * __builtin_popcountll(m & 0xFF00FF00FF00FF00ull) +
+         16 * __builtin_popcountll(m & 0xFFFF0000FFFF0000ull) + 32 * __builtin_popcountll(m & 0xFFFFFFFF00000000ull);
+}
+// All islands cs[0 .. nisl) of one frame; lane / nl: this lane and the number of lanes working together (64; 1 in the
+// CPU tier).  cs[k].bm_off .. xw0 filled in by the caller.  Returns a bit mask of the islands left to scan_window
+// (their pm / ng regions zeroed again); every other island's blobs have been emitted.
+template <class Emit>
+__device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng, CellIsl* cs, int nisl, int lane, int nl,
+                                                const DetectParams& dp, int roi_x, int roi_y, Emit emit) {
+  const int kIntMax = 0x7fffffff;
+  // ---- occupied slot range per island
+  for (int k = lane; k < nisl; k += nl) {
+    cs[k].lo = kIntMax;
+    cs[k].hi = -1;
+    cs[k].nblob = 0;
+    cs[k].state = 0;
+    cs[k].a00 = cs[k].a10 = cs[k].a01 = cs[k].chi = 0;
+    cs[k].xmin = cs[k].ymin = kIntMax;
+    cs[k].xmax = cs[k].ymax = -1;
+  }
+  wave_sync();
+  int rows_total = 0;
+  for (int k = 0; k < nisl; ++k) rows_total += cs[k].H;
+  for (int i = lane; i < rows_total; i += nl) {
+    int k = 0, r = i;
+    while (r >= cs[k].H) r -= cs[k++].H;
+    const int slot = r + 1, W = cs[k].W;
+    u64 any = 0;
+    for (int w = 0; w < W; ++w) any |= nz[cs[k].bm_off + slot * W + w];
+    if (any) {
+      atomicMin(&cs[k].lo, slot);
+      atomicMax(&cs[k].hi, slot);
+    }
+  }
+  wave_sync();
+  if (lane == 0) {  // item ranges (nisl is small: a serial prefix sum)
+    int acc = 0;
+    for (int k = 0; k < nisl; ++k) {
+      int n = 0;
+      if (cs[k].hi < cs[k].lo) {
+        cs[k].state = 1;  // nothing in this island
+      } else {
+        n = (cs[k].hi - cs[k].lo + 3) * cs[k].W;
+        if (n > K1B_CELL_ITEMS) {
+          cs[k].state = 2;
+          n = 0;
+        }
+      }
+      acc += n;
+      cs[k].item_end = acc;
+    }
+  }
+  wave_sync();
+  const int T = cs[nisl - 1].item_end;
+  // item i -> island k, bitmap word offset o of (slot, w)
+  auto locate = [&](int i, int& k, int& slot, int& w) {
+    k = 0;
+    while (i >= cs[k].item_end) ++k;
+    const int li = i - (k ? cs[k - 1].item_end : 0), W = cs[k].W;
+    const int r = li / W;
+    w = li - r * W;
+    slot = cs[k].lo - 1 + r;
+  };
+  for (int i = lane; i < T; i += nl) {  // remaining = the mask, component = empty
+    int k, slot, w;
+    locate(i, k, slot, w);
+    const int o = cs[k].bm_off + slot * cs[k].W + w;
+    ng[o] = nz[o];
+    pm[o] = 0;
+  }
+  wave_sync();
+  for (int round = 0;; ++round) {
+    // ---- seed: the raster-first remaining pixel of every island still in progress
+    for (int k = lane; k < nisl; k += nl) cs[k].seed = kIntMax;
+    wave_sync();
+    for (int i = lane; i < T; i += nl) {
+      int k, slot, w;
+      locate(i, k, slot, w);
+      if (cs[k].state != 0) continue;
+      const u64 m = ng[cs[k].bm_off + slot * cs[k].W + w];
+      if (m) atomicMin(&cs[k].seed, (slot << 16) | (64 * w + __builtin_ctzll(m)));
+    }
+    wave_sync();
+    bool active = false;
+    for (int k = lane; k < nisl; k += nl) {
+      if (cs[k].state == 0 && cs[k].seed == kIntMax) cs[k].state = 1;  // every component of the island is done
+      if (cs[k].state == 0) {
+        active = true;
+        if (cs[k].nblob >= K1B_CELL_BLOBS || round >= 2 * K1B_CELL_BLOBS) {
+          cs[k].state = 2;  // more components than this phase records
+        } else {
+          const int sd = cs[k].seed, slot = sd >> 16, xb = sd & 0xFFFF;
+          pm[cs[k].bm_off + slot * cs[k].W + (xb >> 6)] = 1ull << (xb & 63);
+        }
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(active) == 0) break;  // (uniform)
+    wave_sync();
+    // ---- flood: 3 x 3 dilation under the mask until nothing changes (in place: the fixed point does not depend on
+    //      the order in which rows are updated)
+    bool changed;
+    int it = 0;
+    do {
+      changed = false;
+      for (int i = lane; i < T; i += nl) {
+        int k, slot, w;
+        locate(i, k, slot, w);
+        if (cs[k].state != 0) continue;
+        const int W = cs[k].W, o = cs[k].bm_off + slot * W + w;
+        const u64 m = ng[o];
+        if (!m) continue;
+        u64 acc = 0;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int ro = o + dy * W;
+          const u64 c = pm[ro], l = w > 0 ? pm[ro - 1] : 0, r = w + 1 < W ? pm[ro + 1] : 0;
+          acc |= c | (c << 1) | (c >> 1) | (l >> 63) | (r << 63);
+        }
+        const u64 nv = acc & m;
+        if (nv != pm[o]) {
+          pm[o] = nv;
+          changed = true;
+        }
+      }
+      wave_sync();
+    } while (__builtin_amdgcn_ballot_w64(changed) != 0 && ++it < K1B_CELL_ITERS);
+    const bool settled = it < K1B_CELL_ITERS;
+    // ---- sums over the cells of the row pairs (slot, slot + 1)
+    for (int i = lane; i < T; i += nl) {
+      int k, slot, w;
+      locate(i, k, slot, w);
+      if (cs[k].state != 0 || slot > cs[k].hi) continue;
+      const int W = cs[k].W, o = cs[k].bm_off + slot * W + w;
+      const u64 a = pm[o], an = w + 1 < W ? pm[o + 1] : 0, c = pm[o + W], cn = w + 1 < W ? pm[o + W + 1] : 0;
+      const u64 b = (a >> 1) | (an << 63), d = (c >> 1) | (cn << 63);
+      if ((a | b | c | d) == 0) continue;
+      const u64 full = a & b & c & d;
+      const u64 t1 = ~a & b & c & d, t2 = a & ~b & c & d, t3 = a & b & ~c & d, t4 = a & b & c & ~d;  // missing tl tr bl br
+      const u64 tri = t1 | t2 | t3 | t4;
+      const u64 one = (a ^ b ^ c ^ d) & ~tri;
+      const u64 diag = (a & d & ~b & ~c) | (b & c & ~a & ~d);
+      const int nf = __builtin_popcountll(full), nt = __builtin_popcountll(tri);
+      const int Xb = cs[k].xw0 + 64 * w - 1, Yb = cs[k].ylo + slot - 1;  // image coordinates of bit 0 / of this row
+      atomicAdd(&cs[k].a00, 2 * nf + nt);
+      atomicAdd(&cs[k].a10, 6 * (nf * Xb + bitpos_sum(full)) + 3 * nf + 3 * (nt * Xb + bitpos_sum(tri)) +
+                                2 * __builtin_popcountll(t1 | t3) + __builtin_popcountll(t2 | t4));
+      atomicAdd(&cs[k].a01, (6 * Yb + 3) * nf + 3 * Yb * nt + 2 * __builtin_popcountll(t1 | t2) +
+                                __builtin_popcountll(t3 | t4));
+      atomicAdd(&cs[k].chi, __builtin_popcountll(one) - nt - 2 * __builtin_popcountll(diag));
+      if (a) {
+        atomicMin(&cs[k].xmin, 64 * w + __builtin_ctzll(a));
+        atomicMax(&cs[k].xmax, 64 * w + 63 - __builtin_clzll(a));
+        atomicMin(&cs[k].ymin, slot);
+        atomicMax(&cs[k].ymax, slot);
+      }
+    }
+    wave_sync();
+    // ---- one lane per island: the blob record through the shape filter, or the island to the border trace
+    for (int k = lane; k < nisl; k += nl) {
+      if (cs[k].state != 0) continue;
+      if (!settled || cs[k].chi != 4) {
+        cs[k].state = 2;  // a hole (or several components glued by the flood cap): the literal trace decides
+      } else {
+        BlobRec br;
+        br.a00 = cs[k].a00;
+        br.a10 = cs[k].a10;
+        br.a01 = cs[k].a01;
+        br.xmin = cs[k].xmin + cs[k].xw0 - 1;
+        br.xmax = cs[k].xmax + cs[k].xw0 - 1;
+        br.ymin = cs[k].ymin + cs[k].ylo - 1;
+        br.ymax = cs[k].ymax + cs[k].ylo - 1;
+        const int sd = cs[k].seed;
+        const unsigned key = ((unsigned)(cs[k].ylo + (sd >> 16) - 1) << 12) | (unsigned)((sd & 0xFFFF) + cs[k].xw0 - 1);
+        K1B_ON_BLOBREC(br, key);
+        float mcx, mcy;
+        if (blob_filter(br, dp, roi_x, roi_y, mcx, mcy)) {
+          const int n = cs[k].nblob++;
+          cs[k].bx[n] = mcx;
+          cs[k].by[n] = mcy;
+          cs[k].bkey[n] = key;
+        }
+      }
+      cs[k].a00 = cs[k].a10 = cs[k].a01 = cs[k].chi = 0;
+      cs[k].xmin = cs[k].ymin = kIntMax;
+      cs[k].xmax = cs[k].ymax = -1;
+    }
+    wave_sync();
+    for (int i = lane; i < T; i += nl) {  // the component leaves the remaining set
+      int k, slot, w;
+      locate(i, k, slot, w);
+      const int o = cs[k].bm_off + slot * cs[k].W + w;
+      ng[o] &= ~pm[o];
+      pm[o] = 0;
+    }
+    wave_sync();
+  }
+  wave_sync();
+  // ---- finished islands emit; the others get their mark bitmaps back clean for scan_window
+  unsigned todo = 0;
+  for (int k = 0; k < nisl; ++k)
+    if (cs[k].state == 2) todo |= 1u << k;
+  for (int k = lane; k < nisl; k += nl) {
+    if (cs[k].state != 2)
+      for (int n = 0; n < cs[k].nblob; ++n) emit(cs[k].bx[n], cs[k].by[n], cs[k].bkey[n]);
+  }
+  if (todo) {
+    for (int k = 0; k < nisl; ++k) {
+      if (!((todo >> k) & 1u)) continue;
+      const int n = (cs[k].H + 2) * cs[k].W;
+      for (int i = lane; i < n; i += nl) {
+        pm[cs[k].bm_off + i] = 0;
+        ng[cs[k].bm_off + i] = 0;
+      }
+    }
+    wave_sync();
+  }
+  return todo;
 }
 
 // blurred-mask bits of the 16 outputs of segment column c in image row y -> OR into the bitmap
@@ -1080,9 +1335,38 @@ __device__ __forceinline__ void k1b_wave(const int f, const bool valid, const ui
   }
   __syncthreads();
 
-  // ---- E: one lane per island, over the islands of all frames of the block (the islands are
-  //      independent, see the header comment)
-  if (wv == 0) {
+  // ---- E: the contour phase.  One frame per block (the default): all lanes over the rows of all islands
+  //      (cells_phase), and only islands it hands back — a hole, too large — are followed border by border, one lane
+  //      per island.  Several frames per block (experiment builds): one lane per island of all the block's frames.
+  if constexpr (C::WAVES == 1) {
+    if (ready) {
+      static_assert(sizeof(CellIsl) * C::ISL <= sizeof(W.pool), "the cell phase's island records live in the pixel pool");
+      CellIsl* cs = reinterpret_cast<CellIsl*>(W.pool);  // (the thresholded pixels are dead once the bitmaps exist)
+      const int nisl = S.nisl;
+      if (lane < nisl) {
+        const Island is = S.isl[lane];
+        const int xhi = min(g.cols - 1, 16 * is.chi + 15);
+        cs[lane].bm_off = is.bm_off;
+        cs[lane].W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
+        cs[lane].H = is.yhi - is.ylo + 1;
+        cs[lane].ylo = is.ylo;
+        cs[lane].xw0 = 16 * is.clo;
+      }
+      wave_sync();
+      auto keep = [&](float mcx, float mcy, unsigned key) {
+        const int k = atomicAdd(&S.nkept, 1);
+        if (k < C::KEPT) {
+          S.kx[k] = mcx;
+          S.ky[k] = mcy;
+          S.kkey[k] = key;
+        }
+      };
+      const unsigned todo = cells_phase(S.nz, S.pm, S.ng, cs, nisl, lane, 64, dp, roi_x, roi_y, keep);
+      if (todo && lane < nisl && ((todo >> lane) & 1u))  // (uniform `todo`; rare)
+        scan_window(S.nz + cs[lane].bm_off, S.pm + cs[lane].bm_off, S.ng + cs[lane].bm_off, cs[lane].W, cs[lane].H,
+                    cs[lane].ylo, cs[lane].xw0, dp, roi_x, roi_y, &S.over, keep);
+    }
+  } else if (wv == 0) {
     int base[C::WAVES + 1];
     base[0] = 0;
 #pragma unroll
@@ -1597,6 +1881,13 @@ __device__ __forceinline__ void k2_triple_entry(const double (*iv)[3], int n_d, 
   packed = (unsigned)c0 | ((unsigned)c1 << 8) | ((unsigned)c2 << 16) | (swap << 24);
 }
 
+// The launch's list of hypotheses left to the strict arithmetic (VoteFixup) + the status word of the block's frame
+struct K2SusDesc {
+  unsigned* ctl;      // global: [0] entries appended by this launch, [1] entries lost to a full list (cumulative)
+  u64* list;          // global list, K2_SUS_WORDS words per entry
+  unsigned cap;       // entries the global list holds
+  int* frame_status;  // the frame's detection-record status: set to MPE_FRAME_VOTE_LIST_FULL when an entry is lost
+};
 // What a voting work item reads of its frame and block (LDS in the kernels; plain arrays when the host-tier test runs
 // this source, tests/test_vote_host.py).
 struct K2Frame {
@@ -1616,11 +1907,20 @@ struct K2Frame {
                   // its fill count is a wave-uniform register of the caller)
   int vq_lanes;   // lanes that work the queue off together: 64 (1 when the host-tier test runs this source)
   int pj_base;    // first permutation of the table `tab` points at (0: the whole table; plain variant with LDS slices)
-  // hypotheses this arithmetic does not decide itself (k2_sus_push): list in global memory, worked off by k2_vote_fixup
-  unsigned* sus_ctl;  // [0] entries appended by this launch, [1] appends that found the list full (cumulative)
-  u64* sus_list;      // K2_SUS_WORDS words per entry
-  unsigned sus_cap;   // entries the list holds; 0 = no strict re-evaluation (every hypothesis votes in this arithmetic)
+  // hypotheses this arithmetic does not decide itself (k2_sus_push): collected in a small list of the block (LDS: an
+  // append there is a DS atomic — a global atomic with a return value would wait, in vmcnt order, for the scan rider's
+  // loads in flight, and 30 - 45 % of the wave iterations have SOME lane that appends), moved to the launch's list in
+  // global memory by k2_sus_flush at points where the whole block passes, worked off by k2_vote_fixup
+  // The launch's list is described by a record in LDS (a copy of the kernel argument made once): its pointers are
+  // only read when the block's list is flushed or full, so they do not sit in scalar registers across the voting loop
+  // (the scan-carrying kernel uses every SGPR it has: with these fields passed by value it spilled 460 of them to
+  // vector lanes and its launch went from 1.39 to 1.59 ms).
+  const K2SusDesc* susd;
+  bool fix;           // strict re-evaluation is on; false: every hypothesis is decided in this arithmetic
   int frame;          // index of the frame within the launch
+  u64* sus_lds;       // the block's list
+  unsigned* sus_lds_n;
+  unsigned sus_lds_cap;
 };
 
 // i-th double of the LDS copy of the marker-permutation table (scan-carrying variant), K2_LTAB per permutation:
@@ -1647,13 +1947,13 @@ __device__ __forceinline__ float k2_prefilter_threshold(double back_tol) {
 // differently where that difference is AMPLIFIED past the distance of a back-projection from the vote tolerance, so a
 // hypothesis is not decided here but appended to a list, and re-evaluated by k2_vote_fixup with the strict functions,
 // when
-//   (a) a subtraction of Ferrari's method cancelled below MPE_FERRARI_SUSPECT_EPS (1e-8) of its operands
+//   (a) a subtraction of Ferrari's method cancelled below 2^MPE_FERRARI_SUSPECT_EXP (7.5e-9) of its operands
 //       (solve_quartic_lit2: whole hypothesis, all four roots; 0.2 % of the hypotheses), or, per root,
 //       sin^2(theta) = 1 - root^2 or the vector (cn, cd) behind cot(alpha) is small for how well the quartic was
 //       conditioned (K2_SUS_OM / K2_SUS_HS), or |cos(alpha)| < 1e-6 (the strict arithmetic takes it as
 //       sqrt(1 - sin^2), which then has few digits);
-//   (b) the squared distance of a detection to its nearest back-projection lies within K2_SUS_BAND (relative) of
-//       tolerance^2 — +-1e-2 of the tolerance, e.g. +-0.05 px at 5 px, ten times what (a) lets through — or the
+//   (b) the squared distance of a detection to its nearest back-projection lies within 2^K2_SUS_BAND_EXP (relative) of
+//       tolerance^2 — +-0.8 % of the tolerance, e.g. +-0.04 px at 5 px, ten times what (a) lets through — or the
 //       nearest and the second nearest back-projection are that close to each other while in reach: only those
 //       detections of that root go to the list; the other detections' votes (and whether any of them voted: the
 //       triple's own three votes, pose_estimator.cpp:676-685) are cast here.
@@ -1662,17 +1962,18 @@ __device__ __forceinline__ float k2_prefilter_threshold(double back_tol) {
 // test_fast_votes_equal_strict_votes), at ~0.3 % of the hypotheses re-evaluated.  A full list (sized at > 100 times the
 // expected rate by the host side) leaves the fast verdict in place and counts the event (option
 // "vote_fixup_overflow").
-#ifndef K2_SUS_BAND
-#define K2_SUS_BAND 2e-2
+#ifndef K2_SUS_BAND_EXP
+#define K2_SUS_BAND_EXP (-6)  // 2^-6 = 1.6e-2 of tolerance^2, i.e. +-0.8 % of the tolerance
 #endif
 // per root, by how well the quartic was conditioned (MPE_QUARTIC_MID: roots good to ~2e-8, else to ~2e-11): the error
 // of cos(theta) is divided by sin(theta) in the angle, that of (cn, cd) by its length relative to its operands
+// (single-precision literals and powers of two: no scalar register pairs for double-precision constants in the loop)
 #ifndef K2_SUS_OM
-#define K2_SUS_OM 1e-4       // sin^2(theta) below which a root of a MID quartic is suspect ...
-#define K2_SUS_OM_GOOD 1e-9  // ... and of a well-conditioned one
-#define K2_SUS_HS 1e-4       // (|(cn, cd)| / |operands|)^2 likewise
-#define K2_SUS_HS_GOOD 1e-10
-#define K2_SUS_COSA 1e-6     // |cos(alpha)| below which a root is suspect
+#define K2_SUS_OM 1e-4f        // sin^2(theta) below which a root of a MID quartic is suspect ...
+#define K2_SUS_OM_GOOD 1e-9f   // ... and of a well-conditioned one
+#define K2_SUS_HS_EXP (-13)    // (|(cn, cd)| / |operands|)^2 likewise: 2^-13 = 1.2e-4 ...
+#define K2_SUS_HS_GOOD_EXP (-33)  // ... 2^-33 = 1.2e-10
+#define K2_SUS_COSA 1e-6f      // |cos(alpha)| below which a root is suspect
 #endif
 #define K2_SUS_WORDS 2
 // entry: word 0 = frame | code << 32, word 1 = mask of the detections to decide; code = the hypothesis' detection and
@@ -1682,16 +1983,29 @@ __device__ __forceinline__ unsigned k2_sus_code(int c0, int c1, int c2, int p0, 
   return (unsigned)(c0 | (c1 << 5) | (c2 << 10) | (p0 << 15) | (p1 << 19) | (p2 << 23)) | (kmask << 27) |
          ((unsigned)any_fast << 31);
 }
-// append an entry; false = the list is full (the caller then votes in its own arithmetic)
-__device__ __forceinline__ bool k2_sus_push(const K2Frame& F, unsigned code, unsigned detmask) {
-  const unsigned slot = atomicAdd(&F.sus_ctl[0], 1u);
-  if (slot < F.sus_cap) {
-    F.sus_list[(size_t)K2_SUS_WORDS * slot] = (u64)(unsigned)F.frame | ((u64)code << 32);
-    F.sus_list[(size_t)K2_SUS_WORDS * slot + 1] = (u64)detmask;
-    return true;
+// an entry that finds the global list full is LOST: its votes are cast nowhere, so the frame is marked
+// (MPE_FRAME_VOTE_LIST_FULL in its status: a capacity overrun like MPE_FRAME_TOO_MANY_*, never silent) and counted
+__device__ __forceinline__ void k2_sus_lost(const K2SusDesc& g) {
+  atomicAdd(&g.ctl[1], 1u);
+  *g.frame_status = MPE_FRAME_VOTE_LIST_FULL;
+}
+// append an entry to the block's list (to the global one directly when that is full: rare, slow, correct)
+__device__ __forceinline__ void k2_sus_push(const K2Frame& F, unsigned code, unsigned detmask) {
+  const u64 w0 = (u64)(unsigned)F.frame | ((u64)code << 32);
+  const unsigned slot = atomicAdd(F.sus_lds_n, 1u);
+  if (slot < F.sus_lds_cap) {
+    F.sus_lds[(size_t)K2_SUS_WORDS * slot] = w0;
+    F.sus_lds[(size_t)K2_SUS_WORDS * slot + 1] = (u64)detmask;
+    return;
   }
-  atomicAdd(&F.sus_ctl[1], 1u);
-  return false;
+  const K2SusDesc g = *F.susd;
+  const unsigned gs = atomicAdd(&g.ctl[0], 1u);
+  if (gs < g.cap) {
+    g.list[(size_t)K2_SUS_WORDS * gs] = w0;
+    g.list[(size_t)K2_SUS_WORDS * gs + 1] = (u64)detmask;
+  } else {
+    k2_sus_lost(g);
+  }
 }
 
 // The exact half of the nearest-neighbour vote of ONE root of ONE hypothesis (pose_estimator.cpp:663-702) for the
@@ -1706,65 +2020,47 @@ template <class QAt>
 __device__ __forceinline__ void k2_vote_root_exact(const K2Frame& F, const unsigned cw, const unsigned pw,
                                                    unsigned pass, int k, QAt qat) {
   const double tol2 = F.back_tol * F.back_tol;
-  const double band = F.sus_cap ? tol2 * K2_SUS_BAND : -1.0;  // (< 0: no detection ever is suspect)
+  const double band = F.fix ? ldexp(tol2, K2_SUS_BAND_EXP) : -1.0;  // (< 0: no detection ever is suspect)
   bool any = false;
   unsigned sus = 0;
-  // (one copy of the search in the code: a full list sends the suspects through the same loop once more, unscreened)
-  unsigned todo = pass;
-  bool screen = band >= 0.0;
-  for (;;) {
-    for (; todo; todo &= todo - 1) {
-      const int a = __builtin_ctz(todo);
-      const double au = F.px[a][0], av = F.px[a][1];
-      double best = INFINITY;
-      int bj = 0;
-      for (int jj = 0; jj < F.nuo; ++jj) {
-        double bu, bv;
-        qat(jj, bu, bv);
-        const double du = au - bu, dv = av - bv;
-        const double d2 = du * du + dv * dv;
-        if (d2 < best) {
-          best = d2;
-          bj = jj;
-        }
-      }
-      if (screen) {
-        bool s = fabs(best - tol2) <= band;
-        if (!s && best < tol2) {  // about to vote: is the runner-up as near as the winner?
-          for (int jj = 0; jj < F.nuo; ++jj) {
-            double bu, bv;
-            qat(jj, bu, bv);
-            const double du = au - bu, dv = av - bv;
-            s |= jj != bj && (du * du + dv * dv) - best <= band;
-          }
-        }
-        if (s) {
-          sus |= 1u << a;
-          continue;
-        }
-      }
-      bool within = best < tol2 * (1.0 - 1e-14);
-      if (!within && best < tol2 * (1.0 + 1e-14)) within = sqrt(best) < F.back_tol;
-      if (within) {
-        // bj-th unused marker (ascending) -> marker index: skip over the sorted used indices
-        const int p0 = pw & 0xFF, p1 = (pw >> 8) & 0xFF, p2 = (pw >> 16) & 0xFF;
-        const int lo = min(p0, min(p1, p2)), hi = max(p0, max(p1, p2)), mid = p0 + p1 + p2 - lo - hi;
-        int mi = bj;
-        mi += (mi >= lo);
-        mi += (mi >= mid);
-        mi += (mi >= hi);
-        atomicAdd(&F.hist[a * MPE_MAX_MARKERS + mi], 1u);
-        any = true;
-      }
+  for (unsigned todo = pass; todo; todo &= todo - 1) {
+    const int a = __builtin_ctz(todo);
+    const double au = F.px[a][0], av = F.px[a][1];
+    double best = INFINITY, second = INFINITY;  // (the runner-up: is the CHOICE of the marker safe?)
+    int bj = 0;
+    for (int jj = 0; jj < F.nuo; ++jj) {
+      double bu, bv;
+      qat(jj, bu, bv);
+      const double du = au - bu, dv = av - bv;
+      const double d2 = du * du + dv * dv;
+      const bool nearer = d2 < best;
+      second = nearer ? best : (d2 < second ? d2 : second);
+      bj = nearer ? jj : bj;
+      best = nearer ? d2 : best;
     }
-    if (!sus) break;
-    if (k2_sus_push(F, k2_sus_code(cw & 0xFF, (cw >> 8) & 0xFF, (cw >> 16) & 0xFF, pw & 0xFF, (pw >> 8) & 0xFF,
-                                   (pw >> 16) & 0xFF, 1u << k, any), sus))
-      break;
-    todo = sus;  // list full: this arithmetic's own verdict for them
-    sus = 0;
-    screen = false;
+    // suspect: the distance within the band around the tolerance, or a vote about to be cast for a marker whose
+    // runner-up is as near (band < 0: screening is off, both tests are false)
+    if (fabs(best - tol2) <= band || (best < tol2 && second - best <= band)) {
+      sus |= 1u << a;
+      continue;
+    }
+    bool within = best < tol2 * (1.0 - 1e-14);
+    if (!within && best < tol2 * (1.0 + 1e-14)) within = sqrt(best) < F.back_tol;
+    if (within) {
+      // bj-th unused marker (ascending) -> marker index: skip over the sorted used indices
+      const int p0 = pw & 0xFF, p1 = (pw >> 8) & 0xFF, p2 = (pw >> 16) & 0xFF;
+      const int lo = min(p0, min(p1, p2)), hi = max(p0, max(p1, p2)), mid = p0 + p1 + p2 - lo - hi;
+      int mi = bj;
+      mi += (mi >= lo);
+      mi += (mi >= mid);
+      mi += (mi >= hi);
+      atomicAdd(&F.hist[a * MPE_MAX_MARKERS + mi], 1u);
+      any = true;
+    }
   }
+  if (sus)
+    k2_sus_push(F, k2_sus_code(cw & 0xFF, (cw >> 8) & 0xFF, (cw >> 16) & 0xFF, pw & 0xFF, (pw >> 8) & 0xFF,
+                               (pw >> 16) & 0xFF, 1u << k, any), sus);
   if (any) {  // pose_estimator.cpp:676-685
     atomicAdd(&F.hist[(cw & 0xFF) * MPE_MAX_MARKERS + (pw & 0xFF)], 1u);
     atomicAdd(&F.hist[((cw >> 8) & 0xFF) * MPE_MAX_MARKERS + ((pw >> 8) & 0xFF)], 1u);
@@ -1790,6 +2086,11 @@ __device__ __forceinline__ void k2_vote_exact(const K2Frame& F, const unsigned c
 // order).  A lane that finds the queue full votes on the spot.  Measured: 0.855 -> 0.833 ms per fused launch.
 #define K2_VQ_CAP 12
 #define K2_VQ_WORDS 5
+// Suspect roots and hypotheses of the scan-carrying variant travel through the same queue (flag bits in the entry's
+// index word) and reach the block's suspect list when the queue is worked off: a second, divergent append inside the
+// root loop cost the kernel ~50 scalar-register reloads per root.
+#define K2_VQ_ROOT_SUS (1u << 29)
+#define K2_VQ_ITEM_SUS (1u << 30)
 __device__ __forceinline__ u64 k2_vq_meta(const unsigned cw, const unsigned pw, int k, unsigned pass) {
   const unsigned c0 = cw & 0xFF, c1 = (cw >> 8) & 0xFF, c2 = (cw >> 16) & 0xFF;
   const unsigned p0 = pw & 0xFF, p1 = (pw >> 8) & 0xFF, p2 = (pw >> 16) & 0xFF;
@@ -1804,12 +2105,44 @@ __device__ __forceinline__ void k2_vote_flush(const K2Frame& F, int count) {
     const u64* e = F.vq + (size_t)i * K2_VQ_WORDS;
     const u64 meta = e[4];
     const unsigned ix = (unsigned)(meta >> 32);
+    if (ix & (K2_VQ_ROOT_SUS | K2_VQ_ITEM_SUS)) {  // a suspect root / hypothesis on its way to the strict arithmetic
+      const int c0 = ix & 31, c1 = (ix >> 5) & 31, c2 = (ix >> 10) & 31;
+      const unsigned unused = (0xFFFFFFFFu >> (32 - F.n_d)) & ~((1u << c0) | (1u << c1) | (1u << c2));
+      k2_sus_push(F, k2_sus_code(c0, c1, c2, (ix >> 15) & 15, (ix >> 19) & 15, (ix >> 23) & 15,
+                                 (ix & K2_VQ_ITEM_SUS) ? 0xFu : 1u << ((ix >> 27) & 3), false), unused);
+      continue;
+    }
     k2_vote_exact(F, (ix & 31) | (((ix >> 5) & 31) << 8) | (((ix >> 10) & 31) << 16),
                   ((ix >> 15) & 15) | (((ix >> 19) & 15) << 8) | (((ix >> 23) & 15) << 16),
                   (unsigned)meta, __longlong_as_double((long long)e[0]), __longlong_as_double((long long)e[1]),
                   __longlong_as_double((long long)e[2]), __longlong_as_double((long long)e[3]), (int)((ix >> 27) & 3));
   }
   wave_sync();  // (the entries are read before the next ones overwrite them)
+}
+
+// The block's list -> the launch's list in global memory: ONE returning global atomic per flush (thread 0), at a point
+// every thread of the block passes and where no scan round is in flight.  s_base: one word of LDS for the broadcast.
+#define K2_SUS_LDS_SCAN 30   // entries of the block's list, scan-carrying variant (one frame per block: ~4 on average)
+#define K2_SUS_LDS_PLAIN 96  // plain variant, flushed after every chunk of staged triples
+__device__ __forceinline__ void k2_sus_flush(const K2Frame& F, unsigned* s_base) {
+  __syncthreads();
+  const unsigned n = min(*F.sus_lds_n, F.sus_lds_cap);
+  if (n == 0) return;  // (uniform over the block)
+  const K2SusDesc g = *F.susd;
+  if (F.tid == 0) *s_base = atomicAdd(&g.ctl[0], n);
+  __syncthreads();
+  const unsigned base = *s_base;
+  for (unsigned i = (unsigned)F.tid; i < n; i += (unsigned)F.nthr) {
+    if (base + i < g.cap) {
+      g.list[(size_t)K2_SUS_WORDS * (base + i)] = F.sus_lds[(size_t)K2_SUS_WORDS * i];
+      g.list[(size_t)K2_SUS_WORDS * (base + i) + 1] = F.sus_lds[(size_t)K2_SUS_WORDS * i + 1];
+    } else {
+      k2_sus_lost(g);
+    }
+  }
+  __syncthreads();
+  if (F.tid == 0) *F.sus_lds_n = 0;
+  __syncthreads();
 }
 
 // One work item = (staged detection triple ti, marker permutation pj): quartic coefficients (p3p.cpp:171-185),
@@ -1861,30 +2194,31 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
                     f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
   rider.issue();  // P0: first scan round of the item (nothing is staged here: P6 consumed the last one)
   double root[4];
-  unsigned sus_item;
+  int cancel_exp;
   solve_quartic_lit2(F0, F1, F2, F3, F4, root, [&]() {
     rider.consume();
     rider.issue();
-  }, sus_item);
+  }, cancel_exp);
   rider.consume();  // P1
   rider.issue();
   // the detections outside the triple, as a bit mask (n_d <= 32)
   const unsigned unused = (0xFFFFFFFFu >> (32 - F.n_d)) & ~((1u << c0) | (1u << c1) | (1u << c2));
-  const bool fix = F.sus_cap != 0u;  // (uniform) suspect hypotheses are decided by the strict arithmetic
-  if (fix && (sus_item & MPE_QUARTIC_SUSPECT) && live) {  // (a): Ferrari cancelled — all four roots to the list
-    if (k2_sus_push(F, k2_sus_code(c0, c1, c2, p0, p1, p2, 0xFu, false), unused)) {
-      if constexpr (SCAN)
-        live = false;
-      else
-        return;
+  const bool fix = F.fix;  // (uniform) suspect hypotheses are decided by the strict arithmetic
+  // (a): Ferrari cancelled — all four roots to the list (scan-carrying variant: as a queue entry of the first root)
+  bool item_sus = fix && cancel_exp < MPE_FERRARI_SUSPECT_EXP && live;
+  if constexpr (!SCAN) {
+    if (item_sus) {
+      k2_sus_push(F, k2_sus_code(c0, c1, c2, p0, p1, p2, 0xFu, false), unused);
+      return;
     }
   }
   // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
   const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
   // (cn, cd) below is suspect when it keeps less than 1e-2 of its operands
-  const bool q_mid = (sus_item & MPE_QUARTIC_MID) != 0u;
-  const double hs = (q_mid ? K2_SUS_HS : K2_SUS_HS_GOOD) * (__builtin_fma(g1, g1, p_2 * p_2) + __builtin_fma(g2, g2, g3 * g3));
-  const double oms = q_mid ? K2_SUS_OM : K2_SUS_OM_GOOD;
+  const bool q_mid = cancel_exp < MPE_FERRARI_MID_EXP;
+  const double hs = ldexp(__builtin_fma(g1, g1, p_2 * p_2) + __builtin_fma(g2, g2, g3 * g3),
+                          q_mid ? K2_SUS_HS_EXP : K2_SUS_HS_GOOD_EXP);
+  const float oms = q_mid ? K2_SUS_OM : K2_SUS_OM_GOOD;
   // scan-carrying variant: the first two of them (all of them in a 5-detection frame) stay in registers for the four
   // roots' prefilters; a missing second one sits at infinity and passes no test
   unsigned rest = unused, lsb0 = 0, lsb1 = 0;
@@ -1922,6 +2256,17 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     const double dk = d_12 * __builtin_fma(sin_alpha, b, cos_alpha);
     const double sdk = sin_alpha * dk;
     const double Cx = cos_alpha * dk, Cy = cos_theta * sdk, Cz = sin_theta * sdk;
+    // (a), per root — BEFORE the finiteness test: a root within rounding of +-1 is finite in one arithmetic and NaN
+    // (|root| > 1: sqrt of a negative number) in the other.  sin(theta) = sqrt(1 - root^2) at its branch point, (cn, cd)
+    // cancelled, or cos(alpha) so small that the strict arithmetic's sqrt(1 - sin(alpha)^2) has no digits: this root
+    // goes to the list with all unused detections
+    const bool root_sus = fix && live && (item_sus || fabsf((float)om) < oms || h2 < hs || fabsf((float)cos_alpha) < K2_SUS_COSA);
+    if constexpr (!SCAN) {
+      if (root_sus) {
+        k2_sus_push(F, k2_sus_code(c0, c1, c2, p0, p1, p2, 1u << k, false), unused);
+        continue;
+      }
+    }
     // isFinite([R C]) (pose_estimator.cpp:653): a product is finite only if every factor is (0 * inf = NaN), so
     // R (products of the four sines / cosines with the finite frames) and C are finite iff C_eta is
     bool finite_pose = true;
@@ -1931,17 +2276,7 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
       else
         continue;
     }
-    bool may_vote = live && finite_pose;
-    // (a), per root: sin(theta) = sqrt(1 - root^2) at its branch point, (cn, cd) cancelled, or cos(alpha) so small
-    // that the strict arithmetic's sqrt(1 - sin(alpha)^2) has no digits — this root to the list, all unused detections
-    if (fix && may_vote && (fabs(om) < oms || h2 < hs || fabs(cos_alpha) < K2_SUS_COSA)) {
-      if (k2_sus_push(F, k2_sus_code(c0, c1, c2, p0, p1, p2, 1u << k, false), unused)) {
-        if constexpr (SCAN)
-          may_vote = false;
-        else
-          continue;
-      }
-    }
+    const bool may_vote = live && finite_pose;
     double q0u = 0, q0v = 0, q1u = 0, q1v = 0;
     // the prefilter's operands, transposed: (u of marker 0, u of marker 1) and (v, v); a missing second marker sits
     // at infinity and never is the nearest
@@ -2015,7 +2350,7 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
         pass |= near(F.pxf[a]) ? lsb : 0u;
       }
       // slots by ballot: the queue's fill count is wave-uniform (a scalar register), no LDS atomic
-      const bool want = pass != 0u && may_vote;
+      const bool want = root_sus || (pass != 0u && may_vote);
       const u64 bal = __ballot(want);
       if (bal != 0) {
         const unsigned slot = (unsigned)vq_count + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
@@ -2027,10 +2362,18 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
           e[1] = (u64)__double_as_longlong(q0v);
           e[2] = (u64)__double_as_longlong(q1u);
           e[3] = (u64)__double_as_longlong(q1v);
-          e[4] = k2_vq_meta(ii, (unsigned)packed, k, pass);
+          e[4] = k2_vq_meta(ii, (unsigned)packed, k, pass) |
+                 ((u64)(root_sus ? (item_sus ? K2_VQ_ITEM_SUS : K2_VQ_ROOT_SUS) : 0u) << 32);
         } else {
-          k2_vote_exact(F, ii & 0xFFFFFFu, (unsigned)packed & 0xFFFFFFu, pass, q0u, q0v, q1u, q1v, k);
+          // no room in the queue (6 or more lanes of the wave in one item: ~2e-5 of the hypotheses): this root, with
+          // the detections that passed the prefilter, goes to the strict arithmetic like a suspect one — an exact
+          // search inlined HERE, with the whole item's state alive, is what set the kernel's register peak
+          k2_sus_push(F, k2_sus_code(c0, c1, c2, p0, p1, p2, item_sus ? 0xFu : 1u << k, false), root_sus ? unused : pass);
         }
+      }
+      if (item_sus) {  // (the whole hypothesis is on its way: nothing more of it here)
+        live = false;
+        item_sus = false;
       }
       continue;
     }
@@ -2093,7 +2436,7 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
 // x P(n_m,3) + marker permutation, the reference's loop order — lies in [item_range[2f], item_range[2f+1]); the
 // arithmetic of an item is the hot kernel's (same k2_vote_item).
 template <bool SCAN, bool RANGE = false, int NP = 0>
-__global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(const mpe_detections* __restrict__ dets, SolveParams sp,
+__global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_detections* __restrict__ dets, SolveParams sp,
                                                       const double* __restrict__ tab, uint32_t* __restrict__ hist,
                                                       int splits, ScanArgs scan, const int* __restrict__ item_range,
                                                       int slice_tab, VoteFixup fixup) {
@@ -2107,11 +2450,15 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(const mp
   __shared__ unsigned s_trii[TRI];   // c0 | c1 << 8 | c2 << 16 | swap << 24
   __shared__ unsigned s_hist[MPE_HIST_STRIDE];
   __shared__ f32x2 s_pxf[MPE_MAX_DETECTIONS];  // the detections in single precision (nearest-neighbour prefilter)
+  constexpr int SUSN = SCAN ? K2_SUS_LDS_SCAN : K2_SUS_LDS_PLAIN;
+  __shared__ u64 s_sus[SUSN * K2_SUS_WORDS];  // the block's list of hypotheses left to the strict arithmetic
+  __shared__ unsigned s_sus_n, s_sus_base;
+  __shared__ K2SusDesc s_susd;
 
   const int f = blockIdx.x / splits, part = blockIdx.x - f * splits;
   const int tid = threadIdx.x;
   const int nthr = blockDim.x;
-  const mpe_detections* d = dets + f;
+  mpe_detections* d = dets + f;
   const int n_d = d->n, n_m = sp.n_markers;
   typename std::conditional<SCAN, ScanRider, NoRider>::type rider;
   if constexpr (SCAN) rider.init(scan, smem);  // (this variant keeps the back-projections in registers)
@@ -2121,6 +2468,10 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(const mp
   }
 
   for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) s_hist[i] = 0;
+  if (tid == 0) {
+    s_sus_n = 0;
+    s_susd = K2SusDesc{fixup.ctl, reinterpret_cast<u64*>(fixup.list), fixup.cap, &d->status};
+  }
   if (tid < n_d) {
     const double u = d->undist_xy[2 * tid], v = d->undist_xy[2 * tid + 1];
     s_px[tid][0] = u;
@@ -2187,7 +2538,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(const mp
   }
   const K2Frame F = {s_trii, s_tri, s_px, s_pxf, s_q,  s_qf, s_hist, tab_eff,     s_tab,   n_d,  nuo,
                      nthr,   tid,   esz_eff, fx, fy,   cx,   cy,     sp.back_tol, thr_pre, s_vq, 64, p_lo,
-                     fixup.ctl, reinterpret_cast<u64*>(fixup.list), fixup.cap, f};
+                     &s_susd, fixup.screen != 0u, f, s_sus, &s_sus_n, (unsigned)SUSN};
   int vq_count = 0;  // entries in this wave's queue (wave-uniform)
   for (int tc0 = 0; tc0 < n_combos; tc0 += TRI) {
     const int ntri = min(TRI, n_combos - tc0);
@@ -2231,9 +2582,11 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(const mp
       ti = ti_keep;
       pj = pj_keep;
     }
+    if constexpr (!SCAN) k2_sus_flush(F, &s_sus_base);  // (the scan-carrying variant: once, behind the rider's last round)
   }
   if constexpr (SCAN) k2_vote_flush(F, vq_count);  // what is left in this wave's queue of deferred votes
   rider.drain();
+  if constexpr (SCAN) k2_sus_flush(F, &s_sus_base);
   __syncthreads();
   uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
   if (splits == 1) {
@@ -2374,6 +2727,7 @@ __global__ __launch_bounds__(K2_FIX_THREADS) void k2_vote_fixup(const mpe_detect
                                                                 uint32_t* __restrict__ hist, VoteFixup fx) {
   __shared__ double s_q[2 * (MPE_MAX_MARKERS - 3) * K2_FIX_THREADS];
   const unsigned n = min(fx.ctl[0], fx.cap);
+  if (n == 0) return;  // (nothing appended — every block sees the same count — and nothing to reset)
   const u64* list = reinterpret_cast<const u64*>(fx.list);
   const int tid = threadIdx.x;
   for (unsigned i = blockIdx.x * K2_FIX_THREADS + tid; i < n; i += gridDim.x * K2_FIX_THREADS) {
@@ -2415,15 +2769,18 @@ hipError_t launch_k2_fixup(const mpe_detections* dets, const SolveParams& sp, ui
   return hipGetLastError();
 }
 
-hipError_t launch_k2_vote(const mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
+hipError_t launch_k2_vote(mpe_detections* dets, int n_frames, const SolveParams& sp, const double* tab,
                           uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px,
                           size_t scan_bytes, unsigned long long* scan_flags, int scan_thr, size_t* scanned_bytes,
                           const int* item_range, const VoteFixup* fixup) {
   if (scanned_bytes) *scanned_bytes = 0;
   // vote_arith 1: suspect hypotheses go to `fixup` (the caller launches launch_k2_fixup behind this kernel);
   // 2: the fast arithmetic decides everything itself (round-3 behaviour, for A/B measurements); 0: strict kernel
-  VoteFixup fx = {nullptr, nullptr, 0u};
-  if (sp.vote_arith == 1 && fixup && fixup->ctl && fixup->list) fx = *fixup;
+  VoteFixup fx = {nullptr, nullptr, 0u, 0u};
+  if (sp.vote_arith != 0 && fixup && fixup->ctl && fixup->list) {
+    fx = *fixup;
+    fx.screen = sp.vote_arith == 1 ? 1u : 0u;
+  }
   if (n_frames <= 0 || sp.n_markers < 4) return hipSuccess;
   int slice_tab = 0;
   if (splits < 0) {  // -(blocks per frame): the blocks share the marker permutations, table slices in LDS

@@ -306,34 +306,39 @@ struct NoService {
 // header, fast against strict arithmetic): the real parts of the roots differ by at most ~2e-16 / c where c is the
 // smallest of the five ratios below — and small ratios are COMMON (c < 1e-6 for 1.9 % of the hypotheses, < 1e-8 for
 // 0.25 %, < 1e-10 for 0.04 %: the P3P quartic of a wrong correspondence often has nearly coinciding roots).  With
-// 1e-8 the two arithmetics agree to ~2e-8 in every root that is not reported, i.e. to < 5e-3 px in a back-projection
+// 2^-27 = 7.5e-9 the two arithmetics agree to ~3e-8 in every root that is not reported, i.e. to < 5e-3 px in a back-projection
 // (<= 600 px / sin(theta) per unit of cos(theta), sin(theta) >= 1e-2 or the root is reported separately) — a tenth of
 // the band (b) of the voting kernel.  The voting kernel hands reported hypotheses to the strict functions
 // (k2_vote_fixup) instead of voting on them itself.
-// A second, wider level (1e-5: roots agree to ~2e-11 when it is not reported either) lets the caller choose how close
+// A second, wider level (2^-17 = 7.6e-6: roots agree to ~3e-11 when it is not reported either) lets the caller choose how close
 // to a branch point of the back-substitution (sin(theta) -> 0, cot(alpha) -> 0/0) a root may come before IT is suspect.
-#ifndef MPE_FERRARI_SUSPECT_EPS
-#define MPE_FERRARI_SUSPECT_EPS 1e-8
+// Both levels are powers of two and the ratios are compared by their binary EXPONENTS only (integer arithmetic on the
+// high words, the smallest difference kept in one vector register): 2^-27 = 7.5e-9 and 2^-17 = 7.6e-6, each good to a
+// factor of two.  Written with double-precision compares the two levels cost two pairs of scalar registers across the
+// whole quartic plus a pair per threshold literal, and the scan-carrying voting kernel, which has no scalar register to
+// spare, spilled hundreds of them to vector lanes (its launch went from 1.39 to 1.59 ms).
+#ifndef MPE_FERRARI_SUSPECT_EXP
+#define MPE_FERRARI_SUSPECT_EXP (-27)
 #endif
-#ifndef MPE_FERRARI_MID_EPS
-#define MPE_FERRARI_MID_EPS 1e-5
+#ifndef MPE_FERRARI_MID_EXP
+#define MPE_FERRARI_MID_EXP (-17)
 #endif
-#define MPE_QUARTIC_SUSPECT 1u  // some ratio below MPE_FERRARI_SUSPECT_EPS
-#define MPE_QUARTIC_MID 2u      // some ratio below MPE_FERRARI_MID_EPS
+// biased binary exponent of |x| (0 for zero / subnormal, 2047 for inf / NaN)
+__device__ __forceinline__ int p3p_expo(double x) { return (int)((__double2hiint(x) >> 20) & 0x7FF); }
 __device__ __forceinline__ double cabs1(C2 z) { return fabs(z.re) + fabs(z.im); }
 // `service` is called at two points inside (after the cube root, after w): the voting kernel's scan rider uses
 // them to retire / start LDS-DMA rounds behind the arithmetic; a no-op everywhere else.
-// `suspect` (out, MPE_QUARTIC_*): some subtraction of p3p.cpp:253-283 cancelled below the two levels above — the
+// `cancel_exp` (out): the binary exponent of the worst cancellation among the subtractions of p3p.cpp:253-283 (compare
+// with MPE_FERRARI_SUSPECT_EXP / MPE_FERRARI_MID_EXP) — the
 // discriminant Q^2/4 + P^3/27, R = -Q/2 + sqrt(disc), w^2 = alpha + 2y (y with the magnitudes of ITS operands, so a
 // cancellation inside y counts), the two outer radicands -(3 alpha + 2y +- 2 beta / w): the quantities
 // tests/forensics.py classifies mismatching frames by.  NaN operands never compare true (such roots vote nowhere).
 template <class Service>
 __device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C, double D, double E, double rr[4],
-                                                   Service service, unsigned& suspect) {
-  bool sus = false, mid = false;
-  auto check = [&](const double result, const double operands) {  // (|result|, sum of |operands|)
-    sus |= result < MPE_FERRARI_SUSPECT_EPS * operands;
-    mid |= result < MPE_FERRARI_MID_EPS * operands;
+                                                   Service service, int& cancel_exp) {
+  int minexp = 4096;  // smallest exponent(|result|) - exponent(sum of |operands|) seen (a NaN result: +, never reported)
+  auto check = [&](const double result, const double operands) {
+    minexp = min(minexp, p3p_expo(result) - p3p_expo(operands));
   };
   const double A_pw2 = A * A, B_pw2 = B * B;
   const double A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B;
@@ -380,7 +385,7 @@ __device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C,
   const double rsc = 3.0 * fabs(alpha) + 2.0 * ysc + cabs1(bw);
   check(cabs1(rad1), rsc);
   check(cabs1(rad2), rsc);
-  suspect = (sus ? MPE_QUARTIC_SUSPECT : 0u) | (mid ? MPE_QUARTIC_MID : 0u);
+  cancel_exp = minexp;
   const C2 s1 = csqrt_lit2(rad1);
   const C2 s2 = csqrt_lit2(rad2);
   const double off = div_with_rcp(-B, 4.0 * A, 0.25 * r1);
@@ -392,8 +397,8 @@ __device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C,
 template <class Service = NoService>
 __device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C, double D, double E, double rr[4],
                                                    Service service = Service()) {
-  unsigned suspect;
-  solve_quartic_lit2(A, B, C, D, E, rr, service, suspect);
+  int cancel_exp;
+  solve_quartic_lit2(A, B, C, D, E, rr, service, cancel_exp);
 }
 
 // Everything of computePoses that does not depend on the root index.  p3p.cpp:65-190

@@ -10,6 +10,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 using std::max;
@@ -41,6 +43,19 @@ static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c
   for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
   return c;
 }
+static inline int atomicAdd(int* p, int v) { const int o = *p; *p += v; return o; }
+static inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
+static inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
+static inline void wave_sync() {}
+// raw contour sums of both contour phases (scan_window: the border trace; cells_phase: cell sums), see host_cells_vs_trace
+struct RawRec {
+  long long a00, a10, a01;
+  int xmin, xmax, ymin, ymax;
+  unsigned key;
+};
+static std::vector<RawRec>* g_raw = nullptr;
+#define K1B_ON_BLOBREC(rec, key) \
+  do { if (g_raw) g_raw->push_back(RawRec{(rec).a00, (rec).a10, (rec).a01, (rec).xmin, (rec).xmax, (rec).ymin, (rec).ymax, (key)}); } while (0)
 #define __host__
 #include "k1a_extract.inc"  // ThrTest, make_thr_test, gt_word, maybe_gt16, any_gt16 (`struct ThrTest {` .. `#ifndef K1A_UNROLL`)
 #include "k1b_extract.inc"
@@ -113,4 +128,103 @@ extern "C" int host_scan_tests(const uint8_t* seg16, int thr) {
   const unsigned a_c = q.sel ? any_gt16_c<true>(v, q.kk) : any_gt16_c<false>(v, q.kk);
   const unsigned m_c = q.sel ? maybe_gt16_c<true>(v, q.kk) : maybe_gt16_c<false>(v, q.kk);
   return (any_gt16(v, q) ? 1 : 0) | (maybe_gt16(v, q) ? 2 : 0) | (a_c ? 4 : 0) | (m_c ? 8 : 0);
+}
+
+
+// The contour phase without border following (cells_phase) against the border trace (scan_window) on a binary mask cut
+// into island windows {y0, y1, x0, x1} (half-open; the caller keeps the windows' contents independent): the raw contour
+// sums (orientation-normalised), bounding boxes and start keys of every component must agree, and so must the blobs
+// that pass the shape filter.  Returns the number of components compared (>= 0), -1 on a mismatch; *n_fallback = islands
+// the cell phase handed back to the trace (holes, capacity).
+extern "C" int host_cells_vs_trace(const uint8_t* mask, int rows, int cols, const int* wins, int n_win,
+                                   const double* shape, int* n_fallback) {
+  DetectParams dp;
+  std::memset(&dp, 0, sizeof(dp));
+  dp.min_area = shape[0];
+  dp.max_area = shape[1];
+  dp.max_wh = shape[2];
+  dp.max_circ = shape[3];
+  std::vector<CellIsl> cs(n_win);
+  int off = 0;
+  for (int k = 0; k < n_win; ++k) {
+    const int y0 = wins[4 * k], y1 = wins[4 * k + 1], x0 = wins[4 * k + 2], x1 = wins[4 * k + 3];
+    cs[k].bm_off = off;
+    cs[k].W = ((x1 - x0) + 2 + 63) / 64;
+    cs[k].H = y1 - y0;
+    cs[k].ylo = y0;
+    cs[k].xw0 = x0;
+    off += (cs[k].H + 2) * cs[k].W;
+  }
+  std::vector<u64> nz((size_t)off + 2, 0), pm(nz.size(), 0), ng(nz.size(), 0);
+  for (int k = 0; k < n_win; ++k)
+    for (int y = 0; y < cs[k].H; ++y)
+      for (int x = cs[k].xw0; x < wins[4 * k + 3]; ++x)
+        if (mask[(size_t)(cs[k].ylo + y) * cols + x]) {
+          const int xb = x - cs[k].xw0 + 1;
+          nz[cs[k].bm_off + (size_t)(y + 1) * cs[k].W + (xb >> 6)] |= 1ull << (xb & 63);
+        }
+  struct Kept {
+    float x, y;
+    unsigned key;
+    bool operator<(const Kept& o) const { return key < o.key; }
+    bool operator==(const Kept& o) const { return key == o.key && std::memcmp(&x, &o.x, 4) == 0 && std::memcmp(&y, &o.y, 4) == 0; }
+  };
+  std::vector<Kept> kt, kc;
+  std::vector<RawRec> rt, rc;
+  int over = 0;
+  g_raw = &rt;
+  for (int k = 0; k < n_win; ++k)
+    scan_window(nz.data() + cs[k].bm_off, pm.data() + cs[k].bm_off, ng.data() + cs[k].bm_off, cs[k].W, cs[k].H,
+                cs[k].ylo, cs[k].xw0, dp, 0, 0, &over, [&](float mx, float my, unsigned key) { kt.push_back({mx, my, key}); });
+  std::fill(pm.begin(), pm.end(), 0);
+  std::fill(ng.begin(), ng.end(), 0);
+  g_raw = &rc;
+  const unsigned todo = cells_phase(nz.data(), pm.data(), ng.data(), cs.data(), n_win, 0, 1, dp, 0, 0,
+                                    [&](float mx, float my, unsigned key) { kc.push_back({mx, my, key}); });
+  // islands handed back: the product then runs scan_window on them (mark bitmaps must be clean again)
+  *n_fallback = 0;
+  for (int k = 0; k < n_win; ++k) {
+    if (!((todo >> k) & 1u)) continue;
+    ++*n_fallback;
+    for (int i = 0; i < (cs[k].H + 2) * cs[k].W; ++i)
+      if (pm[cs[k].bm_off + i] || ng[cs[k].bm_off + i]) {
+        g_raw = nullptr;
+        return -1;
+      }
+    // drop what the cell phase recorded for this island before giving up, then let the trace speak
+    const unsigned klo = (unsigned)cs[k].ylo << 12, khi = (unsigned)(cs[k].ylo + cs[k].H) << 12;
+    auto in_island = [&](unsigned key) {
+      const int x = (int)(key & 0xFFF);
+      return key >= klo && key < khi && x >= cs[k].xw0 && x < wins[4 * k + 3];
+    };
+    rc.erase(std::remove_if(rc.begin(), rc.end(), [&](const RawRec& r) { return in_island(r.key); }), rc.end());
+    scan_window(nz.data() + cs[k].bm_off, pm.data() + cs[k].bm_off, ng.data() + cs[k].bm_off, cs[k].W, cs[k].H,
+                cs[k].ylo, cs[k].xw0, dp, 0, 0, &over, [&](float mx, float my, unsigned key) { kc.push_back({mx, my, key}); });
+  }
+  g_raw = nullptr;
+  if (over) return -1;
+  auto norm = [](std::vector<RawRec>& v) {
+    for (auto& r : v)
+      if (r.a00 < 0) {
+        r.a00 = -r.a00;
+        r.a10 = -r.a10;
+        r.a01 = -r.a01;
+      }
+    std::sort(v.begin(), v.end(), [](const RawRec& a, const RawRec& b) { return a.key < b.key; });
+  };
+  norm(rt);
+  norm(rc);
+  if (std::getenv("K1B_HOST_DEBUG")) {
+    for (auto& r : rt) std::fprintf(stderr, "trace a00 %lld a10 %lld a01 %lld bbox %d %d %d %d key %u\n", r.a00, r.a10, r.a01, r.xmin, r.xmax, r.ymin, r.ymax, r.key);
+    for (auto& r : rc) std::fprintf(stderr, "cells a00 %lld a10 %lld a01 %lld bbox %d %d %d %d key %u\n", r.a00, r.a10, r.a01, r.xmin, r.xmax, r.ymin, r.ymax, r.key);
+  }
+  if (rt.size() != rc.size()) return -1;
+  for (size_t i = 0; i < rt.size(); ++i)
+    if (rt[i].a00 != rc[i].a00 || rt[i].a10 != rc[i].a10 || rt[i].a01 != rc[i].a01 || rt[i].xmin != rc[i].xmin ||
+        rt[i].xmax != rc[i].xmax || rt[i].ymin != rc[i].ymin || rt[i].ymax != rc[i].ymax || rt[i].key != rc[i].key)
+      return -1;
+  std::sort(kt.begin(), kt.end());
+  std::sort(kc.begin(), kc.end());
+  if (!(kt == kc)) return -1;
+  return (int)rt.size();
 }

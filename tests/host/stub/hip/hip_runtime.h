@@ -21,3 +21,12 @@
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_sinf(x) sinf(6.28318530717958647692f * (x))
 #define __builtin_amdgcn_cosf(x) cosf(6.28318530717958647692f * (x))
+// high word of a double (biased exponent extraction in mpe_p3p.h) and the integer min it uses
+#include <cstring>
+static inline int __double2hiint(double x) {
+  unsigned long long u;
+  std::memcpy(&u, &x, 8);
+  return (int)(u >> 32);
+}
+#include <algorithm>
+using std::min;

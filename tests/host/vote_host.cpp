@@ -27,6 +27,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
 }
 typedef unsigned long long u64;
 static inline void wave_sync() {}
+static inline void __syncthreads() {}
 static inline double __longlong_as_double(long long v) {
   double d;
   std::memcpy(&d, &v, 8);
@@ -45,12 +46,11 @@ namespace mpe {
 #include "vote_extract.inc"
 }
 using namespace mpe;
-// [0] suspect-list entries of the last call, [1] of which whole hypotheses (Ferrari), [2] list-full events
-static unsigned g_stats[3];
+// [0] suspect-list entries of the last call, [1] of which whole hypotheses (Ferrari), [2] entries lost to a full
+// list, [3] the frame was marked MPE_FRAME_VOTE_LIST_FULL
+static unsigned g_stats[4];
 extern "C" void host_vote_stats(unsigned* out) {
-  out[0] = g_stats[0];
-  out[1] = g_stats[1];
-  out[2] = g_stats[2];
+  for (int i = 0; i < 4; ++i) out[i] = g_stats[i];
 }
 
 // variant 0: k2_vote<false> (back-projections in the LDS columns, votes on the spot); variant 1: k2_vote<true> as far as
@@ -94,13 +94,16 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   std::vector<u64> vq((size_t)K2_VQ_CAP * K2_VQ_WORDS, 0);
   // variants 10 / 11: as 0 / 1 with the suspect list in place, worked off by k2_strict_item afterwards (what
   // k2_vote_fixup does on the device); variant 20: every hypothesis through k2_strict_item (= k2_vote_strict)
-  // variants 30 / 31: the same with a list of four entries — nearly every append finds it full and the fast verdict
-  // stands (counted in the statistics)
+  // variants 30 / 31: the same with a block list of four entries — nearly every append goes straight to the launch's
+  // list instead; variants 40 / 41: that one holds four entries as well — entries are LOST, counted, and the frame is
+  // marked MPE_FRAME_VOTE_LIST_FULL (g_stats[3])
+  const bool tiny_global = variant == 40 || variant == 41;
+  if (tiny_global) variant -= 10;
   const bool tiny_list = variant == 30 || variant == 31;
   if (tiny_list) variant -= 20;
   const bool fixup = variant == 10 || variant == 11;
   if (fixup) variant -= 10;
-  g_stats[0] = g_stats[1] = g_stats[2] = 0;
+  g_stats[0] = g_stats[1] = g_stats[2] = g_stats[3] = 0;
   if (variant == 20) {
     std::vector<double> qs(2 * nuo);
     for (int ti = 0; ti < n_combos; ++ti)
@@ -116,12 +119,16 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
       }
     return 0;
   }
-  const unsigned sus_cap = fixup ? (tiny_list ? 4u : 1u << 16) : 0u;
-  std::vector<u64> sus_list((size_t)K2_SUS_WORDS * (sus_cap + 1), 0);
-  unsigned sus_ctl[4] = {0, 0, 0, 0};
+  const unsigned sus_cap = fixup ? (tiny_global ? 4u : 1u << 16) : 0u;
+  const unsigned lds_cap = tiny_list ? 4u : 1u << 16;
+  std::vector<u64> sus_list((size_t)K2_SUS_WORDS * (sus_cap + 1), 0), sus_lds((size_t)K2_SUS_WORDS * lds_cap, 0);
+  unsigned sus_ctl[4] = {0, 0, 0, 0}, sus_lds_n = 0;
+  int frame_status = 0;
+  const K2SusDesc susd = {sus_ctl, sus_list.data(), sus_cap, &frame_status};
   const K2Frame F = {trii.data(), reinterpret_cast<const double(*)[13]>(tri.data()), px, pxf, q.data(), qf.data(),
                      hist, tab.data(), ltab.data(), n_d, nuo, 1, 0, esz, sp.fx, sp.fy, sp.cx, sp.cy, sp.back_tol,
-                     k2_prefilter_threshold(sp.back_tol), vq.data(), 1, 0, sus_ctl, sus_list.data(), sus_cap, 0};
+                     k2_prefilter_threshold(sp.back_tol), vq.data(), 1, 0, &susd, fixup, 0,
+                     sus_lds.data(), &sus_lds_n, lds_cap};
   struct Fix {
     const K2Frame& F;
     const SolveParams& sp;
@@ -129,14 +136,19 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
     const double (*px)[2];
     unsigned* hist;
     int nuo;
-    ~Fix() {  // the strict re-evaluation of what the fast pass appended (k2_vote_fixup)
+    ~Fix() {  // k2_sus_flush (the block's list -> the launch's), then the strict re-evaluation (k2_vote_fixup)
+      if (!F.fix) return;
+      unsigned s_base = 0;
+      k2_sus_flush(F, &s_base);
       std::vector<double> qs(2 * nuo);
-      const unsigned n = std::min(F.sus_ctl[0], F.sus_cap);
+      const K2SusDesc& g = *F.susd;
+      const unsigned n = std::min(g.ctl[0], g.cap);
       g_stats[0] += n;
-      g_stats[2] += F.sus_ctl[1];
+      g_stats[2] += g.ctl[1];
+      g_stats[3] = *g.frame_status == MPE_FRAME_VOTE_LIST_FULL ? 1u : 0u;
       for (unsigned i = 0; i < n; ++i) {
-        const u64 w0 = F.sus_list[(size_t)K2_SUS_WORDS * i];
-        const unsigned detmask = (unsigned)F.sus_list[(size_t)K2_SUS_WORDS * i + 1];
+        const u64 w0 = g.list[(size_t)K2_SUS_WORDS * i];
+        const unsigned detmask = (unsigned)g.list[(size_t)K2_SUS_WORDS * i + 1];
         const unsigned code = (unsigned)(w0 >> 32);
         const int c0 = code & 31, c1 = (code >> 5) & 31, c2 = (code >> 10) & 31;
         const int p0 = (code >> 15) & 15, p1 = (code >> 19) & 15, p2 = (code >> 23) & 15;

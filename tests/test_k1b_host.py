@@ -170,3 +170,78 @@ def test_scan_threshold_arithmetic_exhaustively(host):
             assert (r & 2) or not want, (thr, s)        # maybe_gt16 is a necessary condition
             assert bool(r & 4) == want, (thr, s)        # ... and the compile-time AND / OR forms agree
             assert (r & 8) or not want, (thr, s)
+
+
+def test_cell_sums_equal_the_border_trace(host):
+    """The contour phase without border following (cells_phase: flood per component, Green sums over the 2 x 2 block
+    cells of row pairs, Euler-number hole test) against the literal Suzuki-Abe trace (scan_window) on random masks: LED-like
+    discs, dense noise with one-pixel-wide bridges and diagonal contacts, rings (holes: the island must go back to the
+    trace), several islands side by side and stacked, islands too big for the phase.  Raw contour sums (up to
+    orientation), bounding boxes, start keys and the filtered blobs must all agree; the phase must decide most islands
+    itself and hand back those with holes."""
+    from scipy import ndimage
+    host.host_cells_vs_trace.restype = C.c_int
+    rng = np.random.default_rng(2024)
+    shape_real = np.array([10.0, 200.0, 0.5, 0.5])
+    shape_open = np.array([0.0, 1e9, 1.0, 1e9])
+    n_comp = n_fb = n_isl = n_hole_isl = 0
+
+    def run(mask, wins, shape):
+        nonlocal n_comp, n_fb, n_isl
+        mask = np.ascontiguousarray(mask, np.uint8)
+        w = np.ascontiguousarray(np.asarray(wins, np.int32).reshape(-1, 4))
+        fb = C.c_int(0)
+        r = host.host_cells_vs_trace(mask.ctypes.data_as(C.c_void_p), mask.shape[0], mask.shape[1],
+                                     w.ctypes.data_as(C.c_void_p), len(w), shape.ctypes.data_as(C.c_void_p), C.byref(fb))
+        assert r >= 0, (wins, np.argwhere(mask)[:10])
+        n_comp += r
+        n_fb += fb.value
+        n_isl += len(w)
+        return fb.value
+
+    yy, xx = np.mgrid[0:40, 0:120]
+    for it in range(1500):
+        kind = it % 5
+        rows, cols = int(rng.integers(4, 40)), int(rng.integers(4, 120))
+        if kind == 0:      # LED-like discs, sometimes touching
+            m = np.zeros((rows, cols), bool)
+            for _ in range(int(rng.integers(1, 4))):
+                cy, cx, rad = rng.uniform(0, rows), rng.uniform(0, cols), rng.uniform(1.0, 6.0)
+                m |= (yy[:rows, :cols] - cy) ** 2 + (xx[:rows, :cols] - cx) ** 2 <= rad ** 2
+        elif kind == 1:    # dense noise: thin bridges, diagonal contacts, small holes
+            m = rng.random((rows, cols)) < rng.uniform(0.2, 0.9)
+        elif kind == 2:    # closed noise: blobs with bays
+            m = ndimage.binary_closing(rng.random((rows, cols)) < 0.35)
+        elif kind == 3:    # a ring (hole) beside a disc
+            m = np.zeros((rows, cols), bool)
+            cy, cx = rows / 2, cols / 3
+            d2 = (yy[:rows, :cols] - cy) ** 2 + (xx[:rows, :cols] - cx) ** 2
+            m |= (d2 <= 36) & (d2 >= 9)
+            m |= (yy[:rows, :cols] - cy) ** 2 + (xx[:rows, :cols] - 2.2 * cx) ** 2 <= 9
+        else:              # sparse specks
+            m = rng.random((rows, cols)) < 0.03
+        shape = shape_real if it % 2 else shape_open
+        run(m, [[0, rows, 0, cols]], shape)
+        # the same content as two or three independent islands: column bands with an empty gap, or row bands
+        if cols >= 30 and it % 3 == 0:
+            c1, c2 = cols // 3, 2 * cols // 3
+            m2 = m.copy()
+            m2[:, c1 - 1:c1 + 1] = False
+            m2[:, c2 - 1:c2 + 1] = False
+            run(m2, [[0, rows, 0, c1], [0, rows, c1, c2], [0, rows, c2, cols]], shape)
+        if rows >= 12 and it % 3 == 1:
+            r1 = rows // 2
+            m2 = m.copy()
+            m2[r1 - 1:r1 + 1, :] = False
+            run(m2, [[0, r1, 0, cols], [r1, rows, 0, cols]], shape)
+    # a ring always goes back to the trace; a plain disc never does
+    ring = ((yy - 20) ** 2 + (xx - 20) ** 2 <= 64) & ((yy - 20) ** 2 + (xx - 20) ** 2 >= 16)
+    assert run(ring[:, :60], [[0, 40, 0, 60]], shape_open) == 1
+    disc = (yy - 20) ** 2 + (xx - 20) ** 2 <= 64
+    assert run(disc[:, :60], [[0, 40, 0, 60]], shape_open) == 0
+    # an island beyond the phase's capacity (rows x words) goes back as a whole
+    big = np.zeros((100, 200), bool)
+    big[5:90, 10:190] = rng.random((85, 180)) < 0.5
+    assert run(big, [[0, 100, 0, 200]], shape_open) == 1
+    assert n_comp > 5000 and n_isl > 2000
+    assert 0 < n_fb < 0.6 * n_isl, (n_fb, n_isl)

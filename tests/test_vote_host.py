@@ -135,9 +135,9 @@ def test_device_voting_source_with_full_queues(host_tiny, orc):
 
 
 def _stats(lib):
-    st = np.zeros(3, np.uint32)
+    st = np.zeros(4, np.uint32)
     lib.host_vote_stats(st.ctypes.data_as(C.c_void_p))
-    return int(st[0]), int(st[1]), int(st[2])
+    return int(st[0]), int(st[1]), int(st[2]), int(st[3])
 
 
 @pytest.mark.parametrize("config,n_frames", [("C1", 30), ("C2", 60), ("C3", 2)])
@@ -158,9 +158,9 @@ def test_fast_votes_with_strict_fixup_equal_strict_votes(host, orc, config, n_fr
         assert np.array_equal(strict, orc.vote_histogram(und, d["markers"], d["K"], tol)), (config, i, "strict vs oracle")
         for variant in ((10, 11) if len(d["markers"]) <= 5 else (10,)):
             got = _host_hist(host, und, d["markers"], d["K"], tol, variant)
-            n, whole, full = _stats(host)
+            n, whole, lost, marked = _stats(host)
             assert np.array_equal(got, strict), (config, i, variant, np.argwhere(got != strict)[:5])
-            assert full == 0
+            assert lost == 0 and marked == 0
             entries += n
     assert entries > 0
 
@@ -184,19 +184,28 @@ def test_fixup_on_the_saved_unstable_frames(host, orc):
             assert _stats(host)[1] >= 1, f   # at least one whole hypothesis went to the strict functions
 
 
-def test_fixup_list_full_leaves_the_fast_verdict(host, orc):
-    """A list of four entries: appends fail all the time, are counted, and the histogram is the fast arithmetic's own
-    (which on ordinary frames is the oracle's as well) — votes are neither lost nor cast twice."""
+def test_fixup_lists_full(host, orc):
+    """The block's list holds four entries: appends go straight to the launch's list instead — same histogram as the
+    strict loop.  That one holds four entries as well: entries are LOST (their votes are cast nowhere), which is
+    counted and marks the frame MPE_FRAME_VOTE_LIST_FULL — a capacity overrun is never silent."""
     d = synth.make_frames("C2", 12, seed=5)
     P = orc.make_params()
-    seen_full = 0
+    tol = P.back_projection_pixel_tolerance
+    seen_lost = seen_entries = 0
     for i in range(12):
         und, _ = orc.find_leds(d["frames"][i], P, d["K"], d["D"])
         if len(und) < 4:
             continue
-        ref = orc.vote_histogram(und, d["markers"], d["K"], P.back_projection_pixel_tolerance)
+        strict = _host_hist(host, und, d["markers"], d["K"], tol, 20)
         for variant in (30, 31):
-            got = _host_hist(host, und, d["markers"], d["K"], P.back_projection_pixel_tolerance, variant)
-            assert np.array_equal(got, ref), (i, variant)
-            seen_full += _stats(host)[2]
-    assert seen_full > 0
+            got = _host_hist(host, und, d["markers"], d["K"], tol, variant)
+            n, whole, lost, marked = _stats(host)
+            assert np.array_equal(got, strict), (i, variant)
+            assert lost == 0 and marked == 0
+            seen_entries += n
+        for variant in (40, 41):
+            _host_hist(host, und, d["markers"], d["K"], tol, variant)
+            n, whole, lost, marked = _stats(host)
+            assert n <= 4 and (lost > 0) == (marked == 1)
+            seen_lost += lost
+    assert seen_lost > 0 and seen_entries > 20
