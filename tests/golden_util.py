@@ -11,7 +11,12 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def golden_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith("seq_"))
+                  if not os.path.basename(p).startswith(("seq_", "witness_seq_")))
+
+
+def witness_sequences():
+    """Tracking-path vectors made by the independent witness (tests/golden/make_witness_seq_golden.py)."""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "witness_seq_*.npz")))
 
 
 def golden_sequences():

@@ -8,7 +8,7 @@ from rpg_monocular_pose_estimator_amd import synth
 import rpg_monocular_pose_estimator_amd as mpe
 from util import (pose_diff, POS_TOL_M, ROT_TOL_RAD, p3p_test_problems, check_p3p_solutions, quartic_test_problems,
                   check_quartic_roots)
-from golden_util import golden_cases, golden_sequences, load as load_golden, load_sequence
+from golden_util import golden_cases, golden_sequences, load as load_golden, load_sequence, witness_sequences
 
 pytestmark = pytest.mark.gpu
 
@@ -1183,6 +1183,32 @@ def test_lockstep_tracker_batch_matches_oracle(orc):
     for t in trackers + t2 + solo + [other]:
         t.close()
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", witness_sequences())
+def test_hip_tracker_against_the_witness_sequences(name):
+    """The HIP tracker (mpe_tracker_*: host state machine + the device steps) against the tracking-path vectors of the
+    independent witness (tests/golden/witness_seq_*.npz, numpy restatement of pose_estimator.cpp:62-147 etc.) — not
+    against the oracle: ROI, it_since_initialized, counts, brute-force flag per frame, poses within the north_star
+    tolerance, covariance rtol 1e-6."""
+    g, d = load_sequence(name)
+    h = mpe.Handle(0)
+    tr = mpe.Tracker(h, d["markers"], d["K"], d["D"], mpe.demo_params())
+    try:
+        rec, info = tr.run_sequence(d["frames"], d["times"])
+        for k in range(int(g["n"])):
+            assert (rec["status"][k] == 0) == bool(g["updated"][k]), k
+            assert tuple(info[k, 0:4]) == tuple(int(v) for v in g["roi"][k]), k
+            assert (info[k, 4], info[k, 5], info[k, 6], int(info[k, 7])) == \
+                   (g["it_since_initialized"][k], g["n_det"][k], g["n_corr"][k], g["used_bruteforce"][k]), k
+            if g["updated"][k]:
+                dp, dr = pose_diff(rec["T"][k].reshape(4, 4), g["T"][k])
+                assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (k, dp, dr)
+                assert np.allclose(rec["cov"][k].reshape(6, 6), g["cov"][k], rtol=1e-6, atol=1e-12), k
+    finally:
+        tr.close()
+        h.close()
 
 
 @pytest.mark.gpu

@@ -554,3 +554,207 @@ def estimate_frame(img, markers, K, D, params):
     r = est.solve_bruteforce(und)
     r.update(und=und, dist=dist)
     return r
+
+
+# ------------------------------------------------------------------------------------------------
+# The tracking path (round 4): estimateBodyPose as a STATE MACHINE over a sequence of frames —
+# pose_estimator.cpp:62-147 (both branches, the whole-image retry), predictWithROI :814-829, predictPose :232-244,
+# logarithmMap :996-1064, predictMarkerPositionsInImage :270-276, findCorrespondences :372-392 (+ calculateMinDistances-
+# AndPairs :862-906), findCorrespondencesAndPredictPose :831-848, optimiseAndUpdatePose / updatePose :794-812;
+# LEDDetector::determineROI / distortPoints, led_detector.cpp:114-224.  Written from those sources (not from the oracle's
+# Tracker): numpy for the 4x4 algebra (numpy.linalg.inv where the reference calls .inverse()), Python floats elsewhere.
+# ------------------------------------------------------------------------------------------------
+
+
+def skew(w):
+    return np.array([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def _is_approx(a, b, prec):
+    """Eigen's isApprox for matrices: ||a - b||_F^2 <= prec^2 * min(||a||_F^2, ||b||_F^2)."""
+    return float(((a - b) ** 2).sum()) <= prec * prec * min(float((a ** 2).sum()), float((b ** 2).sum()))
+
+
+def logarithm_map(T):
+    """pose_estimator.cpp:996-1064 -> twist (upsilon, w)."""
+    T = np.asarray(T, float)
+    R, t = T[:3, :3], T[:3, 3]
+    w_hat = np.zeros((3, 3))
+    if not _is_approx(R, np.eye(3), 1e-10):
+        temp = (np.trace(R) - 1) / 2
+        temp = 1.0 if temp > 1 else (-1.0 if temp < -1 else temp)
+        phi = math.acos(temp)
+        if phi != 0:
+            w_hat = (R - R.T) / (2 * math.sin(phi)) * phi
+    w = np.array([w_hat[2, 1], w_hat[0, 2], w_hat[1, 0]])
+    wn = float(np.sqrt((w ** 2).sum()))
+    # t.isApproxToConstant(0, 1e-10): ||t - 0||^2 <= prec^2 * min(||t||^2, ||0||^2) = 0, i.e. only an exactly zero t
+    if not np.any(t != 0):
+        A_inv = np.zeros((3, 3))
+    elif wn == 0 or math.sin(wn) == 0:
+        A_inv = np.eye(3)
+    else:
+        A_inv = (np.eye(3) - w_hat / 2 +
+                 (2 * math.sin(wn) - wn * (1 + math.cos(wn))) / (2 * wn * wn * math.sin(wn)) * (w_hat @ w_hat))
+    return np.concatenate([A_inv @ t, w])
+
+
+def distort_points(pts, K, D):
+    """LEDDetector::distortPoints, led_detector.cpp:181-224: float32 points in, computed in double, float32 out."""
+    K = np.asarray(K, float).reshape(3, 3)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    k1, k2, p1, p2, k3 = [float(v) for v in np.asarray(D, float).reshape(-1)[:5]]
+    out = []
+    for (px, py) in pts:
+        px, py = float(np.float32(px)), float(np.float32(py))
+        x, y = (px - cx) / fx, (py - cy) / fy
+        r2 = x * x + y * y
+        xc = x * (1. + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2)
+        yc = y * (1. + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2)
+        xc = xc + (2. * p1 * x * y + p2 * (r2 + 2. * x * x))
+        yc = yc + (p1 * (r2 + 2. * y * y) + 2. * p2 * x * y)
+        out.append((float(np.float32(xc * fx + cx)), float(np.float32(yc * fy + cy))))
+    return out
+
+
+def determine_roi(pred_px, rows, cols, border, K, D):
+    """LEDDetector::determineROI, led_detector.cpp:114-179 -> (x, y, w, h).  Quirks kept: x_max / y_max start from 0,
+    the corner points pass through cv::Point2f (float32) before and after the distortion, the rectangle's integer
+    members truncate the doubles."""
+    x_min = y_min = math.inf
+    x_max = y_max = 0.0
+    for (px, py) in np.asarray(pred_px, float).reshape(-1, 2):
+        if px < x_min:
+            x_min = px
+        if px > x_max:
+            x_max = px
+        if py < y_min:
+            y_min = py
+        if py > y_max:
+            y_max = py
+    with np.errstate(all="ignore"):
+        d = distort_points([(np.float32(x_min), np.float32(y_min)), (np.float32(x_max), np.float32(y_max))], K, D)
+    (x_min_d, y_min_d), (x_max_d, y_max_d) = d
+    x0 = max(0.0, min(float(cols), x_min_d - border))
+    x1 = max(0.0, min(float(cols), x_max_d + border))
+    y0 = max(0.0, min(float(rows), y_min_d - border))
+    y1 = max(0.0, min(float(rows), y_max_d + border))
+    if not (x1 - x0 >= 1 and y1 - y0 >= 1):  # (also taken when a coordinate is NaN: every comparison is false)
+        return (0, 0, cols, rows)
+    return (int(x0), int(y0), int(x1 - x0), int(y1 - y0))
+
+
+class Tracker:
+    """One stateful PoseEstimator object (pose_estimator.h:52-803) fed frame after frame."""
+
+    def __init__(self, markers, K, D, params):
+        self.p = dict(params)
+        self.K = np.asarray(K, float).reshape(3, 3)
+        self.D = np.asarray(D, float).reshape(-1)
+        self.est = Estimator(markers, K, params["back_projection_pixel_tolerance"], params["certainty_threshold"],
+                             params["valid_correspondence_threshold"], params.get("histogram_threshold", 0))
+        self.n_m = len(self.est.M)
+        self.it = 0                                   # it_since_initialized_
+        # (the reference leaves poses / times uninitialised; nothing reads them before they are first written except
+        #  previous_pose_ in the third frame's predictPose, which by then holds the first frame's current_pose_)
+        self.prev_pose = np.eye(4)
+        self.cur_pose = np.eye(4)
+        self.pred_pose = np.eye(4)
+        self.prev_time = self.cur_time = self.pred_time = 0.0
+        self.pred_px = np.zeros((self.n_m, 2))
+        self.roi = (0, 0, 0, 0)
+        self.det = np.zeros((0, 2))
+        self.corr = np.zeros((0, 2), np.uint32)
+        self.cov = np.zeros((6, 6))
+        self.used_bruteforce = False
+        self.updated = False
+
+    # -- pieces ------------------------------------------------------------------------------------
+    def _find_leds(self, img, roi):
+        p = self.p
+        und, _ = find_leds(img, p["threshold_value"], p["gaussian_sigma"], p["min_blob_area"], p["max_blob_area"],
+                           p["max_width_height_distortion"], p["max_circular_distortion"], self.K, self.D, roi=roi)
+        return und
+
+    def _initialise(self):
+        """initialise(), pose_estimator.cpp:544-721: 1 and predicted_pose_ set on success."""
+        self.used_bruteforce = True
+        hist = self.est.vote(self.det)
+        if not hist.any():
+            return False
+        self.corr = self.est.correspondences_from_histogram(hist)
+        ok, T0 = self.est.check_correspondences(self.det, self.corr)
+        if ok:
+            self.pred_pose = T0
+        return ok
+
+    def _optimise_and_update(self):
+        T, cov, _ = self.est.optimise_pose(self.det, self.corr, self.pred_pose)
+        self.pred_pose, self.cov = T, cov
+        if self.it < 2:
+            self.it += 1
+        self.prev_pose, self.cur_pose = self.cur_pose, self.pred_pose
+        self.prev_time, self.cur_time = self.cur_time, self.pred_time
+        self.updated = True
+
+    def _predict_with_roi(self, t, rows, cols):
+        if self.it >= 2:
+            self.pred_time = t
+            delta = logarithm_map(np.linalg.inv(self.prev_pose) @ self.cur_pose)
+            delta_hat = delta / (self.cur_time - self.prev_time) * (self.pred_time - self.cur_time)
+            self.pred_pose = self.cur_pose @ exponential_map(delta_hat)
+        else:
+            self.pred_time = t
+        self.pred_px = np.array([self.est.project2d(m, self.pred_pose) for m in self.est.M])
+        self.roi = determine_roi(self.pred_px, rows, cols, int(self.p["roi_border_thickness"]), self.K, self.D)
+
+    def _find_correspondences(self):
+        """findCorrespondences: for every PREDICTED marker pixel its nearest detection (first minimum), kept when the
+        distance is <= nearest_neighbour_pixel_tolerance_; rows (marker, detection), 1-based."""
+        rows = []
+        for i, pp in enumerate(self.pred_px):
+            best, bj = math.inf, 0
+            for j, d in enumerate(self.det):
+                d2 = float((pp[0] - d[0]) ** 2 + (pp[1] - d[1]) ** 2)
+                if d2 < best:
+                    best, bj = d2, j
+            if math.sqrt(best) <= self.p["nearest_neighbour_pixel_tolerance"]:
+                rows.append((i + 1, bj + 1))
+        self.corr = np.array(rows, np.uint32).reshape(-1, 2)
+
+    # -- estimateBodyPose --------------------------------------------------------------------------
+    def estimate(self, img, t):
+        img = np.asarray(img, np.uint8)
+        rows, cols = img.shape
+        self.updated = False
+        self.used_bruteforce = False
+        if self.it < 1:
+            self.pred_time = t
+            self.roi = (0, 0, cols, rows)
+            self.det = self._find_leds(img, self.roi)
+            if len(self.det) >= 4:
+                if self._initialise():
+                    self._optimise_and_update()
+        else:
+            self._predict_with_roi(t, rows, cols)
+            self.det = self._find_leds(img, self.roi)
+            loops = 0
+            while True:
+                loops += 1
+                if len(self.det) >= 4:
+                    self._find_correspondences()
+                    ok, T0 = self.est.check_correspondences(self.det, self.corr)
+                    if ok:
+                        self.pred_pose = T0
+                        self._optimise_and_update()
+                    elif self._initialise():
+                        self._optimise_and_update()
+                    break
+                if loops < 2:
+                    self.roi = (0, 0, cols, rows)
+                    self.det = self._find_leds(img, self.roi)
+                else:
+                    break
+        return dict(updated=self.updated, T=self.pred_pose.copy(), cov=self.cov.copy(), roi=tuple(self.roi),
+                    it_since_initialized=self.it, n_det=len(self.det), n_corr=len(self.corr),
+                    used_bruteforce=self.used_bruteforce)
