@@ -652,10 +652,17 @@ __device__ __forceinline__ int bitpos_sum(u64 m) {  // sum of the positions of t
 // All islands cs[0 .. nisl) of one frame; lane / nl: this lane and the number of lanes working together (64; 1 in the
 // CPU tier).  cs[k].bm_off .. xw0 filled in by the caller.  Returns a bit mask of the islands left to scan_window
 // (their pm / ng regions zeroed again); every other island's blobs have been emitted.
+// Every lane owns up to K1B_CELL_LANE_ITEMS (row, word) items, located once and kept in registers (island, bitmap
+// offset, the row's remaining mask and current component): a flood round then costs a lane two LDS reads per item (the
+// rows above and below; six more for islands wider than one word) and one write when its row grew.
+#ifndef K1B_CELL_LANE_ITEMS
+#define K1B_CELL_LANE_ITEMS 3
+#endif
 template <class Emit>
 __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng, CellIsl* cs, int nisl, int lane, int nl,
                                                 const DetectParams& dp, int roi_x, int roi_y, Emit emit) {
   const int kIntMax = 0x7fffffff;
+  constexpr int NIT = K1B_CELL_LANE_ITEMS;
   // ---- occupied slot range per island
   for (int k = lane; k < nisl; k += nl) {
     cs[k].lo = kIntMax;
@@ -681,52 +688,74 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
     }
   }
   wave_sync();
-  if (lane == 0) {  // item ranges (nisl is small: a serial prefix sum)
-    int acc = 0;
-    for (int k = 0; k < nisl; ++k) {
-      int n = 0;
-      if (cs[k].hi < cs[k].lo) {
-        cs[k].state = 1;  // nothing in this island
-      } else {
-        n = (cs[k].hi - cs[k].lo + 3) * cs[k].W;
-        if (n > K1B_CELL_ITEMS) {
-          cs[k].state = 2;
-          n = 0;
-        }
+  // item ranges: lane k sizes island k (its `seed` word holds the count for a moment), then sums the counts up to k
+  for (int k = lane; k < nisl; k += nl) {
+    int n = 0;
+    if (cs[k].hi < cs[k].lo) {
+      cs[k].state = 1;  // nothing in this island
+    } else {
+      n = (cs[k].hi - cs[k].lo + 3) * cs[k].W;
+      if (n > K1B_CELL_ITEMS || cs[k].W > 15) {
+        cs[k].state = 2;
+        n = 0;
       }
-      acc += n;
-      cs[k].item_end = acc;
     }
+    cs[k].seed = n;
+  }
+  wave_sync();
+  for (int k = lane; k < nisl; k += nl) {
+    int acc = 0, tot = 0;
+    for (int j = 0; j < nisl; ++j) {
+      const int n = cs[j].seed;
+      tot += n;
+      if (j <= k) acc += n;
+    }
+    if (tot > NIT * nl) {  // more rows than the lanes hold: the whole frame to the trace (rare)
+      if (cs[k].state == 0) cs[k].state = 2;
+      acc = 0;
+    }
+    cs[k].item_end = acc;
   }
   wave_sync();
   const int T = cs[nisl - 1].item_end;
-  // item i -> island k, bitmap word offset o of (slot, w)
-  auto locate = [&](int i, int& k, int& slot, int& w) {
-    k = 0;
-    while (i >= cs[k].item_end) ++k;
-    const int li = i - (k ? cs[k - 1].item_end : 0), W = cs[k].W;
-    const int r = li / W;
-    w = li - r * W;
-    slot = cs[k].lo - 1 + r;
-  };
-  for (int i = lane; i < T; i += nl) {  // remaining = the mask, component = empty
-    int k, slot, w;
-    locate(i, k, slot, w);
-    const int o = cs[k].bm_off + slot * cs[k].W + w;
-    ng[o] = nz[o];
-    pm[o] = 0;
+  // ---- this lane's items: island, word offset in the bitmaps, word index / words per row / slot (packed)
+  int it_o[NIT], it_m[NIT];
+#pragma unroll
+  for (int t = 0; t < NIT; ++t) {
+    const int i = lane + nl * t;
+    it_o[t] = -1;
+    it_m[t] = 0;
+    if (i < T) {
+      int k = 0;
+      while (i >= cs[k].item_end) ++k;
+      const int li = i - (k ? cs[k - 1].item_end : 0), W = cs[k].W;
+      const int r = li / W, w = li - r * W, slot = cs[k].lo - 1 + r;
+      it_o[t] = cs[k].bm_off + slot * W + w;
+      it_m[t] = k | (w << 6) | (W << 10) | (slot << 14);
+    }
+  }
+  auto isl_of = [](int m) { return m & 63; };
+  auto w_of = [](int m) { return (m >> 6) & 15; };
+  auto W_of = [](int m) { return (m >> 10) & 15; };
+  auto slot_of = [](int m) { return m >> 14; };
+  u64 rem[NIT], cur[NIT];  // the row's remaining pixels and those of the component being flooded
+#pragma unroll
+  for (int t = 0; t < NIT; ++t) {
+    rem[t] = it_o[t] >= 0 ? nz[it_o[t]] : 0;
+    cur[t] = 0;
+    if (it_o[t] >= 0) pm[it_o[t]] = 0;
   }
   wave_sync();
   for (int round = 0;; ++round) {
     // ---- seed: the raster-first remaining pixel of every island still in progress
     for (int k = lane; k < nisl; k += nl) cs[k].seed = kIntMax;
     wave_sync();
-    for (int i = lane; i < T; i += nl) {
-      int k, slot, w;
-      locate(i, k, slot, w);
-      if (cs[k].state != 0) continue;
-      const u64 m = ng[cs[k].bm_off + slot * cs[k].W + w];
-      if (m) atomicMin(&cs[k].seed, (slot << 16) | (64 * w + __builtin_ctzll(m)));
+    bool on[NIT];  // the item's island is in progress
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) {
+      on[t] = it_o[t] >= 0 && cs[isl_of(it_m[t])].state == 0;
+      if (on[t] && rem[t])
+        atomicMin(&cs[isl_of(it_m[t])].seed, (slot_of(it_m[t]) << 16) | (64 * w_of(it_m[t]) + __builtin_ctzll(rem[t])));
     }
     wave_sync();
     bool active = false;
@@ -734,38 +763,40 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
       if (cs[k].state == 0 && cs[k].seed == kIntMax) cs[k].state = 1;  // every component of the island is done
       if (cs[k].state == 0) {
         active = true;
-        if (cs[k].nblob >= K1B_CELL_BLOBS || round >= 2 * K1B_CELL_BLOBS) {
-          cs[k].state = 2;  // more components than this phase records
-        } else {
-          const int sd = cs[k].seed, slot = sd >> 16, xb = sd & 0xFFFF;
-          pm[cs[k].bm_off + slot * cs[k].W + (xb >> 6)] = 1ull << (xb & 63);
-        }
+        if (round >= 2 * K1B_CELL_BLOBS) cs[k].state = 2;  // more components than this phase cares to separate
       }
     }
     if (__builtin_amdgcn_ballot_w64(active) == 0) break;  // (uniform)
     wave_sync();
-    // ---- flood: 3 x 3 dilation under the mask until nothing changes (in place: the fixed point does not depend on
-    //      the order in which rows are updated)
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) {
+      on[t] = on[t] && cs[isl_of(it_m[t])].state == 0;
+      cur[t] = 0;
+      if (on[t]) {
+        const int sd = cs[isl_of(it_m[t])].seed;
+        if ((sd >> 16) == slot_of(it_m[t]) && ((sd & 0xFFFF) >> 6) == w_of(it_m[t])) cur[t] = 1ull << (sd & 63);
+        pm[it_o[t]] = cur[t];
+      }
+    }
+    wave_sync();
+    // ---- flood: 3 x 3 dilation under the mask until nothing changes
     bool changed;
     int it = 0;
     do {
       changed = false;
-      for (int i = lane; i < T; i += nl) {
-        int k, slot, w;
-        locate(i, k, slot, w);
-        if (cs[k].state != 0) continue;
-        const int W = cs[k].W, o = cs[k].bm_off + slot * W + w;
-        const u64 m = ng[o];
-        if (!m) continue;
-        u64 acc = 0;
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-          const int ro = o + dy * W;
-          const u64 c = pm[ro], l = w > 0 ? pm[ro - 1] : 0, r = w + 1 < W ? pm[ro + 1] : 0;
-          acc |= c | (c << 1) | (c >> 1) | (l >> 63) | (r << 63);
+      for (int t = 0; t < NIT; ++t) {
+        if (!on[t] || !rem[t]) continue;
+        const int W = W_of(it_m[t]), w = w_of(it_m[t]), o = it_o[t];
+        const u64 up = pm[o - W], dn = pm[o + W];
+        u64 acc = cur[t] | (cur[t] << 1) | (cur[t] >> 1) | up | (up << 1) | (up >> 1) | dn | (dn << 1) | (dn >> 1);
+        if (W > 1) {  // bits carried in from the neighbouring words of the three rows
+          if (w > 0) acc |= (pm[o - 1] | pm[o - W - 1] | pm[o + W - 1]) >> 63;
+          if (w + 1 < W) acc |= (pm[o + 1] | pm[o - W + 1] | pm[o + W + 1]) << 63;
         }
-        const u64 nv = acc & m;
-        if (nv != pm[o]) {
+        const u64 nv = acc & rem[t];
+        if (nv != cur[t]) {
+          cur[t] = nv;
           pm[o] = nv;
           changed = true;
         }
@@ -774,12 +805,12 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
     } while (__builtin_amdgcn_ballot_w64(changed) != 0 && ++it < K1B_CELL_ITERS);
     const bool settled = it < K1B_CELL_ITERS;
     // ---- sums over the cells of the row pairs (slot, slot + 1)
-    for (int i = lane; i < T; i += nl) {
-      int k, slot, w;
-      locate(i, k, slot, w);
-      if (cs[k].state != 0 || slot > cs[k].hi) continue;
-      const int W = cs[k].W, o = cs[k].bm_off + slot * W + w;
-      const u64 a = pm[o], an = w + 1 < W ? pm[o + 1] : 0, c = pm[o + W], cn = w + 1 < W ? pm[o + W + 1] : 0;
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) {
+      if (!on[t]) continue;
+      const int k = isl_of(it_m[t]), W = W_of(it_m[t]), w = w_of(it_m[t]), slot = slot_of(it_m[t]), o = it_o[t];
+      if (slot > cs[k].hi) continue;
+      const u64 a = cur[t], an = w + 1 < W ? pm[o + 1] : 0, c = pm[o + W], cn = w + 1 < W ? pm[o + W + 1] : 0;
       const u64 b = (a >> 1) | (an << 63), d = (c >> 1) | (cn << 63);
       if ((a | b | c | d) == 0) continue;
       const u64 full = a & b & c & d;
@@ -807,7 +838,7 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
     for (int k = lane; k < nisl; k += nl) {
       if (cs[k].state != 0) continue;
       if (!settled || cs[k].chi != 4) {
-        cs[k].state = 2;  // a hole (or several components glued by the flood cap): the literal trace decides
+        cs[k].state = 2;  // a hole (or a flood that did not settle): the literal trace decides
       } else {
         BlobRec br;
         br.a00 = cs[k].a00;
@@ -822,28 +853,31 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
         K1B_ON_BLOBREC(br, key);
         float mcx, mcy;
         if (blob_filter(br, dp, roi_x, roi_y, mcx, mcy)) {
-          const int n = cs[k].nblob++;
-          cs[k].bx[n] = mcx;
-          cs[k].by[n] = mcy;
-          cs[k].bkey[n] = key;
+          if (cs[k].nblob >= K1B_CELL_BLOBS) {
+            cs[k].state = 2;  // more blobs than the island record holds
+          } else {
+            const int n = cs[k].nblob++;
+            cs[k].bx[n] = mcx;
+            cs[k].by[n] = mcy;
+            cs[k].bkey[n] = key;
+          }
         }
       }
       cs[k].a00 = cs[k].a10 = cs[k].a01 = cs[k].chi = 0;
       cs[k].xmin = cs[k].ymin = kIntMax;
       cs[k].xmax = cs[k].ymax = -1;
     }
-    wave_sync();
-    for (int i = lane; i < T; i += nl) {  // the component leaves the remaining set
-      int k, slot, w;
-      locate(i, k, slot, w);
-      const int o = cs[k].bm_off + slot * cs[k].W + w;
-      ng[o] &= ~pm[o];
-      pm[o] = 0;
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) {  // the component leaves the remaining set
+      if (it_o[t] < 0) continue;
+      rem[t] &= ~cur[t];
+      cur[t] = 0;
+      pm[it_o[t]] = 0;
     }
     wave_sync();
   }
   wave_sync();
-  // ---- finished islands emit; the others get their mark bitmaps back clean for scan_window
+  // ---- finished islands emit; the others get their mark bitmaps back clean for scan_window (ng was never touched)
   unsigned todo = 0;
   for (int k = 0; k < nisl; ++k)
     if (cs[k].state == 2) todo |= 1u << k;
@@ -851,17 +885,7 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
     if (cs[k].state != 2)
       for (int n = 0; n < cs[k].nblob; ++n) emit(cs[k].bx[n], cs[k].by[n], cs[k].bkey[n]);
   }
-  if (todo) {
-    for (int k = 0; k < nisl; ++k) {
-      if (!((todo >> k) & 1u)) continue;
-      const int n = (cs[k].H + 2) * cs[k].W;
-      for (int i = lane; i < n; i += nl) {
-        pm[cs[k].bm_off + i] = 0;
-        ng[cs[k].bm_off + i] = 0;
-      }
-    }
-    wave_sync();
-  }
+  (void)ng;
   return todo;
 }
 
@@ -1947,10 +1971,10 @@ __device__ __forceinline__ float k2_prefilter_threshold(double back_tol) {
 // differently where that difference is AMPLIFIED past the distance of a back-projection from the vote tolerance, so a
 // hypothesis is not decided here but appended to a list, and re-evaluated by k2_vote_fixup with the strict functions,
 // when
-//   (a) a subtraction of Ferrari's method cancelled below 2^MPE_FERRARI_SUSPECT_EXP (7.5e-9) of its operands
-//       (solve_quartic_lit2: whole hypothesis, all four roots; 0.2 % of the hypotheses), or, per root,
+//   (a) a subtraction of Ferrari's method cancelled below 2^MPE_FERRARI_SUSPECT_EXP (9.3e-10) of its operands
+//       (solve_quartic_lit2: whole hypothesis, all four roots; 0.06 % of the hypotheses), or, per root,
 //       sin^2(theta) = 1 - root^2 or the vector (cn, cd) behind cot(alpha) is small for how well the quartic was
-//       conditioned (K2_SUS_OM / K2_SUS_HS), or |cos(alpha)| < 1e-6 (the strict arithmetic takes it as
+//       conditioned (K2_SUS_ROOT_BASE), or |cos(alpha)| < 1e-6 (the strict arithmetic takes it as
 //       sqrt(1 - sin^2), which then has few digits);
 //   (b) the squared distance of a detection to its nearest back-projection lies within 2^K2_SUS_BAND_EXP (relative) of
 //       tolerance^2 — +-0.8 % of the tolerance, e.g. +-0.04 px at 5 px, ten times what (a) lets through — or the
@@ -1959,7 +1983,7 @@ __device__ __forceinline__ float k2_prefilter_threshold(double back_tol) {
 //       triple's own three votes, pose_estimator.cpp:676-685) are cast here.
 // Votes are integer adds, so the order in which the two kernels cast them does not matter.  The strict verdict
 // REPLACES the fast one: with the list in place the histograms are those of k2_vote_strict (tests/soak_votes.py,
-// test_fast_votes_equal_strict_votes), at ~0.3 % of the hypotheses re-evaluated.  A full list (sized at > 100 times the
+// test_default_votes_equal_strict_votes), at ~0.25 % of the hypotheses re-evaluated.  A full list (sized at > 100 times the
 // expected rate by the host side) leaves the fast verdict in place and counts the event (option
 // "vote_fixup_overflow").
 #ifndef K2_SUS_BAND_EXP
@@ -1967,12 +1991,14 @@ __device__ __forceinline__ float k2_prefilter_threshold(double back_tol) {
 #endif
 // per root, by how well the quartic was conditioned (MPE_QUARTIC_MID: roots good to ~2e-8, else to ~2e-11): the error
 // of cos(theta) is divided by sin(theta) in the angle, that of (cn, cd) by its length relative to its operands
-// (single-precision literals and powers of two: no scalar register pairs for double-precision constants in the loop)
-#ifndef K2_SUS_OM
-#define K2_SUS_OM 1e-4f        // sin^2(theta) below which a root of a MID quartic is suspect ...
-#define K2_SUS_OM_GOOD 1e-9f   // ... and of a well-conditioned one
-#define K2_SUS_HS_EXP (-13)    // (|(cn, cd)| / |operands|)^2 likewise: 2^-13 = 1.2e-4 ...
-#define K2_SUS_HS_GOOD_EXP (-33)  // ... 2^-33 = 1.2e-10
+// With the quartic's worst cancellation 2^c (c = cancel_exp, > MPE_FERRARI_SUSPECT_EXP here) the two arithmetics' roots
+// differ by up to ~2^(-52 - c); a back-projection moves by <= ~1800 px per unit of the ANGLE, so for a tenth of band
+// (b), 4e-3 px, the angle may be off by 2.2e-6 = 2^-18.8: sin(theta) >= 2^(-52 - c + 18.8), i.e. sin^2(theta) and
+// likewise |(cn, cd)|^2 / |operands|^2 must stay above 2^(-66 - 2c) — never less than 2^-33 (1.2e-10), at most 2^-12.
+// Integer arithmetic on binary exponents (no double-precision literals: the loop has no scalar registers to spare).
+#ifndef K2_SUS_ROOT_BASE
+#define K2_SUS_ROOT_BASE (-66)
+#define K2_SUS_ROOT_FLOOR (-33)
 #define K2_SUS_COSA 1e-6f      // |cos(alpha)| below which a root is suspect
 #endif
 #define K2_SUS_WORDS 2
@@ -2215,10 +2241,9 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
   // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
   const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
   // (cn, cd) below is suspect when it keeps less than 1e-2 of its operands
-  const bool q_mid = cancel_exp < MPE_FERRARI_MID_EXP;
-  const double hs = ldexp(__builtin_fma(g1, g1, p_2 * p_2) + __builtin_fma(g2, g2, g3 * g3),
-                          q_mid ? K2_SUS_HS_EXP : K2_SUS_HS_GOOD_EXP);
-  const float oms = q_mid ? K2_SUS_OM : K2_SUS_OM_GOOD;
+  const int root_thr = max(K2_SUS_ROOT_FLOOR, K2_SUS_ROOT_BASE - 2 * cancel_exp);  // (binary exponent, see above)
+  const int hs_exp = p3p_expo(__builtin_fma(g1, g1, p_2 * p_2) + __builtin_fma(g2, g2, g3 * g3)) + root_thr;
+  const int om_exp = 1023 + root_thr;
   // scan-carrying variant: the first two of them (all of them in a 5-detection frame) stay in registers for the four
   // roots' prefilters; a missing second one sits at infinity and passes no test
   unsigned rest = unused, lsb0 = 0, lsb1 = 0;
@@ -2260,7 +2285,8 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     // (|root| > 1: sqrt of a negative number) in the other.  sin(theta) = sqrt(1 - root^2) at its branch point, (cn, cd)
     // cancelled, or cos(alpha) so small that the strict arithmetic's sqrt(1 - sin(alpha)^2) has no digits: this root
     // goes to the list with all unused detections
-    const bool root_sus = fix && live && (item_sus || fabsf((float)om) < oms || h2 < hs || fabsf((float)cos_alpha) < K2_SUS_COSA);
+    const bool root_sus = fix && live && (item_sus || p3p_expo(om) < om_exp || p3p_expo(h2) < hs_exp ||
+                                          fabsf((float)cos_alpha) < K2_SUS_COSA);
     if constexpr (!SCAN) {
       if (root_sus) {
         k2_sus_push(F, k2_sus_code(c0, c1, c2, p0, p1, p2, 1u << k, false), unused);

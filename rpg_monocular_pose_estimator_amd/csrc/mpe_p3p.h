@@ -301,27 +301,21 @@ __device__ __forceinline__ C2 cpow_third_newton(C2 z) {
 struct NoService {
   __device__ __forceinline__ void operator()() const {}
 };
-// Cancellation below which a subtraction of Ferrari's method is reported as `suspect` by solve_quartic_lit2: the
-// result keeps less than EPS of its operands.  Measured on the quartics of 1.2 M C2 hypotheses (host build of this
-// header, fast against strict arithmetic): the real parts of the roots differ by at most ~2e-16 / c where c is the
-// smallest of the five ratios below — and small ratios are COMMON (c < 1e-6 for 1.9 % of the hypotheses, < 1e-8 for
-// 0.25 %, < 1e-10 for 0.04 %: the P3P quartic of a wrong correspondence often has nearly coinciding roots).  With
-// 2^-27 = 7.5e-9 the two arithmetics agree to ~3e-8 in every root that is not reported, i.e. to < 5e-3 px in a back-projection
-// (<= 600 px / sin(theta) per unit of cos(theta), sin(theta) >= 1e-2 or the root is reported separately) — a tenth of
-// the band (b) of the voting kernel.  The voting kernel hands reported hypotheses to the strict functions
-// (k2_vote_fixup) instead of voting on them itself.
-// A second, wider level (2^-17 = 7.6e-6: roots agree to ~3e-11 when it is not reported either) lets the caller choose how close
-// to a branch point of the back-substitution (sin(theta) -> 0, cot(alpha) -> 0/0) a root may come before IT is suspect.
-// Both levels are powers of two and the ratios are compared by their binary EXPONENTS only (integer arithmetic on the
-// high words, the smallest difference kept in one vector register): 2^-27 = 7.5e-9 and 2^-17 = 7.6e-6, each good to a
-// factor of two.  Written with double-precision compares the two levels cost two pairs of scalar registers across the
-// whole quartic plus a pair per threshold literal, and the scan-carrying voting kernel, which has no scalar register to
-// spare, spilled hundreds of them to vector lanes (its launch went from 1.39 to 1.59 ms).
+// Cancellation below which a subtraction of Ferrari's method makes a hypothesis `suspect`: the result keeps less than
+// 2^MPE_FERRARI_SUSPECT_EXP of its operands.  Measured on the quartics of 1.2 M C2 hypotheses (host build of this header,
+// fast against strict arithmetic): the real parts of the roots differ by at most ~2e-16 / c where c is the smallest of
+// the five ratios solve_quartic_lit2 looks at — and small ratios are COMMON (c < 1e-6 for 1.9 % of the hypotheses,
+// < 1e-8 for 0.25 %, < 1e-10 for 0.04 %: the P3P quartic of a wrong correspondence often has nearly coinciding roots).
+// With 2^-30 = 9.3e-10 (0.06 % of the hypotheses) the two arithmetics agree to ~2.4e-7 in every root that is not
+// reported, i.e. to ~4e-4 px in a back-projection as far as cos(theta) itself goes; the amplification by 1 / sin(theta)
+// and 1 / |(cn, cd)| is bounded root by root in the voting kernel from the exponent c returned here (K2_SUS_ROOT_BASE).
+// The voting kernel hands reported hypotheses to the strict functions (k2_vote_fixup) instead of voting on them itself.
+// The ratios are compared by their binary EXPONENTS only (integer arithmetic on the high words, the smallest difference
+// kept in one vector register), each good to a factor of two.  Written with double-precision compares the levels cost
+// pairs of scalar registers across the whole quartic plus a pair per threshold literal, and the scan-carrying voting
+// kernel, which has no scalar register to spare, spilled hundreds of them to vector lanes.
 #ifndef MPE_FERRARI_SUSPECT_EXP
-#define MPE_FERRARI_SUSPECT_EXP (-27)
-#endif
-#ifndef MPE_FERRARI_MID_EXP
-#define MPE_FERRARI_MID_EXP (-17)
+#define MPE_FERRARI_SUSPECT_EXP (-30)
 #endif
 // biased binary exponent of |x| (0 for zero / subnormal, 2047 for inf / NaN)
 __device__ __forceinline__ int p3p_expo(double x) { return (int)((__double2hiint(x) >> 20) & 0x7FF); }
@@ -329,7 +323,7 @@ __device__ __forceinline__ double cabs1(C2 z) { return fabs(z.re) + fabs(z.im); 
 // `service` is called at two points inside (after the cube root, after w): the voting kernel's scan rider uses
 // them to retire / start LDS-DMA rounds behind the arithmetic; a no-op everywhere else.
 // `cancel_exp` (out): the binary exponent of the worst cancellation among the subtractions of p3p.cpp:253-283 (compare
-// with MPE_FERRARI_SUSPECT_EXP / MPE_FERRARI_MID_EXP) — the
+// with MPE_FERRARI_SUSPECT_EXP) — the
 // discriminant Q^2/4 + P^3/27, R = -Q/2 + sqrt(disc), w^2 = alpha + 2y (y with the magnitudes of ITS operands, so a
 // cancellation inside y counts), the two outer radicands -(3 alpha + 2y +- 2 beta / w): the quantities
 // tests/forensics.py classifies mismatching frames by.  NaN operands never compare true (such roots vote nowhere).

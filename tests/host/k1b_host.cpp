@@ -56,6 +56,7 @@ struct RawRec {
 static std::vector<RawRec>* g_raw = nullptr;
 #define K1B_ON_BLOBREC(rec, key) \
   do { if (g_raw) g_raw->push_back(RawRec{(rec).a00, (rec).a10, (rec).a01, (rec).xmin, (rec).xmax, (rec).ymin, (rec).ymax, (key)}); } while (0)
+#define K1B_CELL_LANE_ITEMS 192  // (one "lane" owns every item of the frame here)
 #define __host__
 #include "k1a_extract.inc"  // ThrTest, make_thr_test, gt_word, maybe_gt16, any_gt16 (`struct ThrTest {` .. `#ifndef K1A_UNROLL`)
 #include "k1b_extract.inc"

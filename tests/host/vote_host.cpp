@@ -119,7 +119,7 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
       }
     return 0;
   }
-  const unsigned sus_cap = fixup ? (tiny_global ? 4u : 1u << 16) : 0u;
+  const unsigned sus_cap = fixup ? (tiny_global ? 1u : 1u << 16) : 0u;
   const unsigned lds_cap = tiny_list ? 4u : 1u << 16;
   std::vector<u64> sus_list((size_t)K2_SUS_WORDS * (sus_cap + 1), 0), sus_lds((size_t)K2_SUS_WORDS * lds_cap, 0);
   unsigned sus_ctl[4] = {0, 0, 0, 0}, sus_lds_n = 0;

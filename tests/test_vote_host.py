@@ -186,7 +186,7 @@ def test_fixup_on_the_saved_unstable_frames(host, orc):
 
 def test_fixup_lists_full(host, orc):
     """The block's list holds four entries: appends go straight to the launch's list instead — same histogram as the
-    strict loop.  That one holds four entries as well: entries are LOST (their votes are cast nowhere), which is
+    strict loop.  That one holds a single entry: entries are LOST (their votes are cast nowhere), which is
     counted and marks the frame MPE_FRAME_VOTE_LIST_FULL — a capacity overrun is never silent."""
     d = synth.make_frames("C2", 12, seed=5)
     P = orc.make_params()
@@ -206,6 +206,6 @@ def test_fixup_lists_full(host, orc):
         for variant in (40, 41):
             _host_hist(host, und, d["markers"], d["K"], tol, variant)
             n, whole, lost, marked = _stats(host)
-            assert n <= 4 and (lost > 0) == (marked == 1)
+            assert n <= 1 and (lost > 0) == (marked == 1)
             seen_lost += lost
-    assert seen_lost > 0 and seen_entries > 20
+    assert seen_lost > 0 and seen_entries > 10
