@@ -131,6 +131,10 @@ def main():
                     help="one joined mpe_estimate_batch_device call per step instead of the submit / collect stream of batches")
     ap.add_argument("--no-records-to-host", dest="records_to_host", action="store_false",
                     help="leave the pose records on the device (no D2H copy inside the step)")
+    ap.add_argument("--assume-side-streams", action="store_true",
+                    help="counter passes: skip the stream-concurrency probe (kernels are serialised under rocprofv3 --pmc, "
+                         "the probe would fail and the call fall back to schedule 3) so that the launches have the "
+                         "shapes of the timed schedule 6")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no GPU work: the launch / shard / pose-gather / timing plumbing of the N-rank bench on CPU "
                          "(gloo), with synthetic records instead of kernels; used by the CPU test-suite")
@@ -203,6 +207,8 @@ def main():
     h.set_option("vote_splits", args.vote_splits)
     h.set_option("scan_split_pct", args.scan_split_pct)
     h.set_option("side_scan_blocks", args.side_scan_blocks)
+    if args.assume_side_streams:
+        h.set_option("assume_side_streams", 1)
     if args.k1a_lds >= 0:
         h.set_option("k1a_dummy_lds", args.k1a_lds)
 

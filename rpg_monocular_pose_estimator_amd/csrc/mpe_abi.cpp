@@ -91,6 +91,9 @@ struct mpe_handle {
   int vote_arith = 1;          // 1 = fast voting arithmetic + strict re-evaluation of the hypotheses it cannot decide
                                //     (default), 0 = strict: IEEE operators, the validation kernel's P3P (same quartic
                                //     in K2 and K3), 2 = the fast arithmetic alone (round-3 behaviour, A/B only)
+  int assume_side_streams = 0; // option: take the side streams of schedules 4 / 6 as concurrent without the spin probe —
+                               // for counter passes: the profiler serialises kernels, the probe then fails and the
+                               // call would fall back to schedule 3, i.e. other launch shapes than the timed run's
   int force_rccl_gather = 0;   // option: mpe_estimate_batch_multi_device_gather sends EVERY shard's records (shard 0's
                                // too: a send to itself) through RCCL, also with one handle — the self-test of that leg
                                // on a 1-GPU box (dlopen, ncclCommInitAll, grouped send / recv)
@@ -606,6 +609,17 @@ hipError_t spin_pair_ms(hipStream_t a, hipStream_t b, double& ms) {
 // after 8 replacements -> side_streams_ok = 0 and the caller falls back to the one-stream schedule 3.
 int ensure_side_streams(mpe_handle* h, bool need_scan) {
   if (h->side_streams_ok >= 0 && h->probed_for == h->stream && (!need_scan || h->probed_scan)) return MPE_OK;
+  if (h->assume_side_streams) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!h->tail_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
+    if (need_scan && !h->scan_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking));
+    h->side_streams_ok = 1;
+    h->streams_concurrent = -1;  // (not probed)
+    h->probed_for = h->stream;
+    h->probed_scan = need_scan;
+    h->tail_sub_pending = false;
+    return MPE_OK;
+  }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (!h->tail_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
   if (need_scan && !h->scan_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking));
@@ -1261,6 +1275,7 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "vote_splits") *value = h->vote_splits;
   else if (n == "vote_arith") *value = h->vote_arith;
   else if (n == "force_rccl_gather") *value = h->force_rccl_gather;
+  else if (n == "assume_side_streams") *value = h->assume_side_streams;
   else if (n == "refine_variant") *value = h->refine_variant;
   else if (n == "ingest_chunk") *value = h->ingest_chunk;
   else if (n == "scan_split_pct") *value = h->scan_split_pct;
@@ -1388,6 +1403,11 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   if (!std::strcmp(name, "refine_variant")) {
     if (value < 0 || value > 2) return fail(h, MPE_ERR_ARG, "refine_variant must be 0 (automatic), 1 (lane) or 2 (group)");
     h->refine_variant = value;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "assume_side_streams")) {
+    h->assume_side_streams = value ? 1 : 0;
+    h->side_streams_ok = -1;
     return MPE_OK;
   }
   if (!std::strcmp(name, "force_rccl_gather")) {

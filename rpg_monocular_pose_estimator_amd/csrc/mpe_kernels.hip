@@ -1976,8 +1976,8 @@ __device__ __forceinline__ float k2_prefilter_threshold(double back_tol) {
 //       sin^2(theta) = 1 - root^2 or the vector (cn, cd) behind cot(alpha) is small for how well the quartic was
 //       conditioned (K2_SUS_ROOT_BASE), or |cos(alpha)| < 1e-6 (the strict arithmetic takes it as
 //       sqrt(1 - sin^2), which then has few digits);
-//   (b) the squared distance of a detection to its nearest back-projection lies within 2^K2_SUS_BAND_EXP (relative) of
-//       tolerance^2 — +-0.8 % of the tolerance, e.g. +-0.04 px at 5 px, ten times what (a) lets through — or the
+//   (b) the distance of a detection to its nearest back-projection lies within 2^K2_SUS_BAND_EXP = 0.0156 px of the
+//       tolerance (tested on the squares) — four times the 4e-3 px that (a) lets through — or the
 //       nearest and the second nearest back-projection are that close to each other while in reach: only those
 //       detections of that root go to the list; the other detections' votes (and whether any of them voted: the
 //       triple's own three votes, pose_estimator.cpp:676-685) are cast here.
@@ -1987,7 +1987,7 @@ __device__ __forceinline__ float k2_prefilter_threshold(double back_tol) {
 // expected rate by the host side) leaves the fast verdict in place and counts the event (option
 // "vote_fixup_overflow").
 #ifndef K2_SUS_BAND_EXP
-#define K2_SUS_BAND_EXP (-6)  // 2^-6 = 1.6e-2 of tolerance^2, i.e. +-0.8 % of the tolerance
+#define K2_SUS_BAND_EXP (-6)  // the band's half width in pixels: 2^-6 = 0.0156 px, four times what (a) lets through
 #endif
 // per root, by how well the quartic was conditioned (MPE_QUARTIC_MID: roots good to ~2e-8, else to ~2e-11): the error
 // of cos(theta) is divided by sin(theta) in the angle, that of (cn, cd) by its length relative to its operands
@@ -2046,7 +2046,8 @@ template <class QAt>
 __device__ __forceinline__ void k2_vote_root_exact(const K2Frame& F, const unsigned cw, const unsigned pw,
                                                    unsigned pass, int k, QAt qat) {
   const double tol2 = F.back_tol * F.back_tol;
-  const double band = F.fix ? ldexp(tol2, K2_SUS_BAND_EXP) : -1.0;  // (< 0: no detection ever is suspect)
+  // |d^2 - tol^2| <= 2 tol w with w = tol-independent 2^K2_SUS_BAND_EXP px
+  const double band = F.fix ? ldexp(F.back_tol, K2_SUS_BAND_EXP + 1) : -1.0;  // (< 0: no detection ever is suspect)
   bool any = false;
   unsigned sus = 0;
   for (unsigned todo = pass; todo; todo &= todo - 1) {
@@ -2790,8 +2791,9 @@ __global__ __launch_bounds__(K2_FIX_THREADS) void k2_vote_fixup(const mpe_detect
 hipError_t launch_k2_fixup(const mpe_detections* dets, const SolveParams& sp, uint32_t* hist, const VoteFixup& fx,
                            hipStream_t s) {
   if (!fx.ctl || fx.cap == 0 || sp.n_markers < 4) return hipSuccess;
-  // (the entry count lives on the device: a fixed grid strides over it; lists are short — ~5e-5 of the hypotheses)
-  hipLaunchKernelGGL(k2_vote_fixup, dim3(256), dim3(K2_FIX_THREADS), 0, s, dets, sp, hist, fx);
+  // (the entry count lives on the device: a fixed grid strides over it — wide, every entry is a single-wave chain of
+  //  dependent FP64 operations (~30 us), and blocks beyond the count leave at once; ~0.15 % of the hypotheses)
+  hipLaunchKernelGGL(k2_vote_fixup, dim3(2048), dim3(K2_FIX_THREADS), 0, s, dets, sp, hist, fx);
   return hipGetLastError();
 }
 
