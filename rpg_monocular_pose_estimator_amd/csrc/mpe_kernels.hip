@@ -1959,8 +1959,10 @@ __device__ __forceinline__ double k2_ltab_value(const double* __restrict__ tab, 
 // tol; single precision places both points within 1e-3 px for any point that close to a detection (pixel
 // coordinates < 4096), so "minimum single-precision distance <= tol (1 + 1e-4) + 0.05" is a safe necessary
 // condition, and the exact double-precision search only runs for the few detections that pass it.
-__device__ __forceinline__ float k2_prefilter_threshold(double back_tol) {
-  const double tol_pre = back_tol * (1.0 + 1e-4) + 0.05;
+// (margin_px: 0.05 covers the rounding of double-precision points to single precision; the plain variant's deferred
+//  path, whose back-projections are COMPUTED in single precision, passes 0.25)
+__device__ __forceinline__ float k2_prefilter_threshold(double back_tol, double margin_px = 0.05) {
+  const double tol_pre = back_tol * (1.0 + 1e-4) + margin_px;
   return (float)(tol_pre * tol_pre * (1.0 + 1e-5));
 }
 
@@ -2172,6 +2174,93 @@ __device__ __forceinline__ void k2_sus_flush(const K2Frame& F, unsigned* s_base)
   __syncthreads();
 }
 
+// ---- back-substitution of one root and back-projection of one marker (shared by the voting loop and by the deferred
+//      evaluation of the plain variant, which must produce the same bits) -------------------------------------------
+// p3p.cpp:193-213 without forming [R|C]:  cot_alpha = cn / cd;  sin_alpha = sqrt(1 / (cot^2 + 1)) = |cd| / hypot(cn, cd),
+// cos_alpha = sign(cot) sqrt(1 - sin^2) = cn sign(cd) / hypot(cn, cd)
+struct K2Sub {
+  double cos_theta, sin_theta, cos_alpha, sin_alpha, Cx, Cy, Cz;
+  double om, h2;  // 1 - root^2 and |(cn, cd)|^2: the quantities the suspect screen looks at
+};
+__device__ __forceinline__ K2Sub k2_back_substitute(double rt, double g1, double g2, double g3, double p_2, double d_12,
+                                                    double b) {
+  K2Sub S;
+  const double cn = g1 - rt * p_2, cd = g2 * rt + g3;
+  S.h2 = __builtin_fma(cn, cn, cd * cd);
+  const double ih = rsqrt_nr(S.h2);
+  S.cos_theta = rt;
+  S.om = 1 - rt * rt;
+  S.sin_theta = sqrt_nr(S.om);
+  S.sin_alpha = fabs(cd) * ih;
+  S.cos_alpha = (cd < 0 ? -cn : cn) * ih;
+  const double dk = d_12 * __builtin_fma(S.sin_alpha, b, S.cos_alpha);
+  const double sdk = S.sin_alpha * dk;
+  S.Cx = S.cos_alpha * dk;
+  S.Cy = S.cos_theta * sdk;
+  S.Cz = S.sin_theta * sdk;
+  return S;
+}
+// X_cam = T^T Rm (N (m - P1) - C_eta) through K: mk = the marker in the eta frame, tr = the rows of K T^T
+__device__ __forceinline__ void k2_project_marker(const K2Sub& S, const double* mk, const double* tr, double& qu, double& qv) {
+  const double v0 = mk[0] - S.Cx, v1 = mk[1] - S.Cy, v2 = mk[2] - S.Cz;
+  const double g = __builtin_fma(S.cos_theta, v1, S.sin_theta * v2);
+  const double w0 = -__builtin_fma(S.cos_alpha, v0, S.sin_alpha * g);
+  const double w1 = __builtin_fma(S.sin_alpha, v0, -(S.cos_alpha * g));
+  const double w2 = __builtin_fma(S.cos_theta, v2, -(S.sin_theta * v1));
+  const double U = __builtin_fma(tr[0], w0, __builtin_fma(tr[1], w1, tr[2] * w2));  // K T^T w
+  const double V = __builtin_fma(tr[3], w0, __builtin_fma(tr[4], w1, tr[5] * w2));
+  const double Z = __builtin_fma(tr[6], w0, __builtin_fma(tr[7], w1, tr[8] * w2));
+  const double iZ = rcp_nr(Z);
+  qu = U * iZ;
+  qv = V * iZ;
+}
+
+// ---- plain variant, 3 .. 8 unused markers: single-precision back-projection + deferred exact evaluation -------------
+// With 5 unused markers and 9 unused detections (C3) a root cost 150 double-precision operations for the
+// back-projections, ten LDS column stores, and — in nearly every wave iteration, with a lane or two alive — the exact
+// nearest-neighbour search: together 40 % of the kernel.  The roots themselves need double precision (the quartic
+// cannot be screened in single precision: profiles/round3_study_f32_screen.json), but a back-projection FROM a
+// double-precision root is well conditioned: it is evaluated in packed single precision for two markers at a time
+// (the prefilter only asks "can this come within the tolerance": its margin grows from 0.05 to 0.25 px for the
+// single-precision chain, whose error stays below 0.04 px for any point in front of or behind the camera with
+// |z| >= 0.1 |X| — and a point closer to the image plane than that projects thousands of pixels away from every
+// detection), and a (hypothesis, root) whose prefilter passes is appended to the wave's queue {root, indices, mask}.
+// The queue is worked off with ONE ENTRY PER LANE: back-substitution and back-projections again, in double
+// precision (k2_back_substitute / k2_project_marker: the same operations as the direct path), the exact search, the
+// band screen and the votes (k2_vote_root_exact).
+#define K2_DQ_CAP 320   // entries per wave: a flush threshold of 64 + the 4 x 64 one item can append
+#define K2_DQ_WORDS 2
+__device__ __forceinline__ float k2_rcpf(float x) { return p3p_rcpf(x); }
+__host__ __device__ constexpr bool k2_defers(bool scan, int np) { return !scan && np >= 2; }
+// works the wave's queue off, one entry per lane: everything the voting loop knew about the root is rebuilt from the
+// staged triple ti, the permutation pj and the root's value
+__device__ __forceinline__ void k2_defer_flush(const K2Frame& F, int count) {
+  wave_sync();
+  const unsigned n = (unsigned)count;
+  const unsigned lane = (unsigned)F.tid & 63u;
+  for (unsigned i = lane; i < n; i += (unsigned)F.vq_lanes) {
+    const u64* q = F.vq + (size_t)i * K2_DQ_WORDS;
+    const double rt = __longlong_as_double((long long)q[0]);
+    const unsigned meta = (unsigned)q[1], pass = (unsigned)(q[1] >> 32);
+    const int ti = meta & 0xFF, pj = (meta >> 8) & 0xFFF, k = (meta >> 20) & 3;
+    const unsigned ii = F.trii[ti];
+    const bool swap = (ii >> 24) & 1;
+    const int packed = (int)F.tab[(size_t)(pj - F.pj_base) * F.esz + 16];
+    const int r6 = pj % 6;
+    const int pjs = swap ? (pj - r6 + (int)((0x134052u >> (4 * r6)) & 7u)) : pj;
+    const double* e = F.tab + (size_t)(pjs - F.pj_base) * F.esz;
+    const double p_1 = e[12], p_2 = e[13], d_12 = e[14];
+    const double* tr = F.tri[ti];
+    const double b = tr[11], f12 = tr[12];
+    const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
+    const K2Sub S = k2_back_substitute(rt, g1, g2, g3, p_2, d_12, b);
+    k2_vote_root_exact(F, ii & 0xFFFFFFu, (unsigned)packed & 0xFFFFFFu, pass, k, [&](const int jj, double& bu, double& bv) {
+      k2_project_marker(S, e + 18 + 3 * jj, tr, bu, bv);
+    });
+  }
+  wave_sync();
+}
+
 // One work item = (staged detection triple ti, marker permutation pj): quartic coefficients (p3p.cpp:171-185),
 // Ferrari, and for each root the back-projection of the unused markers and the nearest-neighbour votes
 // (pose_estimator.cpp:596-702).  `live` = false: compute on, never vote (wave-uniform loop of the rider variant).
@@ -2192,8 +2281,11 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
   // that the SAME indices work for p_1 p_2 d_12 valid (12..15), and the markers are read through lt below
   const double* lt = SCAN ? F.ltab + pjs * K2_LTAB : nullptr;
   const double* e = SCAN ? lt - 12 : F.tab + (size_t)(pjs - F.pj_base) * F.esz;
+  // UNI: every lane of the wave runs the whole item (lanes without a valid hypothesis compute on harmlessly and are
+  // barred from voting): the scan rider's rounds and the ballots that hand out queue slots need all 64 lanes
+  constexpr bool UNI = SCAN || k2_defers(SCAN, NP);
   if (e[15] == 0.0) {  // collinear world points: computePoses returns -1
-    if constexpr (SCAN)
+    if constexpr (UNI)
       live = false;
     else
       return;
@@ -2236,7 +2328,12 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
   if constexpr (!SCAN) {
     if (item_sus) {
       k2_sus_push(F, k2_sus_code(c0, c1, c2, p0, p1, p2, 0xFu, false), unused);
-      return;
+      if constexpr (UNI) {
+        live = false;
+        item_sus = false;
+      } else {
+        return;
+      }
     }
   }
   // root-independent parts of cot_alpha (p3p.cpp:195-196), f_1/f_2 folded into one quotient
@@ -2268,42 +2365,34 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     // next scan round: nothing of the voting loop waits on vmcnt (table and triples are in LDS)
     rider.issue();
     const double rt = k == 0 ? root[0] : (k == 1 ? root[1] : (k == 2 ? root[2] : root[3]));
-    // back-substitution, p3p.cpp:193-213
-    // cot_alpha = cn / cd;  sin_alpha = sqrt(1 / (cot^2 + 1)) = |cd| / hypot(cn, cd),
-    // cos_alpha = sign(cot) sqrt(1 - sin^2) = cn sign(cd) / hypot(cn, cd)
-    const double cn = g1 - rt * p_2, cd = g2 * rt + g3;
-    const double h2 = __builtin_fma(cn, cn, cd * cd);
-    const double ih = rsqrt_nr(h2);
-    const double cos_theta = rt;
-    const double om = 1 - rt * rt;
-    const double sin_theta = sqrt_nr(om);
-    const double sin_alpha = fabs(cd) * ih;
-    const double cos_alpha = (cd < 0 ? -cn : cn) * ih;
-    const double dk = d_12 * __builtin_fma(sin_alpha, b, cos_alpha);
-    const double sdk = sin_alpha * dk;
-    const double Cx = cos_alpha * dk, Cy = cos_theta * sdk, Cz = sin_theta * sdk;
+    const K2Sub S = k2_back_substitute(rt, g1, g2, g3, p_2, d_12, b);  // p3p.cpp:193-213
+    const double om = S.om, h2 = S.h2, cos_alpha = S.cos_alpha, Cx = S.Cx, Cy = S.Cy, Cz = S.Cz;
     // (a), per root — BEFORE the finiteness test: a root within rounding of +-1 is finite in one arithmetic and NaN
     // (|root| > 1: sqrt of a negative number) in the other.  sin(theta) = sqrt(1 - root^2) at its branch point, (cn, cd)
     // cancelled, or cos(alpha) so small that the strict arithmetic's sqrt(1 - sin(alpha)^2) has no digits: this root
     // goes to the list with all unused detections
     const bool root_sus = fix && live && (item_sus || p3p_expo(om) < om_exp || p3p_expo(h2) < hs_exp ||
                                           fabsf((float)cos_alpha) < K2_SUS_COSA);
+    bool root_listed = false;
     if constexpr (!SCAN) {
       if (root_sus) {
         k2_sus_push(F, k2_sus_code(c0, c1, c2, p0, p1, p2, 1u << k, false), unused);
-        continue;
+        if constexpr (UNI)
+          root_listed = true;
+        else
+          continue;
       }
     }
     // isFinite([R C]) (pose_estimator.cpp:653): a product is finite only if every factor is (0 * inf = NaN), so
     // R (products of the four sines / cosines with the finite frames) and C are finite iff C_eta is
     bool finite_pose = true;
     if (!(k2_isfinite(Cx) && k2_isfinite(Cy) && k2_isfinite(Cz))) {
-      if constexpr (SCAN)
+      if constexpr (UNI)
         finite_pose = false;
       else
         continue;
     }
-    const bool may_vote = live && finite_pose;
+    const bool may_vote = live && finite_pose && !root_listed;
     double q0u = 0, q0v = 0, q1u = 0, q1v = 0;
     // the prefilter's operands, transposed: (u of marker 0, u of marker 1) and (v, v); a missing second marker sits
     // at infinity and never is the nearest
@@ -2314,16 +2403,8 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     for (int pp = 0; pp < NPA; ++pp) pfu[pp] = pfv[pp] = f32x2{INFINITY, INFINITY};
     auto back_project = [&](const int j) {
       const double* mk = SCAN ? lt + 5 + 3 * j : e + 18 + 3 * j;
-      const double v0 = mk[0] - Cx, v1 = mk[1] - Cy, v2 = mk[2] - Cz;
-      const double g = __builtin_fma(cos_theta, v1, sin_theta * v2);
-      const double w0 = -__builtin_fma(cos_alpha, v0, sin_alpha * g);
-      const double w1 = __builtin_fma(sin_alpha, v0, -(cos_alpha * g));
-      const double w2 = __builtin_fma(cos_theta, v2, -(sin_theta * v1));
-      const double U = __builtin_fma(tr[0], w0, __builtin_fma(tr[1], w1, tr[2] * w2));  // K T^T w
-      const double V = __builtin_fma(tr[3], w0, __builtin_fma(tr[4], w1, tr[5] * w2));
-      const double Z = __builtin_fma(tr[6], w0, __builtin_fma(tr[7], w1, tr[8] * w2));
-      const double iZ = rcp_nr(Z);
-      const double qu = U * iZ, qv = V * iZ;
+      double qu, qv;
+      k2_project_marker(S, mk, tr, qu, qv);
       if constexpr (SCAN) {  // <= 2 unused markers in this variant: registers instead of the LDS columns
         if (j == 0) {
           q0u = qu;
@@ -2352,7 +2433,39 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
         }
       }
     };
-    if constexpr (!SCAN && NP > 0) {
+    if constexpr (k2_defers(SCAN, NP)) {
+      // single-precision back-projections, two markers per packed instruction (see K2_DQ_CAP above)
+      const float ct = (float)S.cos_theta, st = (float)S.sin_theta, ca = (float)S.cos_alpha, sa = (float)S.sin_alpha;
+      const float cxf = (float)S.Cx, cyf = (float)S.Cy, czf = (float)S.Cz;
+      float t[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) t[i] = (float)tr[i];
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        if (2 * pp < F.nuo) {  // (nuo is uniform over the block)
+          const double* m0 = e + 18 + 6 * pp;
+          const bool two = 2 * pp + 1 < F.nuo;
+          const double* m1 = two ? m0 + 3 : m0;
+          const f32x2 v0 = f32x2{(float)m0[0], (float)m1[0]} - f32x2{cxf, cxf};
+          const f32x2 v1 = f32x2{(float)m0[1], (float)m1[1]} - f32x2{cyf, cyf};
+          const f32x2 v2 = f32x2{(float)m0[2], (float)m1[2]} - f32x2{czf, czf};
+          const f32x2 g = k2_pk_fma(f32x2{ct, ct}, v1, f32x2{st, st} * v2);
+          const f32x2 w0 = f32x2{0.f, 0.f} - k2_pk_fma(f32x2{ca, ca}, v0, f32x2{sa, sa} * g);
+          const f32x2 w1 = k2_pk_fma(f32x2{sa, sa}, v0, f32x2{0.f, 0.f} - f32x2{ca, ca} * g);
+          const f32x2 w2 = k2_pk_fma(f32x2{ct, ct}, v2, f32x2{0.f, 0.f} - f32x2{st, st} * v1);
+          const f32x2 U = k2_pk_fma(f32x2{t[0], t[0]}, w0, k2_pk_fma(f32x2{t[1], t[1]}, w1, f32x2{t[2], t[2]} * w2));
+          const f32x2 V = k2_pk_fma(f32x2{t[3], t[3]}, w0, k2_pk_fma(f32x2{t[4], t[4]}, w1, f32x2{t[5], t[5]} * w2));
+          const f32x2 Z = k2_pk_fma(f32x2{t[6], t[6]}, w0, k2_pk_fma(f32x2{t[7], t[7]}, w1, f32x2{t[8], t[8]} * w2));
+          const f32x2 iZ = {k2_rcpf(Z.x), k2_rcpf(Z.y)};
+          pfu[pp] = U * iZ;
+          pfv[pp] = V * iZ;
+          if (!two) {
+            pfu[pp].y = INFINITY;
+            pfv[pp].y = INFINITY;
+          }
+        }
+      }
+    } else if constexpr (!SCAN && NP > 0) {
 #pragma unroll
       for (int j = 0; j < 2 * NP; ++j)
         if (j < F.nuo) back_project(j);  // (nuo is uniform over the block)
@@ -2430,16 +2543,38 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
       }
       pass |= (mn <= F.thr_pre) ? (1u << a) : 0u;
     }
-    if (pass && may_vote)
-      k2_vote_root_exact(F, ii & 0xFFFFFFu, (unsigned)packed & 0xFFFFFFu, pass, k, [&](const int jj, double& bu, double& bv) {
-        bu = F.q[(2 * jj) * F.nthr + F.tid];
-        bv = F.q[(2 * jj + 1) * F.nthr + F.tid];
-      });
+    if constexpr (k2_defers(SCAN, NP)) {
+      // the wave's queue: slots by ballot (its fill count is wave-uniform); room for every lane is guaranteed by the
+      // flush at the end of an item
+      const bool want = pass != 0u && may_vote;
+      const u64 bal = __ballot(want);
+      if (bal != 0) {
+        const unsigned slot = (unsigned)vq_count + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        vq_count += (int)__builtin_popcountll(bal);
+        if (want) {
+          u64* q = F.vq + (size_t)slot * K2_DQ_WORDS;
+          q[0] = (u64)__double_as_longlong(rt);
+          q[1] = (u64)((unsigned)ti | ((unsigned)pj << 8) | ((unsigned)k << 20)) | ((u64)pass << 32);
+        }
+      }
+    } else {
+      if (pass && may_vote)
+        k2_vote_root_exact(F, ii & 0xFFFFFFu, (unsigned)packed & 0xFFFFFFu, pass, k, [&](const int jj, double& bu, double& bv) {
+          bu = F.q[(2 * jj) * F.nthr + F.tid];
+          bv = F.q[(2 * jj + 1) * F.nthr + F.tid];
+        });
+    }
   }
   rider.consume();  // P6: nothing of the scan is in flight while the next item fetches its table values
   if constexpr (SCAN) {
     if (vq_count >= K2_VQ_CAP - 4) {  // wave-uniform
       k2_vote_flush(F, vq_count);
+      vq_count = 0;
+    }
+  }
+  if constexpr (k2_defers(SCAN, NP)) {
+    if (vq_count > K2_DQ_CAP - 256) {  // (wave-uniform) the next item may append 4 x 64 entries
+      k2_defer_flush(F, vq_count);
       vq_count = 0;
     }
   }
@@ -2515,9 +2650,12 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
   const int n_combos = n_d * (n_d - 1) * (n_d - 2) / 6;
   const int n_perms = n_m * (n_m - 1) * (n_m - 2);
   const int nuo = n_m - 3;
-  // single-precision copies of the back-projections behind the double ones: [j][tid] (plain variant)
-  f32x2* s_qf = reinterpret_cast<f32x2*>(s_q + (size_t)2 * nuo * nthr);
-  const float thr_pre = k2_prefilter_threshold(sp.back_tol);
+  // single-precision copies of the back-projections behind the double ones: [j][tid] (plain variant).  Deferred plain
+  // variant: no columns at all — the waves' queues take their place, the table slice follows them
+  constexpr bool DEFER = k2_defers(SCAN, NP);
+  f32x2* s_qf = DEFER ? reinterpret_cast<f32x2*>(smem + (size_t)(nthr >> 6) * K2_DQ_CAP * K2_DQ_WORDS * sizeof(u64))
+                      : reinterpret_cast<f32x2*>(s_q + (size_t)2 * nuo * nthr);
+  const float thr_pre = k2_prefilter_threshold(sp.back_tol, DEFER ? 0.25 : 0.05);
   const int esz = k2_entry_doubles(n_m);
   const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
   // block row with P1 <-> P2 exchanged: {2, 5, 0, 4, 3, 1}, packed 4 bits per row as 0x134052
@@ -2528,6 +2666,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
   //   [0] p_1 [1] p_2 [2] d_12 [3] valid [4] packed marker indices [5..10] eta-frame unused markers (<= 2)
   double* s_tab = nullptr;
   u64* s_vq = nullptr;  // per-wave queue of deferred exact votes, behind the table copy
+  if constexpr (DEFER) s_vq = reinterpret_cast<u64*>(smem) + (size_t)(tid >> 6) * (K2_DQ_CAP * K2_DQ_WORDS);
   if constexpr (SCAN) {
     s_tab = reinterpret_cast<double*>(smem + (size_t)(blockDim.x >> 6) * (K2_SCAN_R * 1024));
     s_vq = reinterpret_cast<u64*>(s_tab + (size_t)n_perms * K2_LTAB) + (size_t)(tid >> 6) * (K2_VQ_CAP * K2_VQ_WORDS);
@@ -2587,27 +2726,38 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
     // a valid item — past the end, collinear marker triple, non-finite root — compute on harmlessly and are
     // merely barred from voting (`live`).  Without a rider those lanes skip ahead as before.
     const int n_iter = (total - part_loc * nthr + stride - 1) / stride;
-    for (int it = 0; SCAN ? (it < n_iter) : (t < total); ++it, t += stride, ti += dti, pj += dpj) {
+    constexpr bool UNI = SCAN || k2_defers(SCAN, NP);  // (see k2_vote_item)
+    for (int it = 0; UNI ? (it < n_iter) : (t < total); ++it, t += stride, ti += dti, pj += dpj) {
       if (pj >= n_perms_loc) {
         pj -= n_perms_loc;
         ++ti;
       }
       bool live = true;
       const int ti_keep = ti, pj_keep = pj;
-      if constexpr (RANGE) {
-        const int g = (tc0 + ti) * n_perms + p_lo + pj;
-        if (g < item_range[2 * f] || g >= item_range[2 * f + 1]) continue;
-      }
-      if constexpr (SCAN) {
+      if constexpr (UNI) {
         if (t >= total) {
           live = false;
           ti = 0;
           pj = 0;
         }
       }
+      if constexpr (RANGE) {
+        const int g = (tc0 + ti) * n_perms + p_lo + pj;
+        if (g < item_range[2 * f] || g >= item_range[2 * f + 1]) {
+          if constexpr (UNI) {
+            live = false;
+          } else {
+            continue;
+          }
+        }
+      }
       k2_vote_item<SCAN, NP>(F, ti, p_lo + pj, live, rider, vq_count);
       ti = ti_keep;
       pj = pj_keep;
+    }
+    if constexpr (k2_defers(SCAN, NP)) {  // (the staged triples the queue's entries refer to are about to be replaced)
+      k2_defer_flush(F, vq_count);
+      vq_count = 0;
     }
     if constexpr (!SCAN) k2_sus_flush(F, &s_sus_base);  // (the scan-carrying variant: once, behind the rider's last round)
   }
@@ -2867,11 +3017,14 @@ hipError_t launch_k2_vote(mpe_detections* dets, int n_frames, const SolveParams&
     // (up to 8 unused markers), else in LDS columns; the forensics instantiation (item_range) the same way
     const int np = nuo <= 8 ? (nuo + 1) / 2 : 0;
     const dim3 grid((unsigned)(n_frames * splits)), block(threads);
+    const bool defer = k2_defers(false, np);
+    if (defer)  // no back-projection columns: the waves' queues of deferred (hypothesis, root) entries instead
+      lds = (size_t)(threads / 64) * K2_DQ_CAP * K2_DQ_WORDS * sizeof(u64);
     // the table slice of a block lives where the (unused, NP > 0) single-precision columns would: make it fit
     if (slice_tab && np > 0) {
       const size_t slice = (size_t)6 * ((size_t)sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2) / 6 / splits + 1) *
                            (k2_entry_doubles(sp.n_markers) - 12) * sizeof(double);
-      const size_t have = (size_t)nuo * threads * sizeof(f32x2);
+      const size_t have = defer ? 0 : (size_t)nuo * threads * sizeof(f32x2);
       if (slice > have) lds += slice - have;
     } else {
       slice_tab = 0;

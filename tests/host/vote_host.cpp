@@ -91,7 +91,7 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   std::memset(hist, 0, sizeof(unsigned) * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS);
   std::vector<double> ltab((size_t)n_perms * K2_LTAB);
   for (size_t i = 0; i < ltab.size(); ++i) ltab[i] = k2_ltab_value(tab.data(), esz, nuo, (int)i);
-  std::vector<u64> vq((size_t)K2_VQ_CAP * K2_VQ_WORDS, 0);
+  std::vector<u64> vq((size_t)std::max(K2_VQ_CAP * K2_VQ_WORDS, K2_DQ_CAP * K2_DQ_WORDS), 0);
   // variants 10 / 11: as 0 / 1 with the suspect list in place, worked off by k2_strict_item afterwards (what
   // k2_vote_fixup does on the device); variant 20: every hypothesis through k2_strict_item (= k2_vote_strict)
   // variants 30 / 31: the same with a block list of four entries — nearly every append goes straight to the launch's
@@ -127,7 +127,8 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   const K2SusDesc susd = {sus_ctl, sus_list.data(), sus_cap, &frame_status};
   const K2Frame F = {trii.data(), reinterpret_cast<const double(*)[13]>(tri.data()), px, pxf, q.data(), qf.data(),
                      hist, tab.data(), ltab.data(), n_d, nuo, 1, 0, esz, sp.fx, sp.fy, sp.cx, sp.cy, sp.back_tol,
-                     k2_prefilter_threshold(sp.back_tol), vq.data(), 1, 0, &susd, fixup, 0,
+                     k2_prefilter_threshold(sp.back_tol, (variant == 0 && k2_defers(false, nuo <= 8 ? (nuo + 1) / 2 : 0)) ? 0.25 : 0.05),
+                     vq.data(), 1, 0, &susd, fixup, 0,
                      sus_lds.data(), &sus_lds_n, lds_cap};
   struct Fix {
     const K2Frame& F;
@@ -170,9 +171,17 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
       for (int pj = 0; pj < n_perms; ++pj) k2_vote_item<true>(F, ti, pj, true, rider, vq_count);
     k2_vote_flush(F, vq_count);
   } else {
-    int unused = 0;
+    int unused = 0;  // (np >= 2: the fill count of the deferred-evaluation queue)
     // the instantiation the launcher would pick: (nuo + 1) / 2 marker pairs in registers up to 8 unused markers
     const int np = nuo <= 8 ? (nuo + 1) / 2 : 0;
+    struct FlushAtExit {  // what is left in the deferred queue (np >= 2), before the suspect list is worked off
+      const K2Frame& F;
+      int& count;
+      bool on;
+      ~FlushAtExit() {
+        if (on) k2_defer_flush(F, count);
+      }
+    } flush_at_exit = {F, unused, variant != 2 && k2_defers(false, np)};
     for (int ti = 0; ti < n_combos; ++ti)
       for (int pj = 0; pj < n_perms; ++pj) {
         switch (variant == 2 ? 0 : np) {   // variant 2: force the LDS-column prefilter
