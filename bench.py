@@ -131,6 +131,9 @@ def main():
                     help="one joined mpe_estimate_batch_device call per step instead of the submit / collect stream of batches")
     ap.add_argument("--no-records-to-host", dest="records_to_host", action="store_false",
                     help="leave the pose records on the device (no D2H copy inside the step)")
+    ap.add_argument("--back-tol", type=float, default=None,
+                    help="back_projection_pixel_tolerance (default: demo.launch's 5).  At C3 the demo value lets few frames "
+                         "initialise (the reference algorithm's own behaviour with 12 detections); 2 gives a pose on most")
     ap.add_argument("--assume-side-streams", action="store_true",
                     help="counter passes: skip the stream-concurrency probe (kernels are serialised under rocprofv3 --pmc, "
                          "the probe would fail and the call fall back to schedule 3) so that the launches have the "
@@ -200,7 +203,7 @@ def main():
     work_stream = torch.cuda.Stream(device=dev)
     if os.environ.get("MPE_BENCH_OWN_STREAM") != "1":
         h.set_stream(work_stream.cuda_stream)
-    P = mpe.demo_params()
+    P = mpe.demo_params() if args.back_tol is None else mpe.demo_params(back_projection_pixel_tolerance=args.back_tol)
     h.set_option("pipeline", args.pipeline)
     h.set_option("pipeline_mode", args.pipeline_mode)
     h.set_option("vote_arith", args.vote_arith)
@@ -415,6 +418,8 @@ def main():
         # the counter passes were taken from a build of THESE kernel sources? (fingerprint of csrc/*.hip, *.h)
         pmc_matches_binary = pmc_all.get("source_fingerprint") == mpe.source_fingerprint()
         pmc = pmc_all["k2_vote_scan" if fused else "k1a_scan"]
+        if fused and args.config in pmc_all.get("by_config", {}):  # counter passes of this resolution's fused launches
+            pmc = pmc_all["by_config"][args.config]["k2_vote_scan"]
         if pmc.get("rows") == rows and pmc.get("cols") == cols:
             # (scaled to the frames' worth of pixels this launch scans: bytes_per_launch / (rows * cols))
             traffic = pmc["hbm_bytes_per_frame"] * (bytes_per_launch / float(rows * cols))
@@ -536,8 +541,10 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %dx%d synthetic frames, %d LEDs, %d distractors, brute-force P3P init every "
-                                   "frame, demo.launch parameters" % (args.config, cols, rows, len(markers),
-                                                                      cfg["n_distractors"]),
+                                   "frame, demo.launch parameters%s" % (args.config, cols, rows, len(markers),
+                                                                        cfg["n_distractors"],
+                                                                        "" if args.back_tol is None else
+                                                                        " except back_projection_pixel_tolerance = %g" % args.back_tol),
                        "frames_per_gpu_per_step": B, "frames_resident_in_hbm": True,
                        "streams_per_gpu": args.pipeline,
                        "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel", 4: "fused + validate/refine on a side stream",
@@ -607,11 +614,12 @@ def main():
             sample = frames[:ns].cpu().numpy()
             cores = effective_cores()
             t1 = time.perf_counter()
-            ref = oracle.estimate_batch(sample, markers, K, D, oracle.make_params(), n_threads=cores)
+            op = oracle.make_params() if args.back_tol is None else oracle.make_params(back_projection_pixel_tolerance=args.back_tol)
+            ref = oracle.estimate_batch(sample, markers, K, D, op, n_threads=cores)
             cpu_dt = time.perf_counter() - t1
             n1 = min(512, ns)
             t2 = time.perf_counter()
-            oracle.estimate_batch(sample[:n1], markers, K, D, oracle.make_params(), n_threads=1)
+            oracle.estimate_batch(sample[:n1], markers, K, D, op, n_threads=1)
             cpu1_dt = time.perf_counter() - t2
             out["cpu_baseline"] = {"value": ns / cpu_dt, "unit": "frames/s", "cores": cores, "kind": "port",
                                    "sample": "%d frames of the same batch, frame-parallel std::thread over %d host "
@@ -631,8 +639,8 @@ def main():
             dall[ok] = dpos
             verdicts = []
             for i in np.nonzero((ref["status"] != got["status"]) | (dall > 1e-4))[0]:
-                und, _ = oracle.find_leds(sample[i], oracle.make_params(), K, D)
-                v = forensics.classify_end_to_end(h, oracle, und, markers, K, P, oracle.make_params())
+                und, _ = oracle.find_leds(sample[i], op, K, D)
+                v = forensics.classify_end_to_end(h, oracle, und, markers, K, P, op)
                 verdicts.append({"frame": int(i), "hip_status": int(got["status"][i]), "oracle_status": int(ref["status"][i]),
                                  "dpos_m": float(dall[i]), "stage": v.get("stage"), "unstable": bool(v["unstable"]),
                                  "min_cancellation": v.get("min_w"), "oracle_flips_under_1ulp": v.get("oracle_flips_under_1ulp")})

@@ -1945,6 +1945,10 @@ struct K2Frame {
   u64* sus_lds;       // the block's list
   unsigned* sus_lds_n;
   unsigned sus_lds_cap;
+  // deferred plain variant: occupancy grid of the frame's detections, dilated by the prefilter radius (K2_GRID x K2_GRID
+  // bits over their bounding box; cell (ix, iy) of a point (u, v): ix = (int)(u * ginv + gxo), iy likewise)
+  const u64* grid;
+  float ginv, gxo, gyo;
 };
 
 // i-th double of the LDS copy of the marker-permutation table (scan-carrying variant), K2_LTAB per permutation:
@@ -2228,22 +2232,70 @@ __device__ __forceinline__ void k2_project_marker(const K2Sub& S, const double* 
 // The queue is worked off with ONE ENTRY PER LANE: back-substitution and back-projections again, in double
 // precision (k2_back_substitute / k2_project_marker: the same operations as the direct path), the exact search, the
 // band screen and the votes (k2_vote_root_exact).
-#define K2_DQ_CAP 320   // entries per wave: a flush threshold of 64 + the 4 x 64 one item can append
+#define K2_DQ_CAP 128   // entries per wave (flushed above 64 at the end of an item; an entry that finds no room goes
+                        // to the strict arithmetic's list instead)
 #define K2_DQ_WORDS 2
+#define K2_GRID 256     // occupancy grid: K2_GRID x K2_GRID bits (8 KB of LDS per block)
+#define K2_GRID_WORDS (K2_GRID / 64)
 __device__ __forceinline__ float k2_rcpf(float x) { return p3p_rcpf(x); }
 __host__ __device__ constexpr bool k2_defers(bool scan, int np) { return !scan && np >= 2; }
+// is the cell of (u, v) within the prefilter radius of a detection?  (NaN / far points: no, or a harmless yes)
+__device__ __forceinline__ bool k2_grid_hit(const K2Frame& F, float fu, float fv) {
+  const int ix = (int)fu, iy = (int)fv;
+  const bool ok = (unsigned)(ix | iy) < (unsigned)K2_GRID;
+  const u64 word = F.grid[(iy & (K2_GRID - 1)) * K2_GRID_WORDS + ((ix >> 6) & (K2_GRID_WORDS - 1))];
+  return ok && ((word >> (ix & 63)) & 1ull);
+}
+// the block's grid: cells within R (infinity norm, one cell of slack) of a detection are set.  All threads; the grid
+// must be zero and the parameters are returned through gp = {ginv, gxo, gyo}.
+__device__ __forceinline__ void k2_grid_build(const double (*px)[2], int n_d, double back_tol, u64* grid, float* gp, int tid,
+                                              int nthr) {
+  const float R = (float)(back_tol * (1.0 + 1e-4) + 0.25);
+  float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+  for (int a = 0; a < n_d; ++a) {  // (every thread: n_d <= 32 LDS reads, once per block)
+    const float u = (float)px[a][0], v = (float)px[a][1];
+    x0 = fminf(x0, u);
+    x1 = fmaxf(x1, u);
+    y0 = fminf(y0, v);
+    y1 = fmaxf(y1, v);
+  }
+  const float span = fmaxf(x1 - x0, y1 - y0) + 2.0f * R;
+  const float cell = fmaxf(span * (1.0f / (K2_GRID - 4)), 0.25f);
+  const float inv = 1.0f / cell;
+  const float ox = -(x0 - R - 2.0f * cell) * inv, oy = -(y0 - R - 2.0f * cell) * inv;
+  if (tid == 0) {
+    gp[0] = inv;
+    gp[1] = ox;
+    gp[2] = oy;
+  }
+  for (int a = tid; a < n_d; a += nthr) {
+    const float u = (float)px[a][0], v = (float)px[a][1];
+    if (!(u == u && v == v)) continue;
+    const int ix0 = max(0, (int)((u - R) * inv + ox) - 1), ix1 = min(K2_GRID - 1, (int)((u + R) * inv + ox) + 1);
+    const int iy0 = max(0, (int)((v - R) * inv + oy) - 1), iy1 = min(K2_GRID - 1, (int)((v + R) * inv + oy) + 1);
+    for (int iy = iy0; iy <= iy1; ++iy)
+      for (int w = ix0 >> 6; w <= (ix1 >> 6); ++w) {
+        const int lo = max(ix0, 64 * w) - 64 * w, hi = min(ix1, 64 * w + 63) - 64 * w;
+        const u64 m = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1)) & ~((1ull << lo) - 1);
+        atomicOr(&grid[iy * K2_GRID_WORDS + w], m);
+      }
+  }
+}
 // works the wave's queue off, one entry per lane: everything the voting loop knew about the root is rebuilt from the
-// staged triple ti, the permutation pj and the root's value
+// staged triple ti, the permutation pj and the root's value — back-substitution, double-precision back-projections,
+// the single-precision prefilter over the unused detections, the exact search, band screen and votes
+template <int NP>
 __device__ __forceinline__ void k2_defer_flush(const K2Frame& F, int count) {
   wave_sync();
-  const unsigned n = (unsigned)count;
+  const unsigned n = min((unsigned)count, (unsigned)K2_DQ_CAP);
   const unsigned lane = (unsigned)F.tid & 63u;
   for (unsigned i = lane; i < n; i += (unsigned)F.vq_lanes) {
     const u64* q = F.vq + (size_t)i * K2_DQ_WORDS;
     const double rt = __longlong_as_double((long long)q[0]);
-    const unsigned meta = (unsigned)q[1], pass = (unsigned)(q[1] >> 32);
+    const unsigned meta = (unsigned)q[1];
     const int ti = meta & 0xFF, pj = (meta >> 8) & 0xFFF, k = (meta >> 20) & 3;
     const unsigned ii = F.trii[ti];
+    const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
     const bool swap = (ii >> 24) & 1;
     const int packed = (int)F.tab[(size_t)(pj - F.pj_base) * F.esz + 16];
     const int r6 = pj % 6;
@@ -2254,9 +2306,44 @@ __device__ __forceinline__ void k2_defer_flush(const K2Frame& F, int count) {
     const double b = tr[11], f12 = tr[12];
     const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
     const K2Sub S = k2_back_substitute(rt, g1, g2, g3, p_2, d_12, b);
-    k2_vote_root_exact(F, ii & 0xFFFFFFu, (unsigned)packed & 0xFFFFFFu, pass, k, [&](const int jj, double& bu, double& bv) {
-      k2_project_marker(S, e + 18 + 3 * jj, tr, bu, bv);
-    });
+    f32x2 pfu[NP], pfv[NP];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+      pfu[pp] = pfv[pp] = f32x2{INFINITY, INFINITY};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int j = 2 * pp + h;
+        if (j < F.nuo) {
+          double qu, qv;
+          k2_project_marker(S, e + 18 + 3 * j, tr, qu, qv);
+          if (h == 0) {
+            pfu[pp].x = (float)qu;
+            pfv[pp].x = (float)qv;
+          } else {
+            pfu[pp].y = (float)qu;
+            pfv[pp].y = (float)qv;
+          }
+        }
+      }
+    }
+    const unsigned unused = (0xFFFFFFFFu >> (32 - F.n_d)) & ~((1u << c0) | (1u << c1) | (1u << c2));
+    unsigned pass = 0;
+    for (unsigned m = unused; m; m &= m - 1) {
+      const int a = __builtin_ctz(m);
+      const f32x2 af = F.pxf[a];
+      float mn = INFINITY;
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        const f32x2 du = f32x2{af.x, af.x} - pfu[pp], dv = f32x2{af.y, af.y} - pfv[pp];
+        const f32x2 d2 = k2_pk_fma(dv, dv, du * du);
+        mn = k2_fminf(mn, k2_fminf(d2.x, d2.y));  // (a NaN distance never wins, as in the exact search)
+      }
+      pass |= (mn <= F.thr_pre) ? (1u << a) : 0u;
+    }
+    if (pass)
+      k2_vote_root_exact(F, ii & 0xFFFFFFu, (unsigned)packed & 0xFFFFFFu, pass, k, [&](const int jj, double& bu, double& bv) {
+        k2_project_marker(S, e + 18 + 3 * jj, tr, bu, bv);
+      });
   }
   wave_sync();
 }
@@ -2517,47 +2604,58 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
       }
       continue;
     }
-    // the detections that are not part of the triple, ascending: a uniform trip count for the frame; the ones that get
-    // through the single-precision prefilter are collected and decided together (k2_vote_root_exact)
-    unsigned pass = 0;
-    for (unsigned m = unused; m; m &= m - 1) {
-      const int a = __builtin_ctz(m);
-      const f32x2 af = F.pxf[a];
-      float mn = INFINITY;
-      if constexpr (NP > 0) {  // two markers per packed instruction, the back-projections from registers
-#pragma unroll
-        for (int pp = 0; pp < NP; ++pp) {
-          const f32x2 du = f32x2{af.x, af.x} - pfu[pp], dv = f32x2{af.y, af.y} - pfv[pp];
-          const f32x2 d2 = k2_pk_fma(dv, dv, du * du);
-          mn = k2_fminf(mn, k2_fminf(d2.x, d2.y));  // (a NaN distance never wins, as in the exact search)
-        }
-      } else {  // (both coordinates per instruction, the back-projections from their LDS columns)
-#pragma unroll 4
-        for (int jj = 0; jj < F.nuo; ++jj) {
-          const f32x2 qf = F.qf[jj * F.nthr + F.tid];
-          f32x2 df = af - qf;
-          df = df * df;
-          const float d2f = df.x + df.y;
-          mn = d2f < mn ? d2f : mn;  // (a NaN distance never wins, as in the exact search)
-        }
-      }
-      pass |= (mn <= F.thr_pre) ? (1u << a) : 0u;
-    }
     if constexpr (k2_defers(SCAN, NP)) {
-      // the wave's queue: slots by ballot (its fill count is wave-uniform); room for every lane is guaranteed by the
-      // flush at the end of an item
-      const bool want = pass != 0u && may_vote;
+      // does ANY back-projection of this root fall into a cell near a detection?  (one grid lookup per marker instead of
+      // a distance per detection x marker pair: 45 pairs at C3)  Then the root goes to the wave's queue: slots by
+      // ballot (the fill count is wave-uniform); an entry beyond the queue's end goes to the strict arithmetic's list
+      bool hit = false;
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        const f32x2 fu = k2_pk_fma(pfu[pp], f32x2{F.ginv, F.ginv}, f32x2{F.gxo, F.gxo});
+        const f32x2 fv = k2_pk_fma(pfv[pp], f32x2{F.ginv, F.ginv}, f32x2{F.gyo, F.gyo});
+        hit = hit || k2_grid_hit(F, fu.x, fv.x) || k2_grid_hit(F, fu.y, fv.y);
+      }
+      const bool want = hit && may_vote;
       const u64 bal = __ballot(want);
       if (bal != 0) {
         const unsigned slot = (unsigned)vq_count + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
         vq_count += (int)__builtin_popcountll(bal);
-        if (want) {
+        if (!want) {
+        } else if (slot < (unsigned)K2_DQ_CAP) {
           u64* q = F.vq + (size_t)slot * K2_DQ_WORDS;
           q[0] = (u64)__double_as_longlong(rt);
-          q[1] = (u64)((unsigned)ti | ((unsigned)pj << 8) | ((unsigned)k << 20)) | ((u64)pass << 32);
+          q[1] = (u64)((unsigned)ti | ((unsigned)pj << 8) | ((unsigned)k << 20));
+        } else {
+          k2_sus_push(F, k2_sus_code(c0, c1, c2, p0, p1, p2, 1u << k, false), unused);
         }
       }
     } else {
+      // the detections that are not part of the triple, ascending: a uniform trip count for the frame; the ones that get
+      // through the single-precision prefilter are collected and decided together (k2_vote_root_exact)
+      unsigned pass = 0;
+      for (unsigned m = unused; m; m &= m - 1) {
+        const int a = __builtin_ctz(m);
+        const f32x2 af = F.pxf[a];
+        float mn = INFINITY;
+        if constexpr (NP > 0) {  // two markers per packed instruction, the back-projections from registers
+#pragma unroll
+          for (int pp = 0; pp < NP; ++pp) {
+            const f32x2 du = f32x2{af.x, af.x} - pfu[pp], dv = f32x2{af.y, af.y} - pfv[pp];
+            const f32x2 d2 = k2_pk_fma(dv, dv, du * du);
+            mn = k2_fminf(mn, k2_fminf(d2.x, d2.y));  // (a NaN distance never wins, as in the exact search)
+          }
+        } else {  // (both coordinates per instruction, the back-projections from their LDS columns)
+#pragma unroll 4
+          for (int jj = 0; jj < F.nuo; ++jj) {
+            const f32x2 qf = F.qf[jj * F.nthr + F.tid];
+            f32x2 df = af - qf;
+            df = df * df;
+            const float d2f = df.x + df.y;
+            mn = d2f < mn ? d2f : mn;  // (a NaN distance never wins, as in the exact search)
+          }
+        }
+        pass |= (mn <= F.thr_pre) ? (1u << a) : 0u;
+      }
       if (pass && may_vote)
         k2_vote_root_exact(F, ii & 0xFFFFFFu, (unsigned)packed & 0xFFFFFFu, pass, k, [&](const int jj, double& bu, double& bv) {
           bu = F.q[(2 * jj) * F.nthr + F.tid];
@@ -2573,8 +2671,8 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     }
   }
   if constexpr (k2_defers(SCAN, NP)) {
-    if (vq_count > K2_DQ_CAP - 256) {  // (wave-uniform) the next item may append 4 x 64 entries
-      k2_defer_flush(F, vq_count);
+    if (vq_count > K2_DQ_CAP / 2) {  // (wave-uniform)
+      k2_defer_flush<NP>(F, vq_count);
       vq_count = 0;
     }
   }
@@ -2653,8 +2751,17 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
   // single-precision copies of the back-projections behind the double ones: [j][tid] (plain variant).  Deferred plain
   // variant: no columns at all — the waves' queues take their place, the table slice follows them
   constexpr bool DEFER = k2_defers(SCAN, NP);
-  f32x2* s_qf = DEFER ? reinterpret_cast<f32x2*>(smem + (size_t)(nthr >> 6) * K2_DQ_CAP * K2_DQ_WORDS * sizeof(u64))
+  // (deferred variant: [waves' queues][occupancy grid][table slice])
+  u64* s_grid = reinterpret_cast<u64*>(smem + (size_t)(nthr >> 6) * K2_DQ_CAP * K2_DQ_WORDS * sizeof(u64));
+  f32x2* s_qf = DEFER ? reinterpret_cast<f32x2*>(s_grid + K2_GRID * K2_GRID_WORDS)
                       : reinterpret_cast<f32x2*>(s_q + (size_t)2 * nuo * nthr);
+  __shared__ float s_gp[4];
+  if constexpr (DEFER) {
+    for (int i = tid; i < K2_GRID * K2_GRID_WORDS; i += nthr) s_grid[i] = 0;
+    __syncthreads();
+    k2_grid_build(s_px, n_d, sp.back_tol, s_grid, s_gp, tid, nthr);
+    __syncthreads();
+  }
   const float thr_pre = k2_prefilter_threshold(sp.back_tol, DEFER ? 0.25 : 0.05);
   const int esz = k2_entry_doubles(n_m);
   const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
@@ -2704,7 +2811,8 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
   }
   const K2Frame F = {s_trii, s_tri, s_px, s_pxf, s_q,  s_qf, s_hist, tab_eff,     s_tab,   n_d,  nuo,
                      nthr,   tid,   esz_eff, fx, fy,   cx,   cy,     sp.back_tol, thr_pre, s_vq, 64, p_lo,
-                     &s_susd, fixup.screen != 0u, f, s_sus, &s_sus_n, (unsigned)SUSN};
+                     &s_susd, fixup.screen != 0u, f, s_sus, &s_sus_n, (unsigned)SUSN,
+                     s_grid, s_gp[0], s_gp[1], s_gp[2]};
   int vq_count = 0;  // entries in this wave's queue (wave-uniform)
   for (int tc0 = 0; tc0 < n_combos; tc0 += TRI) {
     const int ntri = min(TRI, n_combos - tc0);
@@ -2756,7 +2864,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
       pj = pj_keep;
     }
     if constexpr (k2_defers(SCAN, NP)) {  // (the staged triples the queue's entries refer to are about to be replaced)
-      k2_defer_flush(F, vq_count);
+      k2_defer_flush<NP>(F, vq_count);
       vq_count = 0;
     }
     if constexpr (!SCAN) k2_sus_flush(F, &s_sus_base);  // (the scan-carrying variant: once, behind the rider's last round)
@@ -3018,8 +3126,8 @@ hipError_t launch_k2_vote(mpe_detections* dets, int n_frames, const SolveParams&
     const int np = nuo <= 8 ? (nuo + 1) / 2 : 0;
     const dim3 grid((unsigned)(n_frames * splits)), block(threads);
     const bool defer = k2_defers(false, np);
-    if (defer)  // no back-projection columns: the waves' queues of deferred (hypothesis, root) entries instead
-      lds = (size_t)(threads / 64) * K2_DQ_CAP * K2_DQ_WORDS * sizeof(u64);
+    if (defer)  // no back-projection columns: the waves' queues of deferred (hypothesis, root) entries + the grid
+      lds = (size_t)(threads / 64) * K2_DQ_CAP * K2_DQ_WORDS * sizeof(u64) + (size_t)K2_GRID * K2_GRID_WORDS * sizeof(u64);
     // the table slice of a block lives where the (unused, NP > 0) single-precision columns would: make it fit
     if (slice_tab && np > 0) {
       const size_t slice = (size_t)6 * ((size_t)sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2) / 6 / splits + 1) *

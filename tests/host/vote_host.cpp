@@ -26,6 +26,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
   return o;
 }
 typedef unsigned long long u64;
+static inline void atomicOr(u64* p, u64 v) { *p |= v; }
 static inline void wave_sync() {}
 static inline void __syncthreads() {}
 static inline double __longlong_as_double(long long v) {
@@ -123,13 +124,16 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   const unsigned lds_cap = tiny_list ? 4u : 1u << 16;
   std::vector<u64> sus_list((size_t)K2_SUS_WORDS * (sus_cap + 1), 0), sus_lds((size_t)K2_SUS_WORDS * lds_cap, 0);
   unsigned sus_ctl[4] = {0, 0, 0, 0}, sus_lds_n = 0;
+  std::vector<u64> grid((size_t)K2_GRID * K2_GRID_WORDS, 0);  // occupancy grid of the deferred plain variant
+  float gp[4] = {0, 0, 0, 0};
+  k2_grid_build(px, n_d, sp.back_tol, grid.data(), gp, 0, 1);
   int frame_status = 0;
   const K2SusDesc susd = {sus_ctl, sus_list.data(), sus_cap, &frame_status};
   const K2Frame F = {trii.data(), reinterpret_cast<const double(*)[13]>(tri.data()), px, pxf, q.data(), qf.data(),
                      hist, tab.data(), ltab.data(), n_d, nuo, 1, 0, esz, sp.fx, sp.fy, sp.cx, sp.cy, sp.back_tol,
                      k2_prefilter_threshold(sp.back_tol, (variant == 0 && k2_defers(false, nuo <= 8 ? (nuo + 1) / 2 : 0)) ? 0.25 : 0.05),
                      vq.data(), 1, 0, &susd, fixup, 0,
-                     sus_lds.data(), &sus_lds_n, lds_cap};
+                     sus_lds.data(), &sus_lds_n, lds_cap, grid.data(), gp[0], gp[1], gp[2]};
   struct Fix {
     const K2Frame& F;
     const SolveParams& sp;
@@ -178,10 +182,16 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
       const K2Frame& F;
       int& count;
       bool on;
+      int np;
       ~FlushAtExit() {
-        if (on) k2_defer_flush(F, count);
+        if (!on) return;
+        switch (np) {
+          case 2: k2_defer_flush<2>(F, count); break;
+          case 3: k2_defer_flush<3>(F, count); break;
+          default: k2_defer_flush<4>(F, count); break;
+        }
       }
-    } flush_at_exit = {F, unused, variant != 2 && k2_defers(false, np)};
+    } flush_at_exit = {F, unused, variant != 2 && k2_defers(false, np), np};
     for (int ti = 0; ti < n_combos; ++ti)
       for (int pj = 0; pj < n_perms; ++pj) {
         switch (variant == 2 ? 0 : np) {   // variant 2: force the LDS-column prefilter
