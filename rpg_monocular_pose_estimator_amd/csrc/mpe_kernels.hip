@@ -1663,8 +1663,10 @@ __device__ __forceinline__ double pick_root(const P3PCtx& c, int k) {
 // points only (p3p.cpp:124-141): the eta frame N, P1, p_1, p_2, d_12, the collinearity verdict,
 // and the unused markers expressed in the eta frame, N (m - P1), ascending marker index.
 //   [0..8] N rows, [9..11] P1, [12] p_1, [13] p_2, [14] d_12, [15] valid (1/0),
-//   [16] p0 | p1 << 8 | p2 << 16 (as a double), [17] pad, [18 + 3u ..] m_eta[u]
-__host__ __device__ inline int k2_entry_doubles(int n_m) { return 18 + 3 * (n_m - 3); }
+//   [16] p0 | p1 << 8 | p2 << 16 (as a double), [17] pad, [18 + 3u ..] m_eta[u],
+//   behind them the same markers in single precision, 3 floats each (two per double; the plain variant's prefilter)
+__host__ __device__ inline int k2_entry_f32_at(int n_m) { return 18 + 3 * (n_m - 3); }  // (in doubles)
+__host__ __device__ inline int k2_entry_doubles(int n_m) { return k2_entry_f32_at(n_m) + (3 * (n_m - 3) + 1) / 2; }
 
 __device__ __forceinline__ void perm_from_index(int pj, int n_m, int& p0, int& p1, int& p2) {
   int ma, mb, mc;
@@ -1715,6 +1717,9 @@ __device__ __forceinline__ void k2_marker_entry(const SolveParams& sp, int pj, d
     e[18 + 3 * u + 2] = me.z;
     ++u;
   }
+  float* ef = reinterpret_cast<float*>(e + k2_entry_f32_at(n_m));
+  for (int i = 0; i < 3 * u; ++i) ef[i] = (float)e[18 + i];
+  if (u & 1) ef[3 * u] = 0.f;
 }
 
 __global__ void k2_prep_markers(SolveParams sp, double* __restrict__ tab) {
@@ -1857,6 +1862,11 @@ struct ScanRider {
 __device__ __forceinline__ bool k2_isfinite(double x) { return __builtin_isfinite(x); }
 __device__ __forceinline__ f32x2 k2_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ float k2_fminf(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ unsigned k2_cvt_pk_u8(float x, unsigned byte, unsigned into) {  // v_cvt_pk_u8_f32
+  return __builtin_amdgcn_cvt_pk_u8_f32(x, byte, into);
+}
+__device__ __forceinline__ float k2_rsqf(float x) { return __builtin_amdgcn_rsqf(x); }    // v_rsq_f32 (1 ulp)
+__device__ __forceinline__ float k2_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32 (1 ulp)
 struct NoRider {
   __device__ __forceinline__ void consume() {}
   __device__ __forceinline__ void issue() {}
@@ -1949,6 +1959,7 @@ struct K2Frame {
   // bits over their bounding box; cell (ix, iy) of a point (u, v): ix = (int)(u * ginv + gxo), iy likewise)
   const u64* grid;
   float ginv, gxo, gyo;
+  const float (*trif)[12];  // per staged triple, single precision: the rows of G K T^T (k2_triple_f32), b
 };
 
 // i-th double of the LDS copy of the marker-permutation table (scan-carrying variant), K2_LTAB per permutation:
@@ -2219,6 +2230,26 @@ __device__ __forceinline__ void k2_project_marker(const K2Sub& S, const double* 
   qv = V * iZ;
 }
 
+// the same back-substitution in single precision from (cn, cd, |(cn, cd)|^2, 1 - root^2) formed in double precision —
+// the two cancellations of the step happen before the conversion — with -C_eta instead of C_eta
+struct K2SubF {
+  float ct, st, ca, sa, ncx, ncy, ncz;
+};
+__device__ __forceinline__ K2SubF k2_back_substitute_f32(float cn, float cd, float h2, float om, float rt, float d_12, float b) {
+  K2SubF S;
+  const float ih = k2_rsqf(h2);
+  S.ct = rt;
+  S.st = k2_sqrtf(om);
+  S.sa = fabsf(cd) * ih;
+  S.ca = (cd < 0 ? -cn : cn) * ih;
+  const float ndk = -d_12 * __builtin_fmaf(S.sa, b, S.ca);
+  const float nsdk = S.sa * ndk;
+  S.ncx = S.ca * ndk;
+  S.ncy = S.ct * nsdk;
+  S.ncz = S.st * nsdk;
+  return S;
+}
+
 // ---- plain variant, 3 .. 8 unused markers: single-precision back-projection + deferred exact evaluation -------------
 // With 5 unused markers and 9 unused detections (C3) a root cost 150 double-precision operations for the
 // back-projections, ten LDS column stores, and — in nearly every wave iteration, with a lane or two alive — the exact
@@ -2232,6 +2263,9 @@ __device__ __forceinline__ void k2_project_marker(const K2Sub& S, const double* 
 // The queue is worked off with ONE ENTRY PER LANE: back-substitution and back-projections again, in double
 // precision (k2_back_substitute / k2_project_marker: the same operations as the direct path), the exact search, the
 // band screen and the votes (k2_vote_root_exact).
+#ifndef K2_ON_GRID_COORD  // (test hook of the host-tier build: the single-precision chain against the double one)
+#define K2_ON_GRID_COORD(...)
+#endif
 #define K2_DQ_CAP 128   // entries per wave (flushed above 64 at the end of an item; an entry that finds no room goes
                         // to the strict arithmetic's list instead)
 #define K2_DQ_WORDS 2
@@ -2239,15 +2273,24 @@ __device__ __forceinline__ void k2_project_marker(const K2Sub& S, const double* 
 #define K2_GRID_WORDS (K2_GRID / 64)
 __device__ __forceinline__ float k2_rcpf(float x) { return p3p_rcpf(x); }
 __host__ __device__ constexpr bool k2_defers(bool scan, int np) { return !scan && np >= 2; }
-// is the cell of (u, v) within the prefilter radius of a detection?  (NaN / far points: no, or a harmless yes)
-__device__ __forceinline__ bool k2_grid_hit(const K2Frame& F, float fu, float fv) {
-  const int ix = (int)fu, iy = (int)fv;
-  const bool ok = (unsigned)(ix | iy) < (unsigned)K2_GRID;
-  const u64 word = F.grid[(iy & (K2_GRID - 1)) * K2_GRID_WORDS + ((ix >> 6) & (K2_GRID_WORDS - 1))];
-  return ok && ((word >> (ix & 63)) & 1ull);
+// cell index iy * K2_GRID + ix of the grid coordinates (fx, fy): v_cvt_pk_u8_f32 converts, SATURATES to 0 .. 255 and
+// packs in one instruction per coordinate (NaN -> 0); row / column 0 and 255 of the grid are never set, so everything
+// outside the grid reads an empty cell
+__device__ __forceinline__ unsigned k2_grid_cell(float fx, float fy) {
+  return k2_cvt_pk_u8(fy, 1u, k2_cvt_pk_u8(fx, 0u, 0u));
 }
-// the block's grid: cells within R (infinity norm, one cell of slack) of a detection are set.  All threads; the grid
-// must be zero and the parameters are returned through gp = {ginv, gxo, gyo}.
+// 1 if the cell of the grid coordinates is within the prefilter radius of a detection
+__device__ __forceinline__ unsigned k2_grid_bit(const K2Frame& F, float fx, float fy) {
+  const unsigned idx = k2_grid_cell(fx, fy);
+  const unsigned word = reinterpret_cast<const unsigned*>(F.grid)[idx >> 5];
+  return (word >> (idx & 31u)) & 1u;
+}
+// the block's grid: cells within R of a detection (infinity norm) are set.  All threads; the grid must be zero; the
+// parameters are returned through gp = {ginv, gxo, gyo}: grid coordinates of a pixel (u, v) = (u ginv + gxo, v ginv +
+// gyo).  A coordinate c lands in cell floor(c) or floor(c) + 1 whatever the conversion's rounding, and the single-
+// precision chain that produces c is off by a small fraction of a pixel (margin in R): [floor(lo) - 1, floor(hi) + 2]
+// are set for a detection's interval [lo, hi]; 250 cells span the detections' bounding box + 2 R, from cell 3 on, so
+// that cells 0 and 255 stay empty.
 __device__ __forceinline__ void k2_grid_build(const double (*px)[2], int n_d, double back_tol, u64* grid, float* gp, int tid,
                                               int nthr) {
   const float R = (float)(back_tol * (1.0 + 1e-4) + 0.25);
@@ -2260,9 +2303,9 @@ __device__ __forceinline__ void k2_grid_build(const double (*px)[2], int n_d, do
     y1 = fmaxf(y1, v);
   }
   const float span = fmaxf(x1 - x0, y1 - y0) + 2.0f * R;
-  const float cell = fmaxf(span * (1.0f / (K2_GRID - 4)), 0.25f);
+  const float cell = fmaxf(span * (1.0f / (K2_GRID - 8)), 0.25f);
   const float inv = 1.0f / cell;
-  const float ox = -(x0 - R - 2.0f * cell) * inv, oy = -(y0 - R - 2.0f * cell) * inv;
+  const float ox = 3.0f - (x0 - R) * inv, oy = 3.0f - (y0 - R) * inv;
   if (tid == 0) {
     gp[0] = inv;
     gp[1] = ox;
@@ -2271,8 +2314,8 @@ __device__ __forceinline__ void k2_grid_build(const double (*px)[2], int n_d, do
   for (int a = tid; a < n_d; a += nthr) {
     const float u = (float)px[a][0], v = (float)px[a][1];
     if (!(u == u && v == v)) continue;
-    const int ix0 = max(0, (int)((u - R) * inv + ox) - 1), ix1 = min(K2_GRID - 1, (int)((u + R) * inv + ox) + 1);
-    const int iy0 = max(0, (int)((v - R) * inv + oy) - 1), iy1 = min(K2_GRID - 1, (int)((v + R) * inv + oy) + 1);
+    const int ix0 = max(1, (int)((u - R) * inv + ox) - 1), ix1 = min(K2_GRID - 2, (int)((u + R) * inv + ox) + 2);
+    const int iy0 = max(1, (int)((v - R) * inv + oy) - 1), iy1 = min(K2_GRID - 2, (int)((v + R) * inv + oy) + 2);
     for (int iy = iy0; iy <= iy1; ++iy)
       for (int w = ix0 >> 6; w <= (ix1 >> 6); ++w) {
         const int lo = max(ix0, 64 * w) - 64 * w, hi = min(ix1, 64 * w + 63) - 64 * w;
@@ -2280,6 +2323,20 @@ __device__ __forceinline__ void k2_grid_build(const double (*px)[2], int n_d, do
         atomicOr(&grid[iy * K2_GRID_WORDS + w], m);
       }
   }
+}
+// per staged triple, single precision: G K T^T with G = [ginv 0 gxo; 0 ginv gyo; 0 0 1] — a point's GRID coordinates are
+// (U / Z, V / Z) of this matrix times the point in the tau frame.  Layout: rows 0 and 1 column-wise as pairs
+// {T00, T10} {T01, T11} {T02, T12} (the operands of the packed instructions), row 2, b
+__device__ __forceinline__ void k2_triple_f32(const double* T, const float* gp, float* o) {
+  const double gi = gp[0], gx = gp[1], gy = gp[2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    o[2 * c] = (float)(gi * T[c] + gx * T[6 + c]);
+    o[2 * c + 1] = (float)(gi * T[3 + c] + gy * T[6 + c]);
+    o[6 + c] = (float)T[6 + c];
+  }
+  o[9] = (float)T[11];
+  o[10] = o[11] = 0.f;
 }
 // works the wave's queue off, one entry per lane: everything the voting loop knew about the root is rebuilt from the
 // staged triple ti, the permutation pj and the root's value — back-substitution, double-precision back-projections,
@@ -2306,6 +2363,9 @@ __device__ __forceinline__ void k2_defer_flush(const K2Frame& F, int count) {
     const double b = tr[11], f12 = tr[12];
     const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
     const K2Sub S = k2_back_substitute(rt, g1, g2, g3, p_2, d_12, b);
+    // isFinite([R C]) (pose_estimator.cpp:653; see the voting loop): the loop's single-precision chain sends whatever
+    // it cannot evaluate here
+    if (!(k2_isfinite(S.Cx) && k2_isfinite(S.Cy) && k2_isfinite(S.Cz))) continue;
     f32x2 pfu[NP], pfv[NP];
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
@@ -2452,14 +2512,29 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     // next scan round: nothing of the voting loop waits on vmcnt (table and triples are in LDS)
     rider.issue();
     const double rt = k == 0 ? root[0] : (k == 1 ? root[1] : (k == 2 ? root[2] : root[3]));
-    const K2Sub S = k2_back_substitute(rt, g1, g2, g3, p_2, d_12, b);  // p3p.cpp:193-213
-    const double om = S.om, h2 = S.h2, cos_alpha = S.cos_alpha, Cx = S.Cx, Cy = S.Cy, Cz = S.Cz;
+    constexpr bool DEFER = k2_defers(SCAN, NP);
+    K2Sub S;    // p3p.cpp:193-213
+    K2SubF Sf;  // (deferred plain variant: single precision behind the two cancellations)
+    double om, h2;
+    float cos_alpha_f;
+    if constexpr (DEFER) {
+      const double cn = g1 - rt * p_2, cd = g2 * rt + g3;
+      h2 = __builtin_fma(cn, cn, cd * cd);
+      om = 1 - rt * rt;
+      Sf = k2_back_substitute_f32((float)cn, (float)cd, (float)h2, (float)om, (float)rt, (float)d_12, F.trif[ti][9]);
+      cos_alpha_f = Sf.ca;
+    } else {
+      S = k2_back_substitute(rt, g1, g2, g3, p_2, d_12, b);
+      om = S.om;
+      h2 = S.h2;
+      cos_alpha_f = (float)S.cos_alpha;
+    }
     // (a), per root — BEFORE the finiteness test: a root within rounding of +-1 is finite in one arithmetic and NaN
     // (|root| > 1: sqrt of a negative number) in the other.  sin(theta) = sqrt(1 - root^2) at its branch point, (cn, cd)
     // cancelled, or cos(alpha) so small that the strict arithmetic's sqrt(1 - sin(alpha)^2) has no digits: this root
     // goes to the list with all unused detections
     const bool root_sus = fix && live && (item_sus || p3p_expo(om) < om_exp || p3p_expo(h2) < hs_exp ||
-                                          fabsf((float)cos_alpha) < K2_SUS_COSA);
+                                          fabsf(cos_alpha_f) < K2_SUS_COSA);
     bool root_listed = false;
     if constexpr (!SCAN) {
       if (root_sus) {
@@ -2472,8 +2547,12 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     }
     // isFinite([R C]) (pose_estimator.cpp:653): a product is finite only if every factor is (0 * inf = NaN), so
     // R (products of the four sines / cosines with the finite frames) and C are finite iff C_eta is
+    // (deferred plain variant: a root outside [-1, 1] or NaN has no pose; whatever else is not finite in single precision
+    //  goes to the queue, whose double-precision evaluation makes this test)
     bool finite_pose = true;
-    if (!(k2_isfinite(Cx) && k2_isfinite(Cy) && k2_isfinite(Cz))) {
+    if constexpr (DEFER) {
+      finite_pose = om >= 0.0;
+    } else if (!(k2_isfinite(S.Cx) && k2_isfinite(S.Cy) && k2_isfinite(S.Cz))) {
       if constexpr (UNI)
         finite_pose = false;
       else
@@ -2520,38 +2599,40 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
         }
       }
     };
-    if constexpr (k2_defers(SCAN, NP)) {
-      // single-precision back-projections, two markers per packed instruction (see K2_DQ_CAP above)
-      const float ct = (float)S.cos_theta, st = (float)S.sin_theta, ca = (float)S.cos_alpha, sa = (float)S.sin_alpha;
-      const float cxf = (float)S.Cx, cyf = (float)S.Cy, czf = (float)S.Cz;
-      float t[9];
+    unsigned grid_hits = 0;  // deferred plain variant: some back-projection falls into a cell near a detection
+    if constexpr (DEFER) {
+      // M = (G K T^T) Rm and -M C_eta once per root (22 instructions), then a marker's grid coordinates are 3 packed + 3
+      // plain multiply-adds, a reciprocal and a packed multiply; its cell one conversion per coordinate, one LDS read and
+      // one bit test (see K2_DQ_CAP above)
+      const float* tf = F.trif[ti];
+      const f32x2 c0 = {tf[0], tf[1]}, c1 = {tf[2], tf[3]}, c2 = {tf[4], tf[5]};
+      const float z0 = tf[6], z1 = tf[7], z2 = tf[8];
+      const float ct = Sf.ct, st = Sf.st, ca = Sf.ca, sa = Sf.sa;
+      const f32x2 M0 = k2_pk_fma(c1, f32x2{sa, sa}, c0 * f32x2{-ca, -ca});
+      const f32x2 A = k2_pk_fma(c0, f32x2{sa, sa}, c1 * f32x2{ca, ca});
+      const f32x2 M1 = k2_pk_fma(A, f32x2{-ct, -ct}, c2 * f32x2{-st, -st});
+      const f32x2 M2 = k2_pk_fma(A, f32x2{-st, -st}, c2 * f32x2{ct, ct});
+      const float Mz0 = __builtin_fmaf(z1, sa, -(z0 * ca));
+      const float Az = __builtin_fmaf(z0, sa, z1 * ca);
+      const float Mz1 = -__builtin_fmaf(ct, Az, st * z2);
+      const float Mz2 = __builtin_fmaf(-st, Az, ct * z2);
+      const f32x2 nd = k2_pk_fma(M0, f32x2{Sf.ncx, Sf.ncx}, k2_pk_fma(M1, f32x2{Sf.ncy, Sf.ncy}, M2 * f32x2{Sf.ncz, Sf.ncz}));
+      const float ndz = __builtin_fmaf(Mz0, Sf.ncx, __builtin_fmaf(Mz1, Sf.ncy, Mz2 * Sf.ncz));
+      const float* mf = reinterpret_cast<const float*>(e + 18 + 3 * F.nuo);  // the markers in single precision
 #pragma unroll
-      for (int i = 0; i < 9; ++i) t[i] = (float)tr[i];
-#pragma unroll
-      for (int pp = 0; pp < NP; ++pp) {
-        if (2 * pp < F.nuo) {  // (nuo is uniform over the block)
-          const double* m0 = e + 18 + 6 * pp;
-          const bool two = 2 * pp + 1 < F.nuo;
-          const double* m1 = two ? m0 + 3 : m0;
-          const f32x2 v0 = f32x2{(float)m0[0], (float)m1[0]} - f32x2{cxf, cxf};
-          const f32x2 v1 = f32x2{(float)m0[1], (float)m1[1]} - f32x2{cyf, cyf};
-          const f32x2 v2 = f32x2{(float)m0[2], (float)m1[2]} - f32x2{czf, czf};
-          const f32x2 g = k2_pk_fma(f32x2{ct, ct}, v1, f32x2{st, st} * v2);
-          const f32x2 w0 = f32x2{0.f, 0.f} - k2_pk_fma(f32x2{ca, ca}, v0, f32x2{sa, sa} * g);
-          const f32x2 w1 = k2_pk_fma(f32x2{sa, sa}, v0, f32x2{0.f, 0.f} - f32x2{ca, ca} * g);
-          const f32x2 w2 = k2_pk_fma(f32x2{ct, ct}, v2, f32x2{0.f, 0.f} - f32x2{st, st} * v1);
-          const f32x2 U = k2_pk_fma(f32x2{t[0], t[0]}, w0, k2_pk_fma(f32x2{t[1], t[1]}, w1, f32x2{t[2], t[2]} * w2));
-          const f32x2 V = k2_pk_fma(f32x2{t[3], t[3]}, w0, k2_pk_fma(f32x2{t[4], t[4]}, w1, f32x2{t[5], t[5]} * w2));
-          const f32x2 Z = k2_pk_fma(f32x2{t[6], t[6]}, w0, k2_pk_fma(f32x2{t[7], t[7]}, w1, f32x2{t[8], t[8]} * w2));
-          const f32x2 iZ = {k2_rcpf(Z.x), k2_rcpf(Z.y)};
-          pfu[pp] = U * iZ;
-          pfv[pp] = V * iZ;
-          if (!two) {
-            pfu[pp].y = INFINITY;
-            pfv[pp].y = INFINITY;
-          }
+      for (int j = 0; j < 2 * NP; ++j) {
+        if (j < F.nuo) {  // (nuo is uniform over the block)
+          const float mx = mf[3 * j], my = mf[3 * j + 1], mz = mf[3 * j + 2];
+          const f32x2 UV = k2_pk_fma(M0, f32x2{mx, mx}, k2_pk_fma(M1, f32x2{my, my}, k2_pk_fma(M2, f32x2{mz, mz}, nd)));
+          const float Z = __builtin_fmaf(Mz0, mx, __builtin_fmaf(Mz1, my, __builtin_fmaf(Mz2, mz, ndz)));
+          const float iZ = k2_rcpf(Z);
+          const f32x2 g = UV * f32x2{iZ, iZ};
+          K2_ON_GRID_COORD(F, rt, g1, g2, g3, p_2, d_12, b, e + 18 + 3 * j, tr, g.x, g.y);
+          grid_hits |= k2_grid_bit(F, g.x, g.y);
         }
       }
+      // anything this chain could not evaluate (overflow, underflow: (cn, cd) of 1e-20) is left to the double-precision one
+      if (!(fabsf(nd.x + nd.y + ndz) < INFINITY)) grid_hits = 1u;
     } else if constexpr (!SCAN && NP > 0) {
 #pragma unroll
       for (int j = 0; j < 2 * NP; ++j)
@@ -2608,13 +2689,7 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
       // does ANY back-projection of this root fall into a cell near a detection?  (one grid lookup per marker instead of
       // a distance per detection x marker pair: 45 pairs at C3)  Then the root goes to the wave's queue: slots by
       // ballot (the fill count is wave-uniform); an entry beyond the queue's end goes to the strict arithmetic's list
-      bool hit = false;
-#pragma unroll
-      for (int pp = 0; pp < NP; ++pp) {
-        const f32x2 fu = k2_pk_fma(pfu[pp], f32x2{F.ginv, F.ginv}, f32x2{F.gxo, F.gxo});
-        const f32x2 fv = k2_pk_fma(pfv[pp], f32x2{F.ginv, F.ginv}, f32x2{F.gyo, F.gyo});
-        hit = hit || k2_grid_hit(F, fu.x, fv.x) || k2_grid_hit(F, fu.y, fv.y);
-      }
+      const bool hit = grid_hits != 0u;
       const bool want = hit && may_vote;
       const u64 bal = __ballot(want);
       if (bal != 0) {
@@ -2687,10 +2762,10 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
 // which is the same point as project2d(m, inverse(H)) of pose_estimator.cpp:660 up to rounding.
 // Four waves per SIMD (<= 128 VGPRs) is what the voting kernels run at; with the suspect screening the allocator wants
 // 130 - 138, and asked for four waves it keeps a handful of loop-invariant values (table pointers, parameters) in
-// scratch OUTSIDE the item loop instead (checked in the ISA: every scratch access sits at loop depth <= 1).  The
-// instantiation with four packed marker pairs (10 - 11 markers) never fitted and stays at three.
+// scratch OUTSIDE the item loop instead (checked in the ISA: every scratch access sits at loop depth <= 1; the plain
+// instantiations, whose per-root part is single precision since round 4, need 113 - 120 and no scratch).
 #ifndef K2_MIN_WAVES
-#define K2_MIN_WAVES(NP) ((NP) == 4 ? 3 : 4)
+#define K2_MIN_WAVES(NP) 4
 #endif
 // RANGE (forensics only, mpe_vote_items): frame f votes with the hypotheses whose flattened index — detection triple
 // x P(n_m,3) + marker permutation, the reference's loop order — lies in [item_range[2f], item_range[2f+1]); the
@@ -2756,6 +2831,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
   f32x2* s_qf = DEFER ? reinterpret_cast<f32x2*>(s_grid + K2_GRID * K2_GRID_WORDS)
                       : reinterpret_cast<f32x2*>(s_q + (size_t)2 * nuo * nthr);
   __shared__ float s_gp[4];
+  __shared__ float s_trif[DEFER ? TRI : 1][12];  // (deferred variant) k2_triple_f32 of the staged triples
   if constexpr (DEFER) {
     for (int i = tid; i < K2_GRID * K2_GRID_WORDS; i += nthr) s_grid[i] = 0;
     __syncthreads();
@@ -2812,7 +2888,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
   const K2Frame F = {s_trii, s_tri, s_px, s_pxf, s_q,  s_qf, s_hist, tab_eff,     s_tab,   n_d,  nuo,
                      nthr,   tid,   esz_eff, fx, fy,   cx,   cy,     sp.back_tol, thr_pre, s_vq, 64, p_lo,
                      &s_susd, fixup.screen != 0u, f, s_sus, &s_sus_n, (unsigned)SUSN,
-                     s_grid, s_gp[0], s_gp[1], s_gp[2]};
+                     s_grid, s_gp[0], s_gp[1], s_gp[2], s_trif};
   int vq_count = 0;  // entries in this wave's queue (wave-uniform)
   for (int tc0 = 0; tc0 < n_combos; tc0 += TRI) {
     const int ntri = min(TRI, n_combos - tc0);
@@ -2820,6 +2896,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
     // ---- per-triple part of computePoses (p3p.cpp:82-121, 143-154)
     if (tid < ntri) {
       k2_triple_entry(s_iv, n_d, tc0 + tid, fx, fy, cx, cy, s_tri[tid], s_trii[tid]);
+      if constexpr (DEFER) k2_triple_f32(s_tri[tid], s_gp, s_trif[tid]);
     }
     __syncthreads();
 

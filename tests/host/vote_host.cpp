@@ -19,6 +19,14 @@ static inline f32x2 operator-(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y - 
 static inline f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
 static inline f32x2 k2_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{std::fmaf(a.x, b.x, c.x), std::fmaf(a.y, b.y, c.y)}; }
 static inline float k2_fminf(float a, float b) { return std::fminf(a, b); }
+static inline f32x2 operator+(f32x2 a, f32x2 b) { return f32x2{a.x + b.x, a.y + b.y}; }
+static inline unsigned k2_cvt_pk_u8(float x, unsigned byte, unsigned into) {  // saturating, NaN -> 0
+  const float r = std::nearbyintf(x);
+  const unsigned v = !(r > 0.f) ? 0u : (r >= 255.f ? 255u : (unsigned)r);
+  return (into & ~(0xFFu << (8 * byte))) | (v << (8 * byte));
+}
+static inline float k2_rsqf(float x) { return 1.0f / std::sqrt(x); }
+static inline float k2_sqrtf(float x) { return std::sqrt(x); }
 static inline bool k2_isfinite(double x) { return std::isfinite(x); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) {
   const unsigned o = *p;
@@ -43,8 +51,33 @@ static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline u64 __ballot(bool b) { return b ? 1ull : 0ull; }                       // a wave of one lane
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned, unsigned base) { return base; }  // no lower lanes
 static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned, unsigned base) { return base; }
+// test hook: grid coordinates of a back-projection from the voting loop's single-precision chain against the
+// double-precision functions the deferred evaluation uses; g_f32_err[0] = largest difference in PIXELS among the points
+// the double-precision chain puts inside the grid, [1] = number of such points
+static double g_f32_err[2];
+#define K2_ON_GRID_COORD(F, rt, g1, g2, g3, p_2, d_12, b, mk, tr, gx, gy) \
+  host_grid_coord(F, rt, g1, g2, g3, p_2, d_12, b, mk, tr, gx, gy)
 namespace mpe {
+struct K2Frame;
+static void host_grid_coord(const K2Frame& F, double rt, double g1, double g2, double g3, double p_2, double d_12, double b,
+                            const double* mk, const double* tr, float gx, float gy);
 #include "vote_extract.inc"
+static void host_grid_coord(const K2Frame& F, double rt, double g1, double g2, double g3, double p_2, double d_12, double b,
+                            const double* mk, const double* tr, float gx, float gy) {
+  const K2Sub S = k2_back_substitute(rt, g1, g2, g3, p_2, d_12, b);
+  double qu, qv;
+  k2_project_marker(S, mk, tr, qu, qv);
+  const double ex = qu * F.ginv + F.gxo, ey = qv * F.ginv + F.gyo;
+  if (!(ex >= 0 && ex <= K2_GRID && ey >= 0 && ey <= K2_GRID)) return;
+  const double err = std::fmax(std::fabs(ex - gx), std::fabs(ey - gy)) / F.ginv;
+  g_f32_err[1] += 1;
+  if (!(err <= g_f32_err[0])) g_f32_err[0] = err;  // (a NaN sticks)
+}
+}
+extern "C" void host_vote_f32_err(double* out, int reset) {
+  out[0] = g_f32_err[0];
+  out[1] = g_f32_err[1];
+  if (reset) g_f32_err[0] = g_f32_err[1] = 0;
 }
 using namespace mpe;
 // [0] suspect-list entries of the last call, [1] of which whole hypotheses (Ferrari), [2] entries lost to a full
@@ -127,13 +160,16 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   std::vector<u64> grid((size_t)K2_GRID * K2_GRID_WORDS, 0);  // occupancy grid of the deferred plain variant
   float gp[4] = {0, 0, 0, 0};
   k2_grid_build(px, n_d, sp.back_tol, grid.data(), gp, 0, 1);
+  std::vector<float> trif((size_t)n_combos * 12);
+  for (int i = 0; i < n_combos; ++i) k2_triple_f32(tri.data() + (size_t)i * 13, gp, trif.data() + (size_t)i * 12);
   int frame_status = 0;
   const K2SusDesc susd = {sus_ctl, sus_list.data(), sus_cap, &frame_status};
   const K2Frame F = {trii.data(), reinterpret_cast<const double(*)[13]>(tri.data()), px, pxf, q.data(), qf.data(),
                      hist, tab.data(), ltab.data(), n_d, nuo, 1, 0, esz, sp.fx, sp.fy, sp.cx, sp.cy, sp.back_tol,
                      k2_prefilter_threshold(sp.back_tol, (variant == 0 && k2_defers(false, nuo <= 8 ? (nuo + 1) / 2 : 0)) ? 0.25 : 0.05),
                      vq.data(), 1, 0, &susd, fixup, 0,
-                     sus_lds.data(), &sus_lds_n, lds_cap, grid.data(), gp[0], gp[1], gp[2]};
+                     sus_lds.data(), &sus_lds_n, lds_cap, grid.data(), gp[0], gp[1], gp[2],
+                     reinterpret_cast<const float(*)[12]>(trif.data())};
   struct Fix {
     const K2Frame& F;
     const SolveParams& sp;

@@ -209,3 +209,28 @@ def test_fixup_lists_full(host, orc):
             assert n <= 1 and (lost > 0) == (marked == 1)
             seen_lost += lost
     assert seen_lost > 0 and seen_entries > 10
+
+
+def test_single_precision_grid_coordinates_stay_inside_the_margin(host, orc):
+    """Deferred plain variant (6 .. 11 markers): the voting loop decides "can this root's back-projections be near a
+    detection" from grid coordinates computed in SINGLE precision (M = G K T^T Rm per root, 6 multiply-adds and a
+    reciprocal per marker); the occupancy grid is dilated by the vote tolerance + 0.25 px for that chain's error.  Here:
+    every back-projection the double-precision chain puts inside the grid (the only ones that can vote), on detection
+    sets of C3 scenes and of random rigs, differs from it by less than 0.05 px."""
+    host.host_vote_f32_err.restype = None
+    out = (C.c_double * 2)()
+    host.host_vote_f32_err(out, 1)
+    rng = np.random.default_rng(11)
+    cfg = synth.CONFIGS["C3"]
+    K, D = synth.camera_for(cfg["rows"], cfg["cols"])
+    _, spots = synth.make_scenes_batch(cfg, 6, seed=77)
+    for i in range(6):
+        und = np.asarray(orc.undistort_points(spots[i].astype(np.float32), K, D), np.float32).astype(float)
+        _host_hist(host, und[rng.permutation(len(und))][:10], cfg["markers"], K, 5.0, 0)
+    for n_m in (6, 7, 9):      # random rigs, detections that do not come from them
+        markers = rng.uniform(-0.2, 0.2, (n_m, 3))
+        det = np.stack([rng.uniform(50, 700, 7), rng.uniform(50, 430, 7)], 1)
+        _host_hist(host, det, markers, K, 5.0, 0)
+    host.host_vote_f32_err(out, 1)
+    assert out[1] > 1e5, out[1]            # points compared
+    assert out[0] < 0.05, (out[0], out[1])   # (NaN fails too)
