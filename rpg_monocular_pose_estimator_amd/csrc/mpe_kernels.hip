@@ -2285,12 +2285,13 @@ __device__ __forceinline__ unsigned k2_grid_bit(const K2Frame& F, float fx, floa
   const unsigned word = reinterpret_cast<const unsigned*>(F.grid)[idx >> 5];
   return (word >> (idx & 31u)) & 1u;
 }
-// the block's grid: cells within R of a detection (infinity norm) are set.  All threads; the grid must be zero; the
+// the block's grid: cells that a point within R of a detection can land in.  All threads; the grid must be zero; the
 // parameters are returned through gp = {ginv, gxo, gyo}: grid coordinates of a pixel (u, v) = (u ginv + gxo, v ginv +
-// gyo).  A coordinate c lands in cell floor(c) or floor(c) + 1 whatever the conversion's rounding, and the single-
-// precision chain that produces c is off by a small fraction of a pixel (margin in R): [floor(lo) - 1, floor(hi) + 2]
-// are set for a detection's interval [lo, hi]; 250 cells span the detections' bounding box + 2 R, from cell 3 on, so
-// that cells 0 and 255 stay empty.
+// gyo).  A coordinate c lands in cell floor(c) or floor(c) + 1 whatever the conversion's rounding, i.e. cell X takes
+// points with c in [X - 1, X + 1): row Y of a detection's disc (centre (cx, cy), radius r, in cells) is set from
+// floor(cx - hw) to floor(cx + hw) + 1, hw the disc's half-width over y in [Y - 1, Y + 1).  The single-precision chain
+// that produces c is off by < 0.01 px (tests/test_vote_host.py; margin in R: 0.25 px).  248 cells span the detections'
+// bounding box + 2 R, from cell 3 on, so that cells 0 and 255 — where everything outside the grid lands — stay empty.
 __device__ __forceinline__ void k2_grid_build(const double (*px)[2], int n_d, double back_tol, u64* grid, float* gp, int tid,
                                               int nthr) {
   const float R = (float)(back_tol * (1.0 + 1e-4) + 0.25);
@@ -2311,17 +2312,24 @@ __device__ __forceinline__ void k2_grid_build(const double (*px)[2], int n_d, do
     gp[1] = ox;
     gp[2] = oy;
   }
+  const float r = R * inv + 1e-3f;
   for (int a = tid; a < n_d; a += nthr) {
     const float u = (float)px[a][0], v = (float)px[a][1];
     if (!(u == u && v == v)) continue;
-    const int ix0 = max(1, (int)((u - R) * inv + ox) - 1), ix1 = min(K2_GRID - 2, (int)((u + R) * inv + ox) + 2);
-    const int iy0 = max(1, (int)((v - R) * inv + oy) - 1), iy1 = min(K2_GRID - 2, (int)((v + R) * inv + oy) + 2);
-    for (int iy = iy0; iy <= iy1; ++iy)
+    const float cxg = u * inv + ox, cyg = v * inv + oy;  // (>= 3: truncation is floor)
+    const int iy0 = max(1, (int)(cyg - r)), iy1 = min(K2_GRID - 2, (int)(cyg + r) + 1);
+    for (int iy = iy0; iy <= iy1; ++iy) {
+      const float dy = fmaxf(0.f, fmaxf((float)(iy - 1) - cyg, cyg - (float)(iy + 1)));
+      const float hh = r * r - dy * dy;
+      if (!(hh >= 0.f)) continue;
+      const float hw = sqrtf(hh);
+      const int ix0 = max(1, (int)(cxg - hw)), ix1 = min(K2_GRID - 2, (int)(cxg + hw) + 1);
       for (int w = ix0 >> 6; w <= (ix1 >> 6); ++w) {
         const int lo = max(ix0, 64 * w) - 64 * w, hi = min(ix1, 64 * w + 63) - 64 * w;
         const u64 m = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1)) & ~((1ull << lo) - 1);
         atomicOr(&grid[iy * K2_GRID_WORDS + w], m);
       }
+    }
   }
 }
 // per staged triple, single precision: G K T^T with G = [ginv 0 gxo; 0 ginv gyo; 0 0 1] — a point's GRID coordinates are
@@ -2341,12 +2349,16 @@ __device__ __forceinline__ void k2_triple_f32(const double* T, const float* gp, 
 // works the wave's queue off, one entry per lane: everything the voting loop knew about the root is rebuilt from the
 // staged triple ti, the permutation pj and the root's value — back-substitution, double-precision back-projections,
 // the single-precision prefilter over the unused detections, the exact search, band screen and votes
+// `all` = false: only full passes (every lane an entry); what is left moves to the front of the queue and `count` says
+// how many.  Called after every root with 64 or more entries queued, so that the queue (2 x 64 entries) never overflows.
 template <int NP>
-__device__ __forceinline__ void k2_defer_flush(const K2Frame& F, int count) {
+__device__ __forceinline__ void k2_defer_flush(const K2Frame& F, int& count, bool all) {
   wave_sync();
   const unsigned n = min((unsigned)count, (unsigned)K2_DQ_CAP);
-  const unsigned lane = (unsigned)F.tid & 63u;
-  for (unsigned i = lane; i < n; i += (unsigned)F.vq_lanes) {
+  const unsigned W = (unsigned)F.vq_lanes;
+  const unsigned lane = (unsigned)F.tid & (W - 1u);
+  const unsigned n_do = all ? n : n - n % W;  // (wave-uniform)
+  for (unsigned i = lane; i < n_do; i += W) {
     const u64* q = F.vq + (size_t)i * K2_DQ_WORDS;
     const double rt = __longlong_as_double((long long)q[0]);
     const unsigned meta = (unsigned)q[1];
@@ -2406,6 +2418,21 @@ __device__ __forceinline__ void k2_defer_flush(const K2Frame& F, int count) {
       });
   }
   wave_sync();
+  if (n_do < n) {  // (fewer than W entries: one per lane)
+    u64 a = 0, b = 0;
+    const bool mine = n_do + lane < n;
+    if (mine) {
+      a = F.vq[(size_t)(n_do + lane) * K2_DQ_WORDS];
+      b = F.vq[(size_t)(n_do + lane) * K2_DQ_WORDS + 1];
+    }
+    wave_sync();
+    if (mine) {
+      F.vq[(size_t)lane * K2_DQ_WORDS] = a;
+      F.vq[(size_t)lane * K2_DQ_WORDS + 1] = b;
+    }
+    wave_sync();
+  }
+  count = (int)(n - n_do);
 }
 
 // One work item = (staged detection triple ti, marker permutation pj): quartic coefficients (p3p.cpp:171-185),
@@ -2700,9 +2727,10 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
           u64* q = F.vq + (size_t)slot * K2_DQ_WORDS;
           q[0] = (u64)__double_as_longlong(rt);
           q[1] = (u64)((unsigned)ti | ((unsigned)pj << 8) | ((unsigned)k << 20));
-        } else {
+        } else {  // (cannot happen with the flush below; kept as the capacity guard)
           k2_sus_push(F, k2_sus_code(c0, c1, c2, p0, p1, p2, 1u << k, false), unused);
         }
+        if (vq_count >= F.vq_lanes) k2_defer_flush<NP>(F, vq_count, false);  // (wave-uniform)
       }
     } else {
       // the detections that are not part of the triple, ascending: a uniform trip count for the frame; the ones that get
@@ -2742,12 +2770,6 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
   if constexpr (SCAN) {
     if (vq_count >= K2_VQ_CAP - 4) {  // wave-uniform
       k2_vote_flush(F, vq_count);
-      vq_count = 0;
-    }
-  }
-  if constexpr (k2_defers(SCAN, NP)) {
-    if (vq_count > K2_DQ_CAP / 2) {  // (wave-uniform)
-      k2_defer_flush<NP>(F, vq_count);
       vq_count = 0;
     }
   }
@@ -2941,8 +2963,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
       pj = pj_keep;
     }
     if constexpr (k2_defers(SCAN, NP)) {  // (the staged triples the queue's entries refer to are about to be replaced)
-      k2_defer_flush<NP>(F, vq_count);
-      vq_count = 0;
+      k2_defer_flush<NP>(F, vq_count, true);
     }
     if constexpr (!SCAN) k2_sus_flush(F, &s_sus_base);  // (the scan-carrying variant: once, behind the rider's last round)
   }

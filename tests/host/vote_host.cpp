@@ -53,8 +53,9 @@ static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned, unsigned base) { retu
 static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned, unsigned base) { return base; }
 // test hook: grid coordinates of a back-projection from the voting loop's single-precision chain against the
 // double-precision functions the deferred evaluation uses; g_f32_err[0] = largest difference in PIXELS among the points
-// the double-precision chain puts inside the grid, [1] = number of such points
-static double g_f32_err[2];
+// the double-precision chain puts inside the grid, [1] = number of such points, [2] = back-projections within the vote
+// tolerance of a detection, [3] = those of them whose grid cell is NOT set (must be 0: the loop would drop a vote)
+static double g_f32_err[4];
 #define K2_ON_GRID_COORD(F, rt, g1, g2, g3, p_2, d_12, b, mk, tr, gx, gy) \
   host_grid_coord(F, rt, g1, g2, g3, p_2, d_12, b, mk, tr, gx, gy)
 namespace mpe {
@@ -67,6 +68,15 @@ static void host_grid_coord(const K2Frame& F, double rt, double g1, double g2, d
   const K2Sub S = k2_back_substitute(rt, g1, g2, g3, p_2, d_12, b);
   double qu, qv;
   k2_project_marker(S, mk, tr, qu, qv);
+  // a back-projection that votes (within the tolerance of a detection) must find its cell set
+  for (int a = 0; a < F.n_d; ++a) {
+    const double du = qu - F.px[a][0], dv = qv - F.px[a][1];
+    if (du * du + dv * dv < F.back_tol * F.back_tol) {
+      g_f32_err[2] += 1;
+      if (!k2_grid_bit(F, gx, gy)) g_f32_err[3] += 1;
+      break;
+    }
+  }
   const double ex = qu * F.ginv + F.gxo, ey = qv * F.ginv + F.gyo;
   if (!(ex >= 0 && ex <= K2_GRID && ey >= 0 && ey <= K2_GRID)) return;
   const double err = std::fmax(std::fabs(ex - gx), std::fabs(ey - gy)) / F.ginv;
@@ -75,9 +85,8 @@ static void host_grid_coord(const K2Frame& F, double rt, double g1, double g2, d
 }
 }
 extern "C" void host_vote_f32_err(double* out, int reset) {
-  out[0] = g_f32_err[0];
-  out[1] = g_f32_err[1];
-  if (reset) g_f32_err[0] = g_f32_err[1] = 0;
+  for (int i = 0; i < 4; ++i) out[i] = g_f32_err[i];
+  if (reset) g_f32_err[0] = g_f32_err[1] = g_f32_err[2] = g_f32_err[3] = 0;
 }
 using namespace mpe;
 // [0] suspect-list entries of the last call, [1] of which whole hypotheses (Ferrari), [2] entries lost to a full
@@ -222,9 +231,9 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
       ~FlushAtExit() {
         if (!on) return;
         switch (np) {
-          case 2: k2_defer_flush<2>(F, count); break;
-          case 3: k2_defer_flush<3>(F, count); break;
-          default: k2_defer_flush<4>(F, count); break;
+          case 2: k2_defer_flush<2>(F, count, true); break;
+          case 3: k2_defer_flush<3>(F, count, true); break;
+          default: k2_defer_flush<4>(F, count, true); break;
         }
       }
     } flush_at_exit = {F, unused, variant != 2 && k2_defers(false, np), np};

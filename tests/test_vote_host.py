@@ -216,9 +216,10 @@ def test_single_precision_grid_coordinates_stay_inside_the_margin(host, orc):
     detection" from grid coordinates computed in SINGLE precision (M = G K T^T Rm per root, 6 multiply-adds and a
     reciprocal per marker); the occupancy grid is dilated by the vote tolerance + 0.25 px for that chain's error.  Here:
     every back-projection the double-precision chain puts inside the grid (the only ones that can vote), on detection
-    sets of C3 scenes and of random rigs, differs from it by less than 0.05 px."""
+    sets of C3 scenes and of random rigs, differs from it by less than 0.05 px, and every one that lies within the tolerance of a detection finds its cell set
+    (the grid marks, row by row, the cells a disc of that radius can reach)."""
     host.host_vote_f32_err.restype = None
-    out = (C.c_double * 2)()
+    out = (C.c_double * 4)()
     host.host_vote_f32_err(out, 1)
     rng = np.random.default_rng(11)
     cfg = synth.CONFIGS["C3"]
@@ -234,3 +235,5 @@ def test_single_precision_grid_coordinates_stay_inside_the_margin(host, orc):
     host.host_vote_f32_err(out, 1)
     assert out[1] > 1e5, out[1]            # points compared
     assert out[0] < 0.05, (out[0], out[1])   # (NaN fails too)
+    # the occupancy grid itself: every back-projection within the vote tolerance of a detection finds its cell set
+    assert out[2] > 100 and out[3] == 0, (out[2], out[3])
