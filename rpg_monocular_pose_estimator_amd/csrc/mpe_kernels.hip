@@ -1036,6 +1036,20 @@ struct K1bFrameLds {  // what the contour phase needs of one frame
   int ready, cols, roi_x, roi_y;  // for the wave that traces the block's islands
 };
 
+// (experiment builds, profiles/build_k1b_stops.sh: -DK1B_STOP_AFTER=n ends a frame's work after phase n — 1 A, 2 B, 3 C,
+//  4 D, 5 the contour phase — with an empty record, to time the phases on the GPU; never defined in the product build)
+#ifdef K1B_STOP_AFTER
+#define K1B_STOP_POINT(PHASE, REC) \
+  if (K1B_STOP_AFTER <= (PHASE)) { \
+    if (lane == 0) {               \
+      (REC)->n = 0;                \
+      (REC)->status = 0;           \
+    }                              \
+    return false;                  \
+  }
+#else
+#define K1B_STOP_POINT(PHASE, REC)
+#endif
 // Front phases of frame f.  Returns true when the island bitmaps in S are ready for the contour phase,
 // false when the frame is finished (no bright pixel) or was handed to the next tier's work-list.
 template <class C>
@@ -1120,6 +1134,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
     }
     return false;
   }
+  K1B_STOP_POINT(1, out)
   bool fallback = nseg > C::SEG;
   int why = fallback ? 1 : 0;  // which capacity sent the frame on (kept in the top byte of its work-list entry: statistics)
 
@@ -1267,6 +1282,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
     return false;
   }
   wave_sync();
+  K1B_STOP_POINT(2, out)
 
   // ---- C: clear the bitmaps, stage the thresholded pixels of every island (16-byte loads)
   {
@@ -1295,6 +1311,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
     }
   }
   wave_sync();
+  K1B_STOP_POINT(3, out)
 
   // ---- D: blurred mask of every island
   {
@@ -1315,6 +1332,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
     }
   }
   wave_sync();
+  K1B_STOP_POINT(4, out)
   return true;
 }
 
@@ -1418,6 +1436,15 @@ __device__ __forceinline__ void k1b_wave(const int f, const bool valid, const ui
   }
   __syncthreads();
   if (!ready) return;
+#ifdef K1B_STOP_AFTER
+  if (K1B_STOP_AFTER <= 5) {
+    if (lane == 0) {
+      dets[f].n = 0;
+      dets[f].status = 0;
+    }
+    return;
+  }
+#endif
   if (C::KEPT < 2 * MPE_MAX_DETECTIONS && S.nkept > C::KEPT) {  // more blobs than this tier records
     if (lane == 0) k1b_hand_over(f, dets, worklist);
     return;
