@@ -105,7 +105,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=262144, help="frames per GPU per step (device-resident batch, 95 GB)")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="frames per GPU per step (device-resident batch); default: 262 144 (95 GB) at C2, 65 536 at C1 / "
+                         "C3, 16 384 at C4 (38 GB of 1920x1200 frames)")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -142,6 +144,8 @@ def main():
                     help="no GPU work: the launch / shard / pose-gather / timing plumbing of the N-rank bench on CPU "
                          "(gloo), with synthetic records instead of kernels; used by the CPU test-suite")
     args = ap.parse_args()
+    if args.frames <= 0:
+        args.frames = {"C2": 262144, "C1": 65536, "C3": 65536, "C4": 16384}.get(args.config, 16384)
 
     import torch
 

@@ -641,6 +641,7 @@ struct CellIsl {
   int seed;                    // slot << 16 | xb of the raster-first remaining pixel, INT_MAX: none
   int a00, a10, a01, chi, xmin, xmax, ymin, ymax;
   int nblob, state;            // state: 0 in progress, 1 finished, 2 handed to the border trace
+  int simple;                  // one word wide, every row a single run that touches the next row's: one component
   float bx[K1B_CELL_BLOBS], by[K1B_CELL_BLOBS];
   unsigned bkey[K1B_CELL_BLOBS];
 };
@@ -746,6 +747,29 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
     if (it_o[t] >= 0) pm[it_o[t]] = 0;
   }
   wave_sync();
+  // ---- the usual LED needs no flood: an island one word wide whose occupied rows are contiguous, each a single run
+  //      that touches (8-neighbourhood) the run of the next row, is ONE component, and no background pixel of it is
+  //      enclosed (it escapes along its own row, on its side of the run) — all its pixels are the first component
+  for (int k = lane; k < nisl; k += nl) cs[k].simple = (cs[k].W == 1 && cs[k].state == 0) ? 1 : 0;
+  wave_sync();
+#pragma unroll
+  for (int t = 0; t < NIT; ++t) {
+    if (it_o[t] < 0) continue;
+    const int k = isl_of(it_m[t]), slot = slot_of(it_m[t]);
+    if (!cs[k].simple || slot < cs[k].lo || slot > cs[k].hi) continue;
+    const u64 r = rem[t];
+    bool bad = r == 0;
+    if (!bad) {
+      const u64 x = r >> __builtin_ctzll(r);
+      bad = (x & (x + 1)) != 0;
+      if (!bad && slot < cs[k].hi) {
+        const u64 dn = nz[it_o[t] + 1];  // (W == 1: the next row)
+        bad = ((dn | (dn << 1) | (dn >> 1)) & r) == 0;
+      }
+    }
+    if (bad) cs[k].simple = 0;
+  }
+  wave_sync();
   for (int round = 0;; ++round) {
     // ---- seed: the raster-first remaining pixel of every island still in progress
     for (int k = lane; k < nisl; k += nl) cs[k].seed = kIntMax;
@@ -768,21 +792,26 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
     }
     if (__builtin_amdgcn_ballot_w64(active) == 0) break;  // (uniform)
     wave_sync();
+    bool flood = false;  // some island of this lane's items has to be flooded
 #pragma unroll
     for (int t = 0; t < NIT; ++t) {
       on[t] = on[t] && cs[isl_of(it_m[t])].state == 0;
       cur[t] = 0;
       if (on[t]) {
         const int sd = cs[isl_of(it_m[t])].seed;
-        if ((sd >> 16) == slot_of(it_m[t]) && ((sd & 0xFFFF) >> 6) == w_of(it_m[t])) cur[t] = 1ull << (sd & 63);
+        if (round == 0 && cs[isl_of(it_m[t])].simple)
+          cur[t] = rem[t];
+        else if ((sd >> 16) == slot_of(it_m[t]) && ((sd & 0xFFFF) >> 6) == w_of(it_m[t]))
+          cur[t] = 1ull << (sd & 63);
         pm[it_o[t]] = cur[t];
+        if (!(round == 0 && cs[isl_of(it_m[t])].simple)) flood = true;
       }
     }
     wave_sync();
     // ---- flood: 3 x 3 dilation under the mask until nothing changes
     bool changed;
     int it = 0;
-    do {
+    if (__builtin_amdgcn_ballot_w64(flood) != 0) do {
       changed = false;
 #pragma unroll
       for (int t = 0; t < NIT; ++t) {
