@@ -947,7 +947,13 @@ __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int c
     m = blur_item_generic(pw, rows, cols, y, c, taps, ksize);
   }
   if (m) {
-    const int xb0 = x0 - xw0 + 1, wi = xb0 >> 6, shb = xb0 & 63;
+    int xb0 = x0 - xw0 + 1;
+    if (xb0 < 0) {  // (island windows start r pixels left of the first bright segment: the outputs further left are 0)
+      m >>= -xb0;
+      xb0 = 0;
+      if (!m) return;
+    }
+    const int wi = xb0 >> 6, shb = xb0 & 63;
     atomicOr(&nzrow[wi], (u64)m << shb);
     if (shb > 48) atomicOr(&nzrow[wi + 1], (u64)m >> (64 - shb));
   }
@@ -1020,6 +1026,16 @@ struct Island {
   int stage_end, blur_end;  // inclusive prefix sums of the flattened work-item counts
 };
 
+// The island's bitmap window: the blurred mask can only be non-zero within r pixels of a bright segment, i.e. in
+// x = [16 cfirst - r, 16 clast + 15 + r] (clipped to the output columns clo .. chi and the image): bit 0 of a row is pixel
+// xw0 - 1 (one pixel of margin on both sides for the 3 x 3 neighbourhoods).  An LED that straddles a segment boundary
+// then still fits ONE 64-bit word per row (two bright segments: 38 pixels), where the window of the dilated segment
+// columns took two — half the bitmap words to clear and combine, and the contour phase's one-word shortcuts apply.
+__device__ __forceinline__ int isl_xw0(const Island& is, int r) { return max(16 * is.clo, 16 * is.cfirst - r); }
+__device__ __forceinline__ int isl_words(const Island& is, int cols, int r) {
+  const int xhi = min(min(cols - 1, 16 * is.chi + 15), 16 * is.clast + 15 + r);
+  return ((xhi - isl_xw0(is, r) + 1) + 2 + 63) / 64;
+}
 // capacities: thresholded-pixel pool [bytes], bitmap pool [u64 words per bitmap], bright segments, bands,
 // islands, blobs kept per frame; WAVES = frames (one wave each) per block, whose islands ONE wave traces together
 #ifndef K1B_SMALL_WAVES
@@ -1270,8 +1286,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
     if (lane < nisl) {
       const Island is = s_isl[lane];
       const int H = is.yhi - is.ylo + 1;
-      const int xhi = min(g.cols - 1, 16 * is.chi + 15);
-      const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
+      const int W = isl_words(is, g.cols, r);
       const int nbs = is.clast - is.cfirst + 1;
       pixb = H * 16 * nbs;
       bmw = (H + 2) * W;
@@ -1316,8 +1331,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   // ---- C: clear the bitmaps, stage the thresholded pixels of every island (16-byte loads)
   {
     const int tot_bm = s_isl[nisl - 1].bm_off +
-                       (s_isl[nisl - 1].yhi - s_isl[nisl - 1].ylo + 3) *
-                           (((min(g.cols - 1, 16 * s_isl[nisl - 1].chi + 15) - 16 * s_isl[nisl - 1].clo + 1) + 2 + 63) / 64);
+                       (s_isl[nisl - 1].yhi - s_isl[nisl - 1].ylo + 3) * isl_words(s_isl[nisl - 1], g.cols, r);
     for (int i = lane; i < tot_bm; i += 64) {
       s_nz[i] = 0;
       s_pm[i] = 0;
@@ -1353,11 +1367,10 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
       const int ncols = is.chi - is.clo + 1;
       const int yb = li / ncols, c = is.clo + (li - yb * ncols);
       const int H = is.yhi - is.ylo + 1;
-      const int xhi = min(g.cols - 1, 16 * is.chi + 15);
-      const int W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
+      const int W = isl_words(is, g.cols, r);
       const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1)};
       blur_to_bitmap(pw, g.rows, g.cols, dp, s_taps, is.ylo + yb, c, s_nz + is.bm_off + (size_t)(yb + 1) * W,
-                     16 * is.clo);
+                     isl_xw0(is, r));
     }
   }
   wave_sync();
@@ -1416,12 +1429,11 @@ __device__ __forceinline__ void k1b_wave(const int f, const bool valid, const ui
       const int nisl = S.nisl;
       if (lane < nisl) {
         const Island is = S.isl[lane];
-        const int xhi = min(g.cols - 1, 16 * is.chi + 15);
         cs[lane].bm_off = is.bm_off;
-        cs[lane].W = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
+        cs[lane].W = isl_words(is, g.cols, dp.ksize / 2);
         cs[lane].H = is.yhi - is.ylo + 1;
         cs[lane].ylo = is.ylo;
-        cs[lane].xw0 = 16 * is.clo;
+        cs[lane].xw0 = isl_xw0(is, dp.ksize / 2);
       }
       wave_sync();
       auto keep = [&](float mcx, float mcy, unsigned key) {
@@ -1449,9 +1461,8 @@ __device__ __forceinline__ void k1b_wave(const int f, const bool valid, const ui
       K1bFrameLds<C>& F = Sl[fi];
       const Island is = F.isl[it - base[fi]];
       const int H = is.yhi - is.ylo + 1;
-      const int xhi = min(F.cols - 1, 16 * is.chi + 15);
-      const int Wd = ((xhi - 16 * is.clo + 1) + 2 + 63) / 64;
-      scan_window(F.nz + is.bm_off, F.pm + is.bm_off, F.ng + is.bm_off, Wd, H, is.ylo, 16 * is.clo, dp, F.roi_x,
+      const int Wd = isl_words(is, F.cols, dp.ksize / 2);
+      scan_window(F.nz + is.bm_off, F.pm + is.bm_off, F.ng + is.bm_off, Wd, H, is.ylo, isl_xw0(is, dp.ksize / 2), dp, F.roi_x,
                   F.roi_y, &F.over,
                   [&](float mcx, float mcy, unsigned key) {
                     const int k = atomicAdd(&F.nkept, 1);
@@ -1711,7 +1722,7 @@ __device__ __forceinline__ double pick_root(const P3PCtx& c, int k) {
 #define K2_THREADS 256
 #define K2_TRI_CHUNK 64  // detection triples staged in LDS per pass
 #define K2_TRI_CHUNK_SCAN 16
-#define K2_LTAB 11  // doubles per marker permutation in the LDS copy of the table (scan-carrying variant)
+#define K2_LTAB 14  // doubles per marker permutation in the LDS copy of the table (scan-carrying variant)
 
 // ---- marker-permutation table (frame independent) -------------------------------------------
 // One entry per ordered marker triple (P1,P2,P3), in the reference's permutation order
@@ -2020,8 +2031,10 @@ struct K2Frame {
 
 // i-th double of the LDS copy of the marker-permutation table (scan-carrying variant), K2_LTAB per permutation:
 //   [0] p_1 [1] p_2 [2] d_12 [3] valid [4] packed marker indices [5..10] eta-frame unused markers (<= 2)
+//   [11..13] the same markers in single precision (six floats, as the table entry packs them)
 __device__ __forceinline__ double k2_ltab_value(const double* __restrict__ tab, int esz, int nuo, int i) {
   const int pe = i / K2_LTAB, fld = i - pe * K2_LTAB;
+  if (fld >= 11) return (fld - 11 < (3 * nuo + 1) / 2) ? tab[(size_t)pe * esz + 18 + 3 * nuo + (fld - 11)] : 0.0;
   const int src = fld < 5 ? 12 + fld : 13 + fld;  // 12..16, 18..23
   return (fld < 5 + 3 * nuo) ? tab[(size_t)pe * esz + src] : 0.0;
 }
@@ -2184,42 +2197,20 @@ __device__ __forceinline__ void k2_vote_exact(const K2Frame& F, const unsigned c
 // hypothesis root; slots come from a ballot, the fill count is a wave-uniform register) and the wave works the queue
 // off with one entry per LANE whenever it is nearly full: the same exact test, the same votes (integer adds: any
 // order).  A lane that finds the queue full votes on the spot.  Measured: 0.855 -> 0.833 ms per fused launch.
-#define K2_VQ_CAP 12
-#define K2_VQ_WORDS 5
+#define K2_VQ_CAP 28
+#define K2_VQ_WORDS 2
+// Round 4: the loop's back-projections are single precision (see K2SubF below), so an entry is {root, prefilter mask |
+// staged triple, permutation, root number} and the exact evaluation rebuilds the root's back-substitution and its (<= 2)
+// back-projections in double precision — the operations the loop itself used to run for every root.
 // Suspect roots and hypotheses of the scan-carrying variant travel through the same queue (flag bits in the entry's
 // index word) and reach the block's suspect list when the queue is worked off: a second, divergent append inside the
 // root loop cost the kernel ~50 scalar-register reloads per root.
 #define K2_VQ_ROOT_SUS (1u << 29)
 #define K2_VQ_ITEM_SUS (1u << 30)
-__device__ __forceinline__ u64 k2_vq_meta(const unsigned cw, const unsigned pw, int k, unsigned pass) {
-  const unsigned c0 = cw & 0xFF, c1 = (cw >> 8) & 0xFF, c2 = (cw >> 16) & 0xFF;
-  const unsigned p0 = pw & 0xFF, p1 = (pw >> 8) & 0xFF, p2 = (pw >> 16) & 0xFF;
-  return (u64)pass |
-         ((u64)(c0 | (c1 << 5) | (c2 << 10) | (p0 << 15) | (p1 << 19) | (p2 << 23) | ((unsigned)k << 27)) << 32);
+__device__ __forceinline__ u64 k2_vq_meta(int ti, int pj, int k, unsigned pass) {  // ti < 16, pj < 60
+  return (u64)pass | ((u64)((unsigned)ti | ((unsigned)pj << 4) | ((unsigned)k << 10)) << 32);
 }
-__device__ __forceinline__ void k2_vote_flush(const K2Frame& F, int count) {
-  wave_sync();
-  const unsigned n = min((unsigned)count, (unsigned)K2_VQ_CAP);
-  const unsigned lane = (unsigned)F.tid & 63u;
-  for (unsigned i = lane; i < n; i += (unsigned)F.vq_lanes) {  // (one trip at most on the device: n <= 12 < 64)
-    const u64* e = F.vq + (size_t)i * K2_VQ_WORDS;
-    const u64 meta = e[4];
-    const unsigned ix = (unsigned)(meta >> 32);
-    if (ix & (K2_VQ_ROOT_SUS | K2_VQ_ITEM_SUS)) {  // a suspect root / hypothesis on its way to the strict arithmetic
-      const int c0 = ix & 31, c1 = (ix >> 5) & 31, c2 = (ix >> 10) & 31;
-      const unsigned unused = (0xFFFFFFFFu >> (32 - F.n_d)) & ~((1u << c0) | (1u << c1) | (1u << c2));
-      k2_sus_push(F, k2_sus_code(c0, c1, c2, (ix >> 15) & 15, (ix >> 19) & 15, (ix >> 23) & 15,
-                                 (ix & K2_VQ_ITEM_SUS) ? 0xFu : 1u << ((ix >> 27) & 3), false), unused);
-      continue;
-    }
-    k2_vote_exact(F, (ix & 31) | (((ix >> 5) & 31) << 8) | (((ix >> 10) & 31) << 16),
-                  ((ix >> 15) & 15) | (((ix >> 19) & 15) << 8) | (((ix >> 23) & 15) << 16),
-                  (unsigned)meta, __longlong_as_double((long long)e[0]), __longlong_as_double((long long)e[1]),
-                  __longlong_as_double((long long)e[2]), __longlong_as_double((long long)e[3]), (int)((ix >> 27) & 3));
-  }
-  wave_sync();  // (the entries are read before the next ones overwrite them)
-}
-
+__device__ __forceinline__ void k2_vote_flush(const K2Frame& F, int count);  // (behind k2_project_marker below)
 // The block's list -> the launch's list in global memory: ONE returning global atomic per flush (thread 0), at a point
 // every thread of the block passes and where no scan round is in flight.  s_base: one word of LDS for the broadcast.
 #define K2_SUS_LDS_SCAN 30   // entries of the block's list, scan-carrying variant (one frame per block: ~4 on average)
@@ -2284,6 +2275,45 @@ __device__ __forceinline__ void k2_project_marker(const K2Sub& S, const double* 
   const double iZ = rcp_nr(Z);
   qu = U * iZ;
   qv = V * iZ;
+}
+
+// works the scan-carrying variant's queue off, one entry per lane (at most one trip on the device: K2_VQ_CAP < 64)
+__device__ __forceinline__ void k2_vote_flush(const K2Frame& F, int count) {
+  wave_sync();
+  const unsigned n = min((unsigned)count, (unsigned)K2_VQ_CAP);
+  const unsigned lane = (unsigned)F.tid & 63u;
+  for (unsigned i = lane; i < n; i += (unsigned)F.vq_lanes) {
+    const u64* q = F.vq + (size_t)i * K2_VQ_WORDS;
+    const double rt = __longlong_as_double((long long)q[0]);
+    const u64 meta = q[1];
+    const unsigned ix = (unsigned)(meta >> 32);
+    const int ti = ix & 15, pj = (ix >> 4) & 63, k = (ix >> 10) & 3;
+    const unsigned ii = F.trii[ti];
+    const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
+    const int packed = (int)F.ltab[pj * K2_LTAB + 4];
+    if (ix & (K2_VQ_ROOT_SUS | K2_VQ_ITEM_SUS)) {  // a suspect root / hypothesis on its way to the strict arithmetic
+      const unsigned unused = (0xFFFFFFFFu >> (32 - F.n_d)) & ~((1u << c0) | (1u << c1) | (1u << c2));
+      k2_sus_push(F, k2_sus_code(c0, c1, c2, packed & 0xFF, (packed >> 8) & 0xFF, (packed >> 16) & 0xFF,
+                                 (ix & K2_VQ_ITEM_SUS) ? 0xFu : 1u << k, false), unused);
+      continue;
+    }
+    const bool swap = (ii >> 24) & 1;
+    const int r6 = pj % 6;
+    const int pjs = swap ? (pj - r6 + (int)((0x134052u >> (4 * r6)) & 7u)) : pj;
+    const double* lt = F.ltab + pjs * K2_LTAB;
+    const double p_1 = lt[0], p_2 = lt[1], d_12 = lt[2];
+    const double* tr = F.tri[ti];
+    const double b = tr[11], f12 = tr[12];
+    const double g1 = -f12 * p_1 + d_12 * b, g2 = -f12 * p_2, g3 = p_1 - d_12;
+    const K2Sub S = k2_back_substitute(rt, g1, g2, g3, p_2, d_12, b);
+    // isFinite([R C]) (pose_estimator.cpp:653; see the voting loop)
+    if (!(k2_isfinite(S.Cx) && k2_isfinite(S.Cy) && k2_isfinite(S.Cz))) continue;
+    double q0u = 0, q0v = 0, q1u = 0, q1v = 0;
+    k2_project_marker(S, lt + 5, tr, q0u, q0v);
+    if (F.nuo > 1) k2_project_marker(S, lt + 8, tr, q1u, q1v);
+    k2_vote_exact(F, ii & 0xFFFFFFu, (unsigned)packed & 0xFFFFFFu, (unsigned)meta, q0u, q0v, q1u, q1v, k);
+  }
+  wave_sync();  // (the entries are read before the next ones overwrite them)
 }
 
 // the same back-substitution in single precision from (cn, cd, |(cn, cd)|^2, 1 - root^2) formed in double precision —
@@ -2596,11 +2626,12 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     rider.issue();
     const double rt = k == 0 ? root[0] : (k == 1 ? root[1] : (k == 2 ? root[2] : root[3]));
     constexpr bool DEFER = k2_defers(SCAN, NP);
+    constexpr bool F32 = DEFER || SCAN;  // single precision behind the root's two cancellations, exact evaluation deferred
     K2Sub S;    // p3p.cpp:193-213
-    K2SubF Sf;  // (deferred plain variant: single precision behind the two cancellations)
+    K2SubF Sf;  // (F32 variants)
     double om, h2;
     float cos_alpha_f;
-    if constexpr (DEFER) {
+    if constexpr (F32) {
       const double cn = g1 - rt * p_2, cd = g2 * rt + g3;
       h2 = __builtin_fma(cn, cn, cd * cd);
       om = 1 - rt * rt;
@@ -2630,10 +2661,10 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
     }
     // isFinite([R C]) (pose_estimator.cpp:653): a product is finite only if every factor is (0 * inf = NaN), so
     // R (products of the four sines / cosines with the finite frames) and C are finite iff C_eta is
-    // (deferred plain variant: a root outside [-1, 1] or NaN has no pose; whatever else is not finite in single precision
-    //  goes to the queue, whose double-precision evaluation makes this test)
+    // (single-precision variants: a root outside [-1, 1] or NaN has no pose; whatever else is not finite in single
+    //  precision goes to the queue, whose double-precision evaluation makes this test)
     bool finite_pose = true;
-    if constexpr (DEFER) {
+    if constexpr (F32) {
       finite_pose = om >= 0.0;
     } else if (!(k2_isfinite(S.Cx) && k2_isfinite(S.Cy) && k2_isfinite(S.Cz))) {
       if constexpr (UNI)
@@ -2642,31 +2673,15 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
         continue;
     }
     const bool may_vote = live && finite_pose && !root_listed;
-    double q0u = 0, q0v = 0, q1u = 0, q1v = 0;
-    // the prefilter's operands, transposed: (u of marker 0, u of marker 1) and (v, v); a missing second marker sits
-    // at infinity and never is the nearest
-    f32x2 qfu = {0.f, INFINITY}, qfv = {0.f, INFINITY};
     constexpr int NPA = NP > 0 ? NP : 1;
     f32x2 pfu[NPA], pfv[NPA];  // plain variant, NP > 0: (u, u) and (v, v) of marker pair p; missing markers at infinity
 #pragma unroll
     for (int pp = 0; pp < NPA; ++pp) pfu[pp] = pfv[pp] = f32x2{INFINITY, INFINITY};
     auto back_project = [&](const int j) {
-      const double* mk = SCAN ? lt + 5 + 3 * j : e + 18 + 3 * j;
+      const double* mk = e + 18 + 3 * j;
       double qu, qv;
       k2_project_marker(S, mk, tr, qu, qv);
-      if constexpr (SCAN) {  // <= 2 unused markers in this variant: registers instead of the LDS columns
-        if (j == 0) {
-          q0u = qu;
-          q0v = qv;
-          qfu.x = (float)qu;
-          qfv.x = (float)qv;
-        } else {
-          q1u = qu;
-          q1v = qv;
-          qfu.y = (float)qu;
-          qfv.y = (float)qv;
-        }
-      } else {
+      {
         F.q[(2 * j) * F.nthr + F.tid] = qu;
         F.q[(2 * j + 1) * F.nthr + F.tid] = qv;
         if constexpr (NP > 0) {
@@ -2683,10 +2698,13 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
       }
     };
     unsigned grid_hits = 0;  // deferred plain variant: some back-projection falls into a cell near a detection
-    if constexpr (DEFER) {
-      // M = (G K T^T) Rm and -M C_eta once per root (22 instructions), then a marker's grid coordinates are 3 packed + 3
-      // plain multiply-adds, a reciprocal and a packed multiply; its cell one conversion per coordinate, one LDS read and
-      // one bit test (see K2_DQ_CAP above)
+    f32x2 uv0 = {INFINITY, INFINITY}, uv1 = {INFINITY, INFINITY};  // scan-carrying variant: the (<= 2) back-projections
+    bool chain_ok = true;  // the single-precision chain produced finite numbers
+    if constexpr (F32) {
+      // M = (G K T^T) Rm and -M C_eta once per root (22 instructions), then a marker's coordinates are 3 packed + 3 plain
+      // multiply-adds, a reciprocal and a packed multiply.  Deferred plain variant: GRID coordinates (G = the map from
+      // pixels to cells), the cell by one conversion per coordinate, one LDS read and one bit test (see K2_DQ_CAP above);
+      // scan-carrying variant: pixels (G = 1).
       const float* tf = F.trif[ti];
       const f32x2 c0 = {tf[0], tf[1]}, c1 = {tf[2], tf[3]}, c2 = {tf[4], tf[5]};
       const float z0 = tf[6], z1 = tf[7], z2 = tf[8];
@@ -2701,22 +2719,32 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
       const float Mz2 = __builtin_fmaf(-st, Az, ct * z2);
       const f32x2 nd = k2_pk_fma(M0, f32x2{Sf.ncx, Sf.ncx}, k2_pk_fma(M1, f32x2{Sf.ncy, Sf.ncy}, M2 * f32x2{Sf.ncz, Sf.ncz}));
       const float ndz = __builtin_fmaf(Mz0, Sf.ncx, __builtin_fmaf(Mz1, Sf.ncy, Mz2 * Sf.ncz));
-      const float* mf = reinterpret_cast<const float*>(e + 18 + 3 * F.nuo);  // the markers in single precision
+      // the markers in single precision
+      const float* mf = SCAN ? reinterpret_cast<const float*>(lt + 11) : reinterpret_cast<const float*>(e + 18 + 3 * F.nuo);
+      auto coords = [&](const int j) -> f32x2 {
+        const float mx = mf[3 * j], my = mf[3 * j + 1], mz = mf[3 * j + 2];
+        const f32x2 UV = k2_pk_fma(M0, f32x2{mx, mx}, k2_pk_fma(M1, f32x2{my, my}, k2_pk_fma(M2, f32x2{mz, mz}, nd)));
+        const float Z = __builtin_fmaf(Mz0, mx, __builtin_fmaf(Mz1, my, __builtin_fmaf(Mz2, mz, ndz)));
+        const float iZ = k2_rcpf(Z);
+        return UV * f32x2{iZ, iZ};
+      };
+      if constexpr (SCAN) {
+        uv0 = coords(0);
+        if (F.nuo > 1) uv1 = coords(1);  // (uniform)
+      } else {
 #pragma unroll
-      for (int j = 0; j < 2 * NP; ++j) {
-        if (j < F.nuo) {  // (nuo is uniform over the block)
-          const float mx = mf[3 * j], my = mf[3 * j + 1], mz = mf[3 * j + 2];
-          const f32x2 UV = k2_pk_fma(M0, f32x2{mx, mx}, k2_pk_fma(M1, f32x2{my, my}, k2_pk_fma(M2, f32x2{mz, mz}, nd)));
-          const float Z = __builtin_fmaf(Mz0, mx, __builtin_fmaf(Mz1, my, __builtin_fmaf(Mz2, mz, ndz)));
-          const float iZ = k2_rcpf(Z);
-          const f32x2 g = UV * f32x2{iZ, iZ};
-          K2_ON_GRID_COORD(F, rt, g1, g2, g3, p_2, d_12, b, e + 18 + 3 * j, tr, g.x, g.y);
-          grid_hits |= k2_grid_bit(F, g.x, g.y);
+        for (int j = 0; j < 2 * NP; ++j) {
+          if (j < F.nuo) {  // (nuo is uniform over the block)
+            const f32x2 g = coords(j);
+            K2_ON_GRID_COORD(F, rt, g1, g2, g3, p_2, d_12, b, e + 18 + 3 * j, tr, g.x, g.y);
+            grid_hits |= k2_grid_bit(F, g.x, g.y);
+          }
         }
       }
       // anything this chain could not evaluate (overflow, underflow: (cn, cd) of 1e-20) is left to the double-precision one
-      if (!(fabsf(nd.x + nd.y + ndz) < INFINITY)) grid_hits = 1u;
-    } else if constexpr (!SCAN && NP > 0) {
+      chain_ok = fabsf(nd.x + nd.y + ndz) < INFINITY;
+      if (!chain_ok) grid_hits = 1u;
+    } else if constexpr (NP > 0) {
 #pragma unroll
       for (int j = 0; j < 2 * NP; ++j)
         if (j < F.nuo) back_project(j);  // (nuo is uniform over the block)
@@ -2729,9 +2757,9 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
       // squared single-precision distances of one detection to marker 0 / marker 1, the smaller one against the
       // threshold (a NaN distance never wins, as in the exact search)
       auto near = [&](const f32x2 af) -> bool {
-        const f32x2 du = f32x2{af.x, af.x} - qfu, dv = f32x2{af.y, af.y} - qfv;
-        const f32x2 d2 = k2_pk_fma(dv, dv, du * du);
-        return k2_fminf(d2.x, d2.y) <= F.thr_pre;
+        const f32x2 d0 = af - uv0, d1 = af - uv1;
+        const f32x2 s0 = d0 * d0, s1 = d1 * d1;
+        return k2_fminf(s0.x + s0.y, s1.x + s1.y) <= F.thr_pre;
       };
       unsigned pass = (near(af0) ? lsb0 : 0u) | (near(af1) ? lsb1 : 0u);
       for (unsigned m = rest; m;) {  // (more than five detections)
@@ -2740,6 +2768,7 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
         m ^= lsb;
         pass |= near(F.pxf[a]) ? lsb : 0u;
       }
+      if (!chain_ok) pass = unused;  // (the double-precision evaluation decides)
       // slots by ballot: the queue's fill count is wave-uniform (a scalar register), no LDS atomic
       const bool want = root_sus || (pass != 0u && may_vote);
       const u64 bal = __ballot(want);
@@ -2748,13 +2777,9 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
         vq_count += (int)__builtin_popcountll(bal);
         if (!want) {
         } else if (slot < (unsigned)K2_VQ_CAP) {
-          u64* e = F.vq + (size_t)slot * K2_VQ_WORDS;
-          e[0] = (u64)__double_as_longlong(q0u);
-          e[1] = (u64)__double_as_longlong(q0v);
-          e[2] = (u64)__double_as_longlong(q1u);
-          e[3] = (u64)__double_as_longlong(q1v);
-          e[4] = k2_vq_meta(ii, (unsigned)packed, k, pass) |
-                 ((u64)(root_sus ? (item_sus ? K2_VQ_ITEM_SUS : K2_VQ_ROOT_SUS) : 0u) << 32);
+          u64* q = F.vq + (size_t)slot * K2_VQ_WORDS;
+          q[0] = (u64)__double_as_longlong(rt);
+          q[1] = k2_vq_meta(ti, pj, k, pass) | ((u64)(root_sus ? (item_sus ? K2_VQ_ITEM_SUS : K2_VQ_ROOT_SUS) : 0u) << 32);
         } else {
           // no room in the queue (6 or more lanes of the wave in one item: ~2e-5 of the hypotheses): this root, with
           // the detections that passed the prefilter, goes to the strict arithmetic like a suspect one — an exact
@@ -2824,7 +2849,7 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
   }
   rider.consume();  // P6: nothing of the scan is in flight while the next item fetches its table values
   if constexpr (SCAN) {
-    if (vq_count >= K2_VQ_CAP - 4) {  // wave-uniform
+    if (vq_count >= K2_VQ_CAP - 8) {  // wave-uniform
       k2_vote_flush(F, vq_count);
       vq_count = 0;
     }
@@ -2909,14 +2934,22 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
   f32x2* s_qf = DEFER ? reinterpret_cast<f32x2*>(s_grid + K2_GRID * K2_GRID_WORDS)
                       : reinterpret_cast<f32x2*>(s_q + (size_t)2 * nuo * nthr);
   __shared__ float s_gp[4];
-  __shared__ float s_trif[DEFER ? TRI : 1][12];  // (deferred variant) k2_triple_f32 of the staged triples
+  constexpr bool F32 = DEFER || SCAN;             // (see k2_vote_item)
+  __shared__ float s_trif[F32 ? TRI : 1][12];     // k2_triple_f32 of the staged triples
+  if constexpr (SCAN) {  // pixels, not grid cells: G = 1
+    if (tid == 0) {
+      s_gp[0] = 1.f;
+      s_gp[1] = 0.f;
+      s_gp[2] = 0.f;
+    }
+  }
   if constexpr (DEFER) {
     for (int i = tid; i < K2_GRID * K2_GRID_WORDS; i += nthr) s_grid[i] = 0;
     __syncthreads();
     k2_grid_build(s_px, n_d, sp.back_tol, s_grid, s_gp, tid, nthr);
     __syncthreads();
   }
-  const float thr_pre = k2_prefilter_threshold(sp.back_tol, DEFER ? 0.25 : 0.05);
+  const float thr_pre = k2_prefilter_threshold(sp.back_tol, F32 ? 0.25 : 0.05);
   const int esz = k2_entry_doubles(n_m);
   const double fx = sp.fx, fy = sp.fy, cx = sp.cx, cy = sp.cy;
   // block row with P1 <-> P2 exchanged: {2, 5, 0, 4, 3, 1}, packed 4 bits per row as 0x134052
@@ -2974,7 +3007,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
     // ---- per-triple part of computePoses (p3p.cpp:82-121, 143-154)
     if (tid < ntri) {
       k2_triple_entry(s_iv, n_d, tc0 + tid, fx, fy, cx, cy, s_tri[tid], s_trii[tid]);
-      if constexpr (DEFER) k2_triple_f32(s_tri[tid], s_gp, s_trif[tid]);
+      if constexpr (F32) k2_triple_f32(s_tri[tid], s_gp, s_trif[tid]);
     }
     __syncthreads();
 
@@ -3020,6 +3053,12 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
     }
     if constexpr (k2_defers(SCAN, NP)) {  // (the staged triples the queue's entries refer to are about to be replaced)
       k2_defer_flush<NP>(F, vq_count, true);
+    }
+    if constexpr (SCAN) {
+      if (tc0 + TRI < n_combos) {  // (more than 16 triples, i.e. more than 5 detections: the same)
+        k2_vote_flush(F, vq_count);
+        vq_count = 0;
+      }
     }
     if constexpr (!SCAN) k2_sus_flush(F, &s_sus_base);  // (the scan-carrying variant: once, behind the rider's last round)
   }

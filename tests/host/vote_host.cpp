@@ -169,6 +169,10 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   std::vector<u64> grid((size_t)K2_GRID * K2_GRID_WORDS, 0);  // occupancy grid of the deferred plain variant
   float gp[4] = {0, 0, 0, 0};
   k2_grid_build(px, n_d, sp.back_tol, grid.data(), gp, 0, 1);
+  if (variant == 1) {  // scan-carrying variant: pixel coordinates (G = 1)
+    gp[0] = 1.f;
+    gp[1] = gp[2] = 0.f;
+  }
   std::vector<float> trif((size_t)n_combos * 12);
   for (int i = 0; i < n_combos; ++i) k2_triple_f32(tri.data() + (size_t)i * 13, gp, trif.data() + (size_t)i * 12);
   int frame_status = 0;
@@ -215,10 +219,19 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   NoRider rider;
   if (variant == 1) {
     if (nuo > 2) return -2;  // the scan-carrying variant keeps at most two back-projections (in registers)
+    // as on the device: 16 staged triples at a time (a queue entry names its triple by the index within the chunk), the
+    // queue worked off before the next chunk is staged
     int vq_count = 0;
-    for (int ti = 0; ti < n_combos; ++ti)
-      for (int pj = 0; pj < n_perms; ++pj) k2_vote_item<true>(F, ti, pj, true, rider, vq_count);
-    k2_vote_flush(F, vq_count);
+    for (int tc0 = 0; tc0 < n_combos; tc0 += K2_TRI_CHUNK_SCAN) {
+      K2Frame Fc = F;
+      Fc.trii = F.trii + tc0;
+      Fc.tri = F.tri + tc0;
+      Fc.trif = F.trif + tc0;
+      for (int ti = 0; ti < std::min(K2_TRI_CHUNK_SCAN, n_combos - tc0); ++ti)
+        for (int pj = 0; pj < n_perms; ++pj) k2_vote_item<true>(Fc, ti, pj, true, rider, vq_count);
+      k2_vote_flush(Fc, vq_count);
+      vq_count = 0;
+    }
   } else {
     int unused = 0;  // (np >= 2: the fill count of the deferred-evaluation queue)
     // the instantiation the launcher would pick: (nuo + 1) / 2 marker pairs in registers up to 8 unused markers

@@ -26,12 +26,12 @@ def _build(d, tiny_queues=False):
     internal = open(os.path.join(CSRC, "mpe_internal.h")).read()
     inc = _cut(internal, "struct SolveParams {", "#define MPE_HIST_STRIDE")
     inc += _cut(hip, "// lexicographic unranking of the idx-th 3-combination", "#define K2_THREADS")
-    inc += _cut(hip, "#define K2_LTAB", "__global__ void k2_prep_markers(")
+    inc += _cut(hip, "#define K2_TRI_CHUNK 64", "__global__ void k2_prep_markers(")
     inc += _cut(hip, "struct NoRider {", "// Voting kernel.  Work item =")   # incl. the deferred-vote queue
     inc += _cut(hip, "// One hypothesis in the STRICT arithmetic", "// Strict voting kernel (option")
     if tiny_queues:  # capacities at which the "no room: vote on the spot" paths run all the time
-        assert "#define K2_VQ_CAP 12" in inc
-        inc = inc.replace("#define K2_VQ_CAP 12", "#define K2_VQ_CAP 5")
+        assert "#define K2_VQ_CAP 28" in inc
+        inc = inc.replace("#define K2_VQ_CAP 28", "#define K2_VQ_CAP 9")
     with open(os.path.join(d, "vote_extract.inc"), "w") as fh:
         fh.write(inc)
     so = os.path.join(d, "libvote_host.so")
