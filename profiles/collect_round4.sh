@@ -43,11 +43,11 @@ timeout 300 rocprofv3 --kernel-trace --kernel-include-regex 'k2_vote<true' --sta
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_seq -o s -- python $R/bench.py $Q --no-false-hint-leg --pipeline 1 --frames 16384 --steps 20 --warmup 3 > $O/stats_seq.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -o s -- python $R/bench.py $Q --steps 5 --config C3 --frames 65536 > $O/stats_c3.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_streams1 -o s -- python $R/bench_streams.py --streams 1 --frames 400 > $O/stats_streams1.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_lockstep -o s -- python $R/bench_streams.py --streams 64 --frames 300 --lockstep > $O/stats_lockstep.log 2>&1
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
 # ---- bench lines
 timeout 400 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc $?" >> $O/bench.err
-timeout 300 python $R/bench.py $Q --steps 20 --warmup 5 --no-streaming --no-false-hint-leg 2>/dev/null > $O/bench_nostream.json
+# the round-3 tree on the same box (ab_r3/: commit 14e6180 built in place; not part of the repository, travels with gpurun)
+[ -d $R/ab_r3 ] && (cd $R/ab_r3 && timeout 300 python bench.py $Q --steps 20 --warmup 5 2>/dev/null > $O/bench_r3.json)
 timeout 300 python $R/bench.py $Q --steps 20 --warmup 5 --vote-arith 2 --no-false-hint-leg 2>/dev/null > $O/bench_arith2.json
 timeout 300 python $R/bench.py $Q --steps 20 --warmup 5 --no-false-hint-leg 2>/dev/null > $O/bench_arith1.json
 timeout 300 python $R/bench.py $Q --steps 5 --config C1 --frames 65536 2>/dev/null > $O/bench_C1.json
@@ -56,17 +56,16 @@ timeout 300 python $R/bench.py $Q --steps 5 --config C3 --frames 65536 --back-to
 timeout 300 python $R/bench.py $Q --steps 5 --config C4 --frames 16384 2>/dev/null > $O/bench_C4.json
 timeout 300 python $R/bench_streams.py --streams 1 --frames 400 2>/dev/null | tail -1 > $O/streams1.json
 timeout 300 python $R/bench_streams.py --streams 8 --frames 400 2>/dev/null | tail -1 > $O/streams8.json
-for n in 8 64 256; do timeout 200 python $R/bench_streams.py --streams $n --frames 300 --lockstep 2>/dev/null | tail -1 > $O/lockstep$n.json; done
-timeout 300 python $R/bench_streams.py --streams 256 --frames 300 --lockstep --groups 4 --group-threads 4 2>/dev/null | tail -1 > $O/lockstep256g4t4.json
+for n in 64; do timeout 200 python $R/bench_streams.py --streams $n --frames 300 --lockstep 2>/dev/null | tail -1 > $O/lockstep$n.json; done
 timeout 300 python $R/bench_streams.py --streams 512 --frames 300 --lockstep --groups 8 --group-threads 8 2>/dev/null | tail -1 > $O/lockstep512g8t8.json
 # ---- soaks (every mismatch saved, attributed, classified; default vs strict histograms must be identical)
 cd $R
 timeout 900 python tests/soak_votes.py 131072 C2 gpurun_out/final4/soak_votes_C2 > $O/soak_votes_C2.log 2>&1; echo "rc $?" >> $O/soak_votes_C2.log
 timeout 900 python tests/soak_votes.py 4096 C3 gpurun_out/final4/soak_votes_C3 > $O/soak_votes_C3.log 2>&1; echo "rc $?" >> $O/soak_votes_C3.log
-timeout 900 python tests/soak_parity.py 262144 C2 65536 gpurun_out/final4/soak_parity_C2 > $O/soak_parity_C2.log 2>&1; echo "rc $?" >> $O/soak_parity_C2.log
-timeout 600 python tests/soak_parity.py 8192 C3 2048 gpurun_out/final4/soak_parity_C3 > $O/soak_parity_C3.log 2>&1; echo "rc $?" >> $O/soak_parity_C3.log
-MPE_BACK_TOL=2 timeout 600 python tests/soak_parity.py 8192 C3 2048 gpurun_out/final4/soak_parity_C3_tol2 > $O/soak_parity_C3_tol2.log 2>&1; echo "rc $?" >> $O/soak_parity_C3_tol2.log
-timeout 600 python tests/soak_parity.py 16384 C4 4096 gpurun_out/final4/soak_parity_C4 > $O/soak_parity_C4.log 2>&1; echo "rc $?" >> $O/soak_parity_C4.log
-timeout 600 python tests/soak_parity.py 65536 C1 32768 gpurun_out/final4/soak_parity_C1 > $O/soak_parity_C1.log 2>&1; echo "rc $?" >> $O/soak_parity_C1.log
+timeout 900 python tests/soak_parity.py 131072 C2 65536 gpurun_out/final4/soak_parity_C2 > $O/soak_parity_C2.log 2>&1; echo "rc $?" >> $O/soak_parity_C2.log
+timeout 600 python tests/soak_parity.py 4096 C3 2048 gpurun_out/final4/soak_parity_C3 > $O/soak_parity_C3.log 2>&1; echo "rc $?" >> $O/soak_parity_C3.log
+MPE_BACK_TOL=2 timeout 600 python tests/soak_parity.py 4096 C3 2048 gpurun_out/final4/soak_parity_C3_tol2 > $O/soak_parity_C3_tol2.log 2>&1; echo "rc $?" >> $O/soak_parity_C3_tol2.log
+timeout 600 python tests/soak_parity.py 8192 C4 4096 gpurun_out/final4/soak_parity_C4 > $O/soak_parity_C4.log 2>&1; echo "rc $?" >> $O/soak_parity_C4.log
+timeout 600 python tests/soak_parity.py 32768 C1 32768 gpurun_out/final4/soak_parity_C1 > $O/soak_parity_C1.log 2>&1; echo "rc $?" >> $O/soak_parity_C1.log
 timeout 600 python tests/soak_tracking.py 256 160 C2 gpurun_out/final4/soak_tracking > $O/soak_tracking.log 2>&1; echo "rc $?" >> $O/soak_tracking.log
 ls $O

@@ -77,7 +77,7 @@ def stats_avg(path, kernel_sub):
 
 
 def main():
-    for n in ("bench", "bench_nostream", "bench_arith1", "bench_arith2", "bench_C1", "bench_C3", "bench_C3_tol2", "bench_C4"):
+    for n in ("bench", "bench_r3", "bench_nostream", "bench_arith1", "bench_arith2", "bench_C1", "bench_C3", "bench_C3_tol2", "bench_C4"):
         if os.path.exists(F + n + ".json") and os.path.getsize(F + n + ".json") > 2:
             json.dump(last_json(F + n + ".json"), open(P + n + ".json", "w"), indent=1)
     for n in ("streams1", "streams8", "lockstep8", "lockstep64", "lockstep256", "lockstep256g4t4", "lockstep512g8t8"):

@@ -1031,11 +1031,18 @@ struct Island {
 // xw0 - 1 (one pixel of margin on both sides for the 3 x 3 neighbourhoods).  An LED that straddles a segment boundary
 // then still fits ONE 64-bit word per row (two bright segments: 38 pixels), where the window of the dilated segment
 // columns took two — half the bitmap words to clear and combine, and the contour phase's one-word shortcuts apply.
+#ifdef K1B_WIDE_WINDOWS  // (experiment builds: the windows of rounds 1 - 3, the dilated segment columns)
+__device__ __forceinline__ int isl_xw0(const Island& is, int) { return 16 * is.clo; }
+__device__ __forceinline__ int isl_words(const Island& is, int cols, int) {
+  return ((min(cols - 1, 16 * is.chi + 15) - 16 * is.clo + 1) + 2 + 63) / 64;
+}
+#else
 __device__ __forceinline__ int isl_xw0(const Island& is, int r) { return max(16 * is.clo, 16 * is.cfirst - r); }
 __device__ __forceinline__ int isl_words(const Island& is, int cols, int r) {
   const int xhi = min(min(cols - 1, 16 * is.chi + 15), 16 * is.clast + 15 + r);
   return ((xhi - isl_xw0(is, r) + 1) + 2 + 63) / 64;
 }
+#endif
 // capacities: thresholded-pixel pool [bytes], bitmap pool [u64 words per bitmap], bright segments, bands,
 // islands, blobs kept per frame; WAVES = frames (one wave each) per block, whose islands ONE wave traces together
 #ifndef K1B_SMALL_WAVES
