@@ -116,8 +116,10 @@ def main():
     ap.add_argument("--k1a-lds", type=int, default=-1, help="tuning: dummy LDS per scan block (-1 = automatic)")
     ap.add_argument("--pipeline-mode", type=int, default=-1,
                     help="-1 automatic, 0 two-stream pipeline, 3 fused, 4 fused + side-stream tail, 6 = 4 + split scan")
-    ap.add_argument("--side-scan-blocks", type=int, default=3, help="mode 6: resident blocks per CU of the side scan")
-    ap.add_argument("--scan-split-pct", type=int, default=30, help="mode 6: share of a sub-batch scanned on the side stream")
+    ap.add_argument("--side-scan-blocks", type=int, default=-1,
+                    help="mode 6: resident blocks per CU of the side scan (-1 = the library's default)")
+    ap.add_argument("--scan-split-pct", type=int, default=-1,
+                    help="mode 6: share of a sub-batch scanned on the side stream (-1 = the library's default)")
     ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
     ap.add_argument("--vote-arith", type=int, default=1,
                     help="1 fast voting arithmetic with its suspects re-evaluated by the strict functions (default), "
@@ -212,8 +214,10 @@ def main():
     h.set_option("pipeline_mode", args.pipeline_mode)
     h.set_option("vote_arith", args.vote_arith)
     h.set_option("vote_splits", args.vote_splits)
-    h.set_option("scan_split_pct", args.scan_split_pct)
-    h.set_option("side_scan_blocks", args.side_scan_blocks)
+    if args.scan_split_pct >= 0:
+        h.set_option("scan_split_pct", args.scan_split_pct)
+    if args.side_scan_blocks >= 0:
+        h.set_option("side_scan_blocks", args.side_scan_blocks)
     if args.assume_side_streams:
         h.set_option("assume_side_streams", 1)
     if args.k1a_lds >= 0:
@@ -554,6 +558,7 @@ def main():
                        "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel", 4: "fused + validate/refine on a side stream",
                                     6: "fused + side-stream tail + scan split between a side k1a_scan and the rider"}.get(schedule, schedule),
                        "side_streams_concurrent": h.get_option("streams_concurrent"),
+                       "scan_split_pct": h.get_option("scan_split_pct"), "side_scan_blocks": h.get_option("side_scan_blocks"),
                        "entry": ("mpe_estimate_batch_device_submit / _collect: a stream of batches, each announcing the "
                                  "next one's frames" if streaming else "mpe_estimate_batch_device, one joined call per step"),
                        "records_to_host": bool(args.records_to_host),

@@ -723,11 +723,12 @@ def test_full_size_batch_properties(orc):
     fused4 = run(frames, 8)
     assert h.get_option("last_schedule") == 4 and torch.equal(fused4, plain)
     h.set_option("pipeline_mode", 6)                       # ... + the scan split between a side scan kernel and the rider
+    default_pct = h.get_option("scan_split_pct")
     for pct in (20, 0, 55):
         h.set_option("scan_split_pct", pct)
         fused6 = run(frames, 8)
         assert h.get_option("last_schedule") == 6 and torch.equal(fused6, plain), pct
-    h.set_option("scan_split_pct", 30)
+    h.set_option("scan_split_pct", default_pct)
     h.set_option("pipeline_mode", -1)                      # automatic = 6
     piped = run(frames, 8)
     assert h.get_option("last_schedule") == 6 and torch.equal(piped, plain)
