@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, FINAL collection with the committed binary: the GPU suite, the bench line, every profiler pass the bench line
 # and DESIGN.md quote (tied to the sources by source_fingerprint), the other configs, tracked-frame benches, soaks.
-#   gpurun --timeout 3000 -- 'bash profiles/collect_round4.sh'; then python profiles/install_round4.py
+#   gpurun --timeout 2400 -- 'bash profiles/collect_round4.sh'; then python profiles/install_round4.py
 # Counter passes: `--kernel-trace` + `--pmc` only, FETCH_SIZE / WRITE_SIZE / SQ in separate runs, mpe:: kernels only.
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final4
@@ -11,8 +11,7 @@ cd $R && timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; 
 cd /tmp
 python -c "import sys; sys.path.insert(0, '$R'); import rpg_monocular_pose_estimator_amd as m; print(m.source_fingerprint())" > $O/source_fingerprint.txt
 Q="--no-cpu --no-host-leg"
-# ---- counter passes first (the bench line below then finds profiles/round4_pmc.json of THIS collection? no: that file
-#      is installed afterwards; the committed bench line is re-taken by collect_round4_bench_only.sh)
+# ---- counter passes first
 SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE"
 INC='--kernel-include-regex mpe::'
 pmc() {  # name, counters, bench args...
@@ -44,6 +43,10 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_seq
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -o s -- python $R/bench.py $Q --steps 5 --config C3 --frames 65536 > $O/stats_c3.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_streams1 -o s -- python $R/bench_streams.py --streams 1 --frames 400 > $O/stats_streams1.log 2>&1
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
+# ---- the counter file of THIS collection, installed on the box (the same command is run again at home on the merged
+#      gpurun_out/ and produces the same file): the bench line below then carries roofline.traffic / frac_rocprofv3 from
+#      counters of the binary it times (source_fingerprint match True)
+python $R/profiles/install_round4.py > $O/install_on_box.log 2>&1
 # ---- bench lines
 timeout 400 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc $?" >> $O/bench.err
 # the round-3 tree on the same box (ab_r3/: commit 14e6180 built in place; not part of the repository, travels with gpurun)
