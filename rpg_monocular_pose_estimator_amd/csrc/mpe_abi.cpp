@@ -119,8 +119,12 @@ struct mpe_handle {
   int ingest_chunk = 2048;            // frames per ingest chunk (option "ingest_chunk"; 0 = one blocking copy per call)
   hipStream_t scan_stream = nullptr;  // mode 6: part of the next-but-one sub-batch's scan beside blobs / tail
   hipEvent_t scanpart_done[kMaxSub] = {};
-  int side_scan_blocks = 3;           // mode 6: resident blocks per CU of the side scan (4 waves each)
-  int scan_split_pct = 30;            // mode 6: share of a sub-batch scanned by the stand-alone kernel on the side stream
+  // mode 6: resident blocks per CU of the side scan (4 waves each) and the share of a sub-batch it scans on the side
+  // stream.  Round 4: ONE block, 28 % — three blocks (round 3) crowd the blob kernel (window 0.84 instead of 0.50 ms per
+  // 32 768 frames) and, once the voting launch got shorter, did not even finish inside blob window + vote; one block
+  // streams at ~1.5 TB/s beside the rider for the whole period (same-box sweeps: profiles/round4_sweep_side_scan.json)
+  int side_scan_blocks = 1;
+  int scan_split_pct = 28;
   unsigned long long last_rider_bytes = 0;  // bytes one fused voting launch scanned in the last large call
   hipStream_t tail_stream = nullptr;  // fused schedule, mode 4: validate + refine of sub-batch s beside blobs(s + 1)
   hipEvent_t tail_done = nullptr;
@@ -784,8 +788,9 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     // mode 6: the HBM stream is spread over the whole sub-batch period.  In modes 3 / 4 the voting kernel scans all
     // of the next sub-batch and is HBM bound (0.95 ms for 5.9 GB) with 40 % of its issue slots idle, while the blob /
     // tail window before it (0.4 ms) moves no image bytes.  Here a stand-alone k1a_scan on a side stream takes
-    // scan_split_pct % of sub-batch s + 2 DURING the blob / tail window of sub-batch s + 1 (its 48-VGPR waves fit
-    // beside four blob waves per SIMD, it needs no LDS), and the rider of vote(s + 1) scans only the rest.
+    // scan_split_pct % of sub-batch s + 2 from the end of vote(s) to the start of blobs(s + 2) — the blob / tail window of
+    // sub-batch s + 1 and its voting launch — as side_scan_blocks resident blocks per CU (48-VGPR waves, no LDS), and the
+    // rider of vote(s + 1) scans only the rest.
     const bool split_scan = schedule == 6 && h->scan_split_pct > 0;
     if (split_scan) {
       for (auto& e : h->scanpart_done)

@@ -659,6 +659,12 @@ __device__ __forceinline__ int bitpos_sum(u64 m) {  // sum of the positions of t
 #ifndef K1B_CELL_LANE_ITEMS
 #define K1B_CELL_LANE_ITEMS 3
 #endif
+#ifdef K1B_STOP_AFTER  // (experiment builds, see K1B_STOP_POINT: 41 .. 44 end the contour phase early)
+#define K1B_CELL_STOP(PHASE) \
+  if (K1B_STOP_AFTER == (PHASE)) return 0u;
+#else
+#define K1B_CELL_STOP(PHASE)
+#endif
 template <class Emit>
 __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng, CellIsl* cs, int nisl, int lane, int nl,
                                                 const DetectParams& dp, int roi_x, int roi_y, Emit emit) {
@@ -747,6 +753,7 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
     if (it_o[t] >= 0) pm[it_o[t]] = 0;
   }
   wave_sync();
+  K1B_CELL_STOP(41)
   // ---- the usual LED needs no flood: an island one word wide whose occupied rows are contiguous, each a single run
   //      that touches (8-neighbourhood) the run of the next row, is ONE component, and no background pixel of it is
   //      enclosed (it escapes along its own row, on its side of the run) — all its pixels are the first component
@@ -770,6 +777,7 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
     if (bad) cs[k].simple = 0;
   }
   wave_sync();
+  K1B_CELL_STOP(42)
   for (int round = 0;; ++round) {
     // ---- seed: the raster-first remaining pixel of every island still in progress
     for (int k = lane; k < nisl; k += nl) cs[k].seed = kIntMax;
@@ -833,6 +841,7 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
       wave_sync();
     } while (__builtin_amdgcn_ballot_w64(changed) != 0 && ++it < K1B_CELL_ITERS);
     const bool settled = it < K1B_CELL_ITERS;
+    K1B_CELL_STOP(43)
     // ---- sums over the cells of the row pairs (slot, slot + 1)
 #pragma unroll
     for (int t = 0; t < NIT; ++t) {
@@ -863,6 +872,7 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
       }
     }
     wave_sync();
+    K1B_CELL_STOP(44)
     // ---- one lane per island: the blob record through the shape filter, or the island to the border trace
     for (int k = lane; k < nisl; k += nl) {
       if (cs[k].state != 0) continue;
