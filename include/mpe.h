@@ -138,6 +138,10 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
  * each, stride = cols), which is what every other entry point takes.  src / dst may each be a host or a device pointer.
  *   MPE_ENC_BGR8 / RGB8 / BGRA8 / RGBA8: cv::cvtColor(..., COLOR_{BGR,RGB,BGRA,RGBA}2GRAY) on CV_8U:
  *       Y = (B * 1868 + G * 9617 + R * 4899 + 2^13) >> 14   (integer, bit-exact)
+ *       — the 14-bit weights of OpenCV 2.4 and 3.0 .. 3.4.1, the versions the reference's ROS Indigo / Kinetic ship.
+ *       OpenCV >= 3.4.2 / 4.x use 15-bit weights (9798, 19235, 3735, >> 15) and can differ by one gray level: a caller
+ *       linked against one of those keeps cv_bridge for colour frames (compat/ros/mpe_ros_glue.cpp does, unless built
+ *       with -DMPE_OPENCV_GRAY_14BIT)
  *   MPE_ENC_MONO16: cv::Mat::convertTo(CV_8U, 255. / 65535.) = saturate_cast<uchar>((float)v * (float)(255. / 65535.)),
  *       after cv_bridge's byte swap when Image.is_bigendian differs from the host (src_big_endian)
  *   MPE_ENC_MONO8: a (strided) copy.

@@ -778,6 +778,95 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
   }
   wave_sync();
   K1B_CELL_STOP(42)
+  // the cells of the row pair (slot, slot + 1) of one item: a / an = this row's word and the next word of the row, c / cn =
+  // the same of the row below (pixels of the component only)
+  auto item_sums = [&](const int m, const u64 a, const u64 an, const u64 c, const u64 cn) {
+    const int k = isl_of(m), w = w_of(m), slot = slot_of(m);
+    if (slot > cs[k].hi) return;
+    const u64 b = (a >> 1) | (an << 63), d = (c >> 1) | (cn << 63);
+    if ((a | b | c | d) == 0) return;
+    const u64 full = a & b & c & d;
+    const u64 t1 = ~a & b & c & d, t2 = a & ~b & c & d, t3 = a & b & ~c & d, t4 = a & b & c & ~d;  // missing tl tr bl br
+    const u64 tri = t1 | t2 | t3 | t4;
+    const u64 one = (a ^ b ^ c ^ d) & ~tri;
+    const u64 diag = (a & d & ~b & ~c) | (b & c & ~a & ~d);
+    const int nf = __builtin_popcountll(full), nt = __builtin_popcountll(tri);
+    const int Xb = cs[k].xw0 + 64 * w - 1, Yb = cs[k].ylo + slot - 1;  // image coordinates of bit 0 / of this row
+    atomicAdd(&cs[k].a00, 2 * nf + nt);
+    atomicAdd(&cs[k].a10, 6 * (nf * Xb + bitpos_sum(full)) + 3 * nf + 3 * (nt * Xb + bitpos_sum(tri)) +
+                              2 * __builtin_popcountll(t1 | t3) + __builtin_popcountll(t2 | t4));
+    atomicAdd(&cs[k].a01, (6 * Yb + 3) * nf + 3 * Yb * nt + 2 * __builtin_popcountll(t1 | t2) +
+                              __builtin_popcountll(t3 | t4));
+    atomicAdd(&cs[k].chi, __builtin_popcountll(one) - nt - 2 * __builtin_popcountll(diag));
+    if (a) {
+      atomicMin(&cs[k].xmin, 64 * w + __builtin_ctzll(a));
+      atomicMax(&cs[k].xmax, 64 * w + 63 - __builtin_clzll(a));
+      atomicMin(&cs[k].ymin, slot);
+      atomicMax(&cs[k].ymax, slot);
+    }
+  };
+  // island k's component: its record through the shape filter, or the island to the border trace
+  auto island_record = [&](const int k, const bool settled) {
+    if (cs[k].state != 0) return;
+    if (!settled || cs[k].chi != 4) {
+      cs[k].state = 2;  // a hole (or a flood that did not settle): the literal trace decides
+    } else {
+      BlobRec br;
+      br.a00 = cs[k].a00;
+      br.a10 = cs[k].a10;
+      br.a01 = cs[k].a01;
+      br.xmin = cs[k].xmin + cs[k].xw0 - 1;
+      br.xmax = cs[k].xmax + cs[k].xw0 - 1;
+      br.ymin = cs[k].ymin + cs[k].ylo - 1;
+      br.ymax = cs[k].ymax + cs[k].ylo - 1;
+      const int sd = cs[k].seed;
+      const unsigned key = ((unsigned)(cs[k].ylo + (sd >> 16) - 1) << 12) | (unsigned)((sd & 0xFFFF) + cs[k].xw0 - 1);
+      K1B_ON_BLOBREC(br, key);
+      float mcx, mcy;
+      if (blob_filter(br, dp, roi_x, roi_y, mcx, mcy)) {
+        if (cs[k].nblob >= K1B_CELL_BLOBS) {
+          cs[k].state = 2;  // more blobs than the island record holds
+        } else {
+          const int n = cs[k].nblob++;
+          cs[k].bx[n] = mcx;
+          cs[k].by[n] = mcy;
+          cs[k].bkey[n] = key;
+        }
+      }
+    }
+    cs[k].a00 = cs[k].a10 = cs[k].a01 = cs[k].chi = 0;
+    cs[k].xmin = cs[k].ymin = kIntMax;
+    cs[k].xmax = cs[k].ymax = -1;
+  };
+  // ---- every island of the frame is such a one-component island (the usual frame): no seeds, no flood, no mark bitmap
+  //      — the component's rows are the bitmap's rows, its start pixel the first pixel of its first row
+  bool flood_needed = false;
+  for (int k = lane; k < nisl; k += nl) flood_needed = flood_needed || (cs[k].state == 0 && !cs[k].simple);
+  if (__builtin_amdgcn_ballot_w64(flood_needed) == 0) {
+#pragma unroll
+    for (int t = 0; t < NIT; ++t) {
+      if (it_o[t] < 0) continue;
+      const int k = isl_of(it_m[t]);
+      if (cs[k].state != 0) continue;
+      if (slot_of(it_m[t]) == cs[k].lo) cs[k].seed = (cs[k].lo << 16) | __builtin_ctzll(rem[t]);  // (W == 1, rem != 0)
+      item_sums(it_m[t], rem[t], 0, nz[it_o[t] + 1], 0);
+    }
+    wave_sync();
+    K1B_CELL_STOP(44)
+    unsigned todo1 = 0;
+    for (int k = lane; k < nisl; k += nl) {
+      island_record(k, true);
+      if (cs[k].state == 0) cs[k].state = 1;
+      if (cs[k].state == 2)
+        todo1 |= 1u << k;
+      else
+        for (int n = 0; n < cs[k].nblob; ++n) emit(cs[k].bx[n], cs[k].by[n], cs[k].bkey[n]);
+    }
+    // (the islands' states sit in different lanes: a wave-wide OR)
+    unsigned todo_all = 0;
+    for (int k = 0; k < nisl; ++k) todo_all |= (__builtin_amdgcn_ballot_w64(((todo1 >> k) & 1u) != 0) != 0) ? 1u << k : 0u;
+    return todo_all;
+  }
   for (int round = 0;; ++round) {
     // ---- seed: the raster-first remaining pixel of every island still in progress
     for (int k = lane; k < nisl; k += nl) cs[k].seed = kIntMax;
@@ -846,66 +935,13 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
 #pragma unroll
     for (int t = 0; t < NIT; ++t) {
       if (!on[t]) continue;
-      const int k = isl_of(it_m[t]), W = W_of(it_m[t]), w = w_of(it_m[t]), slot = slot_of(it_m[t]), o = it_o[t];
-      if (slot > cs[k].hi) continue;
-      const u64 a = cur[t], an = w + 1 < W ? pm[o + 1] : 0, c = pm[o + W], cn = w + 1 < W ? pm[o + W + 1] : 0;
-      const u64 b = (a >> 1) | (an << 63), d = (c >> 1) | (cn << 63);
-      if ((a | b | c | d) == 0) continue;
-      const u64 full = a & b & c & d;
-      const u64 t1 = ~a & b & c & d, t2 = a & ~b & c & d, t3 = a & b & ~c & d, t4 = a & b & c & ~d;  // missing tl tr bl br
-      const u64 tri = t1 | t2 | t3 | t4;
-      const u64 one = (a ^ b ^ c ^ d) & ~tri;
-      const u64 diag = (a & d & ~b & ~c) | (b & c & ~a & ~d);
-      const int nf = __builtin_popcountll(full), nt = __builtin_popcountll(tri);
-      const int Xb = cs[k].xw0 + 64 * w - 1, Yb = cs[k].ylo + slot - 1;  // image coordinates of bit 0 / of this row
-      atomicAdd(&cs[k].a00, 2 * nf + nt);
-      atomicAdd(&cs[k].a10, 6 * (nf * Xb + bitpos_sum(full)) + 3 * nf + 3 * (nt * Xb + bitpos_sum(tri)) +
-                                2 * __builtin_popcountll(t1 | t3) + __builtin_popcountll(t2 | t4));
-      atomicAdd(&cs[k].a01, (6 * Yb + 3) * nf + 3 * Yb * nt + 2 * __builtin_popcountll(t1 | t2) +
-                                __builtin_popcountll(t3 | t4));
-      atomicAdd(&cs[k].chi, __builtin_popcountll(one) - nt - 2 * __builtin_popcountll(diag));
-      if (a) {
-        atomicMin(&cs[k].xmin, 64 * w + __builtin_ctzll(a));
-        atomicMax(&cs[k].xmax, 64 * w + 63 - __builtin_clzll(a));
-        atomicMin(&cs[k].ymin, slot);
-        atomicMax(&cs[k].ymax, slot);
-      }
+      const int W = W_of(it_m[t]), w = w_of(it_m[t]), o = it_o[t];
+      item_sums(it_m[t], cur[t], w + 1 < W ? pm[o + 1] : 0, pm[o + W], w + 1 < W ? pm[o + W + 1] : 0);
     }
     wave_sync();
     K1B_CELL_STOP(44)
     // ---- one lane per island: the blob record through the shape filter, or the island to the border trace
-    for (int k = lane; k < nisl; k += nl) {
-      if (cs[k].state != 0) continue;
-      if (!settled || cs[k].chi != 4) {
-        cs[k].state = 2;  // a hole (or a flood that did not settle): the literal trace decides
-      } else {
-        BlobRec br;
-        br.a00 = cs[k].a00;
-        br.a10 = cs[k].a10;
-        br.a01 = cs[k].a01;
-        br.xmin = cs[k].xmin + cs[k].xw0 - 1;
-        br.xmax = cs[k].xmax + cs[k].xw0 - 1;
-        br.ymin = cs[k].ymin + cs[k].ylo - 1;
-        br.ymax = cs[k].ymax + cs[k].ylo - 1;
-        const int sd = cs[k].seed;
-        const unsigned key = ((unsigned)(cs[k].ylo + (sd >> 16) - 1) << 12) | (unsigned)((sd & 0xFFFF) + cs[k].xw0 - 1);
-        K1B_ON_BLOBREC(br, key);
-        float mcx, mcy;
-        if (blob_filter(br, dp, roi_x, roi_y, mcx, mcy)) {
-          if (cs[k].nblob >= K1B_CELL_BLOBS) {
-            cs[k].state = 2;  // more blobs than the island record holds
-          } else {
-            const int n = cs[k].nblob++;
-            cs[k].bx[n] = mcx;
-            cs[k].by[n] = mcy;
-            cs[k].bkey[n] = key;
-          }
-        }
-      }
-      cs[k].a00 = cs[k].a10 = cs[k].a01 = cs[k].chi = 0;
-      cs[k].xmin = cs[k].ymin = kIntMax;
-      cs[k].xmax = cs[k].ymax = -1;
-    }
+    for (int k = lane; k < nisl; k += nl) island_record(k, settled);
 #pragma unroll
     for (int t = 0; t < NIT; ++t) {  // the component leaves the remaining set
       if (it_o[t] < 0) continue;
@@ -4403,7 +4439,7 @@ __global__ __launch_bounds__(64) void k_quartic_batch(const double* __restrict__
 // frame decode: sensor_msgs/Image payloads -> mono8 (what cv_bridge::toCvCopy(msg, MONO8) does for the node,
 // monocular_pose_estimator.cpp:147).  HBM bound, one pass: 4 output pixels per lane and step.
 //   bgr8 / rgb8 / bgra8 / rgba8: cv::cvtColor(..., COLOR_*2GRAY) for CV_8U — integer, 14 fractional bits,
-//       Y = (B * 1868 + G * 9617 + R * 4899 + 2^13) >> 14
+//       Y = (B * 1868 + G * 9617 + R * 4899 + 2^13) >> 14   (OpenCV 2.4, 3.0 .. 3.4.1; from 3.4.2 on: 15 bits, see mpe.h)
 //   mono16 (host byte order after cv_bridge's endianness fix): Mat::convertTo(CV_8U, 255. / 65535.) —
 //       saturate_cast<uchar>((float)v * (float)(255. / 65535.)), i.e. round-half-even of the single-precision product
 // =============================================================================================
