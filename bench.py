@@ -419,6 +419,7 @@ def main():
     traffic_source = None
     pmc_all = {}
     pmc_matches_binary = None
+    pmc_file = "round4_pmc.json"
     try:
         pmc_file = "round4_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "round4_pmc.json")) else "round3_pmc.json"
         with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
@@ -439,8 +440,8 @@ def main():
     if fused:
         # the rocprofv3 average of the same kernel in the same command, from the committed kernel-trace pass that traces
         # ONLY this kernel (profiles/: `--kernel-include-regex k2_vote<true`); `frac` is the LOWER of the two clocks
-        rp = pmc_all.get("k2_vote_scan", {}).get("rocprof_avg_launch_ms") if pmc_all.get("k2_vote_scan", {}).get(
-            "rocprof_bytes_per_launch") == bytes_per_launch else None
+        rp = pmc_all.get("k2_vote_scan", {}).get("rocprof_avg_launch_ms") if (args.config == "C2" and pmc_all.get(
+            "k2_vote_scan", {}).get("rocprof_bytes_per_launch") == bytes_per_launch) else None
         frac_events = achieved / 8000.0
         frac_rocprof = (bytes_per_launch / (rp * 1e-3) / 1e9 / 8000.0) if rp else None
         roofline = {"kernel": "k2_vote<scan>", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -464,7 +465,12 @@ def main():
                                 "voting wave streams its share of the next sub-batch's pixels through LDS DMA "
                                 "(global_load_lds) between pieces of P3P arithmetic; bytes = the pixels it scans, "
                                 "time = the whole fused launch (the voting alone: kernel_ms_isolated.vote / "
-                                "launches).  roofline_isolated = the stand-alone scan kernel."}
+                                "launches).  roofline_isolated = the stand-alone scan kernel.  Default schedule "
+                                "since round 4: a one-block-per-CU k1a_scan on a side stream streams config.scan_split_pct "
+                                "% of the next-but-one sub-batch BESIDE this launch for its whole length — the HBM "
+                                "stream is shared on purpose (three blocks per CU finished earlier, crowded the blob "
+                                "kernel and cost 10 % of the step), so this kernel's own fraction is lower than "
+                                "round 3's while step_hbm, the whole step's rate, is higher."}
     elif vote_bound:
         # FP64 VALU issue: a wave64 FP64 instruction occupies a SIMD for 4 cycles -> 1024 SIMDs x clock / 4 wave-
         # instructions per second; the instruction count per frame is the committed SQ_INSTS_VALU pass of this kernel
@@ -609,7 +615,7 @@ def main():
             out["k2_rates"]["valu_util_at_nominal_2.4GHz"] = vp["valu_insts_per_frame"] * n_fr * 4.0 / (1024 * 2.4e9 * t_s)
             out["k2_rates"]["effective_clock_GHz"] = clk
             out["k2_rates"]["valu_insts_per_p3p_solve"] = vp["valu_insts_per_frame"] * 64.0 * n_fr / max(1, solves)
-            out["k2_rates"]["valu_source"] = "profiles/round3_pmc.json k2_vote_valu[%s] (%s), kernel %s; counters from a " \
+            out["k2_rates"]["valu_source"] = "profiles/" + pmc_file + " k2_vote_valu[%s] (%s), kernel %s; counters from a " \
                                              "build of the sources timed here: %s" % (
                 args.config, vp.get("from", ""), vp.get("kernel", ""), pmc_matches_binary)
         if host_leg is not None:
