@@ -9,7 +9,8 @@ traced to the hypotheses that cast it, and each of those must sit in the unstabl
 solver (cancellation < 1e-12) or be one on which the oracle's own P3P answer moves under a 1-ulp change of an input.
 Exit code 1 if a mismatch stays unexplained.
 usage (on an MI355X): python tests/soak_votes.py [frames [config [out_prefix]]]      -> one JSON line
-MPE_SOAK_STRICT=0 skips the strict kernel (2.5x the time; at C3 it is run on the first MPE_SOAK_STRICT_FRAMES frames)"""
+MPE_SOAK_STRICT=0 skips the strict kernel (2.5x the time; at C3 it is run on the first MPE_SOAK_STRICT_FRAMES frames);
+MPE_SOAK_ORACLE=0 skips the oracle and the fast-alone arithmetic: only DEFAULT against STRICT, at GPU speed (large N)"""
 import json
 import os
 import sys
@@ -41,6 +42,7 @@ P = mpe.demo_params()
 TOL = 5.0
 cores = len(os.sched_getaffinity(0))
 STRICT = os.environ.get("MPE_SOAK_STRICT", "1") != "0"
+ORACLE = os.environ.get("MPE_SOAK_ORACLE", "1") != "0"
 STRICT_FRAMES = int(os.environ.get("MPE_SOAK_STRICT_FRAMES", str(N if CONFIG != "C3" else min(N, 4096))))
 diff = {0: 0, 1: 0, 2: 0}
 cells = {0: 0, 1: 0, 2: 0}
@@ -58,15 +60,15 @@ for part in range(max(1, N // CH)):
     det = h.detect_batch(frames, K, D, P)
     nd = det["n"].astype(np.int32)
     dets = det["undist_xy"].reshape(CH, mpe.MAX_DETECTIONS, 2)
-    ref = orc.vote_batch(dets, nd, markers, K, TOL, n_threads=cores)
+    ref = orc.vote_batch(dets, nd, markers, K, TOL, n_threads=cores) if ORACLE else None
     got = {}
     do_strict = STRICT and tot < STRICT_FRAMES
-    for arith in (1, 2, 0):
+    for arith in ((1, 2, 0) if ORACLE else (1, 0)):
         if arith == 0 and not do_strict:
             continue
         h.set_option("vote_arith", arith)
         got[arith] = h.vote_batch([dets[i, :nd[i]] for i in range(CH)], markers, K, TOL)
-        for i in range(CH):
+        for i in (range(CH) if ORACLE else ()):
             r = ref[i, :nd[i], :len(markers)] if nd[i] >= 4 else np.zeros((nd[i], len(markers)), np.uint32)
             g = got[arith][i] if nd[i] >= 4 else np.zeros_like(r)
             if not np.array_equal(g, r):
@@ -92,10 +94,11 @@ if saved:
              **{"oracle_%d" % k: s["oracle"] for k, s in enumerate(saved)},
              meta=json.dumps([{k: v for k, v in s.items() if k not in ("det", "hip", "oracle")} for s in saved]))
 print(json.dumps({"config": CONFIG, "frames": tot, "p3p_solves_per_frame": "C(n_det,3) x P(n_markers,3)",
+                  "oracle_compared": ORACLE,
                   "frames_with_a_different_histogram_vs_oracle": {
                       "default (vote_arith 1: fast + strict re-evaluation of suspects)": diff[1],
                       "strict (vote_arith 0)": diff[0] if strict_frames else None,
-                      "fast alone (vote_arith 2, round 3's default)": diff[2]},
+                      "fast alone (vote_arith 2, round 3's default)": diff[2]} if ORACLE else None,
                   "differing_cells": {"default": cells[1], "strict": cells[0], "fast alone": cells[2]},
                   "frames_compared_default_vs_strict": strict_frames,
                   "frames_default_differs_from_strict": default_vs_strict,
