@@ -244,6 +244,7 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
       ~FlushAtExit() {
         if (!on) return;
         switch (np) {
+          case 1: k2_defer_flush<1>(F, count, true); break;
           case 2: k2_defer_flush<2>(F, count, true); break;
           case 3: k2_defer_flush<3>(F, count, true); break;
           default: k2_defer_flush<4>(F, count, true); break;
