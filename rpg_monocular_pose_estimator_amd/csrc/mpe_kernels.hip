@@ -2411,7 +2411,7 @@ __device__ __forceinline__ K2SubF k2_back_substitute_f32(float cn, float cd, flo
 #define K2_GRID 256     // occupancy grid: K2_GRID x K2_GRID bits (8 KB of LDS per block)
 #define K2_GRID_WORDS (K2_GRID / 64)
 __device__ __forceinline__ float k2_rcpf(float x) { return p3p_rcpf(x); }
-__host__ __device__ constexpr bool k2_defers(bool scan, int np) { return !scan && np >= 1; }
+__host__ __device__ constexpr bool k2_defers(bool scan, int np) { return !scan && np >= 2; }
 // cell index iy * K2_GRID + ix of the grid coordinates (fx, fy): v_cvt_pk_u8_f32 converts, SATURATES to 0 .. 255 and
 // packs in one instruction per coordinate (NaN -> 0); row / column 0 and 255 of the grid are never set, so everything
 // outside the grid reads an empty cell
