@@ -267,9 +267,7 @@ struct PixWin {
 // — the `zone` bits over the taps' input positions j (pixel x0 - R + j) — is non-zero after the threshold, which
 // is reported in edge_or so that the caller can redo the item with the byte-wise border code.  LED spots sit well
 // inside the frame / the tracking ROI (20 px border), so the mirrored zone is almost always dark.
-// X0 .. X1 - 1: the outputs to compute (0 .. 15: all; a segment column next to the bright ones only needs the R outputs
-// on its near side — everything further out is beyond the kernel's reach of any bright pixel)
-template <int KS, bool EDGE, int X0 = 0, int X1 = 16>
+template <int KS, bool EDGE>
 __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, int cols, int y, int c,
                                                    const DetectParams& dp, unsigned zone, unsigned& edge_or) {
   constexpr int R = KS / 2;
@@ -302,13 +300,13 @@ __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, in
     constexpr int NW = 16 + (KS > 4 ? 4 : 0);
     unsigned win[NW];  // win[x] = the bytes of input positions x .. x + 3 (position j = pixel x0 - R + j)
 #pragma unroll
-    for (int x = X0; x < (KS > 4 ? X1 + 4 : X1); ++x) {  // (the entries outputs X0 .. X1 - 1 read)
+    for (int x = 0; x < NW; ++x) {
       const int k = 16 - R + x;
       win[x] = (k & 3) ? __builtin_amdgcn_alignbyte(q[(k >> 2) + 1], q[k >> 2], k & 3) : q[k >> 2];
     }
     const unsigned ky = (unsigned)dp.taps[i];
 #pragma unroll
-    for (int x = X0; x < X1; ++x) {
+    for (int x = 0; x < 16; ++x) {
       unsigned h = __builtin_amdgcn_udot4(win[x], TA, 0u, false);
       if (KS > 4) h = __builtin_amdgcn_udot4(win[x + 4], TB, h, false);
       acc[x] += ky * h;
@@ -316,7 +314,7 @@ __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, in
   }
   unsigned m = 0;
 #pragma unroll
-  for (int x = X0; x < X1; ++x)
+  for (int x = 0; x < 16; ++x)
     if (acc[x] >= (1u << 15)) m |= 1u << x;
   if (EDGE) {
     edge_or = eor;
@@ -967,10 +965,8 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
 }
 
 // blurred-mask bits of the 16 outputs of segment column c in image row y -> OR into the bitmap
-// side: 0 = all 16 outputs; 1 / 2 = column c lies left / right of the window's bright columns and only its R outputs next
-// to them can be non-zero (the fast interior forms use that, the others compute everything)
 __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int cols, const DetectParams& dp,
-                                               const int* taps, int y, int c, u64* nzrow, int xw0, int side = 0) {
+                                               const int* taps, int y, int c, u64* nzrow, int xw0) {
   const int ksize = dp.ksize;
   const int r = ksize / 2;
   const int x0 = 16 * c;
@@ -979,13 +975,9 @@ __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int c
   const bool interior = (x0 - r >= 0) && (x0 + 15 + r < cols);
   unsigned edge_or = 0;
   if (interior && ksize == 5 && dp.taps_u8) {
-    m = side == 1   ? blur_item_fast<5, false, 14, 16>(pw, rows, cols, y, c, dp, 0u, edge_or)
-        : side == 2 ? blur_item_fast<5, false, 0, 2>(pw, rows, cols, y, c, dp, 0u, edge_or)
-                    : blur_item_fast<5, false>(pw, rows, cols, y, c, dp, 0u, edge_or);
+    m = blur_item_fast<5, false>(pw, rows, cols, y, c, dp, 0u, edge_or);
   } else if (interior && ksize == 3 && dp.taps_u8) {
-    m = side == 1   ? blur_item_fast<3, false, 15, 16>(pw, rows, cols, y, c, dp, 0u, edge_or)
-        : side == 2 ? blur_item_fast<3, false, 0, 1>(pw, rows, cols, y, c, dp, 0u, edge_or)
-                    : blur_item_fast<3, false>(pw, rows, cols, y, c, dp, 0u, edge_or);
+    m = blur_item_fast<3, false>(pw, rows, cols, y, c, dp, 0u, edge_or);
   } else if ((ksize == 5 || ksize == 3) && dp.taps_u8 && cols >= 2 * r + 2) {
     // border segment: mirrored input positions j (pixel x = x0 - r + j): left border x in [1, r], right border
     // x in [cols - 1 - r, cols - 2]
@@ -1077,8 +1069,7 @@ struct Island {
   short clo, chi;      // output segment columns
   short cfirst, clast; // bright segment columns (pixel window)
   int pix_off, bm_off; // offsets into the pools
-  int stage_end, blur_end;  // inclusive prefix sums of the flattened work-item counts: (row, bright column) items —
-                            // staging and full blur — and (row, dilated column) items — the blur's slivers
+  int stage_end, blur_end;  // inclusive prefix sums of the flattened work-item counts
 };
 
 // The island's bitmap window: the blurred mask can only be non-zero within r pixels of a bright segment, i.e. in
@@ -1353,7 +1344,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
       pixb = H * 16 * nbs;
       bmw = (H + 2) * W;
       nst = H * nbs;
-      nbl = H * ((is.cfirst - is.clo) + (is.chi - is.clast));  // the dilated columns on both sides
+      nbl = H * (is.chi - is.clo + 1);
     }
     int ip = pixb, ib = bmw, is_ = nst, il = nbl;  // inclusive scans
 #pragma unroll
@@ -1418,40 +1409,21 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   wave_sync();
   K1B_STOP_POINT(3, out)
 
-  // ---- D: blurred mask of every island.  First the bright columns (all 16 outputs of an item), then the dilated
-  //      columns on both sides, whose only outputs within the kernel's reach of a bright pixel are the r nearest ones —
-  //      in two loops, so that the lanes of a wave run the same form
+  // ---- D: blurred mask of every island
   {
-    const int tot_full = s_isl[nisl - 1].stage_end;
-    for (int i = lane; i < tot_full; i += 64) {
-      int k = 0;
-      while (i >= s_isl[k].stage_end) ++k;
-      const Island is = s_isl[k];
-      const int li = i - (k ? s_isl[k - 1].stage_end : 0);
-      const int nbs = is.clast - is.cfirst + 1;
-      const int yb = li / nbs, c = is.cfirst + (li - yb * nbs);
-      const int H = is.yhi - is.ylo + 1;
-      const int W = isl_words(is, g.cols, r);
-      const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * nbs};
-      blur_to_bitmap(pw, g.rows, g.cols, dp, s_taps, is.ylo + yb, c, s_nz + is.bm_off + (size_t)(yb + 1) * W,
-                     isl_xw0(is, r), 0);
-    }
-    const int tot_side = s_isl[nisl - 1].blur_end;
-    for (int i = lane; i < tot_side; i += 64) {
+    const int tot_blur = s_isl[nisl - 1].blur_end;
+    for (int i = lane; i < tot_blur; i += 64) {
       int k = 0;
       while (i >= s_isl[k].blur_end) ++k;
       const Island is = s_isl[k];
       const int li = i - (k ? s_isl[k - 1].blur_end : 0);
-      const int nl_ = is.cfirst - is.clo, nd = nl_ + (is.chi - is.clast);
-      const int yb = li / nd, sd = li - yb * nd;
-      const int c = sd < nl_ ? is.clo + sd : is.clast + 1 + (sd - nl_);
+      const int ncols = is.chi - is.clo + 1;
+      const int yb = li / ncols, c = is.clo + (li - yb * ncols);
       const int H = is.yhi - is.ylo + 1;
       const int W = isl_words(is, g.cols, r);
       const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1)};
-      // (only the column right next to the bright ones is a sliver: with dc > 1 the others have nothing in reach, and
-      //  the forms that use `side` are those of 3 and 5 taps, dc = 1)
       blur_to_bitmap(pw, g.rows, g.cols, dp, s_taps, is.ylo + yb, c, s_nz + is.bm_off + (size_t)(yb + 1) * W,
-                     isl_xw0(is, r), c < is.cfirst ? 1 : 2);
+                     isl_xw0(is, r));
     }
   }
   wave_sync();
