@@ -7,7 +7,8 @@ from the oracle's, per arithmetic, and — the round-4 claim — frames on which
 <out>.npz) and CLASSIFIED (tests/forensics.py): both paths are asked for every hypothesis' own votes, the difference is
 traced to the hypotheses that cast it, and each of those must sit in the unstable corner of the reference's Ferrari
 solver (cancellation < 1e-12) or be one on which the oracle's own P3P answer moves under a 1-ulp change of an input.
-Exit code 1 if a mismatch stays unexplained.
+Exit code 1 if a mismatch of the default or the strict arithmetic stays unexplained (the fast arithmetic alone also
+fails outside that corner — near-degenerate detection triples — which is listed, not counted).
 usage (on an MI355X): python tests/soak_votes.py [frames [config [out_prefix]]]      -> one JSON line
 MPE_SOAK_STRICT=0 skips the strict kernel (2.5x the time; at C3 it is run on the first MPE_SOAK_STRICT_FRAMES frames);
 MPE_SOAK_ORACLE=0 skips the oracle and the fast-alone arithmetic: only DEFAULT against STRICT, at GPU speed (large N)"""
@@ -86,7 +87,10 @@ for part in range(max(1, N // CH)):
                 default_vs_strict_frames.append([part, i])
     tot += CH
     print(part, tot, diff, default_vs_strict, round(time.time() - t0), flush=True)
-unexplained = [s for s in saved if not s["verdict"]["unstable"]]
+# the claim is about the default and the strict arithmetic; what the fast arithmetic ALONE (vote_arith 2, kept for A/B
+# measurements) gets wrong outside the Ferrari corner is reported separately — it is what the round-4 screen exists for
+unexplained = [s for s in saved if not s["verdict"]["unstable"] and s["vote_arith"] != 2]
+fast_alone_other = [s for s in saved if not s["verdict"]["unstable"] and s["vote_arith"] == 2]
 if saved:
     os.makedirs(os.path.dirname(OUT) or ".", exist_ok=True)
     np.savez(OUT + ".npz", **{"det_%d" % k: s["det"] for k, s in enumerate(saved)},
@@ -105,8 +109,9 @@ print(json.dumps({"config": CONFIG, "frames": tot, "p3p_solves_per_frame": "C(n_
                   "frames_default_differs_from_strict_idx": default_vs_strict_frames[:20],
                   "vote_fixup_items": h.get_option("vote_fixup_items"),
                   "vote_fixup_overflow": h.get_option("vote_fixup_overflow"),
-                  "mismatches_classified_unstable": len(saved) - len(unexplained),
+                  "mismatches_classified_unstable": len(saved) - len(unexplained) - len(fast_alone_other),
                   "mismatches_unexplained": len(unexplained),
+                  "fast_alone_mismatches_outside_the_ferrari_corner": [[s["part"], s["frame"]] for s in fast_alone_other],
                   "mismatching_frames_saved_to": (OUT + ".npz") if saved else None,
                   "verdicts": [{k: v for k, v in s.items() if k not in ("det", "hip", "oracle")} for s in saved]}))
 sys.exit(2 if default_vs_strict else (1 if unexplained else 0))

@@ -972,6 +972,10 @@ def test_default_votes_equal_strict_votes(orc):
                  if f.startswith("unstable_det_r3_") or f.startswith("vote_regression_det")]
         assert len(saved) >= 4
         cases.append(("saved", saved, synth.M5, K, 5.0))
+        # the C3 frame of the round-4 soak on which the fast arithmetic ALONE loses a hypothesis' votes outside the
+        # Ferrari corner (a near-degenerate detection triple, tests/test_vote_host.py): default = strict = oracle
+        deg = np.load(os.path.join(data, "c3_degenerate_triple_det.npy"))
+        cases.append(("degenerate triple", [deg], synth.CONFIGS["C3"]["markers"], K, 5.0))
         rng = np.random.default_rng(12)
         for it in range(12):
             n_m = int(rng.integers(4, 8))
@@ -989,6 +993,8 @@ def test_default_votes_equal_strict_votes(orc):
             got = h.vote_batch(dets, markers, Kc, tol)
             for i in range(len(dets)):
                 assert np.array_equal(got[i], strict[i]), (name, i, np.argwhere(got[i] != strict[i])[:5])
+            if name == "degenerate triple":
+                assert np.array_equal(got[0], orc.vote_histogram(dets[0], np.asarray(markers, float), Kc, tol))
         assert h.get_option("vote_fixup_items") > items0
         assert h.get_option("vote_fixup_overflow") == 0
         # the whole path (fused scan-carrying kernel, fix-up on the tail stream of the pipelined schedule, streaming

@@ -237,3 +237,20 @@ def test_single_precision_grid_coordinates_stay_inside_the_margin(host, orc):
     assert out[0] < 0.05, (out[0], out[1])   # (NaN fails too)
     # the occupancy grid itself: every back-projection within the vote tolerance of a detection finds its cell set
     assert out[2] > 100 and out[3] == 0, (out[2], out[3])
+
+
+def test_near_degenerate_detection_triple_goes_to_the_strict_functions(host, orc):
+    """A C3 detection set from the round-4 soak (16 384 frames, tests/soak_votes.py) on which the fast arithmetic ALONE
+    loses the four votes of one hypothesis — detections (3, 4, 7) x markers (6, 2, 7): the third bearing lies 4.8e-8 off
+    the plane of the other two, f_1 = -2e7, the quartic has a double root — although the oracle is stable under 1-ulp
+    changes of its inputs (not the Ferrari corner).  The screen hands the hypothesis to the strict functions: the default
+    equals the strict loop and the oracle."""
+    cfg = synth.CONFIGS["C3"]
+    K, _ = synth.camera_for(cfg["rows"], cfg["cols"])
+    markers = np.ascontiguousarray(cfg["markers"], float)
+    det = np.load(os.path.join(ROOT, "tests", "data", "c3_degenerate_triple_det.npy"))
+    ref = orc.vote_histogram(det, markers, K, 5.0)
+    strict = _host_hist(host, det, markers, K, 5.0, 20)
+    default = _host_hist(host, det, markers, K, 5.0, 10)
+    assert np.array_equal(strict, ref)
+    assert np.array_equal(default, strict)
