@@ -6,6 +6,9 @@
 //   facade_selftest message < 16+36 doubles per line
 //       pose (row-major 4x4) + covariance (row-major 6x6) -> "px py pz qx qy qz qw c0 .. c35" per line, the
 //       PoseWithCovarianceStamped fields as compat/ros/message_conversions.h packs them (host only)
+//   facade_selftest framepath < encoding names
+//       which of the node's three frame paths (in place / back-end decode / cv_bridge) each encoding takes, in the
+//       default build and in the MPE_OPENCV_GRAY_14BIT build (host only)
 //   facade_selftest steps --markers <yaml> --frames <file.raw> --rows R --cols C [--dt s] [--overlay-out file.bgr]
 //       object A: estimateBodyPose per frame.  object B: the same state machine written out with the
 //       class's public step methods exactly as pose_estimator.cpp:62-147 strings them together
@@ -131,6 +134,16 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 36; ++i) std::printf(" %.17g", m.covariance[i]);
       std::printf("\n");
     }
+  }
+  if (argc >= 2 && !std::strcmp(argv[1], "framepath")) {  // "<encoding> <path, default build> <enc> <path, 14-bit build> <enc>" per line
+    char name[64];
+    while (std::scanf("%63s", name) == 1) {
+      int e0 = 99, e1 = 99;
+      const FramePath p0 = framePathForEncoding(name, false, &e0);
+      const FramePath p1 = framePathForEncoding(name, true, &e1);
+      std::printf("%s %d %d %d %d\n", name, (int)p0, e0, (int)p1, e1);
+    }
+    return 0;
   }
   if (argc < 2 || std::strcmp(argv[1], "steps")) {
     std::fprintf(stderr, "usage: facade_selftest combos N K | steps --markers y --frames f --rows R --cols C\n");

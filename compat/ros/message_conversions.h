@@ -77,6 +77,24 @@ inline int mpeEncodingFromString(const std::string& encoding) {
   return -1;
 }
 
+//! How onImage obtains the MONO8 pixels of a frame (monocular_pose_estimator.cpp:147).  mono8 is used in place and
+//! mono16 is decoded by the back-end in every build; the colour encodings are decoded by the back-end only when
+//! the build states that the linked OpenCV uses the 14-bit gray weights mpe_convert_to_mono8 restates
+//! (`gray_14bit`), otherwise they go through cv_bridge like everything the back-end does not know (Bayer ...).
+//! `enc` receives the MPE_ENC_* code for FRAME_BACKEND_DECODE and -1 otherwise: MPE_ENC_MONO8 is 0, so "no code"
+//! must never be spelled 0 (`enc = 0` sent interleaved colour bytes down the mono8 branch).
+enum FramePath { FRAME_IN_PLACE = 0, FRAME_BACKEND_DECODE = 1, FRAME_CV_BRIDGE = 2 };
+inline FramePath framePathForEncoding(const std::string& encoding, bool gray_14bit, int* enc) {
+  const int e = mpeEncodingFromString(encoding);
+  *enc = -1;
+  if (e == MPE_ENC_MONO8) return FRAME_IN_PLACE;
+  if (e == MPE_ENC_MONO16 || (gray_14bit && e > 0)) {
+    *enc = e;
+    return FRAME_BACKEND_DECODE;
+  }
+  return FRAME_CV_BRIDGE;
+}
+
 struct ReconfigureValues {
   int threshold_value;                       // 180  [0, 255]
   double gaussian_sigma;                     // 0.6  [0, 6]

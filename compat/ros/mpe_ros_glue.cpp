@@ -105,16 +105,18 @@ class MPENode {
     // 4899, >> 14 — the rule mpe_convert_to_mono8 restates, for the OpenCV 3.3 of the reference's platform); OpenCV
     // >= 3.4.2 uses 15-bit weights and can differ by one gray level, which near threshold_value flips LED pixels.
     cv_bridge::CvImageConstPtr mono;
-    int enc = mpeEncodingFromString(msg->encoding);
-#ifndef MPE_OPENCV_GRAY_14BIT
-    if (enc != MPE_ENC_MONO8 && enc != MPE_ENC_MONO16) enc = 0;
+    int enc = -1;
+#ifdef MPE_OPENCV_GRAY_14BIT
+    const FramePath path = framePathForEncoding(msg->encoding, true, &enc);
+#else
+    const FramePath path = framePathForEncoding(msg->encoding, false, &enc);
 #endif
     const uint8_t* pixels = nullptr;
     size_t step = 0;
-    if (enc == MPE_ENC_MONO8) {
+    if (path == FRAME_IN_PLACE) {
       pixels = msg->data.data();
       step = msg->step;
-    } else if (enc > 0) {
+    } else if (path == FRAME_BACKEND_DECODE) {
       decoded_.resize((size_t)msg->height * msg->width);
       try {
         estimator_.decodeToMono8(msg->data.data(), enc, msg->is_bigendian != 0, (int)msg->height, (int)msg->width, msg->step,

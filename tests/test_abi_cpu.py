@@ -445,6 +445,34 @@ def test_ros_glue_syntax(tmp_path):
     assert order == sorted(order)
 
 
+def test_ros_glue_frame_path_per_encoding():
+    """Which branch of the node's image callback a sensor_msgs encoding takes (compat/ros/message_conversions.h
+    framePathForEncoding, the function mpe_ros_glue.cpp::onImage switches on).  ADVICE round 4: the default build
+    spelled "leave it to cv_bridge" as `enc = 0` = MPE_ENC_MONO8 and read interleaved colour bytes as gray pixels.
+    Default build: mono8 in place, mono16 decoded by the back-end, every colour / Bayer / unknown encoding through
+    cv_bridge with NO back-end code; MPE_OPENCV_GRAY_14BIT build: the four 8-bit colour encodings decoded by the
+    back-end with their own MPE_ENC_* code.  Also: the glue must switch on that function, not on a raw code."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "compat"), "facade_selftest"])
+    names = ["mono8", "8UC1", "mono16", "bgr8", "rgb8", "bgra8", "rgba8", "bayer_rggb8", "16UC1", "yuv422", "nonsense"]
+    out = subprocess.run([os.path.join(ROOT, "compat", "facade_selftest"), "framepath"], input="\n".join(names) + "\n",
+                         capture_output=True, text=True, check=True).stdout
+    got = {ln.split()[0]: [int(v) for v in ln.split()[1:]] for ln in out.strip().splitlines()}
+    IN_PLACE, BACKEND, CV_BRIDGE = 0, 1, 2
+    enc = {"mono8": 0, "bgr8": 1, "rgb8": 2, "bgra8": 3, "rgba8": 4, "mono16": 5}   # include/mpe.h MPE_ENC_*
+    hdr = open(os.path.join(ROOT, "include", "mpe.h")).read()
+    for k, v in enc.items():
+        assert ("MPE_ENC_%s = %d" % (k.upper(), v)) in hdr or ("MPE_ENC_%s %d" % (k.upper(), v)) in hdr, k
+    for n in ("mono8", "8UC1"):
+        assert got[n] == [IN_PLACE, -1, IN_PLACE, -1]
+    assert got["mono16"] == [BACKEND, enc["mono16"], BACKEND, enc["mono16"]]
+    for n in ("bgr8", "rgb8", "bgra8", "rgba8"):
+        assert got[n] == [CV_BRIDGE, -1, BACKEND, enc[n]], (n, got[n])
+    for n in ("bayer_rggb8", "16UC1", "yuv422", "nonsense"):
+        assert got[n] == [CV_BRIDGE, -1, CV_BRIDGE, -1]
+    glue = open(os.path.join(ROOT, "compat", "ros", "mpe_ros_glue.cpp")).read()
+    assert "framePathForEncoding(msg->encoding" in glue and "enc = 0" not in glue and "enc == MPE_ENC_MONO8" not in glue
+
+
 def test_bench_streams_plumbing_two_ranks():
     """BASELINE configs[4] shards STREAMS, not frames: `bench_streams.py --gpus N` had no CPU coverage of its N > 1
     path.  --plumbing-only runs the launcher, the stream -> rank round robin, the barrier and the MAX (wall time) /
