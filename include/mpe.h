@@ -43,7 +43,9 @@ extern "C" {
 #define MPE_FRAME_TOO_MANY_DETECTIONS (-10) /* > MPE_MAX_DETECTIONS blobs passed the filter */
 #define MPE_FRAME_TOO_MANY_BLOBS (-11)      /* > MPE_MAX_RAW_BLOBS external contours */
 #define MPE_FRAME_TOO_MANY_ROWS (-12)       /* bright rows exceed the LDS band capacity */
-#define MPE_FRAME_VOTE_LIST_FULL (-13)      /* hypotheses left to the strict arithmetic did not fit their list */
+#define MPE_FRAME_VOTE_LIST_FULL (-13)      /* internal since round 5: hypotheses left to the strict arithmetic did not fit
+                                               their list; such a frame is voted again by the strict loop nest before the
+                                               tail and comes out with an ordinary status (never returned to a caller) */
 
 /* call-level error codes */
 #define MPE_OK 0

@@ -62,9 +62,13 @@ struct mpe_handle {
   std::string err;
   DevBuf frames, flags, dets, hist, results, corr, mtab, work, scratch, track, mid;
   // hypotheses the fast voting kernel leaves to the strict arithmetic (VoteFixup, mpe_internal.h): a control block of
-  // kMaxSub x 4 counters, then one list region per voting launch that can be in flight (sub-batch slot)
+  // kMaxSub x MPE_FIX_CTL_WORDS counters, then one list region per voting launch that can be in flight (sub-batch slot;
+  // only as many regions as a call has needed so far: fix_slots)
   DevBuf fix;
   unsigned fix_cap = 0;                 // entries per slot of the current layout
+  int fix_slots = 0;                    // list regions of the current layout
+  unsigned fix_cap_limit = 0;           // option "vote_list_cap" (tests): entries per slot at most; 0 = no limit
+  unsigned long long fix_relost_base = 0;
   bool fix_pending[16] = {};            // slot: a voting launch has appended, its fix-up has not been launched yet
   unsigned long long fix_items_base = 0, fix_overflow_base = 0;  // cumulative counters of layouts that were replaced
   void* mailbox = nullptr;  // pinned host memory for the single-frame tracking step (ROI in, record out)
@@ -370,30 +374,38 @@ int auto_splits(const mpe_handle* h, int n_frames, int n_markers) {
 }
 
 // ---- strict re-evaluation of the fast voting kernel's suspects (VoteFixup) ----------------------------------------
-constexpr size_t kFixCtlBytes = (size_t)mpe_handle::kMaxSub * 4 * sizeof(unsigned);
+constexpr size_t kFixCtlBytes = (size_t)mpe_handle::kMaxSub * MPE_FIX_CTL_WORDS * sizeof(unsigned);
 constexpr size_t kFixEntryBytes = 2 * sizeof(unsigned long long);
-// sum of the per-slot cumulative counters (synchronises the device); which = 1 list-full events, 3 entries re-evaluated
+// sum of the per-slot cumulative counters (synchronises the device); which = 1 list-full events, 3 entries
+// re-evaluated, 6 frames voted again after a list-full event
 int fix_counter_sum(mpe_handle* h, int which, unsigned long long& out) {
-  out = which == 1 ? h->fix_overflow_base : h->fix_items_base;
+  out = which == 1 ? h->fix_overflow_base : which == 6 ? h->fix_relost_base : h->fix_items_base;
   if (!h->fix.p) return MPE_OK;
   HIP_TRY(h, hipDeviceSynchronize());
-  unsigned ctl[mpe_handle::kMaxSub * 4];
+  unsigned ctl[mpe_handle::kMaxSub * MPE_FIX_CTL_WORDS];
   HIP_TRY(h, hipMemcpy(ctl, h->fix.p, sizeof(ctl), hipMemcpyDeviceToHost));
-  for (int s = 0; s < mpe_handle::kMaxSub; ++s) out += ctl[4 * s + which];
+  for (int s = 0; s < mpe_handle::kMaxSub; ++s) out += ctl[MPE_FIX_CTL_WORDS * s + which];
   return MPE_OK;
 }
-// The list of voting launch `slot` (sub-batch index; 0 for single launches) sized for n_frames frames: ~0.6 % of the
-// hypotheses go to the list, the region holds 1/32 of them (>= 64 per frame), within a total of
-// 16 GB for all slots — a full list is not an error: the fast verdict then stands and "vote_fixup_overflow" counts it.
-int vote_fixup_for(mpe_handle* h, int slot, int n_frames, int n_markers, int n_det_hint, hipStream_t st, VoteFixup& fx) {
+// The list of voting launch `slot` (sub-batch index; 0 for single launches) of a call that uses `n_slots` of them, sized
+// for n_frames frames: ~0.6 % of the hypotheses go to the list, the region holds 1/32 of them
+// (>= 64 per frame; small launches are sized for the capacity limit of 32 detections, whatever the caller expects),
+// within 1 GB per slot.  A full list is not an error and costs no pose: the frames that lost an entry are voted again
+// by the strict loop nest behind the fix-up kernel (k2_vote_relost); "vote_fixup_overflow" counts the events,
+// "vote_relost_frames" the frames.  If the device cannot hold the layout the list shrinks (down to 4 096 entries)
+// before the call fails.
+int vote_fixup_for(mpe_handle* h, int slot, int n_slots, int n_frames, int n_markers, int n_det_hint, hipStream_t st,
+                   VoteFixup& fx) {
   fx = VoteFixup{nullptr, nullptr, 0u, 0u};
   if (h->vote_arith == 0 || n_markers < 4 || slot < 0 || slot >= mpe_handle::kMaxSub) return MPE_OK;
-  const long long nd = std::min(32, std::max(n_det_hint, n_markers) + 4);
+  n_slots = std::min((int)mpe_handle::kMaxSub, std::max(n_slots, slot + 1));
+  const long long nd = n_frames <= 256 ? MPE_MAX_DETECTIONS : std::min(MPE_MAX_DETECTIONS, std::max(n_det_hint, n_markers) + 4);
   const long long items = nd * (nd - 1) * (nd - 2) / 6 * n_markers * (n_markers - 1) * (n_markers - 2);
   unsigned long long want = (unsigned long long)n_frames * (unsigned long long)std::max(64ll, items / 32);
-  const unsigned long long most = ((16ull << 30) / kFixEntryBytes) / mpe_handle::kMaxSub;
+  const unsigned long long most = (1ull << 30) / kFixEntryBytes;
   want = std::min(want, most);
-  if (want > h->fix_cap || !h->fix.p) {
+  if (h->fix_cap_limit) want = std::min<unsigned long long>(want, h->fix_cap_limit);
+  if (want > h->fix_cap || n_slots > h->fix_slots || !h->fix.p) {
     // a new layout: nothing may be in flight on the old one (hipFree inside reserve() waits for the device anyway)
     if (h->fix.p) {
       unsigned long long v = 0;
@@ -403,17 +415,30 @@ int vote_fixup_for(mpe_handle* h, int slot, int n_frames, int n_markers, int n_d
       rc = fix_counter_sum(h, 3, v);
       if (rc) return rc;
       h->fix_items_base = v;
+      rc = fix_counter_sum(h, 6, v);
+      if (rc) return rc;
+      h->fix_relost_base = v;
     }
     HIP_TRY(h, hipDeviceSynchronize());
+    const int slots = std::max(n_slots, h->fix_slots);  // (a layout only grows)
+    unsigned long long cap = std::max<unsigned long long>(want, h->fix_cap);
     h->fix.release();
-    const unsigned cap = (unsigned)std::max<unsigned long long>(want, h->fix_cap);
-    HIP_TRY(h, h->fix.reserve(kFixCtlBytes + (size_t)mpe_handle::kMaxSub * cap * kFixEntryBytes));
-    h->fix_cap = cap;
+    h->fix_cap = 0;
+    h->fix_slots = 0;
+    hipError_t e = hipSuccess;
+    for (;; cap /= 4) {
+      e = h->fix.reserve(kFixCtlBytes + (size_t)slots * cap * kFixEntryBytes);
+      if (e == hipSuccess || cap <= 4096) break;
+      (void)hipGetLastError();  // (out of memory: a smaller list only means more frames voted twice)
+    }
+    HIP_TRY(h, e);
+    h->fix_cap = (unsigned)cap;
+    h->fix_slots = slots;
     HIP_TRY(h, hipMemsetAsync(h->fix.p, 0, kFixCtlBytes, st));
     HIP_TRY(h, hipStreamSynchronize(st));  // (other streams may be the first to touch it)
     for (auto& b : h->fix_pending) b = false;
   }
-  fx.ctl = static_cast<unsigned*>(h->fix.p) + 4 * slot;
+  fx.ctl = static_cast<unsigned*>(h->fix.p) + MPE_FIX_CTL_WORDS * slot;
   fx.list = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(h->fix.p) + kFixCtlBytes) +
             (size_t)slot * h->fix_cap * 2;
   fx.cap = h->fix_cap;
@@ -421,14 +446,15 @@ int vote_fixup_for(mpe_handle* h, int slot, int n_frames, int n_markers, int n_d
   if (h->fix_pending[slot]) {  // an earlier call failed between a voting launch and its fix-up: drop those entries
     HIP_TRY(h, hipMemsetAsync(fx.ctl, 0, sizeof(unsigned), st));
     HIP_TRY(h, hipMemsetAsync(fx.ctl + 2, 0, sizeof(unsigned), st));
+    HIP_TRY(h, hipMemsetAsync(fx.ctl + 5, 0, sizeof(unsigned), st));
   }
   h->fix_pending[slot] = true;
   return MPE_OK;
 }
-hipError_t fixup_launch(mpe_handle* h, int slot, const mpe_detections* dets, const SolveParams& sp, uint32_t* hist,
+hipError_t fixup_launch(mpe_handle* h, int slot, mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist,
                         const VoteFixup& fx, hipStream_t st) {
   if (!fx.ctl) return hipSuccess;
-  const hipError_t e = launch_k2_fixup(dets, sp, hist, fx, st);
+  const hipError_t e = launch_k2_fixup(dets, n_frames, sp, hist, fx, st);
   if (e == hipSuccess) h->fix_pending[slot] = false;
   return e;
 }
@@ -464,11 +490,11 @@ int run_back(mpe_handle* h, hipStream_t st, bool prof, int n_frames, const Solve
   if (sp) {
     HIP_TRY(h, hipMemsetAsync(d_hist, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), st));
     VoteFixup fx;
-    { const int rc = vote_fixup_for(h, 0, n_frames, sp->n_markers, sp->n_markers, st, fx); if (rc) return rc; }
+    { const int rc = vote_fixup_for(h, 0, 1, n_frames, sp->n_markers, sp->n_markers, st, fx); if (rc) return rc; }
     HIP_TRY(h, launch_k2_vote(d_dets, n_frames, *sp, static_cast<const double*>(h->mtab.p), d_hist,
                               auto_splits(h, n_frames, sp->n_markers), sp->n_markers, st, nullptr, 0, nullptr, 0,
                               nullptr, nullptr, &fx));
-    HIP_TRY(h, fixup_launch(h, 0, d_dets, *sp, d_hist, fx, st));
+    HIP_TRY(h, fixup_launch(h, 0, d_dets, n_frames, *sp, d_hist, fx, st));
     if (prof) rec(h, 3);
     HIP_TRY(h, launch_k3_tail(d_dets, d_hist, n_frames, *sp, d_results, d_corr, nullptr, nullptr, 0.0, h->mid.p, st));
   } else if (prof) {
@@ -926,7 +952,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       if (nbytes && s + 1 >= n_real && hint && hint->next_ready)  // this launch reads the NEXT submission's frames
         HIP_TRY(h, hipStreamWaitEvent(st, hint->next_ready, 0));
       VoteFixup fx;
-      { const int rc = vote_fixup_for(h, s, per, sp->n_markers, sp->n_markers, st, fx); if (rc) return rc; }
+      { const int rc = vote_fixup_for(h, s, nsub, per, sp->n_markers, sp->n_markers, st, fx); if (rc) return rc; }
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], st));
       HIP_TRY(h, vote_ev_begin(h, s, st));
       HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, *sp, static_cast<const double*>(h->mtab.p), hs,
@@ -955,7 +981,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       }
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][6], tst));
       // the strict verdicts on what vote(s) left undecided: in front of the tail, off the caller's stream with it
-      HIP_TRY(h, fixup_launch(h, s, d_dets + f0, *sp, hs, fx, tst));
+      HIP_TRY(h, fixup_launch(h, s, d_dets + f0, nf, *sp, hs, fx, tst));
       HIP_TRY(h, launch_k3_tail(d_dets + f0, hs, nf, *sp, d_results + f0,
                                 d_corr ? d_corr + (size_t)f0 * 2 * MPE_MAX_MARKERS : nullptr, nullptr, nullptr, 0.0,
                                 static_cast<uint8_t*>(h->mid.p) + k3_mid_bytes(1) * (size_t)f0, tst));
@@ -1037,12 +1063,12 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
     HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), sb));
     VoteFixup fx;
-    { const int rc = vote_fixup_for(h, s, per, sp->n_markers, sp->n_markers, sb, fx); if (rc) return rc; }
+    { const int rc = vote_fixup_for(h, s, nsub, per, sp->n_markers, sp->n_markers, sb, fx); if (rc) return rc; }
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], sb));
     HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, *sp, static_cast<const double*>(h->mtab.p), hs,
                               auto_splits(h, nf, sp->n_markers), sp->n_markers, sb, nullptr, 0, nullptr, 0, nullptr,
                               nullptr, &fx));
-    HIP_TRY(h, fixup_launch(h, s, d_dets + f0, *sp, hs, fx, sb));
+    HIP_TRY(h, fixup_launch(h, s, d_dets + f0, nf, *sp, hs, fx, sb));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], sb));
     HIP_TRY(h, hipEventRecord(h->vote_done[s], sb));
     hipStream_t stail = sb;
@@ -1289,12 +1315,14 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "k1a_dummy_lds") *value = h->k1a_dummy_lds;
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
-  else if (n == "vote_fixup_items" || n == "vote_fixup_overflow") {
+  else if (n == "vote_list_cap") *value = (int)h->fix_cap_limit;
+  else if (n == "vote_fixup_items" || n == "vote_fixup_overflow" || n == "vote_relost_frames") {
     // hypotheses (roots, detections) the fast voting kernel handed to the strict arithmetic since the handle was made,
-    // and how many it could not hand over because a list was full (the fast verdict then stood); saturating at INT_MAX
+    // how many it could not hand over because a list was full, and how many frames were therefore voted again by the
+    // strict loop nest (k2_vote_relost); saturating at INT_MAX
     HIP_TRY(h, hipSetDevice(h->device));
     unsigned long long v = 0;
-    const int rc = fix_counter_sum(h, n == "vote_fixup_items" ? 3 : 1, v);
+    const int rc = fix_counter_sum(h, n == "vote_fixup_items" ? 3 : n == "vote_relost_frames" ? 6 : 1, v);
     if (rc) return rc;
     *value = v > 0x7fffffffull ? 0x7fffffff : (int)v;
   }
@@ -1417,6 +1445,29 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   }
   if (!std::strcmp(name, "force_rccl_gather")) {
     h->force_rccl_gather = value ? 1 : 0;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "vote_list_cap")) {  // tests: a list this small overflows and exercises k2_vote_relost
+    if (value < 0) return fail(h, MPE_ERR_ARG, "vote_list_cap must be >= 0");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    if (h->fix.p) {  // keep the cumulative counters of the layout that goes
+      unsigned long long v = 0;
+      int rc = fix_counter_sum(h, 1, v);
+      if (rc) return rc;
+      h->fix_overflow_base = v;
+      rc = fix_counter_sum(h, 3, v);
+      if (rc) return rc;
+      h->fix_items_base = v;
+      rc = fix_counter_sum(h, 6, v);
+      if (rc) return rc;
+      h->fix_relost_base = v;
+    }
+    h->fix.release();
+    h->fix_cap = 0;
+    h->fix_slots = 0;
+    for (auto& b : h->fix_pending) b = false;
+    h->fix_cap_limit = (unsigned)value;
     return MPE_OK;
   }
   if (!std::strcmp(name, "vote_arith")) {
@@ -1549,13 +1600,13 @@ int vote_batch_impl(mpe_handle* h, const double* det_xy, const int* n_det, int n
   {
     int nd_max = n_markers;
     for (int f = 0; f < n_frames; ++f) nd_max = std::max(nd_max, n_det[f]);
-    const int rc = vote_fixup_for(h, 0, n_frames, n_markers, nd_max, h->stream, fx);
+    const int rc = vote_fixup_for(h, 0, 1, n_frames, n_markers, nd_max, h->stream, fx);
     if (rc) return rc;
   }
   HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), n_frames, sp, static_cast<const double*>(h->mtab.p),
                             static_cast<uint32_t*>(h->hist.p), auto_splits(h, n_frames, n_markers), n_markers,
                             h->stream, nullptr, 0, nullptr, 0, nullptr, d_range, &fx));
-  HIP_TRY(h, fixup_launch(h, 0, static_cast<mpe_detections*>(h->dets.p), sp, static_cast<uint32_t*>(h->hist.p), fx,
+  HIP_TRY(h, fixup_launch(h, 0, static_cast<mpe_detections*>(h->dets.p), n_frames, sp, static_cast<uint32_t*>(h->hist.p), fx,
                           h->stream));
   HIP_TRY(h, hipMemcpyAsync(hist, h->hist.p, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t),
                             hipMemcpyDeviceToHost, h->stream));
@@ -1587,11 +1638,11 @@ int solve_bruteforce_impl(mpe_handle* h, const double* det_xy, int n_det, const 
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, MPE_HIST_STRIDE * sizeof(uint32_t), h->stream));
   { const int rc = prep_marker_table(h, sp); if (rc) return rc; }
   VoteFixup fx;
-  { const int rc = vote_fixup_for(h, 0, 1, n_markers, n_det, h->stream, fx); if (rc) return rc; }
+  { const int rc = vote_fixup_for(h, 0, 1, 1, n_markers, n_det, h->stream, fx); if (rc) return rc; }
   HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), 1, sp, static_cast<const double*>(h->mtab.p),
                             static_cast<uint32_t*>(h->hist.p), auto_splits(h, 1, n_markers), n_det, h->stream, nullptr,
                             0, nullptr, 0, nullptr, nullptr, &fx));
-  HIP_TRY(h, fixup_launch(h, 0, static_cast<mpe_detections*>(h->dets.p), sp, static_cast<uint32_t*>(h->hist.p), fx,
+  HIP_TRY(h, fixup_launch(h, 0, static_cast<mpe_detections*>(h->dets.p), 1, sp, static_cast<uint32_t*>(h->hist.p), fx,
                           h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), 1, sp,
                             static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), nullptr,
@@ -2225,11 +2276,11 @@ int mpe_solve_bruteforce_batch(mpe_handle* h, const double* det_xy, const int* n
   HIP_TRY(h, hipMemsetAsync(h->hist.p, 0, hist_bytes, h->stream));
   { const int rc = prep_marker_table(h, sp); if (rc) return rc; }
   VoteFixup fx;
-  { const int rc = vote_fixup_for(h, 0, n, n_markers, nd_max, h->stream, fx); if (rc) return rc; }
+  { const int rc = vote_fixup_for(h, 0, 1, n, n_markers, nd_max, h->stream, fx); if (rc) return rc; }
   HIP_TRY(h, launch_k2_vote(static_cast<mpe_detections*>(h->dets.p), n, sp, static_cast<const double*>(h->mtab.p),
                             static_cast<uint32_t*>(h->hist.p), auto_splits(h, n, n_markers), nd_max, h->stream, nullptr,
                             0, nullptr, 0, nullptr, nullptr, &fx));
-  HIP_TRY(h, fixup_launch(h, 0, static_cast<mpe_detections*>(h->dets.p), sp, static_cast<uint32_t*>(h->hist.p), fx,
+  HIP_TRY(h, fixup_launch(h, 0, static_cast<mpe_detections*>(h->dets.p), n, sp, static_cast<uint32_t*>(h->hist.p), fx,
                           h->stream));
   HIP_TRY(h, launch_k3_tail(static_cast<mpe_detections*>(h->dets.p), static_cast<uint32_t*>(h->hist.p), n, sp,
                             static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), nullptr, nullptr,

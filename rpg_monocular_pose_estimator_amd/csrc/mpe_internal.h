@@ -63,9 +63,12 @@ struct SolveParams {
 
 // Hypotheses a fast voting launch does not decide itself (mpe_kernels.hip, k2_sus_push): a list in device memory that
 // launch_k2_fixup works off with the strict arithmetic, behind the voting launch and in front of the tail.
+#define MPE_FIX_CTL_WORDS 8
 struct VoteFixup {
-  unsigned* ctl;             // [0] entries appended (reset by the fix-up kernel), [1] appends that found the list full
-                             // (cumulative), [2] blocks done (internal), [3] entries re-evaluated (cumulative)
+  unsigned* ctl;             // MPE_FIX_CTL_WORDS words: [0] entries appended (reset by the fix-up kernel), [1] appends
+                             // that found the list full (cumulative), [2] blocks done (internal), [3] entries
+                             // re-evaluated (cumulative), [4] value of [1] the last k2_vote_relost launch handled,
+                             // [5] its blocks done (internal), [6] frames voted again by it (cumulative)
   unsigned long long* list;  // cap entries of 2 words
   unsigned cap;
   unsigned screen;           // 1: the voting kernel screens its hypotheses (vote_arith 1); 0: it only sends what its
@@ -73,6 +76,7 @@ struct VoteFixup {
 };
 
 // launchers (mpe_kernels.hip)
+int device_cu_count();  // compute units of the current device (cached)
 size_t k1b_scratch_bytes(const FrameGeom& g);
 hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long long* flags, int thr,
                            int dummy_lds_bytes, hipStream_t s, int blocks_per_cu = 0);
@@ -97,11 +101,12 @@ hipError_t launch_k2_vote(mpe_detections* dets, int n_frames, const SolveParams&
                           uint32_t* hist, int splits, int n_det_hint, hipStream_t s, const uint8_t* scan_px = nullptr,
                           size_t scan_bytes = 0, unsigned long long* scan_flags = nullptr, int scan_thr = 0,
                           size_t* scanned_bytes = nullptr, const int* item_range = nullptr,
-                          const VoteFixup* fixup = nullptr);
+                          const VoteFixup* fixup = nullptr);  // (required unless sp.vote_arith == 0)
 // the strict re-evaluation of what that launch appended to `fixup` (sp.vote_arith == 1): same dets / hist pointers,
 // on a stream ordered behind the voting launch; its votes must be in before the tail reads the histograms
-hipError_t launch_k2_fixup(const mpe_detections* dets, const SolveParams& sp, uint32_t* hist, const VoteFixup& fixup,
-                           hipStream_t s);
+// ... and, behind it, the strict re-vote of the frames that lost an entry to a full list (they come out unmarked)
+hipError_t launch_k2_fixup(mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist,
+                           const VoteFixup& fixup, hipStream_t s);
 // splits < 0 (plain kernel): -splits blocks per frame that divide the marker PERMUTATIONS among themselves and keep
 // their slice of the per-permutation table in LDS (k2_table_slices says when and into how many)
 int k2_table_slices(int n_markers);

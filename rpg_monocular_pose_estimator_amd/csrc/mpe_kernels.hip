@@ -159,6 +159,22 @@ __global__ __launch_bounds__(256) void k1a_scan(const uint4* __restrict__ px, u6
 // schedule).  It is then capped to 4 blocks = 4 waves per SIMD (via an otherwise unused dynamic LDS allocation,
 // 40 KB per block by default) so that its 44-VGPR waves leave room for the voting waves; HBM throughput is
 // unchanged at that occupancy (measured).  The value is a per-handle setting (option "k1a_dummy_lds").
+// Compute units of the CURRENT device (hipDeviceProp_t::multiProcessorCount, cached per device): 256 on a whole
+// MI355X, 32 on one partition in CPX mode — "one resident block per CU" must mean that on either.
+int device_cu_count() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] > 0) return cached[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    n = 256;
+  }
+  cached[dev] = n;
+  return n;
+}
+
 hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long long* flags, int thr,
                            int dummy_lds_bytes, hipStream_t s, int blocks_per_cu) {
   const size_t n_seg = n_bytes / 16;
@@ -166,9 +182,9 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
   const ThrTest q = make_thr_test(thr);
   const size_t n_chunks = (n_seg + 64 * K1A_UNROLL - 1) / (64 * K1A_UNROLL);
   size_t blocks = (n_chunks + 3) / 4;  // 4 waves per block
-  // 256 CUs x blocks per CU, grid-stride beyond.  blocks_per_cu > 0: a deliberately small resident set (a side scan
+  // CUs x blocks per CU, grid-stride beyond.  blocks_per_cu > 0: a deliberately small resident set (a side scan
   // that must leave the wave slots to the kernel it runs beside)
-  const size_t max_blocks = 256 * (size_t)(blocks_per_cu > 0 ? blocks_per_cu : K1A_BLOCKS_PER_CU);
+  const size_t max_blocks = (size_t)device_cu_count() * (size_t)(blocks_per_cu > 0 ? blocks_per_cu : K1A_BLOCKS_PER_CU);
   if (blocks > max_blocks) blocks = max_blocks;
   const size_t dummy_lds = dummy_lds_bytes > 0 ? (size_t)dummy_lds_bytes : 0;
   if (dummy_lds > 65536) {  // tuning experiments only: more than the default dynamic-LDS limit
@@ -2123,8 +2139,8 @@ __device__ __forceinline__ float k2_prefilter_threshold(double back_tol, double 
 // Votes are integer adds, so the order in which the two kernels cast them does not matter.  The strict verdict
 // REPLACES the fast one: with the list in place the histograms are those of k2_vote_strict (tests/soak_votes.py,
 // test_default_votes_equal_strict_votes), at ~0.25 % of the hypotheses re-evaluated.  A full list (sized at > 100 times the
-// expected rate by the host side) leaves the fast verdict in place and counts the event (option
-// "vote_fixup_overflow").
+// expected rate by the host side) loses entries: those frames are voted again, whole, by the strict loop nest
+// (k2_vote_relost; options "vote_fixup_overflow" / "vote_relost_frames" count the events and the frames).
 #ifndef K2_SUS_BAND_EXP
 #define K2_SUS_BAND_EXP (-6)  // the band's half width in pixels: 2^-6 = 0.0156 px, four times what (a) lets through
 #endif
@@ -2148,8 +2164,11 @@ __device__ __forceinline__ unsigned k2_sus_code(int c0, int c1, int c2, int p0, 
   return (unsigned)(c0 | (c1 << 5) | (c2 << 10) | (p0 << 15) | (p1 << 19) | (p2 << 23)) | (kmask << 27) |
          ((unsigned)any_fast << 31);
 }
-// an entry that finds the global list full is LOST: its votes are cast nowhere, so the frame is marked
-// (MPE_FRAME_VOTE_LIST_FULL in its status: a capacity overrun like MPE_FRAME_TOO_MANY_*, never silent) and counted
+// an entry that finds the global list full is LOST: its votes are cast nowhere.  The frame is marked
+// (MPE_FRAME_VOTE_LIST_FULL in its status) and counted; k2_vote_relost, launched behind the fix-up kernel, votes every
+// marked frame again with the strict kernel's loop nest (the histogram the default arithmetic has to equal anyway) and
+// clears the mark — a full list costs time, never a pose.  The status only survives to the caller
+// if that launch is skipped (it never is on the library's paths).
 __device__ __forceinline__ void k2_sus_lost(const K2SusDesc& g) {
   atomicAdd(&g.ctl[1], 1u);
   *g.frame_status = MPE_FRAME_VOTE_LIST_FULL;
@@ -2164,6 +2183,7 @@ __device__ __forceinline__ void k2_sus_push(const K2Frame& F, unsigned code, uns
     return;
   }
   const K2SusDesc g = *F.susd;
+  if (!g.ctl) return;  // (no list was supplied: launch_k2_vote refuses that for vote_arith != 0, see there)
   const unsigned gs = atomicAdd(&g.ctl[0], 1u);
   if (gs < g.cap) {
     g.list[(size_t)K2_SUS_WORDS * gs] = w0;
@@ -2273,6 +2293,7 @@ __device__ __forceinline__ void k2_sus_flush(const K2Frame& F, unsigned* s_base)
   const unsigned n = min(*F.sus_lds_n, F.sus_lds_cap);
   if (n == 0) return;  // (uniform over the block)
   const K2SusDesc g = *F.susd;
+  if (!g.ctl) return;  // (uniform as well)
   if (F.tid == 0) *s_base = atomicAdd(&g.ctl[0], n);
   __syncthreads();
   const unsigned base = *s_base;
@@ -2953,7 +2974,12 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
   const int n_d = d->n, n_m = sp.n_markers;
   typename std::conditional<SCAN, ScanRider, NoRider>::type rider;
   if constexpr (SCAN) rider.init(scan, smem);  // (this variant keeps the back-projections in registers)
-  if (n_d < 4 || d->status != 0 || n_m < 4) {  // min_num_leds_detected_ (pose_estimator.h:78)
+  // min_num_leds_detected_ (pose_estimator.h:78).  MPE_FRAME_VOTE_LIST_FULL is written by THIS launch (k2_sus_lost,
+  // possibly by a sibling block of the same frame while this one starts): it must not decide the branch — threads of
+  // one block could read different values around the barriers below — and such a frame is voted again anyway
+  // (k2_vote_relost), so both values take the voting path.
+  const int st_in = d->status;
+  if (n_d < 4 || (st_in != 0 && st_in != MPE_FRAME_VOTE_LIST_FULL) || n_m < 4) {
     rider.drain();
     return;
   }
@@ -3202,18 +3228,15 @@ __device__ __forceinline__ void k2_strict_item(const V3& fa, const V3& fb, const
 // Strict voting kernel (option "vote_arith" = 0): initialise()'s loop nest (pose_estimator.cpp:565-702), every
 // hypothesis through k2_strict_item.  No tables, no scan rider, about 2.5x the instructions of k2_vote: the reference
 // point the default arithmetic is held against, selectable at run time.
-__global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detections* __restrict__ dets, SolveParams sp,
-                                                             uint32_t* __restrict__ hist, int splits,
-                                                             const int* __restrict__ item_range) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ double s_px[MPE_MAX_DETECTIONS][2];
-  __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
-  __shared__ unsigned s_hist[MPE_HIST_STRIDE];
-  const int f = blockIdx.x / splits, part = blockIdx.x - f * splits;
+// One frame's share `part` of `splits` of initialise()'s loop nest with the strict item, votes collected in LDS and
+// then ADDED to (STORE = false) or STORED over (true: a whole frame by one block) the frame's histogram.
+template <bool STORE>
+__device__ __forceinline__ void k2_strict_frame(const mpe_detections* __restrict__ d, const SolveParams& sp,
+                                                uint32_t* __restrict__ gh, int f, int part, int splits,
+                                                const int* __restrict__ item_range, unsigned char* smem,
+                                                double (*s_px)[2], double (*s_iv)[3], unsigned* s_hist) {
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const mpe_detections* d = dets + f;
   const int n_d = d->n, n_m = sp.n_markers;
-  if (n_d < 4 || d->status != 0 || n_m < 4) return;
   for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) s_hist[i] = 0;
   if (tid < n_d) {
     const double u = d->undist_xy[2 * tid], v = d->undist_xy[2 * tid + 1];
@@ -3242,10 +3265,57 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detection
                    [&](const int a, const int m) { atomicAdd(&s_hist[a * MPE_MAX_MARKERS + m], 1u); });
   }
   __syncthreads();
-  uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
   for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) {
     const unsigned v = s_hist[i];
-    if (v) atomicAdd(&gh[i], v);
+    if constexpr (STORE) gh[i] = v;
+    else if (v) atomicAdd(&gh[i], v);
+  }
+}
+__global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detections* __restrict__ dets, SolveParams sp,
+                                                             uint32_t* __restrict__ hist, int splits,
+                                                             const int* __restrict__ item_range) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ double s_px[MPE_MAX_DETECTIONS][2];
+  __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
+  __shared__ unsigned s_hist[MPE_HIST_STRIDE];
+  const int f = blockIdx.x / splits, part = blockIdx.x - f * splits;
+  const mpe_detections* d = dets + f;
+  if (d->n < 4 || d->status != 0 || sp.n_markers < 4) return;
+  k2_strict_frame<false>(d, sp, hist + (size_t)f * MPE_HIST_STRIDE, f, part, splits, item_range, smem, s_px, s_iv, s_hist);
+}
+
+// Frames that lost a suspect entry to a full list (k2_sus_lost) are voted again, whole, with the strict loop nest: the
+// histogram is STORED over whatever the fast launch and the fix-up kernel left, the mark is cleared, the tail then
+// sees an ordinary frame.  A fixed grid: nothing lost since the last launch on this slot (ctl[1] == ctl[4], the rule)
+// -> every block leaves after one load; otherwise the blocks stride over the launch's frames looking for the mark.
+// The last block to finish records what has been handled (ctl[4]; ctl[5] counts the blocks).
+__global__ __launch_bounds__(K2_THREADS) void k2_vote_relost(mpe_detections* __restrict__ dets, int n_frames, SolveParams sp,
+                                                             uint32_t* __restrict__ hist, VoteFixup fx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ double s_px[MPE_MAX_DETECTIONS][2];
+  __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
+  __shared__ unsigned s_hist[MPE_HIST_STRIDE];
+  const unsigned lost = fx.ctl[1];
+  if (lost == fx.ctl[4]) return;  // (only the last block of a launch writes ctl[4], after every block has read it)
+  for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
+    mpe_detections* d = dets + f;
+    if (d->status != MPE_FRAME_VOTE_LIST_FULL) continue;  // (written by an earlier launch: uniform over the block)
+    if (d->n >= 4 && sp.n_markers >= 4)
+      k2_strict_frame<true>(d, sp, hist + (size_t)f * MPE_HIST_STRIDE, f, 0, 1, nullptr, smem, s_px, s_iv, s_hist);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      d->status = 0;
+      atomicAdd(&fx.ctl[6], 1u);  // frames voted again (cumulative)
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&fx.ctl[5], 1u) == gridDim.x - 1) {
+      fx.ctl[4] = lost;
+      fx.ctl[5] = 0;
+      __threadfence();
+    }
   }
 }
 
@@ -3292,12 +3362,18 @@ __global__ __launch_bounds__(K2_FIX_THREADS) void k2_vote_fixup(const mpe_detect
   }
 }
 
-hipError_t launch_k2_fixup(const mpe_detections* dets, const SolveParams& sp, uint32_t* hist, const VoteFixup& fx,
+hipError_t launch_k2_fixup(mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist, const VoteFixup& fx,
                            hipStream_t s) {
   if (!fx.ctl || fx.cap == 0 || sp.n_markers < 4) return hipSuccess;
   // (the entry count lives on the device: a fixed grid strides over it — wide, every entry is a single-wave chain of
   //  dependent FP64 operations (~30 us), and blocks beyond the count leave at once; ~0.15 % of the hypotheses)
   hipLaunchKernelGGL(k2_vote_fixup, dim3(2048), dim3(K2_FIX_THREADS), 0, s, dets, sp, hist, fx);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // frames that lost an entry to a full list: voted again with the strict loop nest (nothing lost: 256 blocks, one load each)
+  const size_t lds_strict = (size_t)(sp.n_markers - 3) * 2 * K2_THREADS * sizeof(double);
+  hipLaunchKernelGGL(k2_vote_relost, dim3((unsigned)std::min(n_frames, 256)), dim3(K2_THREADS), lds_strict, s, dets,
+                     n_frames, sp, hist, fx);
   return hipGetLastError();
 }
 
@@ -3314,6 +3390,8 @@ hipError_t launch_k2_vote(mpe_detections* dets, int n_frames, const SolveParams&
     fx.screen = sp.vote_arith == 1 ? 1u : 0u;
   }
   if (n_frames <= 0 || sp.n_markers < 4) return hipSuccess;
+  // the fast kernels append to the list (suspects, or what their per-wave queues cannot hold): they need one
+  if (sp.vote_arith != 0 && !fx.ctl) return hipErrorInvalidValue;
   int slice_tab = 0;
   if (splits < 0) {  // -(blocks per frame): the blocks share the marker permutations, table slices in LDS
     splits = -splits;
@@ -4504,7 +4582,8 @@ hipError_t launch_to_mono8(const uint8_t* src, size_t src_stride, size_t src_fra
   const long long n_rows = (long long)n_frames * rows;
   const long long items = n_rows * ((cols + 3) / 4);
   long long blocks = (items + 255) / 256;
-  if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond 64 blocks per CU
+  const long long most = (long long)device_cu_count() * 64;  // grid-stride beyond 64 blocks per CU
+  if (blocks > most) blocks = most;
   hipLaunchKernelGGL(k_to_mono8, dim3((unsigned)blocks), dim3(256), 0, s, src, src_stride, src_frame_stride, encoding,
                      big_endian, rows, cols, n_rows, dst);
   return hipGetLastError();

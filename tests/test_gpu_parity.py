@@ -1016,6 +1016,64 @@ def test_default_votes_equal_strict_votes(orc):
 
 
 @pytest.mark.gpu
+def test_a_full_suspect_list_costs_time_not_poses(orc):
+    """a suspect list that overflows used to LOSE entries and reject the frame
+    (MPE_FRAME_VOTE_LIST_FULL).  Now the frames that lost an entry are voted again, whole, by the strict loop nest
+    behind the fix-up kernel (k2_vote_relost) and come out as ordinary frames.  With the list capped at a handful of
+    entries (option "vote_list_cap") the default arithmetic must still produce the strict histograms — plain kernel at
+    5 and 8 markers, a cluttered single frame (8 markers, 28 detections: ~1.1 M hypotheses), the fused scan-carrying
+    kernel over two sub-batches — with overflow events counted, frames re-voted, and no -13 status anywhere."""
+    import torch
+    h = mpe.Handle()
+    try:
+        K, _ = synth.camera_for(480, 752)
+        rng = np.random.default_rng(5)
+        cases = []
+        d2 = synth.make_frames("C2", 128, seed=515)
+        dets = [orc.find_leds(f, orc.make_params(), d2["K"], d2["D"])[0] for f in d2["frames"]]
+        cases.append(("C2", [x for x in dets if len(x) >= 4], d2["markers"], d2["K"], 5.0))
+        d3 = synth.make_frames("C3", 4, seed=516)
+        dets = [orc.find_leds(f, orc.make_params(), d3["K"], d3["D"])[0] for f in d3["frames"]]
+        cases.append(("C3", [x for x in dets if len(x) >= 4], d3["markers"], d3["K"], 5.0))
+        clutter = np.column_stack([rng.uniform(200, 550, 28), rng.uniform(120, 360, 28)])
+        cases.append(("cluttered frame", [clutter], synth.CONFIGS["C3"]["markers"], K, 5.0))
+        for name, dets, markers, Kc, tol in cases:
+            h.set_option("vote_list_cap", 0)
+            h.set_option("vote_arith", 0)
+            strict = h.vote_batch(dets, markers, Kc, tol)
+            h.set_option("vote_arith", 1)
+            roomy = h.vote_batch(dets, markers, Kc, tol)
+            ov0, re0 = h.get_option("vote_fixup_overflow"), h.get_option("vote_relost_frames")
+            assert ov0 == 0 or name == "cluttered frame"
+            h.set_option("vote_list_cap", 4)
+            tight = h.vote_batch(dets, markers, Kc, tol)
+            assert h.get_option("vote_list_cap") == 4
+            assert h.get_option("vote_fixup_overflow") > ov0, name
+            assert h.get_option("vote_relost_frames") > re0, name
+            for i in range(len(dets)):
+                assert np.array_equal(roomy[i], strict[i]), (name, i)
+                assert np.array_equal(tight[i], strict[i]), (name, i, np.argwhere(tight[i] != strict[i])[:5])
+        # the cluttered frame end to end on a single-frame call: a pose-or-not verdict, never a capacity status
+        h.set_option("vote_list_cap", 0)
+        r = h.solve_bruteforce(clutter, synth.CONFIGS["C3"]["markers"], K, mpe.demo_params())
+        assert r["status"] in (0, 1), r["status"]
+        # fused kernel + pipelined schedule + streaming shape: records byte-identical to the roomy list's
+        d = synth.make_frames("C2", 96, seed=78)
+        big = torch.from_numpy(d["frames"]).cuda().repeat(342, 1, 1)[:32768 + 64].contiguous()
+        ra = h.estimate_batch(big, d["markers"], d["K"], d["D"], mpe.demo_params())
+        h.set_option("vote_list_cap", 8)
+        ov0, re0 = h.get_option("vote_fixup_overflow"), h.get_option("vote_relost_frames")
+        rb = h.estimate_batch(big, d["markers"], d["K"], d["D"], mpe.demo_params())
+        assert h.get_option("vote_fixup_overflow") > ov0 and h.get_option("vote_relost_frames") > re0
+        assert not np.any(rb["status"] == -13)
+        for k in ("status", "n_corr", "n_det"):
+            assert np.array_equal(ra[k], rb[k]), k
+        assert np.array_equal(ra["T"], rb["T"], equal_nan=True) and np.array_equal(ra["cov"], rb["cov"], equal_nan=True)
+    finally:
+        h.close()
+
+
+@pytest.mark.gpu
 def test_c3_poses_at_rounding_level(hip, orc):
     """8 markers: 56 validation P3P per frame, summed in the reference's combination order by the tail kernel
     (16 per round, lanes added in order) -> the poses agree with the oracle far below the north_star tolerance."""
