@@ -11,13 +11,24 @@ the per-frame pose records to rank 0 (RCCL point-to-point, 432 B/frame, asynchro
 GPU, rendezvous on 127.0.0.1) when it was not already started by a launcher (WORLD_SIZE unset); under a launcher it
 checks that WORLD_SIZE == N.  Fewer visible GPUs than ranks is a hard error, never a silent share.
 
-Prints ONE JSON line (rank 0): metric/value as BASELINE.json, plus
-  roofline      — the kernel that moves the image bytes in the timed mode (by default the voting kernel that
-                  carries the scan of the next sub-batch, else k1a_scan): algorithmic bytes (rows*cols per
-                  frame scanned) / HIP-event time of its launches; roofline_isolated = k1a_scan alone
-  cpu_baseline  — the CPU oracle (restated reference path, "port") on this box's host cores, bounded sample
+Prints ONE JSON line (rank 0): metric / value as BASELINE.json on C2, plus
+  roofline       the kernel that moves the image bytes in the timed mode (the voting kernel that carries the scan
+                 of the next sub-batch): algorithmic bytes (rows*cols per frame scanned) / HIP-event time of its
+                 launches inside the timed region; roofline_isolated = k1a_scan alone
+  cpu_baseline   the CPU oracle (restated reference path, "port") on this box's host cores, bounded sample
+  parity         HIP vs oracle on the records of the LAST TIMED STEP (host_rec), every mismatch classified
+and — at N = 1, after the headline leg and outside its timed region, each with its own roofline + parity sample —
+  other_configs  C1, C3 (demo tolerance 5 and tolerance 2), C4 (BASELINE.json configs[0], [2], [3])
+  clutter        C2 with 4 / 16 distractor spots, 0.05 % salt noise, a saturated 64x64 patch
+  tracked        the stateful estimator: one stream (latency), 8 and 64 streams in lock step (configs[4] on one GPU)
+  latency_ms_one_frame   one brute-force frame, host memory in / record out
+and — at N > 1 — ranks_seen, per_rank_fps and shard_parity (a sample of EVERY rank's shard checked on rank 0).
+Exit codes: 3 = a mismatch that is not a witnessed instability of the reference algorithm, 4 = a fraction above 1.
+Prose about what each field means lives in DESIGN.md section 4, not in the line.
 """
 import argparse
+import copy
+import hashlib
 import json
 import os
 import sys
@@ -27,6 +38,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+METRIC = "frames/sec at 752x480, 5 LEDs, brute-force init; pose RMSE vs CPU ref"
+PMC_FILES = ("round5_pmc.json", "round4_pmc.json", "round3_pmc.json")
+SAMPLE_PER_RANK = 64  # frames of every rank's shard that rank 0 checks against the oracle at N > 1
 
 
 def effective_cores():
@@ -42,10 +57,30 @@ def effective_cores():
     return n
 
 
+def rank_report(dist, rank, world, device, fps_local):
+    """What the process group itself says about the run (N > 1): the ranks that took part, every rank's own rate."""
+    import torch
+    if world == 1:
+        return [0], [fps_local]
+    mine = torch.tensor([float(rank), float(fps_local)], dtype=torch.float64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    return [int(t[0].item()) for t in every], [float(t[1].item()) for t in every]
+
+
+def records_checksum(rec):
+    """Order-sensitive digest of a record sample: status, correspondences count and pose bits."""
+    h = hashlib.sha256()
+    for k in ("status", "n_det", "n_corr", "T"):
+        h.update(np.ascontiguousarray(rec[k]).tobytes())
+    return h.hexdigest()[:16]
+
+
 def plumbing_only(args, rank, world):
     """The N-rank bench without GPU work (CPU, gloo): same launch path, sharding, double-buffered pose gather to
-    rank 0, barrier / max-over-ranks timing and JSON line as the real run; every rank's "kernels" are replaced by
-    writing recognisable records for its shard.  Lets the CPU test-suite drive the bench ENTRY with world size 2."""
+    rank 0, barrier / max-over-ranks timing, rank report and JSON line as the real run; every rank's "kernels" are
+    replaced by writing recognisable records for its shard.  Lets the CPU test-suite drive the bench ENTRY with world
+    size 2 / 3."""
     import torch
     import torch.distributed as dist
     import rpg_monocular_pose_estimator_amd as mpe
@@ -57,13 +92,17 @@ def plumbing_only(args, rank, world):
     pipe = parallel.RootGatherPipeline(rank, world, B * mpe.RESULT_DTYPE.itemsize, torch.device("cpu"))
     lo, hi = parallel.shard_bounds(world * B, rank, world)  # weak scaling: B frames per rank
 
+    def synthetic(r, k):
+        a, b = parallel.shard_bounds(world * B, r, world)
+        rec = np.zeros(B, mpe.RESULT_DTYPE)
+        rec["n_det"] = np.arange(a, b)     # global frame index
+        rec["n_corr"] = k                  # step marker
+        rec["status"] = r
+        return rec
+
     def step(k):
         buf = pipe.local(k)
-        rec = np.zeros(B, mpe.RESULT_DTYPE)
-        rec["n_det"] = np.arange(lo, hi)   # global frame index
-        rec["n_corr"] = k                  # step marker
-        rec["status"] = rank
-        buf.copy_(torch.from_numpy(np.frombuffer(rec.tobytes(), np.uint8).copy()))
+        buf.copy_(torch.from_numpy(np.frombuffer(synthetic(rank, k).tobytes(), np.uint8).copy()))
         pipe.submit(k)
 
     def barrier():
@@ -78,26 +117,679 @@ def plumbing_only(args, rank, world):
     for k in range(args.warmup, args.warmup + args.steps):
         step(k)
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    ranks_seen, per_rank = rank_report(dist, rank, world, "cpu", B * args.steps / dt_local)
     if rank == 0:
         last = args.warmup + args.steps - 1
         got = parallel.records_from_bytes(pipe.gathered(last))
         ok = (len(got) == world * B and np.array_equal(got["n_det"], np.arange(world * B)) and
               np.all(got["n_corr"] == last) and np.array_equal(got["status"], np.repeat(np.arange(world), B)))
-        print(json.dumps({"metric": "frames/sec at 752x480, 5 LEDs, brute-force init; pose RMSE vs CPU ref",
+        # the self-check of a real N > 1 run, on the synthetic records: a sample of EVERY rank's shard as it arrived
+        # on rank 0 against what that rank must have produced
+        ns = min(SAMPLE_PER_RANK, B)
+        shard = [{"rank": r, "frames": ns, "checksum": records_checksum(got[r * B:r * B + ns]),
+                  "equal": records_checksum(got[r * B:r * B + ns]) == records_checksum(synthetic(r, last)[:ns])}
+                 for r in range(world)]
+        print(json.dumps({"metric": METRIC,
                           "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f64", "data": "synthetic", "plumbing_only": True,
                           "gather_intact": bool(ok), "records_on_rank0": int(len(got)),
+                          "ranks_seen": ranks_seen, "per_rank_fps": per_rank, "shard_parity": shard,
                           "config": {"workload": "plumbing only: no kernels", "frames_per_gpu_per_step": B}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+# ---- synthetic batches --------------------------------------------------------------------------------------------
+CLUTTER = {"d4": "4 distractor spots", "d16": "16 distractor spots", "salt": "0.05 % salt noise (isolated 255 pixels)",
+           "patch": "one saturated 64x64 patch"}
+
+
+def make_batch(synth, config, clutter, B, dev, rank):
+    """B frames of `config` resident on `dev` (+ clutter variant) -> (cfg, frames).  The first 256 scenes come from
+    their own seed so that rank 0 can re-create the head of any rank's shard (N > 1 self-check)."""
+    import torch
+    cfg = dict(synth.CONFIGS[config])
+    if clutter in ("d4", "d16"):
+        cfg["n_distractors"] = int(clutter[1:])
+    head = min(B, 256)
+    _, spots = synth.make_scenes_batch(cfg, head, seed=5000 + rank)
+    if B > head:
+        _, more = synth.make_scenes_batch(cfg, B - head, seed=1000 + rank)
+        spots = np.concatenate([spots, more])
+    frames = synth.render_frames_torch(spots, cfg["rows"], cfg["cols"], cfg["spot_sigma"], dev, seed=77 + rank)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242 + rank)
+    if clutter == "salt":
+        for a in range(0, B, 2048):
+            m = torch.rand(frames[a:a + 2048].shape, generator=g, device=dev) < 0.0005
+            frames[a:a + 2048][m] = 255
+    elif clutter == "patch":
+        rows, cols = cfg["rows"], cfg["cols"]
+        off = torch.arange(64, device=dev)
+        for a in range(0, B, 2048):
+            n = min(2048, B - a)
+            y0 = torch.randint(0, rows - 64, (n,), generator=g, device=dev)
+            x0 = torch.randint(0, cols - 64, (n,), generator=g, device=dev)
+            fi = torch.arange(a, a + n, device=dev)[:, None, None].expand(-1, 64, 64)
+            yy = (y0[:, None] + off)[:, :, None].expand(-1, -1, 64)
+            xx = (x0[:, None] + off)[:, None, :].expand(-1, 64, -1)
+            frames[fi.reshape(-1), yy.reshape(-1), xx.reshape(-1)] = 255
+    return cfg, frames
+
+
+def head_of_shard(synth, config, clutter, n, dev, r):
+    """The first n (<= 256) frames of rank r's batch, re-created on this rank (same seeds, same device type)."""
+    cfg = dict(synth.CONFIGS[config])
+    if clutter in ("d4", "d16"):
+        cfg["n_distractors"] = int(clutter[1:])
+    _, spots = synth.make_scenes_batch(cfg, 256, seed=5000 + r)
+    return synth.render_frames_torch(spots, cfg["rows"], cfg["cols"], cfg["spot_sigma"], dev, seed=77 + r)[:n]
+
+
+# ---- parity of a record sample against the oracle ------------------------------------------------------------------
+def parity_block(h, sample, got, markers, K, D, P, back_tol, cores, time_it=True):
+    """HIP records `got` of the frames `sample` (numpy) against the CPU oracle.  Every frame on which the two paths
+    disagree is traced to the hypotheses / validation solves that differ (tests/forensics.py) and must be a witnessed
+    instability of the reference algorithm itself; an unexplained one makes the run FAIL (exit code 3)."""
+    import oracle
+    oracle.build()
+    ns = len(sample)
+    op = oracle.make_params() if back_tol is None else oracle.make_params(back_projection_pixel_tolerance=back_tol)
+    t1 = time.perf_counter()
+    ref = oracle.estimate_batch(sample, markers, K, D, op, n_threads=cores)
+    cpu_dt = time.perf_counter() - t1
+    n_status = int((ref["status"] != got["status"]).sum())
+    ok = (ref["status"] == 0) & (got["status"] == 0)
+    dpos = np.linalg.norm(ref["T"][ok][:, [3, 7, 11]] - got["T"][ok][:, [3, 7, 11]], axis=1)
+    # rotation difference of the two poses (rad), from the trace of R_ref^T R_hip
+    Ra = ref["T"][ok].reshape(-1, 4, 4)[:, :3, :3]
+    Rb = got["T"][ok].reshape(-1, 4, 4)[:, :3, :3]
+    tr = np.einsum("nij,nij->n", Ra, Rb)
+    drot = np.arccos(np.clip((tr - 1.0) / 2.0, -1.0, 1.0)) if len(tr) else np.zeros(0)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import forensics
+    dall = np.zeros(ns)
+    dall[ok] = dpos
+    rall = np.zeros(ns)
+    rall[ok] = drot
+    verdicts = []
+    for i in np.nonzero((ref["status"] != got["status"]) | (dall > 1e-4) | (rall > 1e-3))[0]:
+        und, _ = oracle.find_leds(sample[i], op, K, D)
+        v = forensics.classify_end_to_end(h, oracle, und, markers, K, P, op)
+        verdicts.append({"frame": int(i), "hip_status": int(got["status"][i]), "oracle_status": int(ref["status"][i]),
+                         "dpos_m": float(dall[i]), "stage": v.get("stage"), "unstable": bool(v["unstable"]),
+                         "min_cancellation": v.get("min_w"), "oracle_flips_under_1ulp": v.get("oracle_flips_under_1ulp")})
+    n_unexplained = sum(1 for v in verdicts if not v["unstable"])
+    blk = {"frames": ns, "status_mismatches": n_status, "poses_compared": int(ok.sum()),
+           "pose_mismatches_gt_1e-4m_or_1e-3rad": int(((dpos > 1e-4) | (drot > 1e-3)).sum()),
+           "pos_rmse_m": float(np.sqrt(np.mean(dpos ** 2))) if len(dpos) else None,
+           "pos_max_m": float(dpos.max()) if len(dpos) else None,
+           "rot_max_rad": float(drot.max()) if len(drot) else None,
+           "mismatches_classified_unstable": len(verdicts) - n_unexplained, "mismatches_unexplained": n_unexplained}
+    if verdicts:
+        blk["verdicts"] = verdicts[:8]
+    return blk, (ns / cpu_dt if time_it else None), n_unexplained > 0
+
+
+def load_pmc(mpe):
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                with open(path) as fh:
+                    d = json.load(fh)
+                return d, name, d.get("source_fingerprint") == mpe.source_fingerprint()
+            except Exception:
+                pass
+    return {}, None, None
+
+
+# ---- one configuration through the streaming entry -------------------------------------------------------------------
+def run_config(args, ctx, light=False):
+    """-> (record for the JSON line or None on ranks > 0, parity_failed, impossible).  `light`: a secondary leg — no
+    false-hint leg, no host-streamed leg, no isolated-kernel pass."""
+    import torch
+    import rpg_monocular_pose_estimator_amd as mpe
+    from rpg_monocular_pose_estimator_amd import synth, parallel
+    rank, local_rank, world, dev, dist = ctx["rank"], ctx["local_rank"], ctx["world"], ctx["dev"], ctx["dist"]
+
+    B = args.frames
+    cfg, frames = make_batch(synth, args.config, args.clutter, B, dev, rank)
+    rows, cols = cfg["rows"], cfg["cols"]
+    K, D = synth.camera_for(rows, cols)
+    markers = np.asarray(cfg["markers"])
+    # two result buffers: while the records of step k travel to rank 0, step k+1 already writes the other one
+    pipe = parallel.RootGatherPipeline(rank, world, B * mpe.RESULT_DTYPE.itemsize, dev)
+    results = pipe.local(0)
+    torch.cuda.synchronize()
+
+    h = mpe.Handle(local_rank)
+    # one explicit (non-default) stream carries the library's kernels AND the pose gather: the collective is then
+    # ordered after the tail kernel by the stream itself (torch's legacy default stream is 0, which the library
+    # reads as "use the handle's own stream" and which would not be ordered with it)
+    work_stream = torch.cuda.Stream(device=dev)
+    if os.environ.get("MPE_BENCH_OWN_STREAM") != "1":
+        h.set_stream(work_stream.cuda_stream)
+    P = mpe.demo_params() if args.back_tol is None else mpe.demo_params(back_projection_pixel_tolerance=args.back_tol)
+    h.set_option("pipeline", args.pipeline)
+    h.set_option("pipeline_mode", args.pipeline_mode)
+    h.set_option("vote_arith", args.vote_arith)
+    h.set_option("vote_splits", args.vote_splits)
+    if args.scan_split_pct >= 0:
+        h.set_option("scan_split_pct", args.scan_split_pct)
+    if args.side_scan_blocks >= 0:
+        h.set_option("side_scan_blocks", args.side_scan_blocks)
+    if args.assume_side_streams:
+        h.set_option("assume_side_streams", 1)
+    if args.k1a_lds >= 0:
+        h.set_option("k1a_dummy_lds", args.k1a_lds)
+    for kv in args.opt or []:
+        k_, v_ = kv.split("=")
+        h.set_option(k_, int(v_))
+
+    step_no = [0]
+    # The steps form a STREAM of batches (mpe_estimate_batch_device_submit / _collect): a submission does not join the
+    # library's side streams back, its completion is an event that the CONSUMER stream waits for — here the stream
+    # that delivers the pose records: an asynchronous, double-buffered D2H copy of the 432-byte records into pinned
+    # host memory on every rank (what a caller of estimateBodyPose ends up holding), and for N > 1 the RCCL gather of
+    # the records to rank 0.  Every submission announces the next one's frames, so its last voting launch carries the
+    # image scan of the next batch's first sub-batch.
+    out_stream = torch.cuda.Stream(device=dev)
+    rec_bytes = B * mpe.RESULT_DTYPE.itemsize
+    host_rec = [torch.empty(rec_bytes, dtype=torch.uint8).pin_memory() for _ in range(2)] if args.records_to_host else None
+    out_done = [None, None]
+    streaming = not args.no_streaming
+
+    def step(next_ptr=None, next_n=None):
+        k = step_no[0]
+        step_no[0] += 1
+        with torch.cuda.stream(work_stream):
+            buf = pipe.local(k)             # (waits until this buffer's previous transfer has left)
+            if out_done[k & 1] is not None:
+                work_stream.wait_event(out_done[k & 1])   # ... and until its previous D2H copy has read it
+            if streaming:
+                h.estimate_batch_device_submit(frames.data_ptr(), B, rows, cols, markers, K, D, P, buf.data_ptr(),
+                                               frames.data_ptr() if next_ptr is None else next_ptr,
+                                               B if next_n is None else next_n)
+                h.estimate_batch_device_collect(out_stream.cuda_stream)
+            else:
+                h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, buf.data_ptr())
+                out_stream.wait_stream(work_stream)
+        with torch.cuda.stream(out_stream):
+            if host_rec is not None:
+                host_rec[k & 1].copy_(buf, non_blocking=True)
+            pipe.submit(k)                  # the only collective: pose records -> rank 0, asynchronous
+            ev = torch.cuda.Event()
+            ev.record(out_stream)
+            out_done[k & 1] = ev
+        return k
+
+    def barrier():
+        with torch.cuda.stream(out_stream):
+            pipe.finish()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # the K timed steps, bracketed by barrier + synchronize; an event between steps on the work stream gives the
+    # per-step durations as well (median reported next to the mean the bracket yields)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # the dominant kernel is timed INSIDE the timed region: a pair of HIP events around every voting launch that
+    # carries a scan, on the stream it is launched on, nothing else recorded (option "vote_events")
+    if args.vote_events:
+        h.set_option("vote_events", args.steps)
+    t0 = time.perf_counter()
+    marks[0].record(work_stream)
+    last_k = 0
+    for i in range(args.steps):
+        last_k = step()
+        marks[i + 1].record(work_stream)
+    barrier()
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    # the records of the LAST TIMED STEP, as they arrived in host memory (parity is computed from these)
+    if host_rec is not None:
+        timed_rec = np.frombuffer(host_rec[last_k & 1].numpy().tobytes(), dtype=mpe.RESULT_DTYPE)
+    else:
+        timed_rec = parallel.records_from_bytes(pipe.local(last_k))
+    gathered_last = parallel.records_from_bytes(pipe.gathered(last_k)) if (world > 1 and rank == 0) else None
+    vote_in_region_ms, vote_in_region_n = None, 0
+    if args.vote_events:
+        vote_in_region_n = h.get_option("vote_launches")
+        if vote_in_region_n > 0:
+            vote_in_region_ms = h.get_option("vote_launch_ns_mean") * 1e-6
+        h.set_option("vote_events", 0)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ranks_seen, per_rank_fps = rank_report(dist, rank, world, dev, B * args.steps / dt_local)
+    fps = world * B * args.steps / dt
+    fix_items = h.get_option("vote_fixup_items")
+    fix_overflow = h.get_option("vote_fixup_overflow")
+    relost = h.get_option("vote_relost_frames")
+
+    # ---- the same steps with a next-batch announcement that does NOT come true (the timed region above is the best
+    #      case: every hint is right).  The announced pointer is another view of the same frames, so the submission
+    #      that follows finds no scan of its own first sub-batch and runs it stand-alone: what a wrong hint costs.
+    false_hint = None
+    if streaming and args.false_hint_leg and not light and B >= 2 * 32768 and len(markers) <= 5:
+        shift = 32768
+        wrong = frames[shift:]
+        nfh = max(3, min(10, args.steps))
+        step(wrong.data_ptr(), B - shift)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(nfh):
+            step(wrong.data_ptr(), B - shift)
+        barrier()
+        dt_fh = time.perf_counter() - t1
+        if world > 1:
+            tmax = torch.tensor([dt_fh], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_fh = float(tmax.item())
+        false_hint = {"ms_per_step": dt_fh / nfh * 1e3, "steps": nfh, "value": world * B * nfh / dt_fh}
+
+    # ---- per-kernel time with HIP events on the launch streams: extra steps in exactly the same mode
+    #      and launch shape as the timed region (a big batch runs as sub-batches, every kernel is launched
+    #      once per sub-batch; the numbers are AVERAGES PER LAUNCH, like rocprofv3 --stats reports them)
+    h.set_profiling(True)
+    kms, subs = [], []
+
+    def one_call():
+        if streaming:  # the same entry, hint included, as the timed region
+            h.estimate_batch_device_submit(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr(),
+                                           frames.data_ptr(), B)
+            h.estimate_batch_device_collect(0)
+        else:
+            h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
+
+    for _ in range(3 if light else min(5, max(3, args.steps))):
+        one_call()
+        kms.append(h.last_kernel_ms())
+        if int(kms[-1]["launches"]) > 1:
+            subs.append([h.last_kernel_ms_sub(i) for i in range(int(kms[-1]["launches"]))])
+    h.set_profiling(False)
+    # frames of one step that the first tier of the blob extraction handed on, by the capacity they exceeded
+    # (why: 1 bright segments, 2 bands, 3 islands, 4 pixel pool, 5 bitmap pool, 6 blobs kept)
+    overflow = {k: h.get_option("overflow_" + k) for k in ("frames", "general", "why_1", "why_2", "why_3", "why_4",
+                                                           "why_5", "why_6")}
+    schedule = h.get_option("last_schedule") if int(kms[0]["launches"]) > 1 else 0
+    kavg = {k: float(np.mean([m[k] for m in kms])) for k in kms[0]}
+    launches, fpl = int(kms[0]["launches"]), int(kms[0]["frames_per_launch"])
+    kavg["launches"], kavg["frames_per_launch"] = launches, fpl
+    bytes_per_launch = min(fpl, B) * rows * cols  # algorithmic: every pixel read once
+    rider_kib = h.get_option("last_rider_kib")
+    # (more than 5 markers: the voting kernel cannot carry the scan -- its LDS table would not fit -- and every
+    #  sub-batch is scanned by a stand-alone k1a_scan although the schedule is nominally fused: rider bytes 0)
+    fused = schedule in (3, 4, 6) and launches > 1 and rider_kib > 0
+    n_fused = 0
+    vote_scan_ms = vote_profiled_ms = None
+    if fused:
+        # fused schedule: the scan of sub-batch s+1 runs INSIDE the voting kernel of sub-batch s; only the first
+        # sub-batch is scanned by a stand-alone k1a_scan launch.  Average the launches that do the same thing.
+        # (streaming: the last launch carries the scan of the NEXT batch's first sub-batch, like all the others)
+        n_fused = launches if streaming else launches - 1
+        vote_scan_ms = float(np.mean([sub[i]["vote"] for sub in subs for i in range(n_fused)]))
+        kavg["per_sub_batch"] = [{k: round(float(np.mean([sub[i][k] for sub in subs])), 4) for k in ("scan", "blobs", "vote", "tail")}
+                                 for i in range(launches)]
+        vote_profiled_ms = vote_scan_ms
+        if vote_in_region_ms:  # the launches of the timed region itself
+            vote_scan_ms = vote_in_region_ms
+        scan_s = vote_scan_ms * 1e-3
+        bytes_per_launch = rider_kib * 1024  # what ONE fused launch actually scanned (mode 6 gives part of a sub-batch to a side scan)
+    else:
+        scan_s = kavg["scan"] * 1e-3
+    # a pipelined step whose voting kernel does not carry the scan (> 5 markers): the dominant kernel is
+    # k2_vote<plain>, bound by FP64 VALU issue, not k1a_scan.  The same holds for a C2 frame with many distractors.
+    vote_bound = (not fused) and launches > 1
+    achieved = bytes_per_launch / scan_s / 1e9
+    # the same kernels one launch per step and back to back (no sub-batch pipelining): what each kernel
+    # does when it has the chip to itself
+    kiso = None
+    if launches > 1 and not light:
+        h.set_option("pipeline", 1)
+        h.set_profiling(True)
+        kk = []
+        for _ in range(3):
+            h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
+            kk.append(h.last_kernel_ms())
+        h.set_profiling(False)
+        h.set_option("pipeline", args.pipeline)
+        kiso = {k: float(np.mean([m[k] for m in kk])) for k in kk[0]}
+
+    # HBM traffic of the same kernel from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on
+    # gfx950), scaled from bytes per frame to this launch
+    pmc_all, pmc_file, pmc_matches_binary = load_pmc(mpe)
+    traffic = None
+    pmc_key = args.config if args.clutter is None else "%s_%s" % (args.config, args.clutter)
+    if args.back_tol is not None:
+        pmc_key += "_tol%g" % args.back_tol
+    try:
+        pmc = pmc_all["k2_vote_scan" if fused else "k1a_scan"]
+        if fused and args.config in pmc_all.get("by_config", {}):  # counter passes of this resolution's fused launches
+            pmc = pmc_all["by_config"][args.config]["k2_vote_scan"]
+        if pmc.get("rows") == rows and pmc.get("cols") == cols:
+            traffic = pmc["hbm_bytes_per_frame"] * (bytes_per_launch / float(rows * cols))
+    except Exception:
+        pass
+    counters = {"file": ("profiles/" + pmc_file) if pmc_file else None, "from_a_build_of_these_sources": pmc_matches_binary}
+    if fused:
+        # the rocprofv3 average of the same kernel in the same command, from the committed kernel-trace pass that traces
+        # ONLY this kernel (profiles/: `--kernel-include-regex k2_vote<true`); `frac` is the LOWER of the two clocks
+        kv = pmc_all.get("k2_vote_scan", {})
+        rp = kv.get("rocprof_avg_launch_ms") if (args.config == "C2" and args.clutter is None and
+                                                  kv.get("rocprof_bytes_per_launch") == bytes_per_launch) else None
+        frac_events = achieved / 8000.0
+        frac_rocprof = (bytes_per_launch / (rp * 1e-3) / 1e9 / 8000.0) if rp else None
+        roofline = {"kernel": "k2_vote<scan>", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": min(frac_events, frac_rocprof) if frac_rocprof else frac_events,
+                    "frac_hip_events": frac_events, "frac_rocprofv3": frac_rocprof, "rocprofv3_avg_launch_ms": rp,
+                    "traffic": traffic, "bytes_per_launch": bytes_per_launch, "avg_launch_ms": vote_scan_ms,
+                    "launches_per_step": n_fused, "frames_per_launch": fpl,
+                    "avg_launch_ms_source": ("HIP events around all %d launches of the timed region" % vote_in_region_n)
+                                            if vote_in_region_ms else "HIP events in extra steps of the same mode",
+                    "avg_launch_ms_in_separately_profiled_steps": vote_profiled_ms, "counters": counters}
+    elif vote_bound:
+        # FP64 VALU issue: a wave64 FP64 instruction occupies a SIMD for 4 cycles -> 1024 SIMDs x clock / 4 wave-
+        # instructions per second; the instruction count per frame is the committed SQ_INSTS_VALU pass of this kernel
+        # at this marker / detection shape, the clock the one that pass measured, the time is measured here
+        vp_ = pmc_all.get("k2_vote_valu", {}).get(pmc_key)
+        vote_launch_s = kavg["vote"] * 1e-3
+        roofline = {"kernel": "k2_vote<plain>", "bound": "fp64_valu", "unit": "G wave-instructions/s",
+                    "avg_launch_ms": kavg["vote"], "launches_per_step": launches, "frames_per_launch": fpl,
+                    "traffic": None, "counters": counters}
+        if vp_:
+            clk_ = float(vp_.get("effective_clock_GHz") or 2.4)
+            insts = vp_["valu_insts_per_frame"] * min(fpl, B)
+            roofline.update({"achieved": insts / vote_launch_s / 1e9, "peak": 1024 * clk_ / 4.0,
+                             "frac": insts * 4.0 / (1024 * clk_ * 1e9 * vote_launch_s),
+                             "valu_wave_insts_per_launch": insts, "effective_clock_GHz": clk_,
+                             "counters_key": "k2_vote_valu[%s]" % pmc_key})
+        else:
+            roofline.update({"achieved": None, "peak": 1024 * 2.4 / 4.0, "frac": None,
+                             "note": "no SQ_INSTS_VALU pass of %s under profiles/" % pmc_key})
+    else:
+        roofline = {"kernel": "k1a_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": traffic, "bytes_per_launch": bytes_per_launch,
+                    "avg_launch_ms": kavg["scan"], "launches_per_step": launches, "frames_per_launch": fpl,
+                    "counters": counters}
+
+    # ---- PCIe-inclusive leg (SURVEY 8d "report both"): the same frames streamed from PINNED HOST memory through
+    #      mpe_estimate_batch every call (double-buffered chunked ingest: the copy of chunk c + 1 beside the kernels of
+    #      chunk c).  Never reported as `value`.
+    host_leg = None
+    if rank == 0 and world == 1 and not args.no_host_leg and not light:
+        nh = min(B, 8192)
+        pin = mpe.PinnedFrames(nh, rows, cols)
+        pin.array[...] = frames[:nh].cpu().numpy()
+        h.set_stream(0)  # the handle's own stream for this blocking entry point
+        h.estimate_batch(pin.array, markers, K, D, P)
+        reps = 3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            h.estimate_batch(pin.array, markers, K, D, P)
+        dt_h = (time.perf_counter() - t1) / reps
+        if os.environ.get("MPE_BENCH_OWN_STREAM") != "1":
+            h.set_stream(work_stream.cuda_stream)
+        host_leg = {"fps": nh / dt_h, "GBps": nh * rows * cols / dt_h / 1e9, "frames_per_call": nh}
+        pin.close()
+
+    out = None
+    parity_failed = False
+    impossible = False
+    if rank == 0:
+        n_pose = int((timed_rec["status"] == 0).sum())
+        out = {
+            # BASELINE.json's metric string for the configuration it is quoted on (C2); the other legs say what they are
+            "metric": (METRIC if (args.config == "C2" and args.clutter is None) else
+                       "frames/sec at %dx%d, %d LEDs / %d spots%s, brute-force init (not the headline)"
+                       % (cols, rows, len(markers), len(markers) + cfg["n_distractors"],
+                          "" if args.clutter is None else ", " + CLUTTER[args.clutter])),
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": float(np.median(step_ms)),
+            "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %dx%d synthetic frames, %d LEDs, %d distractors%s, brute-force P3P init every "
+                                   "frame, demo.launch parameters%s"
+                                   % (args.config, cols, rows, len(markers), cfg["n_distractors"],
+                                      "" if args.clutter is None else " + " + CLUTTER[args.clutter],
+                                      "" if args.back_tol is None else
+                                      " except back_projection_pixel_tolerance = %g" % args.back_tol),
+                       "frames_per_gpu_per_step": B, "frames_resident_in_hbm": True,
+                       "schedule": schedule, "side_streams_concurrent": h.get_option("streams_concurrent"),
+                       "scan_split_pct": h.get_option("scan_split_pct"), "side_scan_blocks": h.get_option("side_scan_blocks"),
+                       "entry": ("mpe_estimate_batch_device_submit / _collect" if streaming else "mpe_estimate_batch_device"),
+                       "records_to_host": bool(args.records_to_host),
+                       "parallelism": "frames sharded over %d GPU(s), pose records gathered to rank 0" % world},
+            "poses_found_frac": n_pose / B,
+            "blob_tier_overflow": overflow,
+            "vote_arith": {"option": args.vote_arith,
+                           "hypotheses_re_evaluated_strictly_per_step": fix_items / max(1, args.steps + args.warmup),
+                           "suspect_list_full_events": fix_overflow, "frames_voted_again": relost},
+            # every pixel of the batch is read once per step: the whole-step HBM rate against the 8 TB/s spec
+            "step_hbm": {"bytes_per_step": B * rows * cols, "achieved_GBps": world * B * rows * cols / (dt / args.steps) / 1e9,
+                         "frac_of_spec": B * rows * cols / (dt / args.steps) / 1e9 / 8000.0},
+            "kernel_ms": kavg,
+            "roofline": roofline,
+        }
+        if false_hint is not None:
+            out["false_hint_leg"] = false_hint
+        if kiso is not None:
+            out["kernel_ms_isolated"] = kiso
+            out["roofline_isolated"] = {"kernel": "k1a_scan", "bound": "hbm",
+                                        "achieved": B * rows * cols / (kiso["scan"] * 1e-3) / 1e9, "peak": 8000.0,
+                                        "unit": "GB/s", "frac": B * rows * cols / (kiso["scan"] * 1e-3) / 1e9 / 8000.0,
+                                        "bytes_per_launch": B * rows * cols, "avg_launch_ms": kiso["scan"]}
+        # SURVEY 8(d): voting-kernel rates next to fps (P3P solves = detection triples x marker 3-permutations)
+        nd = timed_rec["n_det"].astype(np.int64)
+        nd = np.where(timed_rec["status"] >= 0, nd, 0)
+        nm = len(markers)
+        solves = int((nd * (nd - 1) * (nd - 2) // 6).sum()) * nm * (nm - 1) * (nm - 2)
+        vote_ms = (kiso or kavg)["vote"] * (1 if kiso is not None else launches)
+        out["k2_rates"] = {"p3p_solves_per_step": solves, "p3p_solves_per_s": solves / (vote_ms * 1e-3),
+                           "hypotheses_per_s": 4 * solves / (vote_ms * 1e-3), "vote_ms_per_step": vote_ms,
+                           "timing": "isolated launch" if kiso is not None else "launches inside the pipelined step"}
+        vp = pmc_all.get("k2_vote_valu", {}).get(pmc_key)
+        if vp:
+            clk = float(vp.get("effective_clock_GHz") or 2.4)
+            out["k2_rates"]["valu_util"] = vp["valu_insts_per_frame"] * B * 4.0 / (1024 * clk * 1e9 * vote_ms * 1e-3)
+            out["k2_rates"]["effective_clock_GHz"] = clk
+            out["k2_rates"]["valu_insts_per_p3p_solve"] = vp["valu_insts_per_frame"] * 64.0 * B / max(1, solves)
+        if host_leg is not None:
+            out["host_streamed_fps"] = host_leg["fps"]
+            out["host_streamed"] = host_leg
+        if world > 1:
+            out["ranks_seen"] = ranks_seen
+            out["per_rank_fps"] = per_rank_fps
+        # ---- CPU baseline + parity on a bounded sample (oracle = test infrastructure / checker) ----
+        if not args.no_cpu and args.cpu_sample > 0:
+            import oracle
+            oracle.build()
+            cores = effective_cores()
+            if world == 1:  # CPU baseline: rank 0 at N = 1 only
+                ns = min(args.cpu_sample, B)
+                sample = frames[:ns].cpu().numpy()
+                blk, cpu_fps, parity_failed = parity_block(h, sample, timed_rec[:ns], markers, K, D, P, args.back_tol, cores)
+                blk["records"] = "host_rec of the last timed step (streaming submission %d)" % last_k
+                out["parity"] = blk
+                n1 = min(512, ns) if not light else 0
+                cb = {"value": cpu_fps, "unit": "frames/s", "cores": cores, "kind": "port",
+                      "sample": "%d frames of the same batch, frame-parallel std::thread over %d host cores (oracle = "
+                                "restated reference CPU path, not the upstream OpenCV/Eigen binary)" % (ns, cores)}
+                if n1:
+                    op = oracle.make_params() if args.back_tol is None else oracle.make_params(back_projection_pixel_tolerance=args.back_tol)
+                    t2 = time.perf_counter()
+                    oracle.estimate_batch(sample[:n1], markers, K, D, op, n_threads=1)
+                    cb["single_thread_fps"] = n1 / (time.perf_counter() - t2)
+                out["cpu_baseline"] = cb
+            else:
+                # N > 1: a sample of EVERY rank's shard, as gathered on rank 0, against the oracle — the head of each
+                # rank's batch is re-created here from its seeds.  A SCALE run checks itself.
+                ns = min(SAMPLE_PER_RANK, B)
+                shard = []
+                for r in range(world):
+                    sample = head_of_shard(synth, args.config, args.clutter, ns, dev, r).cpu().numpy()
+                    got = gathered_last[r * B:r * B + ns]
+                    blk, _, bad = parity_block(h, sample, got, markers, K, D, P, args.back_tol, cores, time_it=False)
+                    parity_failed = parity_failed or bad
+                    shard.append({"rank": r, "frames": ns, "checksum": records_checksum(got),
+                                  "status_mismatches": blk["status_mismatches"], "pos_max_m": blk["pos_max_m"],
+                                  "mismatches_unexplained": blk["mismatches_unexplained"]})
+                out["shard_parity"] = shard
+        bad_frac = [k for k in ("roofline", "roofline_isolated") if out.get(k) and (out[k].get("frac") or 0) > 1.0]
+        if out["step_hbm"]["frac_of_spec"] > 1.0:
+            bad_frac.append("step_hbm")
+        if bad_frac:
+            sys.stderr.write("bench.py: %s of %s reports more than its peak — the measurement is broken\n"
+                             % (", ".join(bad_frac), args.config))
+            impossible = True
+    h.close()
+    del frames, pipe, results, host_rec
+    torch.cuda.empty_cache()
+    return out, parity_failed, impossible
+
+
+def compact(out):
+    """A secondary leg in a few fields: rate, roofline of its dominant kernel, parity sample, blob tiers."""
+    r = out["roofline"]
+    c = {"workload": out["config"]["workload"], "frames_per_step": out["config"]["frames_per_gpu_per_step"],
+         "value": round(out["value"], 1), "unit": "frames/s", "ms_per_step": round(out["ms_per_step"], 4),
+         "steps": out["steps"], "poses_found_frac": round(out["poses_found_frac"], 4),
+         "step_hbm_frac_of_spec": round(out["step_hbm"]["frac_of_spec"], 4),
+         "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                            "bytes_per_launch", "avg_launch_ms", "counters_key", "note") if r.get(k) is not None},
+         "kernel_ms": {k: round(out["kernel_ms"][k], 4) for k in ("scan", "blobs", "vote", "tail") if k in out["kernel_ms"]},
+         "blob_tier_overflow": {k: out["blob_tier_overflow"][k] for k in ("frames", "general")},
+         "frames_voted_again": out["vote_arith"]["frames_voted_again"]}
+    if "parity" in out:
+        c["parity"] = {k: out["parity"].get(k) for k in ("frames", "status_mismatches", "poses_compared", "pos_max_m",
+                                                         "rot_max_rad", "mismatches_classified_unstable",
+                                                         "mismatches_unexplained")}
+    if "cpu_baseline" in out:
+        c["cpu_fps"] = round(out["cpu_baseline"]["value"], 1)
+    if "k2_rates" in out and "valu_insts_per_p3p_solve" in out["k2_rates"]:
+        c["valu_insts_per_p3p_solve"] = round(out["k2_rates"]["valu_insts_per_p3p_solve"], 1)
+    return c
+
+
+# ---- the stateful estimator (tracking path; BASELINE configs[4] on one GPU) and the one-frame latency ---------------
+def tracked_legs(local_rank, n_frames=200):
+    """One stream alone (latency per tracked frame), 8 and 64 streams in lock step (one device submission per time
+    step), frames in pageable host memory; the first stream's records against the oracle's tracker, whose
+    single-thread rate is the CPU figure beside the one-stream latency.  -> (dict, parity_failed)"""
+    import torch
+    import rpg_monocular_pose_estimator_amd as mpe
+    from rpg_monocular_pose_estimator_amd import synth
+    import oracle
+    oracle.build()
+    seqs = []
+    order = np.concatenate([np.arange(40), np.arange(38, 0, -1)])
+    idx = np.resize(order, n_frames)
+    for s in range(8):
+        d = synth.make_sequence("C2", 40, seed=900 + s)
+        seqs.append(dict(frames=np.ascontiguousarray(d["frames"][idx]), markers=d["markers"], K=d["K"], D=d["D"]))
+    times = np.arange(n_frames) * 0.02
+    out = {"frames_per_stream": n_frames, "workload": "C2 sequences (constant twist + jitter, 50 Hz), demo.launch parameters, "
+                                                      "frames in pageable host memory"}
+    bad = False
+    # one stream alone
+    h = mpe.Handle(local_rank)
+    t = mpe.Tracker(h, seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], mpe.demo_params())
+    t.run_sequence(seqs[0]["frames"][:8], times[:8])
+    t.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec, info = t.run_sequence(seqs[0]["frames"], times)
+    dt = time.perf_counter() - t0
+    out["one_stream"] = {"latency_ms_per_frame": dt / n_frames * 1e3, "fps": n_frames / dt,
+                         "poses_found_frac": float((rec["status"] == 0).mean()),
+                         "bruteforce_frac": float(info[:, 7].mean())}
+    t.close()
+    h.close()
+    # the oracle's tracker on the same stream: parity per frame + the CPU core's rate
+    ot = oracle.Tracker(seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], oracle.make_params())
+    t0 = time.perf_counter()
+    oref = [ot.estimate(seqs[0]["frames"][k], times[k]) for k in range(n_frames)]
+    cpu_dt = time.perf_counter() - t0
+    ot.close()
+    o_found = np.array([r["updated"] for r in oref])
+    o_T = np.array([np.asarray(r["T"], float).reshape(16) for r in oref])
+    h_found = rec["status"] == 0
+    both = o_found & h_found
+    dpos = np.linalg.norm(o_T[both][:, [3, 7, 11]] - rec["T"][both][:, [3, 7, 11]], axis=1)
+    # the state machine frame by frame: ROI rectangle, it_since_initialized, n_det, n_corr, brute-force flag
+    o_info = np.array([list(r["roi"]) + [r["it_since_initialized"], r["n_det"], r["n_corr"], int(r["used_bruteforce"])]
+                       for r in oref])
+    n_state = int((o_info != info[:, :8]).any(axis=1).sum())
+    n_mis = int((o_found != h_found).sum()) + int((dpos > 1e-4).sum()) + n_state
+    out["one_stream"]["cpu_one_core_fps"] = n_frames / cpu_dt
+    out["one_stream"]["parity"] = {"frames": n_frames, "found_mismatches": int((o_found != h_found).sum()),
+                                   "state_mismatches": n_state, "poses_compared": int(both.sum()),
+                                   "pos_max_m": float(dpos.max()) if len(dpos) else None}
+    bad = bad or n_mis > 0
+    # N streams in lock step on one handle
+    for n in (8, 64):
+        h = mpe.Handle(local_rank)
+        tr = [mpe.Tracker(h, seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], mpe.demo_params()) for _ in range(n)]
+        fr = [seqs[i % 8]["frames"] for i in range(n)]
+        mpe.tracker_run_sequences_batch(tr, [f[:8] for f in fr], times[:8], 1)
+        for x in tr:
+            x.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rec_n, _ = mpe.tracker_run_sequences_batch(tr, fr, times, 1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        same = bool(np.array_equal(np.asarray(rec_n["status"]).reshape(n, -1)[0], rec["status"]))
+        out["lockstep_%d" % n] = {"fps": n * n_frames / dt, "ms_per_time_step": dt / n_frames * 1e3,
+                                  "poses_found_frac": float((rec_n["status"] == 0).mean()),
+                                  "stream0_statuses_equal_the_solo_run": same}
+        bad = bad or not same
+        for x in tr:
+            x.close()
+        h.close()
+    return out, bad
+
+
+def one_frame_latency(local_rank, reps=200):
+    """One brute-force frame (C2) through the blocking entry points: pageable / pinned host memory in, record out."""
+    import rpg_monocular_pose_estimator_amd as mpe
+    from rpg_monocular_pose_estimator_amd import synth
+    d = synth.make_frames("C2", 4, seed=31)
+    h = mpe.Handle(local_rank)
+    P = mpe.demo_params()
+    pin = mpe.PinnedFrames(1, d["rows"], d["cols"])
+    res = {}
+    for name, src in (("pageable", d["frames"][:1].copy()), ("pinned", pin.array)):
+        if name == "pinned":
+            pin.array[...] = d["frames"][:1]
+        for _ in range(10):
+            r = h.estimate_batch(src, d["markers"], d["K"], d["D"], P)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = h.estimate_batch(src, d["markers"], d["K"], d["D"], P)
+            ts.append(time.perf_counter() - t0)
+        res[name] = {"median_ms": float(np.median(ts)) * 1e3, "p90_ms": float(np.percentile(ts, 90)) * 1e3,
+                     "pose_found": bool(r["status"][0] == 0)}
+    pin.close()
+    h.close()
+    return res
 
 
 def main():
@@ -109,8 +801,12 @@ def main():
                     help="frames per GPU per step (device-resident batch); default: 262 144 (95 GB) at C2, 65 536 at C1 / "
                          "C3, 16 384 at C4 (38 GB of 1920x1200 frames)")
     ap.add_argument("--config", default="C2")
-    ap.add_argument("--cpu-sample", type=int, default=8192, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--clutter", default=None, choices=sorted(CLUTTER), help="C2 + clutter: " + ", ".join(
+        "%s = %s" % kv for kv in sorted(CLUTTER.items())))
+    ap.add_argument("--cpu-sample", type=int, default=16384, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the other configs, the clutter legs, the tracked streams and the one-frame latency")
     ap.add_argument("--host-frames", action="store_true", help="(kept for compatibility: the host-streamed leg always runs at N = 1)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive host-streamed leg")
     ap.add_argument("--k1a-lds", type=int, default=-1, help="tuning: dummy LDS per scan block (-1 = automatic)")
@@ -120,6 +816,7 @@ def main():
                     help="mode 6: resident blocks per CU of the side scan (-1 = the library's default)")
     ap.add_argument("--scan-split-pct", type=int, default=-1,
                     help="mode 6: share of a sub-batch scanned on the side stream (-1 = the library's default)")
+    ap.add_argument("--opt", action="append", help="name=value: any other mpe_set_option knob (experiments)")
     ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
     ap.add_argument("--vote-arith", type=int, default=1,
                     help="1 fast voting arithmetic with its suspects re-evaluated by the strict functions (default), "
@@ -146,8 +843,11 @@ def main():
                     help="no GPU work: the launch / shard / pose-gather / timing plumbing of the N-rank bench on CPU "
                          "(gloo), with synthetic records instead of kernels; used by the CPU test-suite")
     args = ap.parse_args()
+    headline = args.config == "C2" and args.clutter is None and args.frames <= 0
     if args.frames <= 0:
         args.frames = {"C2": 262144, "C1": 65536, "C3": 65536, "C4": 16384}.get(args.config, 16384)
+        if args.clutter in ("d4", "d16"):
+            args.frames = 32768
 
     import torch
 
@@ -176,9 +876,7 @@ def main():
     if torch.cuda.device_count() < max(1, min(world, local_rank + 1)):
         sys.exit("bench.py: rank %d needs GPU %d, but only %d GPU(s) are visible" % (rank, local_rank, torch.cuda.device_count()))
 
-    import rpg_monocular_pose_estimator_amd as mpe
-    from rpg_monocular_pose_estimator_amd import synth, parallel
-
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -186,508 +884,87 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ctx = {"rank": rank, "local_rank": local_rank, "world": world, "dev": torch.device("cuda", local_rank), "dist": dist}
 
-    cfg = synth.CONFIGS[args.config]
-    rows, cols = cfg["rows"], cfg["cols"]
-    K, D = synth.camera_for(rows, cols)
-    markers = np.asarray(cfg["markers"])
-    B = args.frames
+    t_start = time.perf_counter()
+    out, parity_failed, impossible = run_config(args, ctx)
+    legs_failed = []
+    if rank == 0 and world == 1 and headline and not args.headline_only:
+        # ---- every other BASELINE config, the clutter curve, the tracked streams, one frame: after the headline leg,
+        #      outside its timed region, each with its own roofline and parity sample against the oracle
+        out["headline_leg_s"] = round(time.perf_counter() - t_start, 1)
 
-    # ---- synthetic batch, resident in HBM before the timed region (data: synthetic) ----------
-    _, spots = synth.make_scenes_batch(cfg, B, seed=1000 + rank)
-    frames = synth.render_frames_torch(spots, rows, cols, cfg["spot_sigma"], dev, seed=77 + rank)
-    # two result buffers: while the records of step k travel to rank 0, step k+1 already writes the other one
-    pipe = parallel.RootGatherPipeline(rank, world, B * mpe.RESULT_DTYPE.itemsize, dev)
-    results = pipe.local(0)
-    torch.cuda.synchronize()
-
-    h = mpe.Handle(local_rank)
-    # one explicit (non-default) stream carries the library's kernels AND the pose gather: the collective is then
-    # ordered after the tail kernel by the stream itself (torch's legacy default stream is 0, which the library
-    # reads as "use the handle's own stream" and which would not be ordered with it)
-    work_stream = torch.cuda.Stream(device=dev)
-    if os.environ.get("MPE_BENCH_OWN_STREAM") != "1":
-        h.set_stream(work_stream.cuda_stream)
-    P = mpe.demo_params() if args.back_tol is None else mpe.demo_params(back_projection_pixel_tolerance=args.back_tol)
-    h.set_option("pipeline", args.pipeline)
-    h.set_option("pipeline_mode", args.pipeline_mode)
-    h.set_option("vote_arith", args.vote_arith)
-    h.set_option("vote_splits", args.vote_splits)
-    if args.scan_split_pct >= 0:
-        h.set_option("scan_split_pct", args.scan_split_pct)
-    if args.side_scan_blocks >= 0:
-        h.set_option("side_scan_blocks", args.side_scan_blocks)
-    if args.assume_side_streams:
-        h.set_option("assume_side_streams", 1)
-    if args.k1a_lds >= 0:
-        h.set_option("k1a_dummy_lds", args.k1a_lds)
-
-    step_no = [0]
-    # The steps form a STREAM of batches (mpe_estimate_batch_device_submit / _collect): a submission does not join the
-    # library's side streams back, its completion is an event that the CONSUMER stream waits for — here the stream
-    # that delivers the pose records: an asynchronous, double-buffered D2H copy of the 432-byte records into pinned
-    # host memory on every rank (what a caller of estimateBodyPose ends up holding), and for N > 1 the RCCL gather of
-    # the records to rank 0.  Every submission announces the next one's frames, so its last voting launch carries the
-    # image scan of the next batch's first sub-batch.
-    out_stream = torch.cuda.Stream(device=dev)
-    rec_bytes = B * mpe.RESULT_DTYPE.itemsize
-    host_rec = [torch.empty(rec_bytes, dtype=torch.uint8).pin_memory() for _ in range(2)] if args.records_to_host else None
-    out_done = [None, None]
-    streaming = not args.no_streaming
-
-    def step():
-        k = step_no[0]
-        step_no[0] += 1
-        with torch.cuda.stream(work_stream):
-            buf = pipe.local(k)             # (waits until this buffer's previous transfer has left)
-            if out_done[k & 1] is not None:
-                work_stream.wait_event(out_done[k & 1])   # ... and until its previous D2H copy has read it
-            if streaming:
-                h.estimate_batch_device_submit(frames.data_ptr(), B, rows, cols, markers, K, D, P, buf.data_ptr(),
-                                               frames.data_ptr(), B)
-                h.estimate_batch_device_collect(out_stream.cuda_stream)
-            else:
-                h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, buf.data_ptr())
-                out_stream.wait_stream(work_stream)
-        with torch.cuda.stream(out_stream):
-            if host_rec is not None:
-                host_rec[k & 1].copy_(buf, non_blocking=True)
-            pipe.submit(k)                  # the only collective: pose records -> rank 0, asynchronous
-            ev = torch.cuda.Event()
-            ev.record(out_stream)
-            out_done[k & 1] = ev
-
-    def barrier():
-        with torch.cuda.stream(out_stream):
-            pipe.finish()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # the K timed steps, bracketed by barrier + synchronize; an event between steps on the work stream gives the
-    # per-step durations as well (median reported next to the mean the bracket yields)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    # the dominant kernel is timed INSIDE the timed region: a pair of HIP events around every voting launch that
-    # carries a scan, on the stream it is launched on, nothing else recorded (option "vote_events")
-    if args.vote_events and not args.plumbing_only:
-        h.set_option("vote_events", args.steps)
-    t0 = time.perf_counter()
-    marks[0].record(work_stream)
-    for i in range(args.steps):
-        step()
-        marks[i + 1].record(work_stream)
-    barrier()
-    dt = time.perf_counter() - t0
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
-    vote_in_region_ms, vote_in_region_n = None, 0
-    if args.vote_events and not args.plumbing_only:
-        vote_in_region_n = h.get_option("vote_launches")
-        if vote_in_region_n > 0:
-            vote_in_region_ms = h.get_option("vote_launch_ns_mean") * 1e-6
-        h.set_option("vote_events", 0)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    fps = world * B * args.steps / dt
-    fix_items = h.get_option("vote_fixup_items")
-    fix_overflow = h.get_option("vote_fixup_overflow")
-
-    # ---- the same steps with a next-batch announcement that does NOT come true (the timed region above is the best
-    #      case: every hint is right).  The announced pointer is another view of the same frames, so the submission
-    #      that follows finds no scan of its own first sub-batch and runs it stand-alone: what a wrong hint costs.
-    false_hint = None
-    if streaming and args.false_hint_leg and B >= 2 * 32768 and len(markers) <= 5:
-        shift = 32768
-        wrong = frames[shift:]
-
-        def step_wrong():
-            k = step_no[0]
-            step_no[0] += 1
-            with torch.cuda.stream(work_stream):
-                buf = pipe.local(k)
-                if out_done[k & 1] is not None:
-                    work_stream.wait_event(out_done[k & 1])
-                h.estimate_batch_device_submit(frames.data_ptr(), B, rows, cols, markers, K, D, P, buf.data_ptr(),
-                                               wrong.data_ptr(), B - shift)
-                h.estimate_batch_device_collect(out_stream.cuda_stream)
-            with torch.cuda.stream(out_stream):
-                if host_rec is not None:
-                    host_rec[k & 1].copy_(buf, non_blocking=True)
-                pipe.submit(k)
-                ev = torch.cuda.Event()
-                ev.record(out_stream)
-                out_done[k & 1] = ev
-
-        nfh = max(3, min(10, args.steps))
-        step_wrong()
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(nfh):
-            step_wrong()
-        barrier()
-        dt_fh = time.perf_counter() - t1
-        if world > 1:
-            tmax = torch.tensor([dt_fh], dtype=torch.float64, device=dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt_fh = float(tmax.item())
-        false_hint = {"ms_per_step": dt_fh / nfh * 1e3, "steps": nfh, "value": world * B * nfh / dt_fh,
-                      "note": "every submission announces a batch that does not come: one sub-batch scanned for nothing "
-                              "inside its last voting launch, and the next submission scans its first sub-batch itself"}
-
-    # ---- per-kernel time with HIP events on the launch streams: extra steps in exactly the same mode
-    #      and launch shape as the timed region (a big batch runs as sub-batches, every kernel is launched
-    #      once per sub-batch; the numbers are AVERAGES PER LAUNCH, like rocprofv3 --stats reports them)
-    h.set_profiling(True)
-    kms, subs = [], []
-
-    def one_call():
-        if streaming:  # the same entry, hint included, as the timed region
-            h.estimate_batch_device_submit(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr(),
-                                           frames.data_ptr(), B)
-            h.estimate_batch_device_collect(0)
-        else:
-            h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
-
-    for _ in range(min(5, max(3, args.steps))):
-        one_call()
-        kms.append(h.last_kernel_ms())
-        if int(kms[-1]["launches"]) > 1:
-            subs.append([h.last_kernel_ms_sub(i) for i in range(int(kms[-1]["launches"]))])
-    h.set_profiling(False)
-    # frames of one step that the first tier of the blob extraction handed on, by the capacity they exceeded
-    overflow = None
-    if int(kms[0]["launches"]) > 1:
-        overflow = {k: h.get_option("overflow_" + k) for k in ("frames", "general", "why_1", "why_2", "why_3", "why_4",
-                                                               "why_5", "why_6")}
-        overflow["why"] = "1 bright segments, 2 bands, 3 islands, 4 pixel pool, 5 bitmap pool, 6 blobs kept"
-    schedule = h.get_option("last_schedule") if int(kms[0]["launches"]) > 1 else 0
-    kavg = {k: float(np.mean([m[k] for m in kms])) for k in kms[0]}
-    launches, fpl = int(kms[0]["launches"]), int(kms[0]["frames_per_launch"])
-    kavg["launches"], kavg["frames_per_launch"] = launches, fpl
-    bytes_per_launch = min(fpl, B) * rows * cols  # algorithmic: every pixel read once
-    rider_kib = h.get_option("last_rider_kib")
-    # (more than 5 markers: the voting kernel cannot carry the scan -- its LDS table would not fit -- and every
-    #  sub-batch is scanned by a stand-alone k1a_scan although the schedule is nominally fused: rider bytes 0)
-    fused = schedule in (3, 4, 6) and launches > 1 and rider_kib > 0
-    if fused:
-        # fused schedule: the scan of sub-batch s+1 runs INSIDE the voting kernel of sub-batch s; only the first
-        # sub-batch is scanned by a stand-alone k1a_scan launch.  Average the launches that do the same thing.
-        # (streaming: the last launch carries the scan of the NEXT batch's first sub-batch, like all the others)
-        n_fused = launches if streaming else launches - 1
-        vote_scan_ms = float(np.mean([sub[i]["vote"] for sub in subs for i in range(n_fused)]))
-        scan_alone_ms = float(np.mean([sub[0]["scan"] for sub in subs]))
-        kavg.update({"scan_standalone_first_sub_batch": scan_alone_ms, "vote_with_scan": vote_scan_ms})
-        if not streaming:
-            kavg["vote_last_sub_batch_without_scan"] = float(np.mean([sub[launches - 1]["vote"] for sub in subs]))
-        kavg["per_sub_batch"] = [{k: round(float(np.mean([sub[i][k] for sub in subs])), 4) for k in ("scan", "blobs", "vote", "tail")}
-                                 for i in range(launches)]
-        vote_profiled_ms = vote_scan_ms
-        if vote_in_region_ms:  # the launches of the timed region itself
-            vote_scan_ms = vote_in_region_ms
-        scan_s = vote_scan_ms * 1e-3
-        bytes_per_launch = rider_kib * 1024  # what ONE fused launch actually scanned (mode 6 gives part of a sub-batch to a side scan)
-    else:
-        scan_s = kavg["scan"] * 1e-3
-    # a pipelined step whose voting kernel does not carry the scan (> 5 markers): the per-sub-batch scan events bracket
-    # only the part of a sub-batch the side scan left over, and the step is the FP64 voting anyway — the dominant
-    # kernel is k2_vote<plain>, bound by FP64 VALU issue (roofline below), not k1a_scan
-    vote_bound = (not fused) and launches > 1
-    achieved = bytes_per_launch / scan_s / 1e9
-    # the same kernels one launch per step and back to back (no sub-batch pipelining): what each kernel
-    # does when it has the chip to itself
-    kiso = None
-    if launches > 1:
-        h.set_option("pipeline", 1)
-        h.set_profiling(True)
-        kk = []
-        for _ in range(3):
-            h.estimate_batch_device(frames.data_ptr(), B, rows, cols, markers, K, D, P, results.data_ptr())
-            kk.append(h.last_kernel_ms())
-        h.set_profiling(False)
-        h.set_option("pipeline", args.pipeline)
-        kiso = {k: float(np.mean([m[k] for m in kk])) for k in kk[0]}
-
-    # HBM traffic of the same kernel from the PMC pass committed under profiles/ (rocprofv3 --pmc
-    # FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
-    # coalesced reads on gfx950), scaled from bytes per frame to this launch
-    traffic = None
-    traffic_source = None
-    pmc_all = {}
-    pmc_matches_binary = None
-    pmc_file = "round4_pmc.json"
-    try:
-        pmc_file = "round4_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "round4_pmc.json")) else "round3_pmc.json"
-        with open(os.path.join(ROOT, "profiles", pmc_file)) as fh:
-            pmc_all = json.load(fh)
-        # the counter passes were taken from a build of THESE kernel sources? (fingerprint of csrc/*.hip, *.h)
-        pmc_matches_binary = pmc_all.get("source_fingerprint") == mpe.source_fingerprint()
-        pmc = pmc_all["k2_vote_scan" if fused else "k1a_scan"]
-        if fused and args.config in pmc_all.get("by_config", {}):  # counter passes of this resolution's fused launches
-            pmc = pmc_all["by_config"][args.config]["k2_vote_scan"]
-        if pmc.get("rows") == rows and pmc.get("cols") == cols:
-            # (scaled to the frames' worth of pixels this launch scans: bytes_per_launch / (rows * cols))
-            traffic = pmc["hbm_bytes_per_frame"] * (bytes_per_launch / float(rows * cols))
-            traffic_source = "profiles/" + pmc_file + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel, " \
-                             "FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes; %s; taken from a build of the kernel " \
-                             "sources timed here: %s)" % (pmc.get("from", ""), pmc_matches_binary)
-    except Exception:
-        pass
-    if fused:
-        # the rocprofv3 average of the same kernel in the same command, from the committed kernel-trace pass that traces
-        # ONLY this kernel (profiles/: `--kernel-include-regex k2_vote<true`); `frac` is the LOWER of the two clocks
-        rp = pmc_all.get("k2_vote_scan", {}).get("rocprof_avg_launch_ms") if (args.config == "C2" and pmc_all.get(
-            "k2_vote_scan", {}).get("rocprof_bytes_per_launch") == bytes_per_launch) else None
-        frac_events = achieved / 8000.0
-        frac_rocprof = (bytes_per_launch / (rp * 1e-3) / 1e9 / 8000.0) if rp else None
-        roofline = {"kernel": "k2_vote<scan>", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": min(frac_events, frac_rocprof) if frac_rocprof else frac_events,
-                    "frac_hip_events": frac_events, "frac_rocprofv3": frac_rocprof,
-                    "rocprofv3_avg_launch_ms": rp,
-                    "rocprofv3_source": ("profiles/" + pmc_file + " k2_vote_scan.rocprof_avg_launch_ms: rocprofv3 "
-                                         "--kernel-trace --stats of this command with only this kernel traced") if rp else None,
-                    "traffic": traffic, "traffic_source": traffic_source,
-                    "bytes_per_launch": bytes_per_launch, "avg_launch_ms": vote_scan_ms, "launches_per_step": n_fused, "frames_per_launch": fpl,
-                    "avg_launch_ms_source": ("HIP events around all %d k2_vote<scan> launches of the timed region, on the "
-                                             "stream they are launched on (the only events recorded in that region)"
-                                             % vote_in_region_n) if vote_in_region_ms else
-                                            "HIP events in extra steps of the same mode (--no-vote-events)",
-                    "avg_launch_ms_in_separately_profiled_steps": vote_profiled_ms,
-                    "measured": "HIP events around every k2_vote<scan> launch on its stream.  In the timed region two "
-                                "submissions are in flight (the next batch's blob extraction, the previous one's "
-                                "validate / refine kernels and the D2H copy of its records run beside a launch); in the "
-                                "separately profiled steps — every kernel bracketed, one submission at a time — the "
-                                "same launch is shorter.  This kernel is the image pass AND the FP64 voting: each "
-                                "voting wave streams its share of the next sub-batch's pixels through LDS DMA "
-                                "(global_load_lds) between pieces of P3P arithmetic; bytes = the pixels it scans, "
-                                "time = the whole fused launch (the voting alone: kernel_ms_isolated.vote / "
-                                "launches).  roofline_isolated = the stand-alone scan kernel.  Default schedule "
-                                "since round 4: a one-block-per-CU k1a_scan on a side stream streams config.scan_split_pct "
-                                "% of the next-but-one sub-batch BESIDE this launch for its whole length — the HBM "
-                                "stream is shared on purpose (three blocks per CU finished earlier, crowded the blob "
-                                "kernel and cost 10 % of the step), so this kernel's own fraction is lower than "
-                                "round 3's while step_hbm, the whole step's rate, is higher."}
-    elif vote_bound:
-        # FP64 VALU issue: a wave64 FP64 instruction occupies a SIMD for 4 cycles -> 1024 SIMDs x clock / 4 wave-
-        # instructions per second; the instruction count per frame is the committed SQ_INSTS_VALU pass of this kernel
-        # at this marker / detection shape, the clock the one that pass measured, the time is measured here
-        vp_ = pmc_all.get("k2_vote_valu", {}).get(args.config)
-        vote_launch_s = kavg["vote"] * 1e-3
-        roofline = {"kernel": "k2_vote<plain>", "bound": "fp64_valu", "unit": "G wave-instructions/s",
-                    "avg_launch_ms": kavg["vote"], "launches_per_step": launches, "frames_per_launch": fpl,
-                    "traffic": None,
-                    "measured": "HIP events around every voting launch on its stream, steps in the same mode as the timed "
-                                "region.  With more than 5 markers the voting kernel cannot carry the image scan (its "
-                                "LDS table would not fit) and takes > 95 % of a sub-batch; its bound is FP64 VALU issue "
-                                "(no MFMA: there is no dense contraction), so the figure is wave-instructions issued / "
-                                "what 1024 SIMDs can issue at the measured clock.  The image pass: roofline_isolated."}
-        if vp_:
-            clk_ = float(vp_.get("effective_clock_GHz") or 2.4)
-            insts = vp_["valu_insts_per_frame"] * min(fpl, B)
-            roofline.update({"achieved": insts / vote_launch_s / 1e9, "peak": 1024 * clk_ / 4.0,
-                             "frac": insts * 4.0 / (1024 * clk_ * 1e9 * vote_launch_s),
-                             "valu_wave_insts_per_launch": insts, "effective_clock_GHz": clk_,
-                             "counters": "profiles/%s k2_vote_valu[%s] (%s); from a build of the sources timed here: %s"
-                                         % (pmc_file, args.config, vp_.get("from", ""), pmc_matches_binary)})
-        else:
-            roofline.update({"achieved": None, "peak": 1024 * 2.4 / 4.0, "frac": None,
-                             "note": "no SQ_INSTS_VALU pass of this config under profiles/"})
-    else:
-        roofline = {"kernel": "k1a_scan", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
-                    "bytes_per_launch": bytes_per_launch, "avg_launch_ms": kavg["scan"],
-                    "launches_per_step": launches, "frames_per_launch": fpl,
-                    "measured": "HIP events around every k1a_scan launch on its stream, steps in the same mode as "
-                                "the timed region (with >1 launches per step the scan of sub-batch i+1 runs beside "
-                                "the FP64 voting of sub-batch i and shares the chip with it)"}
-        if kavg.get("vote", 0.0) > 5.0 * kavg["scan"]:
-            roofline["note"] = ("this is the kernel that moves the bytes; the step itself is dominated by k2_vote "
-                                "(FP64 VALU bound, no HBM traffic to speak of): see k2_rates.valu_util")
-
-    # ---- PCIe-inclusive leg (SURVEY 8d "report both"): the same frames streamed from PINNED HOST memory through
-    #      mpe_estimate_batch every call (double-buffered chunked ingest: the copy of chunk c + 1 beside the kernels of
-    #      chunk c).  Never reported as `value`.
-    host_leg = None
-    if rank == 0 and world == 1 and not args.no_host_leg:
-        nh = min(B, 8192)
-        pin = mpe.PinnedFrames(nh, rows, cols)
-        pin.array[...] = frames[:nh].cpu().numpy()
-        h.set_stream(0)  # the handle's own stream for this blocking entry point
-        h.estimate_batch(pin.array, markers, K, D, P)
-        reps = 3
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            h.estimate_batch(pin.array, markers, K, D, P)
-        dt_h = (time.perf_counter() - t1) / reps
-        h.set_option("ingest_chunk", 0)
-        h.estimate_batch(pin.array, markers, K, D, P)
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            h.estimate_batch(pin.array, markers, K, D, P)
-        dt_h0 = (time.perf_counter() - t1) / reps
-        h.set_option("ingest_chunk", 2048)
-        if os.environ.get("MPE_BENCH_OWN_STREAM") != "1":
-            h.set_stream(work_stream.cuda_stream)
-        host_leg = {"fps": nh / dt_h, "GBps": nh * rows * cols / dt_h / 1e9, "frames_per_call": nh,
-                    "fps_single_blocking_copy": nh / dt_h0,
-                    "note": "frames in pinned host memory, H2D copy + all kernels + D2H of the records per call; "
-                            "PCIe Gen5 x16 bound (the kernels take < 2 % of the copy time)"}
-        pin.close()
-
-    out = None
-    parity_failed = False
-    impossible = False
-    if rank == 0:
-        res_host = parallel.records_from_bytes(results)
-        n_pose = int((res_host["status"] == 0).sum())
-        out = {
-            # BASELINE.json's metric string for the configuration it is quoted on (C2); the other configs say what they are
-            "metric": ("frames/sec at 752x480, 5 LEDs, brute-force init; pose RMSE vs CPU ref" if args.config == "C2" else
-                       "frames/sec at %dx%d, %d LEDs / %d detections, brute-force init (BASELINE config %s, not the headline)"
-                       % (cols, rows, len(markers), len(markers) + cfg["n_distractors"], args.config)),
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": float(np.median(step_ms)),
-            "value_at_median_step": world * B / (float(np.median(step_ms)) * 1e-3),
-            "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d synthetic frames, %d LEDs, %d distractors, brute-force P3P init every "
-                                   "frame, demo.launch parameters%s" % (args.config, cols, rows, len(markers),
-                                                                        cfg["n_distractors"],
-                                                                        "" if args.back_tol is None else
-                                                                        " except back_projection_pixel_tolerance = %g" % args.back_tol),
-                       "frames_per_gpu_per_step": B, "frames_resident_in_hbm": True,
-                       "streams_per_gpu": args.pipeline,
-                       "schedule": {0: "two-stream pipeline", 3: "fused: scan rides in the voting kernel", 4: "fused + validate/refine on a side stream",
-                                    6: "fused + side-stream tail + scan split between a side k1a_scan and the rider"}.get(schedule, schedule),
-                       "side_streams_concurrent": h.get_option("streams_concurrent"),
-                       "scan_split_pct": h.get_option("scan_split_pct"), "side_scan_blocks": h.get_option("side_scan_blocks"),
-                       "entry": ("mpe_estimate_batch_device_submit / _collect: a stream of batches, each announcing the "
-                                 "next one's frames" if streaming else "mpe_estimate_batch_device, one joined call per step"),
-                       "records_to_host": bool(args.records_to_host),
-                       "blob_tier_overflow": overflow,
-                       "parallelism": "frames sharded over %d GPU(s), pose records gathered to rank 0 (async, double-buffered)" % world},
-            "poses_found_frac": n_pose / B,
-            "vote_arith": {"option": args.vote_arith,
-                           "meaning": {0: "strict kernel", 1: "fast kernel + strict re-evaluation of its suspects (k2_vote_fixup)",
-                                       2: "fast kernel alone"}.get(args.vote_arith),
-                           "hypotheses_re_evaluated_strictly_per_step": fix_items / max(1, args.steps + args.warmup),
-                           "suspect_list_full_events": fix_overflow},
-            "false_hint_leg": false_hint,
-            # every pixel of the batch is read once per step: the whole-step HBM rate against the 8 TB/s spec
-            "step_hbm": {"bytes_per_step": B * rows * cols, "achieved_GBps": world * B * rows * cols / (dt / args.steps) / 1e9,
-                         "frac_of_spec": B * rows * cols / (dt / args.steps) / 1e9 / 8000.0},
-            "kernel_ms": kavg,
-            "roofline": roofline,
-        }
-        if kiso is not None:
-            out["kernel_ms_isolated"] = kiso
-            out["roofline_isolated"] = {"kernel": "k1a_scan", "bound": "hbm",
-                                        "achieved": B * rows * cols / (kiso["scan"] * 1e-3) / 1e9, "peak": 8000.0,
-                                        "unit": "GB/s", "frac": B * rows * cols / (kiso["scan"] * 1e-3) / 1e9 / 8000.0,
-                                        "bytes_per_launch": B * rows * cols, "avg_launch_ms": kiso["scan"],
-                                        "measured": "one launch per kernel per step, kernels back to back "
-                                                    "(--pipeline 1), HIP events on the launch stream"}
-        # voting-kernel rates next to fps (P3P solves = detection triples x marker 3-permutations)
-        nd = res_host["n_det"].astype(np.int64)
-        nd = np.where(res_host["status"] >= 0, nd, 0)
-        nm = len(markers)
-        solves = int((nd * (nd - 1) * (nd - 2) // 6).sum()) * nm * (nm - 1) * (nm - 2)
-        vote_ms = (kiso or kavg)["vote"] * (1 if kiso is not None else launches)
-        out["k2_rates"] = {"p3p_solves_per_step": solves, "p3p_solves_per_s": solves / (vote_ms * 1e-3),
-                           "hypotheses_per_s": 4 * solves / (vote_ms * 1e-3),
-                           "vote_ms_per_step": vote_ms,
-                           "timing": "isolated launch" if kiso is not None else "launches inside the pipelined step"}
-        # VALU utilisation of the voting kernel = wave-instructions x 4 clk / (1024 SIMDs x 2.4 GHz x time): the
-        # instruction count per frame comes from the committed SQ_INSTS_VALU pass of the same kernel and marker /
-        # detection shape (profiles/round2_pmc.json), the time is the one measured in this run
-        vp = pmc_all.get("k2_vote_valu", {}).get(args.config)
-        if vp:
-            t_s = vote_ms * 1e-3
-            n_fr = B
-            # against the clock the kernel actually ran at (GRBM_GUI_ACTIVE / duration of the same counter pass; dense
-            # FP64 bodies clock below the 2.4 GHz maximum), and against the nominal maximum for comparison
-            clk = float(vp.get("effective_clock_GHz") or 2.4)
-            out["k2_rates"]["valu_util"] = vp["valu_insts_per_frame"] * n_fr * 4.0 / (1024 * clk * 1e9 * t_s)
-            out["k2_rates"]["valu_util_at_nominal_2.4GHz"] = vp["valu_insts_per_frame"] * n_fr * 4.0 / (1024 * 2.4e9 * t_s)
-            out["k2_rates"]["effective_clock_GHz"] = clk
-            out["k2_rates"]["valu_insts_per_p3p_solve"] = vp["valu_insts_per_frame"] * 64.0 * n_fr / max(1, solves)
-            out["k2_rates"]["valu_source"] = "profiles/" + pmc_file + " k2_vote_valu[%s] (%s), kernel %s; counters from a " \
-                                             "build of the sources timed here: %s" % (
-                args.config, vp.get("from", ""), vp.get("kernel", ""), pmc_matches_binary)
-        if host_leg is not None:
-            out["host_streamed_fps"] = host_leg["fps"]
-            out["host_streamed"] = host_leg
-        # ---- CPU baseline + parity on a bounded sample (oracle = test infrastructure / checker) ----
-        if not args.no_cpu and args.cpu_sample > 0 and world == 1:  # CPU baseline: rank 0 at N = 1 only
-            import oracle
-            oracle.build()
-            ns = min(args.cpu_sample, B)
-            sample = frames[:ns].cpu().numpy()
-            cores = effective_cores()
+        def leg(name, **kw):
+            a = copy.copy(args)
+            a.steps, a.warmup, a.cpu_sample, a.back_tol, a.clutter = 5, 2, 512, None, None
+            a.false_hint_leg, a.no_host_leg = False, True
+            for k, v in kw.items():
+                setattr(a, k, v)
             t1 = time.perf_counter()
-            op = oracle.make_params() if args.back_tol is None else oracle.make_params(back_projection_pixel_tolerance=args.back_tol)
-            ref = oracle.estimate_batch(sample, markers, K, D, op, n_threads=cores)
-            cpu_dt = time.perf_counter() - t1
-            n1 = min(512, ns)
-            t2 = time.perf_counter()
-            oracle.estimate_batch(sample[:n1], markers, K, D, op, n_threads=1)
-            cpu1_dt = time.perf_counter() - t2
-            out["cpu_baseline"] = {"value": ns / cpu_dt, "unit": "frames/s", "cores": cores, "kind": "port",
-                                   "sample": "%d frames of the same batch, frame-parallel std::thread over %d host "
-                                             "cores (oracle = restated reference CPU path, not the upstream "
-                                             "OpenCV/Eigen binary)" % (ns, cores),
-                                   "single_thread_fps": n1 / cpu1_dt}
-            got = res_host[:ns]
-            n_status = int((ref["status"] != got["status"]).sum())
-            ok = (ref["status"] == 0) & (got["status"] == 0)
-            dpos = np.linalg.norm(ref["T"][ok][:, [3, 7, 11]] - got["T"][ok][:, [3, 7, 11]], axis=1)
-            # every frame on which the two paths disagree is traced to the hypotheses / validation solves that differ
-            # (tests/forensics.py) and must be a witnessed instability of the reference algorithm itself: an
-            # unexplained one makes this run FAIL (exit code 3) — it is never just counted
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import forensics
-            dall = np.zeros(ns)
-            dall[ok] = dpos
-            verdicts = []
-            for i in np.nonzero((ref["status"] != got["status"]) | (dall > 1e-4))[0]:
-                und, _ = oracle.find_leds(sample[i], op, K, D)
-                v = forensics.classify_end_to_end(h, oracle, und, markers, K, P, op)
-                verdicts.append({"frame": int(i), "hip_status": int(got["status"][i]), "oracle_status": int(ref["status"][i]),
-                                 "dpos_m": float(dall[i]), "stage": v.get("stage"), "unstable": bool(v["unstable"]),
-                                 "min_cancellation": v.get("min_w"), "oracle_flips_under_1ulp": v.get("oracle_flips_under_1ulp")})
-            n_unexplained = sum(1 for v in verdicts if not v["unstable"])
-            out["parity"] = {"frames": ns, "status_equal": n_status == 0, "status_mismatches": n_status,
-                             "poses_compared": int(ok.sum()),
-                             "pose_mismatches_gt_1e-4m": int((dpos > 1e-4).sum()),
-                             "pos_rmse_m": float(np.sqrt(np.mean(dpos ** 2))) if len(dpos) else None,
-                             "pos_max_m": float(dpos.max()) if len(dpos) else None,
-                             "mismatches_classified_unstable": len(verdicts) - n_unexplained,
-                             "mismatches_unexplained": n_unexplained, "verdicts": verdicts,
-                             "note": "a mismatch is only tolerated when it is traced to a hypothesis (or validation "
-                                     "solve) on which the reference algorithm disagrees with itself under a 1-ulp "
-                                     "change of an input (DESIGN.md section 8; ~1 frame in 1e5)"}
-            parity_failed = n_unexplained > 0
+            try:
+                o, pf, imp = run_config(a, ctx, light=True)
+                c = compact(o)
+                c["leg_s"] = round(time.perf_counter() - t1, 1)
+                if pf or imp:
+                    legs_failed.append((name, 3 if pf else 4))
+                return c
+            except Exception as e:  # a leg that cannot run is reported, and fails the run
+                legs_failed.append((name, 5))
+                return {"error": "%s: %s" % (type(e).__name__, e)}
+
+        out["other_configs"] = {
+            "C1": leg("C1", config="C1", frames=65536),
+            "C3": leg("C3", config="C3", frames=16384),
+            "C3_tol2": leg("C3_tol2", config="C3", frames=16384, back_tol=2.0),
+            "C4": leg("C4", config="C4", frames=16384),
+        }
+        out["clutter"] = {
+            "clean_fps": round(out["value"], 1),
+            "d4": leg("d4", clutter="d4", frames=32768, cpu_sample=256),
+            "d16": leg("d16", clutter="d16", frames=16384, cpu_sample=256),
+            "salt": leg("salt", clutter="salt", frames=32768, cpu_sample=256),
+            "patch": leg("patch", clutter="patch", frames=32768, cpu_sample=256),
+        }
+        if not args.no_cpu:
+            try:
+                out["tracked"], bad = tracked_legs(local_rank)
+                if bad:
+                    legs_failed.append(("tracked", 3))
+            except Exception as e:
+                legs_failed.append(("tracked", 5))
+                out["tracked"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            out["latency_ms_one_frame"] = one_frame_latency(local_rank)
+        except Exception as e:
+            legs_failed.append(("latency", 5))
+            out["latency_ms_one_frame"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["legs_failed"] = [n for n, _ in legs_failed]
+        out["total_s"] = round(time.perf_counter() - t_start, 1)
+        # the driver keeps `config`, `roofline`, `cpu_baseline` of the line: a digest of the other legs rides there too
+        out["config"]["other_legs"] = {
+            k: {"fps": v.get("value"), "frac": (v.get("roofline") or {}).get("frac"),
+                "bound": (v.get("roofline") or {}).get("bound"),
+                "parity_unexplained": (v.get("parity") or {}).get("mismatches_unexplained")}
+            for grp in ("other_configs", "clutter") for k, v in out[grp].items() if isinstance(v, dict)}
+        if "tracked" in out and "one_stream" in out["tracked"]:
+            out["config"]["other_legs"]["tracked"] = {
+                "one_stream_ms": round(out["tracked"]["one_stream"]["latency_ms_per_frame"], 4),
+                "lockstep_8_fps": round(out["tracked"]["lockstep_8"]["fps"], 1),
+                "lockstep_64_fps": round(out["tracked"]["lockstep_64"]["fps"], 1)}
+    if rank == 0:
         print(json.dumps(out))
-        bad_frac = [k for k in ("roofline", "roofline_isolated") if out.get(k) and (out[k].get("frac") or 0) > 1.0]
-        if out["step_hbm"]["frac_of_spec"] > 1.0:
-            bad_frac.append("step_hbm")
-        if bad_frac:
-            sys.stderr.write("bench.py: %s reports more than its peak — the measurement is broken\n" % ", ".join(bad_frac))
-            impossible = True
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    h.close()
-    if impossible:
+    if impossible or any(c == 4 for _, c in legs_failed):
         sys.exit(4)
-    if parity_failed:
-        sys.stderr.write("bench.py: a HIP-vs-oracle mismatch of the parity sample is NOT explained by an instability of "
+    if parity_failed or any(c == 3 for _, c in legs_failed):
+        sys.stderr.write("bench.py: a HIP-vs-oracle mismatch of a parity sample is NOT explained by an instability of "
                          "the reference algorithm (see parity.verdicts)\n")
         sys.exit(3)
+    if legs_failed:
+        sys.stderr.write("bench.py: legs that could not run: %s\n" % ", ".join(n for n, _ in legs_failed))
+        sys.exit(5)
 
 
 if __name__ == "__main__":

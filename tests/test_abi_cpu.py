@@ -366,6 +366,28 @@ def test_bench_entry_spawns_its_own_ranks():
     assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["warmup"] == 1 and rec["scaling"] == "weak"
     assert rec["plumbing_only"] is True and rec["gather_intact"] is True
     assert rec["records_on_rank0"] == 2 * rec["config"]["frames_per_gpu_per_step"]
+    _check_rank_report(rec, 2)
+
+
+def _check_rank_report(rec, world):
+    """What makes an N > 1 run self-checking: the ranks the process group itself saw, every
+    rank's own rate, and a sample of EVERY rank's shard checked on rank 0 (here: against the synthetic records)."""
+    assert rec["ranks_seen"] == list(range(world))
+    assert len(rec["per_rank_fps"]) == world and all(v > 0 for v in rec["per_rank_fps"])
+    sp = rec["shard_parity"]
+    assert [s["rank"] for s in sp] == list(range(world))
+    assert all(s["equal"] is True and s["frames"] > 0 for s in sp)
+    assert len({s["checksum"] for s in sp}) == world      # every shard's records differ (status = rank)
+
+
+def test_bench_entry_three_ranks_report():
+    """World size 3 (an odd count, frames per rank fixed): the same report."""
+    import json
+    out = _run_bench(["--gpus", "3", "--plumbing-only", "--steps", "2", "--warmup", "1", "--frames", "100"])
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-1500:])
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 3 and rec["gather_intact"] is True and rec["records_on_rank0"] == 300
+    _check_rank_report(rec, 3)
 
 
 def test_bench_entry_under_a_launcher_and_error_paths(lib):
@@ -384,6 +406,7 @@ def test_bench_entry_under_a_launcher_and_error_paths(lib):
     assert out.returncode == 0, out.stderr[-1500:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert rec["n_gpus"] == 2 and rec["gather_intact"] is True
+    _check_rank_report(rec, 2)
     bad = _run_bench(["--gpus", "2", "--plumbing-only"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
     assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr
     if lib.mpe_device_count() < 2:
