@@ -425,8 +425,10 @@ def run_config(args, ctx, light=False):
     h.set_profiling(False)
     # frames of one step that the first tier of the blob extraction handed on, by the capacity they exceeded
     # (why: 1 bright segments, 2 bands, 3 islands, 4 pixel pool, 5 bitmap pool, 6 blobs kept)
-    overflow = {k: h.get_option("overflow_" + k) for k in ("frames", "general", "why_1", "why_2", "why_3", "why_4",
-                                                           "why_5", "why_6")}
+    overflow = {"frames": None, "general": None}  # (only a pipelined batch keeps these statistics)
+    if int(kms[0]["launches"]) > 1:
+        overflow = {k: h.get_option("overflow_" + k) for k in ("frames", "general", "why_1", "why_2", "why_3", "why_4",
+                                                               "why_5", "why_6")}
     schedule = h.get_option("last_schedule") if int(kms[0]["launches"]) > 1 else 0
     kavg = {k: float(np.mean([m[k] for m in kms])) for k in kms[0]}
     launches, fpl = int(kms[0]["launches"]), int(kms[0]["frames_per_launch"])
