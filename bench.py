@@ -666,26 +666,37 @@ def run_config(args, ctx, light=False):
     return out, parity_failed, impossible
 
 
+def slim(o):
+    """Floats to 6 significant digits (the line is read by people and a size-limited log tail)."""
+    if isinstance(o, float):
+        return float("%.6g" % o) if np.isfinite(o) else None
+    if isinstance(o, dict):
+        return {k: slim(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [slim(v) for v in o]
+    if isinstance(o, (np.floating, np.integer)):
+        return slim(o.item())
+    return o
+
+
 def compact(out):
     """A secondary leg in a few fields: rate, roofline of its dominant kernel, parity sample, blob tiers."""
     r = out["roofline"]
-    c = {"workload": out["config"]["workload"], "frames_per_step": out["config"]["frames_per_gpu_per_step"],
-         "value": round(out["value"], 1), "unit": "frames/s", "ms_per_step": round(out["ms_per_step"], 4),
-         "steps": out["steps"], "poses_found_frac": round(out["poses_found_frac"], 4),
-         "step_hbm_frac_of_spec": round(out["step_hbm"]["frac_of_spec"], 4),
-         "roofline": {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
-                                            "bytes_per_launch", "avg_launch_ms", "counters_key", "note") if r.get(k) is not None},
-         "kernel_ms": {k: round(out["kernel_ms"][k], 4) for k in ("scan", "blobs", "vote", "tail") if k in out["kernel_ms"]},
-         "blob_tier_overflow": {k: out["blob_tier_overflow"][k] for k in ("frames", "general")},
-         "frames_voted_again": out["vote_arith"]["frames_voted_again"]}
+    c = {"frames_per_step": out["config"]["frames_per_gpu_per_step"], "value": out["value"],
+         "ms_per_step": out["ms_per_step"], "poses_found_frac": out["poses_found_frac"],
+         "roofline": {k: r.get(k) for k in ("kernel", "bound", "frac", "achieved", "peak", "unit", "traffic",
+                                            "avg_launch_ms", "note") if r.get(k) is not None},
+         "kernel_ms": {k: out["kernel_ms"][k] for k in ("scan", "blobs", "vote", "tail") if k in out["kernel_ms"]},
+         "blob_tier_overflow": {k: out["blob_tier_overflow"][k] for k in ("frames", "general")}}
+    if out["vote_arith"]["frames_voted_again"]:
+        c["frames_voted_again"] = out["vote_arith"]["frames_voted_again"]
     if "parity" in out:
         c["parity"] = {k: out["parity"].get(k) for k in ("frames", "status_mismatches", "poses_compared", "pos_max_m",
-                                                         "rot_max_rad", "mismatches_classified_unstable",
                                                          "mismatches_unexplained")}
     if "cpu_baseline" in out:
-        c["cpu_fps"] = round(out["cpu_baseline"]["value"], 1)
+        c["cpu_fps"] = out["cpu_baseline"]["value"]
     if "k2_rates" in out and "valu_insts_per_p3p_solve" in out["k2_rates"]:
-        c["valu_insts_per_p3p_solve"] = round(out["k2_rates"]["valu_insts_per_p3p_solve"], 1)
+        c["valu_insts_per_p3p_solve"] = out["k2_rates"]["valu_insts_per_p3p_solve"]
     return c
 
 
@@ -954,7 +965,7 @@ def main():
                 "lockstep_8_fps": round(out["tracked"]["lockstep_8"]["fps"], 1),
                 "lockstep_64_fps": round(out["tracked"]["lockstep_64"]["fps"], 1)}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(slim(out), separators=(",", ":")))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1316,6 +1316,7 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
   else if (n == "vote_list_cap") *value = (int)h->fix_cap_limit;
+  else if (n == "k1b_general_blocks") *value = k1b_get_general_blocks();
   else if (n == "vote_fixup_items" || n == "vote_fixup_overflow" || n == "vote_relost_frames") {
     // hypotheses (roots, detections) the fast voting kernel handed to the strict arithmetic since the handle was made,
     // how many it could not hand over because a list was full, and how many frames were therefore voted again by the
@@ -1445,6 +1446,11 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   }
   if (!std::strcmp(name, "force_rccl_gather")) {
     h->force_rccl_gather = value ? 1 : 0;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "k1b_general_blocks")) {  // tuning, process-wide: waves of the general blob tier in flight
+    if (value < 32 || value > 8192) return fail(h, MPE_ERR_ARG, "k1b_general_blocks must be in [32, 8192]");
+    k1b_set_general_blocks(value);
     return MPE_OK;
   }
   if (!std::strcmp(name, "vote_list_cap")) {  // tests: a list this small overflows and exercises k2_vote_relost

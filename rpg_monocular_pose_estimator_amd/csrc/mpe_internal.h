@@ -78,6 +78,8 @@ struct VoteFixup {
 // launchers (mpe_kernels.hip)
 int device_cu_count();  // compute units of the current device (cached)
 size_t k1b_scratch_bytes(const FrameGeom& g);
+void k1b_set_general_blocks(int cap);  // blocks (= scratch slabs) of the general blob tier at most; process-wide
+int k1b_get_general_blocks();
 hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long long* flags, int thr,
                            int dummy_lds_bytes, hipStream_t s, int blocks_per_cu = 0);
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,

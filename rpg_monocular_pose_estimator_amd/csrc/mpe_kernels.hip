@@ -274,6 +274,8 @@ __device__ __forceinline__ unsigned tozero4(unsigned w, unsigned add) {
 struct PixWin {
   const uint8_t* pix;
   int ylo, H, pwc0, PW;  // PW = bytes per window row
+  unsigned add;          // 0: `pix` holds thresholded pixels (the LDS windows); else: raw frame bytes, THRESH_TOZERO
+                         // applied on the fly with tozero4's constant (255 - thr) * 0x10001 (the general kernel)
 };
 
 // fixed-point Gaussian for the 16 outputs x0..x0+15 of image row y, reading the LDS window.
@@ -283,7 +285,7 @@ struct PixWin {
 // — the `zone` bits over the taps' input positions j (pixel x0 - R + j) — is non-zero after the threshold, which
 // is reported in edge_or so that the caller can redo the item with the byte-wise border code.  LED spots sit well
 // inside the frame / the tracking ROI (20 px border), so the mirrored zone is almost always dark.
-template <int KS, bool EDGE>
+template <int KS, bool EDGE, bool RAW = false>
 __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, int cols, int y, int c,
                                                    const DetectParams& dp, unsigned zone, unsigned& edge_or) {
   constexpr int R = KS / 2;
@@ -305,7 +307,11 @@ __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, in
     const uint4 q0 = ((unsigned)sc < (unsigned)nsw) ? p[sc] : z4;
     const uint4 q1 = ((unsigned)(sc + 1) < (unsigned)nsw) ? p[sc + 1] : z4;
     const uint4 q2 = ((unsigned)(sc + 2) < (unsigned)nsw) ? p[sc + 2] : z4;
-    const unsigned q[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+    unsigned q[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+    if (RAW) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) q[k] = tozero4(q[k], w.add);
+    }
     if (EDGE) {
 #pragma unroll
       for (int j = 0; j < 16 + 2 * R; ++j) {
@@ -355,7 +361,11 @@ __device__ __noinline__ unsigned blur_item_generic(const PixWin& w, int rows, in
       int h = 0;
       for (int j = 0; j < ks; ++j) {
         const int so = reflect101(x0 + x + j - r, cols) - 16 * w.pwc0;
-        if ((unsigned)so < (unsigned)w.PW) h += taps[j] * (int)w.pix[(size_t)yb * w.PW + so];
+        if ((unsigned)so < (unsigned)w.PW) {
+          int v = (int)w.pix[(size_t)yb * w.PW + so];
+          if (w.add && v <= 255 - (int)(w.add & 0xFFFFu)) v = 0;  // raw frame bytes: THRESH_TOZERO here
+          h += taps[j] * v;
+        }
       }
       acc += taps[i] * h;
     }
@@ -981,6 +991,7 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
 }
 
 // blurred-mask bits of the 16 outputs of segment column c in image row y -> OR into the bitmap
+template <bool RAW = false>
 __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int cols, const DetectParams& dp,
                                                const int* taps, int y, int c, u64* nzrow, int xw0) {
   const int ksize = dp.ksize;
@@ -991,9 +1002,9 @@ __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int c
   const bool interior = (x0 - r >= 0) && (x0 + 15 + r < cols);
   unsigned edge_or = 0;
   if (interior && ksize == 5 && dp.taps_u8) {
-    m = blur_item_fast<5, false>(pw, rows, cols, y, c, dp, 0u, edge_or);
+    m = blur_item_fast<5, false, RAW>(pw, rows, cols, y, c, dp, 0u, edge_or);
   } else if (interior && ksize == 3 && dp.taps_u8) {
-    m = blur_item_fast<3, false>(pw, rows, cols, y, c, dp, 0u, edge_or);
+    m = blur_item_fast<3, false, RAW>(pw, rows, cols, y, c, dp, 0u, edge_or);
   } else if ((ksize == 5 || ksize == 3) && dp.taps_u8 && cols >= 2 * r + 2) {
     // border segment: mirrored input positions j (pixel x = x0 - r + j): left border x in [1, r], right border
     // x in [cols - 1 - r, cols - 2]
@@ -1002,8 +1013,8 @@ __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int c
       const int x = x0 - r + j;
       if ((x0 - r < 0 && x >= 1 && x <= r) || (x0 + 15 + r >= cols && x >= cols - 1 - r && x <= cols - 2)) zone |= 1u << j;
     }
-    m = ksize == 5 ? blur_item_fast<5, true>(pw, rows, cols, y, c, dp, zone, edge_or)
-                   : blur_item_fast<3, true>(pw, rows, cols, y, c, dp, zone, edge_or);
+    m = ksize == 5 ? blur_item_fast<5, true, RAW>(pw, rows, cols, y, c, dp, zone, edge_or)
+                   : blur_item_fast<3, true, RAW>(pw, rows, cols, y, c, dp, zone, edge_or);
     if (edge_or) m = blur_item_generic(pw, rows, cols, y, c, taps, ksize);  // a bright pixel next to the border
   } else {
     m = blur_item_generic(pw, rows, cols, y, c, taps, ksize);
@@ -1437,7 +1448,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
       const int yb = li / ncols, c = is.clo + (li - yb * ncols);
       const int H = is.yhi - is.ylo + 1;
       const int W = isl_words(is, g.cols, r);
-      const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1)};
+      const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1), 0u};
       blur_to_bitmap(pw, g.rows, g.cols, dp, s_taps, is.ylo + yb, c, s_nz + is.bm_off + (size_t)(yb + 1) * W,
                      isl_xw0(is, r));
     }
@@ -1587,18 +1598,37 @@ __global__ __launch_bounds__(64 * C::WAVES, C::MIN_WAVES) void k1b_blobs_list(co
 }
 
 // =============================================================================================
-// K1b general path: frames the fast path handed over (too many bright segments / rows for its
-// LDS pools).  One wave per frame, whole-frame window in a global scratch slab: thresholded copy
-// of the frame, three full-frame bitmaps and a segment todo bitset.  Slow but exact on any frame.
+// K1b general path: frames the fast tiers handed over (more bright segments / bands / islands than their LDS pools
+// hold: salt noise, glare, a dot grid).  One wave per frame, whole-frame bitmaps in a global scratch slab, exact on
+// any frame.  Round 5 (on cluttered frames this tier was a cliff — 43 us of ONE LANE per
+// frame on 32 waves of the whole chip, 11.6 k frames/s with 0.05 % salt noise):
+//   * no thresholded copy of the frame: the blur reads the frame's own rows and applies THRESH_TOZERO on the fly
+//     (PixWin::add), only around bright segments;
+//   * the contour scan runs one LANE PER BAND — a maximal run of rows with a non-zero blurred pixel.  A component of
+//     the blurred mask cannot cross an empty row, and a band cannot lie inside a hole of a component of another band,
+//     so cvFindContours' raster scan decomposes exactly, as it does for the islands of the fast tiers; the kept blobs
+//     are put back into raster order of their start pixels at the end (write_detections);
+//   * up to 1024 slabs (1 GB of scratch at most) instead of 32.
 // =============================================================================================
 #define K1B_GEN_KEPT 512
+#define K1B_GEN_BANDS 2048  // rows <= 4096 (make_geom): at most every other row starts a band
 
 __host__ __device__ inline size_t k1b_gen_scratch_bytes(const FrameGeom& g) {
-  const size_t pix = (size_t)g.rows * g.pitch;
   const size_t bm = (size_t)(g.rows + 2) * g.wb * 8;
   const size_t todo = (size_t)g.rows * g.tw * 8;
   const size_t kept = (size_t)K1B_GEN_KEPT * 12;
-  return ((pix + 3 * bm + todo + kept + 255) / 256) * 256;
+  return ((3 * bm + todo + kept + 255) / 256) * 256;
+}
+// slabs = blocks of the launch: as many as 1 GB of scratch holds, 32 .. g_k1b_gen_blocks_cap (a process-wide tuning
+// knob, option "k1b_general_blocks"; the kernel is bound by the latency of its global-memory bitmaps, so its rate
+// follows the number of waves in flight)
+static int g_k1b_gen_blocks_cap = 1024;
+void k1b_set_general_blocks(int cap) { g_k1b_gen_blocks_cap = cap < 32 ? 32 : (cap > 8192 ? 8192 : cap); }
+int k1b_get_general_blocks() { return g_k1b_gen_blocks_cap; }
+static int k1b_gen_blocks(const FrameGeom& g) {
+  const size_t n = ((size_t)1 << 30) / k1b_gen_scratch_bytes(g);
+  const size_t cap = (size_t)g_k1b_gen_blocks_cap;
+  return (int)(n < 32 ? 32 : (n > cap ? cap : n));
 }
 
 __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
@@ -1606,17 +1636,19 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
                                                  const int* __restrict__ worklist, uint8_t* __restrict__ scratch,
                                                  const FrameWin* __restrict__ wins) {
   const FrameGeom& g = gslot;  // slab layout and flag indexing: the slot; rows / cols of a frame: its window (gl below)
-  __shared__ int s_nkept, s_over;
+  __shared__ int s_nkept, s_over, s_nband;
   __shared__ int s_taps[MPE_MAX_KSIZE];
+  __shared__ u64 s_rowact[64];
+  __shared__ short s_blo[K1B_GEN_BANDS], s_bhi[K1B_GEN_BANDS];
   const int lane = threadIdx.x;
+  const int count = worklist[0];
+  if ((int)blockIdx.x >= count) return;  // (the usual launch: nothing was handed over)
   if (lane < MPE_MAX_KSIZE) s_taps[lane] = dp.taps[lane < dp.ksize ? lane : 0];
   __syncthreads();
-  const int count = worklist[0];
   const size_t slab = k1b_gen_scratch_bytes(g);
   uint8_t* base = scratch + (size_t)blockIdx.x * slab;
-  uint8_t* pix = base;
   const size_t bm_words = (size_t)(g.rows + 2) * g.wb;
-  u64* nz = reinterpret_cast<u64*>(base + (size_t)g.rows * g.pitch);
+  u64* nz = reinterpret_cast<u64*>(base);
   u64* pm = nz + bm_words;
   u64* ng = pm + bm_words;
   u64* todo = ng + bm_words;
@@ -1636,22 +1668,16 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     if (lane == 0) {
       s_nkept = 0;
       s_over = 0;
+      s_nband = 0;
     }
+    s_rowact[lane] = 0;
     for (size_t i = lane; i < bm_words; i += 64) {
       nz[i] = 0;
       pm[i] = 0;
       ng[i] = 0;
     }
     for (size_t i = lane; i < (size_t)g.rows * g.tw; i += 64) todo[i] = 0;
-    // thresholded copy of the frame
-    for (size_t i = lane; i < (size_t)g.rows * spr; i += 64) {
-      uint4 v = *reinterpret_cast<const uint4*>(frame + i * 16);
-      v.x = tozero4(v.x, add);
-      v.y = tozero4(v.y, add);
-      v.z = tozero4(v.z, add);
-      v.w = tozero4(v.w, add);
-      *reinterpret_cast<uint4*>(pix + i * 16) = v;
-    }
+    __threadfence_block();
     __syncthreads();
     // todo segments: neighbourhood of every bright segment
     {
@@ -1676,30 +1702,85 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     }
     __threadfence_block();
     __syncthreads();
-    // blur
-    const PixWin pw = {pix, 0, gl.rows, 0, g.pitch};
-    for (int y = lane; y < gl.rows; y += 64)
+    // blur (lane = row): the frame's own bytes, thresholded on the fly; rows that got a non-zero pixel become active
+    const PixWin pw = {frame, 0, gl.rows, 0, g.pitch, add};
+    for (int y = lane; y < gl.rows; y += 64) {
+      u64* nzrow = nz + (size_t)(y + 1) * g.wb;
       for (int tw = 0; tw < g.tw; ++tw) {
         u64 tb = todo[(size_t)y * g.tw + tw];
         while (tb) {
           const int c = tw * 64 + __builtin_ctzll(tb);
           tb &= tb - 1;
-          blur_to_bitmap(pw, gl.rows, gl.cols, dp, s_taps, y, c, nz + (size_t)(y + 1) * g.wb, 0);
+          if (add)
+            blur_to_bitmap<true>(pw, gl.rows, gl.cols, dp, s_taps, y, c, nzrow, 0);
+          else  // (thr = 255: nothing passes the threshold — the flags say so already, no item arrives here)
+            blur_to_bitmap<false>(pw, gl.rows, gl.cols, dp, s_taps, y, c, nzrow, 0);
         }
       }
+    }
     __threadfence_block();
     __syncthreads();
-    if (lane == 0) {
-      int nk = 0;
-      scan_window(nz, pm, ng, g.wb, gl.rows, 0, 0, dp, roi_x, roi_y, &s_over, [&](float mcx, float mcy, unsigned key) {
-        if (nk < K1B_GEN_KEPT) {
-          kx[nk] = mcx;
-          ky[nk] = mcy;
-          kkey[nk] = key;
+    for (int y = lane; y < gl.rows; y += 64) {
+      const u64* nzrow = nz + (size_t)(y + 1) * g.wb;
+      u64 any = 0;
+      for (int w = 0; w < g.wb; ++w) any |= nzrow[w];
+      if (any) atomicOr(&s_rowact[y >> 6], 1ull << (y & 63));
+    }
+    __syncthreads();
+    // bands = maximal runs of active rows (lane w owns word w of the row bitset; ranks by a wave prefix sum)
+    {
+      const int rw = (gl.rows + 63) >> 6;
+      const u64 act = (lane < rw) ? s_rowact[lane] : 0;
+      const u64 prevw = (lane > 0 && lane < rw) ? s_rowact[lane - 1] : 0;
+      const u64 nextw = (lane + 1 < rw) ? s_rowact[lane + 1] : 0;
+      u64 st = act & ~((act << 1) | (prevw >> 63));
+      u64 en = act & ~((act >> 1) | (nextw << 63));
+      const int cs = __builtin_popcountll(st), ce = __builtin_popcountll(en);
+      int ps = cs, pe = ce;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int a = __shfl_up(ps, d), b = __shfl_up(pe, d);
+        if (lane >= d) {
+          ps += a;
+          pe += b;
         }
-        ++nk;
-      });
-      s_nkept = nk;
+      }
+      int is_ = ps - cs, ie = pe - ce;
+      while (st) {
+        const int b = __builtin_ctzll(st);
+        st &= st - 1;
+        if (is_ < K1B_GEN_BANDS) s_blo[is_] = (short)(lane * 64 + b);
+        ++is_;
+      }
+      while (en) {
+        const int b = __builtin_ctzll(en);
+        en &= en - 1;
+        if (ie < K1B_GEN_BANDS) s_bhi[ie] = (short)(lane * 64 + b);
+        ++ie;
+      }
+      if (lane == 63) s_nband = ps;
+    }
+    __syncthreads();
+    const int nband = s_nband;
+    auto keep = [&](float mcx, float mcy, unsigned key) {
+      const int k = atomicAdd(&s_nkept, 1);
+      if (k < K1B_GEN_KEPT) {
+        kx[k] = mcx;
+        ky[k] = mcy;
+        kkey[k] = key;
+      }
+    };
+    if (nband <= K1B_GEN_BANDS) {
+      // one lane per band, the lanes' border followings in lock step (scan_window): slot 0 of a band's window is the
+      // empty row above it, slots 1 .. H its rows, the separator below the empty row that ends it
+      for (int b0 = 0; b0 < nband; b0 += 64) {  // (uniform: every lane enters scan_window, with H = 0 if it has no band)
+        const int b = b0 + lane;
+        const int lo = b < nband ? s_blo[b] : 0, H = b < nband ? s_bhi[b] - lo + 1 : 0;
+        const size_t off = (size_t)lo * g.wb;
+        scan_window(nz + off, pm + off, ng + off, g.wb, H, lo, 0, dp, roi_x, roi_y, &s_over, keep);
+      }
+    } else {  // (cannot happen for rows <= 4096; the literal whole-frame scan by one lane)
+      scan_window(nz, pm, ng, g.wb, lane == 0 ? gl.rows : 0, 0, 0, dp, roi_x, roi_y, &s_over, keep);
     }
     __threadfence_block();
     __syncthreads();
@@ -1708,8 +1789,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
   }
 }
 
-#define K1B_GEN_BLOCKS 32
-size_t k1b_scratch_bytes(const FrameGeom& g) { return k1b_gen_scratch_bytes(g) * K1B_GEN_BLOCKS; }
+size_t k1b_scratch_bytes(const FrameGeom& g) { return k1b_gen_scratch_bytes(g) * (size_t)k1b_gen_blocks(g); }
 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
@@ -1753,7 +1833,7 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k1b_general, dim3(K1B_GEN_BLOCKS), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
+  hipLaunchKernelGGL(k1b_general, dim3(k1b_gen_blocks(g)), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
                      (const int*)list_b, scratch, wins);
   return hipGetLastError();
 }
