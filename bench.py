@@ -506,6 +506,19 @@ def run_config(args, ctx, light=False):
                     "avg_launch_ms_source": ("HIP events around all %d launches of the timed region" % vote_in_region_n)
                                             if vote_in_region_ms else "HIP events in extra steps of the same mode",
                     "avg_launch_ms_in_separately_profiled_steps": vote_profiled_ms, "counters": counters}
+        # a cluttered frame (many distractor spots) makes the same kernel FP64-issue bound: with a SQ_INSTS_VALU pass of
+        # this shape under profiles/, report the roof the launch is closer to
+        vp_ = pmc_all.get("k2_vote_valu", {}).get(pmc_key) if args.clutter else None
+        if vp_:
+            clk_ = float(vp_.get("effective_clock_GHz") or 2.4)
+            insts = vp_["valu_insts_per_frame"] * min(fpl, B)
+            frac_valu = insts * 4.0 / (1024 * clk_ * 1e9 * scan_s)
+            roofline["frac_hbm"] = roofline["frac"]
+            roofline["frac_fp64_valu"] = frac_valu
+            if frac_valu > roofline["frac"]:
+                roofline.update({"bound": "fp64_valu", "achieved": insts / scan_s / 1e9, "peak": 1024 * clk_ / 4.0,
+                                 "unit": "G wave-instructions/s", "frac": frac_valu, "traffic": None,
+                                 "effective_clock_GHz": clk_})
     elif vote_bound:
         # FP64 VALU issue: a wave64 FP64 instruction occupies a SIMD for 4 cycles -> 1024 SIMDs x clock / 4 wave-
         # instructions per second; the instruction count per frame is the committed SQ_INSTS_VALU pass of this kernel

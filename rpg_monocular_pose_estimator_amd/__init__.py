@@ -6,7 +6,7 @@ out.  There is NO CPU fallback: if the library or a HIP device is missing every 
 """
 from .binding import (MpeError, MpeParams, MpeResult, MpeDetections, RESULT_DTYPE, DETECTIONS_DTYPE,  # noqa: F401
                       MAX_DETECTIONS, MAX_MARKERS, Handle, build_library, library_path, load_library,
-                      demo_params, exported_symbols, source_fingerprint, Tracker, determine_roi, distort_points, exponential_map, logarithm_map,
+                      demo_params, exported_symbols, source_fingerprint, device_source, DEVICE_SOURCES, Tracker, determine_roi, distort_points, exponential_map, logarithm_map,
                       predict_pose, project_points, find_correspondences, shard_bounds, estimate_batch_multi,
                       estimate_batch_multi_device_gather, ENCODINGS,
                       tracker_estimate_batch, tracker_run_sequences_batch, PinnedFrames)
@@ -14,6 +14,6 @@ from .pose_estimator import PoseEstimator  # noqa: F401
 
 __all__ = ["MpeError", "MpeParams", "MpeResult", "MpeDetections", "RESULT_DTYPE", "DETECTIONS_DTYPE",
            "MAX_DETECTIONS", "MAX_MARKERS", "Handle", "build_library", "library_path", "load_library",
-           "demo_params", "exported_symbols", "source_fingerprint", "PoseEstimator", "Tracker", "determine_roi", "distort_points",
+           "demo_params", "exported_symbols", "source_fingerprint", "device_source", "DEVICE_SOURCES", "PoseEstimator", "Tracker", "determine_roi", "distort_points",
            "exponential_map", "logarithm_map", "predict_pose", "project_points", "find_correspondences",
            "shard_bounds", "estimate_batch_multi", "estimate_batch_multi_device_gather", "ENCODINGS", "tracker_estimate_batch", "tracker_run_sequences_batch", "PinnedFrames"]

@@ -60,11 +60,28 @@ def library_path():
 
 def build_library(force=False):
     """Compile the HIP library for gfx950 with hipcc (csrc/Makefile).  Works without a GPU."""
-    cmd = ["make", "-s", "-C", _CSRC] + (["-B"] if force else [])
+    cmd = ["make", "-s", "-j4", "-C", _CSRC] + (["-B"] if force else [])
     subprocess.check_call(cmd)
     if not os.path.exists(_LIB):
         raise MpeError("build did not produce %s" % _LIB)
     return _LIB
+
+
+# the kernel sources, in the order in which they read as one text (the former single file mpe_kernels.hip)
+DEVICE_SOURCES = ("mpe_kernels_common.h", "mpe_k1.hip", "mpe_k2_head.h", "mpe_k2.hip", "mpe_k3.hip")
+
+
+def device_source():
+    """The kernel sources as ONE text, file prologues / epilogues (`//@file-prologue` .. `-end`, `//@file-epilogue` ..
+    `-end`) dropped: what the CPU tier cuts its host builds of the device code from."""
+    out = []
+    for name in DEVICE_SOURCES:
+        with open(os.path.join(_CSRC, name)) as fh:
+            txt = fh.read()
+        txt = re.sub(r"//@file-prologue\n.*?//@file-prologue-end\n", "", txt, flags=re.S)
+        txt = re.sub(r"//@file-epilogue\n.*?//@file-epilogue-end\n", "", txt, flags=re.S)
+        out.append(txt)
+    return "".join(out)
 
 
 def source_fingerprint():
@@ -72,7 +89,7 @@ def source_fingerprint():
     (profiles/round3_pmc.json) to the code a bench run times."""
     import hashlib
     hsh = hashlib.sha256()
-    for name in ("mpe_kernels.hip", "mpe_p3p.h", "mpe_internal.h", "mpe_abi.cpp"):
+    for name in DEVICE_SOURCES + ("mpe_p3p.h", "mpe_internal.h", "mpe_abi.cpp"):
         with open(os.path.join(_CSRC, name), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]

@@ -839,7 +839,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
         if (!e) HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     // Fused schedule, ONE stream: the voting kernel of sub-batch s carries the image scan of sub-batch
-    // s + 1 on its idle memory pipeline (ScanRider in mpe_kernels.hip).
+    // s + 1 on its idle memory pipeline (ScanRider in mpe_k2.hip).
     //   scan(0) | blobs(0) vote(0)+scan(1) tail(0) | blobs(1) vote(1)+scan(2) tail(1) | ...
     // Streaming (StreamHint): the LAST voting launch carries the scan of the first sub-batch of the NEXT submission
     // (into the extra flag region behind the nsub regions of this one), whose stand-alone scan then disappears:

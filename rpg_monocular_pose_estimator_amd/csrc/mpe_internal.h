@@ -1,5 +1,5 @@
 // mpe_internal.h — structures shared by the host side (mpe_abi.cpp) and the gfx950 kernels
-// (mpe_kernels.hip).  Not part of the public ABI.
+// (mpe_k1.hip, mpe_k2.hip, mpe_k3.hip).  Not part of the public ABI.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -61,7 +61,7 @@ struct SolveParams {
 
 #define MPE_HIST_STRIDE (MPE_MAX_DETECTIONS * MPE_MAX_MARKERS)
 
-// Hypotheses a fast voting launch does not decide itself (mpe_kernels.hip, k2_sus_push): a list in device memory that
+// Hypotheses a fast voting launch does not decide itself (mpe_k2.hip, k2_sus_push): a list in device memory that
 // launch_k2_fixup works off with the strict arithmetic, behind the voting launch and in front of the tail.
 #define MPE_FIX_CTL_WORDS 8
 struct VoteFixup {
@@ -75,7 +75,7 @@ struct VoteFixup {
                              // per-wave vote queue cannot hold (vote_arith 2: the fast arithmetic decides the rest)
 };
 
-// launchers (mpe_kernels.hip)
+// launchers (mpe_k1.hip / mpe_k2.hip / mpe_k3.hip)
 int device_cu_count();  // compute units of the current device (cached)
 size_t k1b_scratch_bytes(const FrameGeom& g);
 void k1b_set_general_blocks(int cap);  // blocks (= scratch slabs) of the general blob tier at most; process-wide

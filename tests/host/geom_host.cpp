@@ -1,5 +1,5 @@
 // Host build of the DEVICE geometry source (test scaffolding, CPU tier): rpg_monocular_pose_estimator_amd/csrc/mpe_p3p.h
-// as it is, and the tail helpers of mpe_kernels.hip (`struct T34` .. `#define K3_GROUP`: projection, Hestenes-Jacobi
+// as it is, and the tail helpers of mpe_k3.hip (`struct T34` .. `#define K3_GROUP`: projection, Hestenes-Jacobi
 // Kabsch rotation, LDL^T of the normal equations, exponential-map update) cut out at test time into k3_extract.inc.
 #include <cstddef>
 #include <cstring>
@@ -22,7 +22,7 @@ extern "C" void host_quartic(const double* factors, int n, int variant, double* 
   }
 }
 
-// as k_p3p_batch of mpe_kernels.hip
+// as k_p3p_batch of mpe_k3.hip
 extern "C" void host_p3p(const double* fv, const double* wp, int n, double* sol, int* status) {
   for (int i = 0; i < n; ++i) {
     const double* f = fv + (size_t)i * 9;

@@ -1,7 +1,7 @@
 // Host build of the DEVICE blob-extraction source (test scaffolding, CPU tier).
 //
 // tests/test_k1b_host.py cuts the region `struct BlobRec { ... }` .. `// final stage: kept blobs` out of
-// rpg_monocular_pose_estimator_amd/csrc/mpe_kernels.hip (threshold helpers, fixed-point blur, Suzuki border
+// rpg_monocular_pose_estimator_amd/csrc/mpe_k1.hip + mpe_kernels_common.h (threshold helpers, fixed-point blur, Suzuki border
 // following, polygon sums, shape filter, undistortion — everything of K1b that is not wave plumbing) and
 // `struct DetectParams` out of mpe_internal.h into k1b_extract.inc, and compiles this file with g++.  The shims
 // below give the HIP spellings a one-lane meaning.  The flow of host_find_leds is that of the device's

@@ -1,5 +1,5 @@
 // Host build of the DEVICE voting source (test scaffolding, CPU tier): mpe_p3p.h as it is and, cut out of
-// mpe_kernels.hip at test time (vote_extract.inc), the index arithmetic, the marker-permutation table entry, the
+// mpe_k2.hip at test time (vote_extract.inc), the index arithmetic, the marker-permutation table entry, the
 // per-triple part of computePoses and the voting work item (quartic coefficients, Ferrari in the fast arithmetic,
 // back-projection without forming [R|C], single-precision prefilter, exact nearest-neighbour votes) — i.e. what
 // k2_vote<false> runs per lane, driven here by one "lane" over all (triple, permutation) items of a frame.

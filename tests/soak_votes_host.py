@@ -1,4 +1,4 @@
-"""CPU-only vote-histogram soak of the DEVICE voting source: the work item of k2_vote (cut out of mpe_kernels.hip and
+"""CPU-only vote-histogram soak of the DEVICE voting source: the work item of k2_vote (cut out of mpe_k2.hip and
 compiled for the host, as tests/test_vote_host.py does) against the oracle's initialise() loop on N synthetic
 detection sets — the undistorted LED projections of random scenes, rounded to float32 as findLeds delivers them, in
 random order.  Counts the frames whose histogram differs anywhere and classifies each one: a frame is "unstable" when

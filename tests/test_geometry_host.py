@@ -1,5 +1,5 @@
 """The DEVICE geometry source — mpe_p3p.h (Ferrari quartic in both arithmetics, Kneip P3P) and the tail helpers of
-mpe_kernels.hip (Hestenes-Jacobi Kabsch rotation, LDL^T solve, exponential-map update) — compiled for the HOST and
+mpe_k3.hip (Hestenes-Jacobi Kabsch rotation, LDL^T solve, exponential-map update) — compiled for the HOST and
 checked against the oracle with the same criteria the `-m gpu` tests apply to the kernels.  The CPU tier has no GPU,
 but it can still run the source the GPU runs; only the hardware reciprocal / rsqrt seeds of the fast arithmetic are
 replaced (tests/host/stub/hip/hip_runtime.h).  Reference: p3p.cpp:65-286, pose_estimator.cpp:908-994."""
@@ -20,7 +20,8 @@ CSRC = os.path.join(ROOT, "rpg_monocular_pose_estimator_amd", "csrc")
 @pytest.fixture(scope="module")
 def host(tmp_path_factory):
     d = tmp_path_factory.mktemp("geom_host")
-    hip = open(os.path.join(CSRC, "mpe_kernels.hip")).read()
+    import rpg_monocular_pose_estimator_amd as mpe
+    hip = mpe.device_source()
     i = hip.index("struct T34 {")
     with open(os.path.join(d, "k3_extract.inc"), "w") as fh:
         fh.write(hip[i:hip.index("#define K3_GROUP", i)])

@@ -15,7 +15,7 @@ from oracle import binding as orc  # noqa: E402
 
 
 def column_maxima_form(hist, threshold):
-    """The kernel's form (mpe_kernels.hip, k3a_validate, histogram path): hist rows = detections, columns = markers."""
+    """The kernel's form (mpe_k3.hip, k3a_validate, histogram path): hist rows = detections, columns = markers."""
     n_d, n_m = hist.shape
     colmax = np.zeros(n_m, np.uint64)
     colrow = np.zeros(n_m, np.int64)

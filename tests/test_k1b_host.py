@@ -2,7 +2,7 @@
 shape filter, undistortion: everything of K1b that is not wave plumbing), compiled for the HOST and checked against
 the oracle's findLeds — the CPU tier has no GPU, but it can still run the very code the GPU runs.
 
-The region is cut out of rpg_monocular_pose_estimator_amd/csrc/mpe_kernels.hip at test time (tests/host/k1b_host.cpp
+The region is cut out of the kernel sources (rpg_monocular_pose_estimator_amd/csrc/mpe_k1.hip; binding.device_source) at test time (tests/host/k1b_host.cpp
 holds the one-lane shims and the whole-frame flow of the device's general tier).  Reference being matched:
 led_detector.cpp:35-112 through oracle.find_leds."""
 import ctypes as C
@@ -26,7 +26,8 @@ def _cut(text, begin, end):
 @pytest.fixture(scope="module")
 def host(tmp_path_factory):
     d = tmp_path_factory.mktemp("k1b_host")
-    hip = open(os.path.join(CSRC, "mpe_kernels.hip")).read()
+    import rpg_monocular_pose_estimator_amd as mpe
+    hip = mpe.device_source()
     internal = open(os.path.join(CSRC, "mpe_internal.h")).read()
     with open(os.path.join(d, "k1a_extract.inc"), "w") as fh:
         fh.write(_cut(hip, "struct ThrTest {", "#ifndef K1A_UNROLL"))

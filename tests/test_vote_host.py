@@ -22,7 +22,8 @@ def _cut(text, begin, end):
 
 
 def _build(d, tiny_queues=False):
-    hip = open(os.path.join(CSRC, "mpe_kernels.hip")).read()
+    import rpg_monocular_pose_estimator_amd as mpe
+    hip = mpe.device_source()
     internal = open(os.path.join(CSRC, "mpe_internal.h")).read()
     inc = _cut(internal, "struct SolveParams {", "#define MPE_HIST_STRIDE")
     inc += _cut(hip, "// lexicographic unranking of the idx-th 3-combination", "#define K2_THREADS")
