@@ -495,7 +495,14 @@ int mpe_set_option(mpe_handle* h, const char* name, int value);
  *   "track_ns_enqueue", "track_ns_wait" (mean ns per step), "track_steps".
  * get "overflow_frames", "overflow_general", "overflow_why_1" .. "overflow_why_6": frames of the last pipelined batch
  *   that the first blob tier handed on, in all / to the general tier / by the capacity exceeded (bright segments,
- *   bands, islands, pixel pool, bitmap pool, blobs kept); synchronises. */
+ *   bands, islands, pixel pool, bitmap pool, blobs kept); synchronises.
+ * get "vote_fixup_items" / "vote_fixup_overflow" / "vote_relost_frames": hypotheses the fast voting kernel handed to
+ *   the strict arithmetic since the handle was made, appends that found their list full, and frames that were therefore
+ *   voted again by the strict loop nest (a full list costs time, never a pose); synchronises.
+ * Tuning / test knobs (round 5): "vote_list_cap" (entries per suspect list at most, 0 = no limit: a tiny list exercises
+ *   the re-vote path), "k1b_general_blocks" (PROCESS-wide: blocks = scratch slabs of the general blob tier, 32 .. 8192,
+ *   default 4096, within 1 GB of scratch), "tail_priority" / "scan_priority" (-1 / 0 / 1: stream priority of the
+ *   library's two side streams, applied when they are created). */
 /* Read an option back.  Also "streams_concurrent": 1 once the library has verified (spin-kernel probe at
  * the first large batch) that its two pipeline side streams execute concurrently, 0 if no concurrent
  * pair was found (the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues), -1 not probed yet;

@@ -128,6 +128,8 @@ struct mpe_handle {
   // 32 768 frames) and, once the voting launch got shorter, did not even finish inside blob window + vote; one block
   // streams at ~1.5 TB/s beside the rider for the whole period (same-box sweeps: profiles/round4_sweep_side_scan.json)
   int side_scan_blocks = 1;
+  int tail_priority = 0;   // option "tail_priority" / "scan_priority": -1 lowest, 0 default, 1 highest stream priority
+  int scan_priority = 0;   //   of the side streams (applied when they are created; experiments)
   int scan_split_pct = 28;
   unsigned long long last_rider_bytes = 0;  // bytes one fused voting launch scanned in the last large call
   hipStream_t tail_stream = nullptr;  // fused schedule, mode 4: validate + refine of sub-batch s beside blobs(s + 1)
@@ -637,12 +639,21 @@ hipError_t spin_pair_ms(hipStream_t a, hipStream_t b, double& ms) {
 // stream, tail stream, scan stream} must run two 1 ms spin kernels in ~1 ms; a side stream that shares a queue is
 // replaced (the rejected ones stay alive until the end so that the runtime hands out other queues).  No concurrent set
 // after 8 replacements -> side_streams_ok = 0 and the caller falls back to the one-stream schedule 3.
+// a side stream with the priority the handle asks for (hipStreamCreateWithPriority: lower number = higher priority)
+hipError_t make_side_stream(hipStream_t* s, int want) {
+  if (want == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  int least = 0, greatest = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (e != hipSuccess) return e;
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, want < 0 ? least : greatest);
+}
+
 int ensure_side_streams(mpe_handle* h, bool need_scan) {
   if (h->side_streams_ok >= 0 && h->probed_for == h->stream && (!need_scan || h->probed_scan)) return MPE_OK;
   if (h->assume_side_streams) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (!h->tail_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
-    if (need_scan && !h->scan_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking));
+    if (!h->tail_stream) HIP_TRY(h, make_side_stream(&h->tail_stream, h->tail_priority));
+    if (need_scan && !h->scan_stream) HIP_TRY(h, make_side_stream(&h->scan_stream, h->scan_priority));
     h->side_streams_ok = 1;
     h->streams_concurrent = -1;  // (not probed)
     h->probed_for = h->stream;
@@ -651,8 +662,8 @@ int ensure_side_streams(mpe_handle* h, bool need_scan) {
     return MPE_OK;
   }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  if (!h->tail_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking));
-  if (need_scan && !h->scan_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->scan_stream, hipStreamNonBlocking));
+  if (!h->tail_stream) HIP_TRY(h, make_side_stream(&h->tail_stream, h->tail_priority));
+  if (need_scan && !h->scan_stream) HIP_TRY(h, make_side_stream(&h->scan_stream, h->scan_priority));
   HIP_TRY(h, hipStreamSynchronize(h->tail_stream));
   if (h->scan_stream) HIP_TRY(h, hipStreamSynchronize(h->scan_stream));
   double ms = 0;
@@ -677,7 +688,7 @@ int ensure_side_streams(mpe_handle* h, bool need_scan) {
     }
     if (attempt == 8) break;
     hipStream_t fresh = nullptr;
-    HIP_TRY(h, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+    HIP_TRY(h, make_side_stream(&fresh, tail_bad ? h->tail_priority : h->scan_priority));
     if (tail_bad) {
       rejected.push_back(h->tail_stream);
       h->tail_stream = fresh;
@@ -1446,6 +1457,21 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   }
   if (!std::strcmp(name, "force_rccl_gather")) {
     h->force_rccl_gather = value ? 1 : 0;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "tail_priority") || !std::strcmp(name, "scan_priority")) {  // experiments: side-stream priority
+    if (value < -1 || value > 1) return fail(h, MPE_ERR_ARG, "priority must be -1 (lowest), 0 (default) or 1 (highest)");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    const bool tail = name[0] == 't';
+    (tail ? h->tail_priority : h->scan_priority) = value;
+    hipStream_t& st = tail ? h->tail_stream : h->scan_stream;
+    if (st) {  // recreated with the new priority by the next pipelined call (which probes the set again)
+      (void)hipStreamDestroy(st);
+      st = nullptr;
+    }
+    h->side_streams_ok = -1;
+    h->tail_sub_pending = false;
     return MPE_OK;
   }
   if (!std::strcmp(name, "k1b_general_blocks")) {  // tuning, process-wide: waves of the general blob tier in flight
