@@ -366,11 +366,17 @@ def run_config(args, ctx, light=False):
     else:
         timed_rec = parallel.records_from_bytes(pipe.local(last_k))
     gathered_last = parallel.records_from_bytes(pipe.gathered(last_k)) if (world > 1 and rank == 0) else None
-    vote_in_region_ms, vote_in_region_n = None, 0
+    vote_in_region_ms, vote_in_region_n, vote_by_slot = None, 0, None
     if args.vote_events:
         vote_in_region_n = h.get_option("vote_launches")
         if vote_in_region_n > 0:
             vote_in_region_ms = h.get_option("vote_launch_ns_mean") * 1e-6
+            try:  # by position within a submission: the launch and the window in front of it (blobs + whatever waits)
+                nslot = max(1, vote_in_region_n // max(1, args.steps))
+                vote_by_slot = [{"launch_ms": h.get_option("vote_launch_ns_slot_%d" % i) * 1e-6,
+                                 "gap_before_ms": h.get_option("vote_gap_ns_slot_%d" % i) * 1e-6} for i in range(min(16, nslot))]
+            except Exception:
+                vote_by_slot = None
         h.set_option("vote_events", 0)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -506,6 +512,8 @@ def run_config(args, ctx, light=False):
                     "avg_launch_ms_source": ("HIP events around all %d launches of the timed region" % vote_in_region_n)
                                             if vote_in_region_ms else "HIP events in extra steps of the same mode",
                     "avg_launch_ms_in_separately_profiled_steps": vote_profiled_ms, "counters": counters}
+        if vote_by_slot:
+            roofline["timed_region_by_slot"] = vote_by_slot
         # a cluttered frame (many distractor spots) makes the same kernel FP64-issue bound: with a SQ_INSTS_VALU pass of
         # this shape under profiles/, report the roof the launch is closer to
         vp_ = pmc_all.get("k2_vote_valu", {}).get(pmc_key) if args.clutter else None

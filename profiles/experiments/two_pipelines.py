@@ -64,5 +64,5 @@ def run(n_pipes, opts=()):
             "streams_concurrent": conc}
 
 
-res = [run(1), run(2), run(1), run(2), run(2, (("scan_split_pct", 0),)), run(2, (("pipeline_mode", 3),)), run(3)]
+res = [run(1), run(2), run(1), run(2), run(2, (("scan_split_pct", 0),)), run(3)]
 print(json.dumps({"frames_total": B, "steps": STEPS, "runs": res}))

@@ -128,8 +128,19 @@ struct mpe_handle {
   // 32 768 frames) and, once the voting launch got shorter, did not even finish inside blob window + vote; one block
   // streams at ~1.5 TB/s beside the rider for the whole period (same-box sweeps: profiles/round4_sweep_side_scan.json)
   int side_scan_blocks = 1;
-  int tail_priority = 0;   // option "tail_priority" / "scan_priority": -1 lowest, 0 default, 1 highest stream priority
-  int scan_priority = 0;   //   of the side streams (applied when they are created; experiments)
+  // Stream priority of the two side streams (options "tail_priority" / "scan_priority": -1 lowest, 0 default level,
+  // 1 highest, 2 = the default level through the priority entry point; applied when the streams are created).  Round 5:
+  // NOT the default level.  The runtime multiplexes the streams of one priority level onto GPU_MAX_HW_QUEUES (4)
+  // hardware queues; a caller with a work stream, a consumer stream for the records and torch's own streams already
+  // fills them, and a side stream that shares a queue with the consumer's 113 MB D2H copy stalls behind it at every
+  // submission boundary (window in front of the first voting launch 0.8 - 1.2 ms instead of 0.55; step 18.45 ->
+  // 17.55 ms, profiles/round5_exp_side_priorities.json).  Streams of another level get queues of their own.  Which
+  // level makes no measurable difference to the step, only leaving the default one does; the tail takes the highest
+  // (its thin kernels then get their blocks dispatched in front of the voting launch's 32 768 pending ones and a
+  // sub-batch's tail finishes in 1.8 instead of 2.15 ms — the tail chain must never become longer than the period),
+  // the side scan — one resident block per CU, dispatched once — the lowest.
+  int tail_priority = 1;
+  int scan_priority = -1;
   int scan_split_pct = 28;
   unsigned long long last_rider_bytes = 0;  // bytes one fused voting launch scanned in the last large call
   hipStream_t tail_stream = nullptr;  // fused schedule, mode 4: validate + refine of sub-batch s beside blobs(s + 1)
@@ -644,8 +655,14 @@ hipError_t make_side_stream(hipStream_t* s, int want) {
   if (want == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
   int least = 0, greatest = 0;
   hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-  if (e != hipSuccess) return e;
-  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, want < 0 ? least : greatest);
+  if (e == hipSuccess)
+    // (2: the priority entry point at the default level — separates "which hardware queue" from "which priority")
+    e = hipStreamCreateWithPriority(s, hipStreamNonBlocking, want == 2 ? 0 : (want < 0 ? least : greatest));
+  if (e != hipSuccess) {  // a runtime without priority levels: an ordinary stream
+    (void)hipGetLastError();
+    e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  }
+  return e;
 }
 
 int ensure_side_streams(mpe_handle* h, bool need_scan) {
@@ -1338,6 +1355,43 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
     if (rc) return rc;
     *value = v > 0x7fffffffull ? 0x7fffffff : (int)v;
   }
+  else if (n.rfind("vote_launch_ns_slot_", 0) == 0 || n.rfind("vote_gap_ns_slot_", 0) == 0) {
+    // per position within a pipelined call (sub-batch slot): mean duration of the scan-carrying voting launch, and mean
+    // time from the end of the previous voting launch on the same stream (the previous call's last one for slot 0) to
+    // its start — the blob window in front of it
+    const bool gap = n[5] == 'g';
+    const int slot = std::atoi(n.c_str() + (gap ? 17 : 20));
+    if (slot < 0 || slot >= mpe_handle::kMaxSub) return fail(h, MPE_ERR_ARG, "slot out of range");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    double sum_ms = 0;
+    long long cnt = 0;
+    const long long calls = std::min<long long>(h->vote_ev_seq, h->vote_ev_calls);
+    for (long long c = 0; c < calls; ++c) {
+      mpe_handle::VotePair& p = h->vote_ev[(size_t)c * mpe_handle::kMaxSub + slot];
+      if (!p.used) continue;
+      float ms = 0;
+      if (!gap) {
+        HIP_TRY(h, hipEventElapsedTime(&ms, p.a, p.b));
+      } else {
+        // the launch in front: slot - 1 of the same call, or the last used slot of the call before (ring order)
+        mpe_handle::VotePair* q = nullptr;
+        if (slot > 0) {
+          q = &h->vote_ev[(size_t)c * mpe_handle::kMaxSub + slot - 1];
+        } else if (h->vote_ev_seq <= h->vote_ev_calls ? c > 0 : true) {
+          const long long pc = (c + h->vote_ev_calls - 1) % h->vote_ev_calls;
+          if (!(h->vote_ev_seq > h->vote_ev_calls && c == h->vote_ev_seq % h->vote_ev_calls))  // (the oldest call of the ring)
+            for (int k = mpe_handle::kMaxSub - 1; k >= 0 && !q; --k)
+              if (h->vote_ev[(size_t)pc * mpe_handle::kMaxSub + k].used) q = &h->vote_ev[(size_t)pc * mpe_handle::kMaxSub + k];
+        }
+        if (!q || !q->used) continue;
+        HIP_TRY(h, hipEventElapsedTime(&ms, q->b, p.a));
+      }
+      sum_ms += ms;
+      ++cnt;
+    }
+    *value = cnt ? (int)(sum_ms * 1e6 / (double)cnt + 0.5) : 0;
+  }
   else if (n == "vote_launch_ns_mean" || n == "vote_launches") {
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1460,7 +1514,7 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
     return MPE_OK;
   }
   if (!std::strcmp(name, "tail_priority") || !std::strcmp(name, "scan_priority")) {  // experiments: side-stream priority
-    if (value < -1 || value > 1) return fail(h, MPE_ERR_ARG, "priority must be -1 (lowest), 0 (default) or 1 (highest)");
+    if (value < -1 || value > 2) return fail(h, MPE_ERR_ARG, "priority must be -1 (lowest), 0 (default), 1 (highest) or 2 (default level through the priority entry point)");
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipDeviceSynchronize());
     const bool tail = name[0] == 't';

@@ -1586,9 +1586,12 @@ hipError_t launch_k2_fixup(mpe_detections* dets, int n_frames, const SolveParams
   hipLaunchKernelGGL(k2_vote_fixup, dim3(2048), dim3(K2_FIX_THREADS), 0, s, dets, sp, hist, fx);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  // frames that lost an entry to a full list: voted again with the strict loop nest (nothing lost: 256 blocks, one load each)
+  // frames that lost an entry to a full list: voted again with the strict loop nest.  A SMALL grid: the launch sits in
+  // the tail chain of every sub-batch, beside the next voting launch whose pending blocks it has to queue behind —
+  // 256 blocks that only read two words took 0.39 ms there (profiles/round5_bench_kernel_stats.csv of the first
+  // collection; 3 us serialised).  The lists are sized so that nothing is lost as a rule.
   const size_t lds_strict = (size_t)(sp.n_markers - 3) * 2 * K2_THREADS * sizeof(double);
-  hipLaunchKernelGGL(k2_vote_relost, dim3((unsigned)std::min(n_frames, 256)), dim3(K2_THREADS), lds_strict, s, dets,
+  hipLaunchKernelGGL(k2_vote_relost, dim3((unsigned)std::min(n_frames, 32)), dim3(K2_THREADS), lds_strict, s, dets,
                      n_frames, sp, hist, fx);
   return hipGetLastError();
 }
