@@ -46,6 +46,7 @@ timeout 60 python $R/profiles/summarize_pmc_clock.py $O/pmc_track $O/pmc_track_s
 find $O/pmc_track -name "*.csv" -delete
 # ---- rocprofv3 --stats: all kernels, and ONLY the dominant kernel traced (the tracer then stretches the schedule less)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python $R/bench.py $Q --steps 20 --warmup 5 > $O/stats.log 2>&1
+timeout 60 python $R/profiles/summarize_period.py $O/stats $O/period_summary.json > /dev/null
 timeout 300 rocprofv3 --kernel-trace --kernel-include-regex '.*k2_vote<true.*' --stats --output-format csv -d $O/stats_vote -o s -- python $R/bench.py $Q --steps 20 --warmup 5 > $O/stats_vote.log 2>&1
 timeout 60 python $R/profiles/summarize_vote_trace.py $O/stats_vote 8 $O/vote_trace_summary.json
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -o s -- python $R/bench.py $Q --steps 5 --config C3 --frames 16384 > $O/stats_c3.log 2>&1
@@ -63,7 +64,10 @@ timeout 200 python $R/bench.py $Q --steps 20 --warmup 5 2>/dev/null > $O/bench_h
 timeout 200 python $R/bench.py $Q --steps 20 --warmup 5 --vote-arith 2 2>/dev/null > $O/bench_arith2.json
 # ---- soaks (every mismatch saved, attributed, classified)
 cd $R
-timeout 600 python tests/soak_parity.py 131072 C2 65536 gpurun_out/final5/soak_parity_C2 > $O/soak_parity_C2.log 2>&1; echo "rc $?" >> $O/soak_parity_C2.log
-timeout 400 python tests/soak_votes.py 32768 C2 gpurun_out/final5/soak_votes_C2 > $O/soak_votes_C2.log 2>&1; echo "rc $?" >> $O/soak_votes_C2.log
-timeout 400 python tests/soak_tracking.py 64 160 C2 gpurun_out/final5/soak_tracking > $O/soak_tracking.log 2>&1; echo "rc $?" >> $O/soak_tracking.log
+timeout 900 python tests/soak_parity.py 524288 C2 65536 gpurun_out/final5/soak_parity_C2 > $O/soak_parity_C2.log 2>&1; echo "rc $?" >> $O/soak_parity_C2.log
+timeout 400 python tests/soak_votes.py 65536 C2 gpurun_out/final5/soak_votes_C2 > $O/soak_votes_C2.log 2>&1; echo "rc $?" >> $O/soak_votes_C2.log
+timeout 400 python tests/soak_parity.py 4096 C3 2048 gpurun_out/final5/soak_parity_C3 > $O/soak_parity_C3.log 2>&1; echo "rc $?" >> $O/soak_parity_C3.log
+timeout 400 python tests/soak_parity.py 8192 C4 4096 gpurun_out/final5/soak_parity_C4 > $O/soak_parity_C4.log 2>&1; echo "rc $?" >> $O/soak_parity_C4.log
+timeout 400 python tests/soak_parity.py 32768 C1 32768 gpurun_out/final5/soak_parity_C1 > $O/soak_parity_C1.log 2>&1; echo "rc $?" >> $O/soak_parity_C1.log
+timeout 400 python tests/soak_tracking.py 128 160 C2 gpurun_out/final5/soak_tracking > $O/soak_tracking.log 2>&1; echo "rc $?" >> $O/soak_tracking.log
 ls $O

@@ -106,6 +106,8 @@ def main():
                  ("pmc_track", "tracked_frame_sq")):
         if os.path.exists(F + a + "_summary.csv"):
             shutil.copy(F + a + "_summary.csv", P + "pmc_" + b + ".csv")
+    if os.path.exists(F + "period_summary.json"):
+        shutil.copy(F + "period_summary.json", P + "blob_window_timeline.json")
     if os.path.exists(F + "vote_trace_summary.json"):
         shutil.copy(F + "vote_trace_summary.json", P + "vote_launch_outliers.json")
     if os.path.exists(F + "pytest_gpu.log"):
@@ -172,7 +174,7 @@ def main():
                                                          F + "pmc%s_fetch_summary.csv" % cfg, F + "pmc%s_write_summary.csv" % cfg,
                                                          rf, "round5_pmc_%s_*.csv" % cfg, DIMS[cfg])}
     json.dump(out, open(P + "pmc.json", "w"), indent=1)
-    for n in ("soak_votes_C2", "soak_parity_C2", "soak_tracking"):
+    for n in ("soak_votes_C2", "soak_parity_C2", "soak_parity_C3", "soak_parity_C4", "soak_parity_C1", "soak_tracking"):
         if os.path.exists(F + n + ".log"):
             try:
                 json.dump(last_json(F + n + ".log"), open(P + "parity_%s.json" % n, "w"), indent=1)
