@@ -351,8 +351,11 @@ def test_streaming_false_hints_rewrites_and_changing_shapes():
         """seq of (frames, n, announced frames or None, announced n, reference)"""
         outs = []
         for fr, n, nxt, nn, ref in seq:
-            o = torch.zeros(n * item, dtype=torch.uint8, device=dev)
             with torch.cuda.stream(stream):
+                # (the zero fill belongs on the submission's stream: filled on torch's current stream it races with the
+                #  kernels that write the records — found when the library's side streams got queues of their own and
+                #  the fill, queued behind the busy upload stream's kernels below, landed AFTER the tail had written)
+                o = torch.zeros(n * item, dtype=torch.uint8, device=dev)
                 h.estimate_batch_device_submit(fr.data_ptr(), n, rows, cols, markers, K, D, P, o.data_ptr(),
                                                nxt.data_ptr() if nxt is not None else 0, nn)
                 h.estimate_batch_device_collect(consumer.cuda_stream)
@@ -385,9 +388,9 @@ def test_streaming_false_hints_rewrites_and_changing_shapes():
     # the announced buffer is rewritten between the two submissions: withdrawn, scanned again
     buf = fb.clone()
     torch.cuda.synchronize()
-    o1 = torch.zeros(B * item, dtype=torch.uint8, device=dev)
-    o2 = torch.zeros(B * item, dtype=torch.uint8, device=dev)
     with torch.cuda.stream(stream):
+        o1 = torch.zeros(B * item, dtype=torch.uint8, device=dev)
+        o2 = torch.zeros(B * item, dtype=torch.uint8, device=dev)
         h.estimate_batch_device_submit(fa.data_ptr(), B, rows, cols, markers, K, D, P, o1.data_ptr(), buf.data_ptr(), B)
         h.estimate_batch_device_collect(consumer.cuda_stream)
     consumer.synchronize()
