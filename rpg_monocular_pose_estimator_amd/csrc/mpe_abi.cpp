@@ -134,13 +134,13 @@ struct mpe_handle {
   // hardware queues; a caller with a work stream, a consumer stream for the records and torch's own streams already
   // fills them, and a side stream that shares a queue with the consumer's 113 MB D2H copy stalls behind it at every
   // submission boundary (window in front of the first voting launch 0.8 - 1.2 ms instead of 0.55; step 18.45 ->
-  // 17.55 ms, profiles/round5_exp_side_priorities.json).  Streams of another level get queues of their own.  Which
-  // level makes no measurable difference to the step, only leaving the default one does; the tail takes the highest
-  // (its thin kernels then get their blocks dispatched in front of the voting launch's 32 768 pending ones and a
-  // sub-batch's tail finishes in 1.8 instead of 2.15 ms — the tail chain must never become longer than the period),
-  // the side scan — one resident block per CU, dispatched once — the lowest.
+  // 17.55 ms, profiles/round5_exp_side_priorities.json).  Streams of another level get queues of their own.  Both side
+  // streams sit on the SAME non-default level: over three boxes (calls r5f, r5k, r5l, interleaved repetitions) the two
+  // same-level settings average 17.4 ms per step, the two mixed ones 17.8; highest rather than lowest because a
+  // sub-batch's tail then finishes in 1.7 instead of 2.1 ms (its thin kernels get their blocks dispatched in front of
+  // the voting launch's 32 768 pending ones) and the tail chain must never become longer than the period.
   int tail_priority = 1;
-  int scan_priority = -1;
+  int scan_priority = 1;
   int scan_split_pct = 28;
   unsigned long long last_rider_bytes = 0;  // bytes one fused voting launch scanned in the last large call
   hipStream_t tail_stream = nullptr;  // fused schedule, mode 4: validate + refine of sub-batch s beside blobs(s + 1)

@@ -1036,6 +1036,9 @@ __device__ __forceinline__ int isl_words(const Island& is, int cols, int r) {
 #ifndef K1B_SMALL_WAVES
 #define K1B_SMALL_WAVES 1
 #endif
+#ifndef K1B_SMALL_MIN_WAVES
+#define K1B_SMALL_MIN_WAVES 4  // (experiment builds: 5 caps the kernel at 96 VGPRs, so that two side-scan waves per SIMD fit beside four of its own)
+#endif
 #ifndef K1B_SMALL_PIX
 #define K1B_SMALL_PIX 4096
 #endif
@@ -1043,7 +1046,7 @@ __device__ __forceinline__ int isl_words(const Island& is, int cols, int r) {
 #define K1B_SMALL_BM 208
 #endif
 struct K1bSmall {
-  enum { PIX = K1B_SMALL_PIX, BM = K1B_SMALL_BM, SEG = 64, BAND = 8, ISL = 8, KEPT = 16, WAVES = K1B_SMALL_WAVES, MIN_WAVES = 4 };
+  enum { PIX = K1B_SMALL_PIX, BM = K1B_SMALL_BM, SEG = 64, BAND = 8, ISL = 8, KEPT = 16, WAVES = K1B_SMALL_WAVES, MIN_WAVES = K1B_SMALL_MIN_WAVES };
 };
 struct K1bLarge {
   enum { PIX = 12288, BM = 704, SEG = 512, BAND = 32, ISL = 32, KEPT = 64, WAVES = 1, MIN_WAVES = 2 };
@@ -1481,8 +1484,13 @@ __device__ __forceinline__ void k1b_wave(const int f, const bool valid, const ui
 }
 
 // wave w of block b works on frame b * C::WAVES + w
+#ifdef K1B_NUM_VGPR  // (experiment builds: a VGPR cap below what the LDS-limited occupancy would allow the kernel)
+#define K1B_VGPR_ATTR __attribute__((amdgpu_num_vgpr(K1B_NUM_VGPR)))
+#else
+#define K1B_VGPR_ATTR
+#endif
 template <class C>
-__global__ __launch_bounds__(64 * C::WAVES, C::MIN_WAVES) void k1b_blobs(const uint8_t* __restrict__ frames,
+__global__ __launch_bounds__(64 * C::WAVES, C::MIN_WAVES) K1B_VGPR_ATTR void k1b_blobs(const uint8_t* __restrict__ frames,
                                                            const u64* __restrict__ flags, FrameGeom g, DetectParams dp,
                                                            mpe_detections* __restrict__ dets,
                                                            int* __restrict__ worklist, int n_frames,
