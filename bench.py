@@ -665,7 +665,8 @@ def run_config(args, ctx, light=False):
                 # rank's batch is re-created here from its seeds.  A SCALE run checks itself.
                 ns = min(SAMPLE_PER_RANK, B)
                 shard = []
-                for r in range(world):
+                # (the salt / patch variants draw their clutter from one generator over the whole batch: not re-created)
+                for r in (range(world) if args.clutter not in ("salt", "patch") else ()):
                     sample = head_of_shard(synth, args.config, args.clutter, ns, dev, r).cpu().numpy()
                     got = gathered_last[r * B:r * B + ns]
                     blk, _, bad = parity_block(h, sample, got, markers, K, D, P, args.back_tol, cores, time_it=False)

@@ -1224,6 +1224,29 @@ def test_bench_secondary_legs_on_the_gpu_box():
 
 
 @pytest.mark.gpu
+def test_bench_head_of_shard_is_reproducible():
+    """What makes an N > 1 bench run self-checking: rank 0 re-creates the first frames of EVERY rank's shard from that
+    rank's seeds (bench.head_of_shard) and checks the records that arrived through the gather against the oracle on
+    them.  The re-creation must be bit-identical to what the rank itself rendered (bench.make_batch) — for any rank
+    index, batch size and clutter variant — or the check would compare records with the wrong frames."""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    dev = torch.device("cuda", 0)
+    for config, clutter, B, rank in (("C2", None, 1000, 0), ("C2", None, 300, 3), ("C1", None, 4096, 1),
+                                     ("C2", "d4", 512, 2), ("C4", None, 260, 5)):
+        _, frames = bench.make_batch(synth, config, clutter, B, dev, rank)
+        head = bench.head_of_shard(synth, config, clutter, bench.SAMPLE_PER_RANK, dev, rank)
+        assert head.shape[0] == bench.SAMPLE_PER_RANK
+        assert torch.equal(head, frames[:bench.SAMPLE_PER_RANK]), (config, clutter, B, rank)
+        other = bench.head_of_shard(synth, config, clutter, bench.SAMPLE_PER_RANK, dev, rank + 1)
+        assert not torch.equal(other, head)      # (another rank's shard is another set of frames)
+
+
+@pytest.mark.gpu
 def test_lockstep_tracker_batch_matches_oracle(orc):
     """BASELINE configs[4] as ONE submission per time step: N trackers on one handle driven in lock step
     (mpe_tracker_estimate_batch / mpe_tracker_run_sequences_batch: one image scan + blob extraction over the N ROI
