@@ -502,7 +502,8 @@ int mpe_set_option(mpe_handle* h, const char* name, int value);
  * Tuning / test knobs (round 5): "vote_list_cap" (entries per suspect list at most, 0 = no limit: a tiny list exercises
  *   the re-vote path), "k1b_general_blocks" (PROCESS-wide: blocks = scratch slabs of the general blob tier, 32 .. 8192,
  *   default 4096, within 1 GB of scratch), "tail_priority" / "scan_priority" (-1 / 0 / 1: stream priority of the
- *   library's two side streams, applied when they are created). */
+ *   library's two side streams, applied when they are created; default 1 / 1 — off the default level so that they get
+ *   hardware queues of their own, DESIGN.md section 3, Schedules). */
 /* Read an option back.  Also "streams_concurrent": 1 once the library has verified (spin-kernel probe at
  * the first large batch) that its two pipeline side streams execute concurrently, 0 if no concurrent
  * pair was found (the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues), -1 not probed yet;
