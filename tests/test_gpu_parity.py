@@ -142,6 +142,55 @@ def test_pathological_frames_take_the_general_path(hip, orc):
         assert np.array_equal(got["dist_xy"][i][:2 * len(und)].reshape(-1, 2), dist), i
 
 
+def test_general_tier_band_scan_on_random_clutter(hip, orc):
+    """Round 5: the general blob tier scans one lane per BAND of active rows (k1b_general).  Frames built to reach that
+    tier with every band shape: sparse salt noise (many short bands, several blobs per band), dense noise (one band
+    over the whole frame), horizontal stripes of noise separated by empty rows (bands that start / end at the image
+    border), a tall blob that spans bands' worth of rows next to small ones, blobs nested in a ring that itself touches
+    the noise, LEDs on top of everything.  Detections bit-equal to the oracle's on every frame, at two thresholds and
+    for an odd-sized ROI-like frame (pitch != cols)."""
+    rng = np.random.default_rng(77)
+    Po, Ph = orc.make_params(), mpe.demo_params()
+    for rows, cols in ((480, 752), (123, 211)):
+        K, D = synth.camera_for(rows, cols)
+        frames = []
+        leds = synth.make_frames("C2", 4, seed=88)["frames"] if (rows, cols) == (480, 752) else None
+        for dens in (0.0002, 0.0005, 0.002, 0.01):
+            f = (rng.random((rows, cols)) < dens).astype(np.uint8) * rng.integers(150, 256, (rows, cols)).astype(np.uint8)
+            frames.append(f)
+        f = np.zeros((rows, cols), np.uint8)                      # stripes of noise, empty rows between them
+        for y0 in range(0, rows, 17):
+            f[y0:y0 + 6] = (rng.random((min(6, rows - y0), cols)) < 0.004) * 255
+        frames.append(f)
+        f = (rng.random((rows, cols)) < 0.0008).astype(np.uint8) * 255
+        f[10:rows - 10, cols // 3:cols // 3 + 5] = 220            # a tall bar through nearly every band
+        f[rows // 2 - 3:rows // 2 + 3, 5:40] = 200
+        frames.append(f)
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        f = (rng.random((rows, cols)) < 0.0005).astype(np.uint8) * 255
+        ring = np.abs(np.hypot(xx - cols / 2, yy - rows / 2) - min(rows, cols) / 3) < 2.5
+        f[ring] = 240                                             # what lies inside the ring is not external
+        frames.append(f)
+        if leds is not None:
+            for i in range(2):
+                f = np.maximum(leds[i], (rng.random((rows, cols)) < 0.0005).astype(np.uint8) * 255)
+                frames.append(f)
+        frames = np.ascontiguousarray(np.stack(frames))
+        for thr in (140, 60):
+            Po.threshold_value = thr
+            Ph.threshold_value = thr
+            got = hip.detect_batch(frames, K, D, Ph)
+            for i in range(len(frames)):
+                und, dist = orc.find_leds(frames[i], Po, K, D)
+                if len(und) > mpe.MAX_DETECTIONS:
+                    assert got["status"][i] == -10 and got["n"][i] == mpe.MAX_DETECTIONS, (rows, thr, i)
+                    und, dist = und[:mpe.MAX_DETECTIONS], dist[:mpe.MAX_DETECTIONS]
+                else:
+                    assert got["status"][i] == 0 and got["n"][i] == len(und), (rows, thr, i, got["n"][i], len(und))
+                assert np.array_equal(got["dist_xy"][i][:2 * len(und)].reshape(-1, 2), dist), (rows, thr, i)
+                assert np.array_equal(got["undist_xy"][i][:2 * len(und)].reshape(-1, 2), und), (rows, thr, i)
+
+
 def test_too_many_detections_is_loud(hip, orc):
     """> MPE_MAX_DETECTIONS blobs pass the filter: status -10 on that frame, never silent."""
     K, D = synth.camera_for(480, 752)
