@@ -496,6 +496,59 @@ def test_ros_glue_frame_path_per_encoding():
     assert "framePathForEncoding(msg->encoding" in glue and "enc = 0" not in glue and "enc == MPE_ENC_MONO8" not in glue
 
 
+def test_kernel_sources_read_as_one_text():
+    """Round 5 split the kernel sources into three translation units; the CPU tier still cuts its host builds of the
+    device code out of ONE text (binding.device_source): the files in their documented order with the marked
+    prologues / epilogues dropped.  The text must hold every kernel exactly once, no include / namespace line of a file
+    boundary, and the regions the host tests cut must be contiguous (begin marker before end marker, nothing of
+    another file's head in between)."""
+    import re
+    import rpg_monocular_pose_estimator_amd as mpe
+    txt = mpe.device_source()
+    assert "//@file-" not in txt
+    assert txt.count('#include "mpe_kernels_common.h"') == 0 and txt.count("}  // namespace mpe") == 0
+    assert txt.count("namespace mpe {") == 1                      # (the common header opens it once)
+    for kernel in ("void k1a_scan(", "void k1b_blobs(", "void k1b_blobs_list(", "void k1b_general(", "void k2_prep_markers(",
+                   "void k2_vote(", "void k2_vote_strict(", "void k2_vote_relost(", "void k2_vote_fixup(",
+                   "void k3a_validate(", "void k3b_refine(", "void k3b_refine_group(", "void k_to_mono8("):
+        assert len(re.findall(r"__global__[^;{]*?" + re.escape(kernel), txt)) == 1, kernel
+    for begin, end in (("struct ThrTest {", "#ifndef K1A_UNROLL"), ("struct BlobRec {", "// final stage: kept blobs"),
+                       ("// lexicographic unranking of the idx-th 3-combination", "#define K2_THREADS"),
+                       ("#define K2_TRI_CHUNK 64", "__global__ void k2_prep_markers("),
+                       ("struct NoRider {", "// Voting kernel.  Work item ="),
+                       ("// One hypothesis in the STRICT arithmetic", "// Strict voting kernel (option"),
+                       ("struct T34 {", "#define K3_GROUP")):
+        i = txt.index(begin)
+        j = txt.index(end, i)
+        assert "#include" not in txt[i:j], (begin, end)
+    # every file of the list exists and is part of the fingerprint
+    csrc = os.path.join(ROOT, "rpg_monocular_pose_estimator_amd", "csrc")
+    for name in mpe.DEVICE_SOURCES:
+        assert os.path.exists(os.path.join(csrc, name)), name
+    assert len(mpe.source_fingerprint()) == 16
+
+
+def test_bench_line_helpers():
+    """bench.py's pure helpers: floats slimmed to 6 significant digits (NaN / inf -> null: the line must stay JSON),
+    numpy scalars unwrapped, the order-sensitive record digest."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    import rpg_monocular_pose_estimator_amd as mpe
+    o = bench.slim({"a": 1.23456789012, "b": [np.float64(2.5), np.int32(7), float("nan")], "c": {"d": float("inf")}, "e": "x"})
+    assert o == {"a": 1.23457, "b": [2.5, 7, None], "c": {"d": None}, "e": "x"}
+    json.dumps(o)
+    rec = np.zeros(8, mpe.RESULT_DTYPE)
+    rec["status"] = np.arange(8) % 2
+    rec["T"][:, 3] = np.linspace(0, 1, 8)
+    a = bench.records_checksum(rec)
+    assert a == bench.records_checksum(rec.copy()) and len(a) == 16
+    assert a != bench.records_checksum(rec[::-1])
+    rec2 = rec.copy()
+    rec2["T"][5, 7] += 1e-12
+    assert a != bench.records_checksum(rec2)
+
+
 def test_bench_streams_plumbing_two_ranks():
     """BASELINE configs[4] shards STREAMS, not frames: `bench_streams.py --gpus N` had no CPU coverage of its N > 1
     path.  --plumbing-only runs the launcher, the stream -> rank round robin, the barrier and the MAX (wall time) /
