@@ -233,6 +233,39 @@ def make_sequence(config, n, seed, dt=0.02, lin_speed=0.15, ang_speed=0.6, dropo
     return dict(frames=frames, T_true=np.array(Ts), times=np.arange(n) * dt, K=K, D=D, markers=M, rows=rows, cols=cols)
 
 
+CLUTTER_KINDS = ("salt", "salt_dense", "patch", "ring", "grid", "d4", "d16")
+
+
+def make_clutter_frames(kind, n, seed):
+    """C2 frames (5 LEDs) with what a real camera adds (numpy, deterministic; the clutter curve of bench.py draws the
+    same kinds on the device): `salt` 0.05 % isolated saturated pixels, `salt_dense` 0.3 %, `patch` one saturated
+    64x64 square, `ring` a bright ring around the image centre (RETR_EXTERNAL drops what it encloses), `grid` a dot
+    grid (every 7th row, 5th column), `d4` / `d16` distractor spots.  -> dict like make_frames."""
+    cfg = dict(CONFIGS["C2"])
+    if kind in ("d4", "d16"):
+        cfg["n_distractors"] = int(kind[1:])
+    d = make_frames(cfg, n, seed)
+    rows, cols = d["rows"], d["cols"]
+    for i in range(n):
+        rng = np.random.default_rng([seed, i, 11])
+        f = d["frames"][i]
+        if kind in ("salt", "salt_dense"):
+            f[rng.random((rows, cols)) < (0.0005 if kind == "salt" else 0.003)] = 255
+        elif kind == "patch":
+            y0, x0 = int(rng.integers(0, rows - 64)), int(rng.integers(0, cols - 64))
+            f[y0:y0 + 64, x0:x0 + 64] = 255
+        elif kind == "ring":
+            yy, xx = np.mgrid[0:rows, 0:cols]
+            rad = float(rng.uniform(120, 230))
+            f[np.abs(np.hypot(xx - cols / 2, yy - rows / 2) - rad) < 2.5] = 250
+        elif kind == "grid":
+            f[::7, ::5] = np.maximum(f[::7, ::5], 180)
+        elif kind not in ("d4", "d16"):
+            raise ValueError(kind)
+    d["kind"] = kind
+    return d
+
+
 def render_frames_torch(spots, rows, cols, spot_sigma, device, seed=0, peak=400.0, bg_max=30, out=None):
     """Render scenes on a torch device (bench plumbing): same image model as render_frame, noise
     from torch's generator.  spots: (n,S,2) numpy.  -> uint8 tensor (n,rows,cols)."""

@@ -11,7 +11,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def golden_cases():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(p).startswith(("seq_", "witness_seq_")))
+                  if not os.path.basename(p).startswith(("seq_", "witness_seq_", "witness_clutter")))
 
 
 def witness_sequences():
@@ -37,3 +37,23 @@ def load(name):
     sha = [hashlib.sha1(f.tobytes()).hexdigest() for f in d["frames"]]
     assert sha == [str(s) for s in g["sha1"]], "synthetic generator drifted from the golden scenes"
     return g, d
+
+
+def load_clutter():
+    """tests/golden/witness_clutter.npz (detections of cluttered C2 frames by the independent witness) ->
+    list of (kind, threshold, frame (rows, cols) uint8, K, D, n_det, dist_xy (n,2) f32, undist_xy (n,2) f64);
+    frames regenerated from (kind, seed) and checked against their SHA-1."""
+    import hashlib
+    from rpg_monocular_pose_estimator_amd import synth
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "witness_clutter.npz"))
+    cache, out = {}, []
+    for j in range(len(g["kind"])):
+        kind, seed, i, thr = str(g["kind"][j]), int(g["seed"][j]), int(g["frame"][j]), int(g["threshold"][j])
+        if (kind, seed) not in cache:
+            cache[(kind, seed)] = synth.make_clutter_frames(kind, 3, seed)
+        d = cache[(kind, seed)]
+        f = d["frames"][i]
+        assert hashlib.sha1(f.tobytes()).hexdigest() == str(g["sha1"][j]), "clutter frame generator drifted: %s %d" % (kind, i)
+        k = int(g["n_det"][j])
+        out.append((kind, thr, f, d["K"], d["D"], k, g["dist_xy"][j, :k], g["undist_xy"][j, :k]))
+    return out

@@ -3,7 +3,7 @@ tests/golden/make_golden.py): guards the oracle itself against regressions.  CPU
 import numpy as np
 import pytest
 
-from golden_util import golden_cases, golden_sequences, load, load_sequence, witness_sequences
+from golden_util import golden_cases, golden_sequences, load, load_clutter, load_sequence, witness_sequences
 from util import pose_diff
 
 
@@ -82,3 +82,18 @@ def test_witness_tracker_primitives_against_the_oracle(orc):
         if it % 11 == 0:
             px[0, 0] = np.nan
         assert tuple(W.determine_roi(px, 480, 752, 20, K, D)) == tuple(orc.determine_roi(px, 480, 752, 20, K, D)), it
+
+
+def test_oracle_against_the_witness_on_cluttered_frames(orc):
+    """findLeds on what a real camera adds — salt noise (sparse and dense), a saturated patch, a ring that encloses the
+    LEDs (RETR_EXTERNAL), a dot grid, distractor spots — at two thresholds: the oracle's detections (count, order,
+    float32 centroids, undistorted points) equal the INDEPENDENT witness's (tests/golden/witness_clutter.npz: scipy
+    connected components + Moore tracing, tests/witness_pipeline.py::find_leds).  The same vectors pin the HIP path's
+    general blob tier on the GPU (test_hip_against_the_witness_on_cluttered_frames)."""
+    cases = load_clutter()
+    assert len(cases) == 42 and {c[0] for c in cases} == {"salt", "salt_dense", "patch", "ring", "grid", "d4", "d16"}
+    for kind, thr, frame, K, D, k, dist, und in cases:
+        P = orc.make_params(threshold_value=thr)
+        u, ds = orc.find_leds(frame, P, K, D)
+        assert len(u) == k, (kind, thr, len(u), k)
+        assert np.array_equal(ds, dist) and np.array_equal(u, und), (kind, thr)
