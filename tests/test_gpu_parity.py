@@ -1317,6 +1317,53 @@ def test_bench_head_of_shard_is_reproducible():
 
 
 @pytest.mark.gpu
+def test_tracking_on_noisy_frames_matches_oracle(orc):
+    """The tracking path on cluttered frames: salt noise (three densities) over every frame of a stream, so that the ROI
+    detections overflow the small blob tier and are repeated through the whole chain — large LDS tier and the general
+    tier with PER-FRAME WINDOWS (each stream's ROI in its own slot, borders and centroid offsets following the window:
+    the one configuration of the rewritten general tier the batch tests do not reach) — in lock step and one stream at a
+    time.  Every frame must equal the oracle's state machine: updated flag, ROI, it_since_initialized, detection and
+    correspondence counts, brute-force flag, pose."""
+    n_streams, n = 4, 14
+    seqs = [synth.make_sequence("C2", n, seed=160 + s) for s in range(n_streams)]
+    for s, q in enumerate(seqs):
+        rng = np.random.default_rng(500 + s)
+        dens = (0.0005, 0.002, 0.0032, 0.001)[s]
+        for k in range(n):
+            m = rng.random(q["frames"][k].shape) < dens
+            q["frames"][k][m] = 255
+    h = mpe.Handle(0)
+    P = mpe.demo_params()
+    trackers = [mpe.Tracker(h, seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], P) for _ in range(n_streams)]
+    rec, info = mpe.tracker_run_sequences_batch(trackers, [q["frames"] for q in seqs], seqs[0]["times"])
+    solo = mpe.Tracker(h, seqs[0]["markers"], seqs[0]["K"], seqs[0]["D"], P)
+    n_roi = n_pose = 0
+    for s in range(n_streams):
+        to = orc.Tracker(seqs[s]["markers"], seqs[s]["K"], seqs[s]["D"], orc.make_params())
+        solo.reset()
+        for k in range(n):
+            ro = to.estimate(seqs[s]["frames"][k], seqs[s]["times"][k])
+            assert rec["status"][s, k] >= 0, (s, k, rec["status"][s, k])
+            assert (rec["status"][s, k] == 0) == ro["updated"], (s, k)
+            assert tuple(info[s, k, 0:4]) == ro["roi"] and info[s, k, 4] == ro["it_since_initialized"], (s, k)
+            assert info[s, k, 5] == ro["n_det"] and info[s, k, 6] == ro["n_corr"], (s, k, info[s, k], ro["n_det"], ro["n_corr"])
+            assert bool(info[s, k, 7]) == ro["used_bruteforce"], (s, k)
+            n_roi += int(info[s, k, 2] < seqs[s]["cols"])
+            if ro["updated"]:
+                n_pose += 1
+                dp, dr = pose_diff(rec["T"][s, k].reshape(4, 4), ro["T"])
+                assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (s, k, dp, dr)
+            r1 = solo.estimate(seqs[s]["frames"][k], seqs[s]["times"][k])
+            assert r1["updated"] == ro["updated"] and r1["n_det"] == ro["n_det"] and r1["roi"] == ro["roi"], (s, k)
+            if ro["updated"]:
+                assert np.array_equal(r1["T"], rec["T"][s, k].reshape(4, 4)), (s, k)
+    assert n_roi >= n_streams * (n - 6) // 2 and n_pose >= n_streams * n // 3, (n_roi, n_pose)
+    for t in trackers + [solo]:
+        t.close()
+    h.close()
+
+
+@pytest.mark.gpu
 def test_lockstep_tracker_batch_matches_oracle(orc):
     """BASELINE configs[4] as ONE submission per time step: N trackers on one handle driven in lock step
     (mpe_tracker_estimate_batch / mpe_tracker_run_sequences_batch: one image scan + blob extraction over the N ROI
