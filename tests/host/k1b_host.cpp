@@ -229,3 +229,74 @@ extern "C" int host_cells_vs_trace(const uint8_t* mask, int rows, int cols, cons
   if (!(kt == kc)) return -1;
   return (int)rt.size();
 }
+
+
+// The general tier's decomposition (k1b_general, round 5): the whole-frame raster scan against ONE scan per BAND — a
+// maximal run of rows that hold a set pixel — called exactly as the kernel calls it (the band's window starts at the
+// empty row above it: base pointers offset by lo * wb, H = its rows, ylo = lo, xw0 = 0).  Raw contour sums, bounding
+// boxes, start keys and the blobs that pass the shape filter must agree.  Returns the number of components (>= 0), -1
+// on a mismatch; *n_bands = bands found.
+extern "C" int host_bands_vs_whole(const uint8_t* mask, int rows, int cols, const double* shape, int* n_bands) {
+  DetectParams dp;
+  std::memset(&dp, 0, sizeof(dp));
+  dp.min_area = shape[0];
+  dp.max_area = shape[1];
+  dp.max_wh = shape[2];
+  dp.max_circ = shape[3];
+  const int wb = (cols + 2 + 63) / 64 + 1;  // (+ the pad word the pools end in)
+  std::vector<u64> nz((size_t)(rows + 2) * wb + 1, 0), pm(nz.size(), 0), ng(nz.size(), 0);
+  std::vector<int> active(rows, 0);
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x)
+      if (mask[(size_t)y * cols + x]) {
+        const int xb = x + 1;
+        nz[(size_t)(y + 1) * wb + (xb >> 6)] |= 1ull << (xb & 63);
+        active[y] = 1;
+      }
+  struct Kept {
+    float x, y;
+    unsigned key;
+    bool operator<(const Kept& o) const { return key < o.key; }
+    bool operator==(const Kept& o) const { return key == o.key && std::memcmp(&x, &o.x, 4) == 0 && std::memcmp(&y, &o.y, 4) == 0; }
+  };
+  std::vector<Kept> kw, kb;
+  std::vector<RawRec> rw, rb;
+  int over = 0;
+  g_raw = &rw;
+  scan_window(nz.data(), pm.data(), ng.data(), wb, rows, 0, 0, dp, 0, 0, &over,
+              [&](float mx, float my, unsigned key) { kw.push_back({mx, my, key}); });
+  std::fill(pm.begin(), pm.end(), 0);
+  std::fill(ng.begin(), ng.end(), 0);
+  g_raw = &rb;
+  *n_bands = 0;
+  for (int y = 0; y < rows;) {
+    if (!active[y]) {
+      ++y;
+      continue;
+    }
+    int hi = y;
+    while (hi + 1 < rows && active[hi + 1]) ++hi;
+    if (std::getenv("K1B_HOST_BREAK_BANDS")) hi = std::min(hi, y + 3);  // (the test's own check: a cut through a blob must be caught)
+    const size_t off = (size_t)y * wb;
+    scan_window(nz.data() + off, pm.data() + off, ng.data() + off, wb, hi - y + 1, y, 0, dp, 0, 0, &over,
+                [&](float mx, float my, unsigned key) { kb.push_back({mx, my, key}); });
+    ++*n_bands;
+    y = hi + 1;
+  }
+  g_raw = nullptr;
+  if (over) return -1;
+  auto norm = [](std::vector<RawRec>& v) {
+    std::sort(v.begin(), v.end(), [](const RawRec& a, const RawRec& b) { return a.key < b.key; });
+  };
+  norm(rw);
+  norm(rb);
+  if (rw.size() != rb.size()) return -1;
+  for (size_t i = 0; i < rw.size(); ++i)
+    if (rw[i].a00 != rb[i].a00 || rw[i].a10 != rb[i].a10 || rw[i].a01 != rb[i].a01 || rw[i].xmin != rb[i].xmin ||
+        rw[i].xmax != rb[i].xmax || rw[i].ymin != rb[i].ymin || rw[i].ymax != rb[i].ymax || rw[i].key != rb[i].key)
+      return -1;
+  std::sort(kw.begin(), kw.end());
+  std::sort(kb.begin(), kb.end());
+  if (!(kw == kb)) return -1;
+  return (int)rw.size();
+}

@@ -246,3 +246,68 @@ def test_cell_sums_equal_the_border_trace(host):
     assert run(big, [[0, 100, 0, 200]], shape_open) == 1
     assert n_comp > 5000 and n_isl > 2000
     assert 0 < n_fb < 0.6 * n_isl, (n_fb, n_isl)
+
+
+def test_band_scans_equal_the_whole_frame_scan(host):
+    """Round 5: the general blob tier (k1b_general) scans one lane per BAND — a maximal run of rows that hold a set
+    pixel — instead of one lane over the whole frame.  The decomposition must be exact for findContours(RETR_EXTERNAL):
+    same components, raw contour sums, bounding boxes, start keys, filtered blobs.  The device's scan_window (cut out
+    of the kernel source) is run over the whole bitmap and then once per band, called as the kernel calls it, on random
+    masks: specks of several densities (many short bands, several blobs per band), noise stripes, tall bars through
+    many bands' worth of rows, rings with blobs nested inside (not external) and outside, blobs touching the image
+    borders, dense noise (one band), widths on both sides of a 64-bit word boundary."""
+    from scipy import ndimage
+    host.host_bands_vs_whole.restype = C.c_int
+    rng = np.random.default_rng(515)
+    shape_real = np.array([10.0, 200.0, 0.5, 0.5])
+    shape_open = np.array([0.0, 1e9, 1.0, 1e9])
+    n_comp = n_bands = n_multi = 0
+    for it in range(1200):
+        kind = it % 6
+        rows = int(rng.integers(3, 70))
+        cols = int(rng.choice([rng.integers(3, 60), 61, 62, 63, 64, 65, rng.integers(66, 200)]))
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        if kind == 0:      # specks: many bands
+            m = rng.random((rows, cols)) < rng.choice([0.002, 0.01, 0.03])
+            m = ndimage.binary_dilation(m, iterations=int(rng.integers(0, 3))) if rng.random() < 0.7 else m
+        elif kind == 1:    # noise stripes separated by empty rows, first / last stripe at the border
+            m = np.zeros((rows, cols), bool)
+            y = 0
+            while y < rows:
+                h = int(rng.integers(1, 6))
+                m[y:y + h] = rng.random((min(h, rows - y), cols)) < 0.15
+                y += h + int(rng.integers(1, 4))
+        elif kind == 2:    # a tall bar through the specks
+            m = rng.random((rows, cols)) < 0.01
+            x0 = int(rng.integers(0, cols))
+            m[int(rng.integers(0, rows // 2 + 1)):rows - int(rng.integers(0, rows // 3 + 1)), x0:x0 + 2] = True
+        elif kind == 3:    # a ring with blobs inside and outside
+            m = rng.random((rows, cols)) < 0.02
+            rad = min(rows, cols) / 2.5
+            d = np.hypot(yy - rows / 2, xx - cols / 2)
+            m |= np.abs(d - rad) < 1.2
+        elif kind == 4:    # dense noise: one band, holes, diagonal contacts
+            m = rng.random((rows, cols)) < rng.uniform(0.2, 0.7)
+        else:              # discs, some cut by the borders
+            m = np.zeros((rows, cols), bool)
+            for _ in range(int(rng.integers(1, 7))):
+                cy, cx, rad = rng.uniform(-2, rows + 2), rng.uniform(-2, cols + 2), rng.uniform(0.8, 6.0)
+                m |= (yy - cy) ** 2 + (xx - cx) ** 2 <= rad ** 2
+        mask = np.ascontiguousarray(m, np.uint8)
+        shape = shape_real if it % 2 else shape_open
+        nb = C.c_int(0)
+        r = host.host_bands_vs_whole(mask.ctypes.data_as(C.c_void_p), rows, cols, shape.ctypes.data_as(C.c_void_p), C.byref(nb))
+        assert r >= 0, (it, kind, rows, cols)
+        n_comp += r
+        n_bands += nb.value
+        n_multi += int(nb.value > 1)
+    assert n_comp > 8000 and n_bands > 3000 and n_multi > 500, (n_comp, n_bands, n_multi)
+    # the comparison has teeth: bands cut after four rows (through blobs) must be caught
+    os.environ["K1B_HOST_BREAK_BANDS"] = "1"
+    try:
+        m = np.zeros((20, 30), np.uint8)
+        m[3:15, 5:12] = 1
+        nb = C.c_int(0)
+        assert host.host_bands_vs_whole(m.ctypes.data_as(C.c_void_p), 20, 30, shape_open.ctypes.data_as(C.c_void_p), C.byref(nb)) == -1
+    finally:
+        del os.environ["K1B_HOST_BREAK_BANDS"]
