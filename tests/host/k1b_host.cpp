@@ -276,8 +276,8 @@ extern "C" int host_bands_vs_whole(const uint8_t* mask, int rows, int cols, cons
     }
     int hi = y;
     while (hi + 1 < rows && active[hi + 1]) ++hi;
-    if (std::getenv("K1B_HOST_BREAK_BANDS")) hi = std::min(hi, y + 3);  // (the test's own check: a cut through a blob must be caught)
-    const size_t off = (size_t)y * wb;
+    // (the test's own check: a band window that starts one row late — the wrong base pointer — must be caught)
+    const size_t off = (size_t)(y + (std::getenv("K1B_HOST_BREAK_BANDS") ? 1 : 0)) * wb;
     scan_window(nz.data() + off, pm.data() + off, ng.data() + off, wb, hi - y + 1, y, 0, dp, 0, 0, &over,
                 [&](float mx, float my, unsigned key) { kb.push_back({mx, my, key}); });
     ++*n_bands;

@@ -302,7 +302,7 @@ def test_band_scans_equal_the_whole_frame_scan(host):
         n_bands += nb.value
         n_multi += int(nb.value > 1)
     assert n_comp > 8000 and n_bands > 3000 and n_multi > 500, (n_comp, n_bands, n_multi)
-    # the comparison has teeth: bands cut after four rows (through blobs) must be caught
+    # the comparison has teeth: a band window that starts one row late must be caught
     os.environ["K1B_HOST_BREAK_BANDS"] = "1"
     try:
         m = np.zeros((20, 30), np.uint8)
