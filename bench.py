@@ -552,6 +552,26 @@ def run_config(args, ctx, light=False):
                     "avg_launch_ms": kavg["scan"], "launches_per_step": launches, "frames_per_launch": fpl,
                     "counters": counters}
 
+    # a leg whose blob tiers take longer than its voting launch (salt noise, a saturated patch): the dominant kernels are
+    # the follow-up blob tiers — latency bound (one wave per frame; in the general tier one LANE per band) — and the
+    # voting kernel's figures move to `roofline.voting_kernel`
+    if args.clutter and kavg.get("blobs", 0.0) > kavg.get("vote", 0.0):
+        gen = pmc_all.get("k1b_general_salt") if args.clutter == "salt" else None
+        blob_s = kavg["blobs"] * 1e-3
+        dom = {"kernel": "k1b blob tiers (k1b_blobs -> k1b_blobs_list -> k1b_general)", "bound": "latency",
+               "unit": "G wave-instructions/s", "avg_launch_ms": kavg["blobs"], "launches_per_step": launches,
+               "frames_per_launch": fpl, "traffic": None, "counters": counters, "voting_kernel": roofline}
+        if gen:  # VALU issue of the general tier as the fraction (SQ_INSTS_VALU pass of this leg under profiles/)
+            clk_ = float(gen.get("effective_clock_GHz") or 2.4)
+            insts = gen["valu_insts_per_frame"] * min(fpl, B)
+            dom.update({"achieved": insts / blob_s / 1e9, "peak": 1024 * clk_ / 4.0,
+                        "frac": insts * 4.0 / (1024 * clk_ * 1e9 * blob_s), "effective_clock_GHz": clk_,
+                        "note": "VALU issue of k1b_general: the tier is bound by the latency of one lane walking a band"})
+        else:
+            dom.update({"achieved": None, "peak": None, "frac": None,
+                        "note": "no counter pass of this leg's blob tiers under profiles/"})
+        roofline = dom
+
     # ---- PCIe-inclusive leg (SURVEY 8d "report both"): the same frames streamed from PINNED HOST memory through
     #      mpe_estimate_batch every call (double-buffered chunked ingest: the copy of chunk c + 1 beside the kernels of
     #      chunk c).  Never reported as `value`.
@@ -706,8 +726,10 @@ def compact(out):
     r = out["roofline"]
     c = {"frames_per_step": out["config"]["frames_per_gpu_per_step"], "value": out["value"],
          "ms_per_step": out["ms_per_step"], "poses_found_frac": out["poses_found_frac"],
-         "roofline": {k: r.get(k) for k in ("kernel", "bound", "frac", "achieved", "peak", "unit", "traffic",
-                                            "avg_launch_ms", "note") if r.get(k) is not None},
+         "roofline": dict({k: r.get(k) for k in ("kernel", "bound", "frac", "achieved", "peak", "unit", "traffic",
+                                                 "avg_launch_ms", "note") if r.get(k) is not None},
+                          **({"voting_kernel": {k: r["voting_kernel"].get(k) for k in ("kernel", "bound", "frac", "avg_launch_ms")}}
+                             if "voting_kernel" in r else {})),
          "kernel_ms": {k: out["kernel_ms"][k] for k in ("scan", "blobs", "vote", "tail") if k in out["kernel_ms"]},
          "blob_tier_overflow": {k: out["blob_tier_overflow"][k] for k in ("frames", "general")}}
     if out["vote_arith"]["frames_voted_again"]:
