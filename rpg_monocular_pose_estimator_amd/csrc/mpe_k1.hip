@@ -191,6 +191,9 @@ struct PixWin {
   int ylo, H, pwc0, PW;  // PW = bytes per window row
   unsigned add;          // 0: `pix` holds thresholded pixels (the LDS windows); else: raw frame bytes, THRESH_TOZERO
                          // applied on the fly with tozero4's constant (255 - thr) * 0x10001 (the general kernel)
+  const u64* flags;      // raw mode: the image pass's flag bitmap (bit = a 16-byte segment holds a pixel above the
+  size_t fbit0;          //   threshold) and the bit index of this window's first segment: a segment whose bit is clear
+                         //   thresholds to sixteen zeros and is neither loaded nor thresholded
 };
 
 // fixed-point Gaussian for the 16 outputs x0..x0+15 of image row y, reading the LDS window.
@@ -219,9 +222,17 @@ __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, in
     const int sc = c - 1 - w.pwc0, nsw = w.PW >> 4;  // window segment index of column c-1
     const uint4* p = reinterpret_cast<const uint4*>(w.pix + (size_t)yb * w.PW);
     const uint4 z4 = make_uint4(0, 0, 0, 0);
-    const uint4 q0 = ((unsigned)sc < (unsigned)nsw) ? p[sc] : z4;
-    const uint4 q1 = ((unsigned)(sc + 1) < (unsigned)nsw) ? p[sc + 1] : z4;
-    const uint4 q2 = ((unsigned)(sc + 2) < (unsigned)nsw) ? p[sc + 2] : z4;
+    bool in0 = (unsigned)sc < (unsigned)nsw, in1 = (unsigned)(sc + 1) < (unsigned)nsw, in2 = (unsigned)(sc + 2) < (unsigned)nsw;
+    if (RAW) {  // only segments the image pass flagged can hold anything after the threshold
+      const size_t g0 = w.fbit0 + (size_t)yb * (size_t)nsw + (size_t)(sc + 1);  // (segment sc + 1: never negative)
+      in0 = in0 && ((w.flags[(g0 - 1) >> 6] >> ((g0 - 1) & 63)) & 1ull);
+      in1 = in1 && ((w.flags[g0 >> 6] >> (g0 & 63)) & 1ull);
+      in2 = in2 && ((w.flags[(g0 + 1) >> 6] >> ((g0 + 1) & 63)) & 1ull);
+      if (!(in0 || in1 || in2)) continue;  // this row adds nothing to the sums (most rows of most items)
+    }
+    const uint4 q0 = in0 ? p[sc] : z4;
+    const uint4 q1 = in1 ? p[sc + 1] : z4;
+    const uint4 q2 = in2 ? p[sc + 2] : z4;
     unsigned q[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
     if (RAW) {
 #pragma unroll
@@ -947,6 +958,20 @@ __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int c
   }
 }
 
+// Does bitmap row `cur` touch row `prev` (some set pixel of one 8-adjacent to a set pixel of the other)?  Rows of W
+// 64-bit words, bit = pixel; the 3-neighbourhood of `prev` crosses word boundaries.
+__device__ __forceinline__ bool k1b_rows_touch(const u64* cur, const u64* prev, int W) {
+  u64 hit = 0;
+  for (int w = 0; w < W; ++w) {
+    const u64 p = prev[w];
+    u64 dil = p | (p << 1) | (p >> 1);
+    if (w > 0) dil |= prev[w - 1] >> 63;
+    if (w + 1 < W) dil |= prev[w + 1] << 63;
+    hit |= cur[w] & dil;
+  }
+  return hit != 0;
+}
+
 // final stage: kept blobs -> OpenCV's contour order (newest first = descending raster order of
 // the start pixel), float32 centroid -> undistortPoints, write the detection record
 __device__ __forceinline__ void write_detections(const float* kx, const float* ky, const unsigned* kkey, int nk_all,
@@ -1359,7 +1384,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
       const int yb = li / ncols, c = is.clo + (li - yb * ncols);
       const int H = is.yhi - is.ylo + 1;
       const int W = isl_words(is, g.cols, r);
-      const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1), 0u};
+      const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1), 0u, nullptr, 0};
       blur_to_bitmap(pw, g.rows, g.cols, dp, s_taps, is.ylo + yb, c, s_nz + is.bm_off + (size_t)(yb + 1) * W,
                      isl_xw0(is, r));
     }
@@ -1519,27 +1544,32 @@ __global__ __launch_bounds__(64 * C::WAVES, C::MIN_WAVES) void k1b_blobs_list(co
 // any frame.  Round 5 (on cluttered frames this tier was a cliff — 43 us of ONE LANE per
 // frame on 32 waves of the whole chip, 11.6 k frames/s with 0.05 % salt noise):
 //   * no thresholded copy of the frame: the blur reads the frame's own rows and applies THRESH_TOZERO on the fly
-//     (PixWin::add), only around bright segments;
-//   * the contour scan runs one LANE PER BAND — a maximal run of rows with a non-zero blurred pixel.  A component of
-//     the blurred mask cannot cross an empty row, and a band cannot lie inside a hole of a component of another band,
-//     so cvFindContours' raster scan decomposes exactly, as it does for the islands of the fast tiers; the kept blobs
-//     are put back into raster order of their start pixels at the end (write_detections);
+//     (PixWin::add) — and of the 3 x 5 segments under an item only those the image pass FLAGGED (all others threshold
+//     to zeros: neither loaded nor thresholded, rows without one skipped); the (row, segment) items run as a flat
+//     list, 64 at a time whatever their rows;
+//   * the contour scan runs one LANE PER BAND — a maximal run of non-empty rows in which every row TOUCHES the one
+//     above it (a set pixel 8-adjacent to a set pixel of the previous row).  A component of the blurred mask cannot
+//     cross a boundary between two rows that do not touch, and a component below such a boundary cannot lie inside a
+//     hole of one above it, so cvFindContours' raster scan decomposes exactly there, as it does at an empty row and for
+//     the islands of the fast tiers; the kept blobs are put back into raster order of their start pixels at the end
+//     (write_detections).  Empty rows alone cut nothing out of uniformly spread noise (0.05 % salt: every row is
+//     within a blur radius of some pixel); non-touching row pairs cut such a frame into ~100 bands;
 //   * up to 4096 slabs (1 GB of scratch at most) instead of 32: the kernel is bound by the latency of its bitmaps in
 //     global memory, its rate follows the waves in flight (salt-noise leg, 32 768 frames: 1024 slabs 67.5 ms, 2048 45.5,
 //     4096 42.5, 8192 37.2; the clean headline step, whose every sub-batch launches this tier empty, does not notice:
 //     profiles/round5_exp_general_blocks.json).
-// What is left: uniformly spread noise has neither empty rows nor empty columns, so such a frame is one band and one
-// lane walks it (~6 000 dependent bitmap reads, ~2.5 ms per frame and wave); a cut into independent regions would
-// have to come from a connected-component pass, which this tier does not have.
+// What is left: a band is still walked by ONE lane (its rows word by word, dependent bitmap reads from global memory),
+// and a frame whose rows all touch — one big blob, a grid of lines — is one band.
 // =============================================================================================
 #define K1B_GEN_KEPT 512
-#define K1B_GEN_BANDS 2048  // rows <= 4096 (make_geom): at most every other row starts a band
+#define K1B_GEN_BANDS 2048  // (8 KB of LDS; a frame with more bands — only possible above 2 048 rows — is scanned whole by one lane)
 
 __host__ __device__ inline size_t k1b_gen_scratch_bytes(const FrameGeom& g) {
   const size_t bm = (size_t)(g.rows + 2) * g.wb * 8;
   const size_t todo = (size_t)g.rows * g.tw * 8;
   const size_t kept = (size_t)K1B_GEN_KEPT * 12;
-  return ((3 * bm + todo + kept + 255) / 256) * 256;
+  const size_t items = (size_t)g.rows * g.segs_per_row * 4;  // (row << 12 | segment column) of every to-do bit
+  return ((3 * bm + todo + kept + items + 255) / 256) * 256;
 }
 // slabs = blocks of the launch: as many as 1 GB of scratch holds, 32 .. g_k1b_gen_blocks_cap (a process-wide tuning
 // knob, option "k1b_general_blocks"; the kernel is bound by the latency of its global-memory bitmaps, so its rate
@@ -1560,7 +1590,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
   const FrameGeom& g = gslot;  // slab layout and flag indexing: the slot; rows / cols of a frame: its window (gl below)
   __shared__ int s_nkept, s_over, s_nband;
   __shared__ int s_taps[MPE_MAX_KSIZE];
-  __shared__ u64 s_rowact[64];
+  __shared__ u64 s_rowact[64], s_link[64];
   __shared__ short s_blo[K1B_GEN_BANDS], s_bhi[K1B_GEN_BANDS];
   const int lane = threadIdx.x;
   const int count = worklist[0];
@@ -1577,6 +1607,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
   float* kx = reinterpret_cast<float*>(todo + (size_t)g.rows * g.tw);
   float* ky = kx + K1B_GEN_KEPT;
   unsigned* kkey = reinterpret_cast<unsigned*>(ky + K1B_GEN_KEPT);
+  unsigned* items = kkey + K1B_GEN_KEPT;
   const int r = dp.ksize / 2;
   const int dc = (r + 15) / 16;
   const int spr = g.segs_per_row;
@@ -1593,6 +1624,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
       s_nband = 0;
     }
     s_rowact[lane] = 0;
+    s_link[lane] = 0;
     for (size_t i = lane; i < bm_words; i += 64) {
       nz[i] = 0;
       pm[i] = 0;
@@ -1624,21 +1656,43 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     }
     __threadfence_block();
     __syncthreads();
-    // blur (lane = row): the frame's own bytes, thresholded on the fly; rows that got a non-zero pixel become active
-    const PixWin pw = {frame, 0, gl.rows, 0, g.pitch, add};
-    for (int y = lane; y < gl.rows; y += 64) {
-      u64* nzrow = nz + (size_t)(y + 1) * g.wb;
-      for (int tw = 0; tw < g.tw; ++tw) {
-        u64 tb = todo[(size_t)y * g.tw + tw];
-        while (tb) {
-          const int c = tw * 64 + __builtin_ctzll(tb);
-          tb &= tb - 1;
-          if (add)
-            blur_to_bitmap<true>(pw, gl.rows, gl.cols, dp, s_taps, y, c, nzrow, 0);
-          else  // (thr = 255: nothing passes the threshold — the flags say so already, no item arrives here)
-            blur_to_bitmap<false>(pw, gl.rows, gl.cols, dp, s_taps, y, c, nzrow, 0);
-        }
+    // the to-do bits as a LIST of (row, segment column) items, so that the blur below runs them 64 at a time whatever
+    // their rows (one lane per row ran as many rounds as the busiest row of every 64 has items)
+    int n_items = 0;  // (uniform)
+    for (int y0 = 0; y0 < gl.rows; y0 += 64) {
+      const int y = y0 + lane;
+      int cnt = 0;
+      if (y < gl.rows)
+        for (int tw = 0; tw < g.tw; ++tw) cnt += __builtin_popcountll(todo[(size_t)y * g.tw + tw]);
+      int inc = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int a = __shfl_up(inc, d);
+        if (lane >= d) inc += a;
       }
+      int o = n_items + inc - cnt;
+      if (y < gl.rows)
+        for (int tw = 0; tw < g.tw; ++tw) {
+          u64 tb = todo[(size_t)y * g.tw + tw];
+          while (tb) {
+            items[o++] = ((unsigned)y << 12) | (unsigned)(tw * 64 + __builtin_ctzll(tb));
+            tb &= tb - 1;
+          }
+        }
+      n_items += __shfl(inc, 63);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // blur: the frame's own bytes — only the segments the image pass flagged — thresholded on the fly
+    const PixWin pw = {frame, 0, gl.rows, 0, g.pitch, add, flags, (size_t)f * g.segs_per_frame};
+    for (int i = lane; i < n_items; i += 64) {
+      const unsigned it = items[i];
+      const int y = (int)(it >> 12), c = (int)(it & 0xFFFu);
+      u64* nzrow = nz + (size_t)(y + 1) * g.wb;
+      if (add)
+        blur_to_bitmap<true>(pw, gl.rows, gl.cols, dp, s_taps, y, c, nzrow, 0);
+      else  // (thr = 255: nothing passes the threshold — the flags say so already, no item arrives here)
+        blur_to_bitmap<false>(pw, gl.rows, gl.cols, dp, s_taps, y, c, nzrow, 0);
     }
     __threadfence_block();
     __syncthreads();
@@ -1646,17 +1700,23 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
       const u64* nzrow = nz + (size_t)(y + 1) * g.wb;
       u64 any = 0;
       for (int w = 0; w < g.wb; ++w) any |= nzrow[w];
-      if (any) atomicOr(&s_rowact[y >> 6], 1ull << (y & 63));
+      if (any) {
+        atomicOr(&s_rowact[y >> 6], 1ull << (y & 63));
+        // (slot y of the bitmaps is row y - 1; slot 0 is the empty separator above row 0)
+        if (k1b_rows_touch(nzrow, nzrow - g.wb, g.wb)) atomicOr(&s_link[y >> 6], 1ull << (y & 63));
+      }
     }
     __syncthreads();
-    // bands = maximal runs of active rows (lane w owns word w of the row bitset; ranks by a wave prefix sum)
+    // bands = maximal runs of non-empty rows in which every row TOUCHES the one above it (k1b_rows_touch): a band
+    // starts at a non-empty row that is not linked to its predecessor, and ends in front of the next such row or empty
+    // row (lane w owns word w of the row bitsets; ranks by a wave prefix sum)
     {
       const int rw = (gl.rows + 63) >> 6;
       const u64 act = (lane < rw) ? s_rowact[lane] : 0;
-      const u64 prevw = (lane > 0 && lane < rw) ? s_rowact[lane - 1] : 0;
-      const u64 nextw = (lane + 1 < rw) ? s_rowact[lane + 1] : 0;
-      u64 st = act & ~((act << 1) | (prevw >> 63));
-      u64 en = act & ~((act >> 1) | (nextw << 63));
+      const u64 lnk = (lane < rw) ? s_link[lane] : 0;
+      const u64 nextl = (lane + 1 < rw) ? s_link[lane + 1] : 0;
+      u64 st = act & ~lnk;                              // (a linked row's predecessor is non-empty)
+      u64 en = act & ~((lnk >> 1) | (nextl << 63));     // the row below does not continue the band
       const int cs = __builtin_popcountll(st), ce = __builtin_popcountll(en);
       int ps = cs, pe = ce;
 #pragma unroll
@@ -1694,14 +1754,15 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     };
     if (nband <= K1B_GEN_BANDS) {
       // one lane per band, the lanes' border followings in lock step (scan_window): slot 0 of a band's window is the
-      // empty row above it, slots 1 .. H its rows, the separator below the empty row that ends it
+      // row above it — empty, or holding no neighbour of any pixel of the band — slots 1 .. H its rows, and the row
+      // below likewise: no border following leaves the band
       for (int b0 = 0; b0 < nband; b0 += 64) {  // (uniform: every lane enters scan_window, with H = 0 if it has no band)
         const int b = b0 + lane;
         const int lo = b < nband ? s_blo[b] : 0, H = b < nband ? s_bhi[b] - lo + 1 : 0;
         const size_t off = (size_t)lo * g.wb;
         scan_window(nz + off, pm + off, ng + off, g.wb, H, lo, 0, dp, roi_x, roi_y, &s_over, keep);
       }
-    } else {  // (cannot happen for rows <= 4096; the literal whole-frame scan by one lane)
+    } else {  // (more bands than the list holds: the literal whole-frame scan by one lane)
       scan_window(nz, pm, ng, g.wb, lane == 0 ? gl.rows : 0, 0, 0, dp, roi_x, roi_y, &s_over, keep);
     }
     __threadfence_block();

@@ -95,7 +95,7 @@ extern "C" int host_find_leds(const uint8_t* img, int rows, int cols, int thr, c
   }
   const int wb = (cols + 2 + 63) / 64;
   std::vector<u64> nz((size_t)(rows + 2) * wb + 1, 0), pm(nz.size(), 0), ng(nz.size(), 0);
-  const PixWin pw = {pix.data(), 0, rows, 0, PW};
+  const PixWin pw = {pix.data(), 0, rows, 0, PW, 0u, nullptr, 0};
   for (int y = 0; y < rows; ++y)
     for (int c = 0; c < nseg; ++c) blur_to_bitmap(pw, rows, cols, dp, dp.taps, y, c, nz.data() + (size_t)(y + 1) * wb, 0);
   struct Kept {
@@ -231,11 +231,15 @@ extern "C" int host_cells_vs_trace(const uint8_t* mask, int rows, int cols, cons
 }
 
 
-// The general tier's decomposition (k1b_general, round 5): the whole-frame raster scan against ONE scan per BAND — a
-// maximal run of rows that hold a set pixel — called exactly as the kernel calls it (the band's window starts at the
-// empty row above it: base pointers offset by lo * wb, H = its rows, ylo = lo, xw0 = 0).  Raw contour sums, bounding
-// boxes, start keys and the blobs that pass the shape filter must agree.  Returns the number of components (>= 0), -1
-// on a mismatch; *n_bands = bands found.
+// The general tier's decomposition (k1b_general, round 5): the whole-frame raster scan against ONE scan per BAND,
+// called exactly as the kernel calls it (base pointers offset by lo * wb, H = its rows, ylo = lo, xw0 = 0).  A band is a
+// maximal run of non-empty rows in which every row TOUCHES the one above it (some set pixel 8-adjacent to a set pixel
+// of the previous row): no component crosses a boundary between two rows that do not touch, and a component below
+// such a boundary cannot lie in a hole of one above it, so the raster scan decomposes there as it does at an empty
+// row — which is what cuts uniformly spread noise (no empty rows at all) into a hundred bands.  The row above a band's
+// first row may hold pixels now, but none of them is a neighbour of a pixel of the band, so no border following
+// leaves the band.  Raw contour sums, bounding boxes, start keys and the blobs that pass the shape filter must agree.
+// Returns the number of components (>= 0), -1 on a mismatch; *n_bands = bands found.
 extern "C" int host_bands_vs_whole(const uint8_t* mask, int rows, int cols, const double* shape, int* n_bands) {
   DetectParams dp;
   std::memset(&dp, 0, sizeof(dp));
@@ -245,7 +249,7 @@ extern "C" int host_bands_vs_whole(const uint8_t* mask, int rows, int cols, cons
   dp.max_circ = shape[3];
   const int wb = (cols + 2 + 63) / 64 + 1;  // (+ the pad word the pools end in)
   std::vector<u64> nz((size_t)(rows + 2) * wb + 1, 0), pm(nz.size(), 0), ng(nz.size(), 0);
-  std::vector<int> active(rows, 0);
+  std::vector<int> active(rows, 0), linked(rows, 0);
   for (int y = 0; y < rows; ++y)
     for (int x = 0; x < cols; ++x)
       if (mask[(size_t)y * cols + x]) {
@@ -253,6 +257,9 @@ extern "C" int host_bands_vs_whole(const uint8_t* mask, int rows, int cols, cons
         nz[(size_t)(y + 1) * wb + (xb >> 6)] |= 1ull << (xb & 63);
         active[y] = 1;
       }
+  // linked[y]: row y touches row y - 1 — the device's word arithmetic (k1b_rows_touch) on the bitmap rows
+  for (int y = 1; y < rows; ++y)
+    linked[y] = k1b_rows_touch(nz.data() + (size_t)(y + 1) * wb, nz.data() + (size_t)y * wb, wb) ? 1 : 0;
   struct Kept {
     float x, y;
     unsigned key;
@@ -275,7 +282,7 @@ extern "C" int host_bands_vs_whole(const uint8_t* mask, int rows, int cols, cons
       continue;
     }
     int hi = y;
-    while (hi + 1 < rows && active[hi + 1]) ++hi;
+    while (hi + 1 < rows && active[hi + 1] && linked[hi + 1]) ++hi;
     // (the test's own check: a band window that starts one row late — the wrong base pointer — must be caught)
     const size_t off = (size_t)(y + (std::getenv("K1B_HOST_BREAK_BANDS") ? 1 : 0)) * wb;
     scan_window(nz.data() + off, pm.data() + off, ng.data() + off, wb, hi - y + 1, y, 0, dp, 0, 0, &over,
@@ -299,4 +306,57 @@ extern "C" int host_bands_vs_whole(const uint8_t* mask, int rows, int cols, cons
   std::sort(kb.begin(), kb.end());
   if (!(kw == kb)) return -1;
   return (int)rw.size();
+}
+
+
+// The general tier's blur on the RAW frame (PixWin::add + the image pass's flag bits: only flagged segments are loaded
+// and thresholded, rows without one are skipped) against the blur on a thresholded copy of the frame (what the LDS
+// tiers stage): the non-zero bitmaps must be identical.  Flags as the image pass sets them (any_gt16 per 16-byte
+// segment).  Returns the number of set bitmap bits (>= 0), -1 on a mismatch.
+extern "C" int host_blur_raw_vs_copy(const uint8_t* img, int rows, int cols, int thr, const int* taps, int ksize) {
+  DetectParams dp;
+  std::memset(&dp, 0, sizeof(dp));
+  dp.thr = thr;
+  dp.ksize = ksize;
+  for (int i = 0; i < ksize; ++i) dp.taps[i] = taps[i];
+  pack_taps(dp);
+  const int nseg = (cols + 15) / 16, PW = 16 * nseg;
+  std::vector<uint8_t> raw((size_t)rows * PW + 16, 0), pix;
+  for (int y = 0; y < rows; ++y) std::memcpy(&raw[(size_t)y * PW], img + (size_t)y * cols, cols);
+  pix = raw;
+  const unsigned add = (unsigned)(255 - thr) * 0x00010001u;
+  for (size_t i = 0; i + 4 <= pix.size(); i += 4) {
+    unsigned w;
+    std::memcpy(&w, &pix[i], 4);
+    w = tozero4(w, add);
+    std::memcpy(&pix[i], &w, 4);
+  }
+  const size_t fbit0 = 37;  // (a frame in the middle of a batch: its first segment is not word aligned)
+  std::vector<u64> flags((fbit0 + (size_t)rows * nseg) / 64 + 2, 0);
+  const ThrTest q = make_thr_test(thr);
+  for (int y = 0; y < rows; ++y)
+    for (int c = 0; c < nseg; ++c) {
+      uint4 v;
+      std::memcpy(&v, &raw[(size_t)y * PW + 16 * c], 16);
+      if (any_gt16(v, q)) {
+        const size_t g = fbit0 + (size_t)y * nseg + c;
+        flags[g >> 6] |= 1ull << (g & 63);
+      }
+    }
+  const int wb = (cols + 2 + 63) / 64 + 1;
+  std::vector<u64> a((size_t)(rows + 2) * wb + 1, 0), b(a.size(), 0);
+  const PixWin pc = {pix.data(), 0, rows, 0, PW, 0u, nullptr, 0};
+  const PixWin pr = {raw.data(), 0, rows, 0, PW, add ? add : 1u, flags.data(), fbit0};
+  for (int y = 0; y < rows; ++y)
+    for (int c = 0; c < nseg; ++c) {
+      blur_to_bitmap<false>(pc, rows, cols, dp, dp.taps, y, c, a.data() + (size_t)(y + 1) * wb, 0);
+      if (add) blur_to_bitmap<true>(pr, rows, cols, dp, dp.taps, y, c, b.data() + (size_t)(y + 1) * wb, 0);
+    }
+  if (!add) return 0;
+  int bits = 0;
+  for (size_t i = 0; i < a.size(); ++i) {
+    if (a[i] != b[i]) return -1;
+    bits += __builtin_popcountll(a[i]);
+  }
+  return bits;
 }

@@ -311,3 +311,40 @@ def test_band_scans_equal_the_whole_frame_scan(host):
         assert host.host_bands_vs_whole(m.ctypes.data_as(C.c_void_p), 20, 30, shape_open.ctypes.data_as(C.c_void_p), C.byref(nb)) == -1
     finally:
         del os.environ["K1B_HOST_BREAK_BANDS"]
+
+
+def test_raw_frame_blur_equals_the_blur_of_the_thresholded_copy(host, orc):
+    """Round 5: the general blob tier no longer copies the frame; its blur reads the frame's own rows, loads only the
+    segments the image pass FLAGGED, applies THRESH_TOZERO on the fly and skips rows without a flagged segment
+    (blur_item_fast<.., RAW>).  Against the blur of a thresholded copy (the LDS tiers' input) the non-zero bitmaps must
+    be identical: random frames with spots, salt noise, bright patches at the borders (the mirrored-border variant and
+    its byte-wise fallback), widths that are not multiples of 16, 3- and 5-tap kernels, thresholds on both sides of
+    128, a frame whose first flag bit is not word aligned."""
+    host.host_blur_raw_vs_copy.restype = C.c_int
+    rng = np.random.default_rng(99)
+    total = 0
+    for it in range(300):
+        rows, cols = int(rng.integers(6, 60)), int(rng.choice([rng.integers(17, 120), 32, 48, 64, 33, 47]))
+        img = rng.integers(0, 60, (rows, cols)).astype(np.uint8)
+        kind = it % 4
+        if kind == 0:
+            img[rng.random((rows, cols)) < 0.01] = 255
+        elif kind == 1:
+            for _ in range(int(rng.integers(1, 5))):
+                y, x = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+                img[max(0, y - 2):y + 3, max(0, x - 2):x + 3] = rng.integers(100, 256)
+        elif kind == 2:   # bright pixels on the borders
+            img[:, 0] = rng.integers(0, 256, rows)
+            img[:, cols - 1] = rng.integers(0, 256, rows)
+            img[0, :] = rng.integers(0, 256, cols)
+            img[rows - 1, :] = rng.integers(0, 256, cols)
+        else:
+            img = rng.integers(0, 256, (rows, cols)).astype(np.uint8)
+        thr = int(rng.choice([20, 100, 127, 128, 140, 200, 254]))
+        sigma = float(rng.choice([0.4, 0.6, 0.8]))
+        taps = np.ascontiguousarray(orc.gaussian_kernel_q8(sigma), np.int32)
+        img = np.ascontiguousarray(img)
+        r = host.host_blur_raw_vs_copy(img.ctypes.data_as(C.c_void_p), rows, cols, thr, taps.ctypes.data_as(C.c_void_p), len(taps))
+        assert r >= 0, (it, rows, cols, thr, sigma)
+        total += r
+    assert total > 50000
