@@ -123,7 +123,10 @@ def main():
         "k1a_scan": hbm("k1a_scan", "k1a_scan", F + "pmc1_fetch_summary.csv", F + "pmc1_write_summary.csv", 16384,
                         "round5_pmc_sequential_*.csv", DIMS["C2"]),
         "k2_vote_valu": {
-            "C2": valu(F + "pmc1_sq_summary.csv", "k2_vote<false", "k2_vote<false, false, 1>", 16384, "round5_pmc_sequential_sq.csv"),
+            # (--pipeline 1, nothing to scan: since the round's last kernel change the scan-carrying variant with an empty
+            #  rider; before it the plain <= 5-marker kernel k2_vote<false, false, 1>)
+            "C2": valu(F + "pmc1_sq_summary.csv", "k2_vote<true", "k2_vote<true, false, 0> with an empty rider (no pixels to scan)",
+                       16384, "round5_pmc_sequential_sq.csv"),
             "fused_C2": dict(valu(F + "pmc_sq_summary.csv", "k2_vote<true", "k2_vote<true>", fpl, "round5_pmc_timed_sq.csv"),
                              frames_scanned_per_launch=rider_frames, schedule_in_the_counter_pass=sched),
         },
