@@ -468,7 +468,7 @@ def run_config(args, ctx, light=False):
     # the same kernels one launch per step and back to back (no sub-batch pipelining): what each kernel
     # does when it has the chip to itself
     kiso = None
-    if launches > 1 and not light:
+    if launches > 1 and not light and not args.no_isolated:
         h.set_option("pipeline", 1)
         h.set_profiling(True)
         kk = []
@@ -866,6 +866,10 @@ def main():
                     help="skip the other configs, the clutter legs, the tracked streams and the one-frame latency")
     ap.add_argument("--host-frames", action="store_true", help="(kept for compatibility: the host-streamed leg always runs at N = 1)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive host-streamed leg")
+    ap.add_argument("--no-isolated", action="store_true",
+                    help="skip the pass that runs every kernel once per step, back to back (profiler passes: since round 5 "
+                         "that pass launches the scan-carrying voting kernel WITHOUT a scan, and per-kernel means over "
+                         "both kinds of launch would describe neither)")
     ap.add_argument("--k1a-lds", type=int, default=-1, help="tuning: dummy LDS per scan block (-1 = automatic)")
     ap.add_argument("--pipeline-mode", type=int, default=-1,
                     help="-1 automatic, 0 two-stream pipeline, 3 fused, 4 fused + side-stream tail, 6 = 4 + split scan")

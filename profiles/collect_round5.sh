@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $R && timeout 600 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc $?" >> $O/pytest_gpu.log
 cd /tmp
 python -c "import sys; sys.path.insert(0, '$R'); import rpg_monocular_pose_estimator_amd as m; print(m.source_fingerprint())" > $O/source_fingerprint.txt
-Q="--no-cpu --no-host-leg --no-false-hint-leg --headline-only"
+Q="--no-cpu --no-host-leg --no-false-hint-leg --headline-only --no-isolated"
 SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE"
 INC='--kernel-include-regex mpe::'
 pmc() {  # name, counters, bench args...
@@ -60,8 +60,9 @@ python $R/profiles/install_round5.py > $O/install_on_box.log 2>&1
 # ---- the default bench line, as the driver runs it
 ( time timeout 400 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc $?" >> $O/bench.err ) 2>> $O/bench.err
 # same box A/B: headline alone, default vs the fast arithmetic alone
-timeout 200 python $R/bench.py $Q --steps 20 --warmup 5 2>/dev/null > $O/bench_headline_only.json
-timeout 200 python $R/bench.py $Q --steps 20 --warmup 5 --vote-arith 2 2>/dev/null > $O/bench_arith2.json
+QB="--no-cpu --no-host-leg --no-false-hint-leg --headline-only"
+timeout 200 python $R/bench.py $QB --steps 20 --warmup 5 2>/dev/null > $O/bench_headline_only.json
+timeout 200 python $R/bench.py $QB --steps 20 --warmup 5 --vote-arith 2 2>/dev/null > $O/bench_arith2.json
 # ---- soaks (every mismatch saved, attributed, classified)
 cd $R
 timeout 900 python tests/soak_parity.py 524288 C2 65536 gpurun_out/final5/soak_parity_C2 > $O/soak_parity_C2.log 2>&1; echo "rc $?" >> $O/soak_parity_C2.log
