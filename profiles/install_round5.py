@@ -81,6 +81,16 @@ def fused_shape(log, cfg):
         b["roofline"]["bytes_per_launch"]
 
 
+def frames_per_launch(log, expect=None):
+    """frames of ONE kernel launch in a counter pass, from that process's own bench line (a 32768-frame step is two
+    16384-frame sub-batches, a 16384-frame one two of 8192 unless --pipeline 1: dividing per-dispatch means by the
+    step's frames under-counts per-frame figures by 2, which the round's first five collections did for the cluttered
+    legs)"""
+    n = int(bench_line_of(log)["kernel_ms"]["frames_per_launch"])
+    assert expect is None or n == expect, (log, n, expect)
+    return n
+
+
 def stats_avg(path, kernel_sub):
     for r in csv.DictReader(open(path)):
         if kernel_sub in r["Name"]:
@@ -126,7 +136,7 @@ def main():
             # (--pipeline 1, nothing to scan: since the round's last kernel change the scan-carrying variant with an empty
             #  rider; before it the plain <= 5-marker kernel k2_vote<false, false, 1>)
             "C2": valu(F + "pmc1_sq_summary.csv", "k2_vote<true", "k2_vote<true, false, 0> with an empty rider (no pixels to scan)",
-                       16384, "round5_pmc_sequential_sq.csv"),
+                       frames_per_launch(F + "pmc1_sq.log", 16384), "round5_pmc_sequential_sq.csv"),
             "fused_C2": dict(valu(F + "pmc_sq_summary.csv", "k2_vote<true", "k2_vote<true>", fpl, "round5_pmc_timed_sq.csv"),
                              frames_scanned_per_launch=rider_frames, schedule_in_the_counter_pass=sched),
         },
@@ -138,17 +148,19 @@ def main():
     for key, f, kern, label, frames in (
             ("C3", "pmc3_sq", "k2_vote<false", "k2_vote<false, false, 3> (table slices in LDS, deferred exact evaluation)", 16384),
             ("C3_tol2", "pmc3t2_sq", "k2_vote<false", "k2_vote<false, false, 3> at back_projection_pixel_tolerance 2", 16384),
-            ("C2_d4", "pmcd4_sq", "k2_vote<true", "k2_vote<true> on frames with 4 distractor spots (9 detections)", 32768),
-            ("C2_d16", "pmcd16_sq", "k2_vote<true", "k2_vote<true> on frames with 16 distractor spots (21 detections)", 16384)):
+            ("C2_d4", "pmcd4_sq", "k2_vote<true", "k2_vote<true> on frames with 4 distractor spots (9 detections)", None),
+            ("C2_d16", "pmcd16_sq", "k2_vote<true", "k2_vote<true> on frames with 16 distractor spots (21 detections)", None)):
         if os.path.exists(F + f + "_summary.csv"):
             try:
-                out["k2_vote_valu"][key] = valu(F + f + "_summary.csv", kern, label, frames, "round5_pmc_%s_sq.csv" % key)
+                out["k2_vote_valu"][key] = valu(F + f + "_summary.csv", kern, label, frames_per_launch(F + f + ".log", frames),
+                                                "round5_pmc_%s_sq.csv" % key)
             except KeyError as e:
                 print("no counters for", key, e)
     if os.path.exists(F + "pmcsalt_sq_summary.csv"):
         try:
             out["k1b_general_salt"] = valu(F + "pmcsalt_sq_summary.csv", "k1b_general", "k1b_general on frames with 0.05 % salt "
-                                           "noise (every frame reaches this tier)", 32768, "round5_pmc_C2_salt_sq.csv")
+                                           "noise (every frame reaches this tier)", frames_per_launch(F + "pmcsalt_sq.log"),
+                                           "round5_pmc_C2_salt_sq.csv")
         except KeyError as e:
             print("no counters for k1b_general", e)
     if os.path.exists(F + "pmc_track_summary.csv"):
