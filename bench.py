@@ -661,6 +661,7 @@ def run_config(args, ctx, light=False):
             clk = float(vp.get("effective_clock_GHz") or 2.4)
             out["k2_rates"]["valu_util"] = vp["valu_insts_per_frame"] * B * 4.0 / (1024 * clk * 1e9 * vote_ms * 1e-3)
             out["k2_rates"]["effective_clock_GHz"] = clk
+            out["k2_rates"]["valu_util_at_spec_clock"] = out["k2_rates"]["valu_util"] * clk / SPEC_CLOCK_GHZ
             out["k2_rates"]["valu_insts_per_p3p_solve"] = vp["valu_insts_per_frame"] * 64.0 * B / max(1, solves)
         if host_leg is not None:
             out["host_streamed_fps"] = host_leg["fps"]
@@ -739,7 +740,9 @@ def compact(out):
                                                  "avg_launch_ms", "note") if r.get(k) is not None},
                           **({"voting_kernel": {k: r["voting_kernel"].get(k) for k in ("kernel", "bound", "frac", "avg_launch_ms")}}
                              if "voting_kernel" in r else {})),
-         "kernel_ms": {k: out["kernel_ms"][k] for k in ("scan", "blobs", "vote", "tail") if k in out["kernel_ms"]},
+         # (per LAUNCH: a leg's step is `launches` sub-batches of `frames_per_launch` frames)
+         "kernel_ms": {k: out["kernel_ms"][k] for k in ("scan", "blobs", "vote", "tail", "launches", "frames_per_launch")
+                       if k in out["kernel_ms"]},
          "blob_tier_overflow": {k: out["blob_tier_overflow"][k] for k in ("frames", "general")}}
     if out["vote_arith"]["frames_voted_again"]:
         c["frames_voted_again"] = out["vote_arith"]["frames_voted_again"]
