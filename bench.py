@@ -64,10 +64,10 @@ def effective_cores():
     return n
 
 
-def rank_report(dist, rank, world, device, fps_local):
+def rank_report(dist, rank, world, device, fps_local, multi=None):
     """What the process group itself says about the run (N > 1): the ranks that took part, every rank's own rate."""
     import torch
-    if world == 1:
+    if not (world > 1 if multi is None else multi):
         return [0], [fps_local]
     mine = torch.tensor([float(rank), float(fps_local)], dtype=torch.float64, device=device)
     every = [torch.zeros_like(mine) for _ in range(world)]
@@ -268,6 +268,8 @@ def run_config(args, ctx, light=False):
     import rpg_monocular_pose_estimator_amd as mpe
     from rpg_monocular_pose_estimator_amd import synth, parallel
     rank, local_rank, world, dev, dist = ctx["rank"], ctx["local_rank"], ctx["world"], ctx["dev"], ctx["dist"]
+    # every collective of an N > 1 run (--force-process-group: also on a one-rank group, so that a 1-GPU box executes them)
+    multi = world > 1 or bool(ctx.get("force_pg"))
 
     B = args.frames
     cfg, frames = make_batch(synth, args.config, args.clutter, B, dev, rank)
@@ -275,7 +277,7 @@ def run_config(args, ctx, light=False):
     K, D = synth.camera_for(rows, cols)
     markers = np.asarray(cfg["markers"])
     # two result buffers: while the records of step k travel to rank 0, step k+1 already writes the other one
-    pipe = parallel.RootGatherPipeline(rank, world, B * mpe.RESULT_DTYPE.itemsize, dev)
+    pipe = parallel.RootGatherPipeline(rank, world, B * mpe.RESULT_DTYPE.itemsize, dev, force_collective=multi)
     results = pipe.local(0)
     torch.cuda.synchronize()
 
@@ -343,7 +345,7 @@ def run_config(args, ctx, light=False):
     def barrier():
         with torch.cuda.stream(out_stream):
             pipe.finish()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -372,7 +374,7 @@ def run_config(args, ctx, light=False):
         timed_rec = np.frombuffer(host_rec[last_k & 1].numpy().tobytes(), dtype=mpe.RESULT_DTYPE)
     else:
         timed_rec = parallel.records_from_bytes(pipe.local(last_k))
-    gathered_last = parallel.records_from_bytes(pipe.gathered(last_k)) if (world > 1 and rank == 0) else None
+    gathered_last = parallel.records_from_bytes(pipe.gathered(last_k)) if (multi and rank == 0) else None
     vote_in_region_ms, vote_in_region_n, vote_by_slot = None, 0, None
     if args.vote_events:
         vote_in_region_n = h.get_option("vote_launches")
@@ -385,11 +387,11 @@ def run_config(args, ctx, light=False):
             except Exception:
                 vote_by_slot = None
         h.set_option("vote_events", 0)
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    ranks_seen, per_rank_fps = rank_report(dist, rank, world, dev, B * args.steps / dt_local)
+    ranks_seen, per_rank_fps = rank_report(dist, rank, world, dev, B * args.steps / dt_local, multi)
     fps = world * B * args.steps / dt
     fix_items = h.get_option("vote_fixup_items")
     fix_overflow = h.get_option("vote_fixup_overflow")
@@ -410,7 +412,7 @@ def run_config(args, ctx, light=False):
             step(wrong.data_ptr(), B - shift)
         barrier()
         dt_fh = time.perf_counter() - t1
-        if world > 1:
+        if multi:
             tmax = torch.tensor([dt_fh], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt_fh = float(tmax.item())
@@ -666,15 +668,18 @@ def run_config(args, ctx, light=False):
         if host_leg is not None:
             out["host_streamed_fps"] = host_leg["fps"]
             out["host_streamed"] = host_leg
-        if world > 1:
+        if multi:
             out["ranks_seen"] = ranks_seen
             out["per_rank_fps"] = per_rank_fps
+            if world == 1:
+                out["forced_process_group"] = ("one-rank nccl (RCCL) group: record gather (dist.gather, asynchronous, on "
+                                               "the consumer stream), barrier, all_reduce, all_gather executed on this GPU")
         # ---- CPU baseline + parity on a bounded sample (oracle = test infrastructure / checker) ----
         if not args.no_cpu and args.cpu_sample > 0:
             import oracle
             oracle.build()
             cores = effective_cores()
-            if world == 1:  # CPU baseline: rank 0 at N = 1 only
+            if not multi:  # CPU baseline: rank 0 at N = 1 only
                 ns = min(args.cpu_sample, B)
                 sample = frames[:ns].cpu().numpy()
                 blk, cpu_fps, parity_failed = parity_block(h, sample, timed_rec[:ns], markers, K, D, P, args.back_tol, cores)
@@ -878,6 +883,10 @@ def main():
                     help="skip the other configs, the clutter legs, the tracked streams and the one-frame latency")
     ap.add_argument("--host-frames", action="store_true", help="(kept for compatibility: the host-streamed leg always runs at N = 1)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the PCIe-inclusive host-streamed leg")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="N = 1 only: make a one-rank nccl (RCCL) process group anyway and run every collective of an "
+                         "N > 1 step on it (record gather to rank 0, barrier, all_reduce of the step time, rank report, "
+                         "parity of the gathered shard) -- what a 1-GPU box can execute of the multi-GPU path")
     ap.add_argument("--no-isolated", action="store_true",
                     help="skip the pass that runs every kernel once per step, back to back (profiler passes: since round 5 "
                          "that pass launches the scan-carrying voting kernel WITHOUT a scan, and per-kernel means over "
@@ -950,19 +959,25 @@ def main():
         sys.exit("bench.py: rank %d needs GPU %d, but only %d GPU(s) are visible" % (rank, local_rank, torch.cuda.device_count()))
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_process_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # (--force-process-group without a launcher)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
-    ctx = {"rank": rank, "local_rank": local_rank, "world": world, "dev": torch.device("cuda", local_rank), "dist": dist}
+    ctx = {"rank": rank, "local_rank": local_rank, "world": world, "dev": torch.device("cuda", local_rank), "dist": dist,
+           "force_pg": args.force_process_group}
 
     t_start = time.perf_counter()
     out, parity_failed, impossible = run_config(args, ctx)
     legs_failed = []
-    if rank == 0 and world == 1 and headline and not args.headline_only:
+    if rank == 0 and world == 1 and headline and not args.headline_only and not args.force_process_group:
         # ---- every other BASELINE config, the clutter curve, the tracked streams, one frame: after the headline leg,
         #      outside its timed region, each with its own roofline and parity sample against the oracle
         out["headline_leg_s"] = round(time.perf_counter() - t_start, 1)
@@ -1026,7 +1041,7 @@ def main():
                 "lockstep_64_fps": round(out["tracked"]["lockstep_64"]["fps"], 1)}
     if rank == 0:
         print(json.dumps(slim(out), separators=(",", ":")))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if impossible or any(c == 4 for _, c in legs_failed):

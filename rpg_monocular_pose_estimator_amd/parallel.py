@@ -29,14 +29,14 @@ def gather_records(local_bytes, world, out=None):
     return out
 
 
-def gather_records_to_root(local_bytes, rank, world, out=None, dst=0, async_op=False):
+def gather_records_to_root(local_bytes, rank, world, out=None, dst=0, async_op=False, force=False):
     """The per-rank pose gather: rank `dst` receives the record buffers of all ranks (in rank order) into `out`
     (world * len bytes; allocated if None), the others only send theirs — point-to-point traffic over xGMI,
     432 B per frame and rank.  async_op=True returns (out, work): the transfer then runs beside the next batch's
     kernels; call work.wait() before reading `out` on `dst` / before overwriting `local_bytes`."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force:  # (force: the collective itself on a one-rank group — exercises the RCCL path on one GPU)
         return (local_bytes, None) if async_op else local_bytes
     pieces = None
     if rank == dst:
@@ -53,12 +53,13 @@ class RootGatherPipeline:
     k+1 — which write the OTHER local buffer — run beside it.  A buffer is only handed out again after its
     previous transfer has been waited for.  On `dst`, `gathered(k)` is valid after `wait(k)` / `finish()`."""
 
-    def __init__(self, rank, world, nbytes, device, dst=0):
+    def __init__(self, rank, world, nbytes, device, dst=0, force_collective=False):
         import torch
         self.rank, self.world, self.dst = rank, world, dst
+        self.collective = world > 1 or force_collective  # (forced: a one-rank group still runs the gather)
         n = 2  # (also at world == 1: two submissions may be in flight, each with its own record buffer)
         self._local = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(n)]
-        self._out = [torch.zeros(world * nbytes, dtype=torch.uint8, device=device) if (world > 1 and rank == dst)
+        self._out = [torch.zeros(world * nbytes, dtype=torch.uint8, device=device) if (self.collective and rank == dst)
                      else None for _ in range(n)]
         self._work = [None] * n
 
@@ -71,11 +72,11 @@ class RootGatherPipeline:
         return self._local[self._slot(step)]
 
     def submit(self, step):
-        if self.world == 1:
+        if not self.collective:
             return
         b = self._slot(step)
         _, self._work[b] = gather_records_to_root(self._local[b], self.rank, self.world, out=self._out[b],
-                                                  dst=self.dst, async_op=True)
+                                                  dst=self.dst, async_op=True, force=True)
 
     def wait(self, step):
         b = self._slot(step)
@@ -88,7 +89,7 @@ class RootGatherPipeline:
             self.wait(b)
 
     def gathered(self, step):
-        return self._local[self._slot(step)] if self.world == 1 else self._out[self._slot(step)]
+        return self._out[self._slot(step)] if self.collective else self._local[self._slot(step)]
 
 
 def records_from_bytes(t):

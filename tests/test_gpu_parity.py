@@ -1294,6 +1294,33 @@ def test_bench_secondary_legs_on_the_gpu_box():
 
 
 @pytest.mark.gpu
+def test_bench_collectives_on_a_one_rank_rccl_group():
+    """What a 1-GPU box can execute of an N > 1 bench run: `--force-process-group` makes a ONE-rank nccl (= RCCL) group
+    and sends the step through every collective of the multi-GPU path — the asynchronous, double-buffered dist.gather
+    of the record buffers on the consumer stream, barrier, all_reduce of the step time, the rank report, and the parity
+    sample computed from the GATHERED buffer (not from the rank's own)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-process-group", "--frames", "65536",
+                        "--steps", "3", "--warmup", "1", "--no-host-leg", "--no-false-hint-leg", "--headline-only",
+                        "--no-isolated"], capture_output=True, text=True, timeout=400, env=env, cwd=root)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert line["ranks_seen"] == [0] and len(line["per_rank_fps"]) == 1 and line["per_rank_fps"][0] > 0
+    assert "forced_process_group" in line
+    sp = line["shard_parity"]
+    assert len(sp) == 1 and sp[0]["rank"] == 0 and sp[0]["frames"] > 0
+    assert sp[0]["status_mismatches"] == 0 and sp[0]["mismatches_unexplained"] == 0, sp
+
+
+@pytest.mark.gpu
 def test_bench_head_of_shard_is_reproducible():
     """What makes an N > 1 bench run self-checking: rank 0 re-creates the first frames of EVERY rank's shard from that
     rank's seeds (bench.head_of_shard) and checks the records that arrived through the gather against the oracle on
