@@ -236,12 +236,13 @@ def make_sequence(config, n, seed, dt=0.02, lin_speed=0.15, ang_speed=0.6, dropo
 CLUTTER_KINDS = ("salt", "salt_dense", "patch", "ring", "grid", "d4", "d16")
 
 
-def make_clutter_frames(kind, n, seed):
-    """C2 frames (5 LEDs) with what a real camera adds (numpy, deterministic; the clutter curve of bench.py draws the
-    same kinds on the device): `salt` 0.05 % isolated saturated pixels, `salt_dense` 0.3 %, `patch` one saturated
-    64x64 square, `ring` a bright ring around the image centre (RETR_EXTERNAL drops what it encloses), `grid` a dot
-    grid (every 7th row, 5th column), `d4` / `d16` distractor spots.  -> dict like make_frames."""
-    cfg = dict(CONFIGS["C2"])
+def make_clutter_frames(kind, n, seed, config="C2"):
+    """C2 frames (5 LEDs; `config`: another BASELINE config, e.g. the 1920x1200 C4) with what a real camera adds
+    (numpy, deterministic; the clutter curve of bench.py draws the same kinds on the device): `salt` 0.05 % isolated
+    saturated pixels, `salt_dense` 0.3 %, `patch` one saturated 64x64 square, `ring` a bright ring around the image
+    centre (RETR_EXTERNAL drops what it encloses), `grid` a dot grid (every 7th row, 5th column), `d4` / `d16`
+    distractor spots.  -> dict like make_frames."""
+    cfg = dict(CONFIGS[config])
     if kind in ("d4", "d16"):
         cfg["n_distractors"] = int(kind[1:])
     d = make_frames(cfg, n, seed)

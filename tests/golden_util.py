@@ -39,18 +39,20 @@ def load(name):
     return g, d
 
 
-def load_clutter():
-    """tests/golden/witness_clutter.npz (detections of cluttered C2 frames by the independent witness) ->
+def load_clutter(config="C2"):
+    """tests/golden/witness_clutter.npz (detections of cluttered C2 frames by the independent witness; config "C4":
+    witness_clutter_C4.npz, 1920x1200) ->
     list of (kind, threshold, frame (rows, cols) uint8, K, D, n_det, dist_xy (n,2) f32, undist_xy (n,2) f64);
     frames regenerated from (kind, seed) and checked against their SHA-1."""
     import hashlib
     from rpg_monocular_pose_estimator_amd import synth
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "witness_clutter.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                             "witness_clutter.npz" if config == "C2" else "witness_clutter_%s.npz" % config))
     cache, out = {}, []
     for j in range(len(g["kind"])):
         kind, seed, i, thr = str(g["kind"][j]), int(g["seed"][j]), int(g["frame"][j]), int(g["threshold"][j])
         if (kind, seed) not in cache:
-            cache[(kind, seed)] = synth.make_clutter_frames(kind, 3, seed)
+            cache[(kind, seed)] = synth.make_clutter_frames(kind, 3 if config == "C2" else 1, seed, config)
         d = cache[(kind, seed)]
         f = d["frames"][i]
         assert hashlib.sha1(f.tobytes()).hexdigest() == str(g["sha1"][j]), "clutter frame generator drifted: %s %d" % (kind, i)

@@ -92,7 +92,9 @@ def test_oracle_against_the_witness_on_cluttered_frames(orc):
     general blob tier on the GPU (test_hip_against_the_witness_on_cluttered_frames)."""
     cases = load_clutter()
     assert len(cases) == 42 and {c[0] for c in cases} == {"salt", "salt_dense", "patch", "ring", "grid", "d4", "d16"}
-    for kind, thr, frame, K, D, k, dist, und in cases:
+    c4 = load_clutter("C4")   # the same kinds at 1920x1200
+    assert len(c4) == 10 and all(c[2].shape == (1200, 1920) for c in c4)
+    for kind, thr, frame, K, D, k, dist, und in cases + c4:
         P = orc.make_params(threshold_value=thr)
         u, ds = orc.find_leds(frame, P, K, D)
         assert len(u) == k, (kind, thr, len(u), k)

@@ -251,23 +251,23 @@ def test_hip_against_committed_golden_vectors(hip, name):
 
 def test_hip_against_the_witness_on_cluttered_frames(hip):
     """The blob tiers — above all the general tier rewritten in round 5 — against detections made by the INDEPENDENT
-    witness, not by the oracle (tests/golden/witness_clutter.npz): salt noise sparse and dense, a saturated patch, a
-    ring enclosing the LEDs, a dot grid, 4 and 16 distractor spots, two thresholds.  Count, order, float32 centroids
+    witness, not by the oracle (tests/golden/witness_clutter.npz, and witness_clutter_C4.npz at 1920x1200): salt noise
+    sparse and dense, a saturated patch, a ring enclosing the LEDs, a dot grid, 4 and 16 distractor spots, two thresholds.  Count, order, float32 centroids
     and undistorted points bit-equal (or the documented capacity status with the first 32 detections)."""
     from golden_util import load_clutter
-    cases = load_clutter()
-    for thr in sorted({c[1] for c in cases}):
-        sel = [c for c in cases if c[1] == thr]
-        frames = np.ascontiguousarray(np.stack([c[2] for c in sel]))
-        got = hip.detect_batch(frames, sel[0][3], sel[0][4], mpe.demo_params(threshold_value=thr))
-        for i, (kind, _, _, _, _, k, dist, und) in enumerate(sel):
-            if k > mpe.MAX_DETECTIONS:
-                assert got["status"][i] == -10 and got["n"][i] == mpe.MAX_DETECTIONS, (kind, thr)
-                k = mpe.MAX_DETECTIONS
-            else:
-                assert got["status"][i] == 0 and got["n"][i] == k, (kind, thr, got["n"][i], k)
-            assert np.array_equal(got["dist_xy"][i][:2 * k].reshape(-1, 2), dist[:k]), (kind, thr)
-            assert np.array_equal(got["undist_xy"][i][:2 * k].reshape(-1, 2), und[:k]), (kind, thr)
+    for cases in (load_clutter(), load_clutter("C4")):   # 752x480 and 1920x1200
+        for thr in sorted({c[1] for c in cases}):
+            sel = [c for c in cases if c[1] == thr]
+            frames = np.ascontiguousarray(np.stack([c[2] for c in sel]))
+            got = hip.detect_batch(frames, sel[0][3], sel[0][4], mpe.demo_params(threshold_value=thr))
+            for i, (kind, _, _, _, _, k, dist, und) in enumerate(sel):
+                if k > mpe.MAX_DETECTIONS:
+                    assert got["status"][i] == -10 and got["n"][i] == mpe.MAX_DETECTIONS, (kind, thr)
+                    k = mpe.MAX_DETECTIONS
+                else:
+                    assert got["status"][i] == 0 and got["n"][i] == k, (kind, thr, got["n"][i], k)
+                assert np.array_equal(got["dist_xy"][i][:2 * k].reshape(-1, 2), dist[:k]), (kind, thr)
+                assert np.array_equal(got["undist_xy"][i][:2 * k].reshape(-1, 2), und[:k]), (kind, thr)
 
 
 def test_cpp_facade_example_node(orc, tmp_path):
