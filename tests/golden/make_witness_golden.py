@@ -30,12 +30,16 @@ CASES = [  # name, config, frames, seed, back-projection tolerance
     ("witness_c3_eight_leds_tol5", "C3", 2, 9103, 5.0),
     ("witness_c3_eight_leds_tol2", "C3", 3, 9104, 2.0),
     ("witness_c4_1920x1200", "C4", 2, 9105, 5.0),
+    # 5 LEDs + 4 distractor spots: 9 detections, C(9,3) x 60 = 5 040 P3P solves per frame, most of them on triples
+    # that contain an outlier -- the <= 5-marker voting kernels with more detections than markers
+    ("witness_c2_four_distractors", "C2", 16, 9106, 5.0, 4),
 ]
 MAXD, MAXM = 32, 16
 
 
-def build(name, config, n, seed, tol):
-    d = synth.make_frames(config, n, seed)
+def build(name, config, n, seed, tol, n_distractors=None):
+    d = synth.make_frames(config if n_distractors is None else dict(synth.CONFIGS[config], n_distractors=n_distractors),
+                          n, seed)
     P = dict(synth.DEMO_PARAMS, back_projection_pixel_tolerance=tol)
     n_m = len(d["markers"])
     out = dict(config=config, seed=seed, n=n, tol=tol, made_by="tests/witness_pipeline.py",
@@ -45,6 +49,8 @@ def build(name, config, n, seed, tol):
                corr=np.zeros((n, MAXM, 2), np.uint32), n_corr=np.zeros(n, np.int32),
                status=np.zeros(n, np.int32), T=np.zeros((n, 4, 4)), cov=np.zeros((n, 6, 6)),
                gn_iterations=np.zeros(n, np.int32))
+    if n_distractors is not None:
+        out["n_distractors"] = n_distractors
     for i in range(n):
         t0 = time.time()
         r = W.estimate_frame(d["frames"][i], d["markers"], d["K"], d["D"], P)

@@ -33,7 +33,10 @@ def load_sequence(name):
 
 def load(name):
     g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
-    d = synth.make_frames(str(g["config"]), int(g["n"]), int(g["seed"]))
+    cfg = str(g["config"])
+    if "n_distractors" in g:   # (a BASELINE config with another number of distractor spots)
+        cfg = dict(synth.CONFIGS[cfg], n_distractors=int(g["n_distractors"]))
+    d = synth.make_frames(cfg, int(g["n"]), int(g["seed"]))
     sha = [hashlib.sha1(f.tobytes()).hexdigest() for f in d["frames"]]
     assert sha == [str(s) for s in g["sha1"]], "synthetic generator drifted from the golden scenes"
     return g, d
