@@ -195,10 +195,11 @@ def make_frames(config, n, seed):
                 rows=cfg["rows"], cols=cfg["cols"])
 
 
-def make_sequence(config, n, seed, dt=0.02, lin_speed=0.15, ang_speed=0.6, dropout=()):
+def make_sequence(config, n, seed, dt=0.02, lin_speed=0.15, ang_speed=0.6, dropout=(), salt=0.0):
     """A smooth trajectory (constant body twist + small jitter) for the tracking path: frame k is at
     time k*dt.  Frames listed in `dropout` are rendered with only 2 LEDs (forces the retry /
-    re-initialisation logic).  -> dict(frames, T_true, times, K, D, markers)"""
+    re-initialisation logic); `salt`: that fraction of every frame's pixels saturated (isolated bright pixels inside
+    and outside the ROI).  -> dict(frames, T_true, times, K, D, markers)"""
     cfg = CONFIGS[config] if isinstance(config, str) else config
     K, D = camera_for(cfg["rows"], cfg["cols"])
     rows, cols, M = cfg["rows"], cfg["cols"], np.asarray(cfg["markers"])
@@ -230,6 +231,8 @@ def make_sequence(config, n, seed, dt=0.02, lin_speed=0.15, ang_speed=0.6, dropo
         if k in dropout:
             px = px[:2]
         frames[k] = render_frame(np.random.default_rng([seed, k, 3]), px, rows, cols, cfg["spot_sigma"])
+        if salt > 0.0:
+            frames[k][np.random.default_rng([seed, k, 13]).random((rows, cols)) < salt] = 255
     return dict(frames=frames, T_true=np.array(Ts), times=np.arange(n) * dt, K=K, D=D, markers=M, rows=rows, cols=cols)
 
 

@@ -26,17 +26,23 @@ CASES = [  # name, config, frames, seed, LED drop-out frames (fewer than 4 LEDs 
     ("witness_seq_c2_tracking", "C2", 36, 9201, (9, 20, 21)),
     ("witness_seq_c1_demo4", "C1", 30, 9202, (12,)),
     ("witness_seq_c2_long_dropout", "C2", 24, 9203, (6, 7, 8, 9, 10)),
+    # 0.1 % / 0.3 % of every frame's pixels saturated: isolated bright pixels in the ROI and around it (the blob tiers
+    # behind the first one, with per-frame ROI windows on the device), a drop-out in the middle
+    ("witness_seq_c2_salt", "C2", 24, 9204, (11,), 0.001),
+    ("witness_seq_c2_salt_dense", "C2", 20, 9205, (), 0.003),
 ]
 
 
-def build(name, config, n, seed, dropout):
-    seq = synth.make_sequence(config, n, seed=seed, dropout=dropout)
+def build(name, config, n, seed, dropout, salt=0.0):
+    seq = synth.make_sequence(config, n, seed=seed, dropout=dropout, salt=salt)
     tr = W.Tracker(seq["markers"], seq["K"], seq["D"], dict(synth.DEMO_PARAMS))
     out = dict(config=config, seed=seed, n=n, dropout=np.array(dropout, np.int32), made_by="tests/witness_pipeline.py::Tracker",
                sha1=np.array([hashlib.sha1(f.tobytes()).hexdigest() for f in seq["frames"]]),
                updated=np.zeros(n, np.int32), roi=np.zeros((n, 4), np.int32), it_since_initialized=np.zeros(n, np.int32),
                n_det=np.zeros(n, np.int32), n_corr=np.zeros(n, np.int32), used_bruteforce=np.zeros(n, np.int32),
                T=np.zeros((n, 4, 4)), cov=np.zeros((n, 6, 6)))
+    if salt:
+        out["salt"] = salt
     for k in range(n):
         r = tr.estimate(seq["frames"][k], seq["times"][k])
         out["updated"][k] = int(r["updated"])
@@ -53,5 +59,7 @@ def build(name, config, n, seed, dropout):
 
 
 if __name__ == "__main__":
+    only = sys.argv[1:]
     for c in CASES:
-        build(*c)
+        if not only or c[0] in only:
+            build(*c)

@@ -25,7 +25,8 @@ def golden_sequences():
 
 def load_sequence(name):
     g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
-    d = synth.make_sequence(str(g["config"]), int(g["n"]), seed=int(g["seed"]), dropout=tuple(int(x) for x in g["dropout"]))
+    d = synth.make_sequence(str(g["config"]), int(g["n"]), seed=int(g["seed"]), dropout=tuple(int(x) for x in g["dropout"]),
+                            salt=float(g["salt"]) if "salt" in g else 0.0)
     sha = [hashlib.sha1(f.tobytes()).hexdigest() for f in d["frames"]]
     assert sha == [str(s) for s in g["sha1"]], "synthetic sequence generator drifted from the golden scenes"
     return g, d

@@ -59,7 +59,9 @@ def test_oracle_tracker_against_the_witness_sequences(orc, name):
             dp, dr = pose_diff(r["T"], g["T"][k])
             assert dp < 1e-9 and dr < 1e-9, (k, dp, dr)
             assert np.allclose(r["cov"], g["cov"][k], rtol=1e-6, atol=1e-14), k
-    assert n_roi >= int(g["n"]) // 2
+    # (a sequence is mostly ROI frames — except the dense-salt one, whose 12 - 28 detections per frame never validate:
+    #  every frame is a whole-image brute-force attempt, in the witness and in the oracle alike)
+    assert n_roi >= int(g["n"]) // 2 or int(g["updated"].sum()) == 0
 
 
 def test_witness_tracker_primitives_against_the_oracle(orc):
