@@ -520,7 +520,7 @@ def run_config(args, ctx, light=False):
                     "launches_per_step": n_fused, "frames_per_launch": fpl,
                     "avg_launch_ms_source": ("HIP events around all %d launches of the timed region" % vote_in_region_n)
                                             if vote_in_region_ms else "HIP events in extra steps of the same mode",
-                    "avg_launch_ms_in_separately_profiled_steps": vote_profiled_ms, "counters": counters}
+                    "avg_launch_ms_profiled_steps": vote_profiled_ms, "counters": counters}
         if vote_by_slot:
             roofline["timed_region_by_slot"] = vote_by_slot
         # a cluttered frame (many distractor spots) makes the same kernel FP64-issue bound: with a SQ_INSTS_VALU pass of
@@ -1028,17 +1028,39 @@ def main():
             out["latency_ms_one_frame"] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["legs_failed"] = [n for n, _ in legs_failed]
         out["total_s"] = round(time.perf_counter() - t_start, 1)
-        # the driver keeps `config`, `roofline`, `cpu_baseline` of the line: a digest of the other legs rides there too
-        out["config"]["other_legs"] = {
-            k: {"fps": v.get("value"), "frac": (v.get("roofline") or {}).get("frac"),
-                "bound": (v.get("roofline") or {}).get("bound"),
-                "parity_unexplained": (v.get("parity") or {}).get("mismatches_unexplained")}
-            for grp in ("other_configs", "clutter") for k, v in out[grp].items() if isinstance(v, dict)}
-        if "tracked" in out and "one_stream" in out["tracked"]:
-            out["config"]["other_legs"]["tracked"] = {
-                "one_stream_ms": round(out["tracked"]["one_stream"]["latency_ms_per_frame"], 4),
-                "lockstep_8_fps": round(out["tracked"]["lockstep_8"]["fps"], 1),
-                "lockstep_64_fps": round(out["tracked"]["lockstep_64"]["fps"], 1)}
+        # the driver keeps only FLAT SCALARS of `config`, `roofline`, `cpu_baseline` (key names cut at 40 characters;
+        # VERDICT round 5, item 4): every other leg rides in `config` as <leg>_fps / <leg>_frac / <leg>_bad
+        flat = out["config"]
+        unexplained = 0
+        for grp in ("other_configs", "clutter"):
+            for k, v in out[grp].items():
+                if not isinstance(v, dict):
+                    continue
+                k = {"C3_tol2": "C3t2"}.get(k, k)
+                if "error" in v:
+                    flat[k + "_fps"] = None
+                    continue
+                rf = v.get("roofline") or {}
+                flat[k + "_fps"] = round(v.get("value") or 0.0, 1)
+                flat[k + "_frac"] = rf.get("frac")
+                flat[k + "_bound"] = rf.get("bound")
+                bad = (v.get("parity") or {}).get("mismatches_unexplained")
+                flat[k + "_bad"] = bad
+                unexplained += int(bad or 0)
+        trk = out.get("tracked") or {}
+        if "one_stream" in trk:
+            flat["trk1_ms"] = round(trk["one_stream"]["latency_ms_per_frame"], 4)
+            flat["trk8_fps"] = round(trk["lockstep_8"]["fps"], 1)
+            flat["trk64_fps"] = round(trk["lockstep_64"]["fps"], 1)
+            if "cpu_one_core_fps" in trk["one_stream"]:
+                flat["trk_cpu1_fps"] = round(trk["one_stream"]["cpu_one_core_fps"], 1)
+        lat = out.get("latency_ms_one_frame") or {}
+        for k, v in lat.items():
+            if isinstance(v, dict) and "median_ms" in v:
+                flat["lat1_%s_ms" % k[:12]] = round(v["median_ms"], 4)
+        flat["legs_unexplained"] = unexplained
+        flat["legs_failed_n"] = len(legs_failed)
+        flat["total_s"] = out["total_s"]
     if rank == 0:
         print(json.dumps(slim(out), separators=(",", ":")))
     if dist is not None:

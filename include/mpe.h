@@ -33,7 +33,11 @@ extern "C" {
 
 #define MPE_MAX_MARKERS 16    /* object_points_ capacity (reference: unbounded; 32-bit factorial
                                  already overflows at 13, COMB.cpp:34-45 — replicated) */
-#define MPE_MAX_DETECTIONS 32 /* detections kept per frame; more -> status MPE_FRAME_TOO_MANY_DETECTIONS */
+#define MPE_MAX_DETECTIONS 64 /* detections kept per frame; more -> status MPE_FRAME_TOO_MANY_DETECTIONS.  (The
+                                 reference has no limit, led_detector.cpp:65-86 / pose_estimator.cpp:549-557; with 64
+                                 detections and 5 markers initialise() already runs 2.5 M P3P solves for one frame.
+                                 Frames with more than MPE_FAST_VOTE_DETECTIONS are voted by the strict loop nest.) */
+#define MPE_FAST_VOTE_DETECTIONS 32 /* widest frame the fast voting kernels' 32-bit detection masks hold */
 #define MPE_MAX_RAW_BLOBS 256 /* external contours per frame before the shape filter */
 #define MPE_MAX_KSIZE 37      /* Gaussian kernel taps: sigma <= 6 (cfg:13) */
 

@@ -68,8 +68,13 @@ struct mpe_handle {
   unsigned fix_cap = 0;                 // entries per slot of the current layout
   int fix_slots = 0;                    // list regions of the current layout
   unsigned fix_cap_limit = 0;           // option "vote_list_cap" (tests): entries per slot at most; 0 = no limit
-  unsigned long long fix_relost_base = 0;
+  unsigned long long fix_relost_base = 0, fix_wide_base = 0;
   bool fix_pending[16] = {};            // slot: a voting launch has appended, its fix-up has not been launched yet
+  // a pinned host mirror of the lists' control block, copied behind the first fix-up launch of every call and read —
+  // stale by a call or two, which is all a heuristic needs — when the next call sizes its re-vote launches (relost_grid)
+  unsigned* fix_ctl_host = nullptr;
+  unsigned long long relost_prev_sum = 0;
+  bool relost_hot = false;              // frames were marked for the strict re-vote since the reading before
   unsigned long long fix_items_base = 0, fix_overflow_base = 0;  // cumulative counters of layouts that were replaced
   void* mailbox = nullptr;  // pinned host memory for the single-frame tracking step (ROI in, record out)
   size_t mailbox_cap = 0;
@@ -392,7 +397,7 @@ constexpr size_t kFixEntryBytes = 2 * sizeof(unsigned long long);
 // sum of the per-slot cumulative counters (synchronises the device); which = 1 list-full events, 3 entries
 // re-evaluated, 6 frames voted again after a list-full event
 int fix_counter_sum(mpe_handle* h, int which, unsigned long long& out) {
-  out = which == 1 ? h->fix_overflow_base : which == 6 ? h->fix_relost_base : h->fix_items_base;
+  out = which == 1 ? h->fix_overflow_base : which == 6 ? h->fix_relost_base : which == 7 ? h->fix_wide_base : h->fix_items_base;
   if (!h->fix.p) return MPE_OK;
   HIP_TRY(h, hipDeviceSynchronize());
   unsigned ctl[mpe_handle::kMaxSub * MPE_FIX_CTL_WORDS];
@@ -412,7 +417,9 @@ int vote_fixup_for(mpe_handle* h, int slot, int n_slots, int n_frames, int n_mar
   fx = VoteFixup{nullptr, nullptr, 0u, 0u};
   if (h->vote_arith == 0 || n_markers < 4 || slot < 0 || slot >= mpe_handle::kMaxSub) return MPE_OK;
   n_slots = std::min((int)mpe_handle::kMaxSub, std::max(n_slots, slot + 1));
-  const long long nd = n_frames <= 256 ? MPE_MAX_DETECTIONS : std::min(MPE_MAX_DETECTIONS, std::max(n_det_hint, n_markers) + 4);
+  // (wider frames than MPE_FAST_VOTE_DETECTIONS append nothing: the strict loop nest votes them)
+  const long long nd = n_frames <= 256 ? MPE_FAST_VOTE_DETECTIONS
+                                       : std::min(MPE_FAST_VOTE_DETECTIONS, std::max(n_det_hint, n_markers) + 4);
   const long long items = nd * (nd - 1) * (nd - 2) / 6 * n_markers * (n_markers - 1) * (n_markers - 2);
   unsigned long long want = (unsigned long long)n_frames * (unsigned long long)std::max(64ll, items / 32);
   const unsigned long long most = (1ull << 30) / kFixEntryBytes;
@@ -431,6 +438,9 @@ int vote_fixup_for(mpe_handle* h, int slot, int n_slots, int n_frames, int n_mar
       rc = fix_counter_sum(h, 6, v);
       if (rc) return rc;
       h->fix_relost_base = v;
+      rc = fix_counter_sum(h, 7, v);
+      if (rc) return rc;
+      h->fix_wide_base = v;
     }
     HIP_TRY(h, hipDeviceSynchronize());
     const int slots = std::max(n_slots, h->fix_slots);  // (a layout only grows)
@@ -464,12 +474,40 @@ int vote_fixup_for(mpe_handle* h, int slot, int n_slots, int n_frames, int n_mar
   h->fix_pending[slot] = true;
   return MPE_OK;
 }
+// Blocks of the strict re-vote launch behind a fix-up (k2_vote_relost).  As a rule nothing is marked and the launch
+// only has to leave quickly: 32 blocks where it sits in the tail chain of a sub-batch beside the next voting launch
+// (256 no-op blocks took 0.39 ms there, round 5).  Once frames HAVE been marked — a list that overflowed, or frames
+// with more than MPE_FAST_VOTE_DETECTIONS detections — 32 blocks are a cliff: the launch then takes
+// the whole chip, until a call goes by without a mark.  Small calls (single frames, the tracker's initialisation, the
+// stage-level entries) have nothing beside them and always get a grid that follows their frames.
+int relost_grid(mpe_handle* h, int n_frames) {
+  const int wide = 2 * device_cu_count();
+  if (h->relost_hot) return wide;
+  if (n_frames < 4096) return std::min(wide, std::max(32, 8 * n_frames));
+  return 32;
+}
 hipError_t fixup_launch(mpe_handle* h, int slot, mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist,
                         const VoteFixup& fx, hipStream_t st) {
   if (!fx.ctl) return hipSuccess;
-  const hipError_t e = launch_k2_fixup(dets, n_frames, sp, hist, fx, st);
-  if (e == hipSuccess) h->fix_pending[slot] = false;
-  return e;
+  if (slot == 0 && h->fix_ctl_host) {  // once per call: what the mirror says, then the next reading on its way
+    unsigned long long sum = 0;
+    for (int s = 0; s < mpe_handle::kMaxSub; ++s)
+      sum += (unsigned long long)h->fix_ctl_host[MPE_FIX_CTL_WORDS * s + 1] + h->fix_ctl_host[MPE_FIX_CTL_WORDS * s + 7];
+    h->relost_hot = sum != h->relost_prev_sum;
+    h->relost_prev_sum = sum;
+  }
+  const hipError_t e = launch_k2_fixup(dets, n_frames, sp, hist, fx, st, relost_grid(h, n_frames));
+  if (e != hipSuccess) return e;
+  h->fix_pending[slot] = false;
+  if (slot == 0) {
+    if (!h->fix_ctl_host) {
+      const hipError_t ea = hipHostMalloc(reinterpret_cast<void**>(&h->fix_ctl_host), kFixCtlBytes, hipHostMallocDefault);
+      if (ea != hipSuccess) return ea;
+      std::memset(h->fix_ctl_host, 0, kFixCtlBytes);
+    }
+    return hipMemcpyAsync(h->fix_ctl_host, h->fix.p, kFixCtlBytes, hipMemcpyDeviceToHost, st);
+  }
+  return hipSuccess;
 }
 
 // dummy LDS per block of the stand-alone scan kernel: the handle's tuning override, else 40 KB when the scan is
@@ -493,7 +531,7 @@ int run_front(mpe_handle* h, hipStream_t st, bool prof, int chain, int chain_fra
   if (prof) rec(h, 1);
   HIP_TRY(h, launch_k1b_blobs(d_frames, d_flags, n_frames, g, dp, d_dets,
                               static_cast<int*>(h->work.p) + (size_t)chain * 2 * (chain_frames + 1),
-                              static_cast<uint8_t*>(h->scratch.p), sp ? sp->n_markers : 0, st));
+                              static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp ? sp->n_markers : 0, st));
   if (prof) rec(h, 2);
   return MPE_OK;
 }
@@ -785,7 +823,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     }
     return MPE_OK;
   };
-  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
+  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g, nsub <= 1 ? n_frames : per)));
   if (sp) HIP_TRY(h, h->mid.reserve(k3_mid_bytes(n_frames)));
   if (nsub <= 1) {
     { const int rc = drain_tails(); if (rc) return rc; }
@@ -961,7 +999,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], st));
       HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
                                   static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
-                                  static_cast<uint8_t*>(h->scratch.p), sp->n_markers, st, nullptr, true));
+                                  static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp->n_markers, st, nullptr, true));
       h->blob_launches.emplace_back((size_t)s * 2 * (per + 1), nf);
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], st));
       uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
@@ -1084,7 +1122,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], sblob));
     HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
                                 static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
-                                static_cast<uint8_t*>(h->scratch.p), sp->n_markers, sblob));
+                                static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp->n_markers, sblob));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], sblob));
     HIP_TRY(h, hipEventRecord(h->sub_done[s], sblob));
     HIP_TRY(h, hipStreamWaitEvent(sb, h->sub_done[s], 0));
@@ -1213,6 +1251,7 @@ void mpe_destroy(mpe_handle* h) {
   h->scratch.release();
   h->track.release();
   h->mid.release();
+  if (h->fix_ctl_host) (void)hipHostFree(h->fix_ctl_host);
   h->fix.release();
   if (h->mailbox) (void)hipHostFree(h->mailbox);
   for (auto& e : h->ev)
@@ -1345,13 +1384,14 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "last_schedule") *value = h->last_schedule;
   else if (n == "vote_list_cap") *value = (int)h->fix_cap_limit;
   else if (n == "k1b_general_blocks") *value = k1b_get_general_blocks();
-  else if (n == "vote_fixup_items" || n == "vote_fixup_overflow" || n == "vote_relost_frames") {
+  else if (n == "vote_fixup_items" || n == "vote_fixup_overflow" || n == "vote_relost_frames" || n == "vote_wide_frames") {
     // hypotheses (roots, detections) the fast voting kernel handed to the strict arithmetic since the handle was made,
     // how many it could not hand over because a list was full, and how many frames were therefore voted again by the
     // strict loop nest (k2_vote_relost); saturating at INT_MAX
     HIP_TRY(h, hipSetDevice(h->device));
     unsigned long long v = 0;
-    const int rc = fix_counter_sum(h, n == "vote_fixup_items" ? 3 : n == "vote_relost_frames" ? 6 : 1, v);
+    // ("vote_wide_frames": frames with more than MPE_FAST_VOTE_DETECTIONS detections, voted by that loop nest alone)
+    const int rc = fix_counter_sum(h, n == "vote_fixup_items" ? 3 : n == "vote_relost_frames" ? 6 : n == "vote_wide_frames" ? 7 : 1, v);
     if (rc) return rc;
     *value = v > 0x7fffffffull ? 0x7fffffff : (int)v;
   }
@@ -1548,6 +1588,9 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
       rc = fix_counter_sum(h, 6, v);
       if (rc) return rc;
       h->fix_relost_base = v;
+      rc = fix_counter_sum(h, 7, v);
+      if (rc) return rc;
+      h->fix_wide_base = v;
     }
     h->fix.release();
     h->fix_cap = 0;
@@ -1911,7 +1954,7 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   HIP_TRY(h, h->frames.reserve(in_bytes + 16));
   HIP_TRY(h, h->flags.reserve(flag_words(roi_bytes) * 8));
   HIP_TRY(h, h->work.reserve(4 * sizeof(int)));
-  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
+  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g, 1)));
   HIP_TRY(h, h->hist.reserve(MPE_HIST_STRIDE * sizeof(uint32_t)));
   HIP_TRY(h, h->track.reserve(sizeof(TrackRecord)));
   HIP_TRY(h, h->mid.reserve(k3_mid_bytes(1)));
@@ -1930,7 +1973,7 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   const bool optimistic = sp.n_markers >= 1 && sp.n_markers <= 8;
   for (int pass = optimistic ? 0 : 1; pass < 2; ++pass) {
     HIP_TRY(h, launch_k1b_blobs(d_in + kTrackHeader, static_cast<unsigned long long*>(h->flags.p), 1, g, dp, &d_rec->det,
-                                static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), sp.n_markers, h->stream,
+                                static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp.n_markers, h->stream,
                                 nullptr, false, pass == 0));
     HIP_TRY(h, launch_k3_tail(&d_rec->det, static_cast<uint32_t*>(h->hist.p), 1, sp, &d_rec->res, d_rec->corr, nullptr,
                               reinterpret_cast<const double*>(d_in), p->nearest_neighbour_pixel_tolerance, h->mid.p,
@@ -2239,7 +2282,7 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
   HIP_TRY(h, h->frames.reserve(in_bytes + 16));
   HIP_TRY(h, h->flags.reserve(flag_words((size_t)n * slot) * 8));
   HIP_TRY(h, h->work.reserve((size_t)2 * (n + 1) * sizeof(int)));
-  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g)));
+  HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g, n)));
   HIP_TRY(h, h->hist.reserve((size_t)n * MPE_HIST_STRIDE * sizeof(uint32_t)));
   HIP_TRY(h, h->track.reserve(rec_bytes));
   HIP_TRY(h, h->mid.reserve(k3_mid_bytes(n)));
@@ -2266,7 +2309,7 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
   pt.d_wins = d_wins;
   pt.d_pred = d_pred;
   HIP_TRY(h, launch_k1b_blobs(d_pix, static_cast<unsigned long long*>(h->flags.p), n, g, dp, d_dets,
-                              static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), sp.n_markers, h->stream,
+                              static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp.n_markers, h->stream,
                               d_wins, false, pt.optimistic));
   HIP_TRY(h, launch_k3_tail(d_dets, static_cast<uint32_t*>(h->hist.p), n, sp, d_res, d_corr, nullptr, d_pred, pt.nn_tol,
                             h->mid.p, h->stream));
@@ -2305,7 +2348,7 @@ int mpe_track_step_batch_collect(mpe_handle* h, mpe_detections* dets_out, uint32
       uint32_t* d_corr = reinterpret_cast<uint32_t*>(d_dets + n);
       mpe_result* d_res = reinterpret_cast<mpe_result*>(d_corr + (size_t)n * 2 * MPE_MAX_MARKERS);
       HIP_TRY(h, launch_k1b_blobs(pt.d_pix, static_cast<unsigned long long*>(h->flags.p), n, pt.g, pt.dp, d_dets,
-                                  static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), pt.sp.n_markers,
+                                  static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, pt.sp.n_markers,
                                   h->stream, pt.d_wins));
       HIP_TRY(h, launch_k3_tail(d_dets, static_cast<uint32_t*>(h->hist.p), n, pt.sp, d_res, d_corr, nullptr, pt.d_pred,
                                 pt.nn_tol, h->mid.p, h->stream));

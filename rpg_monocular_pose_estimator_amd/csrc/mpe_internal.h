@@ -68,7 +68,8 @@ struct VoteFixup {
   unsigned* ctl;             // MPE_FIX_CTL_WORDS words: [0] entries appended (reset by the fix-up kernel), [1] appends
                              // that found the list full (cumulative), [2] blocks done (internal), [3] entries
                              // re-evaluated (cumulative), [4] value of [1] the last k2_vote_relost launch handled,
-                             // [5] its blocks done (internal), [6] frames voted again by it (cumulative)
+                             // [5] its blocks done (internal), [6] frames voted again by it (cumulative),
+                             // [7] frames too wide for the fast kernels, left to that launch (cumulative)
   unsigned long long* list;  // cap entries of 2 words
   unsigned cap;
   unsigned screen;           // 1: the voting kernel screens its hypotheses (vote_arith 1); 0: it only sends what its
@@ -77,14 +78,14 @@ struct VoteFixup {
 
 // launchers (mpe_k1.hip / mpe_k2.hip / mpe_k3.hip)
 int device_cu_count();  // compute units of the current device (cached)
-size_t k1b_scratch_bytes(const FrameGeom& g);
+size_t k1b_scratch_bytes(const FrameGeom& g, int n_frames);  // general-tier slabs for launches of up to n_frames
 void k1b_set_general_blocks(int cap);  // blocks (= scratch slabs) of the general blob tier at most; process-wide
 int k1b_get_general_blocks();
 hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long long* flags, int thr,
                            int dummy_lds_bytes, hipStream_t s, int blocks_per_cu = 0);
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
-                            int blob_hint, hipStream_t s, const void* frame_windows = nullptr,
+                            size_t scratch_bytes, int blob_hint, hipStream_t s, const void* frame_windows = nullptr,
                             bool lists_zeroed = false, bool first_tier_only = false);
 // worklist: 2 * (n_frames + 1) ints (two device work-lists that chain the capacity tiers); lists_zeroed = the caller
 // has zeroed it in stream order already (one memset for all the sub-batches of a call) and no memset is issued here.
@@ -108,7 +109,7 @@ hipError_t launch_k2_vote(mpe_detections* dets, int n_frames, const SolveParams&
 // on a stream ordered behind the voting launch; its votes must be in before the tail reads the histograms
 // ... and, behind it, the strict re-vote of the frames that lost an entry to a full list (they come out unmarked)
 hipError_t launch_k2_fixup(mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist,
-                           const VoteFixup& fixup, hipStream_t s);
+                           const VoteFixup& fixup, hipStream_t s, int relost_blocks = 32);
 // splits < 0 (plain kernel): -splits blocks per frame that divide the marker PERMUTATIONS among themselves and keep
 // their slice of the per-permutation table in LDS (k2_table_slices says when and into how many)
 int k2_table_slices(int n_markers);

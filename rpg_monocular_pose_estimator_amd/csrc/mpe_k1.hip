@@ -1577,10 +1577,14 @@ __host__ __device__ inline size_t k1b_gen_scratch_bytes(const FrameGeom& g) {
 static int g_k1b_gen_blocks_cap = 4096;
 void k1b_set_general_blocks(int cap) { g_k1b_gen_blocks_cap = cap < 32 ? 32 : (cap > 8192 ? 8192 : cap); }
 int k1b_get_general_blocks() { return g_k1b_gen_blocks_cap; }
-static int k1b_gen_blocks(const FrameGeom& g) {
-  const size_t n = ((size_t)1 << 30) / k1b_gen_scratch_bytes(g);
+// n_frames bounds them too (a one-frame tracked step used to reserve the 1 GB of a 4 096-slab launch)
+static int k1b_gen_blocks(const FrameGeom& g, int n_frames) {
+  size_t n = ((size_t)1 << 30) / k1b_gen_scratch_bytes(g);
   const size_t cap = (size_t)g_k1b_gen_blocks_cap;
-  return (int)(n < 32 ? 32 : (n > cap ? cap : n));
+  if (n < 32) n = 32;
+  if (n > cap) n = cap;
+  if (n_frames > 0 && n > (size_t)n_frames) n = (size_t)n_frames;
+  return (int)n;
 }
 
 __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
@@ -1772,11 +1776,14 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
   }
 }
 
-size_t k1b_scratch_bytes(const FrameGeom& g) { return k1b_gen_scratch_bytes(g) * (size_t)k1b_gen_blocks(g); }
+size_t k1b_scratch_bytes(const FrameGeom& g, int n_frames) {
+  return k1b_gen_scratch_bytes(g) * (size_t)k1b_gen_blocks(g, n_frames);
+}
 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
-                            int blob_hint, hipStream_t s, const void* frame_windows, bool lists_zeroed,
+                            size_t scratch_bytes, int blob_hint, hipStream_t s, const void* frame_windows,
+                            bool lists_zeroed,
                             bool first_tier_only) {
   const FrameWin* wins = static_cast<const FrameWin*>(frame_windows);
   if (first_tier_only) {
@@ -1816,7 +1823,12 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
   }
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k1b_general, dim3(k1b_gen_blocks(g)), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
+  // one slab per block: the grid follows the scratch the CALLER reserved (the process-wide knob may have moved since)
+  size_t gen_blocks = (size_t)k1b_gen_blocks(g, n_frames);
+  const size_t slabs = scratch_bytes / k1b_gen_scratch_bytes(g);
+  if (slabs < 1) return hipErrorInvalidValue;
+  if (gen_blocks > slabs) gen_blocks = slabs;
+  hipLaunchKernelGGL(k1b_general, dim3((unsigned)gen_blocks), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
                      (const int*)list_b, scratch, wins);
   return hipGetLastError();
 }

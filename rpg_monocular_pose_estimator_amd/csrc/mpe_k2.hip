@@ -1163,21 +1163,22 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
 // RANGE (forensics only, mpe_vote_items): frame f votes with the hypotheses whose flattened index — detection triple
 // x P(n_m,3) + marker permutation, the reference's loop order — lies in [item_range[2f], item_range[2f+1]); the
 // arithmetic of an item is the hot kernel's (same k2_vote_item).
+#define K2_FAST_HIST (MPE_FAST_VOTE_DETECTIONS * MPE_MAX_MARKERS)  // histogram rows a fast voting block keeps in LDS
 template <bool SCAN, bool RANGE = false, int NP = 0>
 __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_detections* __restrict__ dets, SolveParams sp,
                                                       const double* __restrict__ tab, uint32_t* __restrict__ hist,
                                                       int splits, ScanArgs scan, const int* __restrict__ item_range,
                                                       int slice_tab, VoteFixup fixup) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ double s_px[MPE_MAX_DETECTIONS][2];
-  __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
+  __shared__ double s_px[MPE_FAST_VOTE_DETECTIONS][2];  // (wider frames leave below)
+  __shared__ double s_iv[MPE_FAST_VOTE_DETECTIONS][3];
   // detection triples staged per pass: 64, or 16 in the scan-carrying variant (LDS goes to the scan staging
   // and to an LDS copy of the marker table instead; more triples simply take more passes)
   constexpr int TRI = SCAN ? K2_TRI_CHUNK_SCAN : K2_TRI_CHUNK;
   __shared__ double s_tri[TRI][13];  // T rows (9), f_1, f_2, b, f_1/f_2
   __shared__ unsigned s_trii[TRI];   // c0 | c1 << 8 | c2 << 16 | swap << 24
-  __shared__ unsigned s_hist[MPE_HIST_STRIDE];
-  __shared__ f32x2 s_pxf[MPE_MAX_DETECTIONS];  // the detections in single precision (nearest-neighbour prefilter)
+  __shared__ unsigned s_hist[K2_FAST_HIST];
+  __shared__ f32x2 s_pxf[MPE_FAST_VOTE_DETECTIONS];  // the detections in single precision (nearest-neighbour prefilter)
   constexpr int SUSN = SCAN ? K2_SUS_LDS_SCAN : K2_SUS_LDS_PLAIN;
   __shared__ u64 s_sus[SUSN * K2_SUS_WORDS];  // the block's list of hypotheses left to the strict arithmetic
   __shared__ unsigned s_sus_n, s_sus_base;
@@ -1199,8 +1200,23 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
     rider.drain();
     return;
   }
+  // More detections than this kernel's 32-bit detection masks and 5-bit suspect codes hold (33 .. MPE_MAX_DETECTIONS):
+  // the frame is left to the strict loop nest (k2_vote_relost, launched behind the fix-up kernel), whose histogram the
+  // fast arithmetic has to equal anyway.  The mark is the one of a frame that lost a suspect entry; ctl[7] counts.
+  if (n_d > MPE_FAST_VOTE_DETECTIONS) {
+    if (part == 0) {  // (the re-vote ADDS its blocks' votes to these rows)
+      uint32_t* gw = hist + (size_t)f * MPE_HIST_STRIDE;
+      for (int i = tid; i < n_d * MPE_MAX_MARKERS; i += nthr) gw[i] = 0;
+      if (tid == 0) {
+        atomicAdd(&fixup.ctl[7], 1u);
+        d->status = MPE_FRAME_VOTE_LIST_FULL;
+      }
+    }
+    rider.drain();
+    return;
+  }
 
-  for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) s_hist[i] = 0;
+  for (int i = tid; i < K2_FAST_HIST; i += nthr) s_hist[i] = 0;
   if (tid == 0) {
     s_sus_n = 0;
     s_susd = K2SusDesc{fixup.ctl, reinterpret_cast<u64*>(fixup.list), fixup.cap, &d->status};
@@ -1367,7 +1383,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
     // the caller then needs no memset of the histogram buffer
     for (int i = tid; i < n_d * MPE_MAX_MARKERS; i += nthr) gh[i] = s_hist[i];
   } else {
-    for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) {
+    for (int i = tid; i < K2_FAST_HIST; i += nthr) {
       const unsigned v = s_hist[i];
       if (v) atomicAdd(&gh[i], v);
     }
@@ -1384,7 +1400,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
 template <class Vote>
 __device__ __forceinline__ void k2_strict_item(const V3& fa, const V3& fb, const V3& fc, const double (*px)[2],
                                                const SolveParams& sp, int c0, int c1, int c2, int p0, int p1, int p2,
-                                               unsigned kmask, unsigned detmask, bool triple_voted, double* q, int qs,
+                                               unsigned kmask, u64 detmask, bool triple_voted, double* q, int qs,
                                                Vote vote) {
   const int n_m = sp.n_markers, nuo = n_m - 3;
   const V3 wa = {sp.markers[3 * p0], sp.markers[3 * p0 + 1], sp.markers[3 * p0 + 2]},
@@ -1410,8 +1426,8 @@ __device__ __forceinline__ void k2_strict_item(const V3& fa, const V3& fb, const
       ++j;
     }
     bool any = false;
-    for (unsigned dm = detmask; dm; dm &= dm - 1) {  // unused detections, ascending (pose_estimator.cpp:576-597, 862-906)
-      const int a = __builtin_ctz(dm);
+    for (u64 dm = detmask; dm; dm &= dm - 1) {  // unused detections, ascending (pose_estimator.cpp:576-597, 862-906)
+      const int a = __builtin_ctzll(dm);
       double best = INFINITY;
       int bj = 0;
       for (int jj = 0; jj < nuo; ++jj) {
@@ -1476,7 +1492,7 @@ __device__ __forceinline__ void k2_strict_frame(const mpe_detections* __restrict
     perm_from_index(pj, n_m, p0, p1, p2);
     const V3 fa = {s_iv[c0][0], s_iv[c0][1], s_iv[c0][2]}, fb = {s_iv[c1][0], s_iv[c1][1], s_iv[c1][2]},
              fc = {s_iv[c2][0], s_iv[c2][1], s_iv[c2][2]};
-    const unsigned unused = (0xFFFFFFFFu >> (32 - n_d)) & ~((1u << c0) | (1u << c1) | (1u << c2));
+    const u64 unused = (~0ull >> (64 - n_d)) & ~((1ull << c0) | (1ull << c1) | (1ull << c2));  // (n_d <= 64)
     k2_strict_item(fa, fb, fc, s_px, sp, c0, c1, c2, p0, p1, p2, 0xFu, unused, false, s_q + tid, nthr,
                    [&](const int a, const int m) { atomicAdd(&s_hist[a * MPE_MAX_MARKERS + m], 1u); });
   }
@@ -1502,22 +1518,37 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detection
 
 // Frames that lost a suspect entry to a full list (k2_sus_lost) are voted again, whole, with the strict loop nest: the
 // histogram is STORED over whatever the fast launch and the fix-up kernel left, the mark is cleared, the tail then
-// sees an ordinary frame.  A fixed grid: nothing lost since the last launch on this slot (ctl[1] == ctl[4], the rule)
-// -> every block leaves after one load; otherwise the blocks stride over the launch's frames looking for the mark.
-// The last block to finish records what has been handled (ctl[4]; ctl[5] counts the blocks).
+// sees an ordinary frame.  Frames too WIDE for the fast kernels (more than MPE_FAST_VOTE_DETECTIONS detections; they
+// carry the same mark and zeroed histogram rows) are voted here for the first time: every block of the launch takes
+// its share of such a frame's hypotheses and ADDS its votes (one frame of 64 detections and 5 markers is 2.5 M P3P
+// solves), and the last block to finish clears those marks.
+// Nothing marked since the last launch on this slot (ctl[1] + ctl[7] == ctl[4], the rule) -> every block leaves after
+// three loads; otherwise the blocks stride over the launch's frames looking for the mark.  The last block to finish
+// records what has been handled (ctl[4]; ctl[5] counts the blocks).
 __global__ __launch_bounds__(K2_THREADS) void k2_vote_relost(mpe_detections* __restrict__ dets, int n_frames, SolveParams sp,
                                                              uint32_t* __restrict__ hist, VoteFixup fx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double s_px[MPE_MAX_DETECTIONS][2];
   __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
   __shared__ unsigned s_hist[MPE_HIST_STRIDE];
-  const unsigned lost = fx.ctl[1];
+  __shared__ int s_last;
+  const unsigned lost = fx.ctl[1] + fx.ctl[7];
   if (lost == fx.ctl[4]) return;  // (only the last block of a launch writes ctl[4], after every block has read it)
-  for (int f = blockIdx.x; f < n_frames; f += gridDim.x) {
+  const bool any_wide = fx.ctl[7] != 0u;  // (cumulative: wide frames have passed through this slot at some time)
+  for (int f = any_wide ? 0 : (int)blockIdx.x; f < n_frames; f += any_wide ? 1 : (int)gridDim.x) {
     mpe_detections* d = dets + f;
     if (d->status != MPE_FRAME_VOTE_LIST_FULL) continue;  // (written by an earlier launch: uniform over the block)
+    const bool wide = d->n > MPE_FAST_VOTE_DETECTIONS;
+    uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
+    if (wide) {  // every block: its share of the frame; the mark stays until all of them are done
+      if (sp.n_markers >= 4)
+        k2_strict_frame<false>(d, sp, gh, f, (int)blockIdx.x, (int)gridDim.x, nullptr, smem, s_px, s_iv, s_hist);
+      __syncthreads();
+      continue;
+    }
+    if (f % (int)gridDim.x != (int)blockIdx.x) continue;  // a narrow frame: one block, the histogram stored
     if (d->n >= 4 && sp.n_markers >= 4)
-      k2_strict_frame<true>(d, sp, hist + (size_t)f * MPE_HIST_STRIDE, f, 0, 1, nullptr, smem, s_px, s_iv, s_hist);
+      k2_strict_frame<true>(d, sp, gh, f, 0, 1, nullptr, smem, s_px, s_iv, s_hist);
     __syncthreads();
     if (threadIdx.x == 0) {
       d->status = 0;
@@ -1527,11 +1558,25 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_relost(mpe_detections* __r
   }
   if (threadIdx.x == 0) {
     __threadfence();
-    if (atomicAdd(&fx.ctl[5], 1u) == gridDim.x - 1) {
-      fx.ctl[4] = lost;
-      fx.ctl[5] = 0;
-      __threadfence();
+    s_last = atomicAdd(&fx.ctl[5], 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (any_wide) {  // every block's votes are in: the wide frames become ordinary ones
+    for (int f = threadIdx.x; f < n_frames; f += blockDim.x) {
+      mpe_detections* d = dets + f;
+      if (d->status == MPE_FRAME_VOTE_LIST_FULL && d->n > MPE_FAST_VOTE_DETECTIONS) {
+        d->status = 0;
+        atomicAdd(&fx.ctl[6], 1u);
+      }
     }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    fx.ctl[4] = lost;
+    fx.ctl[5] = 0;
+    __threadfence();
   }
 }
 
@@ -1549,7 +1594,7 @@ __global__ __launch_bounds__(K2_FIX_THREADS) void k2_vote_fixup(const mpe_detect
   const int tid = threadIdx.x;
   for (unsigned i = blockIdx.x * K2_FIX_THREADS + tid; i < n; i += gridDim.x * K2_FIX_THREADS) {
     const u64 w0 = list[(size_t)K2_SUS_WORDS * i];
-    const unsigned detmask = (unsigned)list[(size_t)K2_SUS_WORDS * i + 1];
+    const u64 detmask = list[(size_t)K2_SUS_WORDS * i + 1];  // (32 bits: the fast kernels only vote frames that narrow)
     const int f = (int)(unsigned)w0;
     const unsigned code = (unsigned)(w0 >> 32);
     const int c0 = code & 31, c1 = (code >> 5) & 31, c2 = (code >> 10) & 31;
@@ -1579,8 +1624,8 @@ __global__ __launch_bounds__(K2_FIX_THREADS) void k2_vote_fixup(const mpe_detect
 }
 
 hipError_t launch_k2_fixup(mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist, const VoteFixup& fx,
-                           hipStream_t s) {
-  if (!fx.ctl || fx.cap == 0 || sp.n_markers < 4) return hipSuccess;
+                           hipStream_t s, int relost_blocks) {
+  if (!fx.ctl || fx.cap == 0 || sp.n_markers < 4 || n_frames <= 0) return hipSuccess;
   // (the entry count lives on the device: a fixed grid strides over it — wide, every entry is a single-wave chain of
   //  dependent FP64 operations (~30 us), and blocks beyond the count leave at once; ~0.15 % of the hypotheses)
   hipLaunchKernelGGL(k2_vote_fixup, dim3(2048), dim3(K2_FIX_THREADS), 0, s, dets, sp, hist, fx);
@@ -1591,7 +1636,10 @@ hipError_t launch_k2_fixup(mpe_detections* dets, int n_frames, const SolveParams
   // 256 blocks that only read two words took 0.39 ms there (profiles/round5_bench_kernel_stats.csv of the first
   // collection; 3 us serialised).  The lists are sized so that nothing is lost as a rule.
   const size_t lds_strict = (size_t)(sp.n_markers - 3) * 2 * K2_THREADS * sizeof(double);
-  hipLaunchKernelGGL(k2_vote_relost, dim3((unsigned)std::min(n_frames, 32)), dim3(K2_THREADS), lds_strict, s, dets,
+  // relost_blocks: the caller's choice — 32 where the launch sits beside a voting launch and nothing has ever been
+  // lost, the whole chip once frames have been (mpe_abi.cpp: relost_grid)
+  if (relost_blocks < 1) relost_blocks = 32;
+  hipLaunchKernelGGL(k2_vote_relost, dim3((unsigned)relost_blocks), dim3(K2_THREADS), lds_strict, s, dets,
                      n_frames, sp, hist, fx);
   return hipGetLastError();
 }

@@ -99,8 +99,8 @@ extern "C" void host_vote_stats(unsigned* out) {
 // variant 0: k2_vote<false> (back-projections in the LDS columns, votes on the spot); variant 1: k2_vote<true> as far as
 // one lane can run it (LDS copy of the table, back-projections by value, exact votes deferred through the queue)
 extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers, int n_m, const double* k4,
-                         double back_tol, unsigned* hist /* MPE_MAX_DETECTIONS x MPE_MAX_MARKERS */, int variant) {
-  if (n_d < 4 || n_m < 4 || n_d > MPE_MAX_DETECTIONS || n_m > MPE_MAX_MARKERS) return -1;
+                         double back_tol, unsigned* hist /* MPE_FAST_VOTE_DETECTIONS x MPE_MAX_MARKERS */, int variant) {
+  if (n_d < 4 || n_m < 4 || n_d > MPE_FAST_VOTE_DETECTIONS || n_m > MPE_MAX_MARKERS) return -1;
   SolveParams sp;
   std::memset(&sp, 0, sizeof(sp));
   sp.n_markers = n_m;
@@ -114,8 +114,8 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   const int esz = k2_entry_doubles(n_m);
   std::vector<double> tab((size_t)n_perms * esz);
   for (int pj = 0; pj < n_perms; ++pj) k2_marker_entry(sp, pj, tab.data() + (size_t)pj * esz);
-  double px[MPE_MAX_DETECTIONS][2], iv[MPE_MAX_DETECTIONS][3];
-  f32x2 pxf[MPE_MAX_DETECTIONS];
+  double px[MPE_FAST_VOTE_DETECTIONS][2], iv[MPE_FAST_VOTE_DETECTIONS][3];
+  f32x2 pxf[MPE_FAST_VOTE_DETECTIONS];
   for (int i = 0; i < n_d; ++i) {
     const double u = undist_xy[2 * i], v = undist_xy[2 * i + 1];
     px[i][0] = u;
@@ -131,7 +131,7 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   for (int i = 0; i < n_combos; ++i) k2_triple_entry(iv, n_d, i, sp.fx, sp.fy, sp.cx, sp.cy, tri.data() + (size_t)i * 13, trii[i]);
   std::vector<double> q(2 * nuo);
   std::vector<f32x2> qf(nuo);
-  std::memset(hist, 0, sizeof(unsigned) * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS);
+  std::memset(hist, 0, sizeof(unsigned) * MPE_FAST_VOTE_DETECTIONS * MPE_MAX_MARKERS);
   std::vector<double> ltab((size_t)n_perms * K2_LTAB);
   for (size_t i = 0; i < ltab.size(); ++i) ltab[i] = k2_ltab_value(tab.data(), esz, nuo, (int)i);
   std::vector<u64> vq((size_t)std::max(K2_VQ_CAP * K2_VQ_WORDS, K2_DQ_CAP * K2_DQ_WORDS), 0);
@@ -265,18 +265,18 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
   return 0;
 }
 
-// n detection sets in one call (tests/soak_votes_host.py): det n x MPE_MAX_DETECTIONS x 2, hist n x MPE_MAX_DETECTIONS
+// n detection sets in one call (tests/soak_votes_host.py): det n x MPE_FAST_VOTE_DETECTIONS x 2, hist n x MPE_FAST_VOTE_DETECTIONS
 // x MPE_MAX_MARKERS
 extern "C" int host_vote_batch(const double* det, const int* n_det, int n, const double* markers, int n_m, const double* k4,
                                double back_tol, unsigned* hist, int variant, unsigned* stats_sum /* 3, optional */) {
   if (stats_sum) stats_sum[0] = stats_sum[1] = stats_sum[2] = 0;
   for (int i = 0; i < n; ++i) {
-    unsigned* h = hist + (size_t)i * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS;
+    unsigned* h = hist + (size_t)i * MPE_FAST_VOTE_DETECTIONS * MPE_MAX_MARKERS;
     if (n_det[i] < 4) {
-      std::memset(h, 0, sizeof(unsigned) * MPE_MAX_DETECTIONS * MPE_MAX_MARKERS);
+      std::memset(h, 0, sizeof(unsigned) * MPE_FAST_VOTE_DETECTIONS * MPE_MAX_MARKERS);
       continue;
     }
-    const int rc = host_vote(det + (size_t)i * 2 * MPE_MAX_DETECTIONS, n_det[i], markers, n_m, k4, back_tol, h, variant);
+    const int rc = host_vote(det + (size_t)i * 2 * MPE_FAST_VOTE_DETECTIONS, n_det[i], markers, n_m, k4, back_tol, h, variant);
     if (rc) return rc;
     if (stats_sum)
       for (int j = 0; j < 3; ++j) stats_sum[j] += g_stats[j];

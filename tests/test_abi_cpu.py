@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_struct_layouts_match_header(lib):
     assert ctypes.sizeof(mpe.MpeResult) == 16 * 8 + 36 * 8 + 4 * 4
-    assert ctypes.sizeof(mpe.MpeDetections) == 8 + 64 * 8 + 64 * 4
+    assert ctypes.sizeof(mpe.MpeDetections) == 8 + 128 * 8 + 128 * 4   # MPE_MAX_DETECTIONS = 64 since round 6
     assert ctypes.sizeof(mpe.MpeParams) == 8 + 9 * 8 + 8
 
 

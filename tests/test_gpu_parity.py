@@ -191,17 +191,74 @@ def test_general_tier_band_scan_on_random_clutter(hip, orc):
                 assert np.array_equal(got["undist_xy"][i][:2 * len(und)].reshape(-1, 2), und), (rows, thr, i)
 
 
-def test_too_many_detections_is_loud(hip, orc):
-    """> MPE_MAX_DETECTIONS blobs pass the filter: status -10 on that frame, never silent."""
+def _wide_frame(rng, n_spots, K, D, rows=480, cols=752):
+    """A C2 scene (5 LEDs) + distractor spots, n_spots blobs in all, >= 12 px apart."""
+    for _ in range(50):
+        T, spots = synth.sample_scene(rng, synth.M5, K, D, rows, cols, n_distractors=n_spots - 5)
+        if len(spots) == n_spots:
+            return synth.render_frame(rng, spots, rows, cols)
+    raise AssertionError("could not place %d spots" % n_spots)
+
+
+def test_frames_with_33_to_64_detections_match_the_oracle(hip, orc):
+    """The reference has no limit on the detections of a frame (led_detector.cpp:65-86 loops over every contour,
+    pose_estimator.cpp:549-557 builds the vote table for any image_points_.size()).  Until round 5 more than 32 were a
+    capacity status; now up to MPE_MAX_DETECTIONS = 64 go through the whole brute-force path — wider frames than the
+    fast voting kernels' 32-bit masks are voted by the strict loop nest (k2_vote_relost) — and have to equal the oracle:
+    detections bit for bit, vote histogram integer-equal, correspondences, status, pose.  Beyond 64: status -10 with
+    the first 64 detections of the reference's order, never silent."""
+    assert mpe.MAX_DETECTIONS == 64
     K, D = synth.camera_for(480, 752)
     rng = np.random.default_rng(8)
-    spots = np.stack([rng.uniform(20, 730, 60), rng.uniform(20, 460, 60)], 1)
-    frames = synth.render_frame(rng, spots, 480, 752)[None]
+    Po, Ph = orc.make_params(), mpe.demo_params()
+    frames = np.stack([_wide_frame(rng, n, K, D) for n in (33, 41, 64, 32, 5)])
+    got = hip.detect_batch(frames, K, D, Ph)
+    wide0 = hip.get_option("vote_wide_frames")
+    res = hip.estimate_batch(frames, synth.M5, K, D, Ph)  # (a batch that mixes wide and narrow frames)
+    assert hip.get_option("vote_wide_frames") == wide0 + 3
+    n_seen = []
+    for i, f in enumerate(frames):
+        und, dist = orc.find_leds(f, Po, K, D)
+        n_seen.append(len(und))
+        assert got["status"][i] == 0 and got["n"][i] == len(und), (i, got["n"][i], len(und))
+        assert np.array_equal(got["dist_xy"][i][:2 * len(und)].reshape(-1, 2), dist), i
+        assert np.array_equal(got["undist_xy"][i][:2 * len(und)].reshape(-1, 2), und), i
+        ro = orc.solve_bruteforce(und, synth.M5, K, Po)
+        rh = hip.solve_bruteforce(und, synth.M5, K, Ph)
+        assert np.array_equal(rh["hist"], ro["hist"]), (i, len(und), np.argwhere(rh["hist"] != ro["hist"])[:6])
+        assert rh["status"] == ro["status"] and rh["n_corr"] == ro["n_corr"], (i, rh["status"], ro["status"])
+        assert np.array_equal(rh["corr"], ro["corr"]), i
+        # ... and the same frame inside the mixed batch
+        assert res["status"][i] == ro["status"] and res["n_det"][i] == len(und) and res["n_corr"][i] == ro["n_corr"], i
+        if ro["status"] == 0:
+            for T in (rh["T"], res["T"][i]):
+                dp, dr = pose_diff(T, ro["T"])
+                assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (i, dp, dr)
+        if len(und) > 32:  # the strict kernel and the stage-level vote entry on a wide frame
+            hip.set_option("vote_arith", 0)
+            try:
+                hs = hip.vote_batch([und], synth.M5, K, 5.0)[0]
+            finally:
+                hip.set_option("vote_arith", 1)
+            assert np.array_equal(hs, ro["hist"]), i
+            assert np.array_equal(hip.vote_batch([und], synth.M5, K, 5.0)[0], ro["hist"]), i
+    assert n_seen[:3] == [33, 41, 64] and n_seen[3] <= 32, n_seen
+    # 8 markers (the plain voting kernels) against 36 detections
+    und = np.column_stack([rng.uniform(150, 600, 36), rng.uniform(100, 380, 36)])
+    M8 = synth.CONFIGS["C3"]["markers"]
+    assert np.array_equal(hip.vote_batch([und], M8, K, 5.0)[0], orc.vote_histogram(und, M8, K, 5.0))
+
+
+def test_too_many_detections_is_loud(hip, orc):
+    """> MPE_MAX_DETECTIONS (64) blobs pass the filter: status -10 on that frame, never silent."""
+    K, D = synth.camera_for(480, 752)
+    rng = np.random.default_rng(8)
+    frames = _wide_frame(rng, 90, K, D)[None]
     got = hip.detect_batch(frames, K, D, mpe.demo_params())
     und, dist = orc.find_leds(frames[0], orc.make_params(), K, D)
     assert len(und) > mpe.MAX_DETECTIONS
     assert got["status"][0] == -10 and got["n"][0] == mpe.MAX_DETECTIONS
-    assert np.array_equal(got["dist_xy"][0][:64].reshape(-1, 2), dist[:32])
+    assert np.array_equal(got["dist_xy"][0][:2 * mpe.MAX_DETECTIONS].reshape(-1, 2), dist[:mpe.MAX_DETECTIONS])
     res = hip.estimate_batch(frames, synth.M5, K, D, mpe.demo_params())
     assert res["status"][0] == -10
 
@@ -462,7 +519,7 @@ def test_abi_error_paths_are_loud(hip):
     with pytest.raises(mpe.MpeError):            # > MPE_MAX_MARKERS
         hip.solve_bruteforce(det, np.random.default_rng(1).normal(size=(17, 3)), K, P)
     with pytest.raises(mpe.MpeError):            # > MPE_MAX_DETECTIONS
-        hip.solve_bruteforce(np.random.default_rng(2).uniform(0, 400, (33, 2)), synth.M5, K, P)
+        hip.solve_bruteforce(np.random.default_rng(2).uniform(0, 400, (65, 2)), synth.M5, K, P)
     with pytest.raises(mpe.MpeError):            # correspondence index out of range
         hip.check_and_refine(det, synth.M5, K, P, np.array([[1, 1], [2, 2], [3, 3], [9, 4]], np.uint32))
 

@@ -460,8 +460,8 @@ def test_capacity_overrun_is_reported_alike_by_single_and_batch_replays(orc):
     seq = synth.make_sequence("C2", 8, seed=61)
     frames = seq["frames"].copy()
     rng = np.random.default_rng(8)
-    spots = np.stack([rng.uniform(20, 730, 60), rng.uniform(20, 460, 60)], 1)
-    # the FIRST frame (whole-image detection: the estimator is not initialised yet) shows 60 blobs, more than
+    spots = np.stack([rng.uniform(20, 730, 130), rng.uniform(20, 460, 130)], 1)
+    # the FIRST frame (whole-image detection: the estimator is not initialised yet) shows ~120 blobs, more than
     # MPE_MAX_DETECTIONS; the ordinary sequence follows
     frames[0] = synth.render_frame(rng, spots, 480, 752)
     times = seq["times"]
