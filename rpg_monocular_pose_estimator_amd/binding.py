@@ -12,7 +12,7 @@ _LIB = os.environ.get("MPE_LIB") or os.path.join(_HERE, "libmpe_hip.so")  # MPE_
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "mpe.h")
 
 MAX_MARKERS = 16
-MAX_DETECTIONS = 64
+MAX_DETECTIONS = int(os.environ.get("MPE_MAX_DET", "64"))  # (MPE_MAX_DET: A/B runs against a library built with another capacity)
 
 
 class MpeError(RuntimeError):

@@ -1737,7 +1737,8 @@ int vote_batch_impl(mpe_handle* h, const double* det_xy, const int* n_det, int n
                             h->stream, nullptr, 0, nullptr, 0, nullptr, d_range, &fx));
   HIP_TRY(h, fixup_launch(h, 0, static_cast<mpe_detections*>(h->dets.p), n_frames, sp, static_cast<uint32_t*>(h->hist.p), fx,
                           h->stream));
-  HIP_TRY(h, hipMemcpyAsync(hist, h->hist.p, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t),
+  HIP_TRY(h, hipMemcpy2DAsync(hist, MPE_HIST_WORDS * sizeof(uint32_t), h->hist.p, MPE_HIST_STRIDE * sizeof(uint32_t),
+                              MPE_HIST_WORDS * sizeof(uint32_t), (size_t)n_frames,
                             hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPE_OK;
@@ -2415,7 +2416,9 @@ int mpe_solve_bruteforce_batch(mpe_handle* h, const double* det_xy, const int* n
                             static_cast<mpe_result*>(h->results.p), static_cast<uint32_t*>(h->corr.p), nullptr, nullptr,
                             0.0, h->mid.p, h->stream));
   HIP_TRY(h, hipMemcpyAsync(out, h->results.p, (size_t)n * sizeof(mpe_result), hipMemcpyDeviceToHost, h->stream));
-  if (hist) HIP_TRY(h, hipMemcpyAsync(hist, h->hist.p, hist_bytes, hipMemcpyDeviceToHost, h->stream));
+  if (hist)  // (device rows are MPE_HIST_STRIDE words apart, the caller's MPE_HIST_WORDS)
+    HIP_TRY(h, hipMemcpy2DAsync(hist, MPE_HIST_WORDS * sizeof(uint32_t), h->hist.p, MPE_HIST_STRIDE * sizeof(uint32_t),
+                                MPE_HIST_WORDS * sizeof(uint32_t), (size_t)n, hipMemcpyDeviceToHost, h->stream));
   if (corr) HIP_TRY(h, hipMemcpyAsync(corr, h->corr.p, corr_bytes, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MPE_OK;

@@ -59,7 +59,12 @@ struct SolveParams {
   int refine_variant;     // option "refine_variant": 0 automatic, 1 one lane per frame, 2 sixteen lanes per frame
 };
 
-#define MPE_HIST_STRIDE (MPE_MAX_DETECTIONS * MPE_MAX_MARKERS)
+// A frame's vote histogram: MPE_HIST_WORDS = MPE_MAX_DETECTIONS x MPE_MAX_MARKERS words (the shape the C ABI hands out),
+// on the device MPE_HIST_STRIDE words apart — 33 x 128 B, not the 4 KB of the bare table: a power-of-two stride puts
+// the few rows every frame of a launch writes (5 x 64 B at C2) onto the same HBM channels, and the voting launch that
+// carries the scan paid for it (round 6: 1.54 -> 1.66 ms per launch when the table went from 2 KB to 4 KB).
+#define MPE_HIST_WORDS (MPE_MAX_DETECTIONS * MPE_MAX_MARKERS)
+#define MPE_HIST_STRIDE (MPE_HIST_WORDS + 32)
 
 // Hypotheses a fast voting launch does not decide itself (mpe_k2.hip, k2_sus_push): a list in device memory that
 // launch_k2_fixup works off with the strict arithmetic, behind the voting launch and in front of the tail.

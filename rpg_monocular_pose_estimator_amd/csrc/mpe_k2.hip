@@ -1469,7 +1469,7 @@ __device__ __forceinline__ void k2_strict_frame(const mpe_detections* __restrict
                                                 double (*s_px)[2], double (*s_iv)[3], unsigned* s_hist) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int n_d = d->n, n_m = sp.n_markers;
-  for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) s_hist[i] = 0;
+  for (int i = tid; i < MPE_HIST_WORDS; i += nthr) s_hist[i] = 0;
   if (tid < n_d) {
     const double u = d->undist_xy[2 * tid], v = d->undist_xy[2 * tid + 1];
     s_px[tid][0] = u;
@@ -1497,7 +1497,7 @@ __device__ __forceinline__ void k2_strict_frame(const mpe_detections* __restrict
                    [&](const int a, const int m) { atomicAdd(&s_hist[a * MPE_MAX_MARKERS + m], 1u); });
   }
   __syncthreads();
-  for (int i = tid; i < MPE_HIST_STRIDE; i += nthr) {
+  for (int i = tid; i < MPE_HIST_WORDS; i += nthr) {
     const unsigned v = s_hist[i];
     if constexpr (STORE) gh[i] = v;
     else if (v) atomicAdd(&gh[i], v);
@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detection
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double s_px[MPE_MAX_DETECTIONS][2];
   __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
-  __shared__ unsigned s_hist[MPE_HIST_STRIDE];
+  __shared__ unsigned s_hist[MPE_HIST_WORDS];
   const int f = blockIdx.x / splits, part = blockIdx.x - f * splits;
   const mpe_detections* d = dets + f;
   if (d->n < 4 || d->status != 0 || sp.n_markers < 4) return;
@@ -1530,7 +1530,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_relost(mpe_detections* __r
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double s_px[MPE_MAX_DETECTIONS][2];
   __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
-  __shared__ unsigned s_hist[MPE_HIST_STRIDE];
+  __shared__ unsigned s_hist[MPE_HIST_WORDS];
   __shared__ int s_last;
   const unsigned lost = fx.ctl[1] + fx.ctl[7];
   if (lost == fx.ctl[4]) return;  // (only the last block of a launch writes ctl[4], after every block has read it)
