@@ -381,7 +381,7 @@ int stage_frames(mpe_handle* h, const uint8_t* frames, int n_frames, int rows, i
 // each block a share of the marker PERMUTATIONS whose table slice it keeps in LDS (6 .. 10 markers, fast arithmetic)
 int auto_splits(const mpe_handle* h, int n_frames, int n_markers) {
   if (h->vote_splits > 0) return h->vote_splits;
-  if (h->vote_arith != 0 && h->vote_splits == 0) {
+  if (!vote_arith_is_strict(h->vote_arith) && h->vote_splits == 0) {
     const int slices = k2_table_slices(n_markers);
     if (slices > 0) return -slices;
   }
@@ -415,7 +415,7 @@ int fix_counter_sum(mpe_handle* h, int which, unsigned long long& out) {
 int vote_fixup_for(mpe_handle* h, int slot, int n_slots, int n_frames, int n_markers, int n_det_hint, hipStream_t st,
                    VoteFixup& fx) {
   fx = VoteFixup{nullptr, nullptr, 0u, 0u};
-  if (h->vote_arith == 0 || n_markers < 4 || slot < 0 || slot >= mpe_handle::kMaxSub) return MPE_OK;
+  if (vote_arith_is_strict(h->vote_arith) || n_markers < 4 || slot < 0 || slot >= mpe_handle::kMaxSub) return MPE_OK;
   n_slots = std::min((int)mpe_handle::kMaxSub, std::max(n_slots, slot + 1));
   // (wider frames than MPE_FAST_VOTE_DETECTIONS append nothing: the strict loop nest votes them)
   const long long nd = n_frames <= 256 ? MPE_FAST_VOTE_DETECTIONS
@@ -465,7 +465,7 @@ int vote_fixup_for(mpe_handle* h, int slot, int n_slots, int n_frames, int n_mar
   fx.list = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(h->fix.p) + kFixCtlBytes) +
             (size_t)slot * h->fix_cap * 2;
   fx.cap = h->fix_cap;
-  fx.screen = h->vote_arith == 1 ? 1u : 0u;
+  fx.screen = vote_arith_screens(h->vote_arith) ? 1u : 0u;
   if (h->fix_pending[slot]) {  // an earlier call failed between a voting launch and its fix-up: drop those entries
     HIP_TRY(h, hipMemsetAsync(fx.ctl, 0, sizeof(unsigned), st));
     HIP_TRY(h, hipMemsetAsync(fx.ctl + 2, 0, sizeof(unsigned), st));
@@ -641,7 +641,7 @@ void sub_batch_shape(const mpe_handle* h, int n_frames, size_t frame_bytes, bool
   if (nsub > h->pipeline) nsub = h->pipeline;
   if (nsub > mpe_handle::kMaxSub) nsub = mpe_handle::kMaxSub;
   if (nsub < 1 || !have_sp) nsub = 1;
-  if (have_sp && vote_arith == 0) nsub = 1;  // strict voting arithmetic: one plain chain of kernels (no scan rider)
+  if (have_sp && vote_arith_is_strict(vote_arith)) nsub = 1;  // strict voting arithmetic: one plain chain of kernels (no scan rider)
   // frames per sub-batch: multiple of 64 so every sub-batch starts on a 16-byte / flag-word boundary
   per = nsub > 1 ? (((n_frames + nsub - 1) / nsub + 63) & ~63) : n_frames;
 }
@@ -1004,7 +1004,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], st));
       uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
       // (with one voting block per frame the kernel stores every histogram row the tail reads: no memset)
-      if (sp->vote_arith == 0 || auto_splits(h, nf, sp->n_markers) != 1)
+      if (vote_arith_is_strict(sp->vote_arith) || auto_splits(h, nf, sp->n_markers) != 1)
         HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), st));
       const uint8_t* nfr = nullptr;
       unsigned long long* nfl = nullptr;
@@ -1600,8 +1600,9 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
     return MPE_OK;
   }
   if (!std::strcmp(name, "vote_arith")) {
-    if (value < 0 || value > 2)
-      return fail(h, MPE_ERR_ARG, "vote_arith must be 0 (strict), 1 (fast + strict re-evaluation of suspects) or 2 (fast alone)");
+    if (value < 0 || value > 4)
+      return fail(h, MPE_ERR_ARG, "vote_arith must be 0 (strict), 1 (fast + strict re-evaluation of suspects), 2 (fast alone), "
+                                  "3 (as 1) or 4 (as 0) with the quartic's complex powers as libstdc++ / glibc evaluate them");
     h->vote_arith = value;
     return MPE_OK;
   }

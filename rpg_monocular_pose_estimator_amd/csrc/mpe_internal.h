@@ -55,9 +55,15 @@ struct SolveParams {
   double valid_corr_thr;  // valid_correspondence_threshold_
   unsigned hist_thr;      // histogram_threshold_
   int vote_arith;         // option "vote_arith": 1 fast voting arithmetic + strict re-evaluation of the hypotheses it
-                          // cannot decide (default), 0 strict (IEEE, literal order), 2 fast alone (round-3 behaviour)
+                          // cannot decide (default), 0 strict (IEEE, literal order), 2 fast alone (round-3 behaviour);
+                          // round 6: 3 = 1 and 4 = 0 with the quartic's three complex powers evaluated as libstdc++ /
+                          // glibc do (mpe_ddmath.h) — the CPU reference's own digits in Ferrari's unstable corner
   int refine_variant;     // option "refine_variant": 0 automatic, 1 one lane per frame, 2 sixteen lanes per frame
 };
+
+__host__ __device__ inline bool vote_arith_is_strict(int a) { return a == 0 || a == 4; }   // the strict kernel votes
+__host__ __device__ inline bool vote_arith_screens(int a) { return a == 1 || a == 3; }     // fast kernel + suspect list
+__host__ __device__ inline bool vote_arith_glibc_pow(int a) { return a == 3 || a == 4; }   // strict item: glibc's powers
 
 // A frame's vote histogram: MPE_HIST_WORDS = MPE_MAX_DETECTIONS x MPE_MAX_MARKERS words (the shape the C ABI hands out),
 // on the device MPE_HIST_STRIDE words apart — 33 x 128 B, not the 4 KB of the bare table: a power-of-two stride puts

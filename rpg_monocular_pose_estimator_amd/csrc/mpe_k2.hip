@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
 // detections to decide (k2_vote_strict: all four, every detection outside the triple; k2_vote_fixup: what the fast
 // kernel left undecided), `triple_voted`: the triple's own three votes of that root have been cast already.
 // q: 2 * (n_m - 3) doubles of scratch per lane, element i at q[i * qs].  vote(detection, marker) casts one vote.
-template <class Vote>
+template <bool GLIBC, class Vote>
 __device__ __forceinline__ void k2_strict_item(const V3& fa, const V3& fb, const V3& fc, const double (*px)[2],
                                                const SolveParams& sp, int c0, int c1, int c2, int p0, int p1, int p2,
                                                unsigned kmask, u64 detmask, bool triple_voted, double* q, int qs,
@@ -1407,7 +1407,9 @@ __device__ __forceinline__ void k2_strict_item(const V3& fa, const V3& fb, const
            wb = {sp.markers[3 * p1], sp.markers[3 * p1 + 1], sp.markers[3 * p1 + 2]},
            wc = {sp.markers[3 * p2], sp.markers[3 * p2 + 1], sp.markers[3 * p2 + 2]};
   P3PCtx ctx;
-  if (!p3p_prepare(fa, fb, fc, wa, wb, wc, ctx)) return;  // computePoses returned -1
+  // (GLIBC — vote_arith 3 / 4: the three complex powers of the quartic as libstdc++ / glibc evaluate them, mpe_ddmath.h;
+  //  a template argument, so that the kernels of the other arithmetics are the code they were)
+  if (!p3p_prepare(fa, fb, fc, wa, wb, wc, ctx, GLIBC)) return;  // computePoses returned -1
 #pragma unroll 1
   for (int k = 0; k < 4; ++k) {
     if (!((kmask >> k) & 1u)) continue;
@@ -1462,7 +1464,7 @@ __device__ __forceinline__ void k2_strict_item(const V3& fa, const V3& fb, const
 // point the default arithmetic is held against, selectable at run time.
 // One frame's share `part` of `splits` of initialise()'s loop nest with the strict item, votes collected in LDS and
 // then ADDED to (STORE = false) or STORED over (true: a whole frame by one block) the frame's histogram.
-template <bool STORE>
+template <bool STORE, bool GLIBC>
 __device__ __forceinline__ void k2_strict_frame(const mpe_detections* __restrict__ d, const SolveParams& sp,
                                                 uint32_t* __restrict__ gh, int f, int part, int splits,
                                                 const int* __restrict__ item_range, unsigned char* smem,
@@ -1493,7 +1495,7 @@ __device__ __forceinline__ void k2_strict_frame(const mpe_detections* __restrict
     const V3 fa = {s_iv[c0][0], s_iv[c0][1], s_iv[c0][2]}, fb = {s_iv[c1][0], s_iv[c1][1], s_iv[c1][2]},
              fc = {s_iv[c2][0], s_iv[c2][1], s_iv[c2][2]};
     const u64 unused = (~0ull >> (64 - n_d)) & ~((1ull << c0) | (1ull << c1) | (1ull << c2));  // (n_d <= 64)
-    k2_strict_item(fa, fb, fc, s_px, sp, c0, c1, c2, p0, p1, p2, 0xFu, unused, false, s_q + tid, nthr,
+    k2_strict_item<GLIBC>(fa, fb, fc, s_px, sp, c0, c1, c2, p0, p1, p2, 0xFu, unused, false, s_q + tid, nthr,
                    [&](const int a, const int m) { atomicAdd(&s_hist[a * MPE_MAX_MARKERS + m], 1u); });
   }
   __syncthreads();
@@ -1503,6 +1505,7 @@ __device__ __forceinline__ void k2_strict_frame(const mpe_detections* __restrict
     else if (v) atomicAdd(&gh[i], v);
   }
 }
+template <bool GLIBC>
 __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detections* __restrict__ dets, SolveParams sp,
                                                              uint32_t* __restrict__ hist, int splits,
                                                              const int* __restrict__ item_range) {
@@ -1513,7 +1516,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detection
   const int f = blockIdx.x / splits, part = blockIdx.x - f * splits;
   const mpe_detections* d = dets + f;
   if (d->n < 4 || d->status != 0 || sp.n_markers < 4) return;
-  k2_strict_frame<false>(d, sp, hist + (size_t)f * MPE_HIST_STRIDE, f, part, splits, item_range, smem, s_px, s_iv, s_hist);
+  k2_strict_frame<false, GLIBC>(d, sp, hist + (size_t)f * MPE_HIST_STRIDE, f, part, splits, item_range, smem, s_px, s_iv, s_hist);
 }
 
 // Frames that lost a suspect entry to a full list (k2_sus_lost) are voted again, whole, with the strict loop nest: the
@@ -1525,6 +1528,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detection
 // Nothing marked since the last launch on this slot (ctl[1] + ctl[7] == ctl[4], the rule) -> every block leaves after
 // three loads; otherwise the blocks stride over the launch's frames looking for the mark.  The last block to finish
 // records what has been handled (ctl[4]; ctl[5] counts the blocks).
+template <bool GLIBC>
 __global__ __launch_bounds__(K2_THREADS) void k2_vote_relost(mpe_detections* __restrict__ dets, int n_frames, SolveParams sp,
                                                              uint32_t* __restrict__ hist, VoteFixup fx) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1542,13 +1546,13 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_relost(mpe_detections* __r
     uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
     if (wide) {  // every block: its share of the frame; the mark stays until all of them are done
       if (sp.n_markers >= 4)
-        k2_strict_frame<false>(d, sp, gh, f, (int)blockIdx.x, (int)gridDim.x, nullptr, smem, s_px, s_iv, s_hist);
+        k2_strict_frame<false, GLIBC>(d, sp, gh, f, (int)blockIdx.x, (int)gridDim.x, nullptr, smem, s_px, s_iv, s_hist);
       __syncthreads();
       continue;
     }
     if (f % (int)gridDim.x != (int)blockIdx.x) continue;  // a narrow frame: one block, the histogram stored
     if (d->n >= 4 && sp.n_markers >= 4)
-      k2_strict_frame<true>(d, sp, gh, f, 0, 1, nullptr, smem, s_px, s_iv, s_hist);
+      k2_strict_frame<true, GLIBC>(d, sp, gh, f, 0, 1, nullptr, smem, s_px, s_iv, s_hist);
     __syncthreads();
     if (threadIdx.x == 0) {
       d->status = 0;
@@ -1585,6 +1589,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_relost(mpe_detections* __r
 // same stream, or an event in between).  The last block to finish resets the list's fill count for the next launch
 // and adds the number of entries to the cumulative counter (ctl[3]).
 #define K2_FIX_THREADS 64
+template <bool GLIBC>
 __global__ __launch_bounds__(K2_FIX_THREADS) void k2_vote_fixup(const mpe_detections* __restrict__ dets, SolveParams sp,
                                                                 uint32_t* __restrict__ hist, VoteFixup fx) {
   __shared__ double s_q[2 * (MPE_MAX_MARKERS - 3) * K2_FIX_THREADS];
@@ -1608,7 +1613,7 @@ __global__ __launch_bounds__(K2_FIX_THREADS) void k2_vote_fixup(const mpe_detect
              fb = bearing(px[c1][0], px[c1][1], sp.fx, sp.fy, sp.cx, sp.cy),
              fc = bearing(px[c2][0], px[c2][1], sp.fx, sp.fy, sp.cx, sp.cy);
     uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
-    k2_strict_item(fa, fb, fc, px, sp, c0, c1, c2, p0, p1, p2, kmask, detmask, triple_voted, s_q + tid, K2_FIX_THREADS,
+    k2_strict_item<GLIBC>(fa, fb, fc, px, sp, c0, c1, c2, p0, p1, p2, kmask, detmask, triple_voted, s_q + tid, K2_FIX_THREADS,
                    [&](const int a, const int m) { atomicAdd(&gh[a * MPE_MAX_MARKERS + m], 1u); });
   }
   __syncthreads();
@@ -1628,7 +1633,11 @@ hipError_t launch_k2_fixup(mpe_detections* dets, int n_frames, const SolveParams
   if (!fx.ctl || fx.cap == 0 || sp.n_markers < 4 || n_frames <= 0) return hipSuccess;
   // (the entry count lives on the device: a fixed grid strides over it — wide, every entry is a single-wave chain of
   //  dependent FP64 operations (~30 us), and blocks beyond the count leave at once; ~0.15 % of the hypotheses)
-  hipLaunchKernelGGL(k2_vote_fixup, dim3(2048), dim3(K2_FIX_THREADS), 0, s, dets, sp, hist, fx);
+  const bool glibc = vote_arith_glibc_pow(sp.vote_arith);
+  if (glibc)
+    hipLaunchKernelGGL(k2_vote_fixup<true>, dim3(2048), dim3(K2_FIX_THREADS), 0, s, dets, sp, hist, fx);
+  else
+    hipLaunchKernelGGL(k2_vote_fixup<false>, dim3(2048), dim3(K2_FIX_THREADS), 0, s, dets, sp, hist, fx);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // frames that lost an entry to a full list: voted again with the strict loop nest.  A SMALL grid: the launch sits in
@@ -1639,8 +1648,12 @@ hipError_t launch_k2_fixup(mpe_detections* dets, int n_frames, const SolveParams
   // relost_blocks: the caller's choice — 32 where the launch sits beside a voting launch and nothing has ever been
   // lost, the whole chip once frames have been (mpe_abi.cpp: relost_grid)
   if (relost_blocks < 1) relost_blocks = 32;
-  hipLaunchKernelGGL(k2_vote_relost, dim3((unsigned)relost_blocks), dim3(K2_THREADS), lds_strict, s, dets,
-                     n_frames, sp, hist, fx);
+  if (glibc)
+    hipLaunchKernelGGL(k2_vote_relost<true>, dim3((unsigned)relost_blocks), dim3(K2_THREADS), lds_strict, s, dets,
+                       n_frames, sp, hist, fx);
+  else
+    hipLaunchKernelGGL(k2_vote_relost<false>, dim3((unsigned)relost_blocks), dim3(K2_THREADS), lds_strict, s, dets,
+                       n_frames, sp, hist, fx);
   return hipGetLastError();
 }
 
@@ -1652,13 +1665,13 @@ hipError_t launch_k2_vote(mpe_detections* dets, int n_frames, const SolveParams&
   // vote_arith 1: suspect hypotheses go to `fixup` (the caller launches launch_k2_fixup behind this kernel);
   // 2: the fast arithmetic decides everything itself (round-3 behaviour, for A/B measurements); 0: strict kernel
   VoteFixup fx = {nullptr, nullptr, 0u, 0u};
-  if (sp.vote_arith != 0 && fixup && fixup->ctl && fixup->list) {
+  if (!vote_arith_is_strict(sp.vote_arith) && fixup && fixup->ctl && fixup->list) {
     fx = *fixup;
-    fx.screen = sp.vote_arith == 1 ? 1u : 0u;
+    fx.screen = vote_arith_screens(sp.vote_arith) ? 1u : 0u;
   }
   if (n_frames <= 0 || sp.n_markers < 4) return hipSuccess;
   // the fast kernels append to the list (suspects, or what their per-wave queues cannot hold): they need one
-  if (sp.vote_arith != 0 && !fx.ctl) return hipErrorInvalidValue;
+  if (!vote_arith_is_strict(sp.vote_arith) && !fx.ctl) return hipErrorInvalidValue;
   int slice_tab = 0;
   if (splits < 0) {  // -(blocks per frame): the blocks share the marker permutations, table slices in LDS
     splits = -splits;
@@ -1666,10 +1679,14 @@ hipError_t launch_k2_vote(mpe_detections* dets, int n_frames, const SolveParams&
   }
   if (splits < 1) splits = 1;
   const int nuo = sp.n_markers - 3;
-  if (sp.vote_arith == 0) {  // strict arithmetic: the validation kernel's P3P, no tables, no scan rider
+  if (vote_arith_is_strict(sp.vote_arith)) {  // strict arithmetic: the validation kernel's P3P, no tables, no scan rider
     const size_t lds_strict = (size_t)nuo * 2 * K2_THREADS * sizeof(double);
-    hipLaunchKernelGGL(k2_vote_strict, dim3((unsigned)(n_frames * splits)), dim3(K2_THREADS), lds_strict, s, dets, sp,
-                       hist, splits, item_range);
+    if (vote_arith_glibc_pow(sp.vote_arith))
+      hipLaunchKernelGGL(k2_vote_strict<true>, dim3((unsigned)(n_frames * splits)), dim3(K2_THREADS), lds_strict, s, dets,
+                         sp, hist, splits, item_range);
+    else
+      hipLaunchKernelGGL(k2_vote_strict<false>, dim3((unsigned)(n_frames * splits)), dim3(K2_THREADS), lds_strict, s, dets,
+                         sp, hist, splits, item_range);
     return hipGetLastError();
   }
   // block size: the multiple of 64 (<= 256) that wastes the fewest lanes on the expected item count

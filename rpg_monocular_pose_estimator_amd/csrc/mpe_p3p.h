@@ -7,6 +7,7 @@
 // through and are filtered by the caller (pose_estimator.cpp:653).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "mpe_ddmath.h"
 
 namespace mpe {
 
@@ -63,13 +64,15 @@ __device__ __forceinline__ C2 cdiv(C2 n, C2 d) {
   double ratio = e / c, denom = e * ratio + c;
   return {(b * ratio + a) / denom, (b - a * ratio) / denom};
 }
-// principal square root
+// principal square root (glibc csqrt for operands in the normal range).  GLIBC: |z| by glibc's own hypot kernel
+// (mpe_ddmath.h) instead of the device library's
+template <bool GLIBC = false>
 __device__ __forceinline__ C2 csqrt_(C2 z) {
   if (z.im == 0.0) {
     if (z.re < 0.0) return {0.0, copysign(sqrt(-z.re), z.im)};
     return {fabs(sqrt(z.re)), z.im};
   }
-  double d = hypot(z.re, z.im);
+  double d = GLIBC ? ddm::hypot_g(z.re, z.im) : hypot(z.re, z.im);
   double r, s;
   if (z.re > 0.0) {
     r = sqrt(0.5 * (d + z.re));
@@ -105,7 +108,18 @@ __device__ __forceinline__ C2 cpow3_real(double p) {
   return {m, 0.0};
 }
 
+// ... and the same three powers as libstdc++ / glibc evaluate them (mpe_ddmath.h: exp(y log|z|) through clog's branches,
+// correctly rounded primitives) — option "vote_arith" = 3
+__device__ __forceinline__ C2 cpow_glibc(C2 z, double y) {
+  C2 r;
+  ddm::cpow_g(z.re, z.im, y, r.re, r.im);
+  return r;
+}
+
 // Ferrari, real parts of the four (possibly complex) roots.  p3p.cpp:238-286
+// GLIBC = false: exact products and cbrt(hypot) for the three complex powers (rounds 1 - 5); true: libstdc++'s
+// pow(complex, double) restated (the CPU reference's own digits in Ferrari's unstable corner)
+template <bool GLIBC = false>
 __device__ __forceinline__ void solve_quartic(double A, double B, double C, double D, double E, double rr[4]) {
   double A_pw2 = A * A, B_pw2 = B * B;
   double A_pw3 = A_pw2 * A, B_pw3 = B_pw2 * B;
@@ -117,24 +131,24 @@ __device__ __forceinline__ void solve_quartic(double A, double B, double C, doub
 
   double Pr = -alpha_pw2 / 12 - gamma;
   double Qr = -alpha_pw3 / 108 + alpha * gamma / 3 - (beta * beta) / 8;
-  C2 q2 = cpow2_real(Qr), p3 = cpow3_real(Pr);
+  C2 q2 = GLIBC ? cpow_glibc(C2{Qr, 0.0}, 2.0) : cpow2_real(Qr), p3 = GLIBC ? cpow_glibc(C2{Pr, 0.0}, 3.0) : cpow3_real(Pr);
   C2 disc = {q2.re / 4.0 + p3.re / 27.0, q2.im / 4.0 + p3.im / 27.0};
-  C2 sq = csqrt_(disc);
+  C2 sq = csqrt_<GLIBC>(disc);
   C2 R = {-Qr / 2.0 + sq.re, sq.im};  // -Q/2 has imaginary part -0/2 = -0
-  C2 U = cpow_third(R);
+  C2 U = GLIBC ? cpow_glibc(R, 1.0 / 3.0) : cpow_third(R);
   C2 y;
   if (U.re == 0.0) {
-    C2 qc = cpow_third(C2{Qr, 0.0});
+    C2 qc = GLIBC ? cpow_glibc(C2{Qr, 0.0}, 1.0 / 3.0) : cpow_third(C2{Qr, 0.0});
     y = {-5.0 * alpha / 6.0 - qc.re, -qc.im};
   } else {
     C2 t = cdiv(C2{Pr, 0.0}, cscale(U, 3.0));
     y = {-5.0 * alpha / 6.0 - t.re + U.re, -t.im + U.im};
   }
-  C2 w = csqrt_(C2{alpha + 2.0 * y.re, 2.0 * y.im});
+  C2 w = csqrt_<GLIBC>(C2{alpha + 2.0 * y.re, 2.0 * y.im});
   C2 bw = cdiv(C2{2.0 * beta, 0.0}, w);
   C2 base = {3.0 * alpha + 2.0 * y.re, 2.0 * y.im};
-  C2 s1 = csqrt_(C2{-(base.re + bw.re), -(base.im + bw.im)});
-  C2 s2 = csqrt_(C2{-(base.re - bw.re), -(base.im - bw.im)});
+  C2 s1 = csqrt_<GLIBC>(C2{-(base.re + bw.re), -(base.im + bw.im)});
+  C2 s2 = csqrt_<GLIBC>(C2{-(base.re - bw.re), -(base.im - bw.im)});
   double off = -B / (4.0 * A);
   rr[0] = off + 0.5 * (w.re + s1.re);
   rr[1] = off + 0.5 * (w.re - s1.re);
@@ -404,8 +418,14 @@ struct P3PCtx {
 };
 
 // returns false iff the world points are exactly collinear (p3p.cpp:77-80)
+// the glibc-faithful quartic as ONE out-of-line function: it is large (double-double log / exp / atan2 / sincos) and
+// runs for the few hypotheses of the strict item only
+static __device__ __noinline__ void solve_quartic_glibc(double A, double B, double C, double D, double E, double rr[4]) {
+  solve_quartic<true>(A, B, C, D, E, rr);
+}
+// glibc_pow: the three complex powers of the quartic as libstdc++ / glibc evaluate them ("vote_arith" 3 / 4)
 __device__ __forceinline__ bool p3p_prepare(const V3& fa, const V3& fb, const V3& fc, const V3& wa, const V3& wb,
-                                            const V3& wc, P3PCtx& c) {
+                                            const V3& wc, P3PCtx& c, const bool glibc_pow = false) {
   V3 P1 = wa, P2 = wb, P3 = wc;
   if (norm(cross(P2 - P1, P3 - P1)) == 0.0) return false;
   V3 f1 = fa, f2 = fb;
@@ -457,7 +477,10 @@ __device__ __forceinline__ bool p3p_prepare(const V3& fa, const V3& fb, const V3
   double F4 = -2 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 + 2 * p_1_pw3 * d_12 -
               p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 - 2 * f_2_pw2 * p_2_pw2 * p_1 * d_12 +
               p_2_pw2 * f_1_pw2 * p_1_pw2 + f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
-  solve_quartic(F0, F1, F2, F3, F4, c.root);
+  if (glibc_pow)
+    solve_quartic_glibc(F0, F1, F2, F3, F4, c.root);
+  else
+    solve_quartic(F0, F1, F2, F3, F4, c.root);
   c.T = T;
   c.N = N;
   c.P1 = P1;

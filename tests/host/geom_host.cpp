@@ -16,6 +16,8 @@ extern "C" void host_quartic(const double* factors, int n, int variant, double* 
     double r[4];
     if (variant == 1)
       solve_quartic_lit2(a[0], a[1], a[2], a[3], a[4], r);
+    else if (variant == 2)  // libstdc++'s pow(complex, double) restated (mpe_ddmath.h; "vote_arith" = 3)
+      solve_quartic<true>(a[0], a[1], a[2], a[3], a[4], r);
     else
       solve_quartic(a[0], a[1], a[2], a[3], a[4], r);
     for (int k = 0; k < 4; ++k) roots[(size_t)i * 4 + k] = r[k];

@@ -157,7 +157,7 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
         const V3 fa = {iv[c0][0], iv[c0][1], iv[c0][2]}, fb = {iv[c1][0], iv[c1][1], iv[c1][2]},
                  fc = {iv[c2][0], iv[c2][1], iv[c2][2]};
         const unsigned unused = (0xFFFFFFFFu >> (32 - n_d)) & ~((1u << c0) | (1u << c1) | (1u << c2));
-        k2_strict_item(fa, fb, fc, px, sp, c0, c1, c2, p0, p1, p2, 0xFu, unused, false, qs.data(), 1,
+        k2_strict_item<false>(fa, fb, fc, px, sp, c0, c1, c2, p0, p1, p2, 0xFu, unused, false, qs.data(), 1,
                        [&](const int a, const int m) { hist[a * MPE_MAX_MARKERS + m] += 1u; });
       }
     return 0;
@@ -211,7 +211,7 @@ extern "C" int host_vote(const double* undist_xy, int n_d, const double* markers
         const V3 fa = {iv[c0][0], iv[c0][1], iv[c0][2]}, fb = {iv[c1][0], iv[c1][1], iv[c1][2]},
                  fc = {iv[c2][0], iv[c2][1], iv[c2][2]};
         unsigned* h = hist;
-        k2_strict_item(fa, fb, fc, px, sp, c0, c1, c2, p0, p1, p2, kmask, detmask, (code >> 31) & 1u, qs.data(), 1,
+        k2_strict_item<false>(fa, fb, fc, px, sp, c0, c1, c2, p0, p1, p2, kmask, detmask, (code >> 31) & 1u, qs.data(), 1,
                        [&](const int a, const int m) { h[a * MPE_MAX_MARKERS + m] += 1u; });
       }
     }

@@ -1143,6 +1143,46 @@ def test_default_votes_equal_strict_votes(orc):
 
 
 @pytest.mark.gpu
+def test_vote_arithmetics_with_the_reference_librarys_powers(orc):
+    """Round 6: "vote_arith" 3 (fast kernel + strict fix-up) and 4 (strict kernel) evaluate the quartic's complex
+    powers as libstdc++ / glibc do (p3p.cpp:262,264,268 through <complex> and clog; csrc/mpe_ddmath.h).  On ordinary
+    frames every arithmetic gives the oracle's histogram; 3 equals 4; wide frames (the strict loop nest) follow the
+    option too; an unknown value is refused."""
+    h = mpe.Handle()
+    try:
+        for config, n in (("C2", 64), ("C3", 3), ("C1", 16)):
+            d = synth.make_frames(config, n, seed=611)
+            dets = [orc.find_leds(f, orc.make_params(), d["K"], d["D"])[0] for f in d["frames"]]
+            dets = [x for x in dets if len(x) >= 4]
+            ref = [orc.vote_histogram(x, d["markers"], d["K"], 5.0) for x in dets]
+            got = {}
+            for a in (0, 1, 3, 4):
+                h.set_option("vote_arith", a)
+                assert h.get_option("vote_arith") == a
+                got[a] = h.vote_batch(dets, d["markers"], d["K"], 5.0)
+            for i in range(len(dets)):
+                assert np.array_equal(got[3][i], got[4][i]), (config, i)
+                for a in (0, 1, 3, 4):
+                    assert np.array_equal(got[a][i], ref[i]), (config, a, i)
+        K, _ = synth.camera_for(480, 752)
+        rng = np.random.default_rng(12)
+        wide = np.column_stack([rng.uniform(150, 600, 35), rng.uniform(100, 380, 35)])
+        ref = orc.vote_histogram(wide, synth.M5, K, 5.0)
+        for a in (3, 4):
+            h.set_option("vote_arith", a)
+            assert np.array_equal(h.vote_batch([wide], synth.M5, K, 5.0)[0], ref), a
+        h.set_option("vote_arith", 3)
+        d = synth.make_frames("C2", 12, seed=612)
+        ro = orc.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], orc.make_params(), n_threads=4)
+        rh = h.estimate_batch(d["frames"], d["markers"], d["K"], d["D"], mpe.demo_params())
+        assert np.array_equal(rh["status"], ro["status"]) and np.array_equal(rh["n_corr"], ro["n_corr"])
+        with pytest.raises(mpe.MpeError):
+            h.set_option("vote_arith", 5)
+    finally:
+        h.close()
+
+
+@pytest.mark.gpu
 def test_a_full_suspect_list_costs_time_not_poses(orc):
     """a suspect list that overflows used to LOSE entries and reject the frame
     (MPE_FRAME_VOTE_LIST_FULL).  Now the frames that lost an entry are voted again, whole, by the strict loop nest
