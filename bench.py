@@ -900,9 +900,10 @@ def main():
                     help="mode 6: share of a sub-batch scanned on the side stream (-1 = the library's default)")
     ap.add_argument("--opt", action="append", help="name=value: any other mpe_set_option knob (experiments)")
     ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
-    ap.add_argument("--vote-arith", type=int, default=1,
-                    help="1 fast voting arithmetic with its suspects re-evaluated by the strict functions (default), "
-                         "0 strict (IEEE), 2 fast alone (round 3's default; A/B only)")
+    ap.add_argument("--vote-arith", type=int, default=3,
+                    help="3 (default) fast voting arithmetic with its suspects re-evaluated by the strict functions, the "
+                         "quartic's complex powers as libstdc++ / glibc evaluate them; 1 the same with exact powers "
+                         "(rounds 4 - 5); 0 / 4 the strict kernel with the powers of 1 / 3; 2 fast alone (A/B only)")
     ap.add_argument("--no-false-hint-leg", dest="false_hint_leg", action="store_false",
                     help="skip the extra steps whose next-batch announcement does not come true")
     ap.add_argument("--no-vote-events", dest="vote_events", action="store_false",

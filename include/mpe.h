@@ -484,11 +484,15 @@ int mpe_last_launch_shape(mpe_handle* h, int* launches, int* frames_per_launch);
  * side stream during the blob / tail window two sub-batches earlier ("side_scan_blocks" resident blocks per CU,
  * default 3), the voting kernel's rider scans the rest), "k1a_dummy_lds" (occupancy cap
  * of the stand-alone scan kernel in mode 0, per handle), "ingest_chunk" (frames per chunk of the double-buffered
- * host-frame ingest of mpe_estimate_batch, default 2048, 0 = one blocking copy per call), "refine_variant" (the refinement kernel: 0 automatic = 16 lanes per frame for launches of up to 2048 frames, else one lane per frame; 1 / 2 force one of them; bit-identical results), "vote_arith" (arithmetic of the voting kernel: 1 (default)
- * = fast — Newton-Raphson division / square root, Newton cube root, per-permutation tables, [R|C]-free
- * back-projection; 0 = strict — the validation kernel's P3P functions with IEEE operators in the reference's
- * statement order, so that voting and validation share one quartic solver; slower, never fused with the scan.
- * The two differ only in the unstable corner of the reference's Ferrari solver).
+ * host-frame ingest of mpe_estimate_batch, default 2048, 0 = one blocking copy per call), "refine_variant" (the refinement kernel: 0 automatic = 16 lanes per frame for launches of up to 2048 frames, else one lane per frame; 1 / 2 force one of them; bit-identical results), "vote_arith" (arithmetic of the voting kernel:
+ * 3 (default since round 6) = fast — Newton-Raphson division / square root, Newton cube root, per-permutation
+ * tables, [R|C]-free back-projection — with every hypothesis it cannot decide safely re-evaluated by the strict
+ * functions, whose quartic evaluates std::pow(complex, double) of p3p.cpp:262,264,268 as libstdc++ / glibc do
+ * (exp(y log|z|) through clog's branches; csrc/mpe_ddmath.h): the vote histograms of the CPU reference build also in
+ * the unstable corner of its Ferrari solver; 1 = the same with exact products / cbrt(hypot)
+ * for those powers (default of rounds 4 - 5); 4 / 0 = strict — the validation kernel's P3P functions with IEEE
+ * operators in the reference's statement order for every hypothesis, powers as in 3 / 1; slower, never fused with
+ * the scan; 2 = the fast arithmetic alone (A/B measurements).  3 and 4 produce identical histograms, as do 1 and 0.
  * Results are bit-identical in every pipeline mode (for a given vote_arith). */
 int mpe_set_option(mpe_handle* h, const char* name, int value);
 /* Measurement read-outs through the same pair of calls:
@@ -505,9 +509,15 @@ int mpe_set_option(mpe_handle* h, const char* name, int value);
  *   voted again by the strict loop nest (a full list costs time, never a pose); synchronises.
  * Tuning / test knobs (round 5): "vote_list_cap" (entries per suspect list at most, 0 = no limit: a tiny list exercises
  *   the re-vote path), "k1b_general_blocks" (PROCESS-wide: blocks = scratch slabs of the general blob tier, 32 .. 8192,
- *   default 4096, within 1 GB of scratch), "tail_priority" / "scan_priority" (-1 / 0 / 1: stream priority of the
- *   library's two side streams, applied when they are created; default 1 / 1 — off the default level so that they get
- *   hardware queues of their own, DESIGN.md section 3, Schedules). */
+ *   default 4096, within 1 GB of scratch and never more than the frames of a launch), "tail_priority" /
+ *   "scan_priority" (stream priority of the library's two side streams, applied when they are created: -1 lowest,
+ *   0 ordinary streams, 1 highest, 2 the default level but created through the priority entry point; default 1 / 1 —
+ *   off the default level so that they get hardware queues of their own, DESIGN.md section 3, Schedules.  NOTE for
+ *   callers: at 1 the side streams' kernels are dispatched ahead of work on the caller's own ordinary-priority
+ *   streams of the same process while a pipelined call is in flight; set both to -1 to keep the queues and yield
+ *   instead — same step time within noise, profiles/round5_exp_side_priorities.json).
+ * get "vote_wide_frames" (round 6): frames with more than MPE_FAST_VOTE_DETECTIONS detections, voted by the strict
+ *   loop nest alone; synchronises. */
 /* Read an option back.  Also "streams_concurrent": 1 once the library has verified (spin-kernel probe at
  * the first large batch) that its two pipeline side streams execute concurrently, 0 if no concurrent
  * pair was found (the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues), -1 not probed yet;

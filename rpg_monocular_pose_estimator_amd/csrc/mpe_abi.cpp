@@ -97,9 +97,12 @@ struct mpe_handle {
   const uint8_t* pending_track_rec = nullptr;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
   int vote_splits = 0;         // 0 = auto
-  int vote_arith = 1;          // 1 = fast voting arithmetic + strict re-evaluation of the hypotheses it cannot decide
-                               //     (default), 0 = strict: IEEE operators, the validation kernel's P3P (same quartic
-                               //     in K2 and K3), 2 = the fast arithmetic alone (round-3 behaviour, A/B only)
+  int vote_arith = 3;          // 3 (default since round 6) = fast voting arithmetic + strict re-evaluation of the hypotheses
+                               //     it cannot decide, the strict item evaluating the quartic's three complex powers as
+                               //     libstdc++ / glibc do (mpe_ddmath.h): the CPU reference's digits in Ferrari's corner;
+                               // 1 = the same with exact products / cbrt(hypot) (default of rounds 4 - 5), 0 / 4 = the
+                               //     strict kernel (IEEE operators, the validation kernel's P3P) with the powers of 1 / 3,
+                               //     2 = the fast arithmetic alone (round-3 behaviour, A/B only)
   int assume_side_streams = 0; // option: take the side streams of schedules 4 / 6 as concurrent without the spin probe —
                                // for counter passes: the profiler serialises kernels, the probe then fails and the
                                // call would fall back to schedule 3, i.e. other launch shapes than the timed run's

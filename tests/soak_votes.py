@@ -44,6 +44,9 @@ TOL = 5.0
 cores = len(os.sched_getaffinity(0))
 STRICT = os.environ.get("MPE_SOAK_STRICT", "1") != "0"
 ORACLE = os.environ.get("MPE_SOAK_ORACLE", "1") != "0"
+# MPE_SOAK_PAIR="3,4": the same soak for the arithmetics with the reference library's powers (round 6): "default" then
+# means vote_arith 3 and "strict" vote_arith 4
+A_DEF, A_STRICT = [int(x) for x in os.environ.get("MPE_SOAK_PAIR", "1,0").split(",")]
 STRICT_FRAMES = int(os.environ.get("MPE_SOAK_STRICT_FRAMES", str(N if CONFIG != "C3" else min(N, 4096))))
 diff = {0: 0, 1: 0, 2: 0}
 cells = {0: 0, 1: 0, 2: 0}
@@ -67,7 +70,7 @@ for part in range(max(1, N // CH)):
     for arith in ((1, 2, 0) if ORACLE else (1, 0)):
         if arith == 0 and not do_strict:
             continue
-        h.set_option("vote_arith", arith)
+        h.set_option("vote_arith", {1: A_DEF, 0: A_STRICT}.get(arith, arith))
         got[arith] = h.vote_batch([dets[i, :nd[i]] for i in range(CH)], markers, K, TOL)
         for i in (range(CH) if ORACLE else ()):
             r = ref[i, :nd[i], :len(markers)] if nd[i] >= 4 else np.zeros((nd[i], len(markers)), np.uint32)
@@ -97,7 +100,7 @@ if saved:
              **{"hip_%d" % k: s["hip"] for k, s in enumerate(saved)},
              **{"oracle_%d" % k: s["oracle"] for k, s in enumerate(saved)},
              meta=json.dumps([{k: v for k, v in s.items() if k not in ("det", "hip", "oracle")} for s in saved]))
-print(json.dumps({"config": CONFIG, "frames": tot, "p3p_solves_per_frame": "C(n_det,3) x P(n_markers,3)",
+print(json.dumps({"config": CONFIG, "frames": tot, "vote_arith_of_default_and_strict": [A_DEF, A_STRICT], "p3p_solves_per_frame": "C(n_det,3) x P(n_markers,3)",
                   "oracle_compared": ORACLE,
                   "frames_with_a_different_histogram_vs_oracle": {
                       "default (vote_arith 1: fast + strict re-evaluation of suspects)": diff[1],

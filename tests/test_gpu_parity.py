@@ -495,8 +495,17 @@ def test_known_divergence_on_an_unstable_quartic(hip, orc):
     import os
     det = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "vote_regression_det_0.npy"))
     K, _ = synth.camera_for(480, 752)
-    got = hip.vote_batch([det], synth.M5, K, 5.0)[0].astype(int)
     ref = orc.vote_histogram(det, synth.M5, K, 5.0).astype(int)
+    # round 6: the default arithmetic ("vote_arith" 3) evaluates the quartic's complex powers as libstdc++ / glibc do
+    # and lands on this CPU build's digits even there: no cell may differ
+    assert hip.get_option("vote_arith") == 3
+    assert np.array_equal(hip.vote_batch([det], synth.M5, K, 5.0)[0].astype(int), ref)
+    # the arithmetic of rounds 4 - 5 (exact products, cbrt(hypot)): those four cells, by one vote
+    hip.set_option("vote_arith", 1)
+    try:
+        got = hip.vote_batch([det], synth.M5, K, 5.0)[0].astype(int)
+    finally:
+        hip.set_option("vote_arith", 3)
     diff = got - ref
     allowed = np.zeros_like(diff, bool)
     for cell in ((0, 2), (1, 4), (2, 1), (3, 0)):
@@ -1071,7 +1080,7 @@ def test_strict_vote_arithmetic(orc):
         assert np.abs(strict["T"][ok] - ref["T"][ok]).max() < 1e-9
         assert np.abs(fast["T"][ok] - ref["T"][ok]).max() < 1e-9
         with pytest.raises(mpe.MpeError):
-            h.set_option("vote_arith", 3)
+            h.set_option("vote_arith", 5)
     finally:
         h.close()
 
@@ -1113,15 +1122,17 @@ def test_default_votes_equal_strict_votes(orc):
                     for k in rng.integers(4, 10, 16)]
             cases.append(("random%d" % it, dets, markers, K, [1.0, 3.0, 5.0][it % 3]))
         items0 = h.get_option("vote_fixup_items")
+        # (round 6: the same claim for the pair with the reference library's powers — 3, the default now, against 4)
         for name, dets, markers, Kc, tol in cases:
-            h.set_option("vote_arith", 0)
-            strict = h.vote_batch(dets, markers, Kc, tol)
-            h.set_option("vote_arith", 1)
-            got = h.vote_batch(dets, markers, Kc, tol)
-            for i in range(len(dets)):
-                assert np.array_equal(got[i], strict[i]), (name, i, np.argwhere(got[i] != strict[i])[:5])
-            if name == "degenerate triple":
-                assert np.array_equal(got[0], orc.vote_histogram(dets[0], np.asarray(markers, float), Kc, tol))
+            for a_strict, a_fast in ((0, 1), (4, 3)):
+                h.set_option("vote_arith", a_strict)
+                strict = h.vote_batch(dets, markers, Kc, tol)
+                h.set_option("vote_arith", a_fast)
+                got = h.vote_batch(dets, markers, Kc, tol)
+                for i in range(len(dets)):
+                    assert np.array_equal(got[i], strict[i]), (name, a_fast, i, np.argwhere(got[i] != strict[i])[:5])
+                if name == "degenerate triple":
+                    assert np.array_equal(got[0], orc.vote_histogram(dets[0], np.asarray(markers, float), Kc, tol))
         assert h.get_option("vote_fixup_items") > items0
         assert h.get_option("vote_fixup_overflow") == 0
         # the whole path (fused scan-carrying kernel, fix-up on the tail stream of the pipelined schedule, streaming
@@ -1129,14 +1140,15 @@ def test_default_votes_equal_strict_votes(orc):
         import torch
         d = synth.make_frames("C2", 96, seed=77)
         big = torch.from_numpy(d["frames"]).cuda().repeat(342, 1, 1)[:32768 + 64].contiguous()  # 2 sub-batches
-        h.set_option("vote_arith", 0)
-        rs = h.estimate_batch(big, d["markers"], d["K"], d["D"], mpe.demo_params())
-        h.set_option("vote_arith", 1)
-        rf = h.estimate_batch(big, d["markers"], d["K"], d["D"], mpe.demo_params())
-        assert h.get_option("last_schedule") in (3, 6)
-        for k in ("status", "n_corr", "n_det"):
-            assert np.array_equal(rs[k], rf[k]), k
-        assert np.array_equal(rs["T"], rf["T"], equal_nan=True) and np.array_equal(rs["cov"], rf["cov"], equal_nan=True)
+        for a_strict, a_fast in ((0, 1), (4, 3)):
+            h.set_option("vote_arith", a_strict)
+            rs = h.estimate_batch(big, d["markers"], d["K"], d["D"], mpe.demo_params())
+            h.set_option("vote_arith", a_fast)
+            rf = h.estimate_batch(big, d["markers"], d["K"], d["D"], mpe.demo_params())
+            assert h.get_option("last_schedule") in (3, 6)
+            for k in ("status", "n_corr", "n_det"):
+                assert np.array_equal(rs[k], rf[k]), k
+            assert np.array_equal(rs["T"], rf["T"], equal_nan=True) and np.array_equal(rs["cov"], rf["cov"], equal_nan=True)
         assert h.get_option("vote_fixup_overflow") == 0
     finally:
         h.close()

@@ -58,7 +58,11 @@ def _compare_with_oracle(hip, orc, config, n, seed, tol, min_pose_frac):
             und, _ = orc.find_leds(host[i], Po, K, D)
             v = forensics.classify_end_to_end(hip, orc, und, markers, K, Ph, Po)
             assert v["unstable"], ("unexplained HIP-vs-oracle mismatch", config, i, v)
-    assert n_bad <= max(1, n // 128), n_bad
+    # rounds 4 - 5 tolerated max(1, n / 128) mismatches the forensics classified as "unstable" (Ferrari's corner, where the
+    # device's exact complex powers and glibc's exp(y log|z|) picked different branches).  The default arithmetic now
+    # evaluates those powers as the CPU build does (vote_arith 3, csrc/mpe_ddmath.h): the allowance is gone
+    assert hip.get_option("vote_arith") == 3
+    assert n_bad == 0, n_bad
     assert n_pose >= min_pose_frac * n, (n_pose, n)
     return n_pose
 
