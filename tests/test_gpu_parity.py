@@ -235,11 +235,11 @@ def test_frames_with_33_to_64_detections_match_the_oracle(hip, orc):
                 dp, dr = pose_diff(T, ro["T"])
                 assert dp <= POS_TOL_M and dr <= ROT_TOL_RAD, (i, dp, dr)
         if len(und) > 32:  # the strict kernel and the stage-level vote entry on a wide frame
-            hip.set_option("vote_arith", 0)
+            hip.set_option("vote_arith", 4)
             try:
                 hs = hip.vote_batch([und], synth.M5, K, 5.0)[0]
             finally:
-                hip.set_option("vote_arith", 1)
+                hip.set_option("vote_arith", 3)
             assert np.array_equal(hs, ro["hist"]), i
             assert np.array_equal(hip.vote_batch([und], synth.M5, K, 5.0)[0], ro["hist"]), i
     assert n_seen[:3] == [33, 41, 64] and n_seen[3] <= 32, n_seen
@@ -1055,7 +1055,11 @@ def test_strict_vote_arithmetic(orc):
     import os
     h = mpe.Handle()
     try:
-        assert h.get_option("vote_arith") == 1
+        assert h.get_option("vote_arith") == 3   # (the default since round 6; 4 is its strict kernel)
+        h.set_option("vote_arith", 4)
+        det = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "vote_regression_det_0.npy"))
+        K, _ = synth.camera_for(480, 752)
+        assert np.array_equal(h.vote_batch([det], synth.M5, K, 5.0)[0], orc.vote_histogram(det, synth.M5, K, 5.0))
         h.set_option("vote_arith", 0)
         assert h.get_option("vote_arith") == 0
         for config, n in (("C2", 24), ("C1", 8), ("C3", 2)):
