@@ -44,7 +44,10 @@ extern "C" {
 /* per-frame status codes (mpe_result.status, mpe_detections.status) */
 #define MPE_FRAME_POSE 0
 #define MPE_FRAME_NO_POSE 1
-#define MPE_FRAME_TOO_MANY_DETECTIONS (-10) /* > MPE_MAX_DETECTIONS blobs passed the filter */
+#define MPE_FRAME_TOO_MANY_DETECTIONS (-10) /* > MPE_MAX_DETECTIONS blobs passed the filter: the record then holds the
+                                               first MPE_MAX_DETECTIONS of the reference's order (OpenCV's contour order)
+                                               — unless more than 512 passed, when WHICH blobs it holds is unspecified
+                                               (the general blob tier keeps 512, appended concurrently) */
 #define MPE_FRAME_TOO_MANY_BLOBS (-11)      /* > MPE_MAX_RAW_BLOBS external contours */
 #define MPE_FRAME_TOO_MANY_ROWS (-12)       /* bright rows exceed the LDS band capacity */
 #define MPE_FRAME_VOTE_LIST_FULL (-13)      /* internal since round 5: hypotheses left to the strict arithmetic did not fit

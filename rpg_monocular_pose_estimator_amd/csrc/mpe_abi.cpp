@@ -490,7 +490,7 @@ int relost_grid(mpe_handle* h, int n_frames) {
   return 32;
 }
 hipError_t fixup_launch(mpe_handle* h, int slot, mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist,
-                        const VoteFixup& fx, hipStream_t st) {
+                        const VoteFixup& fx, hipStream_t st, const int* item_range = nullptr) {
   if (!fx.ctl) return hipSuccess;
   if (slot == 0 && h->fix_ctl_host) {  // once per call: what the mirror says, then the next reading on its way
     unsigned long long sum = 0;
@@ -499,7 +499,7 @@ hipError_t fixup_launch(mpe_handle* h, int slot, mpe_detections* dets, int n_fra
     h->relost_hot = sum != h->relost_prev_sum;
     h->relost_prev_sum = sum;
   }
-  const hipError_t e = launch_k2_fixup(dets, n_frames, sp, hist, fx, st, relost_grid(h, n_frames));
+  const hipError_t e = launch_k2_fixup(dets, n_frames, sp, hist, fx, st, relost_grid(h, n_frames), item_range);
   if (e != hipSuccess) return e;
   h->fix_pending[slot] = false;
   if (slot == 0) {
@@ -1740,7 +1740,7 @@ int vote_batch_impl(mpe_handle* h, const double* det_xy, const int* n_det, int n
                             static_cast<uint32_t*>(h->hist.p), auto_splits(h, n_frames, n_markers), n_markers,
                             h->stream, nullptr, 0, nullptr, 0, nullptr, d_range, &fx));
   HIP_TRY(h, fixup_launch(h, 0, static_cast<mpe_detections*>(h->dets.p), n_frames, sp, static_cast<uint32_t*>(h->hist.p), fx,
-                          h->stream));
+                          h->stream, d_range));
   HIP_TRY(h, hipMemcpy2DAsync(hist, MPE_HIST_WORDS * sizeof(uint32_t), h->hist.p, MPE_HIST_STRIDE * sizeof(uint32_t),
                               MPE_HIST_WORDS * sizeof(uint32_t), (size_t)n_frames,
                             hipMemcpyDeviceToHost, h->stream));

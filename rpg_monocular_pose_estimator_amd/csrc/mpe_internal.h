@@ -120,7 +120,8 @@ hipError_t launch_k2_vote(mpe_detections* dets, int n_frames, const SolveParams&
 // on a stream ordered behind the voting launch; its votes must be in before the tail reads the histograms
 // ... and, behind it, the strict re-vote of the frames that lost an entry to a full list (they come out unmarked)
 hipError_t launch_k2_fixup(mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist,
-                           const VoteFixup& fixup, hipStream_t s, int relost_blocks = 32);
+                           const VoteFixup& fixup, hipStream_t s, int relost_blocks = 32,
+                           const int* item_range = nullptr);  // (item_range: as launch_k2_vote's, for the re-vote)
 // splits < 0 (plain kernel): -splits blocks per frame that divide the marker PERMUTATIONS among themselves and keep
 // their slice of the per-permutation table in LDS (k2_table_slices says when and into how many)
 int k2_table_slices(int n_markers);

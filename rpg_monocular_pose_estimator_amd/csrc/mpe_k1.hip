@@ -1748,6 +1748,8 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     }
     __syncthreads();
     const int nband = s_nband;
+    // (appended by up to 64 lanes at once: beyond K1B_GEN_KEPT blobs the kept SUBSET depends on the order the lanes
+    //  arrive in; the frame then carries MPE_FRAME_TOO_MANY_DETECTIONS anyway and include/mpe.h says so)
     auto keep = [&](float mcx, float mcy, unsigned key) {
       const int k = atomicAdd(&s_nkept, 1);
       if (k < K1B_GEN_KEPT) {

@@ -819,6 +819,9 @@ __device__ __forceinline__ void k2_defer_flush(const K2Frame& F, int& count, boo
 // would read again; 0 = the LDS columns (more than 8 unused markers).
 template <bool SCAN, int NP = 0, class Rider>
 __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, bool live, Rider& rider, int& vq_count) {
+  // (fast item only: a*b+c may fuse — its few-ulp differences from the strict arithmetic are what the suspect margins
+  //  and the strict re-evaluation absorb; the TU default stays -ffp-contract=off)
+#pragma clang fp contract(fast)
   const unsigned ii = F.trii[ti];
   const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
   const bool swap = (ii >> 24) & 1;
@@ -1530,7 +1533,8 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_strict(const mpe_detection
 // records what has been handled (ctl[4]; ctl[5] counts the blocks).
 template <bool GLIBC>
 __global__ __launch_bounds__(K2_THREADS) void k2_vote_relost(mpe_detections* __restrict__ dets, int n_frames, SolveParams sp,
-                                                             uint32_t* __restrict__ hist, VoteFixup fx) {
+                                                             uint32_t* __restrict__ hist, VoteFixup fx,
+                                                             const int* __restrict__ item_range) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double s_px[MPE_MAX_DETECTIONS][2];
   __shared__ double s_iv[MPE_MAX_DETECTIONS][3];
@@ -1546,13 +1550,13 @@ __global__ __launch_bounds__(K2_THREADS) void k2_vote_relost(mpe_detections* __r
     uint32_t* gh = hist + (size_t)f * MPE_HIST_STRIDE;
     if (wide) {  // every block: its share of the frame; the mark stays until all of them are done
       if (sp.n_markers >= 4)
-        k2_strict_frame<false, GLIBC>(d, sp, gh, f, (int)blockIdx.x, (int)gridDim.x, nullptr, smem, s_px, s_iv, s_hist);
+        k2_strict_frame<false, GLIBC>(d, sp, gh, f, (int)blockIdx.x, (int)gridDim.x, item_range, smem, s_px, s_iv, s_hist);
       __syncthreads();
       continue;
     }
     if (f % (int)gridDim.x != (int)blockIdx.x) continue;  // a narrow frame: one block, the histogram stored
     if (d->n >= 4 && sp.n_markers >= 4)
-      k2_strict_frame<true, GLIBC>(d, sp, gh, f, 0, 1, nullptr, smem, s_px, s_iv, s_hist);
+      k2_strict_frame<true, GLIBC>(d, sp, gh, f, 0, 1, item_range, smem, s_px, s_iv, s_hist);  // (forensics: the range)
     __syncthreads();
     if (threadIdx.x == 0) {
       d->status = 0;
@@ -1629,7 +1633,7 @@ __global__ __launch_bounds__(K2_FIX_THREADS) void k2_vote_fixup(const mpe_detect
 }
 
 hipError_t launch_k2_fixup(mpe_detections* dets, int n_frames, const SolveParams& sp, uint32_t* hist, const VoteFixup& fx,
-                           hipStream_t s, int relost_blocks) {
+                           hipStream_t s, int relost_blocks, const int* item_range) {
   if (!fx.ctl || fx.cap == 0 || sp.n_markers < 4 || n_frames <= 0) return hipSuccess;
   // (the entry count lives on the device: a fixed grid strides over it — wide, every entry is a single-wave chain of
   //  dependent FP64 operations (~30 us), and blocks beyond the count leave at once; ~0.15 % of the hypotheses)
@@ -1650,10 +1654,10 @@ hipError_t launch_k2_fixup(mpe_detections* dets, int n_frames, const SolveParams
   if (relost_blocks < 1) relost_blocks = 32;
   if (glibc)
     hipLaunchKernelGGL(k2_vote_relost<true>, dim3((unsigned)relost_blocks), dim3(K2_THREADS), lds_strict, s, dets,
-                       n_frames, sp, hist, fx);
+                       n_frames, sp, hist, fx, item_range);
   else
     hipLaunchKernelGGL(k2_vote_relost<false>, dim3((unsigned)relost_blocks), dim3(K2_THREADS), lds_strict, s, dets,
-                       n_frames, sp, hist, fx);
+                       n_frames, sp, hist, fx, item_range);
   return hipGetLastError();
 }
 
