@@ -148,11 +148,23 @@ def plumbing_only(args, rank, world):
                           "vs_baseline": None, "dtype": "f64", "data": "synthetic", "plumbing_only": True,
                           "gather_intact": bool(ok), "records_on_rank0": int(len(got)),
                           "ranks_seen": ranks_seen, "per_rank_fps": per_rank, "shard_parity": shard,
+                          "shard_bounds": [list(parallel.shard_bounds(world * B, r, world)) for r in range(world)],
                           "config": {"workload": "plumbing only: no kernels", "frames_per_gpu_per_step": B}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def hbm_need_bytes(synth, config, B, frames_only=False):
+    """HBM one rank needs for B resident frames of `config`: pixels (pitch = ceil16(cols)) + per-frame records and
+    scratch of the library, with the 8 suspect-list slots of a pipelined call at their cap."""
+    cfg = synth.CONFIGS[config]
+    pix = B * cfg["rows"] * ((cfg["cols"] + 15) // 16 * 16)
+    if frames_only:
+        return pix
+    per_frame = 1544 + 4224 + 432 + 128 + 256   # detections, histogram, result, correspondences, tail hand-over
+    return pix + pix // 128 + B * per_frame + 2 * B * 432 + (8 << 30) // 4 + (1 << 30)
 
 
 # ---- synthetic batches --------------------------------------------------------------------------------------------
@@ -272,6 +284,17 @@ def run_config(args, ctx, light=False):
     multi = world > 1 or bool(ctx.get("force_pg"))
 
     B = args.frames
+    # what this rank is about to ask of its GPU: the resident batch + the per-frame records and the library's scratch
+    # (flag bitmap 1/128 of the pixels, detections, histograms, results, suspect lists <= 1 GB per slot in use, tail
+    # buffers) — printed for N > 1 and refused EARLY when it cannot fit, instead of an out-of-memory error mid-warm-up
+    need = hbm_need_bytes(synth, args.config, B)
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    if world > 1 or need > free_b:
+        sys.stderr.write("bench.py: rank %d needs ~%.1f GB of HBM (%.1f GB of frames + records / scratch); device %d has "
+                         "%.1f GB free of %.1f GB\n" % (rank, need / 1e9, hbm_need_bytes(synth, args.config, B, True) / 1e9,
+                                                        local_rank, free_b / 1e9, total_b / 1e9))
+    if need > free_b:
+        sys.exit("bench.py: rank %d: the batch does not fit this GPU — lower --frames (now %d per GPU per step)" % (rank, B))
     cfg, frames = make_batch(synth, args.config, args.clutter, B, dev, rank)
     rows, cols = cfg["rows"], cfg["cols"]
     K, D = synth.camera_for(rows, cols)
@@ -293,6 +316,13 @@ def run_config(args, ctx, light=False):
     h.set_option("pipeline_mode", args.pipeline_mode)
     h.set_option("vote_arith", args.vote_arith)
     h.set_option("vote_splits", args.vote_splits)
+    if args.clutter in ("d4", "d16") and args.detections_hint < 0:
+        # what a caller who knows the scene tells the library (the records of this entry stay on the device, so it
+        # cannot see the counts itself): markers + distractor spots.  Never a matter of correctness — it picks the
+        # voting-kernel variant (from 9 detections on: the occupancy-grid prefilter) and sizes the suspect lists
+        h.set_option("detections_hint", len(markers) + int(args.clutter[1:]))
+    elif args.detections_hint >= 0:
+        h.set_option("detections_hint", args.detections_hint)
     if args.scan_split_pct >= 0:
         h.set_option("scan_split_pct", args.scan_split_pct)
     if args.side_scan_blocks >= 0:
@@ -312,7 +342,11 @@ def run_config(args, ctx, light=False):
     # host memory on every rank (what a caller of estimateBodyPose ends up holding), and for N > 1 the RCCL gather of
     # the records to rank 0.  Every submission announces the next one's frames, so its last voting launch carries the
     # image scan of the next batch's first sub-batch.
-    out_stream = torch.cuda.Stream(device=dev)
+    # (its priority LEVEL: the runtime maps the streams of one level onto 4 hardware queues; the
+    #  library's side streams live on the highest level, this one — with RCCL's gather on it for N > 1 — on the lowest,
+    #  so that the default level is left to the work stream and whatever torch / RCCL create there themselves)
+    cons_prio = args.consumer_priority if args.consumer_priority is not None else (1 if world > 1 else 0)
+    out_stream = torch.cuda.Stream(device=dev, priority=cons_prio)
     rec_bytes = B * mpe.RESULT_DTYPE.itemsize
     host_rec = [torch.empty(rec_bytes, dtype=torch.uint8).pin_memory() for _ in range(2)] if args.records_to_host else None
     out_done = [None, None]
@@ -900,6 +934,9 @@ def main():
                     help="mode 6: share of a sub-batch scanned on the side stream (-1 = the library's default)")
     ap.add_argument("--opt", action="append", help="name=value: any other mpe_set_option knob (experiments)")
     ap.add_argument("--pipeline", type=int, default=16, help="cap on the sub-batches per step (1 = one chain of kernels)")
+    ap.add_argument("--detections-hint", type=int, default=-1,
+                    help="option detections_hint of the library (-1: markers + distractors in the d4 / d16 legs, else 0 = "
+                         "automatic); A/B: 0 keeps the per-detection prefilter of round 5 in the cluttered legs")
     ap.add_argument("--vote-arith", type=int, default=3,
                     help="3 (default) fast voting arithmetic with its suspects re-evaluated by the strict functions, the "
                          "quartic's complex powers as libstdc++ / glibc evaluate them; 1 the same with exact powers "
@@ -913,6 +950,11 @@ def main():
                     help="tuning: 0 automatic, n > 0 blocks per frame over the flattened items (no table slices)")
     ap.add_argument("--no-streaming", action="store_true",
                     help="one joined mpe_estimate_batch_device call per step instead of the submit / collect stream of batches")
+    ap.add_argument("--consumer-priority", type=int, default=None,
+                    help="torch stream priority of the consumer stream (D2H copy of the records, RCCL gather): 0 default "
+                         "level, 1 lowest, -1 highest.  Default: 0 on one GPU (same-box A/B, round 6: no difference), "
+                         "lowest for N > 1 — the gather's RCCL kernels then cannot share a hardware queue with the "
+                         "work stream (unmeasured: no multi-GPU node yet)")
     ap.add_argument("--no-records-to-host", dest="records_to_host", action="store_false",
                     help="leave the pose records on the device (no D2H copy inside the step)")
     ap.add_argument("--back-tol", type=float, default=None,

@@ -519,6 +519,11 @@ int mpe_set_option(mpe_handle* h, const char* name, int value);
  *   callers: at 1 the side streams' kernels are dispatched ahead of work on the caller's own ordinary-priority
  *   streams of the same process while a pipelined call is in flight; set both to -1 to keep the queues and yield
  *   instead — same step time within noise, profiles/round5_exp_side_priorities.json).
+ * "detections_hint" (round 6): detections per frame the caller expects in device-resident / streaming calls (0 =
+ *   automatic: the number of markers, or what the last call whose records came back to the host saw — read-out
+ *   "detections_seen").  From 9 on the <= 5-marker voting kernel prefilters its back-projections with an occupancy
+ *   grid of the detections instead of a distance per detection; the suspect lists are sized from it.  Results do not
+ *   depend on it.
  * get "vote_wide_frames" (round 6): frames with more than MPE_FAST_VOTE_DETECTIONS detections, voted by the strict
  *   loop nest alone; synchronises. */
 /* Read an option back.  Also "streams_concurrent": 1 once the library has verified (spin-kernel probe at

@@ -95,6 +95,12 @@ struct mpe_handle {
   } pending_track;
   int pending_track_n = 0;            // mpe_track_step_batch_submit without its _collect yet: streams in flight
   const uint8_t* pending_track_rec = nullptr;
+  // How many detections the frames of a pipelined call are expected to carry: picks the voting-kernel variant (from 9
+  // on: the scan-carrying kernel with an occupancy grid of the detections, mpe_k2.hip K2_CGRID) and sizes the suspect
+  // lists.  Never a matter of correctness.  Option "detections_hint" (0 = automatic: the number of markers, or what the
+  // last call whose records came back to the host saw, det_seen)
+  int detections_hint = 0;
+  int det_seen = 0;
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
   int vote_splits = 0;         // 0 = auto
   int vote_arith = 3;          // 3 (default since round 6) = fast voting arithmetic + strict re-evaluation of the hypotheses
@@ -380,6 +386,11 @@ int stage_frames(mpe_handle* h, const uint8_t* frames, int n_frames, int rows, i
   return MPE_OK;
 }
 
+int det_hint_for(const mpe_handle* h, int n_markers) {
+  const int v = h->detections_hint > 0 ? h->detections_hint : h->det_seen;
+  return std::min(MPE_FAST_VOTE_DETECTIONS, std::max(n_markers, v));
+}
+
 // > 0: blocks per frame, each block a share of the flattened (triple, permutation) items;  < 0: -(blocks per frame),
 // each block a share of the marker PERMUTATIONS whose table slice it keeps in LDS (6 .. 10 markers, fast arithmetic)
 int auto_splits(const mpe_handle* h, int n_frames, int n_markers) {
@@ -544,9 +555,9 @@ int run_back(mpe_handle* h, hipStream_t st, bool prof, int n_frames, const Solve
   if (sp) {
     HIP_TRY(h, hipMemsetAsync(d_hist, 0, (size_t)n_frames * MPE_HIST_STRIDE * sizeof(uint32_t), st));
     VoteFixup fx;
-    { const int rc = vote_fixup_for(h, 0, 1, n_frames, sp->n_markers, sp->n_markers, st, fx); if (rc) return rc; }
+    { const int rc = vote_fixup_for(h, 0, 1, n_frames, sp->n_markers, det_hint_for(h, sp->n_markers), st, fx); if (rc) return rc; }
     HIP_TRY(h, launch_k2_vote(d_dets, n_frames, *sp, static_cast<const double*>(h->mtab.p), d_hist,
-                              auto_splits(h, n_frames, sp->n_markers), sp->n_markers, st, nullptr, 0, nullptr, 0,
+                              auto_splits(h, n_frames, sp->n_markers), det_hint_for(h, sp->n_markers), st, nullptr, 0, nullptr, 0,
                               nullptr, nullptr, &fx));
     HIP_TRY(h, fixup_launch(h, 0, d_dets, n_frames, *sp, d_hist, fx, st));
     if (prof) rec(h, 3);
@@ -1021,11 +1032,11 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       if (nbytes && s + 1 >= n_real && hint && hint->next_ready)  // this launch reads the NEXT submission's frames
         HIP_TRY(h, hipStreamWaitEvent(st, hint->next_ready, 0));
       VoteFixup fx;
-      { const int rc = vote_fixup_for(h, s, nsub, per, sp->n_markers, sp->n_markers, st, fx); if (rc) return rc; }
+      { const int rc = vote_fixup_for(h, s, nsub, per, sp->n_markers, det_hint_for(h, sp->n_markers), st, fx); if (rc) return rc; }
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], st));
       HIP_TRY(h, vote_ev_begin(h, s, st));
       HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, *sp, static_cast<const double*>(h->mtab.p), hs,
-                                auto_splits(h, nf, sp->n_markers), sp->n_markers, st, nbytes ? nfr + P : nullptr,
+                                auto_splits(h, nf, sp->n_markers), det_hint_for(h, sp->n_markers), st, nbytes ? nfr + P : nullptr,
                                 nbytes - P, nbytes ? nfl + P / 1024 : nullptr, dp.thr, &scanned, nullptr, &fx));
       HIP_TRY(h, vote_ev_end(h, s, st, scanned > 0));
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], st));
@@ -1132,10 +1143,10 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
     HIP_TRY(h, hipMemsetAsync(hs, 0, (size_t)nf * MPE_HIST_STRIDE * sizeof(uint32_t), sb));
     VoteFixup fx;
-    { const int rc = vote_fixup_for(h, s, nsub, per, sp->n_markers, sp->n_markers, sb, fx); if (rc) return rc; }
+    { const int rc = vote_fixup_for(h, s, nsub, per, sp->n_markers, det_hint_for(h, sp->n_markers), sb, fx); if (rc) return rc; }
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][4], sb));
     HIP_TRY(h, launch_k2_vote(d_dets + f0, nf, *sp, static_cast<const double*>(h->mtab.p), hs,
-                              auto_splits(h, nf, sp->n_markers), sp->n_markers, sb, nullptr, 0, nullptr, 0, nullptr,
+                              auto_splits(h, nf, sp->n_markers), det_hint_for(h, sp->n_markers), sb, nullptr, 0, nullptr, 0, nullptr,
                               nullptr, &fx));
     HIP_TRY(h, fixup_launch(h, s, d_dets + f0, nf, *sp, hs, fx, sb));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][5], sb));
@@ -1386,6 +1397,8 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "streams_concurrent") *value = h->streams_concurrent;
   else if (n == "last_schedule") *value = h->last_schedule;
   else if (n == "vote_list_cap") *value = (int)h->fix_cap_limit;
+  else if (n == "detections_hint") *value = h->detections_hint;
+  else if (n == "detections_seen") *value = h->det_seen;
   else if (n == "k1b_general_blocks") *value = k1b_get_general_blocks();
   else if (n == "vote_fixup_items" || n == "vote_fixup_overflow" || n == "vote_relost_frames" || n == "vote_wide_frames") {
     // hypotheses (roots, detections) the fast voting kernel handed to the strict arithmetic since the handle was made,
@@ -1574,6 +1587,11 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   if (!std::strcmp(name, "k1b_general_blocks")) {  // tuning, process-wide: waves of the general blob tier in flight
     if (value < 32 || value > 8192) return fail(h, MPE_ERR_ARG, "k1b_general_blocks must be in [32, 8192]");
     k1b_set_general_blocks(value);
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "detections_hint")) {  // detections per frame the caller expects (0 = automatic); see det_hint_for
+    if (value < 0 || value > MPE_MAX_DETECTIONS) return fail(h, MPE_ERR_ARG, "detections_hint must be in [0, MPE_MAX_DETECTIONS]");
+    h->detections_hint = value;
     return MPE_OK;
   }
   if (!std::strcmp(name, "vote_list_cap")) {  // tests: a list this small overflows and exercises k2_vote_relost
@@ -2167,6 +2185,14 @@ int mpe_estimate_batch(mpe_handle* h, const uint8_t* frames, int n_frames, int r
   HIP_TRY(h, hipMemcpyAsync(results, h->results.p, (size_t)n_frames * sizeof(mpe_result), hipMemcpyDeviceToHost,
                             h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  {  // what the next call can expect (det_hint_for): the detections of a typical frame of this one (the 90th percentile
+     // of a sample: a few cluttered frames among clean ones do not switch the voting kernel)
+    const int step = std::max(1, n_frames / 1024);
+    std::vector<int> nd;
+    for (int i = 0; i < n_frames; i += step) nd.push_back(results[i].n_det);
+    std::nth_element(nd.begin(), nd.begin() + (nd.size() * 9) / 10, nd.end());
+    h->det_seen = nd[(nd.size() * 9) / 10];
+  }
   return MPE_OK;
 }
 

@@ -661,6 +661,56 @@ __device__ __forceinline__ unsigned k2_grid_bit(const K2Frame& F, float fx, floa
   const unsigned word = reinterpret_cast<const unsigned*>(F.grid)[idx >> 5];
   return (word >> (idx & 31u)) & 1u;
 }
+// Scan-carrying variant with many detections (CG, round 6).  With 21 detections the per-root prefilter — a single-
+// precision distance per unused detection and marker, 8 instructions each, 144 per root — was a quarter of the kernel.
+// A bit grid as above does not help here: the unused markers of a 5-LED rig back-project NEAR the triple's own
+// detections, where the clutter is, and every fifth root hits a set cell (measured: the wave's queue overflowed into
+// the strict list, 1.6 M -> 8.3 M entries per step).  Instead each cell of a coarse grid (32 x 32 over the detections'
+// bounding box, 4 KB of LDS) holds the MASK of the detections whose prefilter disc can reach it: one lookup per marker
+// gives the handful of candidates, and only those get the distance test — the same `pass` mask as the loop over all
+// detections, bit for bit (the candidates are a superset of the detections within the prefilter radius).
+#define K2_CG_MIN_DETECTIONS 9  // the launcher picks the variant from its detection-count hint
+#define K2_CGRID 32
+__device__ __forceinline__ unsigned k2_cgrid_candidates(const unsigned* cmask, float fx, float fy) {
+  const unsigned ix = min(k2_cvt_pk_u8(fx, 0u, 0u), (unsigned)(K2_CGRID - 1));  // (saturating conversions: NaN, negative
+  const unsigned iy = min(k2_cvt_pk_u8(fy, 0u, 0u), (unsigned)(K2_CGRID - 1));  //  -> cell 0, large -> the last: empty)
+  return cmask[iy * K2_CGRID + ix];
+}
+// cells 2 .. K2_CGRID - 3 span the detections' bounding box + 2 R; a coordinate c lands in cell floor(c) or floor(c) + 1
+// whatever the conversion's rounding, so detection a (centre (cx, cy), radius r, in cells) is entered in the cells
+// floor(c - r) .. floor(c + r) + 1 of both axes (the square around its disc); cells 0 and K2_CGRID - 1 stay empty.
+// All threads; cmask must be zero; gp = {ginv, gxo, gyo}: cell coordinates of a pixel (u, v) = (u ginv + gxo, v ginv + gyo)
+__device__ __forceinline__ void k2_cgrid_build(const double (*px)[2], int n_d, double back_tol, unsigned* cmask, float* gp,
+                                               int tid, int nthr) {
+  const float R = (float)((back_tol * (1.0 + 1e-4) + 0.25) * 1.0001 + 1e-3);
+  float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
+  for (int a = 0; a < n_d; ++a) {
+    const float u = (float)px[a][0], v = (float)px[a][1];
+    x0 = fminf(x0, u);
+    x1 = fmaxf(x1, u);
+    y0 = fminf(y0, v);
+    y1 = fmaxf(y1, v);
+  }
+  const float span = fmaxf(x1 - x0, y1 - y0) + 2.0f * R;
+  const float cell = fmaxf(span * (1.0f / (K2_CGRID - 6)), 0.25f);
+  const float inv = 1.0f / cell;
+  const float ox = 2.0f - (x0 - R) * inv, oy = 2.0f - (y0 - R) * inv;
+  if (tid == 0) {
+    gp[0] = inv;
+    gp[1] = ox;
+    gp[2] = oy;
+  }
+  const float r = R * inv + 1e-3f;
+  for (int a = tid; a < n_d; a += nthr) {
+    const float u = (float)px[a][0], v = (float)px[a][1];
+    if (!(u == u && v == v)) continue;
+    const float cxg = u * inv + ox, cyg = v * inv + oy;  // (>= 2: truncation is floor)
+    const int ix0 = max(1, (int)(cxg - r)), ix1 = min(K2_CGRID - 2, (int)(cxg + r) + 1);
+    const int iy0 = max(1, (int)(cyg - r)), iy1 = min(K2_CGRID - 2, (int)(cyg + r) + 1);
+    for (int iy = iy0; iy <= iy1; ++iy)
+      for (int ix = ix0; ix <= ix1; ++ix) atomicOr(&cmask[iy * K2_CGRID + ix], 1u << a);
+  }
+}
 // the block's grid: cells that a point within R of a detection can land in.  All threads; the grid must be zero; the
 // parameters are returned through gp = {ginv, gxo, gyo}: grid coordinates of a pixel (u, v) = (u ginv + gxo, v ginv +
 // gyo).  A coordinate c lands in cell floor(c) or floor(c) + 1 whatever the conversion's rounding, i.e. cell X takes
@@ -668,8 +718,10 @@ __device__ __forceinline__ unsigned k2_grid_bit(const K2Frame& F, float fx, floa
 // floor(cx - hw) to floor(cx + hw) + 1, hw the disc's half-width over y in [Y - 1, Y + 1).  The single-precision chain
 // that produces c is off by < 0.01 px (tests/test_vote_host.py; margin in R: 0.25 px).  248 cells span the detections'
 // bounding box + 2 R, from cell 3 on, so that cells 0 and 255 — where everything outside the grid lands — stay empty.
+template <int DIM = K2_GRID>
 __device__ __forceinline__ void k2_grid_build(const double (*px)[2], int n_d, double back_tol, u64* grid, float* gp, int tid,
                                               int nthr) {
+  constexpr int WORDS = DIM / 64;
   const float R = (float)(back_tol * (1.0 + 1e-4) + 0.25);
   float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
   for (int a = 0; a < n_d; ++a) {  // (every thread: n_d <= 32 LDS reads, once per block)
@@ -680,7 +732,7 @@ __device__ __forceinline__ void k2_grid_build(const double (*px)[2], int n_d, do
     y1 = fmaxf(y1, v);
   }
   const float span = fmaxf(x1 - x0, y1 - y0) + 2.0f * R;
-  const float cell = fmaxf(span * (1.0f / (K2_GRID - 8)), 0.25f);
+  const float cell = fmaxf(span * (1.0f / (DIM - 8)), 0.25f);
   const float inv = 1.0f / cell;
   const float ox = 3.0f - (x0 - R) * inv, oy = 3.0f - (y0 - R) * inv;
   if (tid == 0) {
@@ -693,17 +745,17 @@ __device__ __forceinline__ void k2_grid_build(const double (*px)[2], int n_d, do
     const float u = (float)px[a][0], v = (float)px[a][1];
     if (!(u == u && v == v)) continue;
     const float cxg = u * inv + ox, cyg = v * inv + oy;  // (>= 3: truncation is floor)
-    const int iy0 = max(1, (int)(cyg - r)), iy1 = min(K2_GRID - 2, (int)(cyg + r) + 1);
+    const int iy0 = max(1, (int)(cyg - r)), iy1 = min(DIM - 2, (int)(cyg + r) + 1);
     for (int iy = iy0; iy <= iy1; ++iy) {
       const float dy = fmaxf(0.f, fmaxf((float)(iy - 1) - cyg, cyg - (float)(iy + 1)));
       const float hh = r * r - dy * dy;
       if (!(hh >= 0.f)) continue;
       const float hw = sqrtf(hh);
-      const int ix0 = max(1, (int)(cxg - hw)), ix1 = min(K2_GRID - 2, (int)(cxg + hw) + 1);
+      const int ix0 = max(1, (int)(cxg - hw)), ix1 = min(DIM - 2, (int)(cxg + hw) + 1);
       for (int w = ix0 >> 6; w <= (ix1 >> 6); ++w) {
         const int lo = max(ix0, 64 * w) - 64 * w, hi = min(ix1, 64 * w + 63) - 64 * w;
         const u64 m = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1)) & ~((1ull << lo) - 1);
-        atomicOr(&grid[iy * K2_GRID_WORDS + w], m);
+        atomicOr(&grid[iy * WORDS + w], m);
       }
     }
   }
@@ -817,11 +869,13 @@ __device__ __forceinline__ void k2_defer_flush(const K2Frame& F, int& count, boo
 // NP (plain variant): the single-precision copies of the back-projections stay in REGISTERS as NP packed marker pairs
 // (2 NP >= the number of unused markers) instead of LDS columns that every (detection, marker) pair of the prefilter
 // would read again; 0 = the LDS columns (more than 8 unused markers).
-template <bool SCAN, int NP = 0, class Rider>
+template <bool SCAN, int NP = 0, bool CG = false, class Rider>
 __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, bool live, Rider& rider, int& vq_count) {
-  // (fast item only: a*b+c may fuse — its few-ulp differences from the strict arithmetic are what the suspect margins
-  //  and the strict re-evaluation absorb; the TU default stays -ffp-contract=off)
-#pragma clang fp contract(fast)
+  // (Round 6, measured and NOT kept: `#pragma clang fp contract(fast)` in this item and in solve_quartic_lit2 — the
+  //  VERDICT's "253 avoidable instructions" — fuses 45 of them (one per product chain: 2 962 -> 2 927 VALU in the C3
+  //  listing), moves no rate, and breaks default == strict on 25 of 65 536 C3 frames: the coefficients F0 .. F4 are the
+  //  one place where the fast and the strict arithmetic agree BIT FOR BIT today, which is why the suspect screen only
+  //  has to watch Ferrari's own cancellations.  profiles/round6_parity_soak_votes_contract_fast.json)
   const unsigned ii = F.trii[ti];
   const int c0 = ii & 0xFF, c1 = (ii >> 8) & 0xFF, c2 = (ii >> 16) & 0xFF;
   const bool swap = (ii >> 24) & 1;
@@ -1054,14 +1108,32 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
         const f32x2 s0 = d0 * d0, s1 = d1 * d1;
         return k2_fminf(s0.x + s0.y, s1.x + s1.y) <= F.thr_pre;
       };
-      unsigned pass = (near(af0) ? lsb0 : 0u) | (near(af1) ? lsb1 : 0u);
-      for (unsigned m = rest; m;) {  // (more than five detections)
-        const unsigned lsb = m & (0u - m);
-        const int a = __builtin_ctz(m);
-        m ^= lsb;
-        pass |= near(F.pxf[a]) ? lsb : 0u;
+      unsigned pass;
+      if constexpr (CG) {
+        // many detections: the candidates of the (<= 2) back-projections' cells, then the same distance test as below
+        // for those alone (F.grid / ginv / gxo / gyo describe the candidate grid in this variant)
+        const unsigned* cm = reinterpret_cast<const unsigned*>(F.grid);
+        unsigned cand = k2_cgrid_candidates(cm, __builtin_fmaf(uv0.x, F.ginv, F.gxo), __builtin_fmaf(uv0.y, F.ginv, F.gyo));
+        if (F.nuo > 1)  // (uniform)
+          cand |= k2_cgrid_candidates(cm, __builtin_fmaf(uv1.x, F.ginv, F.gxo), __builtin_fmaf(uv1.y, F.ginv, F.gyo));
+        pass = 0u;
+        for (unsigned m = cand & unused; m;) {
+          const unsigned lsb = m & (0u - m);
+          const int a = __builtin_ctz(m);
+          m ^= lsb;
+          pass |= near(F.pxf[a]) ? lsb : 0u;
+        }
+        if (!chain_ok) pass = unused;  // (the double-precision evaluation decides)
+      } else {
+        pass = (near(af0) ? lsb0 : 0u) | (near(af1) ? lsb1 : 0u);
+        for (unsigned m = rest; m;) {  // (more than five detections)
+          const unsigned lsb = m & (0u - m);
+          const int a = __builtin_ctz(m);
+          m ^= lsb;
+          pass |= near(F.pxf[a]) ? lsb : 0u;
+        }
+        if (!chain_ok) pass = unused;  // (the double-precision evaluation decides)
       }
-      if (!chain_ok) pass = unused;  // (the double-precision evaluation decides)
       // slots by ballot: the queue's fill count is wave-uniform (a scalar register), no LDS atomic
       const bool want = root_sus || (pass != 0u && may_vote);
       const u64 bal = __ballot(want);
@@ -1167,7 +1239,9 @@ __device__ __forceinline__ void k2_vote_item(const K2Frame& F, int ti, int pj, b
 // x P(n_m,3) + marker permutation, the reference's loop order — lies in [item_range[2f], item_range[2f+1]); the
 // arithmetic of an item is the hot kernel's (same k2_vote_item).
 #define K2_FAST_HIST (MPE_FAST_VOTE_DETECTIONS * MPE_MAX_MARKERS)  // histogram rows a fast voting block keeps in LDS
-template <bool SCAN, bool RANGE = false, int NP = 0>
+// CG (scan-carrying variant only): frames with many detections — a 128 x 128-bit occupancy grid of the detections decides
+// per root whether any unused detection can be near a back-projection (see K2_CGRID)
+template <bool SCAN, bool RANGE = false, int NP = 0, bool CG = false>
 __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_detections* __restrict__ dets, SolveParams sp,
                                                       const double* __restrict__ tab, uint32_t* __restrict__ hist,
                                                       int splits, ScanArgs scan, const int* __restrict__ item_range,
@@ -1257,6 +1331,14 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
       s_gp[2] = 0.f;
     }
   }
+  __shared__ unsigned s_cmask[CG ? K2_CGRID * K2_CGRID : 2];
+  __shared__ float s_cgp[4];
+  if constexpr (CG) {
+    for (int i = tid; i < K2_CGRID * K2_CGRID; i += nthr) s_cmask[i] = 0;
+    __syncthreads();
+    k2_cgrid_build(s_px, n_d, sp.back_tol, s_cmask, s_cgp, tid, nthr);
+    __syncthreads();
+  }
   if constexpr (DEFER) {
     for (int i = tid; i < K2_GRID * K2_GRID_WORDS; i += nthr) s_grid[i] = 0;
     __syncthreads();
@@ -1313,7 +1395,8 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
   const K2Frame F = {s_trii, s_tri, s_px, s_pxf, s_q,  s_qf, s_hist, tab_eff,     s_tab,   n_d,  nuo,
                      nthr,   tid,   esz_eff, fx, fy,   cx,   cy,     sp.back_tol, thr_pre, s_vq, 64, p_lo,
                      &s_susd, fixup.screen != 0u, f, s_sus, &s_sus_n, (unsigned)SUSN,
-                     s_grid, s_gp[0], s_gp[1], s_gp[2], s_trif};
+                     CG ? reinterpret_cast<u64*>(s_cmask) : s_grid, CG ? s_cgp[0] : s_gp[0], CG ? s_cgp[1] : s_gp[1], CG ? s_cgp[2] : s_gp[2],
+                     s_trif};
   int vq_count = 0;  // entries in this wave's queue (wave-uniform)
   for (int tc0 = 0; tc0 < n_combos; tc0 += TRI) {
     const int ntri = min(TRI, n_combos - tc0);
@@ -1361,7 +1444,7 @@ __global__ __launch_bounds__(K2_THREADS, K2_MIN_WAVES(NP)) void k2_vote(mpe_dete
           }
         }
       }
-      k2_vote_item<SCAN, NP>(F, ti, p_lo + pj, live, rider, vq_count);
+      k2_vote_item<SCAN, NP, CG>(F, ti, p_lo + pj, live, rider, vq_count);
       ti = ti_keep;
       pj = pj_keep;
     }
@@ -1730,8 +1813,12 @@ hipError_t launch_k2_vote(mpe_detections* dets, int n_frames, const SolveParams&
           (size_t)sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2) * K2_LTAB * sizeof(double) +
           (size_t)(threads / 64) * K2_VQ_CAP * K2_VQ_WORDS * sizeof(u64);
     if (scanned_bytes) *scanned_bytes = (size_t)sa.n_chunks * chunk_bytes;
-    hipLaunchKernelGGL((k2_vote<true, false>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
-                       splits, sa, (const int*)nullptr, 0, fx);
+    if (n_det_hint >= K2_CG_MIN_DETECTIONS)
+      hipLaunchKernelGGL((k2_vote<true, false, 0, true>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp,
+                         tab, hist, splits, sa, (const int*)nullptr, 0, fx);
+    else
+      hipLaunchKernelGGL((k2_vote<true, false>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab,
+                         hist, splits, sa, (const int*)nullptr, 0, fx);
   } else if (nuo <= 2 && !item_range && splits == 1) {
     // <= 5 markers and nothing to scan (small batches, single frames, the tracker's brute-force initialisation, the
     // stage-level vote entry): the scan-carrying variant all the same, with an EMPTY rider — every service point is a
@@ -1743,8 +1830,12 @@ hipError_t launch_k2_vote(mpe_detections* dets, int n_frames, const SolveParams&
     lds = (size_t)(threads / 64) * chunk_bytes +
           (size_t)sp.n_markers * (sp.n_markers - 1) * (sp.n_markers - 2) * K2_LTAB * sizeof(double) +
           (size_t)(threads / 64) * K2_VQ_CAP * K2_VQ_WORDS * sizeof(u64);
-    hipLaunchKernelGGL((k2_vote<true, false>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab, hist,
-                       splits, sa, (const int*)nullptr, 0, fx);
+    if (n_det_hint >= K2_CG_MIN_DETECTIONS)
+      hipLaunchKernelGGL((k2_vote<true, false, 0, true>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp,
+                         tab, hist, splits, sa, (const int*)nullptr, 0, fx);
+    else
+      hipLaunchKernelGGL((k2_vote<true, false>), dim3((unsigned)(n_frames * splits)), dim3(threads), lds, s, dets, sp, tab,
+                         hist, splits, sa, (const int*)nullptr, 0, fx);
   } else {
     // plain kernel: the prefilter's single-precision back-projections in registers as (nuo + 1) / 2 packed marker pairs
     // (up to 8 unused markers), else in LDS columns; the forensics instantiation (item_range) the same way

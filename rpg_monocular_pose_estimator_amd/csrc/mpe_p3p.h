@@ -247,7 +247,6 @@ __device__ __forceinline__ double div_with_rcp(double a, double den, double rden
 // wave take both cases, a branch would run both sides): the same operations on the same operands, and the two
 // quotients share one reciprocal of denom.
 __device__ __forceinline__ C2 cdiv_lit2(C2 n, C2 d) {
-#pragma clang fp contract(fast)
   const bool swap = fabs(d.re) < fabs(d.im);
   const double big = swap ? d.im : d.re, small = swap ? d.re : d.im;
   const double p = swap ? n.re : n.im, q = swap ? n.im : n.re;
@@ -345,9 +344,6 @@ __device__ __forceinline__ double cabs1(C2 z) { return fabs(z.re) + fabs(z.im); 
 template <class Service>
 __device__ __forceinline__ void solve_quartic_lit2(double A, double B, double C, double D, double E, double rr[4],
                                                    Service service, int& cancel_exp) {
-  // (fast item only: a*b+c may fuse — its few-ulp differences from the strict arithmetic are what the suspect margins
-  //  and the strict re-evaluation absorb; the TU default stays -ffp-contract=off)
-#pragma clang fp contract(fast)
   int minexp = 4096;  // smallest exponent(|result|) - exponent(sum of |operands|) seen (a NaN result: +, never reported)
   auto check = [&](const double result, const double operands) {
     minexp = min(minexp, p3p_expo(result) - p3p_expo(operands));

@@ -33,7 +33,9 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 CONFIG = sys.argv[2] if len(sys.argv) > 2 else "C2"
 OUT = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out/soak_votes_%s" % CONFIG
 CH = min(N, 32768 if CONFIG != "C3" else 2048)
-cfg = synth.CONFIGS[CONFIG]
+cfg = dict(synth.CONFIGS[CONFIG])
+if os.environ.get("MPE_SOAK_DISTRACTORS"):  # cluttered frames (the occupancy-grid variant of the <= 5-marker kernel)
+    cfg["n_distractors"] = int(os.environ["MPE_SOAK_DISTRACTORS"])
 rows, cols = cfg["rows"], cfg["cols"]
 K, D = synth.camera_for(rows, cols)
 markers = np.asarray(cfg["markers"])

@@ -390,6 +390,25 @@ def test_bench_entry_three_ranks_report():
     _check_rank_report(rec, 3)
 
 
+def test_bench_entry_eight_ranks_report():
+    """World size 8 — the shape of the driver's scaling run (`bench.py --gpus 8`, one rank per GPU of one node; no such
+    node has been available to this build in six rounds) — over gloo: every rank seen, contiguous shard bounds that
+    tile the global batch, a distinct checksum per rank's shard on rank 0, records in global frame order."""
+    import json
+    out = _run_bench(["--gpus", "8", "--plumbing-only", "--steps", "2", "--warmup", "1", "--frames", "64"], timeout=420)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-1500:])
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 8 and rec["gather_intact"] is True and rec["records_on_rank0"] == 8 * 64
+    _check_rank_report(rec, 8)
+    assert rec["shard_bounds"] == [[64 * r, 64 * (r + 1)] for r in range(8)]
+    from rpg_monocular_pose_estimator_amd import parallel
+    assert [list(parallel.shard_bounds(8 * 64, r, 8)) for r in range(8)] == rec["shard_bounds"]
+    # uneven split of a global batch: contiguous, ordered, complete (the C ABI's mpe_shard_bounds rule)
+    b = [parallel.shard_bounds(1003, r, 8) for r in range(8)]
+    assert b[0][0] == 0 and b[-1][1] == 1003 and all(b[i][1] == b[i + 1][0] for i in range(7))
+    assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
 def test_bench_entry_under_a_launcher_and_error_paths(lib):
     """Under torch.distributed.run (what the driver uses) the entry reads RANK / WORLD_SIZE; a WORLD_SIZE that
     disagrees with --gpus and a --gpus larger than the visible GPU count are hard errors with a clear message."""

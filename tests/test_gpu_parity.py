@@ -1199,6 +1199,52 @@ def test_vote_arithmetics_with_the_reference_librarys_powers(orc):
 
 
 @pytest.mark.gpu
+def test_occupancy_grid_variant_of_the_scan_carrying_kernel(orc):
+    """Round 6: with 9 or more detections expected per frame (option "detections_hint", or the count the launcher of a
+    stage-level call knows) the <= 5-marker voting kernel decides per root with a 128 x 128-bit occupancy grid of the
+    detections whether any unused detection can be near a back-projection, and queues the few roots that can.  Same
+    histograms as the strict kernel and the oracle on cluttered frames (9 .. 32 detections); the hint never changes a
+    record (the pipelined path with and without it, byte for byte)."""
+    import torch
+    h = mpe.Handle()
+    try:
+        K, _ = synth.camera_for(480, 752)
+        rng = np.random.default_rng(77)
+        dets = []
+        for kind, n in (("d4", 6), ("d16", 6)):
+            d = synth.make_clutter_frames(kind, n, seed=91)
+            dets += [orc.find_leds(f, orc.make_params(), d["K"], d["D"])[0] for f in d["frames"]]
+        dets += [np.column_stack([rng.uniform(100, 650, k), rng.uniform(60, 420, k)]) for k in (9, 12, 17, 25, 32)]
+        assert min(len(x) for x in dets) >= 9
+        h.set_option("vote_arith", 4)
+        strict = h.vote_batch(dets, synth.M5, K, 5.0)
+        h.set_option("vote_arith", 3)
+        got = h.vote_batch(dets, synth.M5, K, 5.0)   # (hint = the largest count of the call: the grid variant)
+        for i, x in enumerate(dets):
+            assert np.array_equal(got[i], strict[i]), (i, len(x), np.argwhere(got[i] != strict[i])[:5])
+            if len(x) <= 21:
+                assert np.array_equal(got[i], orc.vote_histogram(x, synth.M5, K, 5.0)), (i, len(x))
+        # M4 (one unused marker) through the same variant
+        got4 = h.vote_batch(dets[:6], synth.CONFIGS["C1"]["markers"], K, 5.0)
+        for i in range(6):
+            assert np.array_equal(got4[i], orc.vote_histogram(dets[i], synth.CONFIGS["C1"]["markers"], K, 5.0)), i
+        # the pipelined path: records with the hint = records without
+        d = synth.make_clutter_frames("d16", 64, seed=92)
+        big = torch.from_numpy(d["frames"]).cuda().repeat(260, 1, 1)[:16384 + 32].contiguous()
+        h.set_option("detections_hint", 5)    # (an explicit hint below 9: the per-detection prefilter of round 5)
+        ra = h.estimate_batch(big, d["markers"], d["K"], d["D"], mpe.demo_params())
+        assert h.get_option("detections_seen") == 21   # (what an automatic hint would use after this call)
+        h.set_option("detections_hint", 21)
+        assert h.get_option("detections_hint") == 21
+        rb = h.estimate_batch(big, d["markers"], d["K"], d["D"], mpe.demo_params())
+        assert np.array_equal(ra.view(np.uint8), rb.view(np.uint8))
+        ro = orc.estimate_batch(d["frames"][:16], d["markers"], d["K"], d["D"], orc.make_params(), n_threads=4)
+        assert np.array_equal(rb["status"][:16], ro["status"]) and np.array_equal(rb["n_corr"][:16], ro["n_corr"])
+    finally:
+        h.close()
+
+
+@pytest.mark.gpu
 def test_a_full_suspect_list_costs_time_not_poses(orc):
     """a suspect list that overflows used to LOSE entries and reject the frame
     (MPE_FRAME_VOTE_LIST_FULL).  Now the frames that lost an entry are voted again, whole, by the strict loop nest
