@@ -80,6 +80,13 @@ def device_source():
             txt = fh.read()
         txt = re.sub(r"//@file-prologue\n.*?//@file-prologue-end\n", "", txt, flags=re.S)
         txt = re.sub(r"//@file-epilogue\n.*?//@file-epilogue-end\n", "", txt, flags=re.S)
+        # the blob extraction's device functions live in a header both mpe_k1.hip and mpe_k3.hip include (round 6):
+        # its marked body stands where mpe_k1.hip includes it, the second include (mpe_k3.hip) is dropped
+        if "//@include-k1b-dev" in txt:
+            with open(os.path.join(_CSRC, "mpe_k1b_dev.h")) as fh:
+                hdr = fh.read()
+            body = hdr[hdr.index("//@k1b-dev-begin\n") + len("//@k1b-dev-begin\n"):hdr.index("//@k1b-dev-end\n")]
+            txt = re.sub(r"//@include-k1b-dev.*?//@include-k1b-dev-end\n", lambda m: body, txt, count=1, flags=re.S)
         out.append(txt)
     return "".join(out)
 
@@ -89,7 +96,7 @@ def source_fingerprint():
     (profiles/round3_pmc.json) to the code a bench run times."""
     import hashlib
     hsh = hashlib.sha256()
-    for name in DEVICE_SOURCES + ("mpe_p3p.h", "mpe_internal.h", "mpe_abi.cpp"):
+    for name in DEVICE_SOURCES + ("mpe_k1b_dev.h", "mpe_ddmath.h", "mpe_p3p.h", "mpe_internal.h", "mpe_abi.cpp"):
         with open(os.path.join(_CSRC, name), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]

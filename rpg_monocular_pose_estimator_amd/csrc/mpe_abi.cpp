@@ -101,6 +101,10 @@ struct mpe_handle {
   // last call whose records came back to the host saw, det_seen)
   int detections_hint = 0;
   int det_seen = 0;
+  unsigned long long* track_clk = nullptr;   // option "track_phase_clocks": pinned, device-visible; 5 stamps per frame
+  unsigned long long track_clk_sum[4] = {0, 0, 0, 0};
+  long long track_clk_n = 0;
+  int track_fused = 2;         // option "track_fused": a tracked frame's optimistic pass as one launch (k_track_frame)
   int lds_budget = 64 * 1024;  // K1b dynamic LDS per wave (bitmap rows)
   int vote_splits = 0;         // 0 = auto
   int vote_arith = 3;          // 3 (default since round 6) = fast voting arithmetic + strict re-evaluation of the hypotheses
@@ -1244,6 +1248,7 @@ int mpe_create(mpe_handle** out, int device) {
     return MPE_ERR_HIP;
   }
   h->stream = h->own_stream;
+  if (const char* e = std::getenv("MPE_TRACK_FUSED")) h->track_fused = std::max(0, std::min(2, std::atoi(e)));  // (A/B runs of scripts that take no options)
   *out = h;
   return MPE_OK;
 }
@@ -1266,6 +1271,7 @@ void mpe_destroy(mpe_handle* h) {
   h->track.release();
   h->mid.release();
   if (h->fix_ctl_host) (void)hipHostFree(h->fix_ctl_host);
+  if (h->track_clk) (void)hipHostFree(h->track_clk);
   h->fix.release();
   if (h->mailbox) (void)hipHostFree(h->mailbox);
   for (auto& e : h->ev)
@@ -1398,6 +1404,12 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "last_schedule") *value = h->last_schedule;
   else if (n == "vote_list_cap") *value = (int)h->fix_cap_limit;
   else if (n == "detections_hint") *value = h->detections_hint;
+  else if (n == "track_fused") *value = h->track_fused;
+  else if (n.rfind("track_phase_cycles_", 0) == 0) {  // mean shader-clock cycles of phase i = 0 .. 3 of the fused tracked frame
+    const int i = std::atoi(n.c_str() + 19);
+    if (i < 0 || i > 3) return fail(h, MPE_ERR_ARG, "phase out of range");
+    *value = h->track_clk_n ? (int)(h->track_clk_sum[i] / (unsigned long long)h->track_clk_n) : 0;
+  }
   else if (n == "detections_seen") *value = h->det_seen;
   else if (n == "k1b_general_blocks") *value = k1b_get_general_blocks();
   else if (n == "vote_fixup_items" || n == "vote_fixup_overflow" || n == "vote_relost_frames" || n == "vote_wide_frames") {
@@ -1587,6 +1599,24 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   if (!std::strcmp(name, "k1b_general_blocks")) {  // tuning, process-wide: waves of the general blob tier in flight
     if (value < 32 || value > 8192) return fail(h, MPE_ERR_ARG, "k1b_general_blocks must be in [32, 8192]");
     k1b_set_general_blocks(value);
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "track_phase_clocks")) {  // 1: time the phases of k_track_frame (scan / blobs / validate / refine)
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (value && !h->track_clk)
+      HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->track_clk), 8 * sizeof(unsigned long long), hipHostMallocDefault));
+    if (!value && h->track_clk) {
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      (void)hipHostFree(h->track_clk);
+      h->track_clk = nullptr;
+    }
+    for (auto& v : h->track_clk_sum) v = 0;
+    h->track_clk_n = 0;
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "track_fused")) {  // A/B: 0 = the tracked frame as the chain of four kernels (rounds 3 - 5)
+    // (2, the default: the kernel also stores the record to the caller's pinned memory itself; 1: fused kernel + copy)
+    h->track_fused = value < 0 ? 0 : (value > 2 ? 2 : value);
     return MPE_OK;
   }
   if (!std::strcmp(name, "detections_hint")) {  // detections per frame the caller expects (0 = automatic); see det_hint_for
@@ -1989,12 +2019,31 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   h->have_ms = false;
   if (h->track_profile) t_packed = clk::now();
   HIP_TRY(h, hipMemcpyAsync(d_in, mb, in_bytes, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, launch_k1a_scan(d_in + kTrackHeader, roi_bytes, static_cast<unsigned long long*>(h->flags.p), dp.thr, 0,
-                             h->stream));
   // the small blob tier alone first (a tracked ROI holds a handful of LEDs): three launches and a memset less per
   // frame; a frame that overflows it comes back with MPE_FRAME_TOO_MANY_ROWS and is repeated through the whole chain
   const bool optimistic = sp.n_markers >= 1 && sp.n_markers <= 8;
+  // round 6: that optimistic pass is ONE launch — scan, blob extraction, correspondences + validation, refinement as
+  // one kernel of one wave (k_track_frame): the three launch boundaries of the chain are gone (option "track_fused")
+  const bool fused = optimistic && h->track_fused;
+  if (!fused)
+    HIP_TRY(h, launch_k1a_scan(d_in + kTrackHeader, roi_bytes, static_cast<unsigned long long*>(h->flags.p), dp.thr, 0,
+                               h->stream));
   for (int pass = optimistic ? 0 : 1; pass < 2; ++pass) {
+    if (pass == 0 && fused) {
+      HIP_TRY(h, launch_track_frame(d_in, kTrackHeader, g, dp, sp, p->nearest_neighbour_pixel_tolerance,
+                                    static_cast<unsigned long long*>(h->flags.p), static_cast<uint32_t*>(h->hist.p),
+                                    h->mid.p, d_rec, h->stream, h->track_clk, h->track_fused >= 2 ? host_rec : nullptr));
+      if (h->track_fused < 2)
+        HIP_TRY(h, hipMemcpyAsync(host_rec, d_rec, sizeof(TrackRecord), hipMemcpyDeviceToHost, h->stream));
+      if (h->track_profile) t_queued = clk::now();
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      if (h->track_clk && host_rec->det.status != MPE_FRAME_TOO_MANY_ROWS) {
+        for (int i = 0; i < 4; ++i) h->track_clk_sum[i] += h->track_clk[i + 1] - h->track_clk[i];
+        ++h->track_clk_n;
+      }
+      if (host_rec->det.status != MPE_FRAME_TOO_MANY_ROWS) break;
+      continue;  // (rare: the whole chain, its own scan included — the fused kernel wrote the same flag words)
+    }
     HIP_TRY(h, launch_k1b_blobs(d_in + kTrackHeader, static_cast<unsigned long long*>(h->flags.p), 1, g, dp, &d_rec->det,
                                 static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp.n_markers, h->stream,
                                 nullptr, false, pass == 0));

@@ -2,6 +2,7 @@
 // mpe_k3.hip — K3 validate + refine, primitive batches, frame decode, spin (see mpe_kernels_common.h for the map of the kernel sources)
 #include "mpe_kernels_common.h"
 #include "mpe_k2_head.h"
+#include "mpe_k1b_dev.h"  // (the blob extraction's device functions: k_track_frame below runs a whole tracked frame)
 namespace mpe {
 //@file-prologue-end
 // =============================================================================================
@@ -285,13 +286,14 @@ size_t k3_mid_bytes(int n_frames) { return (size_t)(n_frames > 0 ? n_frames : 1)
 // checkCorrespondences run 16 at a time, one per lane, and are summed in combination order.
 // MODE 0 / 1: as described.  MODE 2 (optimisePose alone): only the rows are parsed, no validation.
 // ---------------------------------------------------------------------------------------------
+// (the body is a device function of one 64-thread block `blk`: k3a_validate is that block as a kernel, k_track_frame
+//  runs it behind the blob extraction of a tracked frame inside one launch)
 template <int MODE>
-__global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restrict__ dets,
-                                                   const uint32_t* __restrict__ hist, int n_frames, SolveParams sp,
-                                                   mpe_result* __restrict__ results, uint32_t* __restrict__ corr_out,
-                                                   const uint32_t* __restrict__ corr_in,
-                                                   const double* __restrict__ nn_pred, double nn_tol,
-                                                   TailMid* __restrict__ mid) {
+__device__ __forceinline__ void k3a_body(const mpe_detections* __restrict__ dets, const uint32_t* __restrict__ hist,
+                                         int n_frames, const SolveParams& sp, mpe_result* __restrict__ results,
+                                         uint32_t* __restrict__ corr_out, const uint32_t* __restrict__ corr_in,
+                                         const double* __restrict__ nn_pred, double nn_tol, TailMid* __restrict__ mid,
+                                         const int blk) {
   // dynamic LDS, sized for the actual marker count: per-lane contributions [4][16][3 n_m] and
   // back-projections [2 (rows - 3)][64]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restr
 
   const int tid = threadIdx.x;
   const int grp = tid >> 4, l = tid & 15;
-  const int f = blockIdx.x * K3_FRAMES_PER_BLOCK + grp;
+  const int f = blk * K3_FRAMES_PER_BLOCK + grp;
   const bool live = f < n_frames;
   const mpe_detections* d = dets + (live ? f : 0);
   mpe_result* res = results + (live ? f : 0);
@@ -594,6 +596,15 @@ __global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restr
 #undef s_part
 #undef s_q
 }
+template <int MODE>
+__global__ __launch_bounds__(64) void k3a_validate(const mpe_detections* __restrict__ dets,
+                                                   const uint32_t* __restrict__ hist, int n_frames, SolveParams sp,
+                                                   mpe_result* __restrict__ results, uint32_t* __restrict__ corr_out,
+                                                   const uint32_t* __restrict__ corr_in,
+                                                   const double* __restrict__ nn_pred, double nn_tol,
+                                                   TailMid* __restrict__ mid) {
+  k3a_body<MODE>(dets, hist, n_frames, sp, results, corr_out, corr_in, nn_pred, nn_tol, mid, (int)blockIdx.x);
+}
 
 // ---------------------------------------------------------------------------------------------
 // K3b  k3b_refine: ONE LANE PER FRAME.  computeTransformation (Kabsch, pose_estimator.cpp:908-930), then
@@ -704,14 +715,14 @@ struct GnGroupLds {
 __device__ __forceinline__ int k3g_tri(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void k3b_refine_group(const mpe_detections* __restrict__ dets, int n_frames, SolveParams sp,
-                                                       mpe_result* __restrict__ results, const TailMid* __restrict__ mid,
-                                                       int row_cap) {
+__device__ __forceinline__ void k3b_group_body(const mpe_detections* __restrict__ dets, int n_frames, const SolveParams& sp,
+                                               mpe_result* __restrict__ results, const TailMid* __restrict__ mid,
+                                               int row_cap, const int blk) {
   __shared__ GnGroupLds s_g[K3G_FRAMES];
   const int tid = threadIdx.x;
   const int grp = tid >> 4, l = tid & 15;
   GnGroupLds& G = s_g[grp];
-  const int f = blockIdx.x * K3G_FRAMES + grp;
+  const int f = blk * K3G_FRAMES + grp;
   const bool in_range = f < n_frames;
   const TailMid* m = mid + (in_range ? f : 0);
   const bool live = in_range && m->active;
@@ -949,6 +960,109 @@ __global__ __launch_bounds__(64) void k3b_refine_group(const mpe_detections* __r
     res->gn_iterations = iters;
     res->status = MPE_FRAME_POSE;
   }
+}
+template <int MODE>
+__global__ __launch_bounds__(64) void k3b_refine_group(const mpe_detections* __restrict__ dets, int n_frames, SolveParams sp,
+                                                       mpe_result* __restrict__ results, const TailMid* __restrict__ mid,
+                                                       int row_cap) {
+  k3b_group_body<MODE>(dets, n_frames, sp, results, mid, row_cap, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_track_frame — one TRACKED frame as ONE launch (round 6; pose_estimator.cpp:98-147 on an initialised estimator):
+// image scan of the ROI, blob extraction (small tier), nearest-neighbour correspondences + validation, Kabsch +
+// Gauss-Newton — the bodies of k1a_scan / k1b_blobs<K1bSmall> / k3a_validate<0> / k3b_refine_group<0>, one wave, one
+// after the other, with block barriers where a launch boundary used to be.  What it saves are the three launch
+// boundaries of a four-kernel chain (~3 us each on a stream whose kernels depend on each other); the arithmetic and
+// the records are the chain's, bit for bit (tests: test_track_step_matches_oracle_pieces, the tracker suites).
+// in: [2 MPE_MAX_MARKERS doubles of predicted pixels | ROI rows at pitch g.pitch]; a frame the small blob tier cannot
+// hold comes back with det.status = MPE_FRAME_TOO_MANY_ROWS and the caller repeats it through the chain of kernels.
+// ---------------------------------------------------------------------------------------------
+struct TrackFrameOut {  // (= TrackRecord of mpe_abi.cpp)
+  mpe_detections det;
+  uint32_t corr[2 * MPE_MAX_MARKERS];
+  mpe_result res;
+};
+// CLOCKS (option "track_phase_clocks"): the shader clock at the five phase boundaries -> clk[0 .. 4] (s_memtime)
+template <bool CLOCKS>
+__global__ __launch_bounds__(64) void k_track_frame(const uint8_t* __restrict__ in, size_t header_bytes, FrameGeom g,
+                                                    DetectParams dp, SolveParams sp, ThrTest thr, double nn_tol,
+                                                    u64* __restrict__ flags, uint32_t* __restrict__ hist,
+                                                    TailMid* __restrict__ mid, TrackFrameOut* __restrict__ out,
+                                                    int row_cap, unsigned long long* __restrict__ clk,
+                                                    TrackFrameOut* __restrict__ host_out) {
+  const int lane = threadIdx.x;
+  // the record goes to the caller's pinned host memory from here (132 16-byte stores) instead of through a copy
+  // command behind the kernel: one command less on the stream, ~4 us of a tracked frame
+  auto deliver = [&]() {
+    if (!host_out) return;
+    __syncthreads();  // (every lane's stores to *out are visible to the block)
+    static_assert(sizeof(TrackFrameOut) % 8 == 0, "record copied in 8-byte words");
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(out);
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(host_out);
+    for (unsigned i = lane; i < sizeof(TrackFrameOut) / 8; i += 64) d[i] = s[i];
+  };
+  auto stamp = [&](int i) {
+    if constexpr (CLOCKS) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (lane == 0) clk[i] = t;
+    }
+  };
+  stamp(0);
+  const uint8_t* roi = in + header_bytes;
+  // ---- the image pass over the ROI: one flag bit per 16-byte segment (k1a_scan's test, 64 segments per trip)
+  {
+    const size_t n_seg = ((size_t)g.rows * g.pitch) / 16;
+    const uint4* px = reinterpret_cast<const uint4*>(roi);
+    // (uniform trip counts: the ballots need every lane; eight independent loads in flight per lane — one after the
+    //  other the 15 trips of a 120 x 120 ROI each waited for their own miss: 4.2 us of a 100 us frame)
+    for (size_t s0 = 0; s0 < n_seg; s0 += 64 * 8) {
+      uint4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const size_t s = s0 + 64 * k + lane;
+        v[k] = make_uint4(0, 0, 0, 0);
+        if (s < n_seg) v[k] = px[s];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const u64 b = __ballot(any_gt16(v[k], thr) != 0);
+        if (lane == 0 && s0 + 64 * k < n_seg) flags[(s0 >> 6) + k] = b;
+      }
+    }
+  }
+  __syncthreads();  // (the flag words are read back by other lanes: workgroup-scope release / acquire)
+  stamp(1);
+  // ---- blob extraction, small tier (the frame fills its slot: no per-frame window)
+  k1b_wave<K1bSmall>(0, true, roi, flags, g, dp, &out->det, nullptr, nullptr);
+  __syncthreads();
+  stamp(2);
+  if (out->det.status == MPE_FRAME_TOO_MANY_ROWS) {  // (uniform: written before the barrier)
+    deliver();
+    return;
+  }
+  // ---- correspondences by nearest neighbour to the predicted pixels, validation; Kabsch + Gauss-Newton
+  k3a_body<0>(&out->det, hist, 1, sp, &out->res, out->corr, nullptr, reinterpret_cast<const double*>(in), nn_tol, mid, 0);
+  __syncthreads();
+  stamp(3);
+  k3b_group_body<0>(&out->det, 1, sp, &out->res, mid, row_cap, 0);
+  stamp(4);
+  deliver();
+}
+hipError_t launch_track_frame(const uint8_t* in, size_t header_bytes, const FrameGeom& g, const DetectParams& dp,
+                              const SolveParams& sp, double nn_tol, unsigned long long* flags, uint32_t* hist, void* mid_buf,
+                              void* out_record, hipStream_t s, unsigned long long* phase_clocks, void* host_record) {
+  const int rows = sp.n_markers > 3 ? sp.n_markers : 4;
+  const size_t lds_a = ((size_t)K3_FRAMES_PER_BLOCK * K3_GROUP * 3 * sp.n_markers + (size_t)2 * (rows - 3) * 64) * sizeof(double);
+  if (phase_clocks)
+    hipLaunchKernelGGL(k_track_frame<true>, dim3(1), dim3(64), lds_a, s, in, header_bytes, g, dp, sp, make_thr_test(dp.thr),
+                       nn_tol, (u64*)flags, hist, static_cast<TailMid*>(mid_buf), static_cast<TrackFrameOut*>(out_record),
+                       rows, phase_clocks, static_cast<TrackFrameOut*>(host_record));
+  else
+    hipLaunchKernelGGL(k_track_frame<false>, dim3(1), dim3(64), lds_a, s, in, header_bytes, g, dp, sp, make_thr_test(dp.thr),
+                       nn_tol, (u64*)flags, hist, static_cast<TailMid*>(mid_buf), static_cast<TrackFrameOut*>(out_record),
+                       rows, (unsigned long long*)nullptr, static_cast<TrackFrameOut*>(host_record));
+  return hipGetLastError();
 }
 
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,

@@ -35,6 +35,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
 }
 typedef unsigned long long u64;
 static inline void atomicOr(u64* p, u64 v) { *p |= v; }
+static inline void atomicOr(unsigned* p, unsigned v) { *p |= v; }
 static inline void wave_sync() {}
 static inline void __syncthreads() {}
 static inline double __longlong_as_double(long long v) {
