@@ -84,6 +84,8 @@ struct mpe_handle {
   // what mpe_track_step_batch_collect needs to repeat a submission whose blobs overflowed the small tier
   struct PendingTrack {
     bool optimistic = false;
+    bool fused = false;        // the submission ran as k_track_frame: its flag words are per block, not the scan's bitstream
+    size_t slot_bytes = 0;
     FrameGeom g;
     DetectParams dp;
     SolveParams sp;
@@ -2005,7 +2007,7 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
   }
   TrackRecord* host_rec = reinterpret_cast<TrackRecord*>(mb + ((h->mailbox_cap - sizeof(TrackRecord)) & ~(size_t)63));
   HIP_TRY(h, h->frames.reserve(in_bytes + 16));
-  HIP_TRY(h, h->flags.reserve(flag_words(roi_bytes) * 8));
+  HIP_TRY(h, h->flags.reserve(std::max(flag_words(roi_bytes), track_flag_words(g)) * 8));
   HIP_TRY(h, h->work.reserve(4 * sizeof(int)));
   HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g, 1)));
   HIP_TRY(h, h->hist.reserve(MPE_HIST_STRIDE * sizeof(uint32_t)));
@@ -2030,9 +2032,12 @@ int mpe_track_step(mpe_handle* h, const uint8_t* img, int rows, int cols, size_t
                                h->stream));
   for (int pass = optimistic ? 0 : 1; pass < 2; ++pass) {
     if (pass == 0 && fused) {
-      HIP_TRY(h, launch_track_frame(d_in, kTrackHeader, g, dp, sp, p->nearest_neighbour_pixel_tolerance,
-                                    static_cast<unsigned long long*>(h->flags.p), static_cast<uint32_t*>(h->hist.p),
-                                    h->mid.p, d_rec, h->stream, h->track_clk, h->track_fused >= 2 ? host_rec : nullptr));
+      const bool deliver = h->track_fused >= 2;  // the kernel stores the record to the pinned mailbox itself
+      TrackFramesArgs ta = {d_in + kTrackHeader, roi_bytes, reinterpret_cast<const double*>(d_in), nullptr,
+                            static_cast<unsigned long long*>(h->flags.p), static_cast<uint32_t*>(h->hist.p), h->mid.p,
+                            &d_rec->det, d_rec->corr, &d_rec->res, deliver ? &host_rec->det : nullptr,
+                            deliver ? host_rec->corr : nullptr, deliver ? &host_rec->res : nullptr, h->track_clk};
+      HIP_TRY(h, launch_track_frames(ta, 1, g, dp, sp, p->nearest_neighbour_pixel_tolerance, h->stream));
       if (h->track_fused < 2)
         HIP_TRY(h, hipMemcpyAsync(host_rec, d_rec, sizeof(TrackRecord), hipMemcpyDeviceToHost, h->stream));
       if (h->track_profile) t_queued = clk::now();
@@ -2360,7 +2365,7 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
   }
   uint8_t* host_rec = mb + ((in_bytes + 255) & ~(size_t)255);
   HIP_TRY(h, h->frames.reserve(in_bytes + 16));
-  HIP_TRY(h, h->flags.reserve(flag_words((size_t)n * slot) * 8));
+  HIP_TRY(h, h->flags.reserve(std::max(flag_words((size_t)n * slot), (size_t)n * track_flag_words(g)) * 8));
   HIP_TRY(h, h->work.reserve((size_t)2 * (n + 1) * sizeof(int)));
   HIP_TRY(h, h->scratch.reserve(k1b_scratch_bytes(g, n)));
   HIP_TRY(h, h->hist.reserve((size_t)n * MPE_HIST_STRIDE * sizeof(uint32_t)));
@@ -2375,11 +2380,11 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
   mpe_result* d_res = reinterpret_cast<mpe_result*>(d_corr + (size_t)n * 2 * MPE_MAX_MARKERS);
   h->have_ms = false;
   HIP_TRY(h, hipMemcpyAsync(d_in, mb, in_bytes, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, launch_k1a_scan(d_pix, (size_t)n * slot, static_cast<unsigned long long*>(h->flags.p), dp.thr, 0, h->stream));
   // the small blob tier alone (see mpe_track_step): a slot that overflows it is seen by _collect, which then repeats
   // the blob extraction and the tail of the whole submission through the tier chain
   mpe_handle::PendingTrack& pt = h->pending_track;
   pt.optimistic = sp.n_markers >= 1 && sp.n_markers <= 8;
+  pt.fused = pt.optimistic && h->track_fused;
   pt.g = g;
   pt.dp = dp;
   pt.sp = sp;
@@ -2388,12 +2393,29 @@ int mpe_track_step_batch_submit(mpe_handle* h, const mpe_track_item* items, int 
   pt.d_pix = d_pix;
   pt.d_wins = d_wins;
   pt.d_pred = d_pred;
-  HIP_TRY(h, launch_k1b_blobs(d_pix, static_cast<unsigned long long*>(h->flags.p), n, g, dp, d_dets,
-                              static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp.n_markers, h->stream,
-                              d_wins, false, pt.optimistic));
-  HIP_TRY(h, launch_k3_tail(d_dets, static_cast<uint32_t*>(h->hist.p), n, sp, d_res, d_corr, nullptr, d_pred, pt.nn_tol,
-                            h->mid.p, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(host_rec, d_dets, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+  if (pt.fused) {
+    // round 6: the time step of the n streams as ONE launch, a block per stream (k_track_frame), the records stored to
+    // the pinned staging memory by the kernel (track_fused 2) — scan, small blob tier, tail and copy-out were five
+    // commands, and every stage waited for the slowest stream of the one before
+    const bool deliver = h->track_fused >= 2;
+    mpe_detections* hd = reinterpret_cast<mpe_detections*>(host_rec);
+    uint32_t* hc = reinterpret_cast<uint32_t*>(hd + n);
+    mpe_result* hr = reinterpret_cast<mpe_result*>(hc + (size_t)n * 2 * MPE_MAX_MARKERS);
+    TrackFramesArgs ta = {d_pix, slot, d_pred, d_wins, static_cast<unsigned long long*>(h->flags.p),
+                          static_cast<uint32_t*>(h->hist.p), h->mid.p, d_dets, d_corr, d_res, deliver ? hd : nullptr,
+                          deliver ? hc : nullptr, deliver ? hr : nullptr, nullptr};
+    HIP_TRY(h, launch_track_frames(ta, n, g, dp, sp, pt.nn_tol, h->stream));
+    if (!deliver) HIP_TRY(h, hipMemcpyAsync(host_rec, d_dets, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+  } else {
+    HIP_TRY(h, launch_k1a_scan(d_pix, (size_t)n * slot, static_cast<unsigned long long*>(h->flags.p), dp.thr, 0, h->stream));
+    HIP_TRY(h, launch_k1b_blobs(d_pix, static_cast<unsigned long long*>(h->flags.p), n, g, dp, d_dets,
+                                static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp.n_markers, h->stream,
+                                d_wins, false, pt.optimistic));
+    HIP_TRY(h, launch_k3_tail(d_dets, static_cast<uint32_t*>(h->hist.p), n, sp, d_res, d_corr, nullptr, d_pred, pt.nn_tol,
+                              h->mid.p, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(host_rec, d_dets, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+  }
+  pt.slot_bytes = slot;
   h->pending_track_n = n;
   h->pending_track_rec = host_rec;
   return MPE_OK;
@@ -2427,6 +2449,9 @@ int mpe_track_step_batch_collect(mpe_handle* h, mpe_detections* dets_out, uint32
       mpe_detections* d_dets = static_cast<mpe_detections*>(h->track.p);
       uint32_t* d_corr = reinterpret_cast<uint32_t*>(d_dets + n);
       mpe_result* d_res = reinterpret_cast<mpe_result*>(d_corr + (size_t)n * 2 * MPE_MAX_MARKERS);
+      if (pt.fused)  // (the blob tiers read the image pass's flag bitstream over all slots)
+        HIP_TRY(h, launch_k1a_scan(pt.d_pix, (size_t)n * pt.slot_bytes, static_cast<unsigned long long*>(h->flags.p),
+                                   pt.dp.thr, 0, h->stream));
       HIP_TRY(h, launch_k1b_blobs(pt.d_pix, static_cast<unsigned long long*>(h->flags.p), n, pt.g, pt.dp, d_dets,
                                   static_cast<int*>(h->work.p), static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, pt.sp.n_markers,
                                   h->stream, pt.d_wins));

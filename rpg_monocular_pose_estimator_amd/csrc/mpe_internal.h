@@ -131,15 +131,30 @@ size_t k3_mid_bytes(int n_frames);
 hipError_t launch_k3_tail(const mpe_detections* dets, const uint32_t* hist, int n_frames, const SolveParams& sp,
                           mpe_result* results, uint32_t* corr_out, const uint32_t* corr_in, const double* nn_pred,
                           double nn_tol, void* mid_buf, hipStream_t s, int mode = 0);
-// one tracked frame as one launch (mpe_k3.hip k_track_frame): in = [header_bytes of predicted pixels | ROI rows],
-// out_record = {mpe_detections, correspondences, mpe_result}; small blob tier only (status MPE_FRAME_TOO_MANY_ROWS:
-// repeat the frame through launch_k1a_scan / launch_k1b_blobs / launch_k3_tail)
-hipError_t launch_track_frame(const uint8_t* in, size_t header_bytes, const FrameGeom& g, const DetectParams& dp,
-                              const SolveParams& sp, double nn_tol, unsigned long long* flags, uint32_t* hist, void* mid_buf,
-                              void* out_record, hipStream_t s, unsigned long long* phase_clocks = nullptr,
-                              void* host_record = nullptr);
-// host_record (pinned host memory, optional): the kernel stores the finished record there itself — no copy command
-// phase_clocks (device, 5 words, optional): the shader clock at start / after the scan / blobs / validation / refinement
+// tracked frames as ONE launch, a block per frame (mpe_k3.hip k_track_frame): scan of the ROI slot, small blob tier,
+// nearest-neighbour correspondences + validation, refinement; the records go to three device arrays and, when h_* are
+// given (pinned host memory), are stored there by the kernel itself.  Small blob tier only: a frame it cannot hold has
+// det.status MPE_FRAME_TOO_MANY_ROWS and the caller repeats the submission through launch_k1a_scan / launch_k1b_blobs /
+// launch_k3_tail.
+struct TrackFramesArgs {
+  const uint8_t* pix;          // frame b at pix + b * slot_bytes (g.rows x g.pitch)
+  size_t slot_bytes;
+  const double* pred;          // 2 * MPE_MAX_MARKERS doubles per frame
+  const void* wins;            // n x {rows, cols, roi_x, roi_y} ints, or nullptr
+  unsigned long long* flags;   // n_frames * track_flag_words(g) words
+  uint32_t* hist;              // n_frames * MPE_HIST_STRIDE words
+  void* mid;                   // k3_mid_bytes(n_frames)
+  mpe_detections* dets;        // device records
+  uint32_t* corr;
+  mpe_result* res;
+  mpe_detections* h_dets;      // pinned host records (optional)
+  uint32_t* h_corr;
+  mpe_result* h_res;
+  unsigned long long* phase_clocks;  // optional: 5 shader-clock stamps of frame 0 (start / scan / blobs / validation / refinement)
+};
+size_t track_flag_words(const FrameGeom& g);
+hipError_t launch_track_frames(const TrackFramesArgs& t, int n_frames, const FrameGeom& g, const DetectParams& dp,
+                               const SolveParams& sp, double nn_tol, hipStream_t s);
 hipError_t launch_repack(const uint8_t* src, size_t src_stride, size_t src_frame_stride, int n_frames, int roi_x,
                          int roi_y, int roi_w, int roi_h, uint8_t* dst, int dst_pitch, hipStream_t s);
 

@@ -969,48 +969,66 @@ __global__ __launch_bounds__(64) void k3b_refine_group(const mpe_detections* __r
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_track_frame — one TRACKED frame as ONE launch (round 6; pose_estimator.cpp:98-147 on an initialised estimator):
-// image scan of the ROI, blob extraction (small tier), nearest-neighbour correspondences + validation, Kabsch +
-// Gauss-Newton — the bodies of k1a_scan / k1b_blobs<K1bSmall> / k3a_validate<0> / k3b_refine_group<0>, one wave, one
-// after the other, with block barriers where a launch boundary used to be.  What it saves are the three launch
-// boundaries of a four-kernel chain (~3 us each on a stream whose kernels depend on each other); the arithmetic and
-// the records are the chain's, bit for bit (tests: test_track_step_matches_oracle_pieces, the tracker suites).
-// in: [2 MPE_MAX_MARKERS doubles of predicted pixels | ROI rows at pitch g.pitch]; a frame the small blob tier cannot
-// hold comes back with det.status = MPE_FRAME_TOO_MANY_ROWS and the caller repeats it through the chain of kernels.
+// k_track_frame — TRACKED frames as ONE launch, one block of one wave per frame (round 6; pose_estimator.cpp:98-147 on
+// an initialised estimator): image scan of the frame's ROI slot, blob extraction (small tier), nearest-neighbour
+// correspondences + validation, Kabsch + Gauss-Newton — the bodies of k1a_scan / k1b_blobs<K1bSmall> / k3a_validate<0>
+// / k3b_refine_group<0>, one after the other, with block barriers where a launch boundary used to be, and the finished
+// records stored to the caller's pinned host memory by the kernel itself.  One frame (mpe_track_step) or the N streams
+// of a lock-step time step (mpe_track_step_batch): a block never waits for another stream's slowest stage.  The
+// arithmetic and the records are the chain's, bit for bit (tests: test_track_step_matches_oracle_pieces, the tracker
+// suites).  A frame the small blob tier cannot hold comes back with det.status = MPE_FRAME_TOO_MANY_ROWS and the
+// caller repeats the submission through the chain of kernels.
 // ---------------------------------------------------------------------------------------------
-struct TrackFrameOut {  // (= TrackRecord of mpe_abi.cpp)
-  mpe_detections det;
-  uint32_t corr[2 * MPE_MAX_MARKERS];
-  mpe_result res;
+struct TrackFrames {  // (kernel argument; frame b of the launch = block b)
+  const uint8_t* pix;        // ROI slots: frame b at pix + b * slot_bytes, g.rows x g.pitch
+  size_t slot_bytes;
+  const double* pred;        // predicted pixels, 2 * MPE_MAX_MARKERS doubles per frame
+  const FrameWin* wins;      // per-frame windows inside the slots, or nullptr (every frame fills its slot)
+  u64* flags;                // flag words, flag_words per frame (a region of its own per block)
+  size_t flag_words;
+  uint32_t* hist;            // MPE_HIST_STRIDE words per frame (unused by the nearest-neighbour mode, addressed all the same)
+  TailMid* mid;
+  mpe_detections* dets;      // device records: three arrays of n
+  uint32_t* corr;
+  mpe_result* res;
+  mpe_detections* h_dets;    // the same three arrays in pinned host memory, or nullptr (the caller copies)
+  uint32_t* h_corr;
+  mpe_result* h_res;
+  unsigned long long* clk;   // CLOCKS: 5 stamps of block 0
 };
+__device__ __forceinline__ void track_copy_words(void* dst, const void* src, unsigned bytes, int lane) {
+  const unsigned long long* s = static_cast<const unsigned long long*>(src);
+  unsigned long long* d = static_cast<unsigned long long*>(dst);
+  for (unsigned i = lane; i < bytes / 8; i += 64) d[i] = s[i];
+}
 // CLOCKS (option "track_phase_clocks"): the shader clock at the five phase boundaries -> clk[0 .. 4] (s_memtime)
 template <bool CLOCKS>
-__global__ __launch_bounds__(64) void k_track_frame(const uint8_t* __restrict__ in, size_t header_bytes, FrameGeom g,
-                                                    DetectParams dp, SolveParams sp, ThrTest thr, double nn_tol,
-                                                    u64* __restrict__ flags, uint32_t* __restrict__ hist,
-                                                    TailMid* __restrict__ mid, TrackFrameOut* __restrict__ out,
-                                                    int row_cap, unsigned long long* __restrict__ clk,
-                                                    TrackFrameOut* __restrict__ host_out) {
+__global__ __launch_bounds__(64) void k_track_frame(TrackFrames a, FrameGeom g, DetectParams dp, SolveParams sp, ThrTest thr,
+                                                    double nn_tol, int row_cap) {
   const int lane = threadIdx.x;
-  // the record goes to the caller's pinned host memory from here (132 16-byte stores) instead of through a copy
-  // command behind the kernel: one command less on the stream, ~4 us of a tracked frame
+  const int b = blockIdx.x;
+  mpe_detections* det = a.dets + b;
+  uint32_t* corr = a.corr + (size_t)b * 2 * MPE_MAX_MARKERS;
+  mpe_result* res = a.res + b;
+  u64* flags = a.flags + (size_t)b * a.flag_words;
+  // the record goes to the caller's pinned host memory from here instead of through a copy command behind the kernel
+  static_assert(sizeof(mpe_detections) % 8 == 0 && sizeof(mpe_result) % 8 == 0, "records copied in 8-byte words");
   auto deliver = [&]() {
-    if (!host_out) return;
-    __syncthreads();  // (every lane's stores to *out are visible to the block)
-    static_assert(sizeof(TrackFrameOut) % 8 == 0, "record copied in 8-byte words");
-    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(out);
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(host_out);
-    for (unsigned i = lane; i < sizeof(TrackFrameOut) / 8; i += 64) d[i] = s[i];
+    if (!a.h_dets) return;
+    __syncthreads();  // (every lane's stores to the device records are visible to the block)
+    track_copy_words(a.h_dets + b, det, sizeof(mpe_detections), lane);
+    track_copy_words(a.h_corr + (size_t)b * 2 * MPE_MAX_MARKERS, corr, 2 * MPE_MAX_MARKERS * sizeof(uint32_t), lane);
+    track_copy_words(a.h_res + b, res, sizeof(mpe_result), lane);
   };
   auto stamp = [&](int i) {
     if constexpr (CLOCKS) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
-      if (lane == 0) clk[i] = t;
+      if (lane == 0 && b == 0) a.clk[i] = t;
     }
   };
   stamp(0);
-  const uint8_t* roi = in + header_bytes;
-  // ---- the image pass over the ROI: one flag bit per 16-byte segment (k1a_scan's test, 64 segments per trip)
+  const uint8_t* roi = a.pix + (size_t)b * a.slot_bytes;
+  // ---- the image pass over the slot: one flag bit per 16-byte segment (k1a_scan's test)
   {
     const size_t n_seg = ((size_t)g.rows * g.pitch) / 16;
     const uint4* px = reinterpret_cast<const uint4*>(roi);
@@ -1026,42 +1044,58 @@ __global__ __launch_bounds__(64) void k_track_frame(const uint8_t* __restrict__ 
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const u64 b = __ballot(any_gt16(v[k], thr) != 0);
-        if (lane == 0 && s0 + 64 * k < n_seg) flags[(s0 >> 6) + k] = b;
+        const u64 bb = __ballot(any_gt16(v[k], thr) != 0);
+        if (lane == 0 && s0 + 64 * k < n_seg) flags[(s0 >> 6) + k] = bb;
       }
     }
   }
   __syncthreads();  // (the flag words are read back by other lanes: workgroup-scope release / acquire)
   stamp(1);
-  // ---- blob extraction, small tier (the frame fills its slot: no per-frame window)
-  k1b_wave<K1bSmall>(0, true, roi, flags, g, dp, &out->det, nullptr, nullptr);
+  // ---- blob extraction, small tier: the block's slot is "frame 0" of its own flag region
+  k1b_wave<K1bSmall>(0, true, roi, flags, g, dp, det, nullptr, a.wins ? a.wins + b : nullptr);
   __syncthreads();
   stamp(2);
-  if (out->det.status == MPE_FRAME_TOO_MANY_ROWS) {  // (uniform: written before the barrier)
+  if (det->status == MPE_FRAME_TOO_MANY_ROWS) {  // (uniform: written before the barrier)
     deliver();
     return;
   }
   // ---- correspondences by nearest neighbour to the predicted pixels, validation; Kabsch + Gauss-Newton
-  k3a_body<0>(&out->det, hist, 1, sp, &out->res, out->corr, nullptr, reinterpret_cast<const double*>(in), nn_tol, mid, 0);
+  k3a_body<0>(det, a.hist + (size_t)b * MPE_HIST_STRIDE, 1, sp, res, corr, nullptr, a.pred + (size_t)b * 2 * MPE_MAX_MARKERS,
+              nn_tol, a.mid + b, 0);
   __syncthreads();
   stamp(3);
-  k3b_group_body<0>(&out->det, 1, sp, &out->res, mid, row_cap, 0);
+  k3b_group_body<0>(det, 1, sp, res, a.mid + b, row_cap, 0);
   stamp(4);
   deliver();
 }
-hipError_t launch_track_frame(const uint8_t* in, size_t header_bytes, const FrameGeom& g, const DetectParams& dp,
-                              const SolveParams& sp, double nn_tol, unsigned long long* flags, uint32_t* hist, void* mid_buf,
-                              void* out_record, hipStream_t s, unsigned long long* phase_clocks, void* host_record) {
+size_t track_flag_words(const FrameGeom& g) { return ((size_t)g.rows * g.pitch / 16 + 63) / 64 + 2; }
+hipError_t launch_track_frames(const TrackFramesArgs& t, int n_frames, const FrameGeom& g, const DetectParams& dp,
+                               const SolveParams& sp, double nn_tol, hipStream_t s) {
+  if (n_frames <= 0) return hipSuccess;
   const int rows = sp.n_markers > 3 ? sp.n_markers : 4;
   const size_t lds_a = ((size_t)K3_FRAMES_PER_BLOCK * K3_GROUP * 3 * sp.n_markers + (size_t)2 * (rows - 3) * 64) * sizeof(double);
-  if (phase_clocks)
-    hipLaunchKernelGGL(k_track_frame<true>, dim3(1), dim3(64), lds_a, s, in, header_bytes, g, dp, sp, make_thr_test(dp.thr),
-                       nn_tol, (u64*)flags, hist, static_cast<TailMid*>(mid_buf), static_cast<TrackFrameOut*>(out_record),
-                       rows, phase_clocks, static_cast<TrackFrameOut*>(host_record));
+  TrackFrames a;
+  a.pix = t.pix;
+  a.slot_bytes = t.slot_bytes;
+  a.pred = t.pred;
+  a.wins = static_cast<const FrameWin*>(t.wins);
+  a.flags = reinterpret_cast<u64*>(t.flags);
+  a.flag_words = track_flag_words(g);
+  a.hist = t.hist;
+  a.mid = static_cast<TailMid*>(t.mid);
+  a.dets = t.dets;
+  a.corr = t.corr;
+  a.res = t.res;
+  a.h_dets = t.h_dets;
+  a.h_corr = t.h_corr;
+  a.h_res = t.h_res;
+  a.clk = t.phase_clocks;
+  if (t.phase_clocks)
+    hipLaunchKernelGGL(k_track_frame<true>, dim3((unsigned)n_frames), dim3(64), lds_a, s, a, g, dp, sp, make_thr_test(dp.thr),
+                       nn_tol, rows);
   else
-    hipLaunchKernelGGL(k_track_frame<false>, dim3(1), dim3(64), lds_a, s, in, header_bytes, g, dp, sp, make_thr_test(dp.thr),
-                       nn_tol, (u64*)flags, hist, static_cast<TailMid*>(mid_buf), static_cast<TrackFrameOut*>(out_record),
-                       rows, (unsigned long long*)nullptr, static_cast<TrackFrameOut*>(host_record));
+    hipLaunchKernelGGL(k_track_frame<false>, dim3((unsigned)n_frames), dim3(64), lds_a, s, a, g, dp, sp, make_thr_test(dp.thr),
+                       nn_tol, rows);
   return hipGetLastError();
 }
 
