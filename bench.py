@@ -40,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "frames/sec at 752x480, 5 LEDs, brute-force init; pose RMSE vs CPU ref"
-PMC_FILES = ("round5_pmc.json", "round4_pmc.json", "round3_pmc.json")
+PMC_FILES = ("round6_pmc.json", "round5_pmc.json", "round4_pmc.json", "round3_pmc.json")
 # FP64 VALU issue roof: a wave64 FP64 instruction occupies a SIMD for 4 cycles -> 256 CUs x 4 SIMDs x clock / 4
 # wave-instructions per second, at the SPEC clock (MI355X_MICROARCH.md: max clock 2400 MHz).  Until the round's last
 # collection the roof used the clock of the counter pass (GRBM_GUI_ACTIVE / duration; 2.04 - 2.37 GHz): a profiled pass

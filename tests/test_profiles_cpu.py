@@ -10,6 +10,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
+# the latest collection (profiles/collect.sh <round> -> profiles/install.py <round>)
+RN = "round6_" if os.path.exists(os.path.join(PROF, "round6_pmc.json")) else "round5_"
 
 
 def _mean(csv_name, kernel_sub, counter):
@@ -21,7 +23,7 @@ def _mean(csv_name, kernel_sub, counter):
 
 @pytest.fixture(scope="module")
 def pmc():
-    return json.load(open(os.path.join(PROF, "round5_pmc.json")))
+    return json.load(open(os.path.join(PROF, "%spmc.json" % RN)))
 
 
 @pytest.mark.parametrize("key,tol", [("C2", 0.0), ("fused_C2", 0.0), ("C2_d4", 0.0), ("C2_d16", 0.03)])
@@ -65,10 +67,10 @@ def test_scan_traffic_is_the_algorithmic_bytes_and_a_little(pmc):
 
 
 def test_the_bench_line_of_the_collection_used_these_counters(pmc):
-    b = json.load(open(os.path.join(PROF, "round5_bench.json")))
+    b = json.load(open(os.path.join(PROF, RN + "bench.json")))
     assert b["roofline"]["counters"]["from_a_build_of_these_sources"] is True
     import rpg_monocular_pose_estimator_amd as mpe
-    assert pmc["source_fingerprint"] == mpe.source_fingerprint(), "profiles/round5_pmc.json is not of this tree's kernels"
+    assert pmc["source_fingerprint"] == mpe.source_fingerprint(), "profiles/%spmc.json is not of this tree's kernels" % RN
     assert b["legs_failed"] == []
     for leg in ("d4", "d16"):
         r = b["clutter"][leg]["roofline"]
