@@ -12,11 +12,16 @@
 
 MPE_FACADE_BEGIN
 
+//! the last back-end failure of a static primitive (P3P::*, LEDDetector::*), "" if none; the reference's primitives
+//! have no error channel, these keep its return values and say why here
+const char* mpe_facade_last_error();
+
 class LEDDetector {
  public:
   //! led_detector.cpp:35-112.  pixel_positions is only rewritten when at least one LED was found (as in
-  //! the reference); distorted_detection_centers always.  Throws std::runtime_error on a HIP / usage
-  //! error or when more than MPE_MAX_DETECTIONS blobs pass the filter.
+  //! the reference); distorted_detection_centers always.  Never throws (the reference does not): on a HIP / usage
+  //! error, or when more than MPE_MAX_DETECTIONS (64) blobs pass the filter, NO detections are reported, the reason is
+  //! written to stderr once and kept for mpe_facade_last_error().
   static void findLeds(const ImageView& image, Rect ROI, const int& threshold_value, const double& gaussian_sigma,
                        const double& min_blob_area, const double& max_blob_area,
                        const double& max_width_height_distortion, const double& max_circular_distortion,

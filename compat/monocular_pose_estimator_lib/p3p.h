@@ -17,7 +17,7 @@ class P3P {
  public:
   //! Columns of feature_vectors / world_points are the three unit bearings / world points.  Returns 0 and
   //! fills the four [R|C] solutions (NaN entries where the reference produces NaN), or -1 if the world
-  //! points are collinear (solutions untouched).  Throws std::runtime_error without a HIP device.
+  //! points are collinear (solutions untouched).  Never throws (the reference does not): -1 also when the back-end fails (mpe_facade_last_error()).
   static int computePoses(const Matrix3d& feature_vectors, const Matrix3d& world_points, P3PSolutions& solutions);
   //! Real parts of the four Ferrari roots of factors(0) x^4 + ... + factors(4); always returns 0.
   static int solveQuartic(const Vector5d& factors, Vector4d& real_roots);

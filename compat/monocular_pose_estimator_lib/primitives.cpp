@@ -1,8 +1,15 @@
 // primitives.cpp — the static classes P3P and LEDDetector on top of the C ABI.  The reference's static
 // functions carry no state; here they share one lazily created library handle per process.
+// Error behaviour: the reference's static primitives never throw (p3p.h:105-108:
+// computePoses returns -1 as its only failure; findLeds / determineROI / distortPoints return void or a value), so
+// neither do these: a back-end failure — no HIP device, a usage error — comes back as the reference's own failure value
+// (computePoses / solveQuartic: -1 with the outputs untouched / NaN; findLeds: no detections; determineROI: the whole
+// image; distortPoints: the input points), is written to stderr once per kind, and can be read with
+// mpe_facade_last_error().
 #include "facade_namespace.h"
+#include <cmath>
+#include <cstdio>
 #include <mutex>
-#include <stdexcept>
 #include <string>
 
 #include "led_detector.h"
@@ -13,18 +20,36 @@ MPE_FACADE_BEGIN
 
 namespace {
 std::mutex g_lock;  // one handle = one caller at a time (include/mpe.h)
-mpe_handle* shared_handle() {
+std::string g_last_error;
+mpe_handle* shared_handle() {  // 0: no HIP device (there is no CPU fallback)
   static mpe_handle* h = 0;
-  if (!h && mpe_create(&h, -1) != MPE_OK) {
-    h = 0;
-    throw std::runtime_error("mpe_create failed: no HIP device (there is no CPU fallback)");
+  static bool tried = false;
+  if (!h && !tried) {
+    tried = true;
+    if (mpe_create(&h, -1) != MPE_OK) h = 0;
   }
   return h;
 }
-void check(mpe_handle* h, int rc, const char* what) {
-  if (rc != MPE_OK) throw std::runtime_error(std::string(what) + ": " + mpe_last_error(h));
+// true = the call succeeded; else the message is kept (and printed the first time this `what` fails)
+bool ok(mpe_handle* h, int rc, const char* what) {
+  if (h && rc == MPE_OK) return true;
+  g_last_error = std::string(what) + ": " + (h ? mpe_last_error(h) : "mpe_create failed: no HIP device (there is no CPU fallback)");
+  static std::string printed;
+  if (printed.find(what) == std::string::npos) {
+    printed += what;
+    printed += ';';
+    std::fprintf(stderr, "monocular_pose_estimator (mpe facade): %s\n", g_last_error.c_str());
+  }
+  return false;
 }
 }  // namespace
+
+const char* mpe_facade_last_error() {
+  std::lock_guard<std::mutex> guard(g_lock);
+  static std::string copy;
+  copy = g_last_error;
+  return copy.c_str();
+}
 
 int P3P::computePoses(const Matrix3d& feature_vectors, const Matrix3d& world_points, P3PSolutions& solutions) {
   std::lock_guard<std::mutex> guard(g_lock);
@@ -38,7 +63,7 @@ int P3P::computePoses(const Matrix3d& feature_vectors, const Matrix3d& world_poi
   for (int s = 0; s < 4; ++s)
     for (int i = 0; i < 12; ++i) sol[12 * s + i] = solutions[s](i);
   int status = 0;
-  check(h, mpe_p3p_batch(h, fv, wp, 1, sol, &status), "mpe_p3p_batch");
+  if (!ok(h, h ? mpe_p3p_batch(h, fv, wp, 1, sol, &status) : MPE_ERR_NO_DEVICE, "mpe_p3p_batch")) return -1;
   if (status != 0) return -1;
   for (int s = 0; s < 4; ++s)
     for (int i = 0; i < 12; ++i) solutions[s](i) = sol[12 * s + i];
@@ -48,7 +73,11 @@ int P3P::computePoses(const Matrix3d& feature_vectors, const Matrix3d& world_poi
 int P3P::solveQuartic(const Vector5d& factors, Vector4d& real_roots) {
   std::lock_guard<std::mutex> guard(g_lock);
   mpe_handle* h = shared_handle();
-  check(h, mpe_solve_quartic_batch(h, factors.data(), 1, 0, real_roots.data()), "mpe_solve_quartic_batch");
+  if (!ok(h, h ? mpe_solve_quartic_batch(h, factors.data(), 1, 0, real_roots.data()) : MPE_ERR_NO_DEVICE,
+          "mpe_solve_quartic_batch")) {
+    for (int i = 0; i < 4; ++i) real_roots(i) = std::nan("");
+    return -1;  // (the reference always returns 0: it has no way to fail)
+  }
   return 0;
 }
 
@@ -70,11 +99,13 @@ void LEDDetector::findLeds(const ImageView& image, Rect ROI, const int& threshol
   double und[2 * MPE_MAX_DETECTIONS];
   float dist[2 * MPE_MAX_DETECTIONS];
   int n = 0;
-  check(h,
-        mpe_find_leds(h, image.data, image.rows, image.cols, image.step, ROI.x, ROI.y, ROI.width, ROI.height, &p,
-                      camera_matrix_K.data(), camera_distortion_coeffs.empty() ? 0 : camera_distortion_coeffs.data(),
-                      (int)camera_distortion_coeffs.size(), und, dist, MPE_MAX_DETECTIONS, &n),
-        "mpe_find_leds");
+  if (!ok(h,
+          h ? mpe_find_leds(h, image.data, image.rows, image.cols, image.step, ROI.x, ROI.y, ROI.width, ROI.height, &p,
+                            camera_matrix_K.data(), camera_distortion_coeffs.empty() ? 0 : camera_distortion_coeffs.data(),
+                            (int)camera_distortion_coeffs.size(), und, dist, MPE_MAX_DETECTIONS, &n)
+            : MPE_ERR_NO_DEVICE,
+          "mpe_find_leds"))
+    n = 0;  // (no detections: what the reference's caller sees of a frame without LEDs)
   distorted_detection_centers.resize(n);
   for (int i = 0; i < n; ++i) {
     distorted_detection_centers[i].x = dist[2 * i];
@@ -101,7 +132,11 @@ Rect LEDDetector::determineROI(List2DPoints pixel_positions, Size image_size, co
                                    border_size, camera_matrix_K.data(),
                                    camera_distortion_coeffs.empty() ? 0 : camera_distortion_coeffs.data(),
                                    (int)camera_distortion_coeffs.size(), r);
-  if (rc != MPE_OK) throw std::runtime_error("mpe_determine_roi: bad argument");
+  if (rc != MPE_OK) {  // (the whole image: the region the reference searches when it has no prediction)
+    std::lock_guard<std::mutex> guard(g_lock);
+    ok(0, rc, "mpe_determine_roi");
+    return Rect(0, 0, image_size.width, image_size.height);
+  }
   return Rect(r[0], r[1], r[2], r[3]);
 }
 
@@ -113,7 +148,11 @@ void LEDDetector::distortPoints(const std::vector<Point2f>& src, std::vector<Poi
   const int rc = mpe_distort_points(&src[0].x, &dst[0].x, (int)src.size(), camera_matrix_K.data(),
                                     distortion_matrix.empty() ? 0 : distortion_matrix.data(),
                                     (int)distortion_matrix.size());
-  if (rc != MPE_OK) throw std::runtime_error("mpe_distort_points: bad argument");
+  if (rc != MPE_OK) {
+    std::lock_guard<std::mutex> guard(g_lock);
+    ok(0, rc, "mpe_distort_points");
+    dst = src;
+  }
 }
 
 MPE_FACADE_END  // namespace monocular_pose_estimator
