@@ -96,7 +96,8 @@ def source_fingerprint():
     (profiles/round3_pmc.json) to the code a bench run times."""
     import hashlib
     hsh = hashlib.sha256()
-    for name in DEVICE_SOURCES + ("mpe_k1b_dev.h", "mpe_ddmath.h", "mpe_p3p.h", "mpe_internal.h", "mpe_abi.cpp"):
+    for name in DEVICE_SOURCES + ("mpe_k1b_dev.h", "mpe_ddmath.h", "mpe_p3p.h", "mpe_internal.h", "mpe_host.h", "mpe_schedule.cpp",
+                                  "mpe_options.cpp", "mpe_track_abi.cpp", "mpe_abi.cpp"):
         with open(os.path.join(_CSRC, name), "rb") as fh:
             hsh.update(fh.read())
     return hsh.hexdigest()[:16]

@@ -1,4 +1,4 @@
-// mpe_internal.h — structures shared by the host side (mpe_abi.cpp) and the gfx950 kernels
+// mpe_internal.h — structures shared by the host side (mpe_host.h, mpe_schedule / mpe_options / mpe_track_abi / mpe_abi .cpp) and the gfx950 kernels
 // (mpe_k1.hip, mpe_k2.hip, mpe_k3.hip).  Not part of the public ABI.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1733,7 +1733,7 @@ hipError_t launch_k2_fixup(mpe_detections* dets, int n_frames, const SolveParams
   // collection; 3 us serialised).  The lists are sized so that nothing is lost as a rule.
   const size_t lds_strict = (size_t)(sp.n_markers - 3) * 2 * K2_THREADS * sizeof(double);
   // relost_blocks: the caller's choice — 32 where the launch sits beside a voting launch and nothing has ever been
-  // lost, the whole chip once frames have been (mpe_abi.cpp: relost_grid)
+  // lost, the whole chip once frames have been (mpe_schedule.cpp: relost_grid)
   if (relost_blocks < 1) relost_blocks = 32;
   if (glibc)
     hipLaunchKernelGGL(k2_vote_relost<true>, dim3((unsigned)relost_blocks), dim3(K2_THREADS), lds_strict, s, dets,
