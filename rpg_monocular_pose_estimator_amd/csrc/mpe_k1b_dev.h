@@ -906,6 +906,8 @@ struct Island {
   short cfirst, clast; // bright segment columns (pixel window)
   int pix_off, bm_off; // offsets into the pools
   int stage_end, blur_end;  // inclusive prefix sums of the flattened work-item counts
+  short blo, bhi;      // segment columns the blur actually computes (clo .. chi, or without a neighbour column that
+                       // provably blurs to zero: phase C2)
 };
 
 // The island's bitmap window: the blurred mask can only be non-zero within r pixels of a bright segment, i.e. in
@@ -1156,6 +1158,8 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
         is.clo = (short)max(0, cfirst - dc);
         is.chi = (short)min(spr - 1, clast + dc);
         is.pix_off = is.bm_off = is.stage_end = is.blur_end = 0;
+        is.blo = is.clo;
+        is.bhi = is.chi;
         s_isl[idx] = is;
       }
     }
@@ -1241,6 +1245,54 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   wave_sync();
   K1B_STOP_POINT(3, out)
 
+  // ---- C2 (round 6): which neighbour columns does the blur have to compute at all?  The island's columns clo .. chi
+  //      are its bright segments cfirst .. clast dilated by dc; with dc = 1 the column left of cfirst can only blur to
+  //      something if a thresholded pixel sits in the FIRST r pixels of segment cfirst in some row of the band (an
+  //      output x sees inputs x - r .. x + r), the column right of clast only through the LAST r pixels of clast —
+  //      for an LED of ~5 pixels somewhere in a 16-pixel segment that is one case in four.  A column that cannot is left
+  //      out of the blur's work list (its bitmap words stay zero, which is what its items would have written): 135 ->
+  //      ~70 items for five LEDs, three wave passes -> two.  Only away from the image border (no BORDER_REFLECT_101
+  //      read can reach the bright segments from that column) and for r <= 16.
+  //      MEASURED AND NOT ADOPTED (profiles/round6_exp_blur_narrowing.txt, same box, four pairs): the blob kernel's
+  //      window shrinks from 0.52 to 0.50 ms and the voting launch behind it grows from 1.72 to 1.80 — the step gets
+  //      0.5 ms SLOWER (18.24 - 18.42 against 17.55 - 18.02 ms), as with every other change that only shortens the window
+  //      (Schedules).  Detections bit-equal either way.  Kept for experiment builds.
+#ifdef K1B_BLUR_NARROWING
+  if (dc == 1) {
+    int nbl = 0;
+    if (lane < nisl) {
+      Island is = s_isl[lane];
+      const int H = is.yhi - is.ylo + 1, nbs = is.clast - is.cfirst + 1;
+      const bool may_l = is.clo < is.cfirst && 16 * (is.cfirst - 1) >= r;
+      const bool may_r = is.chi > is.clast && 16 * (is.clast + 2) + r <= g.cols;
+      if (may_l || may_r) {
+        unsigned left = 0, right = 0;
+        const uint8_t* base = s_pix + is.pix_off;
+        for (int yb = 0; yb < H; ++yb) {
+          const uint8_t* rowp = base + (size_t)yb * 16 * nbs;
+          for (int k = 0; k < r; ++k) {
+            left |= rowp[k];
+            right |= rowp[16 * nbs - 1 - k];
+          }
+        }
+        if (may_l && !left) is.blo = is.cfirst;
+        if (may_r && !right) is.bhi = is.clast;
+        s_isl[lane].blo = is.blo;
+        s_isl[lane].bhi = is.bhi;
+      }
+      nbl = H * (is.bhi - is.blo + 1);
+    }
+    int il = nbl;  // inclusive scan (nisl <= 32)
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const int e = __shfl_up(il, d);
+      if (lane >= d) il += e;
+    }
+    if (lane < nisl) s_isl[lane].blur_end = il;
+    wave_sync();
+  }
+#endif
+
   // ---- D: blurred mask of every island
   {
     const int tot_blur = s_isl[nisl - 1].blur_end;
@@ -1249,8 +1301,8 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
       while (i >= s_isl[k].blur_end) ++k;
       const Island is = s_isl[k];
       const int li = i - (k ? s_isl[k - 1].blur_end : 0);
-      const int ncols = is.chi - is.clo + 1;
-      const int yb = li / ncols, c = is.clo + (li - yb * ncols);
+      const int ncols = is.bhi - is.blo + 1;
+      const int yb = li / ncols, c = is.blo + (li - yb * ncols);
       const int H = is.yhi - is.ylo + 1;
       const int W = isl_words(is, g.cols, r);
       const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1), 0u, nullptr, 0};

@@ -5,7 +5,7 @@ hypotheses of the voting, or to the P3P solves of the validation, on which the t
 must be a witnessed instability of the reference algorithm itself (the oracle's own answer moves under a 1-ulp change
 of an input) or sit in the cancellation corner of its Ferrari solver.  Exit code 1 if one stays unexplained.
 usage (on an MI355X): [MPE_VOTE_ARITH=0|1] python tests/soak_parity.py [frames [config [chunk [out_prefix]]]]
-MPE_VOTE_ARITH: option "vote_arith" of the handle (1 = fast voting arithmetic, the default; 0 = strict)."""
+MPE_VOTE_ARITH: option "vote_arith" of the handle (3 = the default since round 6; see include/mpe.h)."""
 import json
 import os
 import sys
@@ -26,7 +26,7 @@ from oracle import binding as orc  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1048576
 CONFIG = sys.argv[2] if len(sys.argv) > 2 else "C2"
 CH = min(N, int(sys.argv[3]) if len(sys.argv) > 3 else 65536)
-ARITH = int(os.environ.get("MPE_VOTE_ARITH", "1"))
+ARITH = int(os.environ.get("MPE_VOTE_ARITH", "3"))
 OUT = sys.argv[4] if len(sys.argv) > 4 else "gpurun_out/soak_parity_%s_arith%d" % (CONFIG, ARITH)
 TOL_PX = float(os.environ.get("MPE_BACK_TOL", "5"))
 cfg = synth.CONFIGS[CONFIG]
@@ -85,5 +85,5 @@ print(json.dumps({"config": CONFIG, "frames": tot, "back_projection_pixel_tolera
                   "mismatches_unexplained": len(unexplained),
                   "mismatching_frames_saved_to": (OUT + ".npz") if saved else None, "verdicts": meta,
                   "schedule": h.get_option("last_schedule"), "vote_arith": ARITH,
-                  "vote_arith_meaning": "1 = fast (Newton-Raphson div / sqrt, Newton cube root), 0 = strict (IEEE, validation kernel's P3P)"}))
+                  "vote_arith_meaning": "3 = fast kernel + strict fix-up with the reference library's complex powers (default); 1 the same with exact powers; 4 / 0 their strict kernels"}))
 sys.exit(1 if unexplained else 0)

@@ -1431,9 +1431,9 @@ def test_bench_secondary_legs_on_the_gpu_box():
     import bench
     ctx = {"rank": 0, "local_rank": 0, "world": 1, "dev": torch.device("cuda", 0), "dist": None}
     base = dict(steps=2, warmup=1, cpu_sample=64, back_tol=None, clutter=None, no_cpu=False, pipeline=16, pipeline_mode=-1,
-                vote_arith=1, vote_splits=0, scan_split_pct=-1, side_scan_blocks=-1, assume_side_streams=False, k1a_lds=-1,
+                vote_arith=3, vote_splits=0, scan_split_pct=-1, side_scan_blocks=-1, assume_side_streams=False, k1a_lds=-1,
                 opt=None, records_to_host=True, no_streaming=False, vote_events=True, false_hint_leg=False,
-                no_host_leg=True)
+                no_host_leg=True, detections_hint=-1, consumer_priority=None)
     for kw in (dict(config="C1", frames=32768 + 512), dict(config="C3", frames=1024, back_tol=2.0),
                dict(config="C4", frames=1024), dict(config="C2", frames=2048, clutter="salt"),
                dict(config="C2", frames=2048, clutter="patch"), dict(config="C2", frames=1024, clutter="d16")):
