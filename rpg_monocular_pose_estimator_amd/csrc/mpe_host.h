@@ -101,6 +101,13 @@ struct mpe_handle {
   // on: the scan-carrying kernel with an occupancy grid of the detections, mpe_k2.hip K2_CGRID) and sizes the suspect
   // lists.  Never a matter of correctness.  Option "detections_hint" (0 = automatic: the number of markers, or what the
   // last call whose records came back to the host saw, det_seen)
+  // Do frames reach the general blob tier?  A pinned mirror of the first blob launch's hand-over count, copied behind it
+  // once per call and read — a call late — when the next call picks that tier's kernel: k1b_general_lds (a CU's whole
+  // LDS per block: not something to launch empty into every blob window) once frames have been seen there, the
+  // slab kernel otherwise.  Option "general_lds": 0 never (DEFAULT: measured, the LDS-resident kernel is 7 % faster on
+  // frames with one large blob and 2 x SLOWER on salt noise — mpe_k1.hip), -1 that automatic choice, 1 always.
+  int* gen_seen_host = nullptr;
+  int general_lds = 0;
   int detections_hint = 0;
   int det_seen = 0;
   unsigned long long* track_clk = nullptr;   // option "track_phase_clocks": pinned, device-visible; 5 stamps per frame

@@ -97,7 +97,9 @@ hipError_t launch_k1a_scan(const uint8_t* frames, size_t n_bytes, unsigned long 
 hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* flags, int n_frames, const FrameGeom& g,
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
                             size_t scratch_bytes, int blob_hint, hipStream_t s, const void* frame_windows = nullptr,
-                            bool lists_zeroed = false, bool first_tier_only = false);
+                            bool lists_zeroed = false, bool first_tier_only = false, bool general_lds = false);
+// general_lds: frames are expected to reach the general tier (the caller saw them in the previous call's work-list): that
+// tier then runs as k1b_general_lds — a block per CU, the frame's bitmaps in LDS — where the frame size allows it
 // worklist: 2 * (n_frames + 1) ints (two device work-lists that chain the capacity tiers); lists_zeroed = the caller
 // has zeroed it in stream order already (one memset for all the sub-batches of a call) and no memset is issued here.
 // first_tier_only: launch the small-pool tier alone (blob_hint 1 .. 8); frames it cannot hold keep status

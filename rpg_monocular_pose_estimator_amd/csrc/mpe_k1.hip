@@ -251,7 +251,14 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
   const int spr = g.segs_per_row;
   const unsigned add = (unsigned)(255 - dp.thr) * 0x00010001u;
 
+#ifdef K1B_GEN_CLOCKS  // (experiment builds: the shader clock at the phase boundaries of block 0's first frame, printed)
+  unsigned long long gclk[9];
+#define K1B_GEN_STAMP(i) gclk[i] = __builtin_amdgcn_s_memtime();
+#else
+#define K1B_GEN_STAMP(i)
+#endif
   for (int wi = blockIdx.x; wi < count; wi += gridDim.x) {
+    K1B_GEN_STAMP(0)
     const int f = worklist[1 + wi] & 0xFFFFFF;
     const uint8_t* frame = frames + (size_t)f * g.rows * g.pitch;
     int roi_x, roi_y;
@@ -271,6 +278,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     for (size_t i = lane; i < (size_t)g.rows * g.tw; i += 64) todo[i] = 0;
     __threadfence_block();
     __syncthreads();
+    K1B_GEN_STAMP(1)
     // todo segments: neighbourhood of every bright segment
     {
       const size_t G0 = (size_t)f * g.segs_per_frame;
@@ -294,6 +302,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     }
     __threadfence_block();
     __syncthreads();
+    K1B_GEN_STAMP(2)
     // the to-do bits as a LIST of (row, segment column) items, so that the blur below runs them 64 at a time whatever
     // their rows (one lane per row ran as many rounds as the busiest row of every 64 has items)
     int n_items = 0;  // (uniform)
@@ -321,6 +330,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     }
     __threadfence_block();
     __syncthreads();
+    K1B_GEN_STAMP(3)
     // blur: the frame's own bytes — only the segments the image pass flagged — thresholded on the fly
     const PixWin pw = {frame, 0, gl.rows, 0, g.pitch, add, flags, (size_t)f * g.segs_per_frame};
     for (int i = lane; i < n_items; i += 64) {
@@ -334,6 +344,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     }
     __threadfence_block();
     __syncthreads();
+    K1B_GEN_STAMP(4)
     for (int y = lane; y < gl.rows; y += 64) {
       const u64* nzrow = nz + (size_t)(y + 1) * g.wb;
       u64 any = 0;
@@ -345,6 +356,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
       }
     }
     __syncthreads();
+    K1B_GEN_STAMP(5)
     // bands = maximal runs of non-empty rows in which every row TOUCHES the one above it (k1b_rows_touch): a band
     // starts at a non-empty row that is not linked to its predecessor, and ends in front of the next such row or empty
     // row (lane w owns word w of the row bitsets; ranks by a wave prefix sum)
@@ -392,6 +404,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
         kkey[k] = key;
       }
     };
+    K1B_GEN_STAMP(6)
     if (nband <= K1B_GEN_BANDS) {
       // one lane per band, the lanes' border followings in lock step (scan_window): slot 0 of a band's window is the
       // row above it — empty, or holding no neighbour of any pixel of the band — slots 1 .. H its rows, and the row
@@ -407,7 +420,226 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     }
     __threadfence_block();
     __syncthreads();
+    K1B_GEN_STAMP(7)
     write_detections(kx, ky, kkey, s_nkept, K1B_GEN_KEPT, s_over, dp, dets + f, lane);
+    __syncthreads();
+    K1B_GEN_STAMP(8)
+#ifdef K1B_GEN_CLOCKS
+    if (blockIdx.x == 0 && lane == 0 && wi == 0)
+      printf("k1b_general phases (cycles): clear %llu todo %llu items %llu (n=%d) blur %llu rows %llu bands %llu (n=%d) scan %llu write %llu\n",
+             gclk[1] - gclk[0], gclk[2] - gclk[1], gclk[3] - gclk[2], n_items, gclk[4] - gclk[3], gclk[5] - gclk[4],
+             gclk[6] - gclk[5], nband, gclk[7] - gclk[6], gclk[8] - gclk[7]);
+#endif
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k1b_general_lds (round 6) — the same tier with the frame's three bitmaps, the to-do bitset and the band list in LDS:
+// ONE block of four waves per CU, 139 KB of the CU's 160 KB at 752 x 480.  The phase clocks of k1b_general on a
+// salt-noise frame (tools/general_tier_probe.py, -DK1B_GEN_CLOCKS: 3.4 M cycles, 47 % the contour scan, 35 % the blur)
+// said why that kernel runs at a quarter of the VALU issue rate with 16 waves per CU: the scan walks its band word by
+// word and follows borders pixel by pixel, every step a dependent read of bitmaps in GLOBAL memory (~1 600 cycles per
+// step), and the blur's items each waited for ten round trips.  With the bitmaps in LDS a step is a ds_read; the four
+// waves share the frame's blur items and its bands (a lane per band, 256 at a time); item list, flag scan, band
+// building are one wave's work as before.  Frames whose bitmaps do not fit (1920 x 1200: 3 x 298 KB) keep k1b_general.
+// The launch needs a CU's whole LDS per block, so it is only used once the previous call's work-list said that frames
+// DO reach this tier (launch_k1b_blobs: general_lds) — an empty launch of the old kernel costs the clean step nothing.
+// Same arithmetic, same decomposition, same records (tests: the general-tier suites, witness clutter vectors).
+// MEASURED, NOT THE DEFAULT (option "general_lds" 0; profiles/round6_exp_general_tier.txt): a frame costs this kernel
+// 1.2 M cycles where the slab kernel needs 3.4 M — but the slab kernel keeps 16 frames per CU in flight and this one ONE:
+// salt noise 1.05 M -> 0.48 M fps, a saturated 64 x 64 patch 2.73 -> 2.93 M.  What is left per frame is the chain of one
+// LANE walking its band (35 bands for ~180 blobs at 0.05 % salt noise: 35 of 256 lanes busy, the slowest band sets the
+// time).  The next step is the VERDICT's: items of (band, run of occupied pixel columns) — exact, an empty column
+// separates components as an empty row does — which needs the scan's candidate and mark words masked to the run and
+// its mark updates atomic; not attempted in round 6.
+// ---------------------------------------------------------------------------------------------
+#define K1B_GENL_THREADS 256
+__host__ __device__ inline size_t k1b_genl_lds_bytes(const FrameGeom& g) {
+  const size_t bm = (size_t)(g.rows + 2) * g.wb * 8;
+  const size_t todo = (size_t)g.rows * g.tw * 8;
+  const size_t bands = ((size_t)2 * g.rows * sizeof(short) + 15) / 16 * 16;
+  return 3 * bm + todo + bands;
+}
+static bool k1b_genl_fits(const FrameGeom& g) { return k1b_genl_lds_bytes(g) + 2048 <= (size_t)160 * 1024; }
+
+__global__ __launch_bounds__(K1B_GENL_THREADS) void k1b_general_lds(const uint8_t* __restrict__ frames,
+                                                                    const u64* __restrict__ flags, FrameGeom gslot,
+                                                                    DetectParams dp, mpe_detections* __restrict__ dets,
+                                                                    const int* __restrict__ worklist,
+                                                                    uint8_t* __restrict__ scratch,
+                                                                    const FrameWin* __restrict__ wins) {
+  const FrameGeom& g = gslot;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  __shared__ int s_nkept, s_over, s_nband, s_nitems;
+  __shared__ int s_taps[MPE_MAX_KSIZE];
+  __shared__ u64 s_rowact[64], s_link[64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int count = worklist[0];
+  if ((int)blockIdx.x >= count) return;
+  if (tid < MPE_MAX_KSIZE) s_taps[tid] = dp.taps[tid < dp.ksize ? tid : 0];
+  __syncthreads();
+  const size_t bm_words = (size_t)(g.rows + 2) * g.wb;
+  u64* nz = reinterpret_cast<u64*>(gsm);
+  u64* pm = nz + bm_words;
+  u64* ng = pm + bm_words;
+  u64* todo = ng + bm_words;
+  short* s_blo = reinterpret_cast<short*>(todo + (size_t)g.rows * g.tw);
+  short* s_bhi = s_blo + g.rows;
+  // the slab of k1b_general (same layout, its bitmap area unused): kept blobs and the item list stay in global memory
+  const size_t slab = k1b_gen_scratch_bytes(g);
+  uint8_t* base = scratch + (size_t)blockIdx.x * slab;
+  float* kx = reinterpret_cast<float*>(reinterpret_cast<u64*>(base) + 3 * bm_words + (size_t)g.rows * g.tw);
+  float* ky = kx + K1B_GEN_KEPT;
+  unsigned* kkey = reinterpret_cast<unsigned*>(ky + K1B_GEN_KEPT);
+  unsigned* items = kkey + K1B_GEN_KEPT;
+  const int r = dp.ksize / 2;
+  const int dc = (r + 15) / 16;
+  const int spr = g.segs_per_row;
+  const unsigned add = (unsigned)(255 - dp.thr) * 0x00010001u;
+
+  for (int wi = blockIdx.x; wi < count; wi += gridDim.x) {
+    const int f = worklist[1 + wi] & 0xFFFFFF;
+    const uint8_t* frame = frames + (size_t)f * g.rows * g.pitch;
+    int roi_x, roi_y;
+    const FrameGeom gl = window_geom(gslot, wins, f, dp, roi_x, roi_y);
+    if (tid == 0) {
+      s_nkept = 0;
+      s_over = 0;
+      s_nband = 0;
+      s_nitems = 0;
+    }
+    if (tid < 64) {
+      s_rowact[tid] = 0;
+      s_link[tid] = 0;
+    }
+    for (size_t i = tid; i < 3 * bm_words + (size_t)g.rows * g.tw; i += K1B_GENL_THREADS) nz[i] = 0;  // (nz, pm, ng, todo: contiguous)
+    __syncthreads();
+    // todo segments: neighbourhood of every bright segment
+    {
+      const size_t G0 = (size_t)f * g.segs_per_frame;
+      const int nwin = (g.segs_per_frame + 63) >> 6;
+      const size_t w0 = G0 >> 6;
+      const int sh = (int)(G0 & 63);
+      for (int i = tid; i < nwin; i += K1B_GENL_THREADS) {
+        const u64 a = flags[w0 + i], b = flags[w0 + i + 1];
+        u64 v = sh ? ((a >> sh) | (b << (64 - sh))) : a;
+        const int rem = g.segs_per_frame - i * 64;
+        if (rem < 64) v &= (1ull << rem) - 1;
+        while (v) {
+          const int sgm = i * 64 + __builtin_ctzll(v);
+          v &= v - 1;
+          const int y0 = sgm / spr, c0 = sgm - y0 * spr;
+          for (int yy = max(0, y0 - r); yy <= min(gl.rows - 1, y0 + r); ++yy)
+            for (int cc = max(0, c0 - dc); cc <= min(spr - 1, c0 + dc); ++cc)
+              atomicOr(&todo[(size_t)yy * g.tw + (cc >> 6)], 1ull << (cc & 63));
+        }
+      }
+    }
+    __syncthreads();
+    // the to-do bits as a LIST of (row, segment column) items (wave 0: ranks by a wave prefix sum, 64 rows at a time)
+    if (wv == 0) {
+      int n_items = 0;  // (uniform)
+      for (int y0 = 0; y0 < gl.rows; y0 += 64) {
+        const int y = y0 + lane;
+        int cnt = 0;
+        if (y < gl.rows)
+          for (int tw = 0; tw < g.tw; ++tw) cnt += __builtin_popcountll(todo[(size_t)y * g.tw + tw]);
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int a = __shfl_up(inc, d);
+          if (lane >= d) inc += a;
+        }
+        int o = n_items + inc - cnt;
+        if (y < gl.rows)
+          for (int tw = 0; tw < g.tw; ++tw) {
+            u64 tb = todo[(size_t)y * g.tw + tw];
+            while (tb) {
+              items[o++] = ((unsigned)y << 12) | (unsigned)(tw * 64 + __builtin_ctzll(tb));
+              tb &= tb - 1;
+            }
+          }
+        n_items += __shfl(inc, 63);
+      }
+      if (lane == 0) s_nitems = n_items;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int n_items = s_nitems;
+    // blur: the frame's own bytes — only the segments the image pass flagged — thresholded on the fly
+    const PixWin pw = {frame, 0, gl.rows, 0, g.pitch, add, flags, (size_t)f * g.segs_per_frame};
+    for (int i = tid; i < n_items; i += K1B_GENL_THREADS) {
+      const unsigned it = items[i];
+      const int y = (int)(it >> 12), c = (int)(it & 0xFFFu);
+      u64* nzrow = nz + (size_t)(y + 1) * g.wb;
+      if (add)
+        blur_to_bitmap<true>(pw, gl.rows, gl.cols, dp, s_taps, y, c, nzrow, 0);
+      else
+        blur_to_bitmap<false>(pw, gl.rows, gl.cols, dp, s_taps, y, c, nzrow, 0);
+    }
+    __syncthreads();
+    for (int y = tid; y < gl.rows; y += K1B_GENL_THREADS) {
+      const u64* nzrow = nz + (size_t)(y + 1) * g.wb;
+      u64 any = 0;
+      for (int w = 0; w < g.wb; ++w) any |= nzrow[w];
+      if (any) {
+        atomicOr(&s_rowact[y >> 6], 1ull << (y & 63));
+        if (k1b_rows_touch(nzrow, nzrow - g.wb, g.wb)) atomicOr(&s_link[y >> 6], 1ull << (y & 63));
+      }
+    }
+    __syncthreads();
+    // bands (see k1b_general): wave 0, lane w owns word w of the row bitsets
+    if (wv == 0) {
+      const int rw = (gl.rows + 63) >> 6;
+      const u64 act = (lane < rw) ? s_rowact[lane] : 0;
+      const u64 lnk = (lane < rw) ? s_link[lane] : 0;
+      const u64 nextl = (lane + 1 < rw) ? s_link[lane + 1] : 0;
+      u64 st = act & ~lnk;
+      u64 en = act & ~((lnk >> 1) | (nextl << 63));
+      const int cs = __builtin_popcountll(st), ce = __builtin_popcountll(en);
+      int ps = cs, pe = ce;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int a = __shfl_up(ps, d), b = __shfl_up(pe, d);
+        if (lane >= d) {
+          ps += a;
+          pe += b;
+        }
+      }
+      int is_ = ps - cs, ie = pe - ce;
+      while (st) {  // (a band has at least one row: never more bands than rows, the lists' capacity)
+        const int b = __builtin_ctzll(st);
+        st &= st - 1;
+        s_blo[is_++] = (short)(lane * 64 + b);
+      }
+      while (en) {
+        const int b = __builtin_ctzll(en);
+        en &= en - 1;
+        s_bhi[ie++] = (short)(lane * 64 + b);
+      }
+      if (lane == 63) s_nband = ps;
+    }
+    __syncthreads();
+    const int nband = s_nband;
+    auto keep = [&](float mcx, float mcy, unsigned key) {  // (see k1b_general on the subset kept beyond K1B_GEN_KEPT)
+      const int k = atomicAdd(&s_nkept, 1);
+      if (k < K1B_GEN_KEPT) {
+        kx[k] = mcx;
+        ky[k] = mcy;
+        kkey[k] = key;
+      }
+    };
+    // one lane per band, 256 bands at a time (every lane enters scan_window, with H = 0 if it has no band)
+    for (int b0 = 0; b0 < nband; b0 += K1B_GENL_THREADS) {
+      const int b = b0 + tid;
+      const int lo = b < nband ? s_blo[b] : 0, H = b < nband ? s_bhi[b] - lo + 1 : 0;
+      const size_t off = (size_t)lo * g.wb;
+      scan_window(nz + off, pm + off, ng + off, g.wb, H, lo, 0, dp, roi_x, roi_y, &s_over, keep);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (wv == 0) write_detections(kx, ky, kkey, s_nkept, K1B_GEN_KEPT, s_over, dp, dets + f, lane);
     __syncthreads();
   }
 }
@@ -420,7 +652,7 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
                             const DetectParams& dp, mpe_detections* dets, int* worklist, uint8_t* scratch,
                             size_t scratch_bytes, int blob_hint, hipStream_t s, const void* frame_windows,
                             bool lists_zeroed,
-                            bool first_tier_only) {
+                            bool first_tier_only, bool general_lds) {
   const FrameWin* wins = static_cast<const FrameWin*>(frame_windows);
   if (first_tier_only) {
     // low-latency tracked frame: the small tier alone, nothing queued behind it.  A frame that overflows it is left
@@ -464,6 +696,23 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
   const size_t slabs = scratch_bytes / k1b_gen_scratch_bytes(g);
   if (slabs < 1) return hipErrorInvalidValue;
   if (gen_blocks > slabs) gen_blocks = slabs;
+  if (general_lds && k1b_genl_fits(g)) {
+    // frames DO reach this tier (the caller's reading of the previous call's work-list): the LDS-resident kernel, a
+    // block of four waves per CU with the frame's bitmaps in the CU's LDS
+    const size_t lds = k1b_genl_lds_bytes(g);
+    static size_t attr_set = 0;  // (the opt-in above 64 KB of dynamic LDS, once per size)
+    if (lds > attr_set) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k1b_general_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+      if (e != hipSuccess) return e;
+      attr_set = lds;
+    }
+    const size_t cus = (size_t)device_cu_count();
+    if (gen_blocks > cus) gen_blocks = cus;
+    hipLaunchKernelGGL(k1b_general_lds, dim3((unsigned)gen_blocks), dim3(K1B_GENL_THREADS), lds, s, frames, (const u64*)flags,
+                       g, dp, dets, (const int*)list_b, scratch, wins);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k1b_general, dim3((unsigned)gen_blocks), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
                      (const int*)list_b, scratch, wins);
   return hipGetLastError();

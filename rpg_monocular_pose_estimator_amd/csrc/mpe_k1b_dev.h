@@ -84,6 +84,42 @@ __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, in
 #pragma unroll
   for (int x = 0; x < 16; ++x) acc[x] = 0;
   unsigned eor = 0;
+  // RAW (the general kernel: frame bytes and flag words in GLOBAL memory): the KS rows' flag words first, then the
+  // pixel segments they allow, all loads of a stage in flight together — row by row an item waited for 2 KS dependent
+  // round trips, and that tier runs too few waves to hide them (round 6: 31 k cycles per round of 64 items)
+  uint4 rq[RAW ? KS : 1][3];
+  unsigned rany = 0;
+  if constexpr (RAW) {
+    const int sc = c - 1 - w.pwc0, nsw = w.PW >> 4;
+    u64 fa[KS], fm[KS], fb[KS];
+    size_t g0s[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int yb = reflect101(y + i - R, rows) - w.ylo;
+      const bool rowok = (unsigned)yb < (unsigned)w.H;
+      g0s[i] = w.fbit0 + (size_t)(rowok ? yb : 0) * (size_t)nsw + (size_t)(sc + 1);  // (segment sc + 1: never negative)
+      // (the neighbour segments' words only where those segments exist: column c - 1 of the frame's first row would
+      //  index the flag stream at -1)
+      fa[i] = (rowok && sc >= 0) ? w.flags[(g0s[i] - 1) >> 6] : 0ull;
+      fm[i] = rowok ? w.flags[g0s[i] >> 6] : 0ull;
+      fb[i] = (rowok && sc + 2 < nsw) ? w.flags[(g0s[i] + 1) >> 6] : 0ull;
+    }
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int yb = reflect101(y + i - R, rows) - w.ylo;
+      const bool rowok = (unsigned)yb < (unsigned)w.H;
+      const size_t g0 = g0s[i];
+      const bool in0 = rowok && (unsigned)sc < (unsigned)nsw && ((fa[i] >> ((g0 - 1) & 63)) & 1ull);
+      const bool in1 = rowok && (unsigned)(sc + 1) < (unsigned)nsw && ((fm[i] >> (g0 & 63)) & 1ull);
+      const bool in2 = rowok && (unsigned)(sc + 2) < (unsigned)nsw && ((fb[i] >> ((g0 + 1) & 63)) & 1ull);
+      const uint4* p = reinterpret_cast<const uint4*>(w.pix + (size_t)(rowok ? yb : 0) * w.PW);
+      rq[i][0] = in0 ? p[sc] : z4;
+      rq[i][1] = in1 ? p[sc + 1] : z4;
+      rq[i][2] = in2 ? p[sc + 2] : z4;
+      rany |= (in0 || in1 || in2) ? (1u << i) : 0u;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
     const int yb = reflect101(y + i - R, rows) - w.ylo;
@@ -91,17 +127,13 @@ __device__ __forceinline__ unsigned blur_item_fast(const PixWin& w, int rows, in
     const int sc = c - 1 - w.pwc0, nsw = w.PW >> 4;  // window segment index of column c-1
     const uint4* p = reinterpret_cast<const uint4*>(w.pix + (size_t)yb * w.PW);
     const uint4 z4 = make_uint4(0, 0, 0, 0);
-    bool in0 = (unsigned)sc < (unsigned)nsw, in1 = (unsigned)(sc + 1) < (unsigned)nsw, in2 = (unsigned)(sc + 2) < (unsigned)nsw;
+    const bool in0 = (unsigned)sc < (unsigned)nsw, in1 = (unsigned)(sc + 1) < (unsigned)nsw, in2 = (unsigned)(sc + 2) < (unsigned)nsw;
     if (RAW) {  // only segments the image pass flagged can hold anything after the threshold
-      const size_t g0 = w.fbit0 + (size_t)yb * (size_t)nsw + (size_t)(sc + 1);  // (segment sc + 1: never negative)
-      in0 = in0 && ((w.flags[(g0 - 1) >> 6] >> ((g0 - 1) & 63)) & 1ull);
-      in1 = in1 && ((w.flags[g0 >> 6] >> (g0 & 63)) & 1ull);
-      in2 = in2 && ((w.flags[(g0 + 1) >> 6] >> ((g0 + 1) & 63)) & 1ull);
-      if (!(in0 || in1 || in2)) continue;  // this row adds nothing to the sums (most rows of most items)
+      if (!((rany >> i) & 1u)) continue;  // this row adds nothing to the sums (most rows of most items)
     }
-    const uint4 q0 = in0 ? p[sc] : z4;
-    const uint4 q1 = in1 ? p[sc + 1] : z4;
-    const uint4 q2 = in2 ? p[sc + 2] : z4;
+    const uint4 q0 = RAW ? rq[RAW ? i : 0][0] : (in0 ? p[sc] : z4);
+    const uint4 q1 = RAW ? rq[RAW ? i : 0][1] : (in1 ? p[sc + 1] : z4);
+    const uint4 q2 = RAW ? rq[RAW ? i : 0][2] : (in2 ? p[sc + 2] : z4);
     unsigned q[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
     if (RAW) {
 #pragma unroll

@@ -74,6 +74,7 @@ void mpe_destroy(mpe_handle* h) {
   h->mid.release();
   if (h->fix_ctl_host) (void)hipHostFree(h->fix_ctl_host);
   if (h->track_clk) (void)hipHostFree(h->track_clk);
+  if (h->gen_seen_host) (void)hipHostFree(h->gen_seen_host);
   h->fix.release();
   if (h->mailbox) (void)hipHostFree(h->mailbox);
   for (auto& e : h->ev)
@@ -205,6 +206,8 @@ int mpe_get_option(mpe_handle* h, const char* name, int* value) {
   else if (n == "last_schedule") *value = h->last_schedule;
   else if (n == "vote_list_cap") *value = (int)h->fix_cap_limit;
   else if (n == "detections_hint") *value = h->detections_hint;
+  else if (n == "general_lds") *value = h->general_lds;
+  else if (n == "general_seen") *value = h->gen_seen_host ? *h->gen_seen_host : 0;
   else if (n == "track_fused") *value = h->track_fused;
   else if (n.rfind("track_phase_cycles_", 0) == 0) {  // mean shader-clock cycles of phase i = 0 .. 3 of the fused tracked frame
     const int i = std::atoi(n.c_str() + 19);
@@ -418,6 +421,11 @@ int mpe_set_option(mpe_handle* h, const char* name, int value) {
   if (!std::strcmp(name, "track_fused")) {  // A/B: 0 = the tracked frame as the chain of four kernels (rounds 3 - 5)
     // (2, the default: the kernel also stores the record to the caller's pinned memory itself; 1: fused kernel + copy)
     h->track_fused = value < 0 ? 0 : (value > 2 ? 2 : value);
+    return MPE_OK;
+  }
+  if (!std::strcmp(name, "general_lds")) {  // the general blob tier's kernel: -1 automatic, 0 slabs in global memory, 1 LDS-resident
+    if (value < -1 || value > 1) return fail(h, MPE_ERR_ARG, "general_lds must be -1, 0 or 1");
+    h->general_lds = value;
     return MPE_OK;
   }
   if (!std::strcmp(name, "detections_hint")) {  // detections per frame the caller expects (0 = automatic); see det_hint_for

@@ -162,6 +162,21 @@ int stage_frames(mpe_handle* h, const uint8_t* frames, int n_frames, int rows, i
   return MPE_OK;
 }
 
+// the general blob tier as k1b_general_lds?  (see mpe_handle::gen_seen_host)
+bool general_lds_now(const mpe_handle* h) {
+  if (h->general_lds >= 0) return h->general_lds != 0;
+  return h->gen_seen_host && *h->gen_seen_host > 0;
+}
+// ... and the reading for the next call: list_b's count of a blob launch over n_frames frames, behind it on `st`
+hipError_t general_seen_copy(mpe_handle* h, const int* worklist, int n_frames, hipStream_t st) {
+  if (!h->gen_seen_host) {
+    const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h->gen_seen_host), 64, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    *h->gen_seen_host = 0;
+  }
+  return hipMemcpyAsync(h->gen_seen_host, worklist + (n_frames + 1), sizeof(int), hipMemcpyDeviceToHost, st);
+}
+
 int det_hint_for(const mpe_handle* h, int n_markers) {
   const int v = h->detections_hint > 0 ? h->detections_hint : h->det_seen;
   return std::min(MPE_FAST_VOTE_DETECTIONS, std::max(n_markers, v));
@@ -317,9 +332,10 @@ int run_front(mpe_handle* h, hipStream_t st, bool prof, int chain, int chain_fra
   if (prof) rec(h, 0);
   HIP_TRY(h, launch_k1a_scan(d_frames, bytes, d_flags, dp.thr, scan_lds(h, false), st));
   if (prof) rec(h, 1);
-  HIP_TRY(h, launch_k1b_blobs(d_frames, d_flags, n_frames, g, dp, d_dets,
-                              static_cast<int*>(h->work.p) + (size_t)chain * 2 * (chain_frames + 1),
-                              static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp ? sp->n_markers : 0, st));
+  int* wl = static_cast<int*>(h->work.p) + (size_t)chain * 2 * (chain_frames + 1);
+  HIP_TRY(h, launch_k1b_blobs(d_frames, d_flags, n_frames, g, dp, d_dets, wl, static_cast<uint8_t*>(h->scratch.p),
+                              h->scratch.cap, sp ? sp->n_markers : 0, st, nullptr, false, false, general_lds_now(h)));
+  if (chain == 0 && n_frames >= 64) HIP_TRY(h, general_seen_copy(h, wl, n_frames, st));
   if (prof) rec(h, 2);
   return MPE_OK;
 }
@@ -584,6 +600,7 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
                  uint32_t* d_corr, const StreamHint* hint) {
   h->done_recorded = false;
   h->ms_accum_valid = false;
+  const bool gen_lds = general_lds_now(h);  // (one reading per call: every sub-batch the same kernel)
   const size_t frame_bytes = (size_t)g.rows * g.pitch;
   const mpe_handle::Prefetch pf = h->prefetch;  // what the previous submission scanned for this one (if anything)
   h->prefetch.valid = false;
@@ -780,7 +797,9 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], st));
       HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
                                   static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
-                                  static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp->n_markers, st, nullptr, true));
+                                  static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp->n_markers, st, nullptr, true,
+                                  false, gen_lds));
+      if (s == 0) HIP_TRY(h, general_seen_copy(h, static_cast<int*>(h->work.p), nf, st));
       h->blob_launches.emplace_back((size_t)s * 2 * (per + 1), nf);
       if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], st));
       uint32_t* hs = d_hist + (size_t)f0 * MPE_HIST_STRIDE;
@@ -903,7 +922,9 @@ int run_pipeline(mpe_handle* h, const uint8_t* d_frames, int n_frames, const Fra
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][2], sblob));
     HIP_TRY(h, launch_k1b_blobs(fr, fl, nf, g, dp, d_dets + f0,
                                 static_cast<int*>(h->work.p) + (size_t)s * 2 * (per + 1),
-                                static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp->n_markers, sblob));
+                                static_cast<uint8_t*>(h->scratch.p), h->scratch.cap, sp->n_markers, sblob, nullptr, false,
+                                false, gen_lds));
+    if (s == 0) HIP_TRY(h, general_seen_copy(h, static_cast<int*>(h->work.p), nf, sblob));
     if (prof) HIP_TRY(h, hipEventRecord(h->pev[s][3], sblob));
     HIP_TRY(h, hipEventRecord(h->sub_done[s], sblob));
     HIP_TRY(h, hipStreamWaitEvent(sb, h->sub_done[s], 0));

@@ -114,7 +114,16 @@ def test_find_leds_roi(hip, orc):
         assert np.array_equal(do, dh) and np.array_equal(uo, uh)
 
 
-def test_pathological_frames_take_the_general_path(hip, orc):
+@pytest.fixture(params=[0, 1], ids=["general_slabs", "general_lds"])
+def general_tier(request, hip):
+    """Both kernels of the general blob tier (round 6): k1b_general (bitmaps in global-memory slabs) and k1b_general_lds
+    (a block per CU, the frame's bitmaps in LDS; frames too large for that fall back to the slabs by themselves)."""
+    hip.set_option("general_lds", request.param)
+    yield request.param
+    hip.set_option("general_lds", 0)
+
+
+def test_pathological_frames_take_the_general_path(hip, orc, general_tier):
     """Frames that overflow the fast kernel's LDS pools (fully bright, dense salt noise, one huge
     ring around the LEDs) are re-done by the general kernel — same results as the oracle."""
     K, D = synth.camera_for(480, 752)
@@ -142,7 +151,7 @@ def test_pathological_frames_take_the_general_path(hip, orc):
         assert np.array_equal(got["dist_xy"][i][:2 * len(und)].reshape(-1, 2), dist), i
 
 
-def test_general_tier_band_scan_on_random_clutter(hip, orc):
+def test_general_tier_band_scan_on_random_clutter(hip, orc, general_tier):
     """Round 5: the general blob tier scans one lane per BAND of active rows (k1b_general).  Frames built to reach that
     tier with every band shape: sparse salt noise (many short bands, several blobs per band), dense noise (one band
     over the whole frame), horizontal stripes of noise separated by empty rows (bands that start / end at the image
@@ -306,7 +315,7 @@ def test_hip_against_committed_golden_vectors(hip, name):
             assert np.allclose(r["cov"], g["cov"][i], rtol=1e-6, atol=1e-12)
 
 
-def test_hip_against_the_witness_on_cluttered_frames(hip):
+def test_hip_against_the_witness_on_cluttered_frames(hip, general_tier):
     """The blob tiers — above all the general tier rewritten in round 5 — against detections made by the INDEPENDENT
     witness, not by the oracle (tests/golden/witness_clutter.npz, and witness_clutter_C4.npz at 1920x1200): salt noise
     sparse and dense, a saturated patch, a ring enclosing the LEDs, a dot grid, 4 and 16 distractor spots, two thresholds.  Count, order, float32 centroids
@@ -1830,3 +1839,33 @@ def test_overlay_geometry_against_an_independent_projection(tmp_path):
             x, y = int(np.rint(q[0])), int(np.rint(q[1]))
             if 2 <= x < cols - 2 and 2 <= y < rows - 2:
                 assert inked[y - 2:y + 3, x - 2:x + 3].any(), (k, t)
+
+
+@pytest.mark.gpu
+def test_general_tier_kernel_follows_what_the_last_call_saw(orc):
+    """Round 6, option "general_lds" = -1: the general blob tier runs as k1b_general_lds — a CU's whole LDS per block —
+    only once a call has SEEN frames reach that tier (a pinned mirror of the hand-over count, read a call late: option read-out "general_seen");
+    records identical whichever kernel ran, in the pipelined path too."""
+    import torch
+    d = synth.make_clutter_frames("salt", 64, seed=17)
+    big = torch.from_numpy(d["frames"]).cuda().repeat(258, 1, 1)[:16384 + 64].contiguous()
+    h = mpe.Handle()
+    try:
+        P = mpe.demo_params()
+        assert h.get_option("general_lds") == 0   # (the default: measured slower on salt noise, see mpe_k1.hip)
+        h.set_option("general_lds", -1)           # the automatic choice
+        assert h.get_option("general_seen") == 0
+        r0 = h.estimate_batch(big, d["markers"], d["K"], d["D"], P)      # slabs (nothing seen yet)
+        assert h.get_option("general_seen") > 0
+        r1 = h.estimate_batch(big, d["markers"], d["K"], d["D"], P)      # LDS-resident now
+        h.set_option("general_lds", 0)
+        r2 = h.estimate_batch(big, d["markers"], d["K"], d["D"], P)
+        assert np.array_equal(r0.view(np.uint8), r1.view(np.uint8)) and np.array_equal(r0.view(np.uint8), r2.view(np.uint8))
+        ro = orc.estimate_batch(d["frames"][:16], d["markers"], d["K"], d["D"], orc.make_params(), n_threads=4)
+        assert np.array_equal(r1["status"][:16], ro["status"]) and np.array_equal(r1["n_det"][:16], ro["n_det"])
+        clean = synth.make_frames("C2", 64, seed=18)
+        h.set_option("general_lds", -1)
+        h.estimate_batch(torch.from_numpy(clean["frames"]).cuda(), clean["markers"], clean["K"], clean["D"], P)
+        assert h.get_option("general_seen") == 0                         # ... and back once a call saw none
+    finally:
+        h.close()
