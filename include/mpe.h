@@ -524,6 +524,14 @@ int mpe_set_option(mpe_handle* h, const char* name, int value);
  *   "detections_seen").  From 9 on the <= 5-marker voting kernel prefilters its back-projections with an occupancy
  *   grid of the detections instead of a distance per detection; the suspect lists are sized from it.  Results do not
  *   depend on it.
+ * "track_fused" (round 6): 2 (default) a tracked frame / lock-step time step is ONE launch (k_track_frame) that also
+ *   stores the records to pinned host memory; 1 the same with a copy command for the records; 0 the chain of four
+ *   kernels + two copies of rounds 3 - 5.  Bit-identical records.  "track_phase_clocks" = 1: that kernel stamps its
+ *   phases; get "track_phase_cycles_0" .. "_3" (scan, blobs, validation, refinement: mean shader-clock cycles).
+ * "general_lds" (round 6): kernel of the general blob tier — 0 (default) bitmaps in global-memory slabs, 16 frames per
+ *   CU in flight; 1 a block per CU with the frame's bitmaps in LDS (faster per frame, one frame per CU: 2 x slower on
+ *   salt noise, 7 % faster on one large blob); -1 the LDS kernel once the previous call saw frames reach the tier
+ *   (read-out "general_seen").  Bit-identical detections.
  * get "vote_wide_frames" (round 6): frames with more than MPE_FAST_VOTE_DETECTIONS detections, voted by the strict
  *   loop nest alone; synchronises. */
 /* Read an option back.  Also "streams_concurrent": 1 once the library has verified (spin-kernel probe at
