@@ -135,6 +135,45 @@ int main(int argc, char** argv) {
       std::printf("\n");
     }
   }
+  if (argc >= 2 && !std::strcmp(argv[1], "nothrow")) {
+    // The reference's static primitives have no error channel and never throw (p3p.h:105-108): neither do these — on a
+    // box WITHOUT a HIP device (the CPU tier) every one of them comes back with the reference's own failure value and
+    // says why through mpe_facade_last_error(); with a device the same calls succeed.
+    try {
+      Matrix3d fv, wp;
+      for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) {
+          fv(k, i) = (k == 2) ? 1.0 : 0.1 * (i + 1) * (k + 1);
+          wp(k, i) = (k == i) ? 0.2 : 0.01 * (k + 1);
+        }
+      P3PSolutions sol;
+      const int rc = P3P::computePoses(fv, wp, sol);
+      Vector5d f;
+      for (int i = 0; i < 5; ++i) f(i) = 1.0 + i;
+      Vector4d roots;
+      const int rq = P3P::solveQuartic(f, roots);
+      std::vector<uint8_t> img(64 * 48, 0);
+      ImageView view;
+      view.data = img.data();
+      view.rows = 48;
+      view.cols = 64;
+      view.step = 64;
+      List2DPoints px;
+      std::vector<Point2f> centers(3);
+      Matrix3d K;
+      for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) K(i, k) = (i == k) ? (i < 2 ? 300.0 : 1.0) : 0.0;
+      K(0, 2) = 32;
+      K(1, 2) = 24;
+      LEDDetector::findLeds(view, Rect(0, 0, 64, 48), 140, 0.6, 10, 200, 0.5, 0.5, px, centers, K, std::vector<double>());
+      std::printf("nothrow computePoses %d solveQuartic %d centers %d last_error [%s]\n", rc, rq, (int)centers.size(),
+                  mpe_facade_last_error());
+      return 0;
+    } catch (...) {
+      std::printf("nothrow THREW\n");
+      return 4;
+    }
+  }
   if (argc >= 2 && !std::strcmp(argv[1], "framepath")) {  // "<encoding> <path, default build> <enc> <path, 14-bit build> <enc>" per line
     char name[64];
     while (std::scanf("%63s", name) == 1) {

@@ -1869,3 +1869,15 @@ def test_general_tier_kernel_follows_what_the_last_call_saw(orc):
         assert h.get_option("general_seen") == 0                         # ... and back once a call saw none
     finally:
         h.close()
+
+
+@pytest.mark.gpu
+def test_facade_static_primitives_with_a_device():
+    """The same calls as tests/test_abi_cpu.py::test_facade_static_primitives_never_throw, with a HIP device: they succeed
+    (0 / 0, an empty image yields no detections) and leave no error behind."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "compat"), "facade_selftest"])
+    out = subprocess.run([os.path.join(root, "compat", "facade_selftest"), "nothrow"], capture_output=True, text=True)
+    assert out.returncode == 0 and "computePoses 0 solveQuartic 0 centers 0 last_error []" in out.stdout, (out.stdout, out.stderr)
