@@ -29,8 +29,9 @@ committed binary (`profiles/collect.sh 6` → `install.py 6`; the counter file c
 sources, `%s`, and the bench line says whether it matches: %s).  This text is generated from those files
 (`tools/write_design_measurement.py`).
 * **value: %s frames/s** (%.2f ms per step, median %.2f; `round6_bench.json`)%s.  Boxes — and runs on one box — differ by
-  ± 3 %% (17.3 – 18.4 ms over the round's boxes and A/B runs), so the round's claims are same-box A/Bs: `vote_arith` 3 against 1
-  17.34 – 17.46 against 17.66 – 18.10 ms (`round6_exp_vote_arith3_step_cost.txt`%s).  %.0f %% of the frames yield a pose
+  ± 3 %% (17.3 – 18.4 ms over the round's boxes and A/B runs; runs on ONE box fall into two modes, ~17.4 and ~18.3 ms), so
+  the round's claims are interleaved same-box A/Bs: `vote_arith` 3 / 1 / 2 17.82 / 17.83 / 17.82 ms in the mean of five runs each
+  (`round6_exp_vote_arith3_step_cost_final.txt`%s).  %.0f %% of the frames yield a pose
   (the rest fail in the reference algorithm too).
 * `parity`: the records of the LAST TIMED submission as they arrived in host memory, %d frames against the oracle: %d
   status mismatches, %d poses within %.1e m / %.1e rad, %d unexplained — and none "explained" either: the
