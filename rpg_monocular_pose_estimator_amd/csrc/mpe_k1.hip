@@ -196,7 +196,9 @@ __global__ __launch_bounds__(64 * C::WAVES, C::MIN_WAVES) void k1b_blobs_list(co
 // and a frame whose rows all touch — one big blob, a grid of lines — is one band.
 // =============================================================================================
 #define K1B_GEN_KEPT 512
-#define K1B_GEN_BANDS 2048  // (8 KB of LDS; a frame with more bands — only possible above 2 048 rows — is scanned whole by one lane)
+#define K1B_GEN_BANDS 1024  // (4 KB of LDS; a frame with more bands — only possible above 1 024 rows — is scanned whole by one lane)
+#define K1B_GEN_RUNS 768    // (band, column run) items of a frame (6 KB of LDS); more: one lane per band as in round 5
+#define K1B_GEN_RUN_WORDS 16  // widest bitmap row (64-bit words) whose column occupancy a lane holds in registers
 
 __host__ __device__ inline size_t k1b_gen_scratch_bytes(const FrameGeom& g) {
   const size_t bm = (size_t)(g.rows + 2) * g.wb * 8;
@@ -226,10 +228,11 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
                                                  const int* __restrict__ worklist, uint8_t* __restrict__ scratch,
                                                  const FrameWin* __restrict__ wins) {
   const FrameGeom& g = gslot;  // slab layout and flag indexing: the slot; rows / cols of a frame: its window (gl below)
-  __shared__ int s_nkept, s_over, s_nband;
+  __shared__ int s_nkept, s_over, s_nband, s_nrun;
   __shared__ int s_taps[MPE_MAX_KSIZE];
   __shared__ u64 s_rowact[64], s_link[64];
   __shared__ short s_blo[K1B_GEN_BANDS], s_bhi[K1B_GEN_BANDS];
+  __shared__ short s_rlo[K1B_GEN_RUNS], s_rh[K1B_GEN_RUNS], s_rx0[K1B_GEN_RUNS], s_rx1[K1B_GEN_RUNS];
   const int lane = threadIdx.x;
   const int count = worklist[0];
   if ((int)blockIdx.x >= count) return;  // (the usual launch: nothing was handed over)
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
       s_nkept = 0;
       s_over = 0;
       s_nband = 0;
+      s_nrun = 0;
     }
     s_rowact[lane] = 0;
     s_link[lane] = 0;
@@ -405,7 +409,44 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
       }
     };
     K1B_GEN_STAMP(6)
-    if (nband <= K1B_GEN_BANDS) {
+    // Round 6: a band is cut again at its EMPTY COLUMNS — (band, run of occupied pixel columns) items, one lane each
+    // (scan_window<true>).  One lane per band left 35 of 64 lanes busy on a salt-noise frame (~180 blobs) and the
+    // longest band set the time: 47 % of the frame's cycles, every step a dependent read of the bitmaps.
+    bool by_runs = false;
+    if (nband <= K1B_GEN_BANDS && g.wb <= K1B_GEN_RUN_WORDS) {
+      for (int b0 = 0; b0 < nband; b0 += 64) {
+        const int b = b0 + lane;
+        if (b < nband) {
+          const int lo = s_blo[b], H = s_bhi[b] - lo + 1;
+          window_column_runs<K1B_GEN_RUN_WORDS>(nz + (size_t)lo * g.wb, g.wb, H, [&](int x0, int x1) {
+            // (Cutting a run again at the rows that are empty within its columns — window_run_rows, exact, in the CPU
+            //  tier's test — was measured here and lost: the band's ONE lane builds all its runs' row lists, a dependent
+            //  read per row and run; scan phase 0.8 -> 1.2 - 2.1 M cycles, salt leg 1.27 -> 1.02 M fps.  It would have
+            //  to run as a second pass, a lane per run.)
+            const int i = atomicAdd(&s_nrun, 1);
+            if (i < K1B_GEN_RUNS) {
+              s_rlo[i] = (short)lo;
+              s_rh[i] = (short)H;
+              s_rx0[i] = (short)x0;
+              s_rx1[i] = (short)x1;
+            }
+          });
+          });
+        }
+      }
+      __syncthreads();
+      by_runs = s_nrun <= K1B_GEN_RUNS;  // (uniform)
+    }
+    if (by_runs) {
+      const int nrun = s_nrun;
+      for (int i0 = 0; i0 < nrun; i0 += 64) {  // (uniform: every lane enters scan_window, with H = 0 if it has no item)
+        const int i = i0 + lane;
+        const int lo = i < nrun ? s_rlo[i] : 0, H = i < nrun ? s_rh[i] : 0;
+        const size_t off = (size_t)lo * g.wb;
+        scan_window<true>(nz + off, pm + off, ng + off, g.wb, H, lo, 0, dp, roi_x, roi_y, &s_over, keep,
+                          i < nrun ? s_rx0[i] : 0, i < nrun ? s_rx1[i] : 0);
+      }
+    } else if (nband <= K1B_GEN_BANDS) {
       // one lane per band, the lanes' border followings in lock step (scan_window): slot 0 of a band's window is the
       // row above it — empty, or holding no neighbour of any pixel of the band — slots 1 .. H its rows, and the row
       // below likewise: no border following leaves the band

@@ -392,10 +392,25 @@ __device__ __forceinline__ bool blob_filter(const BlobRec& b, const DetectParams
 // their borders in the same loop.  With the border following nested inside the scan loops the lanes reached it in
 // different iterations and the wave executed the traces one after the other (the sum of the perimeters instead
 // of the longest one).
-template <class Emit>
+// COLS (round 6, the general tier's (band, column run) items): the scan only looks at the bit columns xb_lo .. xb_hi of
+// the window — a maximal run of pixel columns that hold a set pixel in some row of the window, with an EMPTY column on
+// either side.  No component crosses an empty column, and none beyond it can enclose one inside the run, so the raster
+// scan decomposes there exactly as it does at an empty row: candidate and mark words are masked to the run (other runs
+// of the band share its 64-bit words and are traced by other lanes at the same time: the marks are set atomically),
+// the cursor moves over the run's words only.
+template <bool COLS = false, class Emit>
 __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, int H, int ylo, int xw0,
-                                            const DetectParams& dp, int roi_x, int roi_y, int* over, Emit emit) {
-  int slot = 1, w = 0;
+                                            const DetectParams& dp, int roi_x, int roi_y, int* over, Emit emit,
+                                            int xb_lo = 0, int xb_hi = 0) {
+  const int w_lo = COLS ? (xb_lo >> 6) : 0, w_hi = COLS ? (xb_hi >> 6) : W - 1;
+  auto wmask = [&](int w) -> u64 {
+    if (!COLS) return ~0ull;
+    u64 m = ~0ull;
+    if (w == w_lo) m &= ~0ull << (xb_lo & 63);
+    if (w == w_hi) m &= ~0ull >> (63 - (xb_hi & 63));
+    return m;
+  };
+  int slot = 1, w = w_lo;
   int last_sign = 0;  // sign of the nearest marked pixel to the left (lnbd), 0 = none yet
   u64 done = 0;
   bool fin = H < 1;
@@ -405,18 +420,20 @@ __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, in
     int xb = 0;
     while (!have && !fin) {
       // (empty words — most of a window — only move the cursor: done is 0 on arrival, no mark can sit on them)
-      while (!fin && nz[slot * W + w] == 0) {
-        if (++w == W) {
-          w = 0;
+      while (!fin && (nz[slot * W + w] & wmask(w)) == 0) {
+        if (++w > w_hi) {
+          w = w_lo;
           last_sign = 0;
           fin = ++slot > H;
         }
       }
       if (fin) break;
       const int ro = slot * W + w;
-      const u64 nzw = nz[ro];
-      const u64 pw_ = pm[ro], gw = ng[ro];
-      const u64 leftnz = (nzw << 1) | (w ? (nz[ro - 1] >> 63) : 0);
+      const u64 wm = wmask(w);
+      const u64 nzw = nz[ro] & wm;
+      const u64 pw_ = pm[ro] & wm, gw = ng[ro] & wm;
+      // (COLS: the bit left of the run's first column is an empty column by construction)
+      const u64 leftnz = (nzw << 1) | (w > w_lo ? (nz[ro - 1] >> 63) : 0);
       const u64 cand = nzw & ~(pw_ | gw) & ~leftnz & ~done;
       if (cand) {
         const int bb = __builtin_ctzll(cand);
@@ -438,8 +455,8 @@ __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, in
           last_sign = ((gw >> hb) & 1) ? -1 : 1;
         }
         done = 0;
-        if (++w == W) {
-          w = 0;
+        if (++w > w_hi) {
+          w = w_lo;
           last_sign = 0;
           fin = ++slot > H;
         }
@@ -463,6 +480,70 @@ __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, in
       float mcx, mcy;
       K1B_ON_BLOBREC(br, ((unsigned)(ylo + slot - 1) << 12) | (unsigned)(xb + xw0 - 1));
       if (blob_filter(br, dp, roi_x, roi_y, mcx, mcy)) emit(mcx, mcy, ((unsigned)(ylo + slot - 1) << 12) | (unsigned)(xb + xw0 - 1));
+    }
+  }
+}
+
+// The runs of occupied bit columns of a window (slots 1 .. H, W <= MAXW words per row): OR of the rows, then every
+// maximal run of set bits -> emit(xb_lo, xb_hi).  The general tier's (band, column run) items: scan_window<true>.
+template <int MAXW, class EmitRun>
+__device__ __forceinline__ void window_column_runs(const u64* nz, int W, int H, EmitRun emit) {
+  u64 occ[MAXW];
+#pragma unroll
+  for (int w = 0; w < MAXW; ++w) occ[w] = 0;
+  for (int r = 1; r <= H; ++r) {
+#pragma unroll
+    for (int w = 0; w < MAXW; ++w)
+      if (w < W) occ[w] |= nz[(size_t)r * W + w];
+  }
+  int start = -1;
+#pragma unroll
+  for (int w = 0; w < MAXW; ++w) {
+    if (w >= W) continue;
+    const u64 v = occ[w];
+    int pos = 0;
+    while (pos < 64) {
+      if (start < 0) {
+        const u64 m = v >> pos;
+        if (!m) break;
+        const int t = __builtin_ctzll(m);
+        start = 64 * w + pos + t;
+        pos += t;
+      } else {
+        const u64 m = ~v >> pos;  // (the zeros shifted in from above read as "still set": the run goes on in the next word)
+        if (!m) break;
+        const int t = __builtin_ctzll(m);
+        emit(start, 64 * w + pos + t - 1);
+        start = -1;
+        pos += t;
+      }
+    }
+  }
+  if (start >= 0) emit(start, 64 * W - 1);
+}
+
+// ... and a column run cut again at the rows that are EMPTY within its columns xb0 .. xb1 (the window's rows hang together
+// through OTHER runs): emit(first_slot, n_rows) for every maximal run of non-empty rows.  An empty row separates what is
+// above it from what is below exactly as it does for whole bands, and the run's side columns are empty in every row.
+template <class EmitRows>
+__device__ __forceinline__ void window_run_rows(const u64* nz, int W, int H, int xb0, int xb1, EmitRows emit) {
+  const int wl = xb0 >> 6, wh = xb1 >> 6;
+  const u64 ml = ~0ull << (xb0 & 63), mh = ~0ull >> (63 - (xb1 & 63));
+  int first = -1;
+  for (int r = 1; r <= H + 1; ++r) {
+    u64 any = 0;
+    if (r <= H)
+      for (int w = wl; w <= wh; ++w) {
+        u64 v = nz[(size_t)r * W + w];
+        if (w == wl) v &= ml;
+        if (w == wh) v &= mh;
+        any |= v;
+      }
+    if (any) {
+      if (first < 0) first = r;
+    } else if (first >= 0) {
+      emit(first, r - first);
+      first = -1;
     }
   }
 }

@@ -309,6 +309,93 @@ extern "C" int host_bands_vs_whole(const uint8_t* mask, int rows, int cols, cons
 }
 
 
+// Round 6: ... and every band cut again at its empty COLUMNS — the (band, column run) items of k1b_general: runs from
+// window_column_runs, each scanned by scan_window<true> with its column range, called as the kernel calls them (all runs
+// of a band share the band's rows and mark bitmaps).  Against the whole-frame scan: raw contour sums, boxes, keys, filtered
+// blobs.  Returns the number of components (>= 0), -1 on a mismatch; *n_runs = items found.
+extern "C" int host_runs_vs_whole(const uint8_t* mask, int rows, int cols, const double* shape, int* n_runs) {
+  DetectParams dp;
+  std::memset(&dp, 0, sizeof(dp));
+  dp.min_area = shape[0];
+  dp.max_area = shape[1];
+  dp.max_wh = shape[2];
+  dp.max_circ = shape[3];
+  const int wb = (cols + 2 + 63) / 64 + 1;
+  if (wb > 16) return -2;
+  std::vector<u64> nz((size_t)(rows + 2) * wb + 1, 0), pm(nz.size(), 0), ng(nz.size(), 0);
+  std::vector<int> active(rows, 0), linked(rows, 0);
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x)
+      if (mask[(size_t)y * cols + x]) {
+        const int xb = x + 1;
+        nz[(size_t)(y + 1) * wb + (xb >> 6)] |= 1ull << (xb & 63);
+        active[y] = 1;
+      }
+  for (int y = 1; y < rows; ++y)
+    linked[y] = k1b_rows_touch(nz.data() + (size_t)(y + 1) * wb, nz.data() + (size_t)y * wb, wb) ? 1 : 0;
+  struct Kept {
+    float x, y;
+    unsigned key;
+    bool operator<(const Kept& o) const { return key < o.key; }
+    bool operator==(const Kept& o) const { return key == o.key && std::memcmp(&x, &o.x, 4) == 0 && std::memcmp(&y, &o.y, 4) == 0; }
+  };
+  std::vector<Kept> kw, kb;
+  std::vector<RawRec> rw, rb;
+  int over = 0;
+  g_raw = &rw;
+  scan_window(nz.data(), pm.data(), ng.data(), wb, rows, 0, 0, dp, 0, 0, &over,
+              [&](float mx, float my, unsigned key) { kw.push_back({mx, my, key}); });
+  std::fill(pm.begin(), pm.end(), 0);
+  std::fill(ng.begin(), ng.end(), 0);
+  g_raw = &rb;
+  *n_runs = 0;
+  const bool brk = std::getenv("K1B_HOST_BREAK_RUNS") != nullptr;  // (the test's own check: a run that starts one column late)
+  for (int y = 0; y < rows;) {
+    if (!active[y]) {
+      ++y;
+      continue;
+    }
+    int hi = y;
+    while (hi + 1 < rows && active[hi + 1] && linked[hi + 1]) ++hi;
+    const size_t off = (size_t)y * wb;
+    std::vector<std::pair<int, int>> runs;
+    window_column_runs<16>(nz.data() + off, wb, hi - y + 1, [&](int x0, int x1) { runs.push_back({x0, x1}); });
+    // the runs in REVERSE order: the items of a band run on different lanes at once — no order may matter
+    for (size_t k = runs.size(); k-- > 0;) {
+      // ... each run cut again at the rows that are empty within its columns (window_run_rows), as the kernel does
+      std::vector<std::pair<int, int>> sub;
+      window_run_rows(nz.data() + off, wb, hi - y + 1, runs[k].first, runs[k].second,
+                      [&](int first, int nrows) { sub.push_back({first, nrows}); });
+      for (size_t q = sub.size(); q-- > 0;) {
+        const int lo2 = y + sub[q].first - 1;
+        const size_t off2 = (size_t)lo2 * wb;
+        scan_window<true>(nz.data() + off2, pm.data() + off2, ng.data() + off2, wb, sub[q].second, lo2, 0, dp, 0, 0, &over,
+                          [&](float mx, float my, unsigned key) { kb.push_back({mx, my, key}); },
+                          runs[k].first + (brk ? 1 : 0), runs[k].second);
+        ++*n_runs;
+      }
+    }
+    y = hi + 1;
+  }
+  g_raw = nullptr;
+  if (over) return -1;
+  auto norm = [](std::vector<RawRec>& v) {
+    std::sort(v.begin(), v.end(), [](const RawRec& a, const RawRec& b) { return a.key < b.key; });
+  };
+  norm(rw);
+  norm(rb);
+  if (rw.size() != rb.size()) return -1;
+  for (size_t i = 0; i < rw.size(); ++i)
+    if (rw[i].a00 != rb[i].a00 || rw[i].a10 != rb[i].a10 || rw[i].a01 != rb[i].a01 || rw[i].xmin != rb[i].xmin ||
+        rw[i].xmax != rb[i].xmax || rw[i].ymin != rb[i].ymin || rw[i].ymax != rb[i].ymax || rw[i].key != rb[i].key)
+      return -1;
+  std::sort(kw.begin(), kw.end());
+  std::sort(kb.begin(), kb.end());
+  if (!(kw == kb)) return -1;
+  return (int)rw.size();
+}
+
+
 // The general tier's blur on the RAW frame (PixWin::add + the image pass's flag bits: only flagged segments are loaded
 // and thresholded, rows without one are skipped) against the blur on a thresholded copy of the frame (what the LDS
 // tiers stage): the non-zero bitmaps must be identical.  Flags as the image pass sets them (any_gt16 per 16-byte

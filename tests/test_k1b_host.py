@@ -313,6 +313,70 @@ def test_band_scans_equal_the_whole_frame_scan(host):
         del os.environ["K1B_HOST_BREAK_BANDS"]
 
 
+def test_column_run_scans_equal_the_whole_frame_scan(host):
+    """Round 6: the general blob tier cuts every band again at its EMPTY COLUMNS and scans (band, column run) items, one
+    lane each (window_column_runs + scan_window<true>, cut out of the kernel source and called as the kernel calls
+    them; the runs of a band in reverse order: on the device they run concurrently).  Exact for
+    findContours(RETR_EXTERNAL): same components, raw contour sums, bounding boxes, start keys, filtered blobs as the
+    whole-frame scan — specks (many runs per band, several sharing a 64-bit word), stripes, bars, rings with blobs
+    inside (a ring's columns are one run: what it encloses stays inside it), dense noise, discs cut by the borders,
+    widths around the word boundaries."""
+    from scipy import ndimage
+    host.host_runs_vs_whole.restype = C.c_int
+    rng = np.random.default_rng(616)
+    shape_real = np.array([10.0, 200.0, 0.5, 0.5])
+    shape_open = np.array([0.0, 1e9, 1.0, 1e9])
+    n_comp = n_runs = n_multi = 0
+    for it in range(1500):
+        kind = it % 6
+        rows = int(rng.integers(3, 70))
+        cols = int(rng.choice([rng.integers(3, 60), 61, 62, 63, 64, 65, 126, 127, 128, 129, rng.integers(66, 400)]))
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        if kind == 0:
+            m = rng.random((rows, cols)) < rng.choice([0.002, 0.01, 0.03])
+            m = ndimage.binary_dilation(m, iterations=int(rng.integers(0, 3))) if rng.random() < 0.7 else m
+        elif kind == 1:
+            m = np.zeros((rows, cols), bool)
+            x = 0
+            while x < cols:   # noise stripes separated by empty COLUMNS of width 1 .. 3
+                w = int(rng.integers(1, 9))
+                m[:, x:x + w] = rng.random((rows, min(w, cols - x))) < 0.2
+                x += w + int(rng.integers(1, 4))
+        elif kind == 2:
+            m = rng.random((rows, cols)) < 0.01
+            y0 = int(rng.integers(0, rows))
+            m[y0:y0 + 2, int(rng.integers(0, cols // 2 + 1)):cols - int(rng.integers(0, cols // 3 + 1))] = True  # a wide bar
+        elif kind == 3:
+            m = rng.random((rows, cols)) < 0.02
+            rad = min(rows, cols) / 2.5
+            d = np.hypot(yy - rows / 2, xx - cols / 2)
+            m |= np.abs(d - rad) < 1.2
+        elif kind == 4:
+            m = rng.random((rows, cols)) < rng.uniform(0.05, 0.6)
+        else:
+            m = np.zeros((rows, cols), bool)
+            for _ in range(int(rng.integers(1, 9))):
+                cy, cx, rad = rng.uniform(-2, rows + 2), rng.uniform(-2, cols + 2), rng.uniform(0.8, 6.0)
+                m |= (yy - cy) ** 2 + (xx - cx) ** 2 <= rad ** 2
+        mask = np.ascontiguousarray(m, np.uint8)
+        shape = shape_real if it % 2 else shape_open
+        nr = C.c_int(0)
+        r = host.host_runs_vs_whole(mask.ctypes.data_as(C.c_void_p), rows, cols, shape.ctypes.data_as(C.c_void_p), C.byref(nr))
+        assert r >= 0, (it, kind, rows, cols, r)
+        n_comp += r
+        n_runs += nr.value
+        n_multi += int(nr.value > 3)
+    assert n_comp > 10000 and n_runs > 8000 and n_multi > 700, (n_comp, n_runs, n_multi)
+    os.environ["K1B_HOST_BREAK_RUNS"] = "1"   # the comparison has teeth: a run that starts one column late must be caught
+    try:
+        m = np.zeros((20, 30), np.uint8)
+        m[3:15, 5:12] = 1
+        nr = C.c_int(0)
+        assert host.host_runs_vs_whole(m.ctypes.data_as(C.c_void_p), 20, 30, shape_open.ctypes.data_as(C.c_void_p), C.byref(nr)) == -1
+    finally:
+        del os.environ["K1B_HOST_BREAK_RUNS"]
+
+
 def test_raw_frame_blur_equals_the_blur_of_the_thresholded_copy(host, orc):
     """Round 5: the general blob tier no longer copies the frame; its blur reads the frame's own rows, loads only the
     segments the image pass FLAGGED, applies THRESH_TOZERO on the fly and skips rows without a flagged segment
