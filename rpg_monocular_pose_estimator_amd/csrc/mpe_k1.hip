@@ -431,7 +431,6 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
               s_rx1[i] = (short)x1;
             }
           });
-          });
         }
       }
       __syncthreads();
