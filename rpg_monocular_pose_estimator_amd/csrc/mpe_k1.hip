@@ -195,6 +195,29 @@ __global__ __launch_bounds__(64 * C::WAVES, C::MIN_WAVES) void k1b_blobs_list(co
 // What is left: a band is still walked by ONE lane (its rows word by word, dependent bitmap reads from global memory),
 // and a frame whose rows all touch — one big blob, a grid of lines — is one band.
 // =============================================================================================
+// Which neighbour columns of a bright segment (row y0, segment column c0) can blur to anything?  With dc = 1 the column
+// on the left only through a thresholded pixel in the segment's FIRST r pixels, the one on the right only through its
+// LAST r (an output x sees inputs x - r .. x + r; every other segment that could reach those columns marks them
+// itself).  For an isolated bright pixel that drops two of three columns of to-do items in three cases of four — the
+// blur was 35 % of a salt-noise frame, VALU bound at 16 waves per CU (2 472 items, ~900 instructions each).  Only away
+// from the image border (no BORDER_REFLECT_101 read from the dropped column can reach the segment) and for r <= 16.
+__device__ __forceinline__ void k1b_gen_narrow(const uint8_t* frame, int pitch, int cols, int y0, int c0, int r, int dc,
+                                               unsigned add, int& cl, int& ch) {
+  if (dc != 1 || !add) return;
+  const bool may_l = cl < c0 && 16 * (c0 - 1) >= r, may_r = ch > c0 && 16 * (c0 + 2) + r <= cols;
+  if (!may_l && !may_r) return;
+  const uint4 v = *reinterpret_cast<const uint4*>(frame + (size_t)y0 * pitch + 16 * c0);
+  const unsigned q[4] = {tozero4(v.x, add), tozero4(v.y, add), tozero4(v.z, add), tozero4(v.w, add)};
+  unsigned left = 0, right = 0;
+  for (int j = 0; j < r; ++j) {
+    left |= (q[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+    const int t = 15 - j;
+    right |= (q[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+  }
+  if (may_l && !left) cl = c0;
+  if (may_r && !right) ch = c0;
+}
+
 #define K1B_GEN_KEPT 512
 #define K1B_GEN_BANDS 1024  // (4 KB of LDS; a frame with more bands — only possible above 1 024 rows — is scanned whole by one lane)
 #define K1B_GEN_RUNS 768    // (band, column run) items of a frame (6 KB of LDS); more: one lane per band as in round 5
@@ -298,8 +321,10 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
           const int s = i * 64 + __builtin_ctzll(v);
           v &= v - 1;
           const int y0 = s / spr, c0 = s - y0 * spr;
+          int cl = max(0, c0 - dc), ch = min(spr - 1, c0 + dc);
+          k1b_gen_narrow(frame, g.pitch, gl.cols, y0, c0, r, dc, add, cl, ch);
           for (int yy = max(0, y0 - r); yy <= min(gl.rows - 1, y0 + r); ++yy)
-            for (int cc = max(0, c0 - dc); cc <= min(spr - 1, c0 + dc); ++cc)
+            for (int cc = cl; cc <= ch; ++cc)
               atomicOr(&todo[(size_t)yy * g.tw + (cc >> 6)], 1ull << (cc & 63));
         }
       }
@@ -570,8 +595,10 @@ __global__ __launch_bounds__(K1B_GENL_THREADS) void k1b_general_lds(const uint8_
           const int sgm = i * 64 + __builtin_ctzll(v);
           v &= v - 1;
           const int y0 = sgm / spr, c0 = sgm - y0 * spr;
+          int cl = max(0, c0 - dc), ch = min(spr - 1, c0 + dc);
+          k1b_gen_narrow(frame, g.pitch, gl.cols, y0, c0, r, dc, add, cl, ch);
           for (int yy = max(0, y0 - r); yy <= min(gl.rows - 1, y0 + r); ++yy)
-            for (int cc = max(0, c0 - dc); cc <= min(spr - 1, c0 + dc); ++cc)
+            for (int cc = cl; cc <= ch; ++cc)
               atomicOr(&todo[(size_t)yy * g.tw + (cc >> 6)], 1ull << (cc & 63));
         }
       }
