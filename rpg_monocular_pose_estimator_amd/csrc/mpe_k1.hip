@@ -444,10 +444,8 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
         if (b < nband) {
           const int lo = s_blo[b], H = s_bhi[b] - lo + 1;
           window_column_runs<K1B_GEN_RUN_WORDS>(nz + (size_t)lo * g.wb, g.wb, H, [&](int x0, int x1) {
-            // (Cutting a run again at the rows that are empty within its columns — window_run_rows, exact, in the CPU
-            //  tier's test — was measured here and lost: the band's ONE lane builds all its runs' row lists, a dependent
-            //  read per row and run; scan phase 0.8 -> 1.2 - 2.1 M cycles, salt leg 1.27 -> 1.02 M fps.  It would have
-            //  to run as a second pass, a lane per run.)
+            // (the runs are cut again at their empty rows below, a lane per RUN: done here, by the band's one lane — a
+            //  dependent read per row and run — it cost more than it saved: scan phase 0.8 -> 1.2 - 2.1 M cycles)
             const int i = atomicAdd(&s_nrun, 1);
             if (i < K1B_GEN_RUNS) {
               s_rlo[i] = (short)lo;
@@ -461,14 +459,47 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
       __syncthreads();
       by_runs = s_nrun <= K1B_GEN_RUNS;  // (uniform)
     }
+    // ... and every run again at the rows that are EMPTY within its columns (window_run_rows; a lane per run): the
+    // band's rows chain through OTHER runs — salt pixels three rows tall hang together over sixty rows — so a run holds
+    // several blobs one above the other, and the longest such stack set the time of a round of 64 items (~250 k cycles).
+    // The pieces are appended behind the runs (same lists); if they do not fit, the runs themselves are scanned.
+    int item0 = 0, item1 = by_runs ? s_nrun : 0;  // (uniform) the items the scan below works on: [item0, item1)
     if (by_runs) {
       const int nrun = s_nrun;
-      for (int i0 = 0; i0 < nrun; i0 += 64) {  // (uniform: every lane enters scan_window, with H = 0 if it has no item)
+      __syncthreads();
+      for (int i0 = 0; i0 < nrun; i0 += 64) {
         const int i = i0 + lane;
-        const int lo = i < nrun ? s_rlo[i] : 0, H = i < nrun ? s_rh[i] : 0;
+        if (i < nrun) {
+          const int lo = s_rlo[i], H = s_rh[i], x0 = s_rx0[i], x1 = s_rx1[i];
+          window_run_rows(nz + (size_t)lo * g.wb, g.wb, H, x0, x1, [&](int first, int nrows) {
+            const int j = atomicAdd(&s_nrun, 1);
+            if (j < K1B_GEN_RUNS) {
+              s_rlo[j] = (short)(lo + first - 1);
+              s_rh[j] = (short)nrows;
+              s_rx0[j] = (short)x0;
+              s_rx1[j] = (short)x1;
+            }
+          });
+        }
+      }
+      __syncthreads();
+      if (s_nrun <= K1B_GEN_RUNS) {  // (uniform)
+        item0 = nrun;
+        item1 = s_nrun;
+      } else {
+        item1 = nrun;
+      }
+    }
+#ifdef K1B_GEN_CLOCKS
+    const unsigned long long gclk_runs = __builtin_amdgcn_s_memtime();
+#endif
+    if (by_runs) {
+      for (int i0 = item0; i0 < item1; i0 += 64) {  // (uniform: every lane enters scan_window, with H = 0 if it has no item)
+        const int i = i0 + lane;
+        const int lo = i < item1 ? s_rlo[i] : 0, H = i < item1 ? s_rh[i] : 0;
         const size_t off = (size_t)lo * g.wb;
         scan_window<true>(nz + off, pm + off, ng + off, g.wb, H, lo, 0, dp, roi_x, roi_y, &s_over, keep,
-                          i < nrun ? s_rx0[i] : 0, i < nrun ? s_rx1[i] : 0);
+                          i < item1 ? s_rx0[i] : 0, i < item1 ? s_rx1[i] : 0);
       }
     } else if (nband <= K1B_GEN_BANDS) {
       // one lane per band, the lanes' border followings in lock step (scan_window): slot 0 of a band's window is the
@@ -491,9 +522,9 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     K1B_GEN_STAMP(8)
 #ifdef K1B_GEN_CLOCKS
     if (blockIdx.x == 0 && lane == 0 && wi == 0)
-      printf("k1b_general phases (cycles): clear %llu todo %llu items %llu (n=%d) blur %llu rows %llu bands %llu (n=%d) scan %llu write %llu\n",
+      printf("k1b_general phases (cycles): clear %llu todo %llu items %llu (n=%d) blur %llu rows %llu bands %llu (n=%d) runs %llu (n=%d) scan %llu write %llu\n",
              gclk[1] - gclk[0], gclk[2] - gclk[1], gclk[3] - gclk[2], n_items, gclk[4] - gclk[3], gclk[5] - gclk[4],
-             gclk[6] - gclk[5], nband, gclk[7] - gclk[6], gclk[8] - gclk[7]);
+             gclk[6] - gclk[5], nband, gclk_runs - gclk[6], item1 - item0, gclk[7] - gclk_runs, gclk[8] - gclk[7]);
 #endif
   }
 }

@@ -420,6 +420,24 @@ __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, in
     int xb = 0;
     while (!have && !fin) {
       // (empty words — most of a window — only move the cursor: done is 0 on arrival, no mark can sit on them)
+      if (COLS && w_lo == w_hi) {
+        // a run inside one 64-bit word (the rule): four rows' words in flight at a time — the band's rows chain through
+        // OTHER runs, so most of this run's rows are empty, and every empty row cost a dependent read
+        const u64 m1 = wmask(w_lo);
+        while (!fin && w == w_lo) {
+          const u64* q = nz + (size_t)slot * W + w_lo;
+          const u64 a0 = q[0] & m1;
+          const u64 a1 = (slot + 1 <= H) ? (q[W] & m1) : 0;
+          const u64 a2 = (slot + 2 <= H) ? (q[2 * W] & m1) : 0;
+          const u64 a3 = (slot + 3 <= H) ? (q[3 * W] & m1) : 0;
+          if (a0) break;
+          const int adv = a1 ? 1 : (a2 ? 2 : (a3 ? 3 : 4));  // (an empty word only moves the cursor: done is 0 on arrival)
+          slot += adv;
+          last_sign = 0;
+          fin = slot > H;
+          if (adv < 4) break;
+        }
+      }
       while (!fin && (nz[slot * W + w] & wmask(w)) == 0) {
         if (++w > w_hi) {
           w = w_lo;
@@ -491,7 +509,16 @@ __device__ __forceinline__ void window_column_runs(const u64* nz, int W, int H, 
   u64 occ[MAXW];
 #pragma unroll
   for (int w = 0; w < MAXW; ++w) occ[w] = 0;
-  for (int r = 1; r <= H; ++r) {
+  int r = 1;
+  for (; r + 3 <= H; r += 4) {  // (four rows' loads in flight per trip)
+#pragma unroll
+    for (int w = 0; w < MAXW; ++w)
+      if (w < W) {
+        const u64* q = nz + (size_t)r * W + w;
+        occ[w] |= (q[0] | q[W]) | (q[2 * W] | q[3 * W]);
+      }
+  }
+  for (; r <= H; ++r) {
 #pragma unroll
     for (int w = 0; w < MAXW; ++w)
       if (w < W) occ[w] |= nz[(size_t)r * W + w];
@@ -530,22 +557,34 @@ __device__ __forceinline__ void window_run_rows(const u64* nz, int W, int H, int
   const int wl = xb0 >> 6, wh = xb1 >> 6;
   const u64 ml = ~0ull << (xb0 & 63), mh = ~0ull >> (63 - (xb1 & 63));
   int first = -1;
-  for (int r = 1; r <= H + 1; ++r) {
+  auto row_any = [&](int r) -> u64 {
+    if (r > H) return 0;
     u64 any = 0;
-    if (r <= H)
-      for (int w = wl; w <= wh; ++w) {
-        u64 v = nz[(size_t)r * W + w];
-        if (w == wl) v &= ml;
-        if (w == wh) v &= mh;
-        any |= v;
-      }
+    for (int w = wl; w <= wh; ++w) {
+      u64 v = nz[(size_t)r * W + w];
+      if (w == wl) v &= ml;
+      if (w == wh) v &= mh;
+      any |= v;
+    }
+    return any;
+  };
+  auto step = [&](int r, u64 any) {
     if (any) {
       if (first < 0) first = r;
     } else if (first >= 0) {
       emit(first, r - first);
       first = -1;
     }
+  };
+  int r = 1;
+  for (; r + 3 <= H + 1; r += 4) {  // (four rows' words in flight per trip: the rows are independent reads)
+    const u64 a0 = row_any(r), a1 = row_any(r + 1), a2 = row_any(r + 2), a3 = row_any(r + 3);
+    step(r, a0);
+    step(r + 1, a1);
+    step(r + 2, a2);
+    step(r + 3, a3);
   }
+  for (; r <= H + 1; ++r) step(r, row_any(r));
 }
 
 // ---- contour phase WITHOUT border following ------------------------------------------------------------------
