@@ -219,8 +219,15 @@ __device__ __forceinline__ void k1b_gen_narrow(const uint8_t* frame, int pitch, 
 }
 
 #define K1B_GEN_KEPT 512
-#define K1B_GEN_BANDS 1024  // (4 KB of LDS; a frame with more bands — only possible above 1 024 rows — is scanned whole by one lane)
-#define K1B_GEN_RUNS 768    // (band, column run) items of a frame (6 KB of LDS); more: one lane per band as in round 5
+#ifndef K1B_GEN_OCC
+#define K1B_GEN_OCC 4  // waves per SIMD the kernel is compiled for (128 registers) and its LDS lists are sized for (10 KB)
+#endif
+#ifndef K1B_GEN_BANDS
+#define K1B_GEN_BANDS 768  // (3 KB of LDS; a frame with more bands — only possible above 1 536 rows — is scanned whole by one lane)
+#endif
+#ifndef K1B_GEN_RUNS
+#define K1B_GEN_RUNS 736    // (band, column run) items of a frame and their pieces (5.75 KB of LDS); more: one lane per band as in round 5
+#endif
 #define K1B_GEN_RUN_WORDS 16  // widest bitmap row (64-bit words) whose column occupancy a lane holds in registers
 
 __host__ __device__ inline size_t k1b_gen_scratch_bytes(const FrameGeom& g) {
@@ -246,7 +253,7 @@ static int k1b_gen_blocks(const FrameGeom& g, int n_frames) {
   return (int)n;
 }
 
-__global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
+__global__ __launch_bounds__(64, K1B_GEN_OCC) void k1b_general(const uint8_t* __restrict__ frames, const u64* __restrict__ flags,
                                                  FrameGeom gslot, DetectParams dp, mpe_detections* __restrict__ dets,
                                                  const int* __restrict__ worklist, uint8_t* __restrict__ scratch,
                                                  const FrameWin* __restrict__ wins) {
@@ -254,6 +261,8 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
   __shared__ int s_nkept, s_over, s_nband, s_nrun;
   __shared__ int s_taps[MPE_MAX_KSIZE];
   __shared__ u64 s_rowact[64], s_link[64];
+  static_assert(4 * K1B_GEN_RUN_WORDS <= 64, "s_cor lives in s_rowact");
+  u64(*s_cor)[K1B_GEN_RUN_WORDS] = reinterpret_cast<u64(*)[K1B_GEN_RUN_WORDS]>(s_rowact);  // (the row bitsets are dead by then)
   __shared__ short s_blo[K1B_GEN_BANDS], s_bhi[K1B_GEN_BANDS];
   __shared__ short s_rlo[K1B_GEN_RUNS], s_rh[K1B_GEN_RUNS], s_rx0[K1B_GEN_RUNS], s_rx1[K1B_GEN_RUNS];
   const int lane = threadIdx.x;
@@ -374,14 +383,32 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     __threadfence_block();
     __syncthreads();
     K1B_GEN_STAMP(4)
-    for (int y = lane; y < gl.rows; y += 64) {
-      const u64* nzrow = nz + (size_t)(y + 1) * g.wb;
-      u64 any = 0;
-      for (int w = 0; w < g.wb; ++w) any |= nzrow[w];
-      if (any) {
-        atomicOr(&s_rowact[y >> 6], 1ull << (y & 63));
-        // (slot y of the bitmaps is row y - 1; slot 0 is the empty separator above row 0)
-        if (k1b_rows_touch(nzrow, nzrow - g.wb, g.wb)) atomicOr(&s_link[y >> 6], 1ull << (y & 63));
+    // which rows hold a pixel, and which of them touch the row above (k1b_rows_touch, word by word): the bitmap read as
+    // ONE array, consecutive lanes consecutive words, four loads in flight.  (A lane per row read 64 different cache
+    // lines with every instruction; the kernel is bound by exactly that — ~4 000 memory instructions per frame, most of
+    // them 64 lanes to 64 lines, one every ~70 cycles per CU with 12 waves resident: profiles/round6_exp_general_tier.txt 8.)
+    {
+      const int nw = gl.rows * g.wb;
+      for (int i0 = 0; i0 < nw; i0 += 256) {
+        u64 cur[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + 64 * u + lane;
+          cur[u] = i < nw ? nz[(size_t)g.wb + i] : 0;  // (slot y + 1 holds row y; slot 0 is the empty separator above row 0)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (cur[u]) {
+            const int i = i0 + 64 * u + lane;
+            const int y = i / g.wb, w = i - y * g.wb;
+            atomicOr(&s_rowact[y >> 6], 1ull << (y & 63));
+            const u64* prev = nz + (size_t)y * g.wb;
+            const u64 p = prev[w];
+            u64 dil = p | (p << 1) | (p >> 1);
+            if (w > 0) dil |= prev[w - 1] >> 63;
+            if (w + 1 < g.wb) dil |= prev[w + 1] << 63;
+            if (cur[u] & dil) atomicOr(&s_link[y >> 6], 1ull << (y & 63));
+          }
       }
     }
     __syncthreads();
@@ -439,13 +466,39 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
     // longest band set the time: 47 % of the frame's cycles, every step a dependent read of the bitmaps.
     bool by_runs = false;
     if (nband <= K1B_GEN_BANDS && g.wb <= K1B_GEN_RUN_WORDS) {
-      for (int b0 = 0; b0 < nband; b0 += 64) {
-        const int b = b0 + lane;
-        if (b < nband) {
-          const int lo = s_blo[b], H = s_bhi[b] - lo + 1;
-          window_column_runs<K1B_GEN_RUN_WORDS>(nz + (size_t)lo * g.wb, g.wb, H, [&](int x0, int x1) {
-            // (the runs are cut again at their empty rows below, a lane per RUN: done here, by the band's one lane — a
-            //  dependent read per row and run — it cost more than it saved: scan phase 0.8 -> 1.2 - 2.1 M cycles)
+      // the column occupancy of a band by the WHOLE wave, four bands in flight: lane 16 j + w ORs word w of the band's
+      // rows j, j + 4, ... (consecutive lanes consecutive words: a lane per band read its rows x words one scattered
+      // load after the other, the tallest band setting the time — 1 200 of the frame's 4 000 memory instructions);
+      // then lanes 0 .. 3 cut their band's sixteen words into runs (window_column_runs' second half).
+      // (the runs are cut again at their empty rows below, a lane per RUN: done by the band's one lane — a dependent
+      //  read per row and run — it cost more than it saved: scan phase 0.8 -> 1.2 - 2.1 M cycles)
+      const int cw = lane & 15, cj = lane >> 4;
+      for (int b0 = 0; b0 < nband; b0 += 4) {  // (uniform)
+        int blo[4], bh[4], hmax = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int b = b0 + u;
+          blo[u] = b < nband ? s_blo[b] : 0;
+          bh[u] = b < nband ? s_bhi[b] - blo[u] + 1 : 0;
+          hmax = max(hmax, bh[u]);
+        }
+        u64 acc[4] = {0, 0, 0, 0};
+        if (cw < g.wb)
+          for (int kk = cj; kk < hmax; kk += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (kk < bh[u]) acc[u] |= nz[(size_t)(blo[u] + 1 + kk) * g.wb + cw];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[u] |= __shfl_xor(acc[u], 16);
+          acc[u] |= __shfl_xor(acc[u], 32);
+          if (lane < 16) s_cor[u][lane] = acc[u];
+        }
+        __syncthreads();
+        if (lane < 4 && b0 + lane < nband) {
+          const int lo = s_blo[b0 + lane], H = s_bhi[b0 + lane] - lo + 1;
+          column_runs_of_words(s_cor[lane], g.wb, [&](int x0, int x1) {
             const int i = atomicAdd(&s_nrun, 1);
             if (i < K1B_GEN_RUNS) {
               s_rlo[i] = (short)lo;
@@ -455,8 +508,8 @@ __global__ __launch_bounds__(64) void k1b_general(const uint8_t* __restrict__ fr
             }
           });
         }
+        __syncthreads();
       }
-      __syncthreads();
       by_runs = s_nrun <= K1B_GEN_RUNS;  // (uniform)
     }
     // ... and every run again at the rows that are EMPTY within its columns (window_run_rows; a lane per run): the
@@ -811,6 +864,18 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
                        g, dp, dets, (const int*)list_b, scratch, wins);
     return hipGetLastError();
   }
+  // ... and no more blocks than the device holds at once: a block walks the work-list with the grid as its stride, so the
+  // blocks of a second round would start when the first round's have done ALL their frames (4 096 blocks on the 3 072
+  // resident ones of 256 CUs: the last quarter of a 16 384-frame list ran on a quarter of the machine, 7.9 ms where
+  // 5.3 rounds of frames need ~4)
+  static int resident = 0;
+  if (!resident) {
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k1b_general), 64, 0);
+    if (e != hipSuccess) return e;
+    resident = (per_cu > 0 ? per_cu : 1) * device_cu_count();
+  }
+  if (!getenv("MPE_K1B_GEN_FULL_GRID") && gen_blocks > (size_t)resident) gen_blocks = (size_t)resident;
   hipLaunchKernelGGL(k1b_general, dim3((unsigned)gen_blocks), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
                      (const int*)list_b, scratch, wins);
   return hipGetLastError();

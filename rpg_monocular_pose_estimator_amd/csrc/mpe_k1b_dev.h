@@ -502,6 +502,33 @@ __device__ __forceinline__ void scan_window(u64* nz, u64* pm, u64* ng, int W, in
   }
 }
 
+// Every maximal run of set bits of a row of W words (the OR of a window's rows: its occupied columns) -> emit(xb_lo, xb_hi)
+template <class EmitRun>
+__device__ __forceinline__ void column_runs_of_words(const u64* occ, int W, EmitRun emit) {
+  int start = -1;
+  for (int w = 0; w < W; ++w) {
+    const u64 v = occ[w];
+    int pos = 0;
+    while (pos < 64) {
+      if (start < 0) {
+        const u64 m = v >> pos;
+        if (!m) break;
+        const int t = __builtin_ctzll(m);
+        start = 64 * w + pos + t;
+        pos += t;
+      } else {
+        const u64 m = ~v >> pos;  // (the zeros shifted in from above read as "still set": the run goes on in the next word)
+        if (!m) break;
+        const int t = __builtin_ctzll(m);
+        emit(start, 64 * w + pos + t - 1);
+        start = -1;
+        pos += t;
+      }
+    }
+  }
+  if (start >= 0) emit(start, 64 * W - 1);
+}
+
 // The runs of occupied bit columns of a window (slots 1 .. H, W <= MAXW words per row): OR of the rows, then every
 // maximal run of set bits -> emit(xb_lo, xb_hi).  The general tier's (band, column run) items: scan_window<true>.
 template <int MAXW, class EmitRun>

@@ -360,6 +360,14 @@ extern "C" int host_runs_vs_whole(const uint8_t* mask, int rows, int cols, const
     const size_t off = (size_t)y * wb;
     std::vector<std::pair<int, int>> runs;
     window_column_runs<16>(nz.data() + off, wb, hi - y + 1, [&](int x0, int x1) { runs.push_back({x0, x1}); });
+    {  // the kernel's way since the wave ORs a band's rows together: the rows' OR first, then column_runs_of_words
+      std::vector<u64> occ(wb, 0);
+      for (int r = 1; r <= hi - y + 1; ++r)
+        for (int w = 0; w < wb; ++w) occ[w] |= nz[off + (size_t)r * wb + w];
+      std::vector<std::pair<int, int>> runs2;
+      column_runs_of_words(occ.data(), wb, [&](int x0, int x1) { runs2.push_back({x0, x1}); });
+      if (runs2 != runs) return -1;
+    }
     // the runs in REVERSE order: the items of a band run on different lanes at once — no order may matter
     for (size_t k = runs.size(); k-- > 0;) {
       // ... each run cut again at the rows that are empty within its columns (window_run_rows), as the kernel does
