@@ -90,15 +90,16 @@ clutter = '''| leg | frames/s (round 5) | what grows | voting launch / dominant 
 | clean (headline) | %s (14.61 M) | — | HBM %.2f |
 | 4 distractor spots (9 detections) | %s (3.37 M) | C(9,3) = 84 triples × 60: 8.4 × the hypotheses | FP64 issue %.2f (%d VALU per solve; round 5: 1 668) |
 | 16 distractor spots (21 detections) | **%s** (164 k) | 1 330 triples × 60 = 79 800 P3P per frame (C3's 73 920) | FP64 issue %.2f (%d VALU per solve; round 5: 2 496) |
-| 0.05 %% salt noise (~180 isolated bright pixels) | %s (979 k) | every frame in the general tier | the blob tiers: latency bound (`k1b_general`: %d VALU per frame; round 5: 140 621) |
+| 0.05 %% salt noise (~180 isolated bright pixels) | %s (979 k) | every frame in the general tier | the blob tiers: bound by the request rate of scattered accesses (`k1b_general`: %d VALU per frame; round 5: 140 621) |
 | saturated 64×64 patch | %s (2.80 M) | one 68-row island per frame | blob tiers |
 
 Every leg: 256-frame oracle sample, 0 status mismatches, 0 unexplained.  With distractors it is the VOTING that grows —
 C(n_d,3) — not the blob tiers (the reference's own cost model, `pose_estimator.cpp:565-702`).  Round 5 paid for every unused
 detection in every root's prefilter (2 496 VALU per solve at 21 detections against 1 500 on a clean frame); the grid of
 detection masks (K2 below) makes a solve cost the same ~1 400 at 9 and at 21 detections.  The fractions are against 614 G
-wave-instructions/s (1 024 SIMDs × the 2.4 GHz SPEC clock ÷ 4).  The salt leg's gain is the general tier's batched blur
-loads (`round6_exp_general_tier.txt`); that tier is still one lane per band.
+wave-instructions/s (1 024 SIMDs × the 2.4 GHz SPEC clock ÷ 4).  The salt leg's gain is the general tier's (band, column
+run, row piece) items, narrowed to-do columns, batched and coalesced loads, resident-block grid and 4 waves per SIMD
+(`round6_exp_general_tier.txt`, K1b below).
 ''' % (M(b["value"]), rf["frac"], M(d4[0]), d4[2] or 0, ps("C2_d4", 9), k(d16[0]), d16[2] or 0, ps("C2_d16", 21),
        (M(salt[0]) if salt[0] >= 1e6 else k(salt[0])), g.get("valu_insts_per_frame", 0), M(patch[0]))
 
