@@ -1,0 +1,127 @@
+"""General-blob-tier parity soak (led_detector.cpp:35-112): randomly generated frames that the LDS
+tiers cannot hold — salt noise of many densities, stripes of noise, tall bars, rings with blobs inside, saturated patches,
+glare gradients, LEDs on top of noise — at three frame sizes (one with pitch != cols), several thresholds and blur
+widths, through mpe_detect_batch (k1b_blobs -> k1b_blobs_list -> k1b_general: bands, column runs, row pieces) and,
+frame by frame, through the oracle's findLeds.  Compared: status (-10 beyond the detection capacity), the number of
+detections, the distorted centres bit for bit (float32), the undistorted points bit for bit (float64 of float32).
+Every differing frame is saved.  Exit code 1 on any difference.
+usage (on an MI355X): python tests/soak_general_tier.py [rounds [out_prefix]]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np  # noqa: E402
+import rpg_monocular_pose_estimator_amd as mpe  # noqa: E402
+from rpg_monocular_pose_estimator_amd import synth  # noqa: E402
+import oracle  # noqa: E402
+
+oracle.build()
+from oracle import binding as orc  # noqa: E402
+
+ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+OUT = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/soak_general_tier"
+rng = np.random.default_rng(606)
+
+
+def noise(rows, cols, dens, lo=150):
+    return (rng.random((rows, cols)) < dens).astype(np.uint8) * rng.integers(lo, 256, (rows, cols)).astype(np.uint8)
+
+
+def make_frames(rows, cols, leds):
+    out, kinds = [], []
+
+    def add(kind, f):
+        out.append(np.ascontiguousarray(f, np.uint8))
+        kinds.append(kind)
+
+    for dens in 10.0 ** rng.uniform(-4, -2.2, 6):
+        add("salt %.5f" % dens, noise(rows, cols, dens))
+    f = np.zeros((rows, cols), np.uint8)
+    period, h = int(rng.integers(9, 30)), int(rng.integers(2, 8))
+    for y0 in range(int(rng.integers(0, period)), rows, period):
+        f[y0:y0 + h] = noise(min(h, rows - y0), cols, 10.0 ** rng.uniform(-3, -2))
+    add("stripes", f)
+    f = noise(rows, cols, 10.0 ** rng.uniform(-3.5, -2.8), lo=255)
+    x0 = int(rng.integers(5, cols - 12))
+    f[int(rng.integers(0, 20)):rows - int(rng.integers(0, 20)), x0:x0 + int(rng.integers(2, 7))] = int(rng.integers(160, 256))
+    add("tall bar", f)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    f = noise(rows, cols, 10.0 ** rng.uniform(-3.5, -3), lo=255)
+    rad = min(rows, cols) / rng.uniform(2.5, 5)
+    ring = np.abs(np.hypot(xx - cols * rng.uniform(0.3, 0.7), yy - rows * rng.uniform(0.3, 0.7)) - rad) < rng.uniform(1.5, 3.5)
+    f[ring] = 240
+    add("ring", f)
+    f = noise(rows, cols, 10.0 ** rng.uniform(-4, -3))
+    ph, pw = int(rng.integers(8, min(90, rows - 2))), int(rng.integers(8, min(90, cols - 2)))
+    py, px = int(rng.integers(0, rows - ph)), int(rng.integers(0, cols - pw))
+    f[py:py + ph, px:px + pw] = 255
+    add("patch %dx%d" % (ph, pw), f)
+    f = np.clip((xx * rng.uniform(0.2, 0.5) + yy * rng.uniform(0.0, 0.3)), 0, 255).astype(np.uint8)  # glare: a ramp crossing the threshold
+    add("ramp", np.maximum(f, noise(rows, cols, 0.0005)))
+    g = int(rng.integers(9, 21))
+    f = np.zeros((rows, cols), np.uint8)
+    f[g // 2::g, g // 2::g] = 255
+    f[g // 2 + 1::g, g // 2::g] = 255
+    f[g // 2::g, g // 2 + 1::g] = 255
+    add("dot grid %d" % g, f)
+    if leds is not None:
+        for i in range(len(leds)):
+            add("leds + salt", np.maximum(leds[i], noise(rows, cols, 10.0 ** rng.uniform(-4, -2.8), lo=255)))
+    return np.ascontiguousarray(np.stack(out)), kinds
+
+
+h = mpe.Handle(0)
+t0 = time.time()
+frames_compared = detections_compared = overflow_frames = 0
+bad = []
+by_kind = {}
+for rnd in range(ROUNDS):
+    for rows, cols in ((480, 752), (123, 211), (600, 960)):
+        K, D = synth.camera_for(rows, cols)
+        leds = synth.make_frames("C2", 3, seed=9000 + rnd)["frames"] if (rows, cols) == (480, 752) else None
+        frames, kinds = make_frames(rows, cols, leds)
+        Po, Ph = orc.make_params(), mpe.demo_params()
+        thr = int(rng.choice([60, 100, 140, 200]))
+        sigma = float(rng.choice([0.6, 0.6, 0.6, 0.8, 1.0, 1.5]))  # (at 0.6 an isolated pixel blurs to 9 pixels: below the minimum area)
+        for P in (Po, Ph):
+            P.threshold_value = thr
+            P.gaussian_sigma = sigma
+        got = h.detect_batch(frames, K, D, Ph)
+        for i in range(len(frames)):
+            und, dist = orc.find_leds(frames[i], Po, K, D)
+            n = len(und)
+            ok = True
+            if n > mpe.MAX_DETECTIONS:
+                overflow_frames += 1
+                ok = got["status"][i] == -10 and got["n"][i] == mpe.MAX_DETECTIONS
+                # beyond the 512 blobs the general tier keeps, the record's subset is unspecified (include/mpe.h): compare
+                # the first MAX_DETECTIONS only while the oracle's count stays below that
+                if ok and n <= 512:
+                    und, dist = und[:mpe.MAX_DETECTIONS], dist[:mpe.MAX_DETECTIONS]
+                    n = mpe.MAX_DETECTIONS
+                elif ok:
+                    n = 0
+            else:
+                ok = got["status"][i] == 0 and got["n"][i] == n
+            if ok and n:
+                ok = np.array_equal(got["dist_xy"][i][:2 * n].reshape(-1, 2), dist) and \
+                    np.array_equal(got["undist_xy"][i][:2 * n].reshape(-1, 2), und)
+            frames_compared += 1
+            detections_compared += n
+            k0 = kinds[i].split(" ")[0]
+            by_kind[k0] = by_kind.get(k0, 0) + 1
+            if not ok:
+                bad.append(dict(round=rnd, rows=rows, cols=cols, kind=kinds[i], thr=thr, sigma=sigma, frame=i,
+                                hip_n=int(got["n"][i]), hip_status=int(got["status"][i]), oracle_n=int(len(und))))
+                np.save("%s_bad_%d.npy" % (OUT, len(bad)), frames[i])
+summary = dict(what=__doc__.split("\n")[0], rounds=ROUNDS, frames_compared=frames_compared,
+               detections_compared_bit_for_bit=detections_compared, frames_beyond_the_detection_capacity=overflow_frames,
+               frames_by_kind=by_kind, differing_frames=len(bad), differing=bad[:20], seconds=round(time.time() - t0, 1),
+               source_fingerprint=mpe.source_fingerprint())
+os.makedirs(os.path.dirname(OUT) or ".", exist_ok=True)
+json.dump(summary, open(OUT + ".json", "w"), indent=1)
+print(json.dumps(summary)[:1500])
+sys.exit(1 if bad else 0)
