@@ -196,7 +196,7 @@ def main():
                                                          F + "pmc%s_fetch_summary.csv" % cfg, F + "pmc%s_write_summary.csv" % cfg,
                                                          rf, RN + "pmc_%s_*.csv" % cfg, DIMS[cfg])}
     json.dump(out, open(P + "pmc.json", "w"), indent=1)
-    for n in ("soak_votes_arith_C2", "soak_votes_arith_C3"):
+    for n in ("soak_votes_arith_C2", "soak_votes_arith_C3", "soak_general_tier"):
         if os.path.exists(F + n + ".json"):
             shutil.copy(F + n + ".json", P + "parity_%s.json" % n)
     for n in ("soak_votes_C2", "soak_34_C2", "soak_34_C3", "soak_34_d16", "soak_34_d4", "soak_parity_C2", "soak_parity_C3", "soak_parity_C4", "soak_parity_C1", "soak_tracking"):

@@ -91,7 +91,7 @@ for rnd in range(ROUNDS):
             P.gaussian_sigma = sigma
         got = h.detect_batch(frames, K, D, Ph)
         for i in range(len(frames)):
-            und, dist = orc.find_leds(frames[i], Po, K, D)
+            und, dist = orc.find_leds(frames[i], Po, K, D, cap=65536)
             n = len(und)
             ok = True
             if n > mpe.MAX_DETECTIONS:
