@@ -228,7 +228,7 @@ __device__ __forceinline__ void k1b_gen_narrow(const uint8_t* frame, int pitch, 
 #ifndef K1B_GEN_RUNS
 #define K1B_GEN_RUNS 736    // (band, column run) items of a frame and their pieces (5.75 KB of LDS); more: one lane per band as in round 5
 #endif
-#define K1B_GEN_RUN_WORDS 16  // widest bitmap row (64-bit words) whose column occupancy a lane holds in registers
+#define K1B_GEN_RUN_WORDS 16  // (window_column_runs<MAXW>: the lane-per-band form of the column occupancy, CPU-tier test only)
 
 __host__ __device__ inline size_t k1b_gen_scratch_bytes(const FrameGeom& g) {
   const size_t bm = (size_t)(g.rows + 2) * g.wb * 8;
@@ -260,9 +260,10 @@ __global__ __launch_bounds__(64, K1B_GEN_OCC) void k1b_general(const uint8_t* __
   const FrameGeom& g = gslot;  // slab layout and flag indexing: the slot; rows / cols of a frame: its window (gl below)
   __shared__ int s_nkept, s_over, s_nband, s_nrun;
   __shared__ int s_taps[MPE_MAX_KSIZE];
-  __shared__ u64 s_rowact[64], s_link[64];
-  static_assert(4 * K1B_GEN_RUN_WORDS <= 64, "s_cor lives in s_rowact");
-  u64(*s_cor)[K1B_GEN_RUN_WORDS] = reinterpret_cast<u64(*)[K1B_GEN_RUN_WORDS]>(s_rowact);  // (the row bitsets are dead by then)
+  __shared__ u64 s_rows[128];
+  u64* const s_rowact = s_rows;     // rows that hold a pixel / that touch the row above: bit y of 64 words each
+  u64* const s_link = s_rows + 64;
+  u64* const s_cor = s_rows;        // later (the row bitsets are dead by then): the occupied columns of 2 - 4 bands
   __shared__ short s_blo[K1B_GEN_BANDS], s_bhi[K1B_GEN_BANDS];
   __shared__ short s_rlo[K1B_GEN_RUNS], s_rh[K1B_GEN_RUNS], s_rx0[K1B_GEN_RUNS], s_rx1[K1B_GEN_RUNS];
   const int lane = threadIdx.x;
@@ -464,100 +465,126 @@ __global__ __launch_bounds__(64, K1B_GEN_OCC) void k1b_general(const uint8_t* __
     // Round 6: a band is cut again at its EMPTY COLUMNS — (band, run of occupied pixel columns) items, one lane each
     // (scan_window<true>).  One lane per band left 35 of 64 lanes busy on a salt-noise frame (~180 blobs) and the
     // longest band set the time: 47 % of the frame's cycles, every step a dependent read of the bitmaps.
-    bool by_runs = false;
-    if (nband <= K1B_GEN_BANDS && g.wb <= K1B_GEN_RUN_WORDS) {
-      // the column occupancy of a band by the WHOLE wave, four bands in flight: lane 16 j + w ORs word w of the band's
-      // rows j, j + 4, ... (consecutive lanes consecutive words: a lane per band read its rows x words one scattered
-      // load after the other, the tallest band setting the time — 1 200 of the frame's 4 000 memory instructions);
-      // then lanes 0 .. 3 cut their band's sixteen words into runs (window_column_runs' second half).
-      // (the runs are cut again at their empty rows below, a lane per RUN: done by the band's one lane — a dependent
-      //  read per row and run — it cost more than it saved: scan phase 0.8 -> 1.2 - 2.1 M cycles)
-      const int cw = lane & 15, cj = lane >> 4;
-      for (int b0 = 0; b0 < nband; b0 += 4) {  // (uniform)
-        int blo[4], bh[4], hmax = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int b = b0 + u;
-          blo[u] = b < nband ? s_blo[b] : 0;
-          bh[u] = b < nband ? s_bhi[b] - blo[u] + 1 : 0;
-          hmax = max(hmax, bh[u]);
-        }
-        u64 acc[4] = {0, 0, 0, 0};
-        if (cw < g.wb)
-          for (int kk = cj; kk < hmax; kk += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              if (kk < bh[u]) acc[u] |= nz[(size_t)(blo[u] + 1 + kk) * g.wb + cw];
-          }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          acc[u] |= __shfl_xor(acc[u], 16);
-          acc[u] |= __shfl_xor(acc[u], 32);
-          if (lane < 16) s_cor[u][lane] = acc[u];
-        }
-        __syncthreads();
-        if (lane < 4 && b0 + lane < nband) {
-          const int lo = s_blo[b0 + lane], H = s_bhi[b0 + lane] - lo + 1;
-          column_runs_of_words(s_cor[lane], g.wb, [&](int x0, int x1) {
-            const int i = atomicAdd(&s_nrun, 1);
-            if (i < K1B_GEN_RUNS) {
-              s_rlo[i] = (short)lo;
-              s_rh[i] = (short)H;
-              s_rx0[i] = (short)x0;
-              s_rx1[i] = (short)x1;
-            }
-          });
-        }
-        __syncthreads();
-      }
-      by_runs = s_nrun <= K1B_GEN_RUNS;  // (uniform)
-    }
-    // ... and every run again at the rows that are EMPTY within its columns (window_run_rows; a lane per run): the
-    // band's rows chain through OTHER runs — salt pixels three rows tall hang together over sixty rows — so a run holds
-    // several blobs one above the other, and the longest such stack set the time of a round of 64 items (~250 k cycles).
-    // The pieces are appended behind the runs (same lists); if they do not fit, the runs themselves are scanned.
-    int item0 = 0, item1 = by_runs ? s_nrun : 0;  // (uniform) the items the scan below works on: [item0, item1)
-    if (by_runs) {
-      const int nrun = s_nrun;
-      __syncthreads();
-      for (int i0 = 0; i0 < nrun; i0 += 64) {
-        const int i = i0 + lane;
-        if (i < nrun) {
-          const int lo = s_rlo[i], H = s_rh[i], x0 = s_rx0[i], x1 = s_rx1[i];
-          window_run_rows(nz + (size_t)lo * g.wb, g.wb, H, x0, x1, [&](int first, int nrows) {
-            const int j = atomicAdd(&s_nrun, 1);
-            if (j < K1B_GEN_RUNS) {
-              s_rlo[j] = (short)(lo + first - 1);
-              s_rh[j] = (short)nrows;
-              s_rx0[j] = (short)x0;
-              s_rx1[j] = (short)x1;
-            }
-          });
-        }
-      }
-      __syncthreads();
-      if (s_nrun <= K1B_GEN_RUNS) {  // (uniform)
-        item0 = nrun;
-        item1 = s_nrun;
-      } else {
-        item1 = nrun;
-      }
-    }
 #ifdef K1B_GEN_CLOCKS
-    const unsigned long long gclk_runs = __builtin_amdgcn_s_memtime();
+    unsigned long long gclk_build = 0, gclk_t = 0;
+    int gclk_items = 0;
 #endif
-    if (by_runs) {
-      for (int i0 = item0; i0 < item1; i0 += 64) {  // (uniform: every lane enters scan_window, with H = 0 if it has no item)
-        const int i = i0 + lane;
-        const int lo = i < item1 ? s_rlo[i] : 0, H = i < item1 ? s_rh[i] : 0;
-        const size_t off = (size_t)lo * g.wb;
-        scan_window<true>(nz + off, pm + off, ng + off, g.wb, H, lo, 0, dp, roi_x, roi_y, &s_over, keep,
-                          i < item1 ? s_rx0[i] : 0, i < item1 ? s_rx1[i] : 0);
+    if (nband <= K1B_GEN_BANDS && g.wb <= 64) {
+      // The bands are taken in BATCHES: runs are built until the list is half full (the pieces are appended behind them),
+      // cut, scanned, and the list starts again — items are independent and the kept blobs are put into raster order at
+      // the end, so a frame has as many items as it needs (a 1920-wide frame with 0.05 % noise: ~1 100; one list held
+      // 736 and a frame beyond that fell back to a lane per band after building its runs for nothing).
+      const int lw = g.wb <= 16 ? 4 : (g.wb <= 32 ? 5 : 6);  // (uniform) log2 of the lanes per bitmap row
+      const int cw = lane & ((1 << lw) - 1), cj = lane >> lw, rg = 64 >> lw;
+      const int nb = lw == 4 ? 4 : 2;  // bands in flight: their words share the 128 words of the row bitsets
+      int b_next = 0;
+      while (b_next < nband) {  // (uniform)
+#ifdef K1B_GEN_CLOCKS
+        gclk_t = __builtin_amdgcn_s_memtime();
+#endif
+        const int b_first = b_next;
+        if (lane == 0) s_nrun = 0;
+        __syncthreads();
+        // the column occupancy of a band by the WHOLE wave, four bands in flight (two if a bitmap row has more than 16
+        // words): with 16 / 32 / 64 lanes per row, lane (j, w) ORs word w of the band's rows j, j + 4 / 2 / 1, ...
+        // (consecutive lanes consecutive words: a lane per band read its rows x words one scattered load after the
+        // other, the tallest band setting the time — 1 200 of the frame's 4 000 memory instructions); then lanes 0 .. 3
+        // cut their band's words into runs (column_runs_of_words).
+        while (b_next < nband) {
+          const int b0 = b_next;
+          int blo[4], bh[4], hmax = 0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int b = b0 + u;
+            const bool on = u < nb && b < nband;
+            blo[u] = on ? s_blo[b] : 0;
+            bh[u] = on ? s_bhi[b] - blo[u] + 1 : 0;
+            hmax = max(hmax, bh[u]);
+          }
+          u64 acc[4] = {0, 0, 0, 0};
+          if (cw < g.wb)
+            for (int kk = cj; kk < hmax; kk += rg) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (kk < bh[u]) acc[u] |= nz[(size_t)(blo[u] + 1 + kk) * g.wb + cw];
+            }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (lw <= 4) acc[u] |= __shfl_xor(acc[u], 16);
+            if (lw <= 5) acc[u] |= __shfl_xor(acc[u], 32);
+            if (u < nb && lane < (1 << lw)) s_cor[(u << lw) + lane] = acc[u];
+          }
+          __syncthreads();
+          if (lane < nb && b0 + lane < nband) {
+            const int lo = s_blo[b0 + lane], H = s_bhi[b0 + lane] - lo + 1;
+            column_runs_of_words(s_cor + (lane << lw), g.wb, [&](int x0, int x1) {
+              const int i = atomicAdd(&s_nrun, 1);
+              if (i < K1B_GEN_RUNS) {
+                s_rlo[i] = (short)lo;
+                s_rh[i] = (short)H;
+                s_rx0[i] = (short)x0;
+                s_rx1[i] = (short)x1;
+              }
+            });
+          }
+          __syncthreads();
+          b_next += nb;
+          if (s_nrun > K1B_GEN_RUNS * 3 / 8) break;  // (uniform) room for as many pieces again, and for the next bands' runs
+        }
+        const int nrun = s_nrun;  // (uniform)
+        if (nrun > K1B_GEN_RUNS) {
+          // (the batch's last bands alone overflowed the list — more than ~460 runs in four bands: a lane per band for
+          //  this batch, the round-5 way; slot 0 of a band's window is the row above it — empty, or holding no neighbour
+          //  of any pixel of the band — and the row below likewise: no border following leaves the band)
+          const int b_end = min(b_next, nband);
+          for (int c0 = b_first; c0 < b_end; c0 += 64) {  // (uniform: every lane enters scan_window, with H = 0 if it has no band)
+            const int bb = c0 + lane;
+            const int lo = bb < b_end ? s_blo[bb] : 0, H = bb < b_end ? s_bhi[bb] - lo + 1 : 0;
+            const size_t off = (size_t)lo * g.wb;
+            scan_window(nz + off, pm + off, ng + off, g.wb, H, lo, 0, dp, roi_x, roi_y, &s_over, keep);
+          }
+          __syncthreads();
+          continue;
+        }
+        // ... and every run again at the rows that are EMPTY within its columns (window_run_rows; a lane per run): the
+        // band's rows chain through OTHER runs — salt pixels three rows tall hang together over sixty rows — so a run
+        // holds several blobs one above the other, and the longest such stack set the time of a round of 64 items
+        // (~250 k cycles).  The pieces are appended behind the runs; if they do not fit, the runs themselves are scanned.
+        // (done in the pass above by the band's one lane — a dependent read per row and run — the cut cost more than it
+        //  saved: scan phase 0.8 -> 1.2 - 2.1 M cycles)
+        for (int i0 = 0; i0 < nrun; i0 += 64) {
+          const int i = i0 + lane;
+          if (i < nrun) {
+            const int lo = s_rlo[i], H = s_rh[i], x0 = s_rx0[i], x1 = s_rx1[i];
+            window_run_rows(nz + (size_t)lo * g.wb, g.wb, H, x0, x1, [&](int first, int nrows) {
+              const int j = atomicAdd(&s_nrun, 1);
+              if (j < K1B_GEN_RUNS) {
+                s_rlo[j] = (short)(lo + first - 1);
+                s_rh[j] = (short)nrows;
+                s_rx0[j] = (short)x0;
+                s_rx1[j] = (short)x1;
+              }
+            });
+          }
+        }
+        __syncthreads();
+        const bool cut = s_nrun <= K1B_GEN_RUNS;                       // (uniform)
+        const int item0 = cut ? nrun : 0, item1 = cut ? s_nrun : nrun;  // the items of this batch: [item0, item1)
+#ifdef K1B_GEN_CLOCKS
+        gclk_build += __builtin_amdgcn_s_memtime() - gclk_t;
+        gclk_items += item1 - item0;
+#endif
+        for (int i0 = item0; i0 < item1; i0 += 64) {  // (uniform: every lane enters scan_window, with H = 0 if it has no item)
+          const int i = i0 + lane;
+          const int lo = i < item1 ? s_rlo[i] : 0, H = i < item1 ? s_rh[i] : 0;
+          const size_t off = (size_t)lo * g.wb;
+          scan_window<true>(nz + off, pm + off, ng + off, g.wb, H, lo, 0, dp, roi_x, roi_y, &s_over, keep,
+                            i < item1 ? s_rx0[i] : 0, i < item1 ? s_rx1[i] : 0);
+        }
+        __syncthreads();
       }
     } else if (nband <= K1B_GEN_BANDS) {
-      // one lane per band, the lanes' border followings in lock step (scan_window): slot 0 of a band's window is the
-      // row above it — empty, or holding no neighbour of any pixel of the band — slots 1 .. H its rows, and the row
-      // below likewise: no border following leaves the band
+      // (bitmap rows of more than 64 words — frames wider than 3 966 pixels: one lane per band)
       for (int b0 = 0; b0 < nband; b0 += 64) {  // (uniform: every lane enters scan_window, with H = 0 if it has no band)
         const int b = b0 + lane;
         const int lo = b < nband ? s_blo[b] : 0, H = b < nband ? s_bhi[b] - lo + 1 : 0;
@@ -577,7 +604,7 @@ __global__ __launch_bounds__(64, K1B_GEN_OCC) void k1b_general(const uint8_t* __
     if (blockIdx.x == 0 && lane == 0 && wi == 0)
       printf("k1b_general phases (cycles): clear %llu todo %llu items %llu (n=%d) blur %llu rows %llu bands %llu (n=%d) runs %llu (n=%d) scan %llu write %llu\n",
              gclk[1] - gclk[0], gclk[2] - gclk[1], gclk[3] - gclk[2], n_items, gclk[4] - gclk[3], gclk[5] - gclk[4],
-             gclk[6] - gclk[5], nband, gclk_runs - gclk[6], item1 - item0, gclk[7] - gclk_runs, gclk[8] - gclk[7]);
+             gclk[6] - gclk[5], nband, gclk_build, gclk_items, gclk[7] - gclk[6] - gclk_build, gclk[8] - gclk[7]);
 #endif
   }
 }
@@ -875,7 +902,8 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
     if (e != hipSuccess) return e;
     resident = (per_cu > 0 ? per_cu : 1) * device_cu_count();
   }
-  if (!getenv("MPE_K1B_GEN_FULL_GRID") && gen_blocks > (size_t)resident) gen_blocks = (size_t)resident;
+  static const bool full_grid = getenv("MPE_K1B_GEN_FULL_GRID") != nullptr;  // (A/B of the cap: round6_exp_general_tier.txt 8)
+  if (!full_grid && gen_blocks > (size_t)resident) gen_blocks = (size_t)resident;
   hipLaunchKernelGGL(k1b_general, dim3((unsigned)gen_blocks), dim3(64), 0, s, frames, (const u64*)flags, g, dp, dets,
                      (const int*)list_b, scratch, wins);
   return hipGetLastError();

@@ -321,7 +321,7 @@ extern "C" int host_runs_vs_whole(const uint8_t* mask, int rows, int cols, const
   dp.max_wh = shape[2];
   dp.max_circ = shape[3];
   const int wb = (cols + 2 + 63) / 64 + 1;
-  if (wb > 16) return -2;
+  if (wb > 64) return -2;  // (the kernel's limit: 64 lanes hold a bitmap row's words)
   std::vector<u64> nz((size_t)(rows + 2) * wb + 1, 0), pm(nz.size(), 0), ng(nz.size(), 0);
   std::vector<int> active(rows, 0), linked(rows, 0);
   for (int y = 0; y < rows; ++y)
@@ -359,14 +359,16 @@ extern "C" int host_runs_vs_whole(const uint8_t* mask, int rows, int cols, const
     while (hi + 1 < rows && active[hi + 1] && linked[hi + 1]) ++hi;
     const size_t off = (size_t)y * wb;
     std::vector<std::pair<int, int>> runs;
-    window_column_runs<16>(nz.data() + off, wb, hi - y + 1, [&](int x0, int x1) { runs.push_back({x0, x1}); });
-    {  // the kernel's way since the wave ORs a band's rows together: the rows' OR first, then column_runs_of_words
+    {  // the kernel's way (the wave ORs a band's rows together): the rows' OR first, then column_runs_of_words
       std::vector<u64> occ(wb, 0);
       for (int r = 1; r <= hi - y + 1; ++r)
         for (int w = 0; w < wb; ++w) occ[w] |= nz[off + (size_t)r * wb + w];
-      std::vector<std::pair<int, int>> runs2;
-      column_runs_of_words(occ.data(), wb, [&](int x0, int x1) { runs2.push_back({x0, x1}); });
-      if (runs2 != runs) return -1;
+      column_runs_of_words(occ.data(), wb, [&](int x0, int x1) { runs.push_back({x0, x1}); });
+      if (wb <= 16) {  // ... and the lane-per-band form with the words in registers: the same runs
+        std::vector<std::pair<int, int>> runs2;
+        window_column_runs<16>(nz.data() + off, wb, hi - y + 1, [&](int x0, int x1) { runs2.push_back({x0, x1}); });
+        if (runs2 != runs) return -1;
+      }
     }
     // the runs in REVERSE order: the items of a band run on different lanes at once — no order may matter
     for (size_t k = runs.size(); k-- > 0;) {

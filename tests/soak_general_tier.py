@@ -1,6 +1,6 @@
 """General-blob-tier parity soak (led_detector.cpp:35-112): randomly generated frames that the LDS
 tiers cannot hold — salt noise of many densities, stripes of noise, tall bars, rings with blobs inside, saturated patches,
-glare gradients, LEDs on top of noise — at three frame sizes (one with pitch != cols), several thresholds and blur
+glare gradients, LEDs on top of noise — at four frame sizes (bitmap rows of 5, 13, 17 and 32 words; one with pitch != cols), several thresholds and blur
 widths, through mpe_detect_batch (k1b_blobs -> k1b_blobs_list -> k1b_general: bands, column runs, row pieces) and,
 frame by frame, through the oracle's findLeds.  Compared: status (-10 beyond the detection capacity), the number of
 detections, the distorted centres bit for bit (float32), the undistorted points bit for bit (float64 of float32).
@@ -79,7 +79,7 @@ frames_compared = detections_compared = overflow_frames = 0
 bad = []
 by_kind = {}
 for rnd in range(ROUNDS):
-    for rows, cols in ((480, 752), (123, 211), (600, 960)):
+    for rows, cols in ((480, 752), (123, 211), (600, 960)) + (((1200, 1920),) if rnd % 8 == 3 else ()):
         K, D = synth.camera_for(rows, cols)
         leds = synth.make_frames("C2", 3, seed=9000 + rnd)["frames"] if (rows, cols) == (480, 752) else None
         frames, kinds = make_frames(rows, cols, leds)

@@ -331,6 +331,8 @@ def test_column_run_scans_equal_the_whole_frame_scan(host):
         kind = it % 6
         rows = int(rng.integers(3, 70))
         cols = int(rng.choice([rng.integers(3, 60), 61, 62, 63, 64, 65, 126, 127, 128, 129, rng.integers(66, 400)]))
+        if it % 25 == 7:  # bitmap rows of 17 .. 64 words (a wave holds a row's words on 32 / 64 lanes)
+            cols = int(rng.choice([957, 958, 959, 1022, 1920, 1983, rng.integers(960, 3900), 3966]))
         yy, xx = np.mgrid[0:rows, 0:cols]
         if kind == 0:
             m = rng.random((rows, cols)) < rng.choice([0.002, 0.01, 0.03])

@@ -1,13 +1,13 @@
 """Latency of ONE cluttered frame in the blob tiers (the general tier's worst cases): the noise frames of
 tests/test_gpu_parity.py::test_general_tier_band_scan_on_random_clutter, each detected alone and as 256 copies.
-  MPE_LIB=<libmpe_hip.so> [MPE_MAX_DET=32 for a round-5 library] python tools/dense_frame_probe.py"""
+  MPE_LIB=<libmpe_hip.so> [MPE_MAX_DET=32 for a round-5 library] python tools/dense_frame_probe.py [rows cols]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 import rpg_monocular_pose_estimator_amd as mpe
 from rpg_monocular_pose_estimator_amd import synth
 
-rows, cols = 480, 752
+rows, cols = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (480, 752)
 rng = np.random.default_rng(77)
 K, D = synth.camera_for(rows, cols)
 h = mpe.Handle(0)
