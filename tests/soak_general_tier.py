@@ -67,6 +67,12 @@ def make_frames(rows, cols, leds):
     f[g // 2 + 1::g, g // 2::g] = 255
     f[g // 2::g, g // 2 + 1::g] = 255
     add("dot grid %d" % g, f)
+    gy, gx = int(rng.integers(3, 7)), int(rng.integers(3, 6))  # a fine grid: hundreds of column runs per band (batches; the
+    f = np.zeros((rows, cols), np.uint8)                       # run list overflowing in one step: a lane per band for those)
+    f[1::gy, 1::gx] = 255
+    if rng.random() < 0.5:
+        f[2::gy, 1::gx] = 255
+    add("fine grid %dx%d" % (gy, gx), f)
     if leds is not None:
         for i in range(len(leds)):
             add("leds + salt", np.maximum(leds[i], noise(rows, cols, 10.0 ** rng.uniform(-4, -2.8), lo=255)))

@@ -186,6 +186,16 @@ def test_general_tier_band_scan_on_random_clutter(hip, orc, general_tier):
             for i in range(2):
                 f = np.maximum(leds[i], (rng.random((rows, cols)) < 0.0005).astype(np.uint8) * 255)
                 frames.append(f)
+        # a grid of single pixels every fourth row and column: ~188 column runs per three-row band — four bands overflow the
+        # kernel's run list in ONE step (those bands are then scanned a lane per band), and the frame needs many batches
+        f = np.zeros((rows, cols), np.uint8)
+        f[1::4, 1::4] = 255
+        frames.append(f)
+        f = np.zeros((rows, cols), np.uint8)                      # ... and pairs of pixels: blobs that pass the area filter
+        f[2::6, 2::5] = 255
+        f[3::6, 2::5] = 255
+        f[2::6, 3::5] = 255
+        frames.append(f)
         frames = np.ascontiguousarray(np.stack(frames))
         for thr in (140, 60):
             Po.threshold_value = thr
