@@ -265,7 +265,11 @@ __global__ __launch_bounds__(64, K1B_GEN_OCC) void k1b_general(const uint8_t* __
   u64* const s_link = s_rows + 64;
   u64* const s_cor = s_rows;        // later (the row bitsets are dead by then): the occupied columns of 2 - 4 bands
   __shared__ short s_blo[K1B_GEN_BANDS], s_bhi[K1B_GEN_BANDS];
-  __shared__ short s_rlo[K1B_GEN_RUNS], s_rh[K1B_GEN_RUNS], s_rx0[K1B_GEN_RUNS], s_rx1[K1B_GEN_RUNS];
+  __shared__ __attribute__((aligned(8))) short s_run4[4 * K1B_GEN_RUNS];  // the items: first row, rows, first / last bit column
+  short* const s_rlo = s_run4;
+  short* const s_rh = s_run4 + K1B_GEN_RUNS;
+  short* const s_rx0 = s_run4 + 2 * K1B_GEN_RUNS;
+  short* const s_rx1 = s_run4 + 3 * K1B_GEN_RUNS;
   const int lane = threadIdx.x;
   const int count = worklist[0];
   if ((int)blockIdx.x >= count) return;  // (the usual launch: nothing was handed over)
@@ -322,20 +326,52 @@ __global__ __launch_bounds__(64, K1B_GEN_OCC) void k1b_general(const uint8_t* __
       const int nwin = (g.segs_per_frame + 63) >> 6;
       const size_t w0 = G0 >> 6;
       const int sh = (int)(G0 & 63);
-      for (int i = lane; i < nwin; i += 64) {
+      auto flag_word = [&](int i) -> u64 {  // the frame's flag bits 64 i .. 64 i + 63
+        if (i >= nwin) return 0;
         const u64 a = flags[w0 + i], b = flags[w0 + i + 1];
         u64 v = sh ? ((a >> sh) | (b << (64 - sh))) : a;
         const int rem = g.segs_per_frame - i * 64;
         if (rem < 64) v &= (1ull << rem) - 1;
-        while (v) {
-          const int s = i * 64 + __builtin_ctzll(v);
-          v &= v - 1;
-          const int y0 = s / spr, c0 = s - y0 * spr;
-          int cl = max(0, c0 - dc), ch = min(spr - 1, c0 + dc);
-          k1b_gen_narrow(frame, g.pitch, gl.cols, y0, c0, r, dc, add, cl, ch);
-          for (int yy = max(0, y0 - r); yy <= min(gl.rows - 1, y0 + r); ++yy)
-            for (int cc = cl; cc <= ch; ++cc)
-              atomicOr(&todo[(size_t)yy * g.tw + (cc >> 6)], 1ull << (cc & 63));
+        return v;
+      };
+      auto mark = [&](int s) {
+        const int y0 = s / spr, c0 = s - y0 * spr;
+        int cl = max(0, c0 - dc), ch = min(spr - 1, c0 + dc);
+        k1b_gen_narrow(frame, g.pitch, gl.cols, y0, c0, r, dc, add, cl, ch);
+        for (int yy = max(0, y0 - r); yy <= min(gl.rows - 1, y0 + r); ++yy)
+          for (int cc = cl; cc <= ch; ++cc)
+            atomicOr(&todo[(size_t)yy * g.tw + (cc >> 6)], 1ull << (cc & 63));
+      };
+      // the bright segments as a LIST first (in the run lists' LDS, unused until the bands exist), then a lane per segment:
+      // a lane per flag word walked its bits one dependent pixel read (k1b_gen_narrow) after the other — three of them in
+      // the busiest of every 64 words of a salt frame, six rounds of words: ~18 round trips to cold pixels where the list
+      // needs three.  Four flag words in flight per lane.
+      unsigned* const s_seg = reinterpret_cast<unsigned*>(s_run4);
+      const int seg_cap = 2 * K1B_GEN_RUNS;
+      for (int i0 = 0; i0 < nwin; i0 += 256) {
+        u64 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = flag_word(i0 + 64 * u + lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          while (v[u]) {
+            const int s = (i0 + 64 * u + lane) * 64 + __builtin_ctzll(v[u]);
+            v[u] &= v[u] - 1;
+            const int at = atomicAdd(&s_nrun, 1);
+            if (at < seg_cap) s_seg[at] = (unsigned)s;
+          }
+      }
+      __syncthreads();
+      const int nseg = s_nrun;  // (uniform)
+      if (nseg <= seg_cap) {
+        for (int i = lane; i < nseg; i += 64) mark((int)s_seg[i]);
+      } else {  // (more bright segments than the list holds: a lane per flag word)
+        for (int i = lane; i < nwin; i += 64) {
+          u64 v = flag_word(i);
+          while (v) {
+            mark(i * 64 + __builtin_ctzll(v));
+            v &= v - 1;
+          }
         }
       }
     }
