@@ -92,8 +92,8 @@ typedef struct mpe_result {
 typedef struct mpe_detections {
   int n;      /* min(number of detections, MPE_MAX_DETECTIONS) */
   int status; /* 0 or MPE_FRAME_TOO_MANY_* */
-  double undist_xy[2 * MPE_MAX_DETECTIONS]; /* pixel_positions of findLeds (LED.h:84-88) */
-  float dist_xy[2 * MPE_MAX_DETECTIONS];    /* distorted_detection_centers */
+  double undist_xy[2 * MPE_MAX_DETECTIONS]; /* pixel_positions of findLeds (LED.h:84-88); entries 2 n .. are unspecified */
+  float dist_xy[2 * MPE_MAX_DETECTIONS];    /* distorted_detection_centers; entries 2 n .. are unspecified */
 } mpe_detections;
 
 /* fills *p with the parameter set of launch/demo.launch:12-22 */

@@ -1884,6 +1884,61 @@ def test_general_tier_kernel_follows_what_the_last_call_saw(orc):
 
 
 @pytest.mark.gpu
+def test_general_tier_block_walks_many_frames(orc):
+    """A block of k1b_general strides the work-list by the grid and reuses its slab (bitmaps, to-do bits, item list) frame
+    after frame.  With the slabs capped at 32 (option "k1b_general_blocks", process-wide) 330 DIFFERENT noisy frames make
+    every block take ten or eleven of them one after the other, sparse after dense and the other way round; every frame's
+    record equals the oracle's — nothing of a frame survives in the slab or in a cache line of it."""
+    rng = np.random.default_rng(4242)
+    rows, cols = 480, 752
+    K, D = synth.camera_for(rows, cols)
+    leds = synth.make_frames("C2", 30, seed=4243)["frames"]
+    frames = []
+    for i in range(330):
+        dens = 10.0 ** rng.uniform(-4.0, -2.6)
+        f = (rng.random((rows, cols)) < dens).astype(np.uint8) * rng.integers(150, 256, (rows, cols)).astype(np.uint8)
+        if i % 11 == 0:
+            f = np.maximum(f, leds[i // 11])
+        if i % 7 == 3:
+            f[int(rng.integers(0, rows - 70)):, int(rng.integers(0, cols - 8)):][:60, :6] = 230  # a tall bar
+        frames.append(f)
+    frames = np.ascontiguousarray(np.stack(frames))
+    Po, Ph = orc.make_params(), mpe.demo_params()
+    h0 = mpe.Handle()
+    old = h0.get_option("k1b_general_blocks")
+    h0.set_option("k1b_general_blocks", 32)
+    try:
+        h = mpe.Handle()
+        try:
+            got = h.detect_batch(frames, K, D, Ph)
+            again = h.detect_batch(frames[::-1].copy(), K, D, Ph)
+        finally:
+            h.close()
+    finally:
+        h0.set_option("k1b_general_blocks", old)
+        h0.close()
+    again = again[::-1]   # whatever order the blocks met them in (entries behind a record's n are unspecified)
+    assert np.array_equal(got["n"], again["n"]) and np.array_equal(got["status"], again["status"])
+    for i in range(len(frames)):
+        k = 2 * int(got["n"][i])
+        assert np.array_equal(got["dist_xy"][i][:k], again["dist_xy"][i][:k]), i
+        assert np.array_equal(got["undist_xy"][i][:k], again["undist_xy"][i][:k]), i
+    n_gen = 0
+    for i in range(len(frames)):
+        und, dist = orc.find_leds(frames[i], Po, K, D, cap=65536)
+        n = len(und)
+        if n > mpe.MAX_DETECTIONS:
+            assert got["status"][i] == -10 and got["n"][i] == mpe.MAX_DETECTIONS, i
+            und, dist, n = und[:mpe.MAX_DETECTIONS], dist[:mpe.MAX_DETECTIONS], mpe.MAX_DETECTIONS
+        else:
+            assert got["status"][i] == 0 and got["n"][i] == n, (i, got["n"][i], n)
+        assert np.array_equal(got["dist_xy"][i][:2 * n].reshape(-1, 2), dist), i
+        assert np.array_equal(got["undist_xy"][i][:2 * n].reshape(-1, 2), und), i
+        n_gen += 1
+    assert n_gen == 330
+
+
+@pytest.mark.gpu
 def test_facade_static_primitives_with_a_device():
     """The same calls as tests/test_abi_cpu.py::test_facade_static_primitives_never_throw, with a HIP device: they succeed
     (0 / 0, an empty image yields no detections) and leave no error behind."""
