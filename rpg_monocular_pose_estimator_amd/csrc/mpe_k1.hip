@@ -286,6 +286,8 @@ __global__ __launch_bounds__(64, K1B_GEN_OCC) void k1b_general(const uint8_t* __
   float* ky = kx + K1B_GEN_KEPT;
   unsigned* kkey = reinterpret_cast<unsigned*>(ky + K1B_GEN_KEPT);
   unsigned* items = kkey + K1B_GEN_KEPT;
+  unsigned* const s_seg = reinterpret_cast<unsigned*>(s_run4);  // (before the bands exist: 32-bit lists in the items' LDS)
+  const int seg_cap = 2 * K1B_GEN_RUNS;
   const int r = dp.ksize / 2;
   const int dc = (r + 15) / 16;
   const int spr = g.segs_per_row;
@@ -346,8 +348,6 @@ __global__ __launch_bounds__(64, K1B_GEN_OCC) void k1b_general(const uint8_t* __
       // a lane per flag word walked its bits one dependent pixel read (k1b_gen_narrow) after the other — three of them in
       // the busiest of every 64 words of a salt frame, six rounds of words: ~18 round trips to cold pixels where the list
       // needs three.  Four flag words in flight per lane.
-      unsigned* const s_seg = reinterpret_cast<unsigned*>(s_run4);
-      const int seg_cap = 2 * K1B_GEN_RUNS;
       for (int i0 = 0; i0 < nwin; i0 += 256) {
         u64 v[4];
 #pragma unroll
@@ -408,14 +408,20 @@ __global__ __launch_bounds__(64, K1B_GEN_OCC) void k1b_general(const uint8_t* __
     K1B_GEN_STAMP(3)
     // blur: the frame's own bytes — only the segments the image pass flagged — thresholded on the fly
     const PixWin pw = {frame, 0, gl.rows, 0, g.pitch, add, flags, (size_t)f * g.segs_per_frame};
+    if (lane == 0) s_nrun = 0;  // (the bright segments' list is used up: the same LDS now lists the bitmap words written)
+    __syncthreads();
     for (int i = lane; i < n_items; i += 64) {
       const unsigned it = items[i];
       const int y = (int)(it >> 12), c = (int)(it & 0xFFFu);
       u64* nzrow = nz + (size_t)(y + 1) * g.wb;
+      auto note = [&](int wi) {
+        const int at = atomicAdd(&s_nrun, 1);
+        if (at < seg_cap) s_seg[at] = ((unsigned)y << 8) | (unsigned)wi;
+      };
       if (add)
-        blur_to_bitmap<true>(pw, gl.rows, gl.cols, dp, s_taps, y, c, nzrow, 0);
+        blur_to_bitmap<true>(pw, gl.rows, gl.cols, dp, s_taps, y, c, nzrow, 0, note);
       else  // (thr = 255: nothing passes the threshold — the flags say so already, no item arrives here)
-        blur_to_bitmap<false>(pw, gl.rows, gl.cols, dp, s_taps, y, c, nzrow, 0);
+        blur_to_bitmap<false>(pw, gl.rows, gl.cols, dp, s_taps, y, c, nzrow, 0, note);
     }
     __threadfence_block();
     __syncthreads();
@@ -424,7 +430,35 @@ __global__ __launch_bounds__(64, K1B_GEN_OCC) void k1b_general(const uint8_t* __
     // ONE array, consecutive lanes consecutive words, four loads in flight.  (A lane per row read 64 different cache
     // lines with every instruction; the kernel is bound by exactly that — ~4 000 memory instructions per frame, most of
     // them 64 lanes to 64 lines, one every ~70 cycles per CU with 12 waves resident: profiles/round6_exp_general_tier.txt 8.)
-    {
+    const int nnz = s_nrun;  // (uniform) bitmap words the blur wrote bits into, as (row << 8 | word), with repetitions
+    if (nnz <= seg_cap) {
+      // ... from that list, two entries (eight loads) in flight per lane (a frame's words number a few hundred; reading
+      // the whole bitmap for them — 90 wave-loads, then the rows above — was 46 dependent round trips of a salt frame's ~380)
+      for (int i0 = 0; i0 < nnz; i0 += 128) {
+        u64 cur[2], p0[2], pl[2], pr[2];
+        int yy[2], ww[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = i0 + 64 * u + lane;
+          const unsigned e = i < nnz ? s_seg[i] : 0u;
+          yy[u] = (int)(e >> 8);
+          ww[u] = (int)(e & 255u);
+          const u64* prev = nz + (size_t)yy[u] * g.wb;  // (slot y holds row y - 1; slot 0 is the empty separator above row 0)
+          const bool on = i < nnz;
+          cur[u] = on ? prev[g.wb + ww[u]] : 0;
+          p0[u] = on ? prev[ww[u]] : 0;
+          pl[u] = (on && ww[u] > 0) ? prev[ww[u] - 1] : 0;
+          pr[u] = (on && ww[u] + 1 < g.wb) ? prev[ww[u] + 1] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (cur[u]) {
+            atomicOr(&s_rowact[yy[u] >> 6], 1ull << (yy[u] & 63));
+            const u64 dil = p0[u] | (p0[u] << 1) | (p0[u] >> 1) | (pl[u] >> 63) | (pr[u] << 63);
+            if (cur[u] & dil) atomicOr(&s_link[yy[u] >> 6], 1ull << (yy[u] & 63));
+          }
+      }
+    } else {
       const int nw = gl.rows * g.wb;
       for (int i0 = 0; i0 < nw; i0 += 256) {
         u64 cur[4];
@@ -539,10 +573,17 @@ __global__ __launch_bounds__(64, K1B_GEN_OCC) void k1b_general(const uint8_t* __
           }
           u64 acc[4] = {0, 0, 0, 0};
           if (cw < g.wb)
-            for (int kk = cj; kk < hmax; kk += rg) {
+            for (int kk = cj; kk < hmax; kk += 2 * rg) {  // (eight loads in flight)
+              u64 t[2][4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u)
-                if (kk < bh[u]) acc[u] |= nz[(size_t)(blo[u] + 1 + kk) * g.wb + cw];
+              for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const int k2 = kk + v * rg;
+                  t[v][u] = k2 < bh[u] ? nz[(size_t)(blo[u] + 1 + k2) * g.wb + cw] : 0;
+                }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[u] |= t[0][u] | t[1][u];
             }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {

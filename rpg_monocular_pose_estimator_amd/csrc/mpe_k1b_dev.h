@@ -604,7 +604,14 @@ __device__ __forceinline__ void window_run_rows(const u64* nz, int W, int H, int
     }
   };
   int r = 1;
-  for (; r + 3 <= H + 1; r += 4) {  // (four rows' words in flight per trip: the rows are independent reads)
+  for (; r + 7 <= H + 1; r += 8) {  // (eight rows' words in flight per trip: the rows are independent reads)
+    u64 a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = row_any(r + q);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) step(r + q, a[q]);
+  }
+  for (; r + 3 <= H + 1; r += 4) {
     const u64 a0 = row_any(r), a1 = row_any(r + 1), a2 = row_any(r + 2), a3 = row_any(r + 3);
     step(r, a0);
     step(r + 1, a1);
@@ -965,9 +972,13 @@ __device__ __forceinline__ unsigned cells_phase(const u64* nz, u64* pm, u64* ng,
 }
 
 // blurred-mask bits of the 16 outputs of segment column c in image row y -> OR into the bitmap
-template <bool RAW = false>
+struct BlurNoNote {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// (note(word index): called for every bitmap word of the row that receives a bit — the general kernel lists them)
+template <bool RAW = false, class Note = BlurNoNote>
 __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int cols, const DetectParams& dp,
-                                               const int* taps, int y, int c, u64* nzrow, int xw0) {
+                                               const int* taps, int y, int c, u64* nzrow, int xw0, Note note = Note()) {
   const int ksize = dp.ksize;
   const int r = ksize / 2;
   const int x0 = 16 * c;
@@ -1002,7 +1013,11 @@ __device__ __forceinline__ void blur_to_bitmap(const PixWin& pw, int rows, int c
     }
     const int wi = xb0 >> 6, shb = xb0 & 63;
     atomicOr(&nzrow[wi], (u64)m << shb);
-    if (shb > 48) atomicOr(&nzrow[wi + 1], (u64)m >> (64 - shb));
+    note(wi);
+    if (shb > 48 && ((u64)m >> (64 - shb))) {
+      atomicOr(&nzrow[wi + 1], (u64)m >> (64 - shb));
+      note(wi + 1);
+    }
   }
 }
 
