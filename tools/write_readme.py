@@ -31,7 +31,7 @@ pose covariance — behind a C ABI (`include/mpe.h`) and a source-compatible `Po
 print('''On one MI355X (round 6, `profiles/round6_*`; every figure below is in the default `python bench.py` line, i.e. under
 the driver's clock, with its own roofline and oracle parity sample, and as a flat key of `config`): **%s frames/s** at
 752×480 / 5 LEDs with brute-force initialisation on every frame (%.2f ms per 262 144 frames in the collection's default
-line; 17.3 – 17.9 ms over the round's boxes; target 50 k fps; rounds 5 … 1: 14.6 M, 14.7 M, 13.9 M, 13.3 M, 10.0 M),
+line; 17.05 – 17.9 ms over the round's boxes; target 50 k fps; rounds 5 … 1: 14.6 M, 14.7 M, 13.9 M, 13.3 M, 10.0 M),
 records delivered to pinned host memory inside the step.  Every pixel is read once — 72 %% of them by the FP64 voting
 kernel itself through LDS DMA, the rest by a one-block-per-CU side scan that streams beside it — at %.2f TB/s = %.2f of
 the HBM spec over the WHOLE step (1.10 – 1.13 × the stand-alone scan of the same pixels, the floor of this design; 1.011 ×
