@@ -4,7 +4,7 @@ both records -> <out>.npz) and CLASSIFIED (tests/forensics.py::classify_end_to_e
 hypotheses of the voting, or to the P3P solves of the validation, on which the two paths differ, and each of those
 must be a witnessed instability of the reference algorithm itself (the oracle's own answer moves under a 1-ulp change
 of an input) or sit in the cancellation corner of its Ferrari solver.  Exit code 1 if one stays unexplained.
-usage (on an MI355X): [MPE_VOTE_ARITH=0|1] python tests/soak_parity.py [frames [config [chunk [out_prefix]]]]
+usage (on an MI355X): [MPE_VOTE_ARITH=0|1] [MPE_SOAK_CLUTTER=d4|d16|salt] python tests/soak_parity.py [frames [config [chunk [out_prefix]]]]
 MPE_VOTE_ARITH: option "vote_arith" of the handle (3 = the default since round 6; see include/mpe.h)."""
 import json
 import os
@@ -29,7 +29,10 @@ CH = min(N, int(sys.argv[3]) if len(sys.argv) > 3 else 65536)
 ARITH = int(os.environ.get("MPE_VOTE_ARITH", "3"))
 OUT = sys.argv[4] if len(sys.argv) > 4 else "gpurun_out/soak_parity_%s_arith%d" % (CONFIG, ARITH)
 TOL_PX = float(os.environ.get("MPE_BACK_TOL", "5"))
-cfg = synth.CONFIGS[CONFIG]
+cfg = dict(synth.CONFIGS[CONFIG])
+CLUTTER = os.environ.get("MPE_SOAK_CLUTTER", "")  # d4 / d16: distractor spots; salt: 0.05 % isolated saturated pixels
+if CLUTTER in ("d4", "d16"):
+    cfg["n_distractors"] = int(CLUTTER[1:])
 rows, cols = cfg["rows"], cfg["cols"]
 K, D = synth.camera_for(rows, cols)
 markers = np.asarray(cfg["markers"])
@@ -50,6 +53,12 @@ t0 = time.time()
 for part in range(max(1, N // CH)):
     _, spots = synth.make_scenes_batch(cfg, CH, seed=7000 + part)
     frames = synth.render_frames_torch(spots, rows, cols, cfg["spot_sigma"], dev, seed=8000 + part)
+    if CLUTTER == "salt":
+        g = torch.Generator(device=dev)
+        g.manual_seed(9000 + part)
+        for a in range(0, CH, 1024):  # (in slices: the random field of a whole chunk is 4 bytes a pixel)
+            fr = frames[a:a + 1024]
+            fr[torch.rand(fr.shape, generator=g, device=dev) < 0.0005] = 255
     torch.cuda.synchronize()
     with torch.cuda.stream(st):
         out = torch.zeros(CH * mpe.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
@@ -79,7 +88,7 @@ if saved:
     os.makedirs(os.path.dirname(OUT) or ".", exist_ok=True)
     np.savez_compressed(OUT + ".npz", **{"pixels_%d" % k: s["pixels"] for k, s in enumerate(saved)},
                         **{"det_%d" % k: s["det"] for k, s in enumerate(saved)}, meta=json.dumps(meta))
-print(json.dumps({"config": CONFIG, "frames": tot, "back_projection_pixel_tolerance": TOL_PX, "status_mismatches": st_mis,
+print(json.dumps({"config": CONFIG, "clutter": CLUTTER or None, "frames": tot, "back_projection_pixel_tolerance": TOL_PX, "status_mismatches": st_mis,
                   "poses_compared": n_pose, "pose_mismatches_gt_1e-4m": pose_mis, "worst_position_difference_m": worst,
                   "mismatches_classified_unstable": len(saved) - len(unexplained),
                   "mismatches_unexplained": len(unexplained),
