@@ -81,6 +81,8 @@ timeout 400 python tests/soak_parity.py 32768 C1 32768 gpurun_out/final$ROUND/so
 MPE_SOAK_CLUTTER=salt timeout 400 python tests/soak_parity.py 32768 C2 8192 gpurun_out/final$ROUND/soak_parity_clutter_salt > $O/soak_parity_clutter_salt.log 2>&1; echo "rc $?" >> $O/soak_parity_clutter_salt.log
 MPE_SOAK_CLUTTER=d4 timeout 400 python tests/soak_parity.py 65536 C2 16384 gpurun_out/final$ROUND/soak_parity_clutter_d4 > $O/soak_parity_clutter_d4.log 2>&1; echo "rc $?" >> $O/soak_parity_clutter_d4.log
 MPE_SOAK_CLUTTER=d16 timeout 600 python tests/soak_parity.py 8192 C2 4096 gpurun_out/final$ROUND/soak_parity_clutter_d16 > $O/soak_parity_clutter_d16.log 2>&1; echo "rc $?" >> $O/soak_parity_clutter_d16.log
+MPE_SOAK_CLUTTER=salt timeout 600 python tests/soak_parity.py 4096 C4 2048 gpurun_out/final$ROUND/soak_parity_clutter_salt_C4 > $O/soak_parity_clutter_salt_C4.log 2>&1; echo "rc $?" >> $O/soak_parity_clutter_salt_C4.log
+MPE_SOAK_CLUTTER=d4 timeout 600 python tests/soak_parity.py 4096 C3 2048 gpurun_out/final$ROUND/soak_parity_clutter_d4_C3 > $O/soak_parity_clutter_d4_C3.log 2>&1; echo "rc $?" >> $O/soak_parity_clutter_d4_C3.log
 timeout 400 python tests/soak_general_tier.py 240 gpurun_out/final$ROUND/soak_general_tier > $O/soak_general_tier.log 2>&1; echo "rc $?" >> $O/soak_general_tier.log
 timeout 400 python tests/soak_tracking.py 128 160 C2 gpurun_out/final$ROUND/soak_tracking > $O/soak_tracking.log 2>&1; echo "rc $?" >> $O/soak_tracking.log
 ls $O
