@@ -85,4 +85,5 @@ MPE_SOAK_CLUTTER=salt timeout 600 python tests/soak_parity.py 4096 C4 2048 gpuru
 MPE_SOAK_CLUTTER=d4 timeout 600 python tests/soak_parity.py 4096 C3 2048 gpurun_out/final$ROUND/soak_parity_clutter_d4_C3 > $O/soak_parity_clutter_d4_C3.log 2>&1; echo "rc $?" >> $O/soak_parity_clutter_d4_C3.log
 timeout 400 python tests/soak_general_tier.py 240 gpurun_out/final$ROUND/soak_general_tier > $O/soak_general_tier.log 2>&1; echo "rc $?" >> $O/soak_general_tier.log
 timeout 400 python tests/soak_tracking.py 128 160 C2 gpurun_out/final$ROUND/soak_tracking > $O/soak_tracking.log 2>&1; echo "rc $?" >> $O/soak_tracking.log
+MPE_SOAK_SALT=0.003 timeout 600 python tests/soak_tracking.py 128 160 C2 gpurun_out/final$ROUND/soak_tracking_salt > $O/soak_tracking_salt.log 2>&1; echo "rc $?" >> $O/soak_tracking_salt.log
 ls $O

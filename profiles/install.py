@@ -199,7 +199,7 @@ def main():
     for n in ("soak_votes_arith_C2", "soak_votes_arith_C3", "soak_general_tier"):
         if os.path.exists(F + n + ".json"):
             shutil.copy(F + n + ".json", P + "parity_%s.json" % n)
-    for n in ("soak_votes_C2", "soak_34_C2", "soak_34_C3", "soak_34_d16", "soak_34_d4", "soak_parity_C2", "soak_parity_C3", "soak_parity_C4", "soak_parity_C1", "soak_parity_clutter_salt", "soak_parity_clutter_d4", "soak_parity_clutter_d16", "soak_parity_clutter_salt_C4", "soak_parity_clutter_d4_C3", "soak_tracking"):
+    for n in ("soak_votes_C2", "soak_34_C2", "soak_34_C3", "soak_34_d16", "soak_34_d4", "soak_parity_C2", "soak_parity_C3", "soak_parity_C4", "soak_parity_C1", "soak_parity_clutter_salt", "soak_parity_clutter_d4", "soak_parity_clutter_d16", "soak_parity_clutter_salt_C4", "soak_parity_clutter_d4_C3", "soak_tracking", "soak_tracking_salt"):
         if os.path.exists(F + n + ".log"):
             try:
                 json.dump(last_json(F + n + ".log"), open(P + "parity_%s.json" % n, "w"), indent=1)

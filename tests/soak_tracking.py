@@ -28,6 +28,7 @@ F = int(sys.argv[2]) if len(sys.argv) > 2 else 160
 CONFIG = sys.argv[3] if len(sys.argv) > 3 else "C2"
 OUT = sys.argv[4] if len(sys.argv) > 4 else "gpurun_out/soak_tracking_%s" % CONFIG
 POS_TOL_M, ROT_TOL_RAD = 1e-4, 1e-3
+SALT = float(os.environ.get("MPE_SOAK_SALT", "0"))  # fraction of saturated pixels on every second stream (the general blob tier inside ROIs)
 BASE = 40  # a smooth 40-frame trajectory played forwards and backwards keeps the target inside the image
 
 rng = np.random.default_rng(2024)
@@ -38,7 +39,7 @@ t0 = time.time()
 for s in range(S):
     # LED drop-outs on two thirds of the streams: two LEDs only in those frames (whole-image retry, re-initialisation)
     drop = tuple(int(x) for x in rng.choice(np.arange(4, BASE - 2), size=int(rng.integers(1, 4)), replace=False)) if s % 3 else ()
-    d = synth.make_sequence(CONFIG, BASE, seed=7100 + s, dropout=drop)
+    d = synth.make_sequence(CONFIG, BASE, seed=7100 + s, dropout=drop, salt=SALT if s % 2 else 0.0)
     seqs.append(dict(frames=np.ascontiguousarray(d["frames"][idx]), times=np.arange(F) * 0.02, markers=d["markers"],
                      K=d["K"], D=d["D"], drop=drop, rows=d["frames"].shape[1], cols=d["frames"].shape[2]))
 t_make = time.time() - t0
