@@ -289,7 +289,7 @@ __device__ __forceinline__ bool trace_outer_border(const u64* nz, u64* pm, u64* 
   // positions packed as slot << 16 | x (both < 2^15): one comparison each for "back at the start" and "about to repeat
   // the first step"
   const int pos0 = (slot0 << 16) | xb0;
-  const int pos1 = pos0 + (dir_dy(s) << 16) + dir_dx(s);
+  const int pos1 = pos0 + dir_dy(s) * 65536 + dir_dx(s);  // (dy may be -1: no shift of a negative value)
   int pos = pos0;
   int X = xb0 + xoff, Y = slot0 + yoff;  // image coordinates of the current border pixel
   long long a00 = 0, a10 = 0, a01 = 0;
@@ -308,7 +308,7 @@ __device__ __forceinline__ bool trace_outer_border(const u64* nz, u64* pm, u64* 
     const int xb = pos & 0xFFFF;
     atomicOr((negative ? ng32 : pm32) + rd + (xb >> 5), 1u << (xb & 31));
     const int dx = dir_dx(sn), dy = dir_dy(sn);
-    const int npos = pos + (dy << 16) + dx;
+    const int npos = pos + dy * 65536 + dx;
     done = (npos == pos0) & (pos == pos1);
     const int dxy = mul24(X, dy) - mul24(Y, dx);
     a00 += dxy;

@@ -20,7 +20,7 @@ N = 200000
 def lib(tmp_path_factory):
     d = tmp_path_factory.mktemp("ddm_host")
     so = os.path.join(d, "libddm_host.so")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-w",
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", *os.environ.get("MPE_HOST_CXXFLAGS", "").split(), "-w",
                            "-I", os.path.join(ROOT, "tests", "host", "stub"), "-I", CSRC,
                            os.path.join(ROOT, "tests", "host", "ddmath_host.cpp"), "-o", so])
     return C.CDLL(so)

@@ -31,7 +31,7 @@ def host(tmp_path_factory):
         i = hip.index("__device__ __forceinline__ void perm_from_index(")
         fh.write(hip[i:hip.index("// one entry of the table (layout above) -> e", i)])
     so = os.path.join(d, "libgeom_host.so")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-I", str(d),
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", *os.environ.get("MPE_HOST_CXXFLAGS", "").split(), "-I", str(d),
                            "-I", os.path.join(ROOT, "tests", "host", "stub"), "-I", CSRC,
                            os.path.join(ROOT, "tests", "host", "geom_host.cpp"), "-o", so])
     return C.CDLL(so)

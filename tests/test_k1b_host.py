@@ -36,7 +36,7 @@ def host(tmp_path_factory):
     with open(os.path.join(d, "k1b_extract.inc"), "w") as fh:
         fh.write(inc)
     so = os.path.join(d, "libk1b_host.so")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-I", str(d),
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", *os.environ.get("MPE_HOST_CXXFLAGS", "").split(), "-I", str(d),
                            os.path.join(ROOT, "tests", "host", "k1b_host.cpp"), "-o", so])
     lib = C.CDLL(so)
     lib.host_find_leds.restype = C.c_int

@@ -36,7 +36,7 @@ def _build(d, tiny_queues=False):
     with open(os.path.join(d, "vote_extract.inc"), "w") as fh:
         fh.write(inc)
     so = os.path.join(d, "libvote_host.so")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", *os.environ.get("MPE_HOST_CXXFLAGS", "").split(),
                            *os.environ.get("MPE_HOST_CXXFLAGS", "").split(), "-I", str(d),
                            "-I", os.path.join(ROOT, "tests", "host", "stub"), "-I", CSRC,
                            "-I", os.path.join(ROOT, "include"),
