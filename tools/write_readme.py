@@ -66,4 +66,6 @@ python bench_streams.py --streams 8                    # stateful estimator, 8 c
 python bench_streams.py --streams 64 --lockstep        # 64 streams in lock step: one launch per time step
 bash profiles/collect.sh 6 && python profiles/install.py 6   # (on an MI355X) the round's whole evidence, then condense it
 tools/ab.sh NAME REPS "base build_variants/X/libmpe_hip.so" "bench args"   # same-box A/B of kernel variants (tools/build_variant.sh)
+tools/host_sanitize.sh                                 # the device code's CPU tier (tests/host/*.cpp) under ASan + UBSan
+tools/leg_trace.sh NAME --clutter salt                 # (on an MI355X) rocprofv3 kernel table of one bench leg; tools/leg_pmc.sh: one counter pass
 ```''')
