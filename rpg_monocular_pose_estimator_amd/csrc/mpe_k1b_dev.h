@@ -1151,7 +1151,16 @@ struct K1bWaveLds {  // front-phase storage of one wave
   int taps[MPE_MAX_KSIZE];  // (taking the address of the by-value kernel argument would make the
                             //  compiler copy all of it to scratch)
   int nseg, nband;
+#ifdef K1B_PHASE_CLOCKS  // (experiment builds: the shader clock at the phase boundaries of a frame, printed by block 0)
+  unsigned long long clk[8];
+#endif
 };
+#ifdef K1B_PHASE_CLOCKS
+#define K1B_PHASE_STAMP(W, i) \
+  if ((threadIdx.x & 63) == 0) (W).clk[i] = __builtin_amdgcn_s_memtime();
+#else
+#define K1B_PHASE_STAMP(W, i)
+#endif
 template <class C>
 struct K1bFrameLds {  // what the contour phase needs of one frame
   u64 nz[C::BM + 1], pm[C::BM + 1], ng[C::BM + 1];
@@ -1261,6 +1270,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
     return false;
   }
   K1B_STOP_POINT(1, out)
+  K1B_PHASE_STAMP(W, 1)
   bool fallback = nseg > C::SEG;
   int why = fallback ? 1 : 0;  // which capacity sent the frame on (kept in the top byte of its work-list entry: statistics)
 
@@ -1410,6 +1420,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   }
   wave_sync();
   K1B_STOP_POINT(2, out)
+  K1B_PHASE_STAMP(W, 2)
 
   // ---- C: clear the bitmaps, stage the thresholded pixels of every island (16-byte loads)
   {
@@ -1438,6 +1449,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   }
   wave_sync();
   K1B_STOP_POINT(3, out)
+  K1B_PHASE_STAMP(W, 3)
 
   // ---- C2 (round 6): which neighbour columns does the blur have to compute at all?  The island's columns clo .. chi
   //      are its bright segments cfirst .. clast dilated by dc; with dc = 1 the column left of cfirst can only blur to
@@ -1506,6 +1518,7 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   }
   wave_sync();
   K1B_STOP_POINT(4, out)
+  K1B_PHASE_STAMP(W, 4)
   return true;
 }
 
@@ -1541,6 +1554,7 @@ __device__ __forceinline__ void k1b_wave(const int f, const bool valid, const ui
   int roi_x, roi_y;
   const FrameGeom g = window_geom(gslot, wins, valid ? f : 0, dp, roi_x, roi_y);
   bool ready = false;
+  K1B_PHASE_STAMP(W, 0)
   if (valid) ready = k1b_front<C>(f, frames, slot_bytes, flags, g, dp, dets, worklist, W, S);
   if (lane == 0) {
     S.ready = ready ? 1 : 0;
@@ -1607,6 +1621,7 @@ __device__ __forceinline__ void k1b_wave(const int f, const bool valid, const ui
   }
   __syncthreads();
   if (!ready) return;
+  K1B_PHASE_STAMP(W, 5)
 #ifdef K1B_STOP_AFTER
   if (K1B_STOP_AFTER <= 5) {
     if (lane == 0) {
@@ -1621,6 +1636,13 @@ __device__ __forceinline__ void k1b_wave(const int f, const bool valid, const ui
     return;
   }
   write_detections(S.kx, S.ky, S.kkey, S.nkept, C::KEPT, S.over, dp, dets + f, lane);
+#ifdef K1B_PHASE_CLOCKS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    printf("k1b phases (cycles): flags->segments %llu bands/islands %llu staging %llu blur %llu contours %llu records %llu\n",
+           W.clk[1] - W.clk[0], W.clk[2] - W.clk[1], W.clk[3] - W.clk[2], W.clk[4] - W.clk[3], W.clk[5] - W.clk[4], t - W.clk[5]);
+  }
+#endif
 }
 
 //@k1b-dev-end
