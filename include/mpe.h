@@ -512,7 +512,8 @@ int mpe_set_option(mpe_handle* h, const char* name, int value);
  *   voted again by the strict loop nest (a full list costs time, never a pose); synchronises.
  * Tuning / test knobs (round 5): "vote_list_cap" (entries per suspect list at most, 0 = no limit: a tiny list exercises
  *   the re-vote path), "k1b_general_blocks" (PROCESS-wide: blocks = scratch slabs of the general blob tier, 32 .. 8192,
- *   default 4096, within 1 GB of scratch and never more than the frames of a launch), "tail_priority" /
+ *   default 4096, within 1 GB of scratch, never more than the frames of a launch nor than the blocks the device holds
+ *   at once — 4 096 on an MI355X: a block walks the work-list with the grid as its stride), "tail_priority" /
  *   "scan_priority" (stream priority of the library's two side streams, applied when they are created: -1 lowest,
  *   0 ordinary streams, 1 highest, 2 the default level but created through the priority entry point; default 1 / 1 —
  *   off the default level so that they get hardware queues of their own, DESIGN.md section 3, Schedules.  NOTE for
@@ -529,7 +530,8 @@ int mpe_set_option(mpe_handle* h, const char* name, int value);
  *   kernels + two copies of rounds 3 - 5.  Bit-identical records.  "track_phase_clocks" = 1: that kernel stamps its
  *   phases; get "track_phase_cycles_0" .. "_3" (scan, blobs, validation, refinement: mean shader-clock cycles).
  * "general_lds" (round 6): kernel of the general blob tier — 0 (default) bitmaps in global-memory slabs, 16 frames per
- *   CU in flight; 1 a block per CU with the frame's bitmaps in LDS (faster per frame, one frame per CU: 2 x slower on
+ *   CU in flight, (band, column run, row piece) items of any number per frame for frames up to 3 966 pixels wide; 1 a
+ *   block per CU with the frame's bitmaps in LDS (faster per frame, one frame per CU: 2 x slower on
  *   salt noise, 7 % faster on one large blob); -1 the LDS kernel once the previous call saw frames reach the tier
  *   (read-out "general_seen").  Bit-identical detections.
  * get "vote_wide_frames" (round 6): frames with more than MPE_FAST_VOTE_DETECTIONS detections, voted by the strict
