@@ -1151,6 +1151,7 @@ struct K1bWaveLds {  // front-phase storage of one wave
   int taps[MPE_MAX_KSIZE];  // (taking the address of the by-value kernel argument would make the
                             //  compiler copy all of it to scratch)
   int nseg, nband;
+  int blur_go;  // (k1b_front<C, true>: the block's other waves take their share of the blur's items)
 #ifdef K1B_PHASE_CLOCKS  // (experiment builds: the shader clock at the phase boundaries of a frame, printed by block 0)
   unsigned long long clk[8];
 #endif
@@ -1186,8 +1187,33 @@ struct K1bFrameLds {  // what the contour phase needs of one frame
 #define K1B_STOP_POINT(PHASE, REC)
 #endif
 // Front phases of frame f.  Returns true when the island bitmaps in S are ready for the contour phase,
-// false when the frame is finished (no bright pixel) or was handed to the next tier's work-list.
+// Phase D of k1b_front — the blurred mask of every island, one (row, segment) item per thread `tid` of `nthr`: the wave
+// of the frame alone (64), or every wave of the block (k1b_front<C, true>, the tracked frame's kernel).
 template <class C>
+__device__ __forceinline__ void k1b_blur_items(K1bWaveLds<C>& W, K1bFrameLds<C>& S, const FrameGeom& g, const DetectParams& dp,
+                                               int tid, int nthr) {
+  const Island* s_isl = S.isl;
+  const int nisl = S.nisl, r = dp.ksize / 2;
+  const int tot_blur = s_isl[nisl - 1].blur_end;
+  for (int i = tid; i < tot_blur; i += nthr) {
+    int k = 0;
+    while (i >= s_isl[k].blur_end) ++k;
+    const Island is = s_isl[k];
+    const int li = i - (k ? s_isl[k - 1].blur_end : 0);
+    const int ncols = is.bhi - is.blo + 1;
+    const int yb = li / ncols, c = is.blo + (li - yb * ncols);
+    const int H = is.yhi - is.ylo + 1;
+    const int Wd = isl_words(is, g.cols, r);
+    const PixWin pw = {W.pool + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1), 0u, nullptr, 0};
+    blur_to_bitmap(pw, g.rows, g.cols, dp, W.taps, is.ylo + yb, c, S.nz + is.bm_off + (size_t)(yb + 1) * Wd, isl_xw0(is, r));
+  }
+}
+
+// false when the frame is finished (no bright pixel) or was handed to the next tier's work-list.
+// HELP (the tracked frame's kernel, a block of several waves on ONE frame): the front phases are this wave's, the blur's
+// items every wave's — a lone wave pays ~5 k cycles of latency per round of 64 items whatever the arithmetic (four rounds
+// for five LED islands: 43 k of the blob extraction's 90 k cycles), and the CU's other SIMDs have nothing else to do.
+template <class C, bool HELP = false>
 __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict__ frames, size_t slot_bytes,
                                           const u64* __restrict__ flags, const FrameGeom& g, const DetectParams& dp,
                                           mpe_detections* __restrict__ dets, int* __restrict__ worklist,
@@ -1200,7 +1226,6 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
   short* s_bandlo = reinterpret_cast<short*>(W.pool + 4 * C::SEG + 512 + 32 * C::BAND);
   short* s_bandhi = s_bandlo + C::BAND;
   uint8_t* s_pix = W.pool;
-  const int* s_taps = W.taps;
   int& s_nseg = W.nseg;
   int& s_nband = W.nband;
   u64 *s_nz = S.nz, *s_pm = S.pm, *s_ng = S.ng;
@@ -1500,21 +1525,13 @@ __device__ __forceinline__ bool k1b_front(const int f, const uint8_t* __restrict
 #endif
 
   // ---- D: blurred mask of every island
-  {
-    const int tot_blur = s_isl[nisl - 1].blur_end;
-    for (int i = lane; i < tot_blur; i += 64) {
-      int k = 0;
-      while (i >= s_isl[k].blur_end) ++k;
-      const Island is = s_isl[k];
-      const int li = i - (k ? s_isl[k - 1].blur_end : 0);
-      const int ncols = is.bhi - is.blo + 1;
-      const int yb = li / ncols, c = is.blo + (li - yb * ncols);
-      const int H = is.yhi - is.ylo + 1;
-      const int W = isl_words(is, g.cols, r);
-      const PixWin pw = {s_pix + is.pix_off, is.ylo, H, is.cfirst, 16 * (is.clast - is.cfirst + 1), 0u, nullptr, 0};
-      blur_to_bitmap(pw, g.rows, g.cols, dp, s_taps, is.ylo + yb, c, s_nz + is.bm_off + (size_t)(yb + 1) * W,
-                     isl_xw0(is, r));
-    }
+  if constexpr (HELP) {
+    if (lane == 0) W.blur_go = 1;
+    __syncthreads();  // (the helper waves wait here, k1b_wave: islands, pixels and taps are theirs to read now)
+    k1b_blur_items<C>(W, S, g, dp, (int)threadIdx.x, (int)blockDim.x);
+    __syncthreads();  // (every wave's bits are in the bitmaps)
+  } else {
+    k1b_blur_items<C>(W, S, g, dp, lane, 64);
   }
   wave_sync();
   K1B_STOP_POINT(4, out)
@@ -1537,25 +1554,39 @@ __device__ __forceinline__ void k1b_hand_over(int f, mpe_detections* __restrict_
 // frames, 5 islands per frame): WAVES = 1 / 2 / 4 / 8 take 0.260 / 0.256 / 0.258 / 0.282 ms alone and 20.73 / 20.92 /
 // 20.99 / 21.97 ms per 262 144-frame step inside the pipeline (the other waves of a block wait at the barrier while
 // wave 0 follows the borders), so one frame per block stays the default.  `valid`: this wave has a frame.
-template <class C>
+// HELP: the block has more waves than frames (C::WAVES == 1: one frame); wave 0 runs the frame, the others enter here
+// too, take their share of the blur's items (k1b_front<C, true>) and leave.  Their barriers pair with wave 0's whatever
+// path it takes: if it never reaches the blur (no bright pixel, a capacity hand-over) they meet its next two barriers
+// instead, find blur_go unset and leave.
+template <class C, bool HELP = false>
 __device__ __forceinline__ void k1b_wave(const int f, const bool valid, const uint8_t* __restrict__ frames,
                                          const u64* __restrict__ flags, const FrameGeom& gslot, const DetectParams& dp,
                                          mpe_detections* __restrict__ dets, int* __restrict__ worklist,
                                          const FrameWin* __restrict__ wins) {
   __shared__ K1bWaveLds<C> Wl[C::WAVES];
   __shared__ K1bFrameLds<C> Sl[C::WAVES];
+  static_assert(!HELP || C::WAVES == 1, "helper waves: one frame per block");
   const int lane = threadIdx.x & 63;
   const int wv = C::WAVES > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   K1bWaveLds<C>& W = Wl[wv];
   K1bFrameLds<C>& S = Sl[wv];
+  if (HELP && threadIdx.x == 0) W.blur_go = 0;
   __syncthreads();  // (list mode: the previous group of this block is completely done)
+  if (HELP && threadIdx.x >= 64) {
+    int roi_x, roi_y;
+    const FrameGeom gh = window_geom(gslot, wins, valid ? f : 0, dp, roi_x, roi_y);
+    __syncthreads();  // wave 0: in front of the blur (or, if it never gets there, its barrier behind the front phases)
+    if (W.blur_go) k1b_blur_items<C>(W, S, gh, dp, (int)threadIdx.x, (int)blockDim.x);
+    __syncthreads();  // wave 0: behind the blur
+    return;
+  }
   if (lane < MPE_MAX_KSIZE) W.taps[lane] = dp.taps[lane < dp.ksize ? lane : 0];
   const size_t slot_bytes = (size_t)gslot.rows * gslot.pitch;
   int roi_x, roi_y;
   const FrameGeom g = window_geom(gslot, wins, valid ? f : 0, dp, roi_x, roi_y);
   bool ready = false;
   K1B_PHASE_STAMP(W, 0)
-  if (valid) ready = k1b_front<C>(f, frames, slot_bytes, flags, g, dp, dets, worklist, W, S);
+  if (valid) ready = k1b_front<C, HELP>(f, frames, slot_bytes, flags, g, dp, dets, worklist, W, S);
   if (lane == 0) {
     S.ready = ready ? 1 : 0;
     S.cols = g.cols;

@@ -1002,12 +1002,19 @@ __device__ __forceinline__ void track_copy_words(void* dst, const void* src, uns
   for (unsigned i = lane; i < bytes / 8; i += 64) d[i] = s[i];
 }
 // CLOCKS (option "track_phase_clocks"): the shader clock at the five phase boundaries -> clk[0 .. 4] (s_memtime)
+#define K_TRACK_THREADS 256  // wave 0 runs the frame; waves 1 .. 3 take their share of the blur's items (k1b_wave<C, true>)
 template <bool CLOCKS>
-__global__ __launch_bounds__(64) void k_track_frame(TrackFrames a, FrameGeom g, DetectParams dp, SolveParams sp, ThrTest thr,
-                                                    double nn_tol, int row_cap) {
+__global__ __launch_bounds__(K_TRACK_THREADS) void k_track_frame(TrackFrames a, FrameGeom g, DetectParams dp, SolveParams sp,
+                                                                 ThrTest thr, double nn_tol, int row_cap) {
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   mpe_detections* det = a.dets + b;
+  if (threadIdx.x >= 64) {  // a helper wave: the barrier behind the image pass, then the blob extraction's blur
+    __syncthreads();
+    k1b_wave<K1bSmall, true>(0, true, a.pix + (size_t)b * a.slot_bytes, a.flags + (size_t)b * a.flag_words, g, dp, det, nullptr,
+                             a.wins ? a.wins + b : nullptr);
+    return;
+  }
   uint32_t* corr = a.corr + (size_t)b * 2 * MPE_MAX_MARKERS;
   mpe_result* res = a.res + b;
   u64* flags = a.flags + (size_t)b * a.flag_words;
@@ -1052,7 +1059,7 @@ __global__ __launch_bounds__(64) void k_track_frame(TrackFrames a, FrameGeom g, 
   __syncthreads();  // (the flag words are read back by other lanes: workgroup-scope release / acquire)
   stamp(1);
   // ---- blob extraction, small tier: the block's slot is "frame 0" of its own flag region
-  k1b_wave<K1bSmall>(0, true, roi, flags, g, dp, det, nullptr, a.wins ? a.wins + b : nullptr);
+  k1b_wave<K1bSmall, true>(0, true, roi, flags, g, dp, det, nullptr, a.wins ? a.wins + b : nullptr);
   __syncthreads();
   stamp(2);
   if (det->status == MPE_FRAME_TOO_MANY_ROWS) {  // (uniform: written before the barrier)
@@ -1091,10 +1098,10 @@ hipError_t launch_track_frames(const TrackFramesArgs& t, int n_frames, const Fra
   a.h_res = t.h_res;
   a.clk = t.phase_clocks;
   if (t.phase_clocks)
-    hipLaunchKernelGGL(k_track_frame<true>, dim3((unsigned)n_frames), dim3(64), lds_a, s, a, g, dp, sp, make_thr_test(dp.thr),
+    hipLaunchKernelGGL(k_track_frame<true>, dim3((unsigned)n_frames), dim3(K_TRACK_THREADS), lds_a, s, a, g, dp, sp, make_thr_test(dp.thr),
                        nn_tol, rows);
   else
-    hipLaunchKernelGGL(k_track_frame<false>, dim3((unsigned)n_frames), dim3(64), lds_a, s, a, g, dp, sp, make_thr_test(dp.thr),
+    hipLaunchKernelGGL(k_track_frame<false>, dim3((unsigned)n_frames), dim3(K_TRACK_THREADS), lds_a, s, a, g, dp, sp, make_thr_test(dp.thr),
                        nn_tol, rows);
   return hipGetLastError();
 }
