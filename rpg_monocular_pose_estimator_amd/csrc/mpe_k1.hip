@@ -157,6 +157,18 @@ __global__ __launch_bounds__(64 * C::WAVES, C::MIN_WAVES) K1B_VGPR_ATTR void k1b
   const int f = blockIdx.x * C::WAVES + (int)(threadIdx.x >> 6);
   k1b_wave<C>(f, f < n_frames, frames, flags, g, dp, dets, worklist, wins);
 }
+// Few frames (a lone frame of the stage entries, the tracker's whole-image retries, small batches): a block of four
+// waves per frame, waves 1 - 3 take their share of the blur's items (k1b_wave<C, true>, as in k_track_frame) — with fewer
+// than four blocks per CU the other SIMDs idle, and a lone wave's blur is 43 k of its 90 k cycles.
+#define K1B_HELP_THREADS 256
+#define K1B_HELP_MAX_FRAMES 1024
+template <class C>
+__global__ __launch_bounds__(K1B_HELP_THREADS) void k1b_blobs_few(const uint8_t* __restrict__ frames,
+                                                                   const u64* __restrict__ flags, FrameGeom g, DetectParams dp,
+                                                                   mpe_detections* __restrict__ dets,
+                                                                   int* __restrict__ worklist, const FrameWin* __restrict__ wins) {
+  k1b_wave<C, true>((int)blockIdx.x, true, frames, flags, g, dp, dets, worklist, wins);
+}
 // frames taken from a device work-list (those the smaller tier handed over)
 template <class C>
 __global__ __launch_bounds__(64 * C::WAVES, C::MIN_WAVES) void k1b_blobs_list(const uint8_t* __restrict__ frames,
@@ -916,8 +928,12 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
     if (n_frames <= 0) return hipSuccess;
     if (blob_hint <= 0 || blob_hint > 8) return hipErrorInvalidValue;
     const int blocks = (n_frames + K1bSmall::WAVES - 1) / K1bSmall::WAVES;
-    hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64 * K1bSmall::WAVES), 0, s, frames, (const u64*)flags, g,
-                       dp, dets, (int*)nullptr, n_frames, wins);
+    if (K1bSmall::WAVES == 1 && n_frames <= K1B_HELP_MAX_FRAMES)
+      hipLaunchKernelGGL((k1b_blobs_few<K1bSmall>), dim3(n_frames), dim3(K1B_HELP_THREADS), 0, s, frames, (const u64*)flags, g,
+                         dp, dets, (int*)nullptr, wins);
+    else
+      hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64 * K1bSmall::WAVES), 0, s, frames, (const u64*)flags, g,
+                         dp, dets, (int*)nullptr, n_frames, wins);
     return hipGetLastError();
   }
   // Three tiers, chained through device work-lists (no host round trip):
@@ -935,11 +951,18 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
   }
   if (blob_hint > 0 && blob_hint <= 8) {  // (the small tier is cheap to try: frames that overflow it go on to the large one)
     const int blocks = (n_frames + K1bSmall::WAVES - 1) / K1bSmall::WAVES;
-    hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64 * K1bSmall::WAVES), 0, s, frames, (const u64*)flags, g, dp, dets,
-                       list_a, n_frames, wins);
+    if (K1bSmall::WAVES == 1 && n_frames <= K1B_HELP_MAX_FRAMES)
+      hipLaunchKernelGGL((k1b_blobs_few<K1bSmall>), dim3(n_frames), dim3(K1B_HELP_THREADS), 0, s, frames, (const u64*)flags, g, dp,
+                         dets, list_a, wins);
+    else
+      hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64 * K1bSmall::WAVES), 0, s, frames, (const u64*)flags, g, dp, dets,
+                         list_a, n_frames, wins);
     const int grid = n_frames < 2048 ? n_frames : 2048;
     hipLaunchKernelGGL((k1b_blobs_list<K1bLarge>), dim3(grid), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
                        dets, (const int*)list_a, list_b, wins);
+  } else if (n_frames <= K1B_HELP_MAX_FRAMES) {
+    hipLaunchKernelGGL((k1b_blobs_few<K1bLarge>), dim3(n_frames), dim3(K1B_HELP_THREADS), 0, s, frames, (const u64*)flags, g, dp,
+                       dets, list_b, wins);
   } else {
     hipLaunchKernelGGL((k1b_blobs<K1bLarge>), dim3(n_frames), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
                        dets, list_b, n_frames, wins);
