@@ -184,6 +184,19 @@ __global__ __launch_bounds__(64 * C::WAVES, C::MIN_WAVES) void k1b_blobs_list(co
   }
 }
 
+// ... and its four-wave form for launches of few frames (k1b_blobs_few): every wave of a block follows the list together
+template <class C>
+__global__ __launch_bounds__(K1B_HELP_THREADS) void k1b_blobs_list_few(const uint8_t* __restrict__ frames,
+                                                                        const u64* __restrict__ flags, FrameGeom g,
+                                                                        DetectParams dp, mpe_detections* __restrict__ dets,
+                                                                        const int* __restrict__ in_list,
+                                                                        int* __restrict__ worklist,
+                                                                        const FrameWin* __restrict__ wins) {
+  const int count = in_list[0];
+  for (int w0 = blockIdx.x; w0 < count; w0 += gridDim.x)  // (uniform over the block)
+    k1b_wave<C, true>(in_list[1 + w0] & 0xFFFFFF, true, frames, flags, g, dp, dets, worklist, wins);
+}
+
 // =============================================================================================
 // K1b general path: frames the fast tiers handed over (more bright segments / bands / islands than their LDS pools
 // hold: salt noise, glare, a dot grid).  One wave per frame, whole-frame bitmaps in a global scratch slab, exact on
@@ -958,8 +971,12 @@ hipError_t launch_k1b_blobs(const uint8_t* frames, const unsigned long long* fla
       hipLaunchKernelGGL((k1b_blobs<K1bSmall>), dim3(blocks), dim3(64 * K1bSmall::WAVES), 0, s, frames, (const u64*)flags, g, dp, dets,
                          list_a, n_frames, wins);
     const int grid = n_frames < 2048 ? n_frames : 2048;
-    hipLaunchKernelGGL((k1b_blobs_list<K1bLarge>), dim3(grid), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
-                       dets, (const int*)list_a, list_b, wins);
+    if (n_frames <= K1B_HELP_MAX_FRAMES)
+      hipLaunchKernelGGL((k1b_blobs_list_few<K1bLarge>), dim3(grid), dim3(K1B_HELP_THREADS), 0, s, frames, (const u64*)flags, g,
+                         dp, dets, (const int*)list_a, list_b, wins);
+    else
+      hipLaunchKernelGGL((k1b_blobs_list<K1bLarge>), dim3(grid), dim3(64), 0, s, frames, (const u64*)flags, g, dp,
+                         dets, (const int*)list_a, list_b, wins);
   } else if (n_frames <= K1B_HELP_MAX_FRAMES) {
     hipLaunchKernelGGL((k1b_blobs_few<K1bLarge>), dim3(n_frames), dim3(K1B_HELP_THREADS), 0, s, frames, (const u64*)flags, g, dp,
                        dets, list_b, wins);

@@ -1556,8 +1556,8 @@ __device__ __forceinline__ void k1b_hand_over(int f, mpe_detections* __restrict_
 // wave 0 follows the borders), so one frame per block stays the default.  `valid`: this wave has a frame.
 // HELP: the block has more waves than frames (C::WAVES == 1: one frame); wave 0 runs the frame, the others enter here
 // too, take their share of the blur's items (k1b_front<C, true>) and leave.  Their barriers pair with wave 0's whatever
-// path it takes: if it never reaches the blur (no bright pixel, a capacity hand-over) they meet its next two barriers
-// instead, find blur_go unset and leave.
+// path it takes: if it never reaches the blur (no bright pixel, a capacity hand-over) they meet its two barriers behind
+// the front phases instead and find blur_go unset; if it does, they pass those two as well.
 template <class C, bool HELP = false>
 __device__ __forceinline__ void k1b_wave(const int f, const bool valid, const uint8_t* __restrict__ frames,
                                          const u64* __restrict__ flags, const FrameGeom& gslot, const DetectParams& dp,
@@ -1576,8 +1576,13 @@ __device__ __forceinline__ void k1b_wave(const int f, const bool valid, const ui
     int roi_x, roi_y;
     const FrameGeom gh = window_geom(gslot, wins, valid ? f : 0, dp, roi_x, roi_y);
     __syncthreads();  // wave 0: in front of the blur (or, if it never gets there, its barrier behind the front phases)
-    if (W.blur_go) k1b_blur_items<C>(W, S, gh, dp, (int)threadIdx.x, (int)blockDim.x);
-    __syncthreads();  // wave 0: behind the blur
+    const bool go = W.blur_go != 0;
+    if (go) k1b_blur_items<C>(W, S, gh, dp, (int)threadIdx.x, (int)blockDim.x);
+    __syncthreads();  // wave 0: behind the blur (or its barrier behind the contour phase)
+    if (go) {         // ... and wave 0's two barriers behind the front phases: every wave of the block passes the same
+      __syncthreads();  // number of barriers per frame, so a block may take frame after frame (k1b_blobs_list_few)
+      __syncthreads();
+    }
     return;
   }
   if (lane < MPE_MAX_KSIZE) W.taps[lane] = dp.taps[lane < dp.ksize ? lane : 0];
