@@ -598,7 +598,7 @@ def run_config(args, ctx, light=False):
                     "counters": counters}
 
     # a leg whose blob tiers take longer than its voting launch (salt noise, a saturated patch): the dominant kernels are
-    # the follow-up blob tiers — latency bound (one wave per frame; in the general tier one LANE per band) — and the
+    # the follow-up blob tiers — latency bound (one wave per frame; in the general tier a lane per (band, column run, row piece)) — and the
     # voting kernel's figures move to `roofline.voting_kernel`
     if args.clutter and kavg.get("blobs", 0.0) > kavg.get("vote", 0.0):
         gen = pmc_all.get("k1b_general_salt") if args.clutter == "salt" else None
@@ -611,7 +611,8 @@ def run_config(args, ctx, light=False):
             insts = gen["valu_insts_per_frame"] * min(fpl, B)
             dom.update({"achieved": insts / blob_s / 1e9, "peak": VALU_ISSUE_PEAK,
                         "frac": insts / blob_s / 1e9 / VALU_ISSUE_PEAK, "effective_clock_GHz_in_the_counter_pass": clk_,
-                        "note": "VALU issue of k1b_general: the tier is bound by the latency of one lane walking a band"})
+                        "note": "VALU issue of k1b_general: the tier is bound by the request rate and latency of its scattered "
+                                "accesses to bitmaps in global memory (DESIGN.md section 3, K1b), not by instructions"})
         else:
             dom.update({"achieved": None, "peak": None, "frac": None,
                         "note": "no counter pass of this leg's blob tiers under profiles/"})
